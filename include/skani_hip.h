@@ -1,0 +1,151 @@
+/*
+ * skani_hip.h -- C ABI of the MI355X-native skani hot path (libskani_hip.so).
+ *
+ * The reference (bluenote-1577/skani v0.3.0) has no FFI; its de-facto operator API is the pub Rust
+ * library surface used by src/triangle.rs, src/dist.rs, src/search.rs and by pyskani.  Each entry point
+ * below replaces one of those calls at BATCH granularity (per-pair FFI calls would serialise the GPU).
+ * Citations are reference file:line.  The Rust-side binding a skani maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; inputs are caller-owned and read-only for the call; outputs
+ * allocated by the library are released with skh_free()/..._destroy(); every function returns 0 on success
+ * or a negative skh_status and never unwinds across the boundary (skh_last_error() gives the message).
+ * A context is bound to one GPU and must be driven by one host thread at a time.  Sketch sets are immutable
+ * after creation and device resident.  There is NO CPU path: skh_ctx_create fails when no gfx950 device
+ * is visible.
+ */
+#ifndef SKANI_HIP_H
+#define SKANI_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SKH_OK = 0,
+    SKH_ERR_INVALID = -1,   /* bad argument (k > 16, c > marker_c, ...: seeding.rs:239, params.rs:183-185) */
+    SKH_ERR_DEVICE = -2,    /* HIP runtime failure / no device */
+    SKH_ERR_NOMEM = -3,
+    SKH_ERR_INTERNAL = -4
+} skh_status;
+
+typedef struct skh_ctx skh_ctx;
+typedef struct skh_genome_set skh_genome_set;   /* 2-bit packed contigs resident in HBM */
+typedef struct skh_sketch_set skh_sketch_set;   /* Vec<Sketch> (types.rs:252-277) as device SoA + tables */
+
+/* SketchParams (params.rs:136-196) + which seeding semantics to reproduce:
+ * SKH_SEED_SCALAR = seeding.rs:225-323 (what non-x86 hosts run), SKH_SEED_AVX2 = avx2_seeding.rs:33-272
+ * (what every x86-64+AVX2 host runs, file_io.rs:194-206) -- they differ in tail windows and N handling. */
+enum { SKH_SEED_SCALAR = 0, SKH_SEED_AVX2 = 1 };
+typedef struct {
+    uint32_t c;            /* -c, default 125 */
+    uint32_t k;            /* -k, default 15, <= 16 */
+    uint32_t marker_c;     /* -m, default 1000, >= c */
+    uint32_t seeding_mode; /* SKH_SEED_* */
+} skh_sketch_params;
+
+/* The CommandParams / MapParams fields that change chain_seeds results (chain.rs:88-142, params.rs:74-123).
+ * Everything else in MapParams is a constant derived from the ref sketch's c,k. */
+typedef struct {
+    double min_af;        /* --min-af /100; < 0 selects the 0.15 default (chain.rs:100-107) */
+    double both_min_af;   /* --both-min-af /100; <= 0 disabled (chain.rs:500-504) */
+    uint8_t robust;       /* --robust */
+    uint8_t median;       /* --median */
+    uint8_t learned_ani;  /* apply regression.rs:30-64 (caller decides via regression.rs:8-10) */
+    uint8_t compute_ci;   /* also fill ci_lower/ci_upper with the percentile bootstrap of chain.rs:57-86 */
+} skh_map_params;
+
+/* AniEstResult minus the strings (types.rs:559-582).  ani = NaN: no anchors/estimates (chain.rs:416-420);
+ * ani = -1: aligned-fraction cut-off (chain.rs:500-517). */
+typedef struct {
+    float ani, af_query, af_ref, ci_lower, ci_upper, std;
+    float q90_q, q90_r, q50_q, q50_r, q10_q, q10_r;
+    uint32_t num_contigs_q, num_contigs_r, avg_chain_int_len, total_bases_covered;
+} skh_ani_result;
+
+/* per-pair stage sizes, for parity tests of intermediate stages and for profiling */
+typedef struct {
+    uint32_t switched, n_chunks, n_intervals, n_accepted, n_estimates, reserved;
+    uint64_t n_anchors, n_qpos, anchor_checksum;
+} skh_chain_stats;
+
+/* ------------------------------------------------------------------ context */
+int skh_ctx_create(int device, skh_ctx** out);
+void skh_ctx_destroy(skh_ctx*);
+const char* skh_last_error(const skh_ctx*);
+void skh_free(void* p);
+/* learned-ANI regression tables (regression.rs:12-28 picks by |c-125| < |c-200|); files are the flat tables
+ * under skani_amd/data/ produced by tools/extract_gbdt_model.py */
+int skh_load_models(skh_ctx*, const char* path_c125, const char* path_c200);
+
+/* ------------------------------------------------------------------ ingest (file_io.rs:158-183) */
+/* bases: ASCII contig bytes, contig i = bases[contig_off[i] .. contig_off[i+1]); contig_genome[i] = genome id
+ * (non-decreasing).  The caller has already applied the >= 500 bp contig filter (file_io.rs:176) -- contigs
+ * are indexed in the order given.  bases_on_device != 0: `bases` is a device pointer. */
+int skh_genomes_pack(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome,
+                     uint32_t n_contigs, uint32_t n_genomes, int bases_on_device, int seeding_mode,
+                     skh_genome_set** out);
+void skh_genomes_destroy(skh_genome_set*);
+uint64_t skh_genomes_total_bases(const skh_genome_set*);
+
+/* ------------------------------------------------------------------ sketch: fmh_seeds / avx2_fmh_seeds
+ * (seeding.rs:225, avx2_seeding.rs:33) for every contig + Sketch construction (types.rs:281-304).
+ * genome_rank: optional lexicographic rank of each genome's file name, used only for the switch_qr tie
+ * (chain.rs:20-22); NULL = genome index. */
+int skh_sketch_genomes(skh_ctx*, const skh_genome_set*, const skh_sketch_params*, const uint32_t* genome_rank,
+                       skh_sketch_set** out);
+/* convenience = skh_genomes_pack + skh_sketch_genomes (the fastx_to_sketches body, file_io.rs:141-252) */
+int skh_sketch_batch(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome,
+                     uint32_t n_contigs, uint32_t n_genomes, const skh_sketch_params*, const uint32_t* genome_rank,
+                     skh_sketch_set** out);
+void skh_sketch_set_destroy(skh_sketch_set*);
+
+/* sizes */
+uint32_t skh_sketch_n_genomes(const skh_sketch_set*);
+int skh_sketch_sizes(const skh_sketch_set*, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers,
+                     uint32_t* n_contigs, uint64_t* total_len);
+/* flat export for serialisation / exchange between GPUs / parity checks.  Arrays are caller-allocated from
+ * skh_sketch_sizes; seeds come in position order (contig, pos); ctgcanon = contig<<1 | canonical
+ * (types.rs:124-143); markers sorted ascending (marker_seeds is a set, types.rs:272). */
+int skh_sketch_export(const skh_sketch_set*, uint32_t g, uint32_t* seed, uint32_t* pos, uint32_t* ctgcanon,
+                      uint64_t* markers, uint32_t* contig_lengths);
+/* build a set from exported arrays of n_genomes genomes (concatenated; *_off have n_genomes+1 entries).
+ * This is sketches_from_sketch (file_io.rs:680-729) for an in-memory format. */
+int skh_sketch_import(skh_ctx*, const skh_sketch_params*, uint32_t n_genomes, const uint64_t* pos_off,
+                      const uint32_t* seed, const uint32_t* pos, const uint32_t* ctgcanon, const uint64_t* marker_off,
+                      const uint64_t* markers, const uint64_t* contig_off, const uint32_t* contig_lengths,
+                      const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out);
+
+/* ------------------------------------------------------------------ screen (screen.rs) */
+enum { SKH_SCREEN_REFS = 0,            /* screen_refs, screen.rs:148-189 (triangle, dist with index) */
+       SKH_SCREEN_QUICK = 1,           /* check_markers_quickly, screen.rs:84-142 */
+       SKH_SCREEN_REFS_INDICES = 2 };  /* screen_refs_indices, screen.rs:39-77 (search with index) */
+/* queries == NULL: triangle mode -- pairs (i, j>i) of `refs` with row genome i as the "query" of the rule
+ * (triangle.rs:71-90).  Otherwise all (ref r, query q) pairs passing the rule.  identity == 0 selects the
+ * 0.80 default (triangle.rs:34-42).  Output pair arrays (library-allocated, skh_free) are sorted by
+ * (first, second): first = row/query index, second = ref index (triangle: i, j). */
+int skh_screen(skh_ctx*, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
+               int rescue_small, uint32_t** pair_first, uint32_t** pair_second, uint64_t* n_pairs);
+
+/* ------------------------------------------------------------------ chain: chain_seeds (chain.rs:144-171)
+ * for each pair p: out[p] = chain_seeds(refs[pair_ref[p]], queries[pair_query[p]], map_params_from_sketch(ref)).
+ * queries == NULL means queries = refs.  stats may be NULL. */
+int skh_chain_pairs(skh_ctx*, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref,
+                    const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params*, skh_ani_result* out,
+                    skh_chain_stats* stats);
+
+/* ------------------------------------------------------------------ triangle body (triangle.rs:55-105):
+ * screen rows, chain pairs j>i, keep ani > 0.1.  part/n_parts shard the screened pair list round-robin
+ * across GPUs (part r takes pairs r, r+n_parts, ...); results come back sorted by (i,j). */
+int skh_triangle(skh_ctx*, const skh_sketch_set*, double identity, int rescue_small, const skh_map_params*,
+                 uint32_t part, uint32_t n_parts, uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res,
+                 uint64_t* n_kept, uint64_t* n_chained);
+
+/* last-call timing breakdown in milliseconds (HIP events on the library's stream), for bench.py */
+typedef struct { float pack_ms, seed_ms, sketch_build_ms, screen_ms, chain_ms, seed_kernel_ms; uint32_t seed_kernel_launches; uint32_t pad; } skh_timings;
+int skh_get_timings(const skh_ctx*, skh_timings* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

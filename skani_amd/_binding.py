@@ -1,0 +1,63 @@
+"""ctypes prototypes for the C ABI declared in include/skani_hip.h."""
+import ctypes as C
+
+import numpy as np
+
+
+class SketchParams(C.Structure):
+    """skh_sketch_params (reference SketchParams, params.rs:136-196)."""
+    _fields_ = [("c", C.c_uint32), ("k", C.c_uint32), ("marker_c", C.c_uint32), ("seeding_mode", C.c_uint32)]
+
+
+class MapParams(C.Structure):
+    """skh_map_params (the CommandParams fields consumed by map_params_from_sketch, chain.rs:88-142)."""
+    _fields_ = [("min_af", C.c_double), ("both_min_af", C.c_double), ("robust", C.c_uint8), ("median", C.c_uint8),
+                ("learned_ani", C.c_uint8), ("compute_ci", C.c_uint8)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("pack_ms", "seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "seed_kernel_ms")] + \
+               [("seed_kernel_launches", C.c_uint32), ("pad", C.c_uint32)]
+
+
+RESULT_DTYPE = np.dtype([(n, np.float32) for n in
+                         ("ani", "af_query", "af_ref", "ci_lower", "ci_upper", "std",
+                          "q90_q", "q90_r", "q50_q", "q50_r", "q10_q", "q10_r")] +
+                        [(n, np.uint32) for n in ("num_contigs_q", "num_contigs_r", "avg_chain_int_len", "total_bases_covered")])
+
+STATS_DTYPE = np.dtype([(n, np.uint32) for n in ("switched", "n_chunks", "n_intervals", "n_accepted", "n_estimates", "reserved")] +
+                       [(n, np.uint64) for n in ("n_anchors", "n_qpos", "anchor_checksum")])
+
+EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
+           "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_batch", "skh_sketch_set_destroy",
+           "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_screen", "skh_chain_pairs",
+           "skh_triangle", "skh_get_timings"]
+
+
+def load(path):
+    L = C.CDLL(path)
+    vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    pp = C.POINTER(vp)
+    L.skh_ctx_create.restype = i32; L.skh_ctx_create.argtypes = [i32, pp]
+    L.skh_ctx_destroy.restype = None; L.skh_ctx_destroy.argtypes = [vp]
+    L.skh_last_error.restype = C.c_char_p; L.skh_last_error.argtypes = [vp]
+    L.skh_free.restype = None; L.skh_free.argtypes = [vp]
+    L.skh_load_models.restype = i32; L.skh_load_models.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.skh_genomes_pack.restype = i32; L.skh_genomes_pack.argtypes = [vp, vp, vp, vp, u32, u32, i32, i32, pp]
+    L.skh_genomes_destroy.restype = None; L.skh_genomes_destroy.argtypes = [vp]
+    L.skh_genomes_total_bases.restype = u64; L.skh_genomes_total_bases.argtypes = [vp]
+    L.skh_sketch_genomes.restype = i32; L.skh_sketch_genomes.argtypes = [vp, vp, C.POINTER(SketchParams), vp, pp]
+    L.skh_sketch_batch.restype = i32; L.skh_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, C.POINTER(SketchParams), vp, pp]
+    L.skh_sketch_set_destroy.restype = None; L.skh_sketch_set_destroy.argtypes = [vp]
+    L.skh_sketch_n_genomes.restype = u32; L.skh_sketch_n_genomes.argtypes = [vp]
+    L.skh_sketch_sizes.restype = i32
+    L.skh_sketch_sizes.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]
+    L.skh_sketch_export.restype = i32; L.skh_sketch_export.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    L.skh_sketch_import.restype = i32
+    L.skh_sketch_import.argtypes = [vp, C.POINTER(SketchParams), u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp]
+    L.skh_screen.restype = i32; L.skh_screen.argtypes = [vp, vp, vp, dbl, i32, i32, pp, pp, C.POINTER(u64)]
+    L.skh_chain_pairs.restype = i32; L.skh_chain_pairs.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp, vp]
+    L.skh_triangle.restype = i32
+    L.skh_triangle.argtypes = [vp, vp, dbl, i32, C.POINTER(MapParams), u32, u32, pp, pp, pp, C.POINTER(u64), C.POINTER(u64)]
+    L.skh_get_timings.restype = i32; L.skh_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    return L

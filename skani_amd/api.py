@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's operator API for the hot path (names follow src/lib.rs:1-22):
+fastx_to_sketches (file_io.rs:141), screen_refs / check_markers_quickly (screen.rs), map_params_from_sketch +
+chain_seeds (chain.rs:88,144), the triangle body (triangle.rs:55-105) -- all at batch granularity."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _binding as B
+from .fastx import read_fasta
+
+SEED_SCALAR, SEED_AVX2 = 0, 1
+MIN_LENGTH_CONTIG = 500          # params.rs:42
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_LIB = None
+
+
+class SkaniHipError(RuntimeError):
+    pass
+
+
+def SketchParams(c=125, k=15, marker_c=1000, seeding_mode=SEED_AVX2):
+    """reference SketchParams::new (params.rs:148-196); seeding_mode selects which reference seeding path's
+    semantics are reproduced (x86-64 hosts run the AVX2 one, file_io.rs:194-206)."""
+    return B.SketchParams(c, k, marker_c, seeding_mode)
+
+
+def MapParams(min_af=0.15, both_min_af=-0.01, robust=False, median=False, learned_ani=False, compute_ci=False):
+    return B.MapParams(min_af, both_min_af, int(robust), int(median), int(learned_ani), int(compute_ci))
+
+
+def use_learned_ani(c, individual_contig_q=False, individual_contig_r=False, median=False):
+    """regression.rs:8-10"""
+    return c >= 70 and not individual_contig_q and not individual_contig_r and not median
+
+
+def _default_lib():
+    global _DEFAULT_LIB
+    if _DEFAULT_LIB is None:
+        path = os.path.join(_HERE, "libskani_hip.so")
+        if not os.path.exists(path):
+            raise SkaniHipError(f"{path} is missing: build it with `python -m skani_amd.build` (hipcc, gfx950). "
+                                "skani_amd has no CPU fallback.")
+        _DEFAULT_LIB = B.load(path)
+    return _DEFAULT_LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU.  `lib` is only overridden by the kernel-simulator tests (tests/emu)."""
+
+    def __init__(self, device=0, lib=None, load_models=True):
+        self.L = lib if lib is not None else _default_lib()
+        h = C.c_void_p()
+        rc = self.L.skh_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise SkaniHipError(f"skh_ctx_create(device={device}) failed with {rc}: no usable gfx950 device (no CPU path)")
+        self.h = h
+        if load_models:
+            self.check(self.L.skh_load_models(self.h, os.path.join(_HERE, "data", "gbdt_c125.bin").encode(),
+                                              os.path.join(_HERE, "data", "gbdt_c200.bin").encode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.skh_ctx_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise SkaniHipError(f"skani_hip error {rc}: {self.L.skh_last_error(self.h).decode()}")
+
+    def timings(self):
+        t = B.Timings(); self.check(self.L.skh_get_timings(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_ if n != "pad"}
+
+    # ---- ingest -------------------------------------------------------------------------------------------------
+    def pack_genomes(self, genomes, seeding_mode=SEED_AVX2):
+        """genomes: list (one per genome) of lists of contig byte strings (already >= 500 bp filtered)."""
+        contig_genome, lens = [], []
+        for g, ctgs in enumerate(genomes):
+            for s in ctgs:
+                contig_genome.append(g); lens.append(len(s))
+        off = np.zeros(len(lens) + 1, np.uint64); off[1:] = np.cumsum(np.array(lens, np.uint64))
+        bases = np.frombuffer(b"".join(s for ctgs in genomes for s in ctgs), np.uint8) if lens else np.zeros(1, np.uint8)
+        return self.pack_buffer(bases, off, np.array(contig_genome, np.uint32), len(genomes), seeding_mode)
+
+    def pack_buffer(self, bases, contig_off, contig_genome, n_genomes, seeding_mode=SEED_AVX2, device_ptr=None):
+        """bases: numpy uint8 (host) or, with device_ptr, a raw device address of ASCII bases already in HBM."""
+        contig_off = np.ascontiguousarray(contig_off, np.uint64); contig_genome = np.ascontiguousarray(contig_genome, np.uint32)
+        h = C.c_void_p()
+        ptr = C.c_void_p(device_ptr) if device_ptr is not None else _p(np.ascontiguousarray(bases, np.uint8))
+        self.check(self.L.skh_genomes_pack(self.h, ptr, _p(contig_off), _p(contig_genome), len(contig_genome), n_genomes,
+                                           1 if device_ptr is not None else 0, seeding_mode, C.byref(h)))
+        return GenomeSet(self, h, seeding_mode, contig_off, contig_genome, n_genomes)
+
+    # ---- sketch -------------------------------------------------------------------------------------------------
+    def sketch_genomes(self, gs, params, genome_rank=None, names=None):
+        h = C.c_void_p()
+        rank = np.ascontiguousarray(genome_rank, np.uint32) if genome_rank is not None else None
+        self.check(self.L.skh_sketch_genomes(self.h, gs.h, C.byref(params), _p(rank), C.byref(h)))
+        return SketchSet(self, h, params, names)
+
+    def sketch_records(self, genomes, params, names=None):
+        """genomes: list of lists of (name, seq) records for one file each; applies file_io.rs:176 (>= 500 bp)."""
+        kept = [[s for _, s in recs if len(s) >= MIN_LENGTH_CONTIG] for recs in genomes]
+        rank = None
+        if names is not None:
+            order = sorted(range(len(names)), key=lambda i: names[i]); rank = np.empty(len(names), np.uint32)
+            rank[order] = np.arange(len(names), dtype=np.uint32)
+        gs = self.pack_genomes(kept, params.seeding_mode)
+        try:
+            return self.sketch_genomes(gs, params, rank, names)
+        finally:
+            gs.close()
+
+    def import_sketches(self, params, per_genome, names=None, genome_rank=None):
+        """per_genome: list of dicts with seed,pos,ctgcanon (position order), markers (sorted), contig_lengths, total_len."""
+        ng = len(per_genome)
+        def cat(key, dt):
+            return np.ascontiguousarray(np.concatenate([np.asarray(d[key], dt) for d in per_genome]) if ng else np.zeros(0, dt), dt)
+        def offs(key):
+            o = np.zeros(ng + 1, np.uint64); o[1:] = np.cumsum([len(d[key]) for d in per_genome]); return o
+        order = np.lexsort  # noqa
+        fixed = []
+        for d in per_genome:   # make sure seeds are in (contig, pos) order
+            cc = np.asarray(d["ctgcanon"], np.uint32); ps = np.asarray(d["pos"], np.uint32)
+            o = np.lexsort((ps, cc >> 1))
+            fixed.append(dict(seed=np.asarray(d["seed"], np.uint32)[o], pos=ps[o], ctgcanon=cc[o], markers=np.sort(np.asarray(d["markers"], np.uint64)),
+                              contig_lengths=np.asarray(d["contig_lengths"], np.uint32), total_len=int(d["total_len"])))
+        per_genome = fixed
+        seed, pos, cc = cat("seed", np.uint32), cat("pos", np.uint32), cat("ctgcanon", np.uint32)
+        mk, cl = cat("markers", np.uint64), cat("contig_lengths", np.uint32)
+        tl = np.array([d["total_len"] for d in per_genome], np.uint64)
+        rank = np.ascontiguousarray(genome_rank, np.uint32) if genome_rank is not None else None
+        if rank is None and names is not None:
+            o = sorted(range(ng), key=lambda i: names[i]); rank = np.empty(ng, np.uint32); rank[o] = np.arange(ng, dtype=np.uint32)
+        h = C.c_void_p()
+        po, mo, co = offs("seed"), offs("markers"), offs("contig_lengths")
+        self.check(self.L.skh_sketch_import(self.h, C.byref(params), ng, _p(po), _p(seed), _p(pos), _p(cc), _p(mo), _p(mk), _p(co), _p(cl),
+                                            _p(tl), _p(rank), C.byref(h)))
+        return SketchSet(self, h, params, names)
+
+    # ---- screen / chain / triangle ------------------------------------------------------------------------------
+    def screen(self, refs, queries=None, identity=0.0, rule=0, rescue_small=True):
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.check(self.L.skh_screen(self.h, refs.h, queries.h if queries is not None else None, identity, rule, int(rescue_small),
+                                     C.byref(a), C.byref(b), C.byref(n)))
+        try:
+            first = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+            second = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+        finally:
+            self.L.skh_free(a); self.L.skh_free(b)
+        return first, second
+
+    def chain_pairs(self, refs, queries, pair_ref, pair_query, map_params, stats=False):
+        """chain_seeds(refs[pair_ref[p]], queries[pair_query[p]], map_params_from_sketch(ref)) for every p (chain.rs:144)."""
+        pr = np.ascontiguousarray(pair_ref, np.uint32); pq = np.ascontiguousarray(pair_query, np.uint32)
+        out = np.zeros(len(pr), B.RESULT_DTYPE); st = np.zeros(len(pr), B.STATS_DTYPE) if stats else None
+        self.check(self.L.skh_chain_pairs(self.h, refs.h, queries.h if queries is not None else None, _p(pr), _p(pq), len(pr),
+                                          C.byref(map_params), _p(out), _p(st)))
+        return (out, st) if stats else out
+
+    def triangle(self, sketches, map_params, identity=0.0, rescue_small=True, part=0, n_parts=1):
+        oi, oj, orr, n, nch = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self.check(self.L.skh_triangle(self.h, sketches.h, identity, int(rescue_small), C.byref(map_params), part, n_parts,
+                                       C.byref(oi), C.byref(oj), C.byref(orr), C.byref(n), C.byref(nch)))
+        try:
+            k = n.value
+            i = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
+            j = np.ctypeslib.as_array(C.cast(oj, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
+            buf = (C.c_char * (max(k, 1) * B.RESULT_DTYPE.itemsize)).from_address(orr.value)
+            res = np.frombuffer(buf, B.RESULT_DTYPE)[:k].copy()
+        finally:
+            self.L.skh_free(oi); self.L.skh_free(oj); self.L.skh_free(orr)
+        return i, j, res, nch.value
+
+
+class GenomeSet:
+    def __init__(self, ctx, h, mode, contig_off, contig_genome, n_genomes):
+        self.ctx, self.h, self.mode = ctx, h, mode
+        self.contig_off, self.contig_genome, self.n_genomes = contig_off, contig_genome, n_genomes
+
+    @property
+    def total_bases(self):
+        return self.ctx.L.skh_genomes_total_bases(self.h)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.skh_genomes_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SketchSet:
+    """Vec<Sketch> resident on the GPU."""
+
+    def __init__(self, ctx, h, params, names=None):
+        self.ctx, self.h, self.params, self.names = ctx, h, params, names
+
+    def __len__(self):
+        return self.ctx.L.skh_sketch_n_genomes(self.h)
+
+    def sizes(self, g):
+        a, b, c_, d, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        self.ctx.check(self.ctx.L.skh_sketch_sizes(self.h, g, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(e)))
+        return dict(n_pos=a.value, n_distinct=b.value, n_markers=c_.value, n_contigs=d.value, total_len=e.value)
+
+    def export(self, g):
+        s = self.sizes(g)
+        seed = np.empty(s["n_pos"], np.uint32); pos = np.empty(s["n_pos"], np.uint32); cc = np.empty(s["n_pos"], np.uint32)
+        mk = np.empty(s["n_markers"], np.uint64); cl = np.empty(s["n_contigs"], np.uint32)
+        self.ctx.check(self.ctx.L.skh_sketch_export(self.h, g, _p(seed), _p(pos), _p(cc), _p(mk), _p(cl)))
+        return dict(seed=seed, pos=pos, ctgcanon=cc, markers=mk, contig_lengths=cl, total_len=s["total_len"])
+
+    def close(self):
+        if self.h:
+            self.ctx.L.skh_sketch_set_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fastx_to_sketches(ctx, files, params):
+    """file_io.rs:141-252: one sketch per file, contigs < 500 bp skipped, files with no kept contig dropped,
+    result sorted by file name (file_io.rs:250)."""
+    files = sorted(files)
+    genomes, names = [], []
+    for f in files:
+        recs = [(n, s) for n, s in read_fasta(f) if len(s) >= MIN_LENGTH_CONTIG]
+        if recs:
+            genomes.append(recs); names.append(f)
+    return ctx.sketch_records(genomes, params, names)

@@ -1,0 +1,55 @@
+"""Builds libskani_hip.so (hipcc, gfx950) in-tree.  `python -m skani_amd.build`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "capi.hip"]
+LIB = os.path.join(HERE, "libskani_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fgpu-rdc-not-needed"]
+FLAGS = [f for f in FLAGS if f != "-fgpu-rdc-not-needed"]
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(HERE, "..", "include", "skani_hip.h")]
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build_hip(force=False, verbose=False):
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    deps = _deps()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s); obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + deps):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout[-4000:], r.stderr[-8000:]))
+        return r.stderr
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn[-2000:])
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,305 @@
+// capi.hip -- the extern "C" boundary declared in include/skani_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+#include "internal.h"
+
+using namespace skh;
+
+namespace {
+
+template <class F> int guarded(skh_ctx* ctx, F&& f) {
+    try { f(); return SKH_OK; }
+    catch (const std::bad_alloc&) { if (ctx) ctx->err = "out of host memory"; return SKH_ERR_NOMEM; }
+    catch (const Error& e) { if (ctx) ctx->err = e.what(); return SKH_ERR_DEVICE; }
+    catch (const std::invalid_argument& e) { if (ctx) ctx->err = e.what(); return SKH_ERR_INVALID; }
+    catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return SKH_ERR_INTERNAL; }
+    catch (...) { if (ctx) ctx->err = "unknown error"; return SKH_ERR_INTERNAL; }
+}
+
+void check_params(const skh_sketch_params* p) {
+    if (!p) throw std::invalid_argument("null sketch params");
+    if (p->k == 0 || p->k > 16) throw std::invalid_argument("k must be in 1..16 (seeding.rs:239)");
+    if (p->c == 0) throw std::invalid_argument("c must be >= 1");
+    if (p->c > p->marker_c) throw std::invalid_argument("c > marker_c is not allowed (params.rs:183-185)");
+    if (p->seeding_mode > 1) throw std::invalid_argument("bad seeding_mode");
+}
+
+struct Stopwatch {   // wall-clock around stream-synchronous phases
+    skh_ctx* ctx; float* dst;
+#ifndef SKANI_EMU
+    hipEvent_t e0, e1;
+    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
+    ~Stopwatch() { (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *dst += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+#else
+    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) {}
+#endif
+};
+
+void load_model(skh_ctx* ctx, const char* path, GbdtModel& m) {
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::invalid_argument(std::string("cannot open model table ") + path);
+    char magic[4]; uint32_t nt = 0, nf = 0, nn = 0; float sh = 0, bias = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "GBDT", 4) && fread(&nt, 4, 1, f) == 1 && fread(&nf, 4, 1, f) == 1 &&
+              fread(&sh, 4, 1, f) == 1 && fread(&bias, 4, 1, f) == 1 && fread(&nn, 4, 1, f) == 1;
+    std::vector<uint32_t> off(nt + 1); std::vector<GbdtModel::Node> nodes(nn);
+    ok = ok && fread(off.data(), 4, nt + 1, f) == nt + 1 && fread(nodes.data(), sizeof(GbdtModel::Node), nn, f) == nn;
+    fclose(f);
+    if (!ok) throw std::invalid_argument(std::string("malformed model table ") + path);
+    m.n_trees = nt; m.n_feat = nf; m.n_nodes = nn; m.shrinkage = sh; m.bias = bias;
+    m.off.alloc(nt + 1); m.nodes.alloc(nn);
+    h2d(m.off.p, off.data(), (nt + 1) * 4, ctx->stream); h2d(m.nodes.p, nodes.data(), nn * sizeof(GbdtModel::Node), ctx->stream);
+    dsync(ctx->stream);
+}
+
+skh_sketch_set* new_sketch_set(skh_ctx* ctx, const skh_sketch_params& sp, uint32_t ng, const uint32_t* rank) {
+    skh_sketch_set* ss = new skh_sketch_set();
+    ss->ctx = ctx; ss->params = sp; ss->n_genomes = ng;
+    ss->rank.resize(ng);
+    for (uint32_t g = 0; g < ng; g++) ss->rank[g] = rank ? rank[g] : g;
+    return ss;
+}
+
+void upload_contig_tables(skh_ctx* ctx, skh_sketch_set* ss) {
+    ss->d_ctg_len.alloc(ss->ctg_len.size() ? ss->ctg_len.size() : 1);
+    h2d(ss->d_ctg_len.p, ss->ctg_len.data(), ss->ctg_len.size() * 4, ctx->stream);
+    ss->d_ctg_off.alloc(ss->n_genomes + 1);
+    h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ss->n_genomes + 1) * 8, ctx->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int skh_ctx_create(int device, skh_ctx** out) {
+    if (!out) return SKH_ERR_INVALID;
+    *out = nullptr;
+    skh_ctx* ctx = new (std::nothrow) skh_ctx();
+    if (!ctx) return SKH_ERR_NOMEM;
+    int rc = guarded(ctx, [&] {
+#ifndef SKANI_EMU
+        int n = 0;
+        hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
+        if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+#endif
+        ctx->device = device;
+    });
+    if (rc != SKH_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return SKH_OK;
+}
+
+void skh_ctx_destroy(skh_ctx* ctx) {
+    if (!ctx) return;
+#ifndef SKANI_EMU
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+#endif
+    ctx->arena.release_all();
+    ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel();
+#ifndef SKANI_EMU
+    (void)hipStreamDestroy(ctx->stream);
+#endif
+    delete ctx;
+}
+
+const char* skh_last_error(const skh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void skh_free(void* p) { free(p); }
+
+int skh_load_models(skh_ctx* ctx, const char* p125, const char* p200) {
+    if (!ctx || !p125 || !p200) return SKH_ERR_INVALID;
+    return guarded(ctx, [&] { load_model(ctx, p125, ctx->model_c125); load_model(ctx, p200, ctx->model_c200); });
+}
+
+int skh_genomes_pack(skh_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome, uint32_t n_contigs,
+                     uint32_t n_genomes, int on_device, int seeding_mode, skh_genome_set** out) {
+    if (!ctx || !out || (n_contigs && (!bases || !contig_off || !contig_genome))) return SKH_ERR_INVALID;
+    *out = nullptr;
+    skh_genome_set* gs = nullptr;
+    int rc = guarded(ctx, [&] {
+        if (seeding_mode != SKH_SEED_SCALAR && seeding_mode != SKH_SEED_AVX2) throw std::invalid_argument("bad seeding_mode");
+        gs = new skh_genome_set();
+        gs->ctx = ctx; gs->seeding_mode = seeding_mode; gs->n_genomes = n_genomes; gs->n_contigs = n_contigs;
+        gs->contigs.resize(n_contigs); gs->genome_contig_off.assign(n_genomes + 1, 0);
+        uint32_t prev = 0, idx = 0;
+        for (uint32_t i = 0; i < n_contigs; i++) {
+            uint32_t g = contig_genome[i];
+            if (g >= n_genomes || g < prev) throw std::invalid_argument("contig_genome must be non-decreasing and < n_genomes");
+            if (g != prev) idx = 0;
+            gs->contigs[i].genome = g; gs->contigs[i].index = idx++;
+            gs->genome_contig_off[g + 1]++; prev = g;
+        }
+        for (uint32_t g = 0; g < n_genomes; g++) gs->genome_contig_off[g + 1] += gs->genome_contig_off[g];
+        static const uint64_t zero_off[1] = {0};
+        Stopwatch sw(ctx, &ctx->timings.pack_ms);
+        genomes_pack(ctx, gs, bases, n_contigs ? contig_off : zero_off, on_device);
+    });
+    ctx->arena.reset();
+    if (rc != SKH_OK) { delete gs; return rc; }
+    *out = gs;
+    return SKH_OK;
+}
+
+void skh_genomes_destroy(skh_genome_set* gs) { delete gs; }
+uint64_t skh_genomes_total_bases(const skh_genome_set* gs) { return gs ? gs->total_bases : 0; }
+
+int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketch_params* sp, const uint32_t* genome_rank, skh_sketch_set** out) {
+    if (!ctx || !gs_c || !out) return SKH_ERR_INVALID;
+    *out = nullptr;
+    skh_genome_set* gs = const_cast<skh_genome_set*>(gs_c);
+    skh_sketch_set* ss = nullptr;
+    int rc = guarded(ctx, [&] {
+        check_params(sp);
+        if ((int)sp->seeding_mode != gs->seeding_mode) throw std::invalid_argument("genome set was packed for the other seeding_mode");
+        ss = new_sketch_set(ctx, *sp, gs->n_genomes, genome_rank);
+        const uint32_t ng = gs->n_genomes;
+        ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
+        for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
+        finalize_metadata(ss);
+        upload_contig_tables(ctx, ss);
+        SeedOutput so;
+        { Stopwatch sw(ctx, &ctx->timings.seed_ms); seed_genomes(ctx, gs, *sp, so); }
+        ss->p_seed = std::move(so.seed); ss->p_pos = std::move(so.pos); ss->p_cc = std::move(so.cc); ss->pos_off = so.pos_off;
+        Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
+        build_sketch_tables(ctx, ss);
+        ctx->arena.reset();
+        build_markers(ctx, ss, so.markers_raw, so.mk_off);
+    });
+    ctx->arena.reset();
+    if (rc != SKH_OK) { delete ss; return rc; }
+    *out = ss;
+    return SKH_OK;
+}
+
+int skh_sketch_batch(skh_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome, uint32_t n_contigs,
+                     uint32_t n_genomes, const skh_sketch_params* sp, const uint32_t* genome_rank, skh_sketch_set** out) {
+    if (!ctx || !sp || !out) return SKH_ERR_INVALID;
+    skh_genome_set* gs = nullptr;
+    int rc = skh_genomes_pack(ctx, bases, contig_off, contig_genome, n_contigs, n_genomes, 0, (int)sp->seeding_mode, &gs);
+    if (rc != SKH_OK) return rc;
+    rc = skh_sketch_genomes(ctx, gs, sp, genome_rank, out);
+    skh_genomes_destroy(gs);
+    return rc;
+}
+
+void skh_sketch_set_destroy(skh_sketch_set* ss) { delete ss; }
+uint32_t skh_sketch_n_genomes(const skh_sketch_set* ss) { return ss ? ss->n_genomes : 0; }
+
+int skh_sketch_sizes(const skh_sketch_set* ss, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers, uint32_t* n_contigs, uint64_t* total_len) {
+    if (!ss || g >= ss->n_genomes) return SKH_ERR_INVALID;
+    if (n_pos) *n_pos = ss->pos_off[g + 1] - ss->pos_off[g];
+    if (n_distinct) *n_distinct = ss->dist_off[g + 1] - ss->dist_off[g];
+    if (n_markers) *n_markers = ss->mk_off[g + 1] - ss->mk_off[g];
+    if (n_contigs) *n_contigs = (uint32_t)(ss->ctg_off[g + 1] - ss->ctg_off[g]);
+    if (total_len) *total_len = ss->total_len[g];
+    return SKH_OK;
+}
+
+int skh_sketch_export(const skh_sketch_set* ss, uint32_t g, uint32_t* seed, uint32_t* pos, uint32_t* cc, uint64_t* markers, uint32_t* contig_lengths) {
+    if (!ss || g >= ss->n_genomes) return SKH_ERR_INVALID;
+    skh_ctx* ctx = ss->ctx;
+    return guarded(ctx, [&] {
+        const uint64_t p0 = ss->pos_off[g], np = ss->pos_off[g + 1] - p0, m0 = ss->mk_off[g], nm = ss->mk_off[g + 1] - m0;
+        if (seed) d2h(seed, ss->p_seed.p + p0, np * 4, ctx->stream);
+        if (pos) d2h(pos, ss->p_pos.p + p0, np * 4, ctx->stream);
+        if (cc) d2h(cc, ss->p_cc.p + p0, np * 4, ctx->stream);
+        if (markers) d2h(markers, ss->markers.p + m0, nm * 8, ctx->stream);
+        if (contig_lengths) memcpy(contig_lengths, ss->ctg_len.data() + ss->ctg_off[g], (ss->ctg_off[g + 1] - ss->ctg_off[g]) * 4);
+        dsync(ctx->stream);
+    });
+}
+
+int skh_sketch_import(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, const uint64_t* pos_off, const uint32_t* seed, const uint32_t* pos,
+                      const uint32_t* cc, const uint64_t* marker_off, const uint64_t* markers, const uint64_t* contig_off,
+                      const uint32_t* contig_lengths, const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out) {
+    if (!ctx || !out || !pos_off || !marker_off || !contig_off || !total_len) return SKH_ERR_INVALID;
+    *out = nullptr;
+    skh_sketch_set* ss = nullptr;
+    int rc = guarded(ctx, [&] {
+        check_params(sp);
+        ss = new_sketch_set(ctx, *sp, ng, genome_rank);
+        ss->pos_off.assign(pos_off, pos_off + ng + 1); ss->mk_off.assign(marker_off, marker_off + ng + 1);
+        ss->ctg_off.assign(contig_off, contig_off + ng + 1);
+        ss->ctg_len.assign(contig_lengths, contig_lengths + contig_off[ng]);
+        ss->total_len.assign(total_len, total_len + ng);
+        finalize_metadata(ss);
+        upload_contig_tables(ctx, ss);
+        const uint64_t P = pos_off[ng], M = marker_off[ng];
+        ss->p_seed.alloc(P); ss->p_pos.alloc(P); ss->p_cc.alloc(P); ss->markers.alloc(M);
+        h2d(ss->p_seed.p, seed, P * 4, ctx->stream); h2d(ss->p_pos.p, pos, P * 4, ctx->stream); h2d(ss->p_cc.p, cc, P * 4, ctx->stream);
+        h2d(ss->markers.p, markers, M * 8, ctx->stream);
+        ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
+        build_sketch_tables(ctx, ss);
+    });
+    ctx->arena.reset();
+    if (rc != SKH_OK) { delete ss; return rc; }
+    *out = ss;
+    return SKH_OK;
+}
+
+int skh_screen(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
+               uint32_t** pair_first, uint32_t** pair_second, uint64_t* n_pairs) {
+    if (!ctx || !refs || !pair_first || !pair_second || !n_pairs) return SKH_ERR_INVALID;
+    *pair_first = *pair_second = nullptr; *n_pairs = 0;
+    int rc = guarded(ctx, [&] {
+        if (rule < 0 || rule > 2) throw std::invalid_argument("bad screen rule");
+        std::vector<uint32_t> a, b;
+        { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, refs, queries, identity, rule, rescue_small, a, b); }
+        uint32_t* pa = (uint32_t*)malloc((a.size() + 1) * 4); uint32_t* pb = (uint32_t*)malloc((b.size() + 1) * 4);
+        if (!pa || !pb) { free(pa); free(pb); throw std::bad_alloc(); }
+        memcpy(pa, a.data(), a.size() * 4); memcpy(pb, b.data(), b.size() * 4);
+        *pair_first = pa; *pair_second = pb; *n_pairs = a.size();
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref, const uint32_t* pair_query,
+                    uint64_t n_pairs, const skh_map_params* mp, skh_ani_result* out, skh_chain_stats* stats) {
+    if (!ctx || !refs || !mp || (n_pairs && (!pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;
+    int rc = guarded(ctx, [&] {
+        Stopwatch sw(ctx, &ctx->timings.chain_ms);
+        chain_pairs(ctx, refs, queries ? queries : refs, pair_ref, pair_query, n_pairs, *mp, out, stats);
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int rescue_small, const skh_map_params* mp, uint32_t part,
+                 uint32_t n_parts, uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained) {
+    if (!ctx || !ss || !mp || !out_i || !out_j || !out_res || !n_kept || n_parts == 0 || part >= n_parts) return SKH_ERR_INVALID;
+    *out_i = *out_j = nullptr; *out_res = nullptr; *n_kept = 0;
+    int rc = guarded(ctx, [&] {
+        std::vector<uint32_t> a, b;
+        { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, ss, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b); }
+        ctx->arena.reset();
+        std::vector<uint32_t> pi, pj;
+        for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
+        std::vector<skh_ani_result> res(pi.size());
+        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, ss, ss, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
+        if (n_chained) *n_chained = pi.size();
+        size_t kept = 0;
+        for (auto& r : res) if (r.ani > 0.1f) kept++;                                                      // triangle.rs:99
+        uint32_t* oi = (uint32_t*)malloc((kept + 1) * 4); uint32_t* oj = (uint32_t*)malloc((kept + 1) * 4);
+        skh_ani_result* orr = (skh_ani_result*)malloc((kept + 1) * sizeof(skh_ani_result));
+        if (!oi || !oj || !orr) { free(oi); free(oj); free(orr); throw std::bad_alloc(); }
+        size_t q = 0;
+        for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) { oi[q] = pi[p]; oj[q] = pj[p]; orr[q] = res[p]; q++; }
+        *out_i = oi; *out_j = oj; *out_res = orr; *n_kept = kept;
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_get_timings(const skh_ctx* ctx, skh_timings* out) {
+    if (!ctx || !out) return SKH_ERR_INVALID;
+    *out = ctx->timings;
+    const_cast<skh_ctx*>(ctx)->timings = skh_timings{};
+    return SKH_OK;
+}
+
+}  // extern "C"

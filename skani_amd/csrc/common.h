@@ -1,0 +1,64 @@
+// common.h -- constants, hashes and small POD types shared by host and device code.
+// Constants restate the reference's src/params.rs (file:line cited per item).
+#pragma once
+#include <cstdint>
+
+#include "dev.h"
+
+namespace skh {
+
+// ---- reference constants -------------------------------------------------------------------------
+constexpr uint32_t K_MARKER = 21;            // params.rs:36 K_MARKER_DNA
+constexpr uint32_t CHUNK_SIZE = 20000;       // params.rs:40 CHUNK_SIZE_DNA (fragment_length, params.rs:125-134)
+constexpr uint32_t MIN_LENGTH_COVER = 500;   // params.rs:44
+constexpr uint32_t BP_CHAIN_BAND = 2500;     // params.rs:45
+constexpr int32_t MAX_GAP = 300;             // params.rs:19 D_MAX_GAP_LENGTH
+constexpr int32_t MAX_LIN = 5000;            // params.rs:21 D_MAX_LIN_LENGTH
+constexpr int32_t ANCHOR_SCORE = 20;         // params.rs:22 D_ANCHOR_SCORE_ANI
+constexpr uint32_t MIN_ANCHORS = 3;          // params.rs:24 D_MIN_ANCHORS_ANI
+constexpr int32_t MIN_SCORE = 45;            // chain.rs:113  3 * 20 * 0.75
+constexpr uint32_t SCREEN_MIN_KMERS = 20;    // params.rs:49
+constexpr uint32_t REGRESS_CUTOFF = 150000;  // params.rs:53 TOTAL_BASES_REGRESS_CUTOFF
+
+// ---- seeding geometry -----------------------------------------------------------------------------
+constexpr uint32_t SEED_THREADS = 256;
+constexpr uint32_t SEED_RUN = 32;                          // windows per thread
+constexpr uint32_t SEED_TILE = SEED_THREADS * SEED_RUN;    // 8192 windows per workgroup
+constexpr uint32_t CONTIG_ALIGN = 64;                      // contigs start on a 64-base (16 B packed) boundary
+
+// Thomas Wang / minimap2 64-bit mix -- types.rs:86-96 (mm_hash64)
+__host__ __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
+    key = ~(key + (key << 21));
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// table hash for the per-sketch seed tables (internal; murmur3 finaliser)
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+// contig descriptor inside a packed genome set
+struct ContigDesc {
+    uint64_t base;      // first base in the packed stream (multiple of CONTIG_ALIGN)
+    uint32_t len;       // bases
+    uint32_t genome;    // genome id within the set
+    uint32_t index;     // contig index within its genome (types.rs:124 contig_index)
+    uint32_t has_n;     // set by the pack kernel when the contig contains a masked byte
+};
+
+// one seeding workgroup's work: SEED_TILE consecutive windows of one contig
+struct SeedTile {
+    uint32_t contig;    // index into ContigDesc[]
+    uint32_t first;     // tile index within the contig: windows i in [20 + first*SEED_TILE, ...)
+};
+
+constexpr uint64_t TAB_EMPTY = ~0ull;
+
+}  // namespace skh

@@ -1,0 +1,111 @@
+// dev.h -- device runtime glue for the skani-hip kernels (gfx950).
+//
+// Product builds compile this with hipcc for gfx950 only.  The single SKANI_EMU switch lets the test
+// suite compile the very same kernel sources against tests/emu/emu.h (a lockstep CPU simulator used to
+// debug kernels in a container without a GPU); it is never defined in libskani_hip.so.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#ifdef SKANI_EMU
+#include "emu.h"
+typedef int devStream_t;
+#define SKH_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch_k(dim3(grid), dim3(block), (smem), kernel, __VA_ARGS__)
+#define SKH_DYN_SMEM(name) char* name = emu::g_blk->dyn_smem
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t devStream_t;
+#define SKH_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
+#define SKH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+namespace skh {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#ifdef SKANI_EMU
+inline void* dmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); return p; }
+inline void dfree(void* p) { free(p); }
+inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
+inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
+inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }
+inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
+inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
+inline void dsync(devStream_t) {}
+inline void check_launch(const char*) {}
+#else
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
+}
+inline void* dmalloc(size_t n) { void* p = nullptr; hip_check(hipMalloc(&p, n ? n : 16), "hipMalloc"); return p; }
+inline void dfree(void* p) { if (p) (void)hipFree(p); }
+inline void h2d(void* d, const void* h, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d"); }
+inline void d2h(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }
+inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "d2d"); }
+inline void dzero(void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, 0, n, s), "memset"); }
+inline void dfill(void* d, int byte, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, byte, n, s), "memset"); }
+inline void dsync(devStream_t s) { hip_check(hipStreamSynchronize(s), "stream sync"); }
+inline void check_launch(const char* what) { hip_check(hipGetLastError(), what); }
+#endif
+
+// RAII device buffer
+template <class T> struct DBuf {
+    T* p = nullptr; size_t n = 0;
+    DBuf() {}
+    explicit DBuf(size_t n_) { alloc(n_); }
+    DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DBuf() { release(); }
+    void alloc(size_t n_) { release(); n = n_; p = (T*)dmalloc(n_ * sizeof(T)); }
+    void release() { if (p) dfree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- wave helpers (wave = 64 lanes on gfx950) ----
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane) {
+    return __shfl(v, src_lane, 64);
+}
+// uniform-lane broadcast: lane index is the same for the whole wave -> v_readlane on gfx950
+__device__ __forceinline__ int wave_readlane(int v, int uniform_lane) {
+#ifdef SKANI_EMU
+    return emu::shfl(v, uniform_lane);
+#else
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane));
+#endif
+}
+__device__ __forceinline__ unsigned wave_readlane(unsigned v, int uniform_lane) { return (unsigned)wave_readlane((int)v, uniform_lane); }
+__device__ __forceinline__ int wave_first(int v) {
+#ifdef SKANI_EMU
+    return emu::readfirstlane(v);
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    unsigned l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(v, d, 64); if (l >= (unsigned)d) v += t; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { unsigned long long t = __shfl_xor(v, d, 64); v = t > v ? t : v; }
+    return v;
+}
+
+}  // namespace skh

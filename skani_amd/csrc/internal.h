@@ -1,0 +1,127 @@
+// internal.h -- host-side declarations shared by the translation units of libskani_hip.so.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/skani_hip.h"
+#include "common.h"
+
+namespace skh {
+
+// Stream-ordered scratch: bump allocation out of large device chunks; everything handed out is recycled
+// when the owning API call finishes (reset()).  Avoids hipMalloc/hipFree (implicit syncs) between kernels.
+struct Arena {
+    struct Chunk { char* p; size_t cap, off; };
+    std::vector<Chunk> chunks;
+    size_t min_chunk = (size_t)256 << 20;
+    ~Arena() { for (auto& c : chunks) dfree(c.p); }
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (auto& c : chunks) if (c.cap - c.off >= bytes) { void* r = c.p + c.off; c.off += bytes; return r; }
+        size_t cap = bytes > min_chunk ? bytes : min_chunk;
+        Chunk c{(char*)dmalloc(cap), cap, bytes};
+        chunks.push_back(c);
+        return c.p;
+    }
+    template <class T> T* get(size_t n) { return (T*)take(n * sizeof(T)); }
+    void reset() {  // keep the largest chunk, free the rest (callers sync the stream first)
+        if (chunks.size() > 1) {
+            size_t tot = 0; for (auto& c : chunks) { tot += c.cap; dfree(c.p); }
+            chunks.clear(); Chunk c{(char*)dmalloc(tot), tot, 0}; chunks.push_back(c);
+        } else for (auto& c : chunks) c.off = 0;
+    }
+    void release_all() { for (auto& c : chunks) dfree(c.p); chunks.clear(); }
+};
+
+struct GbdtModel {  // flat table from tools/extract_gbdt_model.py (regression.rs:12-28)
+    uint32_t n_trees = 0, n_feat = 0, n_nodes = 0; float shrinkage = 0, bias = 0;
+    struct Node { int32_t feat; float thr, pred; int32_t left, right; };
+    DBuf<uint32_t> off; DBuf<Node> nodes;
+    bool loaded() const { return n_trees != 0; }
+};
+
+}  // namespace skh
+
+struct skh_ctx {
+    int device = 0;
+    devStream_t stream{};
+    std::string err;
+    skh::Arena arena;
+    skh::GbdtModel model_c125, model_c200;
+    skh_timings timings{};
+};
+
+struct skh_genome_set {
+    skh_ctx* ctx = nullptr;
+    int seeding_mode = 0;
+    uint32_t n_genomes = 0, n_contigs = 0;
+    uint64_t n_words = 0, total_bases = 0;
+    std::vector<skh::ContigDesc> contigs;          // host copy
+    std::vector<uint64_t> genome_contig_off;       // n_genomes+1
+    skh::DBuf<uint32_t> packed;                    // 2-bit MSB-first, 16 bases per word
+    skh::DBuf<uint32_t> nmask;                     // 1 bit per base, LSB-first, 32 bases per word
+    skh::DBuf<skh::ContigDesc> d_contigs;
+    std::vector<skh::SeedTile> tiles;              // host tile list, ordered by (genome, contig, first)
+    std::vector<uint32_t> tile_cached_for;         // {mode} the tile list was built for
+    skh::DBuf<skh::SeedTile> d_tiles;
+};
+
+// Device-resident Vec<Sketch>.  Index conventions: *_off are per-genome u64 offsets into the concatenated arrays.
+struct skh_sketch_set {
+    skh_ctx* ctx = nullptr;
+    skh_sketch_params params{};
+    uint32_t n_genomes = 0;
+    // host metadata (one entry per genome unless noted)
+    std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
+    std::vector<uint32_t> tab_mask;
+    std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
+    std::vector<uint64_t> total_len;
+    std::vector<double> mean_ctg;
+    std::vector<float> q10, q50, q90;
+    std::vector<uint32_t> rank;
+    // device arrays
+    skh::DBuf<uint32_t> p_seed, p_pos, p_cc;       // position order (contig, pos)
+    skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)
+    skh::DBuf<uint32_t> s_pos, s_cc;               // seed order (seed, contig, pos)
+    skh::DBuf<uint32_t> u_seed, u_start;           // distinct seeds: value, start in the genome's seed-order arrays
+    skh::DBuf<uint16_t> u_cnt;                     // distinct seeds: multiplicity (clamped)
+    skh::DBuf<uint64_t> table;                     // open addressing: (seed<<32 | local distinct idx), TAB_EMPTY
+    skh::DBuf<uint64_t> markers;                   // sorted unique per genome
+    skh::DBuf<uint32_t> d_ctg_len;
+    skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_tab_off;
+    skh::DBuf<uint32_t> d_tab_mask;
+};
+
+namespace skh {
+
+// ---- scan.hip
+void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t* d_out /* n+1 entries */);
+
+// ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
+void sort_pairs_u64_u32(skh_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int end_bit);
+void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit);
+
+// ---- pack_seed.hip
+void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);
+struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
+    DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> markers_raw;
+    std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
+};
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out);
+
+// ---- sketch_build.hip
+void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss);                       // needs p_* and pos_off filled
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);
+void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means
+
+// ---- screen.hip
+void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
+                  int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second);
+
+// ---- chain.hip
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref,
+                 const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
+                 skh_chain_stats* stats);
+
+}  // namespace skh

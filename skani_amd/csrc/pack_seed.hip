@@ -1,0 +1,298 @@
+// pack_seed.hip -- genome ingest (ASCII -> 2-bit) and FracMinHash k-mer seeding on gfx950.
+//
+// Replaces seeding.rs:225-323 (fmh_seeds) / avx2_seeding.rs:33-272 (avx2_fmh_seeds) as called per contig
+// from file_io.rs:194-226.  Data layout in HBM:
+//   packed : u32 words, 16 bases per word, MSB first (base b of a contig -> word (base0+b)/16, shift 30-2*(b%16));
+//            every contig starts on a 64-base boundary, so a workgroup's tile starts on a 16 B boundary.
+//   nmask  : 1 bit per base (LSB first) marking the bytes the selected reference seeding path treats as
+//            "N" ('N' and 'n' for the scalar path, 'N' only for the AVX2 path); read only for contigs that
+//            have one (ContigDesc::has_n).  BYTE_TO_SEQ maps every non-ACGTU byte to A (types.rs:40-49), so the
+//            N information has to travel separately.
+// Kernel shape: one workgroup (256 threads) per tile of 8192 consecutive windows of one contig; the tile's
+// 2 KB of packed bases (+20-base halo) are staged through LDS with coalesced dword loads; each thread rolls
+// the forward / reverse-complement 21-mers over 32 consecutive windows entirely in registers, keeps a 32-bit
+// hit mask, and hits (1/c of windows) are re-derived by bit extraction and written in window order after a
+// workgroup prefix sum -- so the output is already sorted by (contig, pos) and needs no sort.
+#include "internal.h"
+
+namespace skh {
+
+// ------------------------------------------------------------------------------------------------ pack
+__device__ __forceinline__ uint32_t base_code(uint32_t b) {   // types.rs:40-49 BYTE_TO_SEQ
+    if (b < 4) return b;
+    uint32_t l = b | 0x20u;
+    if (l == 'c') return 1;
+    if (l == 'g') return 2;
+    if (l == 't' || l == 'u') return 3;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t* bases, const uint64_t* src_off, const uint64_t* unit_off,
+                                                   ContigDesc* contigs, uint32_t n_contigs, uint64_t n_units, int mode,
+                                                   uint32_t* packed, uint32_t* nmask) {
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_units) return;
+    uint32_t lo = 0, hi = n_contigs;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= u) lo = mid; else hi = mid; }
+    const uint32_t ci = lo;
+    const uint64_t b0 = (u - unit_off[ci]) * 32;
+    const uint32_t len = contigs[ci].len;
+    const uint8_t* src = bases + src_off[ci];
+    uint32_t w0 = 0, w1 = 0, m = 0;
+    for (uint32_t x = 0; x < 32; x++) {
+        uint64_t p = b0 + x;
+        uint32_t byte = p < len ? src[p] : (uint32_t)'A';
+        uint32_t code = base_code(byte);
+        // seeding.rs:272-275 tests 'N'(78) and 'n'(110); avx2_seeding.rs:115-126 tests 'N' only
+        bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
+        if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
+        m |= (is_n ? 1u : 0u) << x;
+    }
+    packed[2 * u] = w0; packed[2 * u + 1] = w1; nmask[u] = m;     // contig bases are laid out at 32*unit_off
+    if (m) atomicOr(&contigs[ci].has_n, 1u);
+}
+
+static inline uint32_t windows_end(uint32_t len, int mode) {  // exclusive bound on the window's last-base index i
+    if (len < 2 * K_MARKER) return K_MARKER - 1;                                  // seeding.rs:242 / avx2_seeding.rs:56
+    if (mode == SKH_SEED_AVX2) return (K_MARKER - 1) + 4 * ((len - (K_MARKER - 1)) / 4);   // avx2_seeding.rs:48,108
+    return len;                                                                    // seeding.rs:271
+}
+
+void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device) {
+    const uint32_t nc = gs->n_contigs;
+    std::vector<uint64_t> unit_off(nc + 1, 0), src_off(nc);
+    uint64_t total_src = contig_off[nc];
+    for (uint32_t i = 0; i < nc; i++) {
+        uint64_t len = contig_off[i + 1] - contig_off[i];
+        if (len > 0xFFFFFFF0ull) throw Error("contig longer than 2^32 bases");
+        ContigDesc& cd = gs->contigs[i];
+        cd.len = (uint32_t)len; cd.base = unit_off[i] * 32; cd.has_n = 0;
+        src_off[i] = contig_off[i];
+        uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
+        unit_off[i + 1] = unit_off[i] + padded / 32;
+        gs->total_bases += len;
+    }
+    const uint64_t n_units = unit_off[nc];
+    const uint64_t slack_words = 2 * (SEED_TILE / 16) + 64;    // a tile may read one tile + halo past its contig
+    gs->n_words = n_units * 2 + slack_words;
+    gs->packed.alloc(gs->n_words); gs->nmask.alloc(n_units + slack_words / 2 + 2);
+    dzero(gs->packed.p + n_units * 2, slack_words * 4, ctx->stream);
+    dzero(gs->nmask.p + n_units, (slack_words / 2 + 2) * 4, ctx->stream);
+    gs->d_contigs.alloc(nc ? nc : 1);
+    h2d(gs->d_contigs.p, gs->contigs.data(), nc * sizeof(ContigDesc), ctx->stream);
+    const uint8_t* d_bases = bases;
+    if (!on_device) { uint8_t* stage = ctx->arena.get<uint8_t>(total_src + 16); h2d(stage, bases, total_src, ctx->stream); d_bases = stage; }
+    uint64_t* d_src = ctx->arena.get<uint64_t>(nc + 1); uint64_t* d_unit = ctx->arena.get<uint64_t>(nc + 1);
+    h2d(d_src, src_off.data(), nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), (nc + 1) * 8, ctx->stream);
+    if (n_units) {
+        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, (const uint64_t*)d_src,
+                   (const uint64_t*)d_unit, gs->d_contigs.p, nc, n_units, gs->seeding_mode, gs->packed.p, gs->nmask.p);
+        check_launch("pack_kernel");
+    }
+    d2h(gs->contigs.data(), gs->d_contigs.p, nc * sizeof(ContigDesc), ctx->stream);   // picks up has_n (syncs)
+    // tile list in (genome, contig, window) order
+    gs->tiles.clear();
+    for (uint32_t i = 0; i < nc; i++) {
+        uint32_t iend = windows_end(gs->contigs[i].len, gs->seeding_mode);
+        uint32_t nwin = iend - (K_MARKER - 1);
+        for (uint32_t t = 0; t * SEED_TILE < nwin; t++) gs->tiles.push_back(SeedTile{i, t});
+    }
+    gs->d_tiles.alloc(gs->tiles.size() ? gs->tiles.size() : 1);
+    h2d(gs->d_tiles.p, gs->tiles.data(), gs->tiles.size() * sizeof(SeedTile), ctx->stream);
+    dsync(ctx->stream);
+}
+
+// ------------------------------------------------------------------------------------------------ seeding
+__device__ __forceinline__ uint64_t rev2_64(uint64_t x) {   // reverse the order of the 32 two-bit groups
+    uint64_t y = __brevll(x);
+    return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+}
+
+// Slow path, taken only by contigs that contain an N: bit j set = window j of this thread is suppressed.
+// scalar (seeding.rs:272-275,300): an N/n at p (p >= 20) suppresses windows i in [p, p+k).
+// avx2 (avx2_seeding.rs:63-81,115-126,181): lanes are substrings of length len4 = (L-20)/4; only an 'N' seen in the
+// lane's main loop (p >= lane_start = l*len4+20) suppresses that lane's windows i in [p, p+21).
+__device__ uint32_t n_suppress_mask(const uint32_t* nmask, const ContigDesc& cd, uint32_t i0, uint32_t iend, uint32_t k, int mode) {
+    uint32_t out = 0;
+    const uint32_t len4 = (cd.len - (K_MARKER - 1)) / 4;
+    for (uint32_t j = 0; j < SEED_RUN; j++) {
+        uint32_t i = i0 + j;
+        if (i >= iend) break;
+        uint32_t span, lo;
+        if (mode == SKH_SEED_AVX2) { span = K_MARKER; uint32_t l = (i - (K_MARKER - 1)) / len4; lo = l * len4 + (K_MARKER - 1); }
+        else { span = k; lo = K_MARKER - 1; }
+        uint32_t start = i + 1 >= span ? i + 1 - span : 0;
+        if (start < lo) start = lo;
+        bool sup = false;
+        for (uint32_t p = start; p <= i; p++) { uint64_t gb = cd.base + p; if ((nmask[gb >> 5] >> (gb & 31)) & 1u) { sup = true; break; } }
+        if (sup) out |= 1u << j;
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
+                                                         const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
+                                                         uint32_t k, uint64_t thr, uint64_t thr_m, int mode,
+                                                         uint32_t* __restrict__ t_seed, uint16_t* __restrict__ t_loc,
+                                                         uint64_t* __restrict__ t_marker, uint32_t* __restrict__ cnt_s,
+                                                         uint32_t* __restrict__ cnt_m) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w[SEED_TILE / 16 + 8];
+    __shared__ uint32_t lds_scan[16];
+    const uint32_t tid = threadIdx.x;
+    const SeedTile tile = tiles[blockIdx.x];
+    const ContigDesc cd = contigs[tile.contig];
+    const uint32_t iend = cd.len < 2 * K_MARKER ? (K_MARKER - 1)
+                        : (mode == SKH_SEED_AVX2 ? (K_MARKER - 1) + 4 * ((cd.len - (K_MARKER - 1)) / 4) : cd.len);
+    // stage: words covering bases [first*8192, first*8192 + 8192 + 20)
+    const uint64_t word0 = (cd.base + (uint64_t)tile.first * SEED_TILE) >> 4;
+    for (uint32_t w = tid; w < SEED_TILE / 16 + 2; w += SEED_THREADS) lds_w[w] = packed[word0 + w];
+    __syncthreads();
+    // this thread: bases [32*tid, 32*tid+52) of the tile = 20 warm-up bases + 32 windows
+    const uint32_t a0 = lds_w[2 * tid], a1 = lds_w[2 * tid + 1], a2 = lds_w[2 * tid + 2], a3 = lds_w[2 * tid + 3];
+    const uint64_t M42 = (1ull << 42) - 1;
+    const uint32_t smask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    // state after the 20 warm-up bases (seeding.rs:260-269): f = the 20 bases, r = reversed complement, newest at bits 40..41
+    uint64_t f = ((uint64_t)a0 << 8) | (a1 >> 24);
+    uint64_t r = (rev2_64(~f & ((1ull << 40) - 1)) >> 24) << 2;
+    uint32_t hits = 0, mhits = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SEED_RUN; j++) {
+        const uint32_t x = 20 + j;                           // base index within the thread's 52-base string
+        const uint32_t word = x < 32 ? a1 : (x < 48 ? a2 : a3);
+        const uint32_t nf = (word >> (30 - 2 * (x & 15))) & 3u;
+        f = ((f << 2) | nf) & M42;                                               // seeding.rs:278-280
+        r = (r >> 2) | ((uint64_t)(3u - nf) << 40);                              // seeding.rs:281-283
+        const uint32_t fs = (uint32_t)f & smask, rs = (uint32_t)r & smask;       // seeding.rs:288-289
+        const uint32_t seed = fs < rs ? fs : rs;                                 // seeding.rs:290-296
+        const uint64_t h = mm_hash64((uint64_t)seed);
+        hits |= (h < thr ? 1u : 0u) << j;                                        // seeding.rs:300
+        mhits |= (h < thr_m ? 1u : 0u) << j;                                     // seeding.rs:318
+    }
+    const uint32_t i0 = (K_MARKER - 1) + tile.first * SEED_TILE + SEED_RUN * tid;   // i of this thread's window 0
+    uint32_t nvalid = iend > i0 ? iend - i0 : 0;
+    const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+    hits &= vmask;
+    if (cd.has_n) hits &= ~n_suppress_mask(nmask, cd, i0, iend, k, mode);
+    mhits &= hits;
+    // workgroup prefix sum of (seed count | marker count << 16)
+    const uint32_t c = (uint32_t)__popc(hits) | ((uint32_t)__popc(mhits) << 16);
+    uint32_t incl = wave_incl_scan(c);
+    const uint32_t wv = tid >> 6, ln = tid & 63;
+    if (ln == 63) lds_scan[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t q = 0; q < SEED_THREADS / 64; q++) { uint32_t t = lds_scan[q]; if (q < wv) base += t; tot += t; }
+    const uint32_t excl = base + incl - c;
+    uint32_t so = excl & 0xFFFFu, mo = excl >> 16;
+    if (tid == 0) { cnt_s[blockIdx.x] = tot & 0xFFFFu; cnt_m[blockIdx.x] = tot >> 16; }
+    // emit hits in window order; values re-derived by extracting the 21-mer from the thread's 104 packed bits
+    const uint64_t hi = ((uint64_t)a0 << 32) | a1, lo = ((uint64_t)a2 << 32) | a3;
+    const uint64_t obase = (uint64_t)blockIdx.x * SEED_TILE;
+    uint32_t hm = hits;
+    while (hm) {
+        const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
+        const uint32_t s = 86u - 2u * j;                       // 128 - 2*(j+21)
+        uint64_t ff = s >= 64 ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
+        ff &= M42;
+        const uint64_t rr = rev2_64(~ff) >> 22;
+        const uint32_t fs = (uint32_t)ff & smask, rs = (uint32_t)rr & smask;
+        const bool canon = fs < rs;
+        t_seed[obase + so] = canon ? fs : rs;
+        t_loc[obase + so] = (uint16_t)((SEED_RUN * tid + j) | (canon ? 0x8000u : 0u));
+        so++;
+        if ((mhits >> j) & 1u) { t_marker[obase + mo] = ff < rr ? ff : rr; mo++; }   // seeding.rs:311-319
+    }
+}
+
+// one wave per tile: copy the tile's records to their final (contig,pos)-ordered place
+__global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __restrict__ tiles, const ContigDesc* __restrict__ contigs,
+                                                           uint32_t n_tiles, const uint32_t* __restrict__ t_seed,
+                                                           const uint16_t* __restrict__ t_loc, const uint64_t* __restrict__ t_marker,
+                                                           const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
+                                                           uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_pos,
+                                                           uint32_t* __restrict__ o_cc, uint64_t* __restrict__ o_marker) {
+    const uint32_t lt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (lt >= n_tiles) return;
+    const uint32_t ln = threadIdx.x & 63;
+    const SeedTile tile = tiles[lt];
+    const uint32_t cidx = contigs[tile.contig].index;
+    const uint32_t s0 = off_s[lt], ns = off_s[lt + 1] - s0, m0 = off_m[lt], nm = off_m[lt + 1] - m0;
+    const uint64_t ib = (uint64_t)lt * SEED_TILE;
+    for (uint32_t x = ln; x < ns; x += 64) {
+        const uint32_t loc = t_loc[ib + x];
+        o_seed[s0 + x] = t_seed[ib + x];
+        o_pos[s0 + x] = (K_MARKER - 1) + tile.first * SEED_TILE + (loc & 0x1FFFu);   // pos = index of the window's last base
+        o_cc[s0 + x] = (cidx << 1) | (loc >> 15);                                     // types.rs:131-138
+    }
+    for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = t_marker[ib + x];
+}
+
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out) {
+    const uint64_t thr = ~0ull / (uint64_t)sp.c, thr_m = ~0ull / (uint64_t)sp.marker_c;   // seeding.rs:258-259
+    const size_t n_tiles = gs->tiles.size();
+    const uint32_t ng = gs->n_genomes;
+    out.pos_off.assign(ng + 1, 0); out.mk_off.assign(ng + 1, 0);
+    const size_t MAX_TILES = 16384;     // per launch: 134 M windows, 1.9 GB of worst-case tile scratch
+    struct Part { DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
+    std::vector<Part> parts;
+    std::vector<uint64_t> g_ns(ng, 0), g_nm(ng, 0);
+#ifndef SKANI_EMU
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+#endif
+    for (size_t t0 = 0; t0 < n_tiles; t0 += MAX_TILES) {
+        const uint32_t nt = (uint32_t)std::min(MAX_TILES, n_tiles - t0);
+        uint32_t* t_seed = ctx->arena.get<uint32_t>((size_t)nt * SEED_TILE);
+        uint16_t* t_loc = ctx->arena.get<uint16_t>((size_t)nt * SEED_TILE);
+        uint64_t* t_marker = ctx->arena.get<uint64_t>((size_t)nt * SEED_TILE);
+        uint32_t* cnt_s = ctx->arena.get<uint32_t>(nt); uint32_t* cnt_m = ctx->arena.get<uint32_t>(nt);
+        uint32_t* off_s = ctx->arena.get<uint32_t>(nt + 1); uint32_t* off_m = ctx->arena.get<uint32_t>(nt + 1);
+#ifndef SKANI_EMU
+        hipEvent_t e0, e1; hip_check(hipEventCreate(&e0), "event"); hip_check(hipEventCreate(&e1), "event");
+        hip_check(hipEventRecord(e0, ctx->stream), "event record");
+#endif
+        SKH_LAUNCH(seed_tiles_kernel, nt, SEED_THREADS, 0, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+                   (const ContigDesc*)gs->d_contigs.p, (const SeedTile*)(gs->d_tiles.p + t0), sp.k, thr, thr_m, gs->seeding_mode,
+                   t_seed, t_loc, t_marker, cnt_s, cnt_m);
+        check_launch("seed_tiles_kernel");
+#ifndef SKANI_EMU
+        hip_check(hipEventRecord(e1, ctx->stream), "event record"); evs.push_back({e0, e1});
+#endif
+        exclusive_scan_u32(ctx, cnt_s, nt, off_s);
+        exclusive_scan_u32(ctx, cnt_m, nt, off_m);
+        std::vector<uint32_t> h_s(nt + 1), h_m(nt + 1);
+        d2h(h_s.data(), off_s, (nt + 1) * 4, ctx->stream); d2h(h_m.data(), off_m, (nt + 1) * 4, ctx->stream);
+        Part p; p.ns = h_s[nt]; p.nm = h_m[nt];
+        p.seed.alloc(p.ns); p.pos.alloc(p.ns); p.cc.alloc(p.ns); p.mk.alloc(p.nm);
+        SKH_LAUNCH(seed_compact_kernel, (nt + 3) / 4, 256, 0, ctx->stream, (const SeedTile*)(gs->d_tiles.p + t0),
+                   (const ContigDesc*)gs->d_contigs.p, nt, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker,
+                   (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.pos.p, p.cc.p, p.mk.p);
+        check_launch("seed_compact_kernel");
+        for (uint32_t lt = 0; lt < nt; lt++) {
+            uint32_t g = gs->contigs[gs->tiles[t0 + lt].contig].genome;
+            g_ns[g] += h_s[lt + 1] - h_s[lt]; g_nm[g] += h_m[lt + 1] - h_m[lt];
+        }
+        parts.push_back(std::move(p));
+        dsync(ctx->stream);
+        ctx->arena.reset();
+    }
+    for (uint32_t g = 0; g < ng; g++) { out.pos_off[g + 1] = out.pos_off[g] + g_ns[g]; out.mk_off[g + 1] = out.mk_off[g] + g_nm[g]; }
+    const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
+    if (parts.size() == 1) {
+        out.seed = std::move(parts[0].seed); out.pos = std::move(parts[0].pos); out.cc = std::move(parts[0].cc); out.markers_raw = std::move(parts[0].mk);
+    } else {
+        out.seed.alloc(NS); out.pos.alloc(NS); out.cc.alloc(NS); out.markers_raw.alloc(NM);
+        uint64_t so = 0, mo = 0;
+        for (auto& p : parts) {
+            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.pos.p + so, p.pos.p, p.ns * 4, ctx->stream);
+            d2d(out.cc.p + so, p.cc.p, p.ns * 4, ctx->stream); d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
+            so += p.ns; mo += p.nm;
+        }
+        dsync(ctx->stream);
+    }
+#ifndef SKANI_EMU
+    float ms = 0; for (auto& e : evs) { float t = 0; hip_check(hipEventElapsedTime(&t, e.first, e.second), "event time"); ms += t; (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    ctx->timings.seed_kernel_ms += ms; ctx->timings.seed_kernel_launches += (uint32_t)evs.size();
+#endif
+}
+
+}  // namespace skh

@@ -1,0 +1,195 @@
+// sketch_build.hip -- turns raw seeding output into the device-resident Sketch tables.
+//
+// Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
+// (types.rs:272) with, per genome:
+//   position order : p_seed/p_pos/p_cc (+ p_cnt = multiplicity of the entry's seed in this genome)  -- enumeration side
+//   seed order     : s_pos/s_cc sorted by (seed, contig, pos); u_seed/u_start/u_cnt = CSR over distinct seeds
+//   hash table     : open addressing, 64-bit slots (seed << 32 | distinct index), load <= 0.6              -- probe side
+//   markers        : sorted unique u64
+#include <algorithm>
+
+#include "internal.h"
+
+namespace skh {
+
+__device__ __forceinline__ uint32_t seg_of(const uint64_t* off, uint32_t n_seg, uint64_t i) {  // largest g with off[g] <= i
+    uint32_t lo = 0, hi = n_seg;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n,
+                                                             uint64_t* keys, uint32_t* vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t g = seg_of(pos_off, ng, i);
+    keys[i] = ((uint64_t)g << 32) | p_seed[i];
+    vals[i] = (uint32_t)(i - pos_off[g]);
+}
+
+__global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, uint64_t n, uint32_t* head) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void distinct_kernel(const uint64_t* keys, const uint32_t* head, const uint32_t* excl, uint64_t n,
+                                                       const uint64_t* pos_off, uint32_t* u_seed, uint32_t* u_start, uint16_t* u_cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const uint64_t key = keys[i];
+    uint32_t cnt = 1;
+    while (i + cnt < n && keys[i + cnt] == key) cnt++;
+    const uint32_t d = excl[i], g = (uint32_t)(key >> 32);
+    u_seed[d] = (uint32_t)key; u_start[d] = (uint32_t)(i - pos_off[g]); u_cnt[d] = (uint16_t)(cnt > 65535u ? 65535u : cnt);
+}
+
+__global__ __launch_bounds__(256) void seed_order_gather_kernel(const uint64_t* keys, const uint32_t* vals, const uint32_t* head,
+                                                                const uint32_t* excl, uint64_t n, const uint64_t* pos_off,
+                                                                const uint32_t* p_pos, const uint32_t* p_cc, const uint16_t* u_cnt,
+                                                                uint32_t* s_pos, uint32_t* s_cc, uint16_t* p_cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = (uint32_t)(keys[i] >> 32);
+    const uint64_t src = pos_off[g] + vals[i];
+    s_pos[i] = p_pos[src]; s_cc[i] = p_cc[src];
+    p_cnt[src] = u_cnt[excl[i] + head[i] - 1];
+}
+
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* u_seed, const uint64_t* dist_off, uint32_t ng, uint64_t n_dist,
+                                                           const uint64_t* tab_off, const uint32_t* tab_mask, uint64_t* table) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dist) return;
+    const uint32_t g = seg_of(dist_off, ng, d);
+    const uint32_t seed = u_seed[d], mask = tab_mask[g];
+    const unsigned long long entry = ((unsigned long long)seed << 32) | (uint32_t)(d - dist_off[g]);
+    unsigned long long* tab = (unsigned long long*)(table + tab_off[g]);
+    uint32_t h = mix32(seed) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&tab[h], (unsigned long long)TAB_EMPTY, entry);
+        if (prev == (unsigned long long)TAB_EMPTY) break;
+        h = (h + 1) & mask;
+    }
+}
+
+static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
+
+void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
+    const uint32_t ng = ss->n_genomes;
+    const uint64_t P = ss->pos_off[ng];
+    ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->s_pos.alloc(P); ss->s_cc.alloc(P); ss->p_cnt.alloc(P);
+    ss->dist_off.assign(ng + 1, 0);
+    uint64_t D = 0;
+    if (P > 0) {
+        if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
+        uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P);
+        const unsigned nb = (unsigned)((P + 255) / 256);
+        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, keys, vals);
+        check_launch("make_seed_keys");
+        sort_pairs_u64_u32(ctx, keys, vals, P, 32 + bits_for(ng));
+        uint32_t* head = ctx->arena.get<uint32_t>(P); uint32_t* excl = ctx->arena.get<uint32_t>(P + 1);
+        SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, P, head);
+        check_launch("head_flags");
+        exclusive_scan_u32(ctx, head, P, excl);
+        uint32_t* d_do = ctx->arena.get<uint32_t>(ng + 1);
+        SKH_LAUNCH(gather_u32_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)excl, (const uint64_t*)ss->d_pos_off.p, ng + 1, d_do);
+        check_launch("gather_u32");
+        std::vector<uint32_t> h_do(ng + 1);
+        d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
+        for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
+        D = ss->dist_off[ng];
+        ss->u_seed.alloc(D); ss->u_start.alloc(D); ss->u_cnt.alloc(D);
+        SKH_LAUNCH(distinct_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)head, (const uint32_t*)excl, P,
+                   (const uint64_t*)ss->d_pos_off.p, ss->u_seed.p, ss->u_start.p, ss->u_cnt.p);
+        check_launch("distinct");
+        SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
+                   (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_pos.p, (const uint32_t*)ss->p_cc.p,
+                   (const uint16_t*)ss->u_cnt.p, ss->s_pos.p, ss->s_cc.p, ss->p_cnt.p);
+        check_launch("seed_order_gather");
+    }
+    // hash tables (north-star requirement: per-sketch seed -> position tables built on device)
+    ss->tab_off.assign(ng + 1, 0); ss->tab_mask.assign(ng, 0);
+    for (uint32_t g = 0; g < ng; g++) {
+        uint64_t dg = ss->dist_off[g + 1] - ss->dist_off[g];
+        uint64_t cap = 16; while (cap * 6 < dg * 10) cap <<= 1;     // load factor <= 0.6
+        ss->tab_mask[g] = (uint32_t)(cap - 1); ss->tab_off[g + 1] = ss->tab_off[g] + cap;
+    }
+    const uint64_t S = ss->tab_off[ng];
+    ss->table.alloc(S);
+    dfill(ss->table.p, 0xFF, S * 8, ctx->stream);
+    ss->d_dist_off.alloc(ng + 1); h2d(ss->d_dist_off.p, ss->dist_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->d_tab_off.alloc(ng + 1); h2d(ss->d_tab_off.p, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->d_tab_mask.alloc(ng ? ng : 1); h2d(ss->d_tab_mask.p, ss->tab_mask.data(), ng * 4, ctx->stream);
+    if (D > 0) {
+        SKH_LAUNCH(table_insert_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->u_seed.p,
+                   (const uint64_t*)ss->d_dist_off.p, ng, D, (const uint64_t*)ss->d_tab_off.p, (const uint32_t*)ss->d_tab_mask.p, ss->table.p);
+        check_launch("table_insert");
+    }
+    dsync(ctx->stream);
+}
+
+// ---- markers: sort by (genome, marker), drop duplicates (marker_seeds is a set: seeding.rs:318, types.rs:272)
+__global__ __launch_bounds__(256) void marker_keys_kernel(uint64_t* raw, const uint64_t* raw_off, uint32_t ng, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    raw[i] |= (uint64_t)seg_of(raw_off, ng, i) << 42;
+}
+__global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t* keys, const uint32_t* head, const uint32_t* excl, uint64_t n, uint64_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    out[excl[i]] = keys[i] & ((1ull << 42) - 1);
+}
+
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
+    const uint32_t ng = ss->n_genomes;
+    const uint64_t M = raw_off[ng];
+    ss->mk_off.assign(ng + 1, 0);
+    if (ng >= (1u << 22)) throw Error("more than 4M genomes in one sketch set");
+    if (M >= 0xFFFFFFF0ull) throw Error("too many markers for one build; split the batch");
+    if (M > 0) {
+        uint64_t* d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
+        const unsigned nb = (unsigned)((M + 255) / 256);
+        SKH_LAUNCH(marker_keys_kernel, nb, 256, 0, ctx->stream, raw.p, (const uint64_t*)d_ro, ng, M);
+        check_launch("marker_keys");
+        sort_keys_u64(ctx, raw.p, M, 42 + bits_for(ng));
+        uint32_t* head = ctx->arena.get<uint32_t>(M); uint32_t* excl = ctx->arena.get<uint32_t>(M + 1);
+        SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)raw.p, M, head);
+        check_launch("head_flags");
+        exclusive_scan_u32(ctx, head, M, excl);
+        uint32_t* d_mo = ctx->arena.get<uint32_t>(ng + 1);
+        SKH_LAUNCH(gather_u32_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)excl, (const uint64_t*)d_ro, ng + 1, d_mo);
+        check_launch("gather_u32");
+        std::vector<uint32_t> h_mo(ng + 1);
+        d2h(h_mo.data(), d_mo, (ng + 1) * 4, ctx->stream);
+        for (uint32_t g = 0; g <= ng; g++) ss->mk_off[g] = h_mo[g];
+        ss->markers.alloc(ss->mk_off[ng]);
+        SKH_LAUNCH(marker_compact_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint32_t*)head, (const uint32_t*)excl, M, ss->markers.p);
+        check_launch("marker_compact");
+    } else ss->markers.alloc(0);
+    ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
+    dsync(ctx->stream);
+}
+
+// host-only: per-genome contig statistics used by switch_qr (chain.rs:625-631) and the regression features
+// (chain.rs:519-526): sorted contig lengths at indices n*10/100, n*50/100, n*90/100.
+void finalize_metadata(skh_sketch_set* ss) {
+    const uint32_t ng = ss->n_genomes;
+    ss->mean_ctg.assign(ng, 0.); ss->q10.assign(ng, 0.f); ss->q50.assign(ng, 0.f); ss->q90.assign(ng, 0.f);
+    for (uint32_t g = 0; g < ng; g++) {
+        std::vector<uint32_t> v(ss->ctg_len.begin() + ss->ctg_off[g], ss->ctg_len.begin() + ss->ctg_off[g + 1]);
+        if (v.empty()) continue;
+        double s = 0; for (auto x : v) s += (double)x;
+        ss->mean_ctg[g] = s / (double)v.size();
+        std::sort(v.begin(), v.end());
+        size_t n = v.size();
+        ss->q10[g] = (float)v[n * 10 / 100]; ss->q50[g] = (float)v[n * 50 / 100]; ss->q90[g] = (float)v[n * 90 / 100];
+    }
+}
+
+}  // namespace skh

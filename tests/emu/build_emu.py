@@ -1,0 +1,39 @@
+"""Builds tests/emu/libskani_emu.so: the kernel sources of skani_amd/csrc compiled by g++ against the
+lockstep simulator (emu.h).  TEST-ONLY -- see emu.h."""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "skani_amd", "csrc")
+SOURCES = ["scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "capi.hip"]
+LIB = os.path.join(HERE, "libskani_emu.so")
+FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-DSKANI_EMU", "-I", HERE, "-I", CSRC, "-pthread", "-Wall", "-Wno-unknown-pragmas",
+         "-Wno-attributes", "-fno-strict-aliasing"]
+
+
+def build(force=False):
+    objdir = os.path.join(HERE, "build"); os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "emu.h"),
+            os.path.join(ROOT, "include", "skani_hip.h")]
+    jobs = []
+    srcs = [(os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))) for s in SOURCES]
+    srcs.append((os.path.join(HERE, "emu.cpp"), os.path.join(objdir, "emu.o")))
+    for src, obj in srcs:
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + deps):
+            jobs.append(["g++"] + FLAGS + ["-x", "c++", "-c", src, "-o", obj])
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed: %s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    objs = [o for _, o in srcs]
+    if force or jobs or not os.path.exists(LIB):
+        run(["g++", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

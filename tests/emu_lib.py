@@ -1,0 +1,17 @@
+"""Loads the TEST-ONLY kernel simulator build (tests/emu) behind the same ctypes prototypes as the product library."""
+import importlib.util
+import os
+
+from skani_amd import _binding
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def emu_lib():
+    global _LIB
+    if _LIB is None:
+        spec = importlib.util.spec_from_file_location("build_emu", os.path.join(_HERE, "emu", "build_emu.py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        _LIB = _binding.load(m.build())
+    return _LIB
