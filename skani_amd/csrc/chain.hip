@@ -1,4 +1,793 @@
+// chain.hip -- chain_seeds (chain.rs:144-171) for a batch of genome pairs on gfx950.
+//
+// Reference stages and their GPU formulation (all integer until the final pow/mean; bit-exact stage outputs):
+//   get_anchors join      chain.rs:608-737  -> join_count_kernel / join_fill_kernel
+//        The enumerated sketch ("chain-query", A) is walked in POSITION order and every position probes the other
+//        sketch's (B) hash table.  Because A is in (contig,pos) order and B's seed-order arrays are in
+//        (seed,contig,pos) order, anchors are PRODUCED in the reference's sorted order
+//        (query_contig, query_pos, ref_contig, ref_pos, reverse) -- the reference's sort (chain.rs:721) disappears,
+//        and query_positions_all (chain.rs:682-700,722-724) is just the filtered position list.
+//   chunking              chain.rs:738-836  -> chunk_kernel: one wave per pair walks the anchors with 64-wide ballots
+//   chain_anchors_ani     chain.rs:838-896  -> chain_dp_kernel: one wave per chunk; lanes own 64 consecutive anchors,
+//        sources are swept in order and broadcast with v_readlane; each lane keeps (score, ptr, root, depth)
+//   get_chain_intervals   chain.rs:939-1007 -> per-component argmax by 64-bit atomicMax(score<<32|index), interval_emit_kernel
+//   get_nonoverlapping    chain.rs:1008-1099-> greedy_kernel: one wave per pair, bitonic sort of interval indices + greedy
+//   calculate_ani         chain.rs:173-555  -> chunk_stats_kernel (per chunk) + finalize_kernel (per pair, incl. CI and GBDT)
+#include <algorithm>
+#include <cmath>
+
 #include "internal.h"
+
 namespace skh {
-void chain_pairs(skh_ctx*, const skh_sketch_set*, const skh_sketch_set*, const uint32_t*, const uint32_t*, uint64_t, const skh_map_params&, skh_ani_result*, skh_chain_stats*) { throw Error("chain not built yet"); }
+
+// ------------------------------------------------------------------------------------------------ views & descriptors
+struct SetView {
+    const uint32_t *p_seed, *p_pos, *p_cc; const uint16_t* p_cnt;
+    const uint32_t *s_pos, *s_cc, *u_seed, *u_start; const uint16_t* u_cnt;
+    const uint64_t* table;
+};
+static SetView view_of(const skh_sketch_set* s) {
+    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->u_seed.p, s->u_start.p, s->u_cnt.p, s->table.p};
 }
+
+struct PairDesc {
+    uint64_t a_pos0;    // A (enumerated sketch): first entry in its set's position-order arrays
+    uint64_t b_pos0;    // B (probed sketch): first entry in its set's seed-order arrays
+    uint64_t b_dist0;   // B: first entry in u_seed/u_start/u_cnt
+    uint64_t b_tab0;    // B: first slot of its hash table
+    uint32_t a_n;       // positions in A
+    uint32_t b_mask;    // B table size - 1
+    uint32_t flags;     // bit0: A lives in set 1, bit1: B lives in set 1, bit2: switched (chain.rs:649)
+    uint32_t tile0;     // first join tile of this pair (global over the call)
+    // finalisation inputs (ref/query in the caller's sense, NOT A/B)
+    uint64_t ref_total_len, query_total_len;
+    float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
+    uint32_t nctg_q, nctg_r;
+};
+
+constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct Chunk { uint32_t a_begin, a_end, s_begin, s_end; };            // batch-relative anchor / seed-list ranges
+struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };   // types.rs:508-519 field order = sort order
+
+// ------------------------------------------------------------------------------------------------ join
+struct Probe { uint32_t n_anch; uint32_t inq; uint64_t b_start; };
+
+__device__ __forceinline__ Probe probe_position(const SetView& A, const SetView& B, const PairDesc& pd, uint64_t ai, uint32_t band) {
+    Probe pr{0, 0, 0};
+    if ((uint32_t)A.p_cnt[ai] > band) return pr;                                   // chain.rs:674-676
+    const uint32_t seed = A.p_seed[ai];
+    const uint64_t* tab = B.table + pd.b_tab0;
+    uint32_t h = mix32(seed) & pd.b_mask;
+    for (;;) {
+        const uint64_t e = tab[h];
+        if (e == TAB_EMPTY) { pr.inq = 1; return pr; }                             // absent in B: chain.rs:682-685
+        if ((uint32_t)(e >> 32) == seed) {
+            const uint64_t d = pd.b_dist0 + (uint32_t)e;
+            const uint32_t cnt = B.u_cnt[d];
+            if (cnt > band) return pr;                                             // chain.rs:694-696 (not even counted as a query seed)
+            pr.inq = 1; pr.n_anch = cnt; pr.b_start = pd.b_pos0 + B.u_start[d];
+            return pr;
+        }
+        h = (h + 1) & pd.b_mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* tile_pair, uint32_t band,
+                                                         uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq) {
+    __shared__ uint32_t lds[16];
+    const uint32_t tile = blockIdx.x, p = tile_pair[tile];
+    const PairDesc pd = pairs[p];
+    const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
+    const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
+    uint32_t na = 0, nq = 0;
+    for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
+        const uint32_t i = start + r * 256 + threadIdx.x;
+        if (i < pd.a_n) { Probe pr = probe_position(A, B, pd, pd.a_pos0 + i, band); na += pr.n_anch; nq += pr.inq; }
+    }
+    na = wave_sum(na); nq = wave_sum(nq);
+    const uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds[w] = na; lds[8 + w] = nq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tq = 0;
+        for (uint32_t i = 0; i < 4; i++) { ta += lds[i]; tq += lds[8 + i]; }
+        tile_anch[tile] = ta; tile_inq[tile] = tq;
+        if (ta) atomicAdd(&pair_anch[p], ta);
+        if (tq) atomicAdd(&pair_inq[p], tq);
+    }
+}
+
+// Emits anchors and the query-position list of one tile at the offsets given by the tile scans.
+__global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* tile_pair, uint32_t tile_base,
+                                                        uint32_t band, const uint32_t* toff_a, const uint32_t* toff_q,
+                                                        uint32_t* a_q, uint32_t* a_r, uint32_t* a_cr, uint32_t* a_qc, uint32_t* ql_pos, uint32_t* ql_ctg) {
+    __shared__ uint32_t lds[16];
+    const uint32_t lt = blockIdx.x, tile = tile_base + lt, p = tile_pair[tile];
+    const PairDesc pd = pairs[p];
+    const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
+    const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
+    uint32_t run_a = toff_a[lt], run_q = toff_q[lt];
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
+        const uint32_t i = start + r * 256 + threadIdx.x;
+        Probe pr{0, 0, 0};
+        if (i < pd.a_n) pr = probe_position(A, B, pd, pd.a_pos0 + i, band);
+        // workgroup exclusive scans of n_anch and inq (packed: anchors in the low 24 bits is not enough -> two scans)
+        const uint32_t ia = wave_incl_scan(pr.n_anch), iq = wave_incl_scan(pr.inq);
+        if (l == 63) { lds[w] = ia; lds[8 + w] = iq; }
+        __syncthreads();
+        uint32_t ba = 0, bq = 0, ta = 0, tq = 0;
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds[k], y = lds[8 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
+        __syncthreads();
+        if (pr.inq) {
+            const uint64_t ai = pd.a_pos0 + i;
+            const uint32_t qpos = A.p_pos[ai], qcc = A.p_cc[ai];
+            const uint32_t oq = run_q + bq + iq - 1;
+            ql_pos[oq] = qpos; ql_ctg[oq] = qcc >> 1;
+            uint32_t oa = run_a + ba + ia - pr.n_anch;
+            for (uint32_t k = 0; k < pr.n_anch; k++, oa++) {                       // chain.rs:703-711, already in sorted order
+                const uint32_t rcc = B.s_cc[pr.b_start + k];
+                a_q[oa] = qpos; a_qc[oa] = qcc >> 1; a_r[oa] = B.s_pos[pr.b_start + k];
+                a_cr[oa] = (rcc & ~1u) | ((rcc ^ qcc) & 1u);                       // ref_contig << 1 | reverse_match
+            }
+        }
+        run_a += ta; run_q += tq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chunking (chain.rs:738-836)
+// One wave per pair.  All control flow is wave-uniform; lanes only differ in the element they test.
+__device__ __forceinline__ uint32_t first_anchor_break(const uint32_t* a_q, const uint32_t* a_qc, uint32_t from, uint32_t to, uint32_t last, uint32_t end) {
+    const uint32_t l = lane_id();
+    for (uint32_t p = from; p < to; p += 64) {
+        const uint32_t i = p + l;
+        const bool brk = i < to && (a_qc[i] != last || a_q[i] > end);
+        const unsigned long long m = __ballot(brk);
+        if (m) return p + (uint32_t)__ffsll((long long)m) - 1u;
+    }
+    return to;
+}
+__device__ __forceinline__ uint32_t first_seed_beyond(const uint32_t* ql_pos, const uint32_t* ql_ctg, uint32_t from, uint32_t to, uint32_t ctg, uint32_t limit) {
+    const uint32_t l = lane_id();
+    for (uint32_t p = from; p < to; p += 64) {
+        const uint32_t i = p + l;
+        const bool brk = i < to && (ql_ctg[i] != ctg || ql_pos[i] > limit);
+        const unsigned long long m = __ballot(brk);
+        if (m) return p + (uint32_t)__ffsll((long long)m) - 1u;
+    }
+    return to;
+}
+__device__ __forceinline__ uint32_t lower_bound_ctg(const uint32_t* ql_ctg, uint32_t lo, uint32_t hi, uint32_t ctg) {   // uniform
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ql_ctg[mid] < ctg) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint32_t* pa0, const uint32_t* pq0, const uint32_t* pc0,
+                                                    const uint32_t* a_q, const uint32_t* a_qc, const uint32_t* ql_pos, const uint32_t* ql_ctg,
+                                                    Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    const uint32_t l = lane_id();
+    const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
+    uint32_t nc = 0;
+    if (A1 > A0) {
+        uint32_t last = a_qc[A0], end = a_q[A0] + CHUNK_SIZE;                       // chain.rs:742-744
+        uint32_t rc = lower_bound_ctg(ql_ctg, Q0, Q1, last);                        // running_counter = 0 within contig `last`
+        uint32_t cur = A0, scan = A0 + 1;
+        for (;;) {
+            const uint32_t t = first_anchor_break(a_q, a_qc, scan, A1, last, end);
+            Chunk ck; ck.a_begin = cur; ck.s_begin = rc;
+            if (t == A1) {                                                         // final chunk: seeds <= last anchor's pos (chain.rs:794-824)
+                ck.a_end = A1; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, a_q[A1 - 1]);
+            } else {                                                               // chain.rs:747-790
+                ck.a_end = t; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, end);
+            }
+            if (C0 + nc < C1) { if (l == 0) { chunks[C0 + nc] = ck; chunk_pair[C0 + nc] = p; } }
+            else if (l == 0) atomicAdd(err, 1u);
+            nc++;
+            if (t == A1) break;
+            rc = ck.s_end; end += CHUNK_SIZE;                                      // one step only (chain.rs:782)
+            const uint32_t nctg = a_qc[t];
+            if (nctg != last) { end = a_q[t] + CHUNK_SIZE; rc = lower_bound_ctg(ql_ctg, Q0, Q1, nctg); last = nctg; }   // chain.rs:786-789
+            cur = t; scan = t + 1;
+        }
+    }
+    for (uint32_t s = C0 + nc + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0}; chunk_pair[s] = p; }
+    if (l == 0) n_chunks[p] = nc;
+}
+
+// ------------------------------------------------------------------------------------------------ banded chaining DP
+// chain.rs:838-896 + score_anchors :558-603.  One wave per chunk.  Lanes own anchors base..base+63; sources j are
+// swept in increasing order; a source's score is final when the sweep reaches it, so it is broadcast with v_readlane.
+// All values are integers (positions, 20, gap) => int32 is exact where the reference uses f64.
+struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
+
+template <int PB>
+__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* a_q, const uint32_t* a_r,
+                                                       const uint32_t* a_cr, int32_t* o_score, uint32_t* o_root, uint32_t* o_depth, uint32_t* o_chunk,
+                                                       unsigned long long* best) {
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= n_slots) return;
+    const Chunk ck = chunks[slot];
+    if (ck.a_end <= ck.a_begin) return;
+    const int l = (int)lane_id();
+    Blk prev[PB];
+#pragma unroll
+    for (int b = 0; b < PB; b++) prev[b] = Blk{0, 0, 0, 0, 0, 0};
+    for (uint32_t base = ck.a_begin; base < ck.a_end; base += 64) {
+        const uint32_t t = base + (uint32_t)l;
+        const bool valid = t < ck.a_end;
+        Blk cur;
+        cur.q = valid ? a_q[t] : 0; cur.r = valid ? a_r[t] : 0; cur.cr = valid ? a_cr[t] : 0xFFFFFFFFu;
+        cur.score = 0; cur.root = t; cur.depth = 1;
+        uint32_t ptr = t;
+        const uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
+        const uint32_t jhi = ck.a_end < base + 64 ? ck.a_end : base + 64;
+        for (uint32_t j = jlo; j < jhi; j++) {
+            uint32_t qj, rj, crj; int32_t sj;
+            if (j >= base) {
+                const int ln = (int)(j - base);
+                // finalise lane ln: its score/ptr can no longer change (all its predecessors were swept)
+                const uint32_t pj = wave_readlane(ptr, ln);
+                uint32_t rootj = j, depthj = 1;
+                if (pj != j) {
+                    if (pj >= base) { rootj = wave_readlane(cur.root, (int)(pj - base)); depthj = wave_readlane(cur.depth, (int)(pj - base)) + 1; }
+                    else {
+#pragma unroll
+                        for (int b = 0; b < PB; b++) {
+                            const uint32_t bb = base - 64u * (uint32_t)(b + 1);
+                            if (base >= 64u * (uint32_t)(b + 1) && pj >= bb && pj < bb + 64) { rootj = wave_readlane(prev[b].root, (int)(pj - bb)); depthj = wave_readlane(prev[b].depth, (int)(pj - bb)) + 1; }
+                        }
+                    }
+                }
+                if (l == ln) { cur.root = rootj; cur.depth = depthj; }
+                qj = wave_readlane(cur.q, ln); rj = wave_readlane(cur.r, ln); crj = wave_readlane(cur.cr, ln); sj = wave_readlane(cur.score, ln);
+            } else {
+                qj = rj = crj = 0; sj = 0;
+#pragma unroll
+                for (int b = 0; b < PB; b++) {
+                    const uint32_t bb = base - 64u * (uint32_t)(b + 1);
+                    if (base >= 64u * (uint32_t)(b + 1) && j >= bb && j < bb + 64) {
+                        const int ln = (int)(j - bb);
+                        qj = wave_readlane(prev[b].q, ln); rj = wave_readlane(prev[b].r, ln); crj = wave_readlane(prev[b].cr, ln); sj = wave_readlane(prev[b].score, ln);
+                    }
+                }
+            }
+            // link j -> t (score_anchors).  Candidates: same ref contig and strand, i-j <= band, 0 < dq <= 2500,
+            // 0 < dr <= 5000, |dr-dq| <= 300 (chain.rs:856-863, 564-597)
+            if (valid && t > j && t - j <= band && cur.cr == crj) {
+                const uint32_t dq = cur.q - qj;
+                const bool rev = (crj & 1u) != 0;
+                const bool fwd_ok = rev ? (rj > cur.r) : (cur.r > rj);
+                const uint32_t dr = rev ? rj - cur.r : cur.r - rj;
+                if (dq != 0 && dq <= BP_CHAIN_BAND && fwd_ok && dr <= (uint32_t)MAX_LIN) {
+                    const int32_t gap = (int32_t)dr > (int32_t)dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+                    const int32_t s = ANCHOR_SCORE - gap + sj;
+                    // reference scans j downwards and replaces only on strictly greater => among equal maxima the largest j wins
+                    if (gap <= MAX_GAP && s > 0 && s >= cur.score) { cur.score = s; ptr = j; }
+                }
+            }
+        }
+        if (valid) {
+            o_score[t] = cur.score; o_root[t] = cur.root; o_depth[t] = cur.depth; o_chunk[t] = slot;
+            atomicMax(&best[cur.root], ((unsigned long long)(uint32_t)cur.score << 32) | t);   // argmax, ties -> largest index (chain.rs:952-964)
+        }
+#pragma unroll
+        for (int b = PB - 1; b > 0; b--) prev[b] = prev[b - 1];
+        prev[0] = cur;
+    }
+}
+
+// chain.rs:939-1007: one candidate interval per pointer-forest component that reaches 3 anchors / score 45
+__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_anch, const uint32_t* a_q, const uint32_t* a_r, const uint32_t* a_cr, const uint32_t* a_qc,
+                                                            const uint32_t* o_root, const uint32_t* o_depth, const uint32_t* o_chunk,
+                                                            const unsigned long long* best, const uint32_t* chunk_pair, const uint32_t* pc0,
+                                                            const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_anch || o_root[i] != i) return;
+    const unsigned long long b = best[i];
+    const uint32_t bi = (uint32_t)b; const int32_t sc = (int32_t)(b >> 32);
+    const uint32_t na = o_depth[bi];
+    if (na < MIN_ANCHORS || sc < MIN_SCORE) return;                                 // chain.rs:974-977
+    const uint32_t slot = o_chunk[i], p = chunk_pair[slot];
+    const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
+    if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); return; }
+    Interval iv;
+    iv.score = (uint32_t)sc; iv.na = na; iv.q0 = a_q[i]; iv.q1 = a_q[bi];
+    const uint32_t e1 = a_r[i], e2 = a_r[bi];
+    iv.r0 = e1 < e2 ? e1 : e2; iv.r1 = e1 < e2 ? e2 : e1;
+    iv.rctg = a_cr[i] >> 1; iv.qctg = a_qc[i]; iv.chunk = slot - pc0[p]; iv.rev = a_cr[i] & 1u;
+    ivls[pi0[p] + k] = iv;
+}
+
+// ------------------------------------------------------------------------------------------------ greedy selection
+__device__ __forceinline__ int ivl_cmp(const Interval& a, const Interval& b) {     // derived PartialOrd over the field order
+#define SKH_CMP(f) if (a.f != b.f) return a.f < b.f ? -1 : 1;
+    SKH_CMP(score) SKH_CMP(na) SKH_CMP(q0) SKH_CMP(q1) SKH_CMP(r0) SKH_CMP(r1) SKH_CMP(rctg) SKH_CMP(qctg) SKH_CMP(chunk) SKH_CMP(rev)
+#undef SKH_CMP
+    return 0;
+}
+
+constexpr uint32_t GREEDY_LDS = 2048;   // sorted-index slots per wave kept in LDS; larger pairs sort in their global scratch
+
+// One wave per pair: bitonic-sort the pair's candidate interval indices into DESCENDING tuple order (chain.rs:1012),
+// then accept greedily (chain.rs:1017-1095).  An accepted interval is flagged in bit 31 of its sorted slot and pushed
+// on its chunk's list (good_non_overlap_intervals[chunk_id], order-free downstream).
+__global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                     const Interval* ivls, uint32_t* sorted_glob, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    __shared__ uint32_t lds_idx[4][GREEDY_LDS];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (p >= n_pairs) return;
+    const uint32_t l = lane_id();
+    const uint32_t I0 = pi0[p];
+    uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
+    if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
+    uint32_t N = 1; while (N < n) N <<= 1;                                          // ps0 reserves pow2(cap) >= N slots per pair
+    uint32_t* idx = N <= GREEDY_LDS ? lds_idx[wv] : sorted_glob + ps0[p];
+    const Interval* iv = ivls + I0;
+    for (uint32_t i = l; i < N; i += 64) idx[i] = i < n ? i : NONE;
+    wave_sync_mem();
+    // before(a,b): a precedes b in the final order (greater tuple first; padding last)
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = l; i < N; i += 64) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = idx[i], b = idx[x];
+                    const bool up = (i & k) == 0;
+                    const uint32_t first = up ? b : a, second = up ? a : b;          // swap iff `first` must precede `second`
+                    const bool sw = first != NONE && (second == NONE || ivl_cmp(iv[first], iv[second]) > 0);
+                    if (sw) { idx[i] = b; idx[x] = a; }
+                }
+            }
+            wave_sync_mem();
+        }
+    }
+    uint32_t nacc = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint32_t ci = idx[s] & 0x7FFFFFFFu;
+        const Interval c = iv[ci];
+        uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
+        for (uint32_t t = l; t < s; t += 64) {
+            const uint32_t e = idx[t];
+            if (e & 0x80000000u) {
+                const Interval o = iv[e & 0x7FFFFFFFu];
+                if (o.rctg == c.rctg && o.r0 < c.r1 && c.r0 < o.r1) { cnt_r++; const uint32_t x = c.r1 - o.r0, y = o.r1 - c.r0; sum_r += x < y ? x : y; }   // chain.rs:1036-1045
+                if (o.qctg == c.qctg && o.q0 < c.q1 && c.q0 < o.q1) { cnt_q++; const uint32_t x = c.q1 - o.q0, y = o.q1 - c.q0; sum_q += x < y ? x : y; }   // chain.rs:1065-1073
+            }
+        }
+        sum_r = wave_sum(sum_r); sum_q = wave_sum(sum_q); cnt_r = wave_sum(cnt_r); cnt_q = wave_sum(cnt_q);
+        const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;      // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+        const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;      // chain.rs:1075
+        if (ok_r && ok_q) {
+            if (l == 0) {
+                idx[s] = ci | 0x80000000u;
+                const uint32_t slot = pc0[p] + c.chunk;
+                ivl_next[I0 + ci] = chunk_head[slot]; chunk_head[slot] = I0 + ci;
+            }
+            nacc++;
+        }
+        wave_sync_mem();
+    }
+    if (l == 0) n_accepted[p] = nacc;
+}
+
+// ------------------------------------------------------------------------------------------------ per-chunk ANI inputs
+// chain.rs:199-413.  One wave per chunk: walk the chunk's accepted intervals, then count the chunk's query seed
+// positions that fall inside the union of the (padded) intervals and inside the covered range.
+constexpr uint32_t STATS_MAXI = 32;   // intervals of one chunk cached in LDS (more -> slow path re-walks the list)
+
+__global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
+                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_pos,
+                                                          uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint32_t* pair_tqb, uint32_t* pair_acl,
+                                                          uint32_t* pair_nchains) {
+    __shared__ uint32_t lds_lo[4][STATS_MAXI], lds_hi[4][STATS_MAXI];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (slot >= n_slots) return;
+    const uint32_t l = lane_id();
+    const uint32_t head = chunk_head[slot];
+    if (l == 0) chunk_w[slot] = NONE;                                               // NONE = no estimate from this chunk
+    if (head == NONE) return;                                                       // total_anchors == 0 (chain.rs:253)
+    const Chunk ck = chunks[slot];
+    const uint32_t p = chunk_pair[slot];
+    const bool switched = (pairs[p].flags & 4u) != 0;
+    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0;
+    for (uint32_t e = head; e != NONE; e = ivl_next[e]) {                           // wave-uniform walk
+        const Interval iv = ivls[e];
+        total_anchors += iv.na;
+        if (iv.q0 < rq0) rq0 = iv.q0;
+        if (iv.q1 > rq1) rq1 = iv.q1;
+        tbcq += (switched ? iv.r1 - iv.r0 : iv.q1 - iv.q0) + k + 2 * c;             // chain.rs:223-237
+        sum_len += (iv.q1 - iv.q0) + 2 * c + k;                                     // chain.rs:245-249 (overlap is always 0, chain.rs:1091-1093)
+        if (n_int < STATS_MAXI && l == 0) { lds_lo[wv][n_int] = iv.q0 > c ? iv.q0 - c : 0; lds_hi[wv][n_int] = iv.q1 + c; }   // chain.rs:239-242
+        n_int++;
+    }
+    wave_sync_mem();
+    const bool sensitive = c < 200;                                                 // chain.rs:184-190
+    if (l == 0) {
+        if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
+        atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
+    }
+    if (rq1 - rq0 < MIN_LENGTH_COVER) return;                                       // chain.rs:257
+    if (!sensitive && l == 0) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);       // chain.rs:261-264
+    uint32_t in_u = 0, in_range = 0;
+    for (uint32_t s = ck.s_begin + l; s < ck.s_end; s += 64) {
+        const uint32_t pos = ql_pos[s];
+        bool hit = false;
+        if (n_int <= STATS_MAXI) { for (uint32_t i = 0; i < n_int; i++) hit = hit || (pos >= lds_lo[wv][i] && pos <= lds_hi[wv][i]); }
+        else for (uint32_t e = head; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t lo = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos >= lo && pos <= iv.q1 + c); }
+        in_u += hit ? 1u : 0u;                                                      // chain.rs:268-272
+        in_range += (pos >= rq0 && pos <= rq1) ? 1u : 0u;                           // chain.rs:326-332 (spacing estimates are 0)
+    }
+    in_u = wave_sum(in_u); in_range = wave_sum(in_range);
+    if (l == 0) {
+        uint32_t considered = ck.s_end - ck.s_begin;
+        const double inv_k = 1. / (double)k;
+        const double putative = pow((double)total_anchors / (double)in_u, inv_k);   // chain.rs:335-339
+        if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < CHUNK_SIZE * 9 / 10 && (double)considered > 1.05 * (double)in_range)
+            considered = in_range;                                                  // chain.rs:340-351
+        double ml = (double)total_anchors / (double)considered;
+        if (!(ml < 1.)) ml = 1.;                                                    // f64::min(1., x) (x = NaN or >= 1 -> 1)
+        chunk_est[slot] = pow(ml, inv_k); chunk_w[slot] = considered;               // chain.rs:363-396
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-pair result
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct FinalizeArgs {
+    uint32_t n_pairs, c, k;
+    double min_af, both_min_af; int robust, median, learned, compute_ci;
+    const GbdtModel::Node* nodes; const uint32_t* tree_off; uint32_t n_trees; float shrinkage, bias;
+};
+struct FinalizeScratch { double *u_est, *s_est; uint32_t *u_w, *s_w; uint64_t* cum; };
+
+// fastrand 1.9.0 WyRand stream seeded with 7 (chain.rs:62); draw number d (0-based) is a pure function of d
+__device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) {
+    const uint64_t s = 7ull + (d + 1ull) * 0xA0761D6478BD642Full;
+    const uint64_t b = s ^ 0xE7037ED1A0B428DBull;
+    return (s * b) ^ __umul64hi(s, b);
+}
+
+// chain.rs:414-555 + regression.rs:30-64.  One wave per pair.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
+                                                       const double* chunk_est, const uint32_t* chunk_w, const uint32_t* pair_tqb, const uint32_t* pair_acl,
+                                                       const uint32_t* pair_nchains, FinalizeScratch fs, uint32_t* n_est_out, skh_ani_result* out) {
+    __shared__ double lds_boot[4][128];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (p >= fa.n_pairs) return;
+    const uint32_t l = lane_id();
+    const PairDesc pd = pairs[p];
+    const uint32_t C0 = pc0[p], nc = n_chunks[p];
+    double* U = fs.u_est + C0; uint32_t* UW = fs.u_w + C0; double* S = fs.s_est + C0; uint32_t* SW = fs.s_w + C0; uint64_t* CUM = fs.cum + C0;
+    // 1. valid (estimate, weight) pairs in chunk order
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < nc; b += 64) {
+        const uint32_t s = C0 + b + l;
+        const bool v = b + l < nc && chunk_w[s] != NONE;
+        const unsigned long long m = __ballot(v);
+        if (v) { const uint32_t o = n + (uint32_t)__popcll(m & ((1ull << l) - 1ull)); U[o] = chunk_est[s]; UW[o] = chunk_w[s]; }
+        n += (uint32_t)__popcll(m);
+    }
+    if (l == 0) n_est_out[p] = n;
+    skh_ani_result res;
+    memset(&res, 0, sizeof res);
+    const uint32_t nchains = pair_nchains[p];
+    if (n == 0 || nchains == 0) {                                                   // chain.rs:416-420: AniEstResult::default() with ani = NaN
+        res.ani = __builtin_nanf("");
+        if (l == 0) out[p] = res;
+        return;
+    }
+    wave_sync_mem();
+    // 2. ascending sort by (estimate, weight) by rank counting (chain.rs:414)
+    for (uint32_t i = l; i < n; i += 64) {
+        const double e = U[i]; const uint32_t w = UW[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) { const double ej = U[j]; const uint32_t wj = UW[j]; rank += (ej < e || (ej == e && (wj < w || (wj == w && j < i)))) ? 1u : 0u; }
+        S[rank] = e; SW[rank] = w;
+    }
+    wave_sync_mem();
+    // 3. inclusive cumulative weights
+    uint64_t carry = 0;
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t i = b + l;
+        uint64_t v = i < n ? SW[i] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v += t; }
+        if (i < n) CUM[i] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+    const uint64_t total_mult = carry;
+    wave_sync_mem();
+    // 4. quantile window (chain.rs:426-460)
+    double lower = 0., upper = 1.;
+    if (fa.median) { lower = 0.499; upper = 0.501; } else if (fa.robust) { lower = 0.10; upper = 0.90; }
+    const uint64_t thr_lo = (uint64_t)((double)total_mult * lower), thr_hi = (uint64_t)((double)total_mult * upper);
+    uint32_t lower_i = n, upper_i = n;   // first indices reaching the thresholds
+    for (uint32_t b = 0; b < n && (lower_i == n || upper_i == n); b += 64) {
+        const uint32_t i = b + l;
+        const uint64_t cv = i < n ? CUM[i] : 0;
+        const unsigned long long mlo = __ballot(i < n && cv >= thr_lo), mhi = __ballot(i < n && cv >= thr_hi);
+        if (lower_i == n && mlo) lower_i = b + (uint32_t)__ffsll((long long)mlo) - 1u;
+        if (upper_i == n && mhi) upper_i = b + (uint32_t)__ffsll((long long)mhi) - 1u;
+    }
+    if (lower_i == n) lower_i = 0;
+    upper_i = upper_i == n ? n - 1 : upper_i + 1;                                   // chain.rs:444,455-458
+    // 5. weighted mean over [lower_i, upper_i) and population std of all estimates (chain.rs:462-471, 39-55)
+    double wsum = 0., esum = 0.; uint64_t tm = 0;
+    for (uint32_t i = l; i < n; i += 64) {
+        const double e = S[i]; esum += e;
+        if (i >= lower_i && i < upper_i) { wsum += e * (double)SW[i]; tm += SW[i]; }
+    }
+    wsum = wave_sum_f64(wsum); esum = wave_sum_f64(esum); tm = wave_sum_u64(tm);
+    double final_ani = wsum / (double)tm;
+    const double mean = esum / (double)n;
+    double var = 0.;
+    for (uint32_t i = l; i < n; i += 64) { const double d = mean - S[i]; var += d * d; }
+    var = wave_sum_f64(var);
+    const double sd = sqrt(var / (double)n);
+    // 6. percentile bootstrap (chain.rs:57-86): 100 resamples of n draws from the multiplicity-expanded list
+    double ci_lo = 0., ci_hi = 1.;
+    if (fa.compute_ci && n >= 10) {
+        for (uint32_t it = 0; it < 100; it++) {
+            double s = 0.;
+            for (uint32_t j = l; j < n; j += 64) {
+                const uint64_t r = wyrand_draw((uint64_t)it * n + j);
+                const uint64_t x = __umul64hi(r, total_mult);                       // Lemire reduction; its rejection branch has probability total/2^64
+                uint32_t lo = 0, hi = n - 1;                                        // first i with CUM[i] > x
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (CUM[mid] > x) hi = mid; else lo = mid + 1; }
+                s += S[lo];
+            }
+            s = wave_sum_f64(s);
+            if (l == 0) lds_boot[wv][it] = s / (double)n;
+        }
+        wave_sync_mem();
+        for (uint32_t i = l; i < 100; i += 64) {
+            const double e = lds_boot[wv][i]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < 100; j++) { const double ej = lds_boot[wv][j]; rank += (ej < e || (ej == e && j < i)) ? 1u : 0u; }
+            if (rank == 4) lds_boot[wv][100] = e;
+            if (rank == 94) lds_boot[wv][101] = e;
+        }
+        wave_sync_mem();
+        ci_lo = lds_boot[wv][100]; ci_hi = lds_boot[wv][101];
+    }
+    if (l != 0) return;
+    // 7. aligned fractions, cut-offs, output record (chain.rs:477-554)
+    const uint32_t tqb = pair_tqb[p];
+    double cov_q = (double)tqb / (double)pd.query_total_len; if (!(cov_q < 1.)) cov_q = 1.;
+    double cov_r = (double)tqb / (double)pd.ref_total_len; if (!(cov_r < 1.)) cov_r = 1.;   // total_ref_range has the same numerator (chain.rs:245-246)
+    const double cutoff = fa.min_af < 0. ? 0.15 : fa.min_af;                        // chain.rs:100-107
+    if (fa.both_min_af > 0.0) { if (cov_q < fa.both_min_af || cov_r < fa.both_min_af) final_ani = -1.; }
+    else if (cov_q < cutoff && cov_r < cutoff) final_ani = -1.;
+    res.ani = (float)final_ani; res.af_query = (float)cov_q; res.af_ref = (float)cov_r;
+    res.ci_lower = (float)ci_lo; res.ci_upper = (float)ci_hi; res.std = (float)sd;
+    res.q90_q = pd.q90_q; res.q90_r = pd.q90_r; res.q50_q = pd.q50_q; res.q50_r = pd.q50_r; res.q10_q = pd.q10_q; res.q10_r = pd.q10_r;
+    res.num_contigs_q = pd.nctg_q; res.num_contigs_r = pd.nctg_r;
+    res.avg_chain_int_len = pair_acl[p] / nchains;                                  // chain.rs:421
+    res.total_bases_covered = tqb;
+    // 8. learned ANI (regression.rs:30-64; gbdt 0.1.1 LAD predict = bias + sum shrinkage * leaf, f32, tree order)
+    if (fa.learned && res.ani > 0.9f && res.total_bases_covered > REGRESS_CUTOFF) {
+        float x[5];
+        x[0] = res.ani * 100.f; x[1] = res.std; x[4] = (float)res.avg_chain_int_len;
+        if (res.q50_r > res.q50_q) { x[2] = res.q90_r; x[3] = res.q90_q; } else { x[2] = res.q90_q; x[3] = res.q90_r; }
+        float pred = fa.bias;
+        for (uint32_t t = 0; t < fa.n_trees; t++) {
+            const GbdtModel::Node* nd = fa.nodes + fa.tree_off[t]; int32_t i = 0;
+            while (nd[i].feat >= 0) i = x[nd[i].feat] < nd[i].thr ? nd[i].left : nd[i].right;
+            pred += fa.shrinkage * nd[i].pred;
+        }
+        if (pred < 100.f) {
+            res.ci_upper = (res.ci_upper - res.ani) + pred / 100.f;
+            res.ci_lower = (res.ci_lower - res.ani) + pred / 100.f;
+            res.ani = pred / 100.f;
+        }
+    }
+    out[p] = res;
+}
+
+// ------------------------------------------------------------------------------------------------ host driver
+namespace {
+
+// chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
+bool is_switched(const skh_sketch_set* R, uint32_t r, const skh_sketch_set* Q, uint32_t q) {
+    double q_proxy, r_proxy;
+    if (Q->total_len[q] > 100000 && R->total_len[r] > 100000) {
+        q_proxy = (double)(Q->mk_off[q + 1] - Q->mk_off[q]) * (double)Q->params.c;
+        r_proxy = (double)(R->mk_off[r + 1] - R->mk_off[r]) * (double)R->params.c;
+    } else { q_proxy = (double)Q->total_len[q]; r_proxy = (double)R->total_len[r]; }
+    const double sq = q_proxy * std::min(Q->mean_ctg[q], 300000.), sr = r_proxy * std::min(R->mean_ctg[r], 300000.);
+    if (sq == sr) return Q->rank[q] > R->rank[r];                                   // query_file_name > ref_file_name
+    return sq > sr;
+}
+
+uint64_t fnv_anchors(const std::vector<uint32_t>& q, const std::vector<uint32_t>& r, const std::vector<uint32_t>& cr, const std::vector<uint32_t>& qc,
+                     size_t a0, size_t a1) {   // same checksum as the oracle's ora_chain_stats.anchor_checksum
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t x) { h ^= x; h *= 1099511628211ull; };
+    for (size_t i = a0; i < a1; i++) { mix(qc[i]); mix(q[i]); mix(cr[i] >> 1); mix(r[i]); mix(cr[i] & 1u); }
+    return h;
+}
+
+template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
+    T* d = ctx->arena.get<T>(v.size() ? v.size() : 1);
+    h2d(d, v.data(), v.size() * sizeof(T), ctx->stream);
+    return d;
+}
+
+}  // namespace
+
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q, const uint32_t* pair_ref, const uint32_t* pair_query,
+                 uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats) {
+    if (n_pairs_all == 0) return;
+    if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
+    if (R->params.c != Q->params.c || R->params.k != Q->params.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    const uint32_t c = R->params.c, k = R->params.k;
+    const uint32_t band = BP_CHAIN_BAND / c;                                        // chain.rs:111-112 index_chain_band (ref sketch's c)
+    if (band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
+    const GbdtModel* model = nullptr;
+    if (mp.learned_ani) {
+        model = std::abs((int)c - 125) < std::abs((int)c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22
+        if (!model->loaded()) throw std::invalid_argument("learned_ani requested but skh_load_models was not called");
+    }
+    const uint32_t NP = (uint32_t)n_pairs_all;
+    // ---- pair descriptors and join tiles
+    std::vector<PairDesc> pds(NP); std::vector<uint32_t> tile_pair;
+    std::vector<uint32_t> chunk_bound(NP);
+    for (uint32_t p = 0; p < NP; p++) {
+        const uint32_t r = pair_ref[p], q = pair_query[p];
+        if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
+        PairDesc& pd = pds[p];
+        const bool empty = R->ctg_off[r + 1] == R->ctg_off[r] || Q->ctg_off[q + 1] == Q->ctg_off[q];   // chain.rs:618-620
+        const bool sw = is_switched(R, r, Q, q);
+        const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
+        const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
+        pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
+        pd.b_pos0 = B->pos_off[gb]; pd.b_dist0 = B->dist_off[gb]; pd.b_tab0 = B->tab_off[gb]; pd.b_mask = B->tab_mask[gb];
+        pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
+        pd.tile0 = (uint32_t)tile_pair.size();
+        pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
+        pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
+        pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
+        for (uint32_t t = 0; t * JOIN_TILE < pd.a_n; t++) tile_pair.push_back(p);
+        // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
+        chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
+    }
+    const SetView v0 = view_of(R), v1 = view_of(Q);
+    const uint32_t NT = (uint32_t)tile_pair.size();
+    PairDesc* d_pairs_all = upload(ctx, pds);
+    uint32_t* d_tile_pair = upload(ctx, tile_pair);
+    uint32_t* tile_anch = ctx->arena.get<uint32_t>(NT + 1); uint32_t* tile_inq = ctx->arena.get<uint32_t>(NT + 1);
+    uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
+    dzero(d_pair_anch, NP * 4, ctx->stream); dzero(d_pair_inq, NP * 4, ctx->stream);
+    if (NT) {
+        SKH_LAUNCH(join_count_kernel, NT, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq,
+                   d_pair_anch, d_pair_inq);
+        check_launch("join_count");
+    }
+    std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
+    d2h(pair_anch.data(), d_pair_anch, NP * 4, ctx->stream); d2h(pair_inq.data(), d_pair_inq, NP * 4, ctx->stream);
+    skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
+    uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
+
+    // ---- batches bounded by scratch (anchors dominate: ~44 B per anchor)
+    const uint64_t ANCH_BUDGET = (uint64_t)96 << 20;     // anchors per batch
+    auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
+    uint32_t p0 = 0;
+    while (p0 < NP) {
+        uint64_t na = 0; uint32_t p1 = p0;
+        while (p1 < NP && (p1 == p0 || na + pair_anch[p1] <= ANCH_BUDGET) && p1 - p0 < (1u << 20)) { na += pair_anch[p1]; p1++; }
+        const uint32_t np = p1 - p0;
+        const std::vector<size_t> arena_mark = ctx->arena.mark();
+        if (na >= 0xFFFFFFF0ull) throw Error("a single genome pair produces more than 2^32 anchors");
+        // per-pair prefix arrays (batch-relative)
+        std::vector<uint32_t> pa0(np + 1, 0), pq0(np + 1, 0), pc0(np + 1, 0), pi0(np + 1, 0), ps0(np + 1, 0);
+        for (uint32_t i = 0; i < np; i++) {
+            pa0[i + 1] = pa0[i] + pair_anch[p0 + i]; pq0[i + 1] = pq0[i] + pair_inq[p0 + i];
+            pc0[i + 1] = pc0[i] + (pair_anch[p0 + i] ? std::min(chunk_bound[p0 + i], pair_anch[p0 + i]) : 0);
+            const uint32_t icap = pair_anch[p0 + i] / MIN_ANCHORS;
+            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
+        }
+        const uint32_t NA = pa0[np], NQ = pq0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
+        const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
+        const PairDesc* d_pairs = d_pairs_all + p0;
+        // rebase tile0 for the batch: kernels index tiles globally, pairs batch-relatively -> tile_pair - p0 handled via pointer math below
+        uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pq0 = upload(ctx, pq0); uint32_t* d_pc0 = upload(ctx, pc0);
+        uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
+        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
+        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); exclusive_scan_u32(ctx, tile_inq + t0, nt, toff_q);
+        uint32_t* a_q = ctx->arena.get<uint32_t>(NA + 64); uint32_t* a_r = ctx->arena.get<uint32_t>(NA + 64);
+        uint32_t* a_cr = ctx->arena.get<uint32_t>(NA + 64); uint32_t* a_qc = ctx->arena.get<uint32_t>(NA + 64);
+        uint32_t* ql_pos = ctx->arena.get<uint32_t>(NQ + 64); uint32_t* ql_ctg = ctx->arena.get<uint32_t>(NQ + 64);
+        if (nt) {
+            SKH_LAUNCH(join_fill_kernel, nt, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_tile_pair, t0, band,
+                       (const uint32_t*)toff_a, (const uint32_t*)toff_q, a_q, a_r, a_cr, a_qc, ql_pos, ql_ctg);
+            check_launch("join_fill");
+        }
+        Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
+        uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0, (const uint32_t*)d_pc0,
+                   (const uint32_t*)a_q, (const uint32_t*)a_qc, (const uint32_t*)ql_pos, (const uint32_t*)ql_ctg, chunks, chunk_pair, n_chunks, d_err);
+        check_launch("chunk");
+        int32_t* o_score = ctx->arena.get<int32_t>(NA + 64); uint32_t* o_root = ctx->arena.get<uint32_t>(NA + 64);
+        uint32_t* o_depth = ctx->arena.get<uint32_t>(NA + 64); uint32_t* o_chunk = ctx->arena.get<uint32_t>(NA + 64);
+        unsigned long long* best = ctx->arena.get<unsigned long long>(NA + 64);
+        dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
+        if (NC) {
+            const unsigned gb = (NC + 3) / 4;
+#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)a_q, (const uint32_t*)a_r, \
+                              (const uint32_t*)a_cr, o_score, o_root, o_depth, o_chunk, best)
+            if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
+#undef SKH_DP
+            check_launch("chain_dp");
+        }
+        Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
+        uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
+        uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
+        dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
+        if (NA) {
+            SKH_LAUNCH(interval_emit_kernel, (NA + 255) / 256, 256, 0, ctx->stream, NA, (const uint32_t*)a_q, (const uint32_t*)a_r, (const uint32_t*)a_cr,
+                       (const uint32_t*)a_qc, (const uint32_t*)o_root, (const uint32_t*)o_depth, (const uint32_t*)o_chunk, (const unsigned long long*)best,
+                       (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
+            check_launch("interval_emit");
+        }
+        SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
+                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
+        check_launch("greedy");
+        double* chunk_est = ctx->arena.get<double>(NC + 1); uint32_t* chunk_w = ctx->arena.get<uint32_t>(NC + 1);
+        uint32_t* pair_tqb = ctx->arena.get<uint32_t>(np); uint32_t* pair_acl = ctx->arena.get<uint32_t>(np); uint32_t* pair_nch = ctx->arena.get<uint32_t>(np);
+        dzero(pair_tqb, np * 4, ctx->stream); dzero(pair_acl, np * 4, ctx->stream); dzero(pair_nch, np * 4, ctx->stream);
+        if (NC) {
+            SKH_LAUNCH(chunk_stats_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
+                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_pos, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
+            check_launch("chunk_stats");
+        }
+        FinalizeArgs fa{};
+        fa.n_pairs = np; fa.c = c; fa.k = k; fa.min_af = mp.min_af; fa.both_min_af = mp.both_min_af; fa.robust = mp.robust; fa.median = mp.median;
+        fa.learned = model ? 1 : 0; fa.compute_ci = mp.compute_ci;
+        if (model) { fa.nodes = model->nodes.p; fa.tree_off = model->off.p; fa.n_trees = model->n_trees; fa.shrinkage = model->shrinkage; fa.bias = model->bias; }
+        FinalizeScratch fs{ctx->arena.get<double>(NC + 1), ctx->arena.get<double>(NC + 1), ctx->arena.get<uint32_t>(NC + 1), ctx->arena.get<uint32_t>(NC + 1),
+                           ctx->arena.get<uint64_t>(NC + 1)};
+        uint32_t* n_est = ctx->arena.get<uint32_t>(np);
+        SKH_LAUNCH(finalize_kernel, (np + 3) / 4, 256, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, (const double*)chunk_est,
+                   (const uint32_t*)chunk_w, (const uint32_t*)pair_tqb, (const uint32_t*)pair_acl, (const uint32_t*)pair_nch, fs, n_est, d_out + p0);
+        check_launch("finalize");
+        if (stats) {   // parity/debug path: pull the stage sizes (and the anchors, for the checksum) back to the host
+            std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
+            d2h(h_nc.data(), n_chunks, np * 4, ctx->stream); d2h(h_ni.data(), ivl_cnt, np * 4, ctx->stream);
+            d2h(h_nacc.data(), n_acc, np * 4, ctx->stream); d2h(h_ne.data(), n_est, np * 4, ctx->stream);
+            std::vector<uint32_t> hq(NA), hr(NA), hcr(NA), hqc(NA);
+            d2h(hq.data(), a_q, (uint64_t)NA * 4, ctx->stream); d2h(hr.data(), a_r, (uint64_t)NA * 4, ctx->stream);
+            d2h(hcr.data(), a_cr, (uint64_t)NA * 4, ctx->stream); d2h(hqc.data(), a_qc, (uint64_t)NA * 4, ctx->stream);
+            for (uint32_t i = 0; i < np; i++) {
+                skh_chain_stats& st = stats[p0 + i];
+                st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
+                st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
+                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hq, hr, hcr, hqc, pa0[i], pa0[i + 1]) : 0;
+                if (pair_anch[p0 + i] == 0) st.switched = 1;   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
+            }
+        }
+        dsync(ctx->stream);
+        ctx->arena.rewind(arena_mark);
+        p0 = p1;
+    }
+    uint32_t h_err = 0;
+    d2h(&h_err, d_err, 4, ctx->stream);
+    d2h(out, d_out, (uint64_t)NP * sizeof(skh_ani_result), ctx->stream);
+    if (h_err) throw Error("internal capacity bound violated in chain pipeline (" + std::to_string(h_err) + " events)");
+}
+
+}  // namespace skh

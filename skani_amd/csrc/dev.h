@@ -90,6 +90,16 @@ __device__ __forceinline__ int wave_first(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
+// Point where lanes of ONE wave exchange data through LDS/global memory: orders the memory operations and
+// keeps the compiler from moving accesses across it (the lanes themselves run in lockstep on hardware).
+__device__ __forceinline__ void wave_sync_mem() {
+#ifdef SKANI_EMU
+    emu::wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
     unsigned l = lane_id();

@@ -25,6 +25,10 @@ struct Arena {
         return c.p;
     }
     template <class T> T* get(size_t n) { return (T*)take(n * sizeof(T)); }
+    std::vector<size_t> mark() const { std::vector<size_t> m; for (auto& c : chunks) m.push_back(c.off); return m; }
+    void rewind(const std::vector<size_t>& m) {   // callers sync the stream first
+        for (size_t i = 0; i < chunks.size(); i++) chunks[i].off = i < m.size() ? m[i] : 0;
+    }
     void reset() {  // keep the largest chunk, free the rest (callers sync the stream first)
         if (chunks.size() > 1) {
             size_t tot = 0; for (auto& c : chunks) { tot += c.cap; dfree(c.p); }

@@ -1,4 +1,171 @@
+// screen.hip -- marker k-mer screen as a batched set-intersection prefilter.
+//
+// Replaces screen.rs:190-210 (kmer_to_sketch_from_refs, the marker -> genome-ids inverted index), :148-189
+// (screen_refs), :39-77 (screen_refs_indices) and :84-142 (check_markers_quickly).
+// GPU formulation: all (marker, genome) incidences are radix-sorted by marker (the inverted index becomes runs of
+// equal markers); every incidence adds 1 to count[row][col] for each co-occurring genome on the other side; a
+// second pass applies the reference's exact cut-off rule per cell and compacts the passing pairs in
+// (row, col) order.  Counts are exact integers, so the pass set is identical to the reference's.
+#include <algorithm>
+
 #include "internal.h"
+
 namespace skh {
-void screen_pairs(skh_ctx*, const skh_sketch_set*, const skh_sketch_set*, double, int, int, std::vector<uint32_t>&, std::vector<uint32_t>&) { throw Error("screen not built yet"); }
+
+constexpr int ID_BITS = 21;                       // genome id field inside the sort key (marker is 42 bits)
+constexpr uint64_t ID_MASK = (1ull << ID_BITS) - 1;
+
+__device__ __forceinline__ uint32_t seg_of64(const uint64_t* off, uint32_t n_seg, uint64_t i) {
+    uint32_t lo = 0, hi = n_seg;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
 }
+
+// key = marker << 22 | is_query << 21 | genome
+__global__ __launch_bounds__(256) void screen_keys_kernel(const uint64_t* markers, const uint64_t* mk_off, uint32_t ng, uint64_t n,
+                                                          uint32_t is_query, uint64_t* keys) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (markers[i] << (ID_BITS + 1)) | ((uint64_t)is_query << ID_BITS) | seg_of64(mk_off, ng, i);
+}
+
+// triangle: incidence (m, a) pairs with every later incidence (m, b), b > a  ->  count[a - row0][b]
+__global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
+                                                               uint32_t* cnt) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t key = keys[e], marker = key >> (ID_BITS + 1);
+    const uint32_t a = (uint32_t)(key & ID_MASK);
+    if (a < row0 || a >= row0 + rows) return;
+    uint32_t* row = cnt + (uint64_t)(a - row0) * ncols;
+    for (uint64_t f = e + 1; f < n; f++) {
+        const uint64_t k2 = keys[f];
+        if ((k2 >> (ID_BITS + 1)) != marker) break;
+        atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+    }
+}
+
+// two sets: a query incidence (m, q) pairs with every ref incidence (m, r); refs sort before queries within a marker
+__global__ __launch_bounds__(256) void screen_count_qr_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
+                                                              uint32_t* cnt) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t key = keys[e];
+    if (!((key >> ID_BITS) & 1ull)) return;
+    const uint64_t marker = key >> (ID_BITS + 1);
+    const uint32_t q = (uint32_t)(key & ID_MASK);
+    if (q < row0 || q >= row0 + rows) return;
+    uint32_t* row = cnt + (uint64_t)(q - row0) * ncols;
+    for (uint64_t f = e; f-- > 0;) {
+        const uint64_t k2 = keys[f];
+        if ((k2 >> (ID_BITS + 1)) != marker) break;
+        if (!((k2 >> ID_BITS) & 1ull)) atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+    }
+}
+
+struct ScreenRule { double cutoff; int rule; int rescue_small; int triangle; };
+
+__device__ __forceinline__ bool cell_passes(const ScreenRule& sr, uint32_t count, uint64_t m_row, uint64_t m_col, uint32_t row, uint32_t col) {
+    if (sr.triangle && col <= row) return false;                                 // triangle.rs:90
+    const uint64_t mn = m_row < m_col ? m_row : m_col;
+    if (sr.rule == SKH_SCREEN_QUICK) {                                           // screen.rs:84-142
+        if (mn < SCREEN_MIN_KMERS && sr.rescue_small) return true;
+        if (mn == 0) return sr.rescue_small != 0;
+        uint64_t ratio = (uint64_t)(sr.cutoff * (double)mn);
+        if (ratio == 0) ratio = 1;
+        return (uint64_t)count >= ratio;
+    }
+    if (sr.rule == SKH_SCREEN_REFS && m_row < SCREEN_MIN_KMERS && sr.rescue_small) return true;   // screen.rs:158-160
+    if (count == 0) return false;                                                // only refs present in the count map can pass
+    uint64_t thr = (uint64_t)(sr.cutoff * (double)mn);                           // screen.rs:176-187 / :64-75
+    if (thr < 1) thr = 1;
+    return (uint64_t)count > thr;
+}
+
+// one workgroup per row: pass 0 counts passing cells, pass 1 writes them in column order
+__global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* cnt, uint32_t row0, uint32_t ncols, ScreenRule sr,
+                                                               const uint64_t* mk_off_rows, const uint64_t* mk_off_cols, int pass,
+                                                               uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t running;
+    const uint32_t r = blockIdx.x, row = row0 + r;
+    const uint64_t m_row = mk_off_rows[row + 1] - mk_off_rows[row];
+    const uint32_t* crow = cnt + (uint64_t)r * ncols;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const uint32_t base_out = pass ? row_off[r] : 0;
+    for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
+        const uint32_t col = c0 + threadIdx.x;
+        bool ok = false;
+        if (col < ncols) ok = cell_passes(sr, crow[col], m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
+        // workgroup exclusive scan of the flags
+        uint32_t incl = wave_incl_scan(ok ? 1u : 0u);
+        const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 63) lds[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { uint32_t t = lds[i]; if (i < w) before += t; tot += t; }
+        const uint32_t run = running;
+        if (pass && ok) { const uint32_t o = base_out + run + before + incl - 1; out_first[o] = row; out_second[o] = col; }
+        __syncthreads();
+        if (threadIdx.x == 0) running = run + tot;
+        __syncthreads();
+    }
+    if (!pass && threadIdx.x == 0) row_cnt[r] = running;
+}
+
+static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __powidf2: square-and-multiply from the low bit
+    int b = (int)K_MARKER; double r = 1;
+    while (true) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
+    return r;
+}
+
+void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
+                  std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
+    first.clear(); second.clear();
+    if (identity == 0.) identity = 0.80;                                          // triangle.rs:34-42, SEARCH_ANI_CUTOFF_DEFAULT
+    const bool tri = queries == nullptr;
+    const skh_sketch_set* rowset = tri ? refs : queries;
+    const uint32_t nrows = rowset->n_genomes, ncols = refs->n_genomes;
+    if (nrows == 0 || ncols == 0) return;
+    if (ncols > ID_MASK || nrows > ID_MASK) throw Error("more than 2M genomes in one screen call");
+    const uint64_t MR = refs->mk_off[ncols], MQ = tri ? 0 : queries->mk_off[nrows], M = MR + MQ;
+    uint64_t* keys = ctx->arena.get<uint64_t>(M ? M : 1);
+    if (MR) { SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)refs->markers.p,
+                         (const uint64_t*)refs->d_mk_off.p, ncols, MR, 0u, keys); check_launch("screen_keys"); }
+    if (MQ) { SKH_LAUNCH(screen_keys_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)queries->markers.p,
+                         (const uint64_t*)queries->d_mk_off.p, nrows, MQ, 1u, keys + MR); check_launch("screen_keys"); }
+    sort_keys_u64(ctx, keys, M, 64);
+    ScreenRule sr{powi21(identity), rule, rescue_small, tri ? 1 : 0};
+    // row blocking keeps the dense count matrix within a fixed budget
+    const uint64_t budget_cells = (uint64_t)2 << 30;     // 8 GiB of u32 counters
+    uint32_t rows_per = (uint32_t)std::min<uint64_t>(nrows, std::max<uint64_t>(1, budget_cells / ncols));
+    uint32_t* cnt = ctx->arena.get<uint32_t>((uint64_t)rows_per * ncols);
+    uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
+    for (uint32_t row0 = 0; row0 < nrows; row0 += rows_per) {
+        const uint32_t rows = std::min(rows_per, nrows - row0);
+        dzero(cnt, (uint64_t)rows * ncols * 4, ctx->stream);
+        if (M) {
+            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((M + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)keys, M, row0, rows, ncols, cnt);
+            else SKH_LAUNCH(screen_count_qr_kernel, (unsigned)((M + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)keys, M, row0, rows, ncols, cnt);
+            check_launch("screen_count");
+        }
+        SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
+                   (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        check_launch("screen_threshold0");
+        exclusive_scan_u32(ctx, row_cnt, rows, row_off);
+        uint32_t total = 0;
+        d2h(&total, row_off + rows, 4, ctx->stream);
+        if (total) {
+            uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total);
+            SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
+                       (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os);
+            check_launch("screen_threshold1");
+            size_t old = first.size(); first.resize(old + total); second.resize(old + total);
+            d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
+        }
+    }
+    dsync(ctx->stream);
+}
+
+}  // namespace skh
