@@ -9,8 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libskani_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fgpu-rdc-not-needed"]
-FLAGS = [f for f in FLAGS if f != "-fgpu-rdc-not-needed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-ffp-contract=off"]
 
 
 def _deps():

@@ -1,0 +1,227 @@
+"""Parity cases shared by the GPU tests (tests/test_gpu_parity.py, through libskani_hip.so on an MI355X) and by the
+kernel-simulator tests (tests/test_emu_pipeline.py, same kernel sources under tests/emu on the CPU).
+Every case compares the C-ABI path with the CPU oracle on identical inputs.  Integer outputs must be bit-exact;
+ANI/AF are compared with the north-star tolerance 1e-4 (they are in fact expected to be identical to f32 rounding)."""
+import numpy as np
+
+import skani_amd as sk
+from tests.helpers import (MODEL_C125, MODEL_C200, golden_records, mutate, o157_arrays, ora, oracle_o157, oracle_sketch_file,
+                           pinned, random_genome)
+
+TOL = 1e-4
+FLOAT_FIELDS = ("ani", "af_query", "af_ref", "ci_lower", "ci_upper", "std")
+EXACT_FIELDS = ("q90_q", "q90_r", "q50_q", "q50_r", "q10_q", "q10_r", "num_contigs_q", "num_contigs_r", "avg_chain_int_len",
+                "total_bases_covered")
+
+
+def assert_sketch_equal(ss, g, osk):
+    e = ss.export(g)
+    s, p, cc = osk.seeds(pos_order=True)
+    assert np.array_equal(e["seed"], s) and np.array_equal(e["pos"], p) and np.array_equal(e["ctgcanon"], cc), "seed records differ"
+    assert np.array_equal(e["markers"], osk.markers()), "marker set differs"
+    assert np.array_equal(e["contig_lengths"], osk.contig_lengths())
+    sz = ss.sizes(g)
+    assert (sz["n_pos"], sz["n_distinct"], sz["n_markers"], sz["total_len"]) == (osk.n_positions, osk.n_distinct, osk.n_markers, osk.total_len)
+
+
+def assert_result_close(got, want, ctx=""):
+    """got: numpy record (skh_ani_result); want: oracle AniResult or numpy record."""
+    for f in FLOAT_FIELDS:
+        a = float(got[f]); b = float(want[f]) if isinstance(want, np.void) else float(getattr(want, f))
+        if np.isnan(b):
+            assert np.isnan(a), (ctx, f, a, b)
+        else:
+            assert abs(a - b) <= TOL, (ctx, f, a, b)
+    for f in EXACT_FIELDS:
+        a = got[f]; b = want[f] if isinstance(want, np.void) else getattr(want, f)
+        assert a == b, (ctx, f, a, b)
+
+
+def import_o157(ctx, params=None):
+    z = o157_arrays()
+    return ctx.import_sketches(params or sk.SketchParams(), [dict(seed=z["seed"], pos=z["pos"], ctgcanon=z["ctgcanon"], markers=z["markers"],
+                                                                  contig_lengths=z["contig_lengths"], total_len=int(z["total_len"]))],
+                               names=[str(z["file_name"])], genome_rank=[1000])
+
+
+# ---------------------------------------------------------------------------------------------------- seeding
+def case_seeding_golden_plasmid(ctx):
+    """759 seed records + 81 markers of the reference's golden sketch (both seeding semantics agree here)."""
+    z = o157_arrays(); sel = (z["ctgcanon"] >> 1) == 1
+    o = np.lexsort((z["pos"][sel],))
+    for mode in (sk.SEED_SCALAR, sk.SEED_AVX2):
+        ss = ctx.sketch_records([golden_records("o157_plasmid.fasta")], sk.SketchParams(seeding_mode=mode), ["p"])
+        e = ss.export(0)
+        assert np.array_equal(e["seed"], z["seed"][sel][o]) and np.array_equal(e["pos"], z["pos"][sel][o])
+        assert np.array_equal(e["ctgcanon"] & 1, z["ctgcanon"][sel][o] & 1)
+        assert len(e["markers"]) == 81 and np.isin(e["markers"], z["markers"]).all()
+
+
+def case_seeding_fixtures(ctx):
+    """viruses.fna ((L-20)%4 != 0: AVX2 tail rule), all-N, tiny/short contigs, N and n runs, k=16, c=30/m=200."""
+    V = golden_records("viruses.fna"); P = golden_records("o157_plasmid.fasta"); N = golden_records("all_ns.fa")
+    mixed = [("a", random_genome(30011, 1, 0.001)), ("short", random_genome(777, 2)), ("c", random_genome(50003, 3, 0.01)),
+             ("tiny", random_genome(120, 4))]
+    lower = [("x", random_genome(20000, 5, 0.002).replace(b"N", b"n", 10))]
+    for mode in (sk.SEED_SCALAR, sk.SEED_AVX2):
+        for (c, k, m) in ((125, 15, 1000), (30, 16, 200), (70, 15, 1000), (200, 14, 1000)):
+            genomes = [V, P, mixed, lower, N]
+            ss = ctx.sketch_records(genomes, sk.SketchParams(c, k, m, mode), [str(i) for i in range(len(genomes))])
+            assert len(ss) == len(genomes)
+            for g, recs in enumerate(genomes):
+                assert_sketch_equal(ss, g, ora.sketch_records(recs, c, k, m, str(g), mode))
+    ss = ctx.sketch_records([N], sk.SketchParams(), ["n"])
+    assert ss.sizes(0)["n_pos"] == 0
+
+
+def case_seeding_ecoli_w(ctx):
+    W = golden_records("e.coli-W.fasta.gz")
+    ss = ctx.sketch_records([W], sk.SketchParams(), ["w"])
+    osk = ora.sketch_records(W, mode=1)
+    assert_sketch_equal(ss, 0, osk)
+    sz = ss.sizes(0)
+    assert (sz["n_pos"], sz["n_distinct"], sz["n_markers"]) == (39310, 37786, 4649)
+
+
+def case_seeding_low_complexity(ctx):
+    """A period-2/3/7 repeat makes every window of a region hit => exercises worst-case tile capacity and table multiplicities."""
+    rng = np.random.default_rng(5)
+    found = None
+    thr = (2**64 - 1) // 30
+    for _ in range(4000):
+        unit = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 7))
+        rep = unit * 40
+        sk_o = ora.Sketch(30, 15, 1000, ""); sk_o.add_contig(rep, 0, 0)
+        if sk_o.n_positions > 30:
+            found = unit; break
+    assert found is not None
+    seq = random_genome(5000, 1) + found * 3000 + random_genome(5000, 2)
+    for mode in (0, 1):
+        ss = ctx.sketch_records([[("lc", seq)]], sk.SketchParams(30, 15, 1000, mode), ["lc"])
+        assert_sketch_equal(ss, 0, ora.sketch_records([("lc", seq)], 30, 15, 1000, "lc", mode))
+        assert ss.sizes(0)["n_pos"] > 2000
+
+
+# ---------------------------------------------------------------------------------------------------- chain
+def case_pinned_triples(ctx):
+    """reference test_results_versions/0.3.0:130-135 (search --median; learned ANI off) through the GPU path."""
+    names = ["test_files/e.coli-W.fasta", "test_files/o157_plasmid.fasta"]
+    refs = ctx.sketch_records([golden_records("e.coli-W.fasta.gz"), golden_records("o157_plasmid.fasta")], sk.SketchParams(), names)
+    o157 = import_o157(ctx)
+    mp = sk.MapParams(median=True, compute_ci=True)
+    res, st = ctx.chain_pairs(refs, o157, [1, 0], [0, 0], mp, stats=True)
+    self_res = ctx.chain_pairs(o157, None, [0], [0], mp)
+    got = [("%.2f" % (r["ani"] * 100), "%.2f" % (r["af_ref"] * 100), "%.2f" % (r["af_query"] * 100)) for r in list(res) + list(self_res)]
+    want = [("%.2f" % t["ani"], "%.2f" % t["af_ref"], "%.2f" % t["af_query"]) for t in pinned()["triples_median_percent"]]
+    assert got == want, (got, want)
+    assert (int(st[1]["n_anchors"]), int(st[1]["n_chunks"]), int(st[1]["n_intervals"]), int(st[1]["n_accepted"]), int(st[1]["n_estimates"])) == \
+        (31989, 245, 500, 380, 234)
+    # and against the oracle, field by field, incl. the stage checksums
+    ow = oracle_sketch_file("e.coli-W.fasta.gz", file_name=names[0]); op = oracle_sketch_file("o157_plasmid.fasta", file_name=names[1]); oo = oracle_o157()
+    for i, oref in ((0, op), (1, ow)):
+        r, s = ora.chain_seeds(oref, oo, median=True, stats=True)
+        assert_result_close(res[i], r, i)
+        assert (int(st[i]["switched"]), int(st[i]["n_anchors"]), int(st[i]["n_qpos"]), int(st[i]["anchor_checksum"])) == \
+            (s.switched, s.n_anchors, s.n_qpos, s.anchor_checksum)
+
+
+def case_w_vs_w(ctx):
+    """tests/tests.rs:42-60"""
+    W = golden_records("e.coli-W.fasta.gz")
+    ss = ctx.sketch_records([W], sk.SketchParams(), ["w"])
+    r = ctx.chain_pairs(ss, None, [0], [0], sk.MapParams())[0]
+    assert r["ani"] >= 1.0 and r["af_query"] >= 0.99 and r["af_ref"] >= 0.99
+
+
+def case_viruses_individual(ctx):
+    """tests/int_test_new.rs:57-62 (triangle -i): one sketch per contig."""
+    recs = golden_records("viruses.fna")
+    ss = ctx.sketch_records([[r] for r in recs], sk.SketchParams(), ["test_files/viruses.fna"] * len(recs))
+    osk = []
+    for name, seq in recs:
+        s = ora.Sketch(125, 15, 1000, "test_files/viruses.fna"); s.add_contig(seq, 1); osk.append(s)
+    pr = [0, 0, 1]; pq = [1, 2, 2]
+    res = ctx.chain_pairs(ss, None, pr, pq, sk.MapParams(compute_ci=True))
+    anis = []
+    for x, (i, j) in enumerate(zip(pr, pq)):
+        assert_result_close(res[x], ora.chain_seeds(osk[i], osk[j]), (i, j))
+        if res[x]["ani"] > 0.1:
+            anis.append(res[x]["ani"] * 100)
+    assert any(99.0 < a < 99.9 for a in anis) and any(a > 99.9 for a in anis), anis
+
+
+def synthetic_clades(n_clades=2, members=3, length=200000, seed=11, tiny=True):
+    genomes = []
+    for cl in range(n_clades):
+        root = random_genome(length, seed + cl)
+        for m in range(members):
+            s = mutate(root, 0.005 + 0.02 * m, (seed + cl) * 100 + m)
+            cuts = sorted(np.random.default_rng((seed + cl) * 7 + m).integers(1000, length - 1000, m))
+            ctgs, prev = [], 0
+            for c in list(cuts) + [length]:
+                ctgs.append(("c%d" % len(ctgs), s[prev:c])); prev = c
+            genomes.append(ctgs)
+    if tiny:
+        genomes.append([("tiny", random_genome(3000, 99))])
+    return genomes
+
+
+def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200)), length=200000):
+    """triangle.rs:55-105 on synthetic clades: screen pass set, chained pairs, all result fields, learned ANI on/off,
+    robust/median windows."""
+    genomes = synthetic_clades(length=length)
+    names = ["g%02d.fa" % i for i in range(len(genomes))]
+    for mode, c in params:
+        ss = ctx.sketch_records(genomes, sk.SketchParams(c=c, seeding_mode=mode), names)
+        osk = [ora.sketch_records(g, c, 15, 1000, names[i], mode) for i, g in enumerate(genomes)]
+        a, b = ctx.screen(ss, None, 0.0, 0, True)
+        exp = [(i, int(j)) for i in range(len(osk) - 1) for j in ora.screen_refs(osk, osk[i], 0.8, 0, True) if j > i]
+        assert list(zip(a.tolist(), b.tolist())) == sorted(exp)
+        learned = sk.use_learned_ani(c)
+        model = ora.Model(MODEL_C125 if abs(c - 125) < abs(c - 200) else MODEL_C200) if learned else None
+        for kw in (dict(), dict(robust=True), dict(median=True)):
+            use_model = learned and not kw.get("median")
+            mp = sk.MapParams(learned_ani=use_model, compute_ci=True, **kw)
+            i, j, res, nch = ctx.triangle(ss, mp)
+            oi, oj, ores, onch, _ = ora.triangle(osk, model=model if use_model else None, **kw)
+            assert nch == onch and np.array_equal(i, oi) and np.array_equal(j, oj), (mode, c, kw)
+            for x in range(len(res)):
+                assert_result_close(res[x], ores[x], (mode, c, kw, int(i[x]), int(j[x])))
+
+
+def case_screen_rules(ctx):
+    """screen.rs rules 0/1/2, query-vs-ref and triangle forms, rescue_small on/off."""
+    genomes = synthetic_clades(n_clades=2, members=2, length=60000, seed=31) + [[("few", random_genome(9000, 77))]]
+    names = ["s%02d.fa" % i for i in range(len(genomes))]
+    queries = [genomes[0], [("q", mutate(genomes[2][0][1], 0.03, 5))], [("none", random_genome(40000, 1234))]]
+    for m in (1000, 200):
+        sp = sk.SketchParams(marker_c=m)
+        refs = ctx.sketch_records(genomes, sp, names); qs = ctx.sketch_records(queries, sp, ["q0", "q1", "q2"])
+        orefs = [ora.sketch_records(g, 125, 15, m, names[i], 1) for i, g in enumerate(genomes)]
+        oqs = [ora.sketch_records(g, 125, 15, m, "q%d" % i, 1) for i, g in enumerate(queries)]
+        for rescue in (True, False):
+            for rule in (0, 2):
+                a, b = ctx.screen(refs, qs, 0.8, rule, rescue)
+                exp = [(q, int(r)) for q in range(len(oqs)) for r in ora.screen_refs(orefs, oqs[q], 0.8, rule, rescue)]
+                assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, rule)
+            a, b = ctx.screen(refs, qs, 0.8, 1, rescue)
+            exp = [(q, r) for q in range(len(oqs)) for r in range(len(orefs)) if ora.check_markers_quickly(orefs[r], oqs[q], 0.8, rescue)]
+            assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "quick")
+            a, b = ctx.screen(refs, None, 0.8, 0, rescue)
+            exp = [(i, int(j)) for i in range(len(orefs) - 1) for j in ora.screen_refs(orefs, orefs[i], 0.8, 0, rescue) if j > i]
+            assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri")
+
+
+def case_degenerate_pairs(ctx):
+    """empty sketches, unrelated genomes (no anchors -> NaN), both-min-af and min-af cut-offs (-1)."""
+    g = [[("a", random_genome(50000, 1))], [("b", random_genome(50000, 2))], [("n", b"N" * 3000)],
+         [("a2", mutate(random_genome(50000, 1), 0.01, 3)[:20000])]]
+    names = ["d%d" % i for i in range(len(g))]
+    ss = ctx.sketch_records(g, sk.SketchParams(), names)
+    osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]
+    pr = [0, 0, 2, 0, 3]; pq = [1, 2, 2, 3, 0]
+    for kw in (dict(), dict(both_min_af=0.5), dict(min_af=0.9)):
+        res = ctx.chain_pairs(ss, None, pr, pq, sk.MapParams(compute_ci=True, **kw))
+        for x, (i, j) in enumerate(zip(pr, pq)):
+            assert_result_close(res[x], ora.chain_seeds(osk[i], osk[j], **kw), (kw, i, j))
+    assert np.isnan(res[0]["ani"]) and np.isnan(res[1]["ani"])

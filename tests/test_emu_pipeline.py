@@ -1,0 +1,26 @@
+"""Runs the parity cases against the kernel sources compiled for the CPU simulator (tests/emu).  This is a
+debugging aid for a container without a GPU -- NOT a parity claim (those are the -m gpu tests)."""
+import pytest
+
+import skani_amd as sk
+from tests import parity_cases as pc
+from tests.emu_lib import emu_lib
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sk.Context(0, lib=emu_lib())
+    yield c
+    c.close()
+
+
+def test_emu_seeding_golden(ctx): pc.case_seeding_golden_plasmid(ctx)
+def test_emu_seeding_fixtures(ctx): pc.case_seeding_fixtures(ctx)
+def test_emu_seeding_ecoli_w(ctx): pc.case_seeding_ecoli_w(ctx)
+def test_emu_seeding_low_complexity(ctx): pc.case_seeding_low_complexity(ctx)
+def test_emu_pinned_triples(ctx): pc.case_pinned_triples(ctx)
+def test_emu_w_vs_w(ctx): pc.case_w_vs_w(ctx)
+def test_emu_viruses(ctx): pc.case_viruses_individual(ctx)
+def test_emu_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx, params=((1, 125), (0, 30)), length=120000)
+def test_emu_screen_rules(ctx): pc.case_screen_rules(ctx)
+def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)

@@ -1,0 +1,81 @@
+"""GPU parity tests proper: the HIP path (libskani_hip.so through the C ABI) against the CPU oracle and the
+reference's golden vectors, on an MI355X.  `python -m pytest tests -m gpu`."""
+import numpy as np
+import pytest
+
+import skani_amd as sk
+from tests import parity_cases as pc
+from tests.helpers import mutate, ora, random_genome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sk.Context(0)          # raises loudly when libskani_hip.so or the GPU is missing
+    yield c
+    c.close()
+
+
+def test_library_is_the_hip_build(ctx):
+    import os
+    assert os.path.exists(sk.library_path())
+    maps = open("/proc/self/maps").read()
+    assert "libskani_hip.so" in maps and "libskani_emu" not in maps
+
+
+def test_seeding_golden(ctx): pc.case_seeding_golden_plasmid(ctx)
+def test_seeding_fixtures(ctx): pc.case_seeding_fixtures(ctx)
+def test_seeding_ecoli_w(ctx): pc.case_seeding_ecoli_w(ctx)
+def test_seeding_low_complexity(ctx): pc.case_seeding_low_complexity(ctx)
+def test_pinned_triples(ctx): pc.case_pinned_triples(ctx)
+def test_w_vs_w(ctx): pc.case_w_vs_w(ctx)
+def test_viruses(ctx): pc.case_viruses_individual(ctx)
+def test_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx)
+def test_screen_rules(ctx): pc.case_screen_rules(ctx)
+def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
+
+
+def test_w_derivatives_triangle(ctx):
+    """SURVEY 8d config 2 substitute: E. coli W + 5 substitution derivatives (0.5/1/2/4/8 %), 15 pairs, default
+    -c 125 -k 15 -m 1000, learned ANI on; GPU vs oracle on every field."""
+    from tests.helpers import MODEL_C125, golden_records
+    W = golden_records("e.coli-W.fasta.gz")
+    genomes = [W] + [[(W[0][0], mutate(W[0][1], r, 0x5EED0001 + i))] for i, r in enumerate((0.005, 0.01, 0.02, 0.04, 0.08))]
+    names = ["w%d.fa" % i for i in range(len(genomes))]
+    ss = ctx.sketch_records(genomes, sk.SketchParams(), names)
+    osk = [ora.sketch_records(g, file_name=names[i]) for i, g in enumerate(genomes)]
+    for g in range(len(genomes)):
+        pc.assert_sketch_equal(ss, g, osk[g])
+    i, j, res, nch = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+    assert nch == onch == 15 and np.array_equal(i, oi) and np.array_equal(j, oj)
+    for x in range(len(res)):
+        pc.assert_result_close(res[x], ores[x], (int(i[x]), int(j[x])))
+    # size-independent properties: symmetry of roles (chain(a,b) vs chain(b,a) swap the aligned fractions), self = 1
+    fwd = ctx.chain_pairs(ss, None, [0, 1], [3, 4], sk.MapParams())
+    rev = ctx.chain_pairs(ss, None, [3, 4], [0, 1], sk.MapParams())
+    assert np.allclose(fwd["ani"], rev["ani"], atol=2e-3)
+    selfr = ctx.chain_pairs(ss, None, list(range(6)), list(range(6)), sk.MapParams())
+    assert (selfr["ani"] >= 0.9999).all() and (selfr["af_ref"] >= 0.99).all()
+
+
+def test_many_genomes_batching(ctx):
+    """Several hundred small genomes: exercises multi-tile launches, the screen matrix, pair batching and ordering."""
+    rng = np.random.default_rng(3)
+    genomes, names = [], []
+    for cl in range(12):
+        root = random_genome(int(rng.integers(30000, 60000)), 1000 + cl)
+        for m in range(6):
+            genomes.append([("c", mutate(root, float(rng.uniform(0.003, 0.06)), cl * 10 + m))]); names.append("b%03d.fa" % len(names))
+    ss = ctx.sketch_records(genomes, sk.SketchParams(c=30, marker_c=200), names)
+    osk = [ora.sketch_records(g, 30, 15, 200, names[i]) for i, g in enumerate(genomes)]
+    i, j, res, nch = ctx.triangle(ss, sk.MapParams(compute_ci=True))
+    oi, oj, ores, onch, _ = ora.triangle(osk)
+    assert nch == onch and np.array_equal(i, oi) and np.array_equal(j, oj) and len(i) >= 12 * 15
+    for x in range(len(res)):
+        pc.assert_result_close(res[x], ores[x], (int(i[x]), int(j[x])))
+    # sharded triangle (the multi-GPU partition): union of parts == whole
+    parts = [ctx.triangle(ss, sk.MapParams(compute_ci=True), part=r, n_parts=3) for r in range(3)]
+    allp = sorted((int(a), int(b)) for pi, pj, _, _ in parts for a, b in zip(pi, pj))
+    assert allp == sorted(zip(i.tolist(), j.tolist()))
