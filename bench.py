@@ -143,19 +143,11 @@ def main():
     mp = sk.MapParams(learned_ani=sk.use_learned_ani(C), compute_ci=not args.no_ci)
     ctx.timings()
 
-    def exchange(ss_local):
-        """all-gather of the raw sketches (position-ordered seeds + markers + contig tables): the one collective."""
-        if world == 1:
-            return ss_local
-        per = [ss_local.export(g) for g in range(len(ss_local))]
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per)      # round-1 exchange goes through host pickles; see DESIGN.md (e)
-        allg = [d for part in gathered for d in part]
-        return ctx.import_sketches(params, allg, genome_rank=np.arange(len(allg), dtype=np.uint32))
+    from skani_amd.distributed import exchange_sketches
 
     def step():
         ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32))
-        ss = exchange(ss_local)
+        ss = exchange_sketches(ctx, ss_local, params, dist, world)     # the one collective
         i, j, res, n_chained = ctx.triangle(ss, mp, part=rank, n_parts=world)
         return len(i), n_chained
 
