@@ -74,17 +74,27 @@ __device__ __forceinline__ Probe probe_position(const SetView& A, const SetView&
     }
 }
 
-__global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* tile_pair, uint32_t band,
-                                                         uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq) {
+// Workgroups are launched in "slots": slot b runs logical tile slot_tile[b] (or nothing).  The host interleaves the
+// tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
+// table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
+__global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+                                                         uint32_t band, uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq,
+                                                         uint32_t* pinfo_start, uint16_t* pinfo_cnt) {
     __shared__ uint32_t lds[16];
-    const uint32_t tile = blockIdx.x, p = tile_pair[tile];
+    const uint32_t tile = slot_tile[blockIdx.x];
+    if (tile == NONE) return;
+    const uint32_t p = tile_pair[tile];
     const PairDesc pd = pairs[p];
     const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     uint32_t na = 0, nq = 0;
     for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
-        const uint32_t i = start + r * 256 + threadIdx.x;
-        if (i < pd.a_n) { Probe pr = probe_position(A, B, pd, pd.a_pos0 + i, band); na += pr.n_anch; nq += pr.inq; }
+        const uint32_t o = r * 256 + threadIdx.x, i = start + o;
+        if (i < pd.a_n) {
+            Probe pr = probe_position(A, B, pd, pd.a_pos0 + i, band); na += pr.n_anch; nq += pr.inq;
+            pinfo_start[(uint64_t)tile * JOIN_TILE + o] = (uint32_t)(pr.b_start - pd.b_pos0);
+            pinfo_cnt[(uint64_t)tile * JOIN_TILE + o] = (uint16_t)(pr.n_anch | (pr.inq << 15));
+        }
     }
     na = wave_sum(na); nq = wave_sum(nq);
     const uint32_t w = threadIdx.x >> 6;
@@ -99,38 +109,44 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     }
 }
 
-// Emits anchors and the query-position list of one tile at the offsets given by the tile scans.
-__global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* tile_pair, uint32_t tile_base,
-                                                        uint32_t band, const uint32_t* toff_a, const uint32_t* toff_q,
-                                                        uint32_t* a_q, uint32_t* a_r, uint32_t* a_cr, uint32_t* a_qc, uint32_t* ql_pos, uint32_t* ql_ctg) {
+// Emits anchors and the query-position list of one tile at the offsets given by the tile scans, from the per-position
+// probe results recorded by join_count_kernel (no second probe).
+__global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+                                                        uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
+                                                        const uint16_t* pinfo_cnt, uint32_t* a_q, uint32_t* a_r, uint32_t* a_cr, uint32_t* a_qc,
+                                                        uint32_t* ql_pos, uint32_t* ql_ctg) {
     __shared__ uint32_t lds[16];
-    const uint32_t lt = blockIdx.x, tile = tile_base + lt, p = tile_pair[tile];
+    const uint32_t tile = slot_tile[blockIdx.x];
+    if (tile == NONE) return;
+    const uint32_t lt = tile - tile_base, p = tile_pair[tile];
     const PairDesc pd = pairs[p];
     const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     uint32_t run_a = toff_a[lt], run_q = toff_q[lt];
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
-        const uint32_t i = start + r * 256 + threadIdx.x;
-        Probe pr{0, 0, 0};
-        if (i < pd.a_n) pr = probe_position(A, B, pd, pd.a_pos0 + i, band);
-        // workgroup exclusive scans of n_anch and inq (packed: anchors in the low 24 bits is not enough -> two scans)
-        const uint32_t ia = wave_incl_scan(pr.n_anch), iq = wave_incl_scan(pr.inq);
+        const uint32_t o = r * 256 + threadIdx.x, i = start + o;
+        uint32_t n_anch = 0, inq = 0;
+        if (i < pd.a_n) { const uint32_t c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; n_anch = c & 0x7FFFu; inq = c >> 15; }
+        const uint32_t ia = wave_incl_scan(n_anch), iq = wave_incl_scan(inq);
         if (l == 63) { lds[w] = ia; lds[8 + w] = iq; }
         __syncthreads();
         uint32_t ba = 0, bq = 0, ta = 0, tq = 0;
         for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds[k], y = lds[8 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
         __syncthreads();
-        if (pr.inq) {
+        if (inq) {
             const uint64_t ai = pd.a_pos0 + i;
             const uint32_t qpos = A.p_pos[ai], qcc = A.p_cc[ai];
             const uint32_t oq = run_q + bq + iq - 1;
             ql_pos[oq] = qpos; ql_ctg[oq] = qcc >> 1;
-            uint32_t oa = run_a + ba + ia - pr.n_anch;
-            for (uint32_t k = 0; k < pr.n_anch; k++, oa++) {                       // chain.rs:703-711, already in sorted order
-                const uint32_t rcc = B.s_cc[pr.b_start + k];
-                a_q[oa] = qpos; a_qc[oa] = qcc >> 1; a_r[oa] = B.s_pos[pr.b_start + k];
-                a_cr[oa] = (rcc & ~1u) | ((rcc ^ qcc) & 1u);                       // ref_contig << 1 | reverse_match
+            if (n_anch) {
+                const uint64_t bs = pd.b_pos0 + pinfo_start[(uint64_t)tile * JOIN_TILE + o];
+                uint32_t oa = run_a + ba + ia - n_anch;
+                for (uint32_t k = 0; k < n_anch; k++, oa++) {                        // chain.rs:703-711, already in sorted order
+                    const uint32_t rcc = B.s_cc[bs + k];
+                    a_q[oa] = qpos; a_qc[oa] = qcc >> 1; a_r[oa] = B.s_pos[bs + k];
+                    a_cr[oa] = (rcc & ~1u) | ((rcc ^ qcc) & 1u);                     // ref_contig << 1 | reverse_match
+                }
             }
         }
         run_a += ta; run_q += tq;
@@ -198,6 +214,14 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint
     if (l == 0) n_chunks[p] = nc;
 }
 
+// Per-component argmax record kept at the component's ROOT anchor: score (24 bits) | index of the best anchor inside its
+// chunk (20 bits) | number of anchors on the chain ending there (20 bits).  Max over the packed value = max score, ties ->
+// largest index (chain.rs:952-964 with the set iteration order of partitions 0.2.4); 0 = "not a root".
+__device__ __forceinline__ unsigned long long best_payload(uint32_t score, uint32_t local_idx, uint32_t depth) {
+    return ((unsigned long long)score << 40) | ((unsigned long long)(local_idx & 0xFFFFFu) << 20) | (depth > 0xFFFFFu ? 0xFFFFFu : depth);
+}
+constexpr uint32_t MAX_CHUNK_ANCHORS = 1u << 20;
+
 // ------------------------------------------------------------------------------------------------ banded chaining DP
 // chain.rs:838-896 + score_anchors :558-603.  One wave per chunk.  Lanes own anchors base..base+63; sources j are
 // swept in increasing order; a source's score is final when the sweep reaches it, so it is broadcast with v_readlane.
@@ -206,8 +230,7 @@ struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
 
 template <int PB>
 __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* a_q, const uint32_t* a_r,
-                                                       const uint32_t* a_cr, int32_t* o_score, uint32_t* o_root, uint32_t* o_depth, uint32_t* o_chunk,
-                                                       unsigned long long* best) {
+                                                       const uint32_t* a_cr, unsigned long long* best) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
@@ -270,36 +293,86 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
                 }
             }
         }
-        if (valid) {
-            o_score[t] = cur.score; o_root[t] = cur.root; o_depth[t] = cur.depth; o_chunk[t] = slot;
-            atomicMax(&best[cur.root], ((unsigned long long)(uint32_t)cur.score << 32) | t);   // argmax, ties -> largest index (chain.rs:952-964)
-        }
+        if (valid) atomicMax(&best[cur.root], best_payload((uint32_t)cur.score, t - ck.a_begin, cur.depth));   // chain.rs:952-964
 #pragma unroll
         for (int b = PB - 1; b > 0; b--) prev[b] = prev[b - 1];
         prev[0] = cur;
     }
 }
 
+// Thread-per-chunk variant for small bands (c >= 63): a wave chains 64 chunks in lockstep, every lane walks its own chunk
+// sequentially and keeps the last `band` anchors (q, r, contig/strand, score | root, depth) in an LDS ring laid out
+// [slot][lane] so that a wave's accesses are conflict-free.  All 64 lanes evaluate links (the sweep kernel above keeps only
+// band/64 of them busy) and the downward scan can stop at the first predecessor further than 2500 bp (chain.rs:859-863).
+// A chunk is owned by one thread, so the per-component argmax needs no atomics.
+template <int T>
+__global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* a_q, const uint32_t* a_r,
+                                                            const uint32_t* a_cr, unsigned long long* best) {
+    SKH_DYN_SMEM(smem);
+    uint4* ring_a = (uint4*)smem;                                  // [band][T]: q, r, cr, score
+    uint2* ring_b = (uint2*)(smem + (size_t)band * T * sizeof(uint4));   // [band][T]: root (chunk-local), depth
+    const uint32_t slot = blockIdx.x * T + threadIdx.x;
+    Chunk ck{0, 0, 0, 0};
+    if (slot < n_slots) ck = chunks[slot];
+    const uint32_t n = ck.a_end - ck.a_begin;
+    uint32_t w = 0;                                               // ring write position = i % band
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t t = ck.a_begin + i;
+        const uint32_t q = a_q[t], r = a_r[t], cr = a_cr[t];
+        const bool rev = (cr & 1u) != 0;
+        int32_t bscore = 0; uint32_t bslot = 0xFFFFFFFFu;
+        const uint32_t nd = i < band ? i : band;
+        uint32_t rs = w;                                          // ring slot of predecessor j = i - d
+        for (uint32_t d = 1; d <= nd; d++) {
+            rs = rs == 0 ? band - 1 : rs - 1;
+            const uint4 e = ring_a[rs * T + threadIdx.x];
+            const uint32_t dq = q - e.x;
+            if (dq > BP_CHAIN_BAND) break;                        // all earlier anchors are at least as far (sorted by query pos)
+            if (e.z != cr || dq == 0) continue;                   // other ref contig / strand, or same query position
+            const bool fwd_ok = rev ? (e.y > r) : (r > e.y);
+            const uint32_t dr = rev ? e.y - r : r - e.y;
+            if (!fwd_ok || dr > (uint32_t)MAX_LIN) continue;
+            const int32_t gap = (int32_t)dr > (int32_t)dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+            if (gap > MAX_GAP) continue;
+            const int32_t sc = ANCHOR_SCORE - gap + (int32_t)e.w;
+            if (sc > bscore) { bscore = sc; bslot = rs; }          // downward scan + strict '>' = reference tie rule
+        }
+        uint32_t root = i, depth = 1;
+        if (bslot != 0xFFFFFFFFu) { const uint2 rb = ring_b[bslot * T + threadIdx.x]; root = rb.x; depth = rb.y + 1; }
+        ring_a[w * T + threadIdx.x] = make_uint4(q, r, cr, (uint32_t)bscore);
+        ring_b[w * T + threadIdx.x] = make_uint2(root, depth);
+        w = w + 1 == band ? 0 : w + 1;
+        const unsigned long long pay = best_payload((uint32_t)bscore, i, depth);
+        unsigned long long* slot_best = &best[ck.a_begin + root];
+        if (root == i || pay > *slot_best) *slot_best = pay;      // single owner thread per chunk: plain read-modify-write
+    }
+}
+
 // chain.rs:939-1007: one candidate interval per pointer-forest component that reaches 3 anchors / score 45
-__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_anch, const uint32_t* a_q, const uint32_t* a_r, const uint32_t* a_cr, const uint32_t* a_qc,
-                                                            const uint32_t* o_root, const uint32_t* o_depth, const uint32_t* o_chunk,
-                                                            const unsigned long long* best, const uint32_t* chunk_pair, const uint32_t* pc0,
-                                                            const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_anch || o_root[i] != i) return;
-    const unsigned long long b = best[i];
-    const uint32_t bi = (uint32_t)b; const int32_t sc = (int32_t)(b >> 32);
-    const uint32_t na = o_depth[bi];
-    if (na < MIN_ANCHORS || sc < MIN_SCORE) return;                                 // chain.rs:974-977
-    const uint32_t slot = o_chunk[i], p = chunk_pair[slot];
-    const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
-    if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); return; }
-    Interval iv;
-    iv.score = (uint32_t)sc; iv.na = na; iv.q0 = a_q[i]; iv.q1 = a_q[bi];
-    const uint32_t e1 = a_r[i], e2 = a_r[bi];
-    iv.r0 = e1 < e2 ? e1 : e2; iv.r1 = e1 < e2 ? e2 : e1;
-    iv.rctg = a_cr[i] >> 1; iv.qctg = a_qc[i]; iv.chunk = slot - pc0[p]; iv.rev = a_cr[i] & 1u;
-    ivls[pi0[p] + k] = iv;
+// One wave per chunk: roots are the anchors whose argmax record is non-zero.
+__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* a_q, const uint32_t* a_r, const uint32_t* a_cr,
+                                                            const uint32_t* a_qc, const unsigned long long* best, const uint32_t* chunk_pair,
+                                                            const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= n_slots) return;
+    const Chunk ck = chunks[slot];
+    if (ck.a_end <= ck.a_begin) return;
+    const uint32_t p = chunk_pair[slot];
+    if (ck.a_end - ck.a_begin >= MAX_CHUNK_ANCHORS) { if (lane_id() == 0) atomicAdd(err, 1u); return; }
+    for (uint32_t i = ck.a_begin + lane_id(); i < ck.a_end; i += 64) {
+        const unsigned long long b = best[i];
+        if (b == 0) continue;                                                       // not a root
+        const uint32_t sc = (uint32_t)(b >> 40), bi = ck.a_begin + (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
+        if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) continue;                  // chain.rs:954-957, 974-977
+        const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
+        if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); continue; }
+        Interval iv;
+        iv.score = sc; iv.na = na; iv.q0 = a_q[i]; iv.q1 = a_q[bi];
+        const uint32_t e1 = a_r[i], e2 = a_r[bi];
+        iv.r0 = e1 < e2 ? e1 : e2; iv.r1 = e1 < e2 ? e2 : e1;
+        iv.rctg = a_cr[i] >> 1; iv.qctg = a_qc[i]; iv.chunk = slot - pc0[p]; iv.rev = a_cr[i] & 1u;
+        ivls[pi0[p] + k] = iv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ greedy selection
@@ -630,6 +703,16 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 
 }  // namespace
 
+// slot order for the join kernels: tiles grouped by (key % 8) and interleaved so that slot b (-> XCD b % 8) serves queue b % 8
+static std::vector<uint32_t> xcd_slots(uint32_t t0, uint32_t t1, const std::vector<uint32_t>& tile_pair, const std::vector<uint32_t>& pair_key) {
+    std::vector<uint32_t> q[8];
+    for (uint32_t t = t0; t < t1; t++) q[pair_key[tile_pair[t]] & 7u].push_back(t);
+    size_t mx = 0; for (auto& v : q) mx = std::max(mx, v.size());
+    std::vector<uint32_t> slots(mx * 8, NONE);
+    for (uint32_t x = 0; x < 8; x++) for (size_t i = 0; i < q[x].size(); i++) slots[i * 8 + x] = q[x][i];
+    return slots;
+}
+
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q, const uint32_t* pair_ref, const uint32_t* pair_query,
                  uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats) {
     if (n_pairs_all == 0) return;
@@ -646,7 +729,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     const uint32_t NP = (uint32_t)n_pairs_all;
     // ---- pair descriptors and join tiles
     std::vector<PairDesc> pds(NP); std::vector<uint32_t> tile_pair;
-    std::vector<uint32_t> chunk_bound(NP);
+    std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
     for (uint32_t p = 0; p < NP; p++) {
         const uint32_t r = pair_ref[p], q = pair_query[p];
         if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
@@ -663,6 +746,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
         pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
         for (uint32_t t = 0; t * JOIN_TILE < pd.a_n; t++) tile_pair.push_back(p);
+        pair_key[p] = gb;                                                           // tiles probing the same sketch share an XCD
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }
@@ -670,26 +754,40 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     const uint32_t NT = (uint32_t)tile_pair.size();
     PairDesc* d_pairs_all = upload(ctx, pds);
     uint32_t* d_tile_pair = upload(ctx, tile_pair);
-    uint32_t* tile_anch = ctx->arena.get<uint32_t>(NT + 1); uint32_t* tile_inq = ctx->arena.get<uint32_t>(NT + 1);
-    uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
-    dzero(d_pair_anch, NP * 4, ctx->stream); dzero(d_pair_inq, NP * 4, ctx->stream);
-    if (NT) {
-        SKH_LAUNCH(join_count_kernel, NT, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq,
-                   d_pair_anch, d_pair_inq);
-        check_launch("join_count");
-    }
-    std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
-    d2h(pair_anch.data(), d_pair_anch, NP * 4, ctx->stream); d2h(pair_inq.data(), d_pair_inq, NP * 4, ctx->stream);
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
+    uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_inq = ctx->arena.get<uint32_t>((size_t)NT + 1);
+    uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
+    dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
-    // ---- batches bounded by scratch (anchors dominate: ~44 B per anchor)
-    const uint64_t ANCH_BUDGET = (uint64_t)96 << 20;     // anchors per batch
+    const uint64_t ANCH_BUDGET = (uint64_t)512 << 20;    // anchors per batch (~44 B of scratch each)
+    const uint32_t SUPER_TILES = 1u << 20;               // join tiles per count pass (6 KiB of probe records each)
     auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
-    uint32_t p0 = 0;
-    while (p0 < NP) {
+    std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
+    uint32_t sp0 = 0;
+    while (sp0 < NP) {
+        // ---- super-batch: pairs [sp0, sp1) = tiles [st0, st1); count pass records one probe result per position
+        uint32_t sp1 = sp0;
+        while (sp1 < NP && (sp1 == sp0 || (sp1 + 1 < NP ? pds[sp1 + 1].tile0 : NT) - pds[sp0].tile0 <= SUPER_TILES)) sp1++;
+        const uint32_t st0 = pds[sp0].tile0, st1 = sp1 < NP ? pds[sp1].tile0 : NT, snt = st1 - st0;
+        const std::vector<size_t> super_mark = ctx->arena.mark();
+        uint32_t* pinfo_start = ctx->arena.get<uint32_t>((size_t)snt * JOIN_TILE + 1);
+        uint16_t* pinfo_cnt = ctx->arena.get<uint16_t>((size_t)snt * JOIN_TILE + 1);
+        // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
+        uint32_t* pis = pinfo_start - (size_t)st0 * JOIN_TILE; uint16_t* pic = pinfo_cnt - (size_t)st0 * JOIN_TILE;
+        if (snt) {
+            const std::vector<uint32_t> slots = xcd_slots(st0, st1, tile_pair, pair_key);
+            uint32_t* d_slots = upload(ctx, slots);
+            SKH_LAUNCH(join_count_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+                       (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic);
+            check_launch("join_count");
+        }
+        d2h(pair_anch.data() + sp0, d_pair_anch + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
+        d2h(pair_inq.data() + sp0, d_pair_inq + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
+        uint32_t p0 = sp0;
+        while (p0 < sp1) {
         uint64_t na = 0; uint32_t p1 = p0;
-        while (p1 < NP && (p1 == p0 || na + pair_anch[p1] <= ANCH_BUDGET) && p1 - p0 < (1u << 20)) { na += pair_anch[p1]; p1++; }
+        while (p1 < sp1 && (p1 == p0 || na + pair_anch[p1] <= ANCH_BUDGET)) { na += pair_anch[p1]; p1++; }
         const uint32_t np = p1 - p0;
         const std::vector<size_t> arena_mark = ctx->arena.mark();
         if (na >= 0xFFFFFFF0ull) throw Error("a single genome pair produces more than 2^32 anchors");
@@ -704,7 +802,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         const uint32_t NA = pa0[np], NQ = pq0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
         const PairDesc* d_pairs = d_pairs_all + p0;
-        // rebase tile0 for the batch: kernels index tiles globally, pairs batch-relatively -> tile_pair - p0 handled via pointer math below
         uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pq0 = upload(ctx, pq0); uint32_t* d_pc0 = upload(ctx, pc0);
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
         uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
@@ -713,8 +810,11 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* a_cr = ctx->arena.get<uint32_t>(NA + 64); uint32_t* a_qc = ctx->arena.get<uint32_t>(NA + 64);
         uint32_t* ql_pos = ctx->arena.get<uint32_t>(NQ + 64); uint32_t* ql_ctg = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
-            SKH_LAUNCH(join_fill_kernel, nt, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_tile_pair, t0, band,
-                       (const uint32_t*)toff_a, (const uint32_t*)toff_q, a_q, a_r, a_cr, a_qc, ql_pos, ql_ctg);
+            const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key);
+            uint32_t* d_slots = upload(ctx, slots);
+            SKH_LAUNCH(join_fill_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+                       (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
+                       a_q, a_r, a_cr, a_qc, ql_pos, ql_ctg);
             check_launch("join_fill");
         }
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
@@ -722,26 +822,31 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0, (const uint32_t*)d_pc0,
                    (const uint32_t*)a_q, (const uint32_t*)a_qc, (const uint32_t*)ql_pos, (const uint32_t*)ql_ctg, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
-        int32_t* o_score = ctx->arena.get<int32_t>(NA + 64); uint32_t* o_root = ctx->arena.get<uint32_t>(NA + 64);
-        uint32_t* o_depth = ctx->arena.get<uint32_t>(NA + 64); uint32_t* o_chunk = ctx->arena.get<uint32_t>(NA + 64);
         unsigned long long* best = ctx->arena.get<unsigned long long>(NA + 64);
         dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
         if (NC) {
-            const unsigned gb = (NC + 3) / 4;
+            if (band <= 40) {   // thread-per-chunk: LDS ring of `band` x 24 B per lane
+                constexpr int T = 64;
+                const size_t smem = (size_t)band * T * 24;
+                SKH_LAUNCH(chain_dp_thread_kernel<T>, (NC + T - 1) / T, T, smem, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)a_q,
+                           (const uint32_t*)a_r, (const uint32_t*)a_cr, best);
+            } else {
+                const unsigned gb = (NC + 3) / 4;
 #define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)a_q, (const uint32_t*)a_r, \
-                              (const uint32_t*)a_cr, o_score, o_root, o_depth, o_chunk, best)
-            if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
+                              (const uint32_t*)a_cr, best)
+                if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
 #undef SKH_DP
+            }
             check_launch("chain_dp");
         }
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
-        if (NA) {
-            SKH_LAUNCH(interval_emit_kernel, (NA + 255) / 256, 256, 0, ctx->stream, NA, (const uint32_t*)a_q, (const uint32_t*)a_r, (const uint32_t*)a_cr,
-                       (const uint32_t*)a_qc, (const uint32_t*)o_root, (const uint32_t*)o_depth, (const uint32_t*)o_chunk, (const unsigned long long*)best,
-                       (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
+        if (NC) {
+            SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)a_q, (const uint32_t*)a_r,
+                       (const uint32_t*)a_cr, (const uint32_t*)a_qc, (const unsigned long long*)best, (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0,
+                       (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
             check_launch("interval_emit");
         }
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
@@ -783,6 +888,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         dsync(ctx->stream);
         ctx->arena.rewind(arena_mark);
         p0 = p1;
+        }
+        ctx->arena.rewind(super_mark);
+        sp0 = sp1;
     }
     uint32_t h_err = 0;
     d2h(&h_err, d_err, 4, ctx->stream);

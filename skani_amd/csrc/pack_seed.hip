@@ -132,14 +132,15 @@ __device__ uint32_t n_suppress_mask(const uint32_t* nmask, const ContigDesc& cd,
 
 __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                                                          const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
-                                                         uint32_t k, uint64_t thr, uint64_t thr_m, int mode,
+                                                         const uint32_t* __restrict__ tile_ids, uint32_t k, uint64_t thr, uint64_t thr_m,
+                                                         int mode, uint32_t cap_s, uint32_t cap_m,
                                                          uint32_t* __restrict__ t_seed, uint16_t* __restrict__ t_loc,
                                                          uint64_t* __restrict__ t_marker, uint32_t* __restrict__ cnt_s,
                                                          uint32_t* __restrict__ cnt_m) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[SEED_TILE / 16 + 8];
     __shared__ uint32_t lds_scan[16];
     const uint32_t tid = threadIdx.x;
-    const SeedTile tile = tiles[blockIdx.x];
+    const SeedTile tile = tiles[tile_ids ? tile_ids[blockIdx.x] : blockIdx.x];
     const ContigDesc cd = contigs[tile.contig];
     const uint32_t iend = cd.len < 2 * K_MARKER ? (K_MARKER - 1)
                         : (mode == SKH_SEED_AVX2 ? (K_MARKER - 1) + 4 * ((cd.len - (K_MARKER - 1)) / 4) : cd.len);
@@ -187,7 +188,9 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     if (tid == 0) { cnt_s[blockIdx.x] = tot & 0xFFFFu; cnt_m[blockIdx.x] = tot >> 16; }
     // emit hits in window order; values re-derived by extracting the 21-mer from the thread's 104 packed bits
     const uint64_t hi = ((uint64_t)a0 << 32) | a1, lo = ((uint64_t)a2 << 32) | a3;
-    const uint64_t obase = (uint64_t)blockIdx.x * SEED_TILE;
+    // tile scratch holds cap_s seeds / cap_m markers; a tile that needs more (low-complexity sequence) is re-run
+    // by the host with full capacity -- the counts above are exact either way
+    const uint64_t obase = (uint64_t)blockIdx.x * cap_s, mbase = (uint64_t)blockIdx.x * cap_m;
     uint32_t hm = hits;
     while (hm) {
         const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
@@ -197,17 +200,31 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
         const uint64_t rr = rev2_64(~ff) >> 22;
         const uint32_t fs = (uint32_t)ff & smask, rs = (uint32_t)rr & smask;
         const bool canon = fs < rs;
-        t_seed[obase + so] = canon ? fs : rs;
-        t_loc[obase + so] = (uint16_t)((SEED_RUN * tid + j) | (canon ? 0x8000u : 0u));
+        if (so < cap_s) {
+            t_seed[obase + so] = canon ? fs : rs;
+            t_loc[obase + so] = (uint16_t)((SEED_RUN * tid + j) | (canon ? 0x8000u : 0u));
+        }
         so++;
-        if ((mhits >> j) & 1u) { t_marker[obase + mo] = ff < rr ? ff : rr; mo++; }   // seeding.rs:311-319
+        if ((mhits >> j) & 1u) { if (mo < cap_m) t_marker[mbase + mo] = ff < rr ? ff : rr; mo++; }   // seeding.rs:311-319
     }
+}
+
+// tiles whose counts exceed the capped scratch get a slot in the full-capacity overflow scratch
+__global__ __launch_bounds__(256) void seed_overflow_kernel(const uint32_t* cnt_s, const uint32_t* cnt_m, uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m,
+                                                            uint32_t* ovf_idx, uint32_t* ovf_list, uint32_t* n_ovf) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t idx = 0xFFFFFFFFu;
+    if (cnt_s[t] > cap_s || cnt_m[t] > cap_m) { idx = atomicAdd(n_ovf, 1u); ovf_list[idx] = t; }
+    ovf_idx[t] = idx;
 }
 
 // one wave per tile: copy the tile's records to their final (contig,pos)-ordered place
 __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __restrict__ tiles, const ContigDesc* __restrict__ contigs,
-                                                           uint32_t n_tiles, const uint32_t* __restrict__ t_seed,
-                                                           const uint16_t* __restrict__ t_loc, const uint64_t* __restrict__ t_marker,
+                                                           uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m, const uint32_t* __restrict__ ovf_idx,
+                                                           const uint32_t* __restrict__ t_seed, const uint16_t* __restrict__ t_loc,
+                                                           const uint64_t* __restrict__ t_marker, const uint32_t* __restrict__ o_seed2,
+                                                           const uint16_t* __restrict__ o_loc2, const uint64_t* __restrict__ o_marker2,
                                                            const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
                                                            uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_pos,
                                                            uint32_t* __restrict__ o_cc, uint64_t* __restrict__ o_marker) {
@@ -217,14 +234,22 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     const SeedTile tile = tiles[lt];
     const uint32_t cidx = contigs[tile.contig].index;
     const uint32_t s0 = off_s[lt], ns = off_s[lt + 1] - s0, m0 = off_m[lt], nm = off_m[lt + 1] - m0;
-    const uint64_t ib = (uint64_t)lt * SEED_TILE;
+    const uint32_t ov = ovf_idx[lt];
+    const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
+    const uint16_t* src_loc = ov == 0xFFFFFFFFu ? t_loc + (uint64_t)lt * cap_s : o_loc2 + (uint64_t)ov * SEED_TILE;
+    const uint64_t* src_mk = ov == 0xFFFFFFFFu ? t_marker + (uint64_t)lt * cap_m : o_marker2 + (uint64_t)ov * SEED_TILE;
     for (uint32_t x = ln; x < ns; x += 64) {
-        const uint32_t loc = t_loc[ib + x];
-        o_seed[s0 + x] = t_seed[ib + x];
+        const uint32_t loc = src_loc[x];
+        o_seed[s0 + x] = src_seed[x];
         o_pos[s0 + x] = (K_MARKER - 1) + tile.first * SEED_TILE + (loc & 0x1FFFu);   // pos = index of the window's last base
         o_cc[s0 + x] = (cidx << 1) | (loc >> 15);                                     // types.rs:131-138
     }
-    for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = t_marker[ib + x];
+    for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = src_mk[x];
+}
+
+__global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
 }
 
 void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out) {
@@ -232,50 +257,86 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const size_t n_tiles = gs->tiles.size();
     const uint32_t ng = gs->n_genomes;
     out.pos_off.assign(ng + 1, 0); out.mk_off.assign(ng + 1, 0);
-    const size_t MAX_TILES = 16384;     // per launch: 134 M windows, 1.9 GB of worst-case tile scratch
+    // capped tile scratch: 4x the expected hits per tile; tiles that exceed it are re-run with full capacity
+    const uint32_t cap_s = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
+    const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
+    const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
+    const size_t MAX_TILES = std::max<size_t>(1024, ((size_t)6 << 30) / tile_bytes);     // <= 6 GiB of tile scratch per launch
     struct Part { DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
-    std::vector<uint64_t> g_ns(ng, 0), g_nm(ng, 0);
+    // first tile of every genome (tiles are ordered by genome)
+    std::vector<uint32_t> g_first(ng + 1, (uint32_t)n_tiles);
+    for (size_t t = n_tiles; t-- > 0;) g_first[gs->contigs[gs->tiles[t].contig].genome] = (uint32_t)t;
+    for (uint32_t g = ng; g-- > 0;) if (g_first[g] == (uint32_t)n_tiles || g_first[g] > g_first[g + 1]) g_first[g] = std::min(g_first[g], g_first[g + 1]);
+    std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);   // running totals at genome starts
 #ifndef SKANI_EMU
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
 #endif
+    uint64_t base_s = 0, base_m = 0;
     for (size_t t0 = 0; t0 < n_tiles; t0 += MAX_TILES) {
         const uint32_t nt = (uint32_t)std::min(MAX_TILES, n_tiles - t0);
-        uint32_t* t_seed = ctx->arena.get<uint32_t>((size_t)nt * SEED_TILE);
-        uint16_t* t_loc = ctx->arena.get<uint16_t>((size_t)nt * SEED_TILE);
-        uint64_t* t_marker = ctx->arena.get<uint64_t>((size_t)nt * SEED_TILE);
+        uint32_t* t_seed = ctx->arena.get<uint32_t>((size_t)nt * cap_s);
+        uint16_t* t_loc = ctx->arena.get<uint16_t>((size_t)nt * cap_s);
+        uint64_t* t_marker = ctx->arena.get<uint64_t>((size_t)nt * cap_m);
         uint32_t* cnt_s = ctx->arena.get<uint32_t>(nt); uint32_t* cnt_m = ctx->arena.get<uint32_t>(nt);
         uint32_t* off_s = ctx->arena.get<uint32_t>(nt + 1); uint32_t* off_m = ctx->arena.get<uint32_t>(nt + 1);
+        uint32_t* ovf_idx = ctx->arena.get<uint32_t>(nt); uint32_t* ovf_list = ctx->arena.get<uint32_t>(nt);
+        uint32_t* n_ovf = ctx->arena.get<uint32_t>(1);
+        dzero(n_ovf, 4, ctx->stream);
+        const SeedTile* d_tiles = gs->d_tiles.p + t0;
 #ifndef SKANI_EMU
         hipEvent_t e0, e1; hip_check(hipEventCreate(&e0), "event"); hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, ctx->stream), "event record");
 #endif
         SKH_LAUNCH(seed_tiles_kernel, nt, SEED_THREADS, 0, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
-                   (const ContigDesc*)gs->d_contigs.p, (const SeedTile*)(gs->d_tiles.p + t0), sp.k, thr, thr_m, gs->seeding_mode,
+                   (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
                    t_seed, t_loc, t_marker, cnt_s, cnt_m);
         check_launch("seed_tiles_kernel");
 #ifndef SKANI_EMU
         hip_check(hipEventRecord(e1, ctx->stream), "event record"); evs.push_back({e0, e1});
 #endif
+        SKH_LAUNCH(seed_overflow_kernel, (nt + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf);
+        check_launch("seed_overflow");
         exclusive_scan_u32(ctx, cnt_s, nt, off_s);
         exclusive_scan_u32(ctx, cnt_m, nt, off_m);
-        std::vector<uint32_t> h_s(nt + 1), h_m(nt + 1);
-        d2h(h_s.data(), off_s, (nt + 1) * 4, ctx->stream); d2h(h_m.data(), off_m, (nt + 1) * 4, ctx->stream);
-        Part p; p.ns = h_s[nt]; p.nm = h_m[nt];
-        p.seed.alloc(p.ns); p.pos.alloc(p.ns); p.cc.alloc(p.ns); p.mk.alloc(p.nm);
-        SKH_LAUNCH(seed_compact_kernel, (nt + 3) / 4, 256, 0, ctx->stream, (const SeedTile*)(gs->d_tiles.p + t0),
-                   (const ContigDesc*)gs->d_contigs.p, nt, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker,
-                   (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.pos.p, p.cc.p, p.mk.p);
-        check_launch("seed_compact_kernel");
-        for (uint32_t lt = 0; lt < nt; lt++) {
-            uint32_t g = gs->contigs[gs->tiles[t0 + lt].contig].genome;
-            g_ns[g] += h_s[lt + 1] - h_s[lt]; g_nm[g] += h_m[lt + 1] - h_m[lt];
+        // genome boundaries inside this launch + totals + overflow count in one small read-back
+        std::vector<uint32_t> want;   // local tile indices whose offsets we need
+        std::vector<uint32_t> want_g;
+        for (uint32_t g = 0; g <= ng; g++) if (g_first[g] >= t0 && g_first[g] <= t0 + nt) { want.push_back((uint32_t)(g_first[g] - t0)); want_g.push_back(g); }
+        want.push_back(nt);
+        uint32_t* d_want = ctx->arena.get<uint32_t>(want.size()); uint32_t* d_got = ctx->arena.get<uint32_t>(2 * want.size() + 1);
+        h2d(d_want, want.data(), want.size() * 4, ctx->stream);
+        SKH_LAUNCH(gather_u32_at_kernel, (unsigned)((want.size() + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)off_s, (const uint32_t*)d_want, (uint32_t)want.size(), d_got);
+        SKH_LAUNCH(gather_u32_at_kernel, (unsigned)((want.size() + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)off_m, (const uint32_t*)d_want, (uint32_t)want.size(), d_got + want.size());
+        check_launch("gather_u32_at");
+        d2d(d_got + 2 * want.size(), n_ovf, 4, ctx->stream);
+        std::vector<uint32_t> got(2 * want.size() + 1);
+        d2h(got.data(), d_got, got.size() * 4, ctx->stream);
+        const uint32_t h_novf = got[2 * want.size()];
+        Part p; p.ns = got[want.size() - 1]; p.nm = got[2 * want.size() - 1];
+        for (size_t x = 0; x < want_g.size(); x++) { g_ns[want_g[x]] = base_s + got[x]; g_nm[want_g[x]] = base_m + got[want.size() + x]; }
+        uint32_t *o_seed2 = nullptr; uint16_t* o_loc2 = nullptr; uint64_t* o_marker2 = nullptr;
+        if (h_novf) {   // second pass over the overflowing tiles with worst-case capacity
+            o_seed2 = ctx->arena.get<uint32_t>((size_t)h_novf * SEED_TILE); o_loc2 = ctx->arena.get<uint16_t>((size_t)h_novf * SEED_TILE);
+            o_marker2 = ctx->arena.get<uint64_t>((size_t)h_novf * SEED_TILE);
+            uint32_t* c2 = ctx->arena.get<uint32_t>(2 * (size_t)h_novf);
+            SKH_LAUNCH(seed_tiles_kernel, h_novf, SEED_THREADS, 0, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+                       (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
+                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
+            check_launch("seed_tiles_kernel(overflow)");
         }
+        p.seed.alloc(p.ns); p.pos.alloc(p.ns); p.cc.alloc(p.ns); p.mk.alloc(p.nm);
+        SKH_LAUNCH(seed_compact_kernel, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m,
+                   (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2,
+                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.pos.p, p.cc.p, p.mk.p);
+        check_launch("seed_compact_kernel");
+        base_s += p.ns; base_m += p.nm;
         parts.push_back(std::move(p));
         dsync(ctx->stream);
         ctx->arena.reset();
     }
-    for (uint32_t g = 0; g < ng; g++) { out.pos_off[g + 1] = out.pos_off[g] + g_ns[g]; out.mk_off[g + 1] = out.mk_off[g] + g_nm[g]; }
+    g_ns[ng] = base_s; g_nm[ng] = base_m;
+    for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
     const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
     if (parts.size() == 1) {
         out.seed = std::move(parts[0].seed); out.pos = std::move(parts[0].pos); out.cc = std::move(parts[0].cc); out.markers_raw = std::move(parts[0].mk);
