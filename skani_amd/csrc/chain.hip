@@ -113,8 +113,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
 // probe results recorded by join_count_kernel (no second probe).
 __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                         uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
-                                                        const uint16_t* pinfo_cnt, uint32_t* a_q, uint32_t* a_r, uint32_t* a_cr, uint32_t* a_qc,
-                                                        uint32_t* ql_pos, uint32_t* ql_ctg) {
+                                                        const uint16_t* pinfo_cnt, uint4* anc, uint32_t* ql_pos, uint32_t* ql_ctg) {
     __shared__ uint32_t lds[16];
     const uint32_t tile = slot_tile[blockIdx.x];
     if (tile == NONE) return;
@@ -144,8 +143,8 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
                 uint32_t oa = run_a + ba + ia - n_anch;
                 for (uint32_t k = 0; k < n_anch; k++, oa++) {                        // chain.rs:703-711, already in sorted order
                     const uint32_t rcc = B.s_cc[bs + k];
-                    a_q[oa] = qpos; a_qc[oa] = qcc >> 1; a_r[oa] = B.s_pos[bs + k];
-                    a_cr[oa] = (rcc & ~1u) | ((rcc ^ qcc) & 1u);                     // ref_contig << 1 | reverse_match
+                    // anchor record: x = query pos, y = ref pos, z = ref_contig << 1 | reverse_match, w = query contig
+                    anc[oa] = make_uint4(qpos, B.s_pos[bs + k], (rcc & ~1u) | ((rcc ^ qcc) & 1u), qcc >> 1);
                 }
             }
         }
@@ -155,11 +154,12 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
 
 // ------------------------------------------------------------------------------------------------ chunking (chain.rs:738-836)
 // One wave per pair.  All control flow is wave-uniform; lanes only differ in the element they test.
-__device__ __forceinline__ uint32_t first_anchor_break(const uint32_t* a_q, const uint32_t* a_qc, uint32_t from, uint32_t to, uint32_t last, uint32_t end) {
+__device__ __forceinline__ uint32_t first_anchor_break(const uint4* anc, uint32_t from, uint32_t to, uint32_t last, uint32_t end) {
     const uint32_t l = lane_id();
     for (uint32_t p = from; p < to; p += 64) {
         const uint32_t i = p + l;
-        const bool brk = i < to && (a_qc[i] != last || a_q[i] > end);
+        bool brk = false;
+        if (i < to) { const uint4 a = anc[i]; brk = a.w != last || a.x > end; }
         const unsigned long long m = __ballot(brk);
         if (m) return p + (uint32_t)__ffsll((long long)m) - 1u;
     }
@@ -181,7 +181,7 @@ __device__ __forceinline__ uint32_t lower_bound_ctg(const uint32_t* ql_ctg, uint
 }
 
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint32_t* pa0, const uint32_t* pq0, const uint32_t* pc0,
-                                                    const uint32_t* a_q, const uint32_t* a_qc, const uint32_t* ql_pos, const uint32_t* ql_ctg,
+                                                    const uint4* anc, const uint32_t* ql_pos, const uint32_t* ql_ctg,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
@@ -189,14 +189,15 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint
     const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
-        uint32_t last = a_qc[A0], end = a_q[A0] + CHUNK_SIZE;                       // chain.rs:742-744
+        const uint4 first = anc[A0];
+        uint32_t last = first.w, end = first.x + CHUNK_SIZE;                        // chain.rs:742-744
         uint32_t rc = lower_bound_ctg(ql_ctg, Q0, Q1, last);                        // running_counter = 0 within contig `last`
         uint32_t cur = A0, scan = A0 + 1;
         for (;;) {
-            const uint32_t t = first_anchor_break(a_q, a_qc, scan, A1, last, end);
+            const uint32_t t = first_anchor_break(anc, scan, A1, last, end);
             Chunk ck; ck.a_begin = cur; ck.s_begin = rc;
             if (t == A1) {                                                         // final chunk: seeds <= last anchor's pos (chain.rs:794-824)
-                ck.a_end = A1; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, a_q[A1 - 1]);
+                ck.a_end = A1; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, anc[A1 - 1].x);
             } else {                                                               // chain.rs:747-790
                 ck.a_end = t; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, end);
             }
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint
             nc++;
             if (t == A1) break;
             rc = ck.s_end; end += CHUNK_SIZE;                                      // one step only (chain.rs:782)
-            const uint32_t nctg = a_qc[t];
-            if (nctg != last) { end = a_q[t] + CHUNK_SIZE; rc = lower_bound_ctg(ql_ctg, Q0, Q1, nctg); last = nctg; }   // chain.rs:786-789
+            const uint4 at = anc[t];
+            if (at.w != last) { end = at.x + CHUNK_SIZE; rc = lower_bound_ctg(ql_ctg, Q0, Q1, at.w); last = at.w; }   // chain.rs:786-789
             cur = t; scan = t + 1;
         }
     }
@@ -229,8 +230,7 @@ constexpr uint32_t MAX_CHUNK_ANCHORS = 1u << 20;
 struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
 
 template <int PB>
-__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* a_q, const uint32_t* a_r,
-                                                       const uint32_t* a_cr, unsigned long long* best) {
+__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint4* anc, unsigned long long* best) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
         const uint32_t t = base + (uint32_t)l;
         const bool valid = t < ck.a_end;
         Blk cur;
-        cur.q = valid ? a_q[t] : 0; cur.r = valid ? a_r[t] : 0; cur.cr = valid ? a_cr[t] : 0xFFFFFFFFu;
+        uint4 av = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+        if (valid) av = anc[t];
+        cur.q = av.x; cur.r = av.y; cur.cr = av.z;
         cur.score = 0; cur.root = t; cur.depth = 1;
         uint32_t ptr = t;
         const uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
@@ -300,58 +302,108 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
     }
 }
 
-// Thread-per-chunk variant for small bands (c >= 63): a wave chains 64 chunks in lockstep, every lane walks its own chunk
-// sequentially and keeps the last `band` anchors (q, r, contig/strand, score | root, depth) in an LDS ring laid out
-// [slot][lane] so that a wave's accesses are conflict-free.  All 64 lanes evaluate links (the sweep kernel above keeps only
-// band/64 of them busy) and the downward scan can stop at the first predecessor further than 2500 bp (chain.rs:859-863).
-// A chunk is owned by one thread, so the per-component argmax needs no atomics.
-template <int T>
-__global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* a_q, const uint32_t* a_r,
-                                                            const uint32_t* a_cr, unsigned long long* best) {
+// Thread-per-chunk chaining for small bands (c >= 63): chain_anchors_ani + get_chain_intervals fused.
+// A wave chains 64 chunks in lockstep; every lane walks its own chunk sequentially and keeps
+//   * the last NB anchors (q, r, ref contig/strand, score, depth | component slot) in REGISTERS as a shift register, so the
+//     predecessor scan is a fully unrolled, branch-free block of integer selects;
+//   * a table of the LIVE pointer-forest components (those with an anchor still inside the ring -- only they can be extended,
+//     chain.rs:859-863) in LDS, laid out [slot][lane]: the component's argmax record (score | best index | chain length) and
+//     root << 8 | reference count.
+// All 64 lanes evaluate links (the sweep kernel keeps band/64 of them busy).  When the last anchor of a component leaves the
+// ring the component is final and, if it reaches 3 anchors / score 45 (chain.rs:954-977), its interval is emitted straight
+// away: the kernel writes nothing per anchor.
+__device__ __forceinline__ void dp_emit(const uint4* anc, const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b,
+                                        const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
+    const uint32_t sc = (uint32_t)(b >> 40), bi = (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
+    if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) return;                        // chain.rs:954-957, 974-977
+    const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
+    if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); return; }
+    const uint4 ar = anc[ck.a_begin + root], ab = anc[ck.a_begin + bi];
+    Interval iv;
+    iv.score = sc; iv.na = na; iv.q0 = ar.x; iv.q1 = ab.x;
+    iv.r0 = ar.y < ab.y ? ar.y : ab.y; iv.r1 = ar.y < ab.y ? ab.y : ar.y;
+    iv.rctg = ar.z >> 1; iv.qctg = ar.w; iv.chunk = slot - pc0[p]; iv.rev = ar.z & 1u;
+    ivls[pi0[p] + k] = iv;
+}
+
+template <int NB, int T>
+__global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, uint32_t band, const uint4* anc,
+                                                            const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
     SKH_DYN_SMEM(smem);
-    uint4* ring_a = (uint4*)smem;                                  // [band][T]: q, r, cr, score
-    uint2* ring_b = (uint2*)(smem + (size_t)band * T * sizeof(uint4));   // [band][T]: root (chunk-local), depth
-    const uint32_t slot = blockIdx.x * T + threadIdx.x;
+    const uint32_t C = band + 1, tid = threadIdx.x;
+    unsigned long long* ct_best = (unsigned long long*)smem;                        // [C][T]
+    uint32_t* ct_rr = (uint32_t*)(smem + (size_t)C * T * 8);                        // [C][T]: root << 8 | refcount
+    const uint32_t slot = blockIdx.x * T + tid;
     Chunk ck{0, 0, 0, 0};
     if (slot < n_slots) ck = chunks[slot];
     const uint32_t n = ck.a_end - ck.a_begin;
-    uint32_t w = 0;                                               // ring write position = i % band
+    if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(err, 1u); return; }
+    const uint32_t p = n ? chunk_pair[slot] : 0;
+    unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+    uint32_t rq[NB], rr[NB], rc[NB], rs[NB], rd[NB];                                // q, r, contig/strand, score, depth << 8 | component
+#pragma unroll
+    for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rc[k] = 0xFFFFFFFFu; rs[k] = 0; rd[k] = 0; }
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (n) nxt = anc[ck.a_begin];
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t t = ck.a_begin + i;
-        const uint32_t q = a_q[t], r = a_r[t], cr = a_cr[t];
+        const uint4 a = nxt;
+        if (i + 1 < n) nxt = anc[ck.a_begin + i + 1];                               // prefetch: independent of this iteration's work
+        const uint32_t q = a.x, r = a.y, cr = a.z;
         const bool rev = (cr & 1u) != 0;
-        int32_t bscore = 0; uint32_t bslot = 0xFFFFFFFFu;
         const uint32_t nd = i < band ? i : band;
-        uint32_t rs = w;                                          // ring slot of predecessor j = i - d
-        for (uint32_t d = 1; d <= nd; d++) {
-            rs = rs == 0 ? band - 1 : rs - 1;
-            const uint4 e = ring_a[rs * T + threadIdx.x];
-            const uint32_t dq = q - e.x;
-            if (dq > BP_CHAIN_BAND) break;                        // all earlier anchors are at least as far (sorted by query pos)
-            if (e.z != cr || dq == 0) continue;                   // other ref contig / strand, or same query position
-            const bool fwd_ok = rev ? (e.y > r) : (r > e.y);
-            const uint32_t dr = rev ? e.y - r : r - e.y;
-            if (!fwd_ok || dr > (uint32_t)MAX_LIN) continue;
+        int32_t bscore = 0; uint32_t bdc = NONE;
+        // predecessors j = i-1-k for k = 0..nd-1 (downward scan; strict '>' keeps the largest j among equal maxima, chain.rs:852-880)
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const uint32_t dq = q - rq[k];
+            const uint32_t dr = rev ? rr[k] - r : r - rr[k];                        // wrong direction wraps to a huge value
             const int32_t gap = (int32_t)dr > (int32_t)dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-            if (gap > MAX_GAP) continue;
-            const int32_t sc = ANCHOR_SCORE - gap + (int32_t)e.w;
-            if (sc > bscore) { bscore = sc; bslot = rs; }          // downward scan + strict '>' = reference tie rule
+            const int32_t sc = ANCHOR_SCORE - gap + (int32_t)rs[k];
+            const bool ok = ((uint32_t)k < nd) & (rc[k] == cr) & (dq - 1u < BP_CHAIN_BAND) & (dr - 1u < (uint32_t)MAX_LIN) & ((uint32_t)gap <= (uint32_t)MAX_GAP) &
+                            (sc > bscore);                                          // chain.rs:856-863, 564-597
+            bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
         }
-        uint32_t root = i, depth = 1;
-        if (bslot != 0xFFFFFFFFu) { const uint2 rb = ring_b[bslot * T + threadIdx.x]; root = rb.x; depth = rb.y + 1; }
-        ring_a[w * T + threadIdx.x] = make_uint4(q, r, cr, (uint32_t)bscore);
-        ring_b[w * T + threadIdx.x] = make_uint2(root, depth);
-        w = w + 1 == band ? 0 : w + 1;
-        const unsigned long long pay = best_payload((uint32_t)bscore, i, depth);
-        unsigned long long* slot_best = &best[ck.a_begin + root];
-        if (root == i || pay > *slot_best) *slot_best = pay;      // single owner thread per chunk: plain read-modify-write
+        uint32_t comp, depth;
+        if (bdc != NONE) {
+            comp = bdc & 0xFFu; depth = (bdc >> 8) + 1;
+            ct_rr[comp * T + tid] += 1;
+            const unsigned long long pay = best_payload((uint32_t)bscore, i, depth);
+            if (pay > ct_best[comp * T + tid]) ct_best[comp * T + tid] = pay;       // argmax, ties -> largest index (chain.rs:952-964)
+        } else {                                                                    // new root: at most `band` components are live, one slot is free
+            comp = (uint32_t)__ffsll((long long)free_mask) - 1u; free_mask &= free_mask - 1ull; depth = 1;
+            ct_rr[comp * T + tid] = (i << 8) | 1u; ct_best[comp * T + tid] = best_payload(0, i, 1);
+        }
+        // anchor i-band (a legal predecessor of anchor i, hence handled after the scan) leaves the ring and releases its
+        // component; a component without ring members can never be extended again => it is final
+        uint32_t leaving = 0;
+#pragma unroll
+        for (int k = 0; k < NB; k++) leaving = ((uint32_t)k == band - 1) ? rd[k] : leaving;
+        if (i >= band) {
+            const uint32_t c_old = leaving & 0xFFu;
+            const uint32_t v = ct_rr[c_old * T + tid] - 1u;
+            ct_rr[c_old * T + tid] = v;
+            if ((v & 0xFFu) == 0) { dp_emit(anc, ck, slot, p, v >> 8, ct_best[c_old * T + tid], pc0, pi0, ivl_cnt, ivls, err); free_mask |= 1ull << c_old; }
+        }
+#pragma unroll
+        for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rc[k] = rc[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
+        rq[0] = q; rr[0] = r; rc[0] = cr; rs[0] = (uint32_t)bscore; rd[0] = (depth << 8) | comp;
+    }
+    // chunk end: every component still referenced by the ring is final now
+    const uint32_t live = n < band ? n : band;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if ((uint32_t)k < live) {
+            const uint32_t c_old = rd[k] & 0xFFu;
+            const uint32_t v = ct_rr[c_old * T + tid] - 1u;
+            ct_rr[c_old * T + tid] = v;
+            if ((v & 0xFFu) == 0) dp_emit(anc, ck, slot, p, v >> 8, ct_best[c_old * T + tid], pc0, pi0, ivl_cnt, ivls, err);
+        }
     }
 }
 
 // chain.rs:939-1007: one candidate interval per pointer-forest component that reaches 3 anchors / score 45
 // One wave per chunk: roots are the anchors whose argmax record is non-zero.
-__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* a_q, const uint32_t* a_r, const uint32_t* a_cr,
-                                                            const uint32_t* a_qc, const unsigned long long* best, const uint32_t* chunk_pair,
+__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const uint4* anc, const unsigned long long* best, const uint32_t* chunk_pair,
                                                             const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
@@ -366,11 +418,11 @@ __global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, co
         if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) continue;                  // chain.rs:954-957, 974-977
         const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
         if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); continue; }
+        const uint4 ar = anc[i], ab = anc[bi];
         Interval iv;
-        iv.score = sc; iv.na = na; iv.q0 = a_q[i]; iv.q1 = a_q[bi];
-        const uint32_t e1 = a_r[i], e2 = a_r[bi];
-        iv.r0 = e1 < e2 ? e1 : e2; iv.r1 = e1 < e2 ? e2 : e1;
-        iv.rctg = a_cr[i] >> 1; iv.qctg = a_qc[i]; iv.chunk = slot - pc0[p]; iv.rev = a_cr[i] & 1u;
+        iv.score = sc; iv.na = na; iv.q0 = ar.x; iv.q1 = ab.x;
+        iv.r0 = ar.y < ab.y ? ar.y : ab.y; iv.r1 = ar.y < ab.y ? ab.y : ar.y;
+        iv.rctg = ar.z >> 1; iv.qctg = ar.w; iv.chunk = slot - pc0[p]; iv.rev = ar.z & 1u;
         ivls[pi0[p] + k] = iv;
     }
 }
@@ -687,11 +739,10 @@ bool is_switched(const skh_sketch_set* R, uint32_t r, const skh_sketch_set* Q, u
     return sq > sr;
 }
 
-uint64_t fnv_anchors(const std::vector<uint32_t>& q, const std::vector<uint32_t>& r, const std::vector<uint32_t>& cr, const std::vector<uint32_t>& qc,
-                     size_t a0, size_t a1) {   // same checksum as the oracle's ora_chain_stats.anchor_checksum
+uint64_t fnv_anchors(const std::vector<uint32_t>& anc, size_t a0, size_t a1) {   // same checksum as the oracle's ora_chain_stats.anchor_checksum
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t x) { h ^= x; h *= 1099511628211ull; };
-    for (size_t i = a0; i < a1; i++) { mix(qc[i]); mix(q[i]); mix(cr[i] >> 1); mix(r[i]); mix(cr[i] & 1u); }
+    for (size_t i = a0; i < a1; i++) { mix(anc[4 * i + 3]); mix(anc[4 * i]); mix(anc[4 * i + 2] >> 1); mix(anc[4 * i + 1]); mix(anc[4 * i + 2] & 1u); }
     return h;
 }
 
@@ -806,48 +857,47 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
         uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
         exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); exclusive_scan_u32(ctx, tile_inq + t0, nt, toff_q);
-        uint32_t* a_q = ctx->arena.get<uint32_t>(NA + 64); uint32_t* a_r = ctx->arena.get<uint32_t>(NA + 64);
-        uint32_t* a_cr = ctx->arena.get<uint32_t>(NA + 64); uint32_t* a_qc = ctx->arena.get<uint32_t>(NA + 64);
+        uint4* anc = ctx->arena.get<uint4>((size_t)NA + 16);
         uint32_t* ql_pos = ctx->arena.get<uint32_t>(NQ + 64); uint32_t* ql_ctg = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
             const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key);
             uint32_t* d_slots = upload(ctx, slots);
             SKH_LAUNCH(join_fill_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
-                       a_q, a_r, a_cr, a_qc, ql_pos, ql_ctg);
+                       anc, ql_pos, ql_ctg);
             check_launch("join_fill");
         }
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
         SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0, (const uint32_t*)d_pc0,
-                   (const uint32_t*)a_q, (const uint32_t*)a_qc, (const uint32_t*)ql_pos, (const uint32_t*)ql_ctg, chunks, chunk_pair, n_chunks, d_err);
+                   (const uint4*)anc, (const uint32_t*)ql_pos, (const uint32_t*)ql_ctg, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
-        unsigned long long* best = ctx->arena.get<unsigned long long>(NA + 64);
-        dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
-        if (NC) {
-            if (band <= 40) {   // thread-per-chunk: LDS ring of `band` x 24 B per lane
-                constexpr int T = 64;
-                const size_t smem = (size_t)band * T * 24;
-                SKH_LAUNCH(chain_dp_thread_kernel<T>, (NC + T - 1) / T, T, smem, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)a_q,
-                           (const uint32_t*)a_r, (const uint32_t*)a_cr, best);
-            } else {
-                const unsigned gb = (NC + 3) / 4;
-#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)a_q, (const uint32_t*)a_r, \
-                              (const uint32_t*)a_cr, best)
-                if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
-#undef SKH_DP
-            }
-            check_launch("chain_dp");
-        }
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
         if (NC) {
-            SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)a_q, (const uint32_t*)a_r,
-                       (const uint32_t*)a_cr, (const uint32_t*)a_qc, (const unsigned long long*)best, (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0,
-                       (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
-            check_launch("interval_emit");
+            if (band <= 40) {   // fused thread-per-chunk chaining + interval emission
+                constexpr int T = 64;
+                const size_t lds = (size_t)(band + 1) * T * 12;
+                const unsigned gt = (NC + T - 1) / T;
+#define SKH_DPT(NB) SKH_LAUNCH((chain_dp_thread_kernel<NB, T>), gt, T, lds, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, band, \
+                               (const uint4*)anc, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err)
+                if (band <= 12) SKH_DPT(12); else if (band <= 20) SKH_DPT(20); else if (band <= 28) SKH_DPT(28); else SKH_DPT(40);
+#undef SKH_DPT
+                check_launch("chain_dp_thread");
+            } else {            // wave-per-chunk sweep + per-anchor argmax records + emit
+                unsigned long long* best = ctx->arena.get<unsigned long long>((size_t)NA + 64);
+                dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
+                const unsigned gb = (NC + 3) / 4;
+#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint4*)anc, best)
+                if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
+#undef SKH_DP
+                check_launch("chain_dp");
+                SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint4*)anc, (const unsigned long long*)best,
+                           (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
+                check_launch("interval_emit");
+            }
         }
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
@@ -874,14 +924,13 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
             std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
             d2h(h_nc.data(), n_chunks, np * 4, ctx->stream); d2h(h_ni.data(), ivl_cnt, np * 4, ctx->stream);
             d2h(h_nacc.data(), n_acc, np * 4, ctx->stream); d2h(h_ne.data(), n_est, np * 4, ctx->stream);
-            std::vector<uint32_t> hq(NA), hr(NA), hcr(NA), hqc(NA);
-            d2h(hq.data(), a_q, (uint64_t)NA * 4, ctx->stream); d2h(hr.data(), a_r, (uint64_t)NA * 4, ctx->stream);
-            d2h(hcr.data(), a_cr, (uint64_t)NA * 4, ctx->stream); d2h(hqc.data(), a_qc, (uint64_t)NA * 4, ctx->stream);
+            std::vector<uint32_t> hanc((size_t)NA * 4);
+            d2h(hanc.data(), anc, (uint64_t)NA * 16, ctx->stream);
             for (uint32_t i = 0; i < np; i++) {
                 skh_chain_stats& st = stats[p0 + i];
                 st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
                 st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
-                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hq, hr, hcr, hqc, pa0[i], pa0[i + 1]) : 0;
+                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hanc, pa0[i], pa0[i + 1]) : 0;
                 if (pair_anch[p0 + i] == 0) st.switched = 1;   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
