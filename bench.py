@@ -143,13 +143,12 @@ def main():
     mp = sk.MapParams(learned_ani=sk.use_learned_ani(C), compute_ci=not args.no_ci)
     ctx.timings()
 
-    from skani_amd.distributed import exchange_sketches
+    from skani_amd.distributed import distributed_triangle
 
     def step():
         ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32))
-        ss = exchange_sketches(ctx, ss_local, params, dist, world)     # the one collective
-        i, j, res, n_chained = ctx.triangle(ss, mp, part=rank, n_parts=world)
-        return len(i), n_chained
+        i, j, res, n_chained = distributed_triangle(ctx, ss_local, params, mp, dist, rank, world, torch=torch, device=device)
+        return (len(i) if i is not None else 0), n_chained
 
     for _ in range(args.warmup):
         step()
@@ -168,7 +167,10 @@ def main():
     tm = ctx.timings()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        c2 = torch.tensor([chained, kept], dtype=torch.int64, device=device); dist.all_reduce(c2); chained, kept = int(c2[0]), int(c2[1])
+        c2 = torch.tensor([chained if rank != 0 else 0, kept], dtype=torch.int64, device=device)
+        if rank == 0:
+            c2[0] = chained      # rank 0 already holds the total (gathered); the others report their own share
+        dist.broadcast(c2, src=0); chained, kept = int(c2[0]), int(c2[1])
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -23,17 +23,17 @@ namespace skh {
 // ------------------------------------------------------------------------------------------------ views & descriptors
 struct SetView {
     const uint32_t *p_seed, *p_pos, *p_cc; const uint16_t* p_cnt;
-    const uint32_t *s_pos, *s_cc, *u_seed, *u_start; const uint16_t* u_cnt;
+    const uint32_t *s_pos, *s_cc;
     const uint64_t* table;
 };
 static SetView view_of(const skh_sketch_set* s) {
-    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->u_seed.p, s->u_start.p, s->u_cnt.p, s->table.p};
+    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->table.p};
 }
 
 struct PairDesc {
     uint64_t a_pos0;    // A (enumerated sketch): first entry in its set's position-order arrays
     uint64_t b_pos0;    // B (probed sketch): first entry in its set's seed-order arrays
-    uint64_t b_dist0;   // B: first entry in u_seed/u_start/u_cnt
+    uint64_t reserved0;
     uint64_t b_tab0;    // B: first slot of its hash table
     uint32_t a_n;       // positions in A
     uint32_t b_mask;    // B table size - 1
@@ -52,28 +52,6 @@ struct Chunk { uint32_t a_begin, a_end, s_begin, s_end; };            // batch-r
 struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };   // types.rs:508-519 field order = sort order
 
 // ------------------------------------------------------------------------------------------------ join
-struct Probe { uint32_t n_anch; uint32_t inq; uint64_t b_start; };
-
-__device__ __forceinline__ Probe probe_position(const SetView& A, const SetView& B, const PairDesc& pd, uint64_t ai, uint32_t band) {
-    Probe pr{0, 0, 0};
-    if ((uint32_t)A.p_cnt[ai] > band) return pr;                                   // chain.rs:674-676
-    const uint32_t seed = A.p_seed[ai];
-    const uint64_t* tab = B.table + pd.b_tab0;
-    uint32_t h = mix32(seed) & pd.b_mask;
-    for (;;) {
-        const uint64_t e = tab[h];
-        if (e == TAB_EMPTY) { pr.inq = 1; return pr; }                             // absent in B: chain.rs:682-685
-        if ((uint32_t)(e >> 32) == seed) {
-            const uint64_t d = pd.b_dist0 + (uint32_t)e;
-            const uint32_t cnt = B.u_cnt[d];
-            if (cnt > band) return pr;                                             // chain.rs:694-696 (not even counted as a query seed)
-            pr.inq = 1; pr.n_anch = cnt; pr.b_start = pd.b_pos0 + B.u_start[d];
-            return pr;
-        }
-        h = (h + 1) & pd.b_mask;
-    }
-}
-
 // Workgroups are launched in "slots": slot b runs logical tile slot_tile[b] (or nothing).  The host interleaves the
 // tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
 // table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
@@ -87,14 +65,40 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     const PairDesc pd = pairs[p];
     const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
+    const uint64_t* tab = B.table + pd.b_tab0;
+    constexpr int R = JOIN_TILE / 256;
+    // the four positions of this thread are probed together: their loads are independent, so they overlap
+    uint32_t seed[R], h[R]; bool live[R]; unsigned long long e[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = start + r * 256 + threadIdx.x;
+        live[r] = i < pd.a_n;
+        const uint32_t cnt = live[r] ? (uint32_t)A.p_cnt[pd.a_pos0 + i] : 0xFFFFu;
+        seed[r] = live[r] ? A.p_seed[pd.a_pos0 + i] : 0u;
+        live[r] = live[r] && cnt <= band;                                          // chain.rs:674-676
+        h[r] = mix32(seed[r]) & pd.b_mask;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) e[r] = live[r] ? tab[h[r]] : TAB_EMPTY;
     uint32_t na = 0, nq = 0;
-    for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        if (i < pd.a_n) {
-            Probe pr = probe_position(A, B, pd, pd.a_pos0 + i, band); na += pr.n_anch; nq += pr.inq;
-            pinfo_start[(uint64_t)tile * JOIN_TILE + o] = (uint32_t)(pr.b_start - pd.b_pos0);
-            pinfo_cnt[(uint64_t)tile * JOIN_TILE + o] = (uint16_t)(pr.n_anch | (pr.inq << 15));
+        uint32_t n_anch = 0, inq = 0, bstart = 0;
+        if (live[r]) {
+            unsigned long long x = e[r]; uint32_t hh = h[r];
+            while (x != TAB_EMPTY && (uint32_t)(x >> 32) != seed[r]) { hh = (hh + 1) & pd.b_mask; x = tab[hh]; }
+            if (x == TAB_EMPTY) inq = 1;                                           // absent in B: chain.rs:682-685
+            else {
+                const uint32_t cnt = (uint32_t)x & 0xFFu;
+                if (cnt <= band) { inq = 1; n_anch = cnt; bstart = ((uint32_t)x >> 8) & 0xFFFFFFu; }   // else chain.rs:694-696: dropped entirely
+            }
         }
+        if (i < pd.a_n) {
+            pinfo_start[(uint64_t)tile * JOIN_TILE + o] = bstart;
+            pinfo_cnt[(uint64_t)tile * JOIN_TILE + o] = (uint16_t)(n_anch | (inq << 15));
+        }
+        na += n_anch; nq += inq;
     }
     na = wave_sum(na); nq = wave_sum(nq);
     const uint32_t w = threadIdx.x >> 6;
@@ -790,7 +794,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
         const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
         pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.b_pos0 = B->pos_off[gb]; pd.b_dist0 = B->dist_off[gb]; pd.b_tab0 = B->tab_off[gb]; pd.b_mask = B->tab_mask[gb];
+        pd.b_pos0 = B->pos_off[gb]; pd.reserved0 = 0; pd.b_tab0 = B->tab_off[gb]; pd.b_mask = B->tab_mask[gb];
         pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
         pd.tile0 = (uint32_t)tile_pair.size();
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];

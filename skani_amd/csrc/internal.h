@@ -88,9 +88,8 @@ struct skh_sketch_set {
     skh::DBuf<uint32_t> p_seed, p_pos, p_cc;       // position order (contig, pos)
     skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)
     skh::DBuf<uint32_t> s_pos, s_cc;               // seed order (seed, contig, pos)
-    skh::DBuf<uint32_t> u_seed, u_start;           // distinct seeds: value, start in the genome's seed-order arrays
-    skh::DBuf<uint16_t> u_cnt;                     // distinct seeds: multiplicity (clamped)
-    skh::DBuf<uint64_t> table;                     // open addressing: (seed<<32 | local distinct idx), TAB_EMPTY
+    skh::DBuf<uint64_t> table;                     // open addressing: seed << 32 | start (24 bits, in the genome's seed-order
+                                                   // arrays) << 8 | min(multiplicity, 255); TAB_EMPTY
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_ctg_len;
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_tab_off;

@@ -3,8 +3,8 @@
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
 //   position order : p_seed/p_pos/p_cc (+ p_cnt = multiplicity of the entry's seed in this genome)  -- enumeration side
-//   seed order     : s_pos/s_cc sorted by (seed, contig, pos); u_seed/u_start/u_cnt = CSR over distinct seeds
-//   hash table     : open addressing, 64-bit slots (seed << 32 | distinct index), load <= 0.6              -- probe side
+//   seed order     : s_pos/s_cc sorted by (seed, contig, pos)
+//   hash table     : open addressing, 64-bit slots seed << 32 | start << 8 | multiplicity, load <= 0.6       -- probe side
 //   markers        : sorted unique u64
 #include <algorithm>
 
@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
     if (i < n) out[i] = src[idx[i]];
 }
 
-__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* u_seed, const uint64_t* dist_off, uint32_t ng, uint64_t n_dist,
-                                                           const uint64_t* tab_off, const uint32_t* tab_mask, uint64_t* table) {
+__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* u_seed, const uint32_t* u_start, const uint16_t* u_cnt, const uint64_t* dist_off,
+                                                           uint32_t ng, uint64_t n_dist, const uint64_t* tab_off, const uint32_t* tab_mask, uint64_t* table) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_dist) return;
     const uint32_t g = seg_of(dist_off, ng, d);
     const uint32_t seed = u_seed[d], mask = tab_mask[g];
-    const unsigned long long entry = ((unsigned long long)seed << 32) | (uint32_t)(d - dist_off[g]);
+    const uint32_t cnt = u_cnt[d] > 255 ? 255u : (uint32_t)u_cnt[d];
+    // one 8-byte slot answers a probe completely: seed | first entry in the seed-order arrays | multiplicity
+    const unsigned long long entry = ((unsigned long long)seed << 32) | ((unsigned long long)(u_start[d] & 0xFFFFFFu) << 8) | cnt;
     unsigned long long* tab = (unsigned long long*)(table + tab_off[g]);
     uint32_t h = mix32(seed) & mask;
     for (;;) {
@@ -85,7 +87,10 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->s_pos.alloc(P); ss->s_cc.alloc(P); ss->p_cnt.alloc(P);
     ss->dist_off.assign(ng + 1, 0);
+    for (uint32_t g = 0; g < ng; g++)
+        if (ss->pos_off[g + 1] - ss->pos_off[g] >= (1ull << 24)) throw Error("a genome with >= 2^24 seed positions does not fit the 24-bit table slot field");
     uint64_t D = 0;
+    uint32_t *u_seed = nullptr, *u_start = nullptr; uint16_t* u_cnt = nullptr;       // CSR over distinct seeds: build-time temporaries
     if (P > 0) {
         if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
         uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P);
@@ -104,13 +109,13 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
         d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
         for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
         D = ss->dist_off[ng];
-        ss->u_seed.alloc(D); ss->u_start.alloc(D); ss->u_cnt.alloc(D);
+        u_seed = ctx->arena.get<uint32_t>(D); u_start = ctx->arena.get<uint32_t>(D); u_cnt = ctx->arena.get<uint16_t>(D);
         SKH_LAUNCH(distinct_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)head, (const uint32_t*)excl, P,
-                   (const uint64_t*)ss->d_pos_off.p, ss->u_seed.p, ss->u_start.p, ss->u_cnt.p);
+                   (const uint64_t*)ss->d_pos_off.p, u_seed, u_start, u_cnt);
         check_launch("distinct");
         SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
                    (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_pos.p, (const uint32_t*)ss->p_cc.p,
-                   (const uint16_t*)ss->u_cnt.p, ss->s_pos.p, ss->s_cc.p, ss->p_cnt.p);
+                   (const uint16_t*)u_cnt, ss->s_pos.p, ss->s_cc.p, ss->p_cnt.p);
         check_launch("seed_order_gather");
     }
     // hash tables (north-star requirement: per-sketch seed -> position tables built on device)
@@ -127,8 +132,9 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
     ss->d_tab_off.alloc(ng + 1); h2d(ss->d_tab_off.p, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_tab_mask.alloc(ng ? ng : 1); h2d(ss->d_tab_mask.p, ss->tab_mask.data(), ng * 4, ctx->stream);
     if (D > 0) {
-        SKH_LAUNCH(table_insert_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->u_seed.p,
-                   (const uint64_t*)ss->d_dist_off.p, ng, D, (const uint64_t*)ss->d_tab_off.p, (const uint32_t*)ss->d_tab_mask.p, ss->table.p);
+        SKH_LAUNCH(table_insert_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)u_seed, (const uint32_t*)u_start,
+                   (const uint16_t*)u_cnt, (const uint64_t*)ss->d_dist_off.p, ng, D, (const uint64_t*)ss->d_tab_off.p, (const uint32_t*)ss->d_tab_mask.p,
+                   ss->table.p);
         check_launch("table_insert");
     }
     dsync(ctx->stream);

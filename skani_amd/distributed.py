@@ -1,36 +1,105 @@
 """Multi-GPU triangle: one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
 
-The path shards: sketching is per genome, chaining per pair.  The only exchange is an all-gather of the
-raw sketches so that every rank holds the full set; after that the screened pair list is split round-robin and there is
-no collective until the (small) result gather on rank 0."""
+The path shards: sketching is per genome, chaining per pair.  Genomes are block-distributed; every rank
+sketches its own block.  Exchange steps:
+  1. all-gather of the MARKER sets + per-genome metadata only (~40 KB per 5 Mbp genome) -> every rank runs the screen
+     over the full set and obtains the same global candidate pair list;
+  2. pair (i, j), i < j, is owned by the rank that owns genome i; a rank therefore needs the full sketch of a remote
+     genome j only when a candidate pair crosses blocks.  Exactly those sketches travel point-to-point (all-to-all of
+     variable-size buffers).  For clade-structured collections almost nothing moves; in the worst case (every pair
+     crosses) it degenerates to an all-gather of the raw sketches.
+No collective inside the pair pipeline; the (small) results are gathered on rank 0."""
+import pickle
+
 import numpy as np
 
 from . import _binding as B
 
 
-def exchange_sketches(ctx, ss_local, params, dist, world):
-    """All-gather position-ordered seeds, markers and contig tables of every rank's genomes; rebuild the derived
-    tables (seed order, CSR, hash tables) locally.  Genome order = rank order, so global ids are contiguous blocks."""
+def _all_to_all_bytes(dist, torch, device, payloads):
+    """payloads[r] = bytes for rank r -> list of bytes received from every rank."""
+    world = len(payloads)
+    sizes = torch.tensor([len(p) for p in payloads], dtype=torch.int64, device=device)
+    rsizes = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(rsizes, sizes)
+    rs = [int(x) for x in rsizes.cpu()]
+    send = torch.frombuffer(bytearray(b"".join(payloads)) or bytearray(1), dtype=torch.uint8)[:sum(len(p) for p in payloads)].to(device)
+    recv = torch.empty(sum(rs), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[len(p) for p in payloads])
+    buf = recv.cpu().numpy().tobytes()
+    out, o = [], 0
+    for n in rs:
+        out.append(buf[o:o + n]); o += n
+    return out
+
+
+def _marker_record(ss, g):
+    e = ss.export(g)
+    return dict(seed=np.zeros(0, np.uint32), pos=np.zeros(0, np.uint32), ctgcanon=np.zeros(0, np.uint32), markers=e["markers"],
+                contig_lengths=e["contig_lengths"], total_len=e["total_len"])
+
+
+def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, identity=0.0, rescue_small=True, torch=None, device=None):
+    """ss_local: this rank's block of sketches, created with genome_rank = GLOBAL genome index; all blocks have the same
+    size.  Returns (i, j, results, n_chained_total) with global indices, sorted by (i, j), on rank 0; (None, None, None, n)
+    on the other ranks."""
     if world == 1:
-        return ss_local
-    per = [ss_local.export(g) for g in range(len(ss_local))]
+        return ctx.triangle(ss_local, map_params, identity, rescue_small)
+    n_local = len(ss_local)
+    base = rank * n_local
+    # 1. markers + metadata of every genome, everywhere
+    mine = [_marker_record(ss_local, g) for g in range(n_local)]
     gathered = [None] * world
-    dist.all_gather_object(gathered, per)
-    allg = [d for part in gathered for d in part]
-    return ctx.import_sketches(params, allg, genome_rank=np.arange(len(allg), dtype=np.uint32))
-
-
-def distributed_triangle(ctx, ss_all, map_params, dist, rank, world, identity=0.0, rescue_small=True):
-    """Every rank screens the full set, chains pairs rank, rank+world, ... and rank 0 receives all kept results
-    sorted by (i, j).  Returns (i, j, results, n_chained_total) on rank 0 and (None, None, None, n) elsewhere."""
-    i, j, res, n_chained = ctx.triangle(ss_all, map_params, identity, rescue_small, part=rank, n_parts=world)
-    if world == 1:
-        return i, j, res, n_chained
+    dist.all_gather_object(gathered, mine)
+    allm = [d for part in gathered for d in part]
+    n_total = len(allm)
+    markers_only = ctx.import_sketches(params, allm, genome_rank=np.arange(n_total, dtype=np.uint32))
+    gi, gj = ctx.screen(markers_only, None, identity, 0, rescue_small)          # identical on every rank
+    markers_only.close()
+    owner_i = gi // n_local; owner_j = gj // n_local
+    # 2. sketches of remote partners j of my rows i, fetched point-to-point
+    send_lists = []
+    for r in range(world):
+        need = np.unique(gj[(owner_i == r) & (owner_j == rank) & (r != rank)]) if r != rank else np.zeros(0, np.uint32)
+        send_lists.append(need)                                                    # my genomes that rank r needs
+    payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in send_lists]
+    if torch is None:
+        import torch as _t
+        torch = _t
+    if device is None:
+        device = torch.device("cpu")
+    received = _all_to_all_bytes(dist, torch, device, payloads)
+    remote = {}
+    for blob in received:
+        for g, rec in pickle.loads(blob):
+            remote[g] = rec
+    rem_ids = sorted(remote)
+    rem_index = {g: k for k, g in enumerate(rem_ids)}
+    my = owner_i == rank
+    li, lj = gi[my], gj[my]
+    local_pair = (lj // n_local) == rank
+    res_parts = []
+    n_chained = int(my.sum())
+    if local_pair.any():
+        r = ctx.chain_pairs(ss_local, None, li[local_pair] - base, lj[local_pair] - base, map_params)
+        res_parts.append((li[local_pair], lj[local_pair], r))
+    if (~local_pair).any():
+        ss_rem = ctx.import_sketches(params, [remote[g] for g in rem_ids], genome_rank=np.array(rem_ids, dtype=np.uint32))
+        qi = np.array([rem_index[int(g)] for g in lj[~local_pair]], dtype=np.uint32)
+        r = ctx.chain_pairs(ss_local, ss_rem, li[~local_pair] - base, qi, map_params)      # ref = genome i (local), query = genome j (remote)
+        res_parts.append((li[~local_pair], lj[~local_pair], r))
+        ss_rem.close()
+    if res_parts:
+        ai = np.concatenate([p[0] for p in res_parts]); aj = np.concatenate([p[1] for p in res_parts]); ar = np.concatenate([p[2] for p in res_parts])
+        keep = ar["ani"] > 0.1                                                       # triangle.rs:99
+        ai, aj, ar = ai[keep], aj[keep], ar[keep]
+    else:
+        ai = np.zeros(0, np.uint32); aj = np.zeros(0, np.uint32); ar = np.zeros(0, B.RESULT_DTYPE)
     parts = [None] * world if rank == 0 else None
-    dist.gather_object((i, j, res, n_chained), parts, dst=0)
+    dist.gather_object((ai, aj, ar, n_chained), parts, dst=0)
     if rank != 0:
         return None, None, None, n_chained
     ai = np.concatenate([p[0] for p in parts]); aj = np.concatenate([p[1] for p in parts])
     ar = np.concatenate([p[2] for p in parts]).view(B.RESULT_DTYPE)
     order = np.lexsort((aj, ai))
-    return ai[order], aj[order], ar[order], sum(p[3] for p in parts)
+    return ai[order].astype(np.uint32), aj[order].astype(np.uint32), ar[order], sum(p[3] for p in parts)

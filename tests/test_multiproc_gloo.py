@@ -15,25 +15,31 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _test_genomes():
+    """3 clades x 4 members, interleaved so that most candidate pairs cross the two rank blocks."""
+    from tests.parity_cases import synthetic_clades
+    g = synthetic_clades(n_clades=3, members=4, length=60000, seed=51, tiny=False)
+    return [g[(k % 3) * 4 + k // 3] for k in range(12)]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     import skani_amd as sk
-    from skani_amd.distributed import distributed_triangle, exchange_sketches
+    from skani_amd.distributed import distributed_triangle
     from tests.emu_lib import emu_lib
     from tests.parity_cases import synthetic_clades
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ctx = sk.Context(0, lib=emu_lib())
-        genomes = synthetic_clades(n_clades=2, members=4, length=60000, seed=51, tiny=False)
+        genomes = _test_genomes()
         per = len(genomes) // world
         mine = genomes[rank * per:(rank + 1) * per]
         params = sk.SketchParams()
-        ss_local = ctx.sketch_records(mine, params, None)
-        ss_all = exchange_sketches(ctx, ss_local, params, dist, world)
-        assert len(ss_all) == len(genomes)
-        i, j, res, n = distributed_triangle(ctx, ss_all, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world)
+        gs = ctx.pack_genomes([[s for _, s in g] for g in mine], params.seeding_mode)
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(rank * per, (rank + 1) * per)))
+        i, j, res, n = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world)
         if rank == 0:
             q.put((i, j, res, n))
     finally:
@@ -55,7 +61,7 @@ def test_two_rank_triangle_matches_single_process():
     i, j, res, n = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60); assert p.exitcode == 0
-    genomes = synthetic_clades(n_clades=2, members=4, length=60000, seed=51, tiny=False)
+    genomes = _test_genomes()
     # oracle: genome ranks are the global indices (names sort like indices)
     osk = [ora.sketch_records(g, file_name="g%03d" % k) for k, g in enumerate(genomes)]
     oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
