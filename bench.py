@@ -77,8 +77,9 @@ def make_genomes(torch, device, first_clade, n_clades, members=CLADE, mean_len=5
     return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), g_idx, host_genomes
 
 
-def cpu_baseline(host_genomes, n_full, chained_full, threads):
-    """Times the oracle (port of the reference algorithms; kind = 'port') on the sample with all host cores."""
+def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
+    """Times the oracle (port of the reference algorithms; kind = 'port') on the sample with all host cores and, when the
+    GPU triangle result is given, reports the metric's "ANI delta vs ref" on the sample's pairs."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as ora
     names = ["s%04d.fa" % i for i in range(len(host_genomes))]
@@ -94,7 +95,19 @@ def cpu_baseline(host_genomes, n_full, chained_full, threads):
     sketch_s, chain_s = t1 - t0, t2 - t1
     # per-unit costs -> the same workload the GPU ran (sketching is linear in genomes, chaining in chained pairs)
     est_full = sketch_s / n * n_full + chain_s / max(n_chained, 1) * chained_full
-    return {"value": (n_full * (n_full - 1) // 2) / est_full, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+    delta = None
+    if gpu_result is not None:
+        gi, gj, gres = gpu_result
+        sel = (gi < n) & (gj < n)
+        gkeys = gi[sel].astype(np.int64) * n + gj[sel]; okeys = oi.astype(np.int64) * n + oj
+        same = len(gkeys) == len(okeys) and bool(np.array_equal(gkeys, okeys))
+        delta = {"pairs_compared": int(len(okeys)), "same_pair_set": same}
+        if same and len(okeys):
+            g = gres[sel]
+            for f in ("ani", "af_ref", "af_query"):
+                delta["max_abs_d_" + f] = float(np.max(np.abs(g[f].astype(np.float64) - res[f].astype(np.float64))))
+            delta["int_fields_equal"] = bool(all(np.array_equal(g[f], res[f]) for f in ("avg_chain_int_len", "total_bases_covered", "num_contigs_q", "num_contigs_r")))
+    return {"value": (n_full * (n_full - 1) // 2) / est_full, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "delta_vs_oracle": delta,
             "sample": "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + screen/chain of %d pairs (%d chained) %.2f s on %d threads; "
                       "value = full-workload pairs / (per-genome sketch cost x %d + per-chained-pair cost x %d)" %
                       (n, n // CLADE, CLADE, bases / 1e6, sketch_s, pairs, n_chained, chain_s, threads, n_full, chained_full),
@@ -144,10 +157,12 @@ def main():
     ctx.timings()
 
     from skani_amd.distributed import distributed_triangle
+    last = {}
 
     def step():
         ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32))
         i, j, res, n_chained = distributed_triangle(ctx, ss_local, params, mp, dist, rank, world, torch=torch, device=device)
+        last["result"] = (i, j, res)
         return (len(i) if i is not None else 0), n_chained
 
     for _ in range(args.warmup):
@@ -205,7 +220,7 @@ def main():
                      "note": "0.354 algorithmic B/base; kernel is VALU-bound (64-bit hash mix per base), see DESIGN.md"},
     }
     if host_genomes:
-        out["cpu_baseline"] = cpu_baseline(host_genomes, n_total, chained, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(host_genomes, n_total, chained, os.cpu_count() or 1, last.get("result"))
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -41,6 +41,13 @@ def _default_lib():
         if not os.path.exists(path):
             raise SkaniHipError(f"{path} is missing: build it with `python -m skani_amd.build` (hipcc, gfx950). "
                                 "skani_amd has no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime under the same soname (libamdhip64.so.7) as /opt/rocm's: whichever is
+        # loaded first serves the whole process.  Torch cannot run on the system runtime, the library can run on
+        # torch's, so torch (when installed) goes first.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _DEFAULT_LIB = B.load(path)
     return _DEFAULT_LIB
 

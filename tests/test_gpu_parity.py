@@ -79,3 +79,38 @@ def test_many_genomes_batching(ctx):
     parts = [ctx.triangle(ss, sk.MapParams(compute_ci=True), part=r, n_parts=3) for r in range(3)]
     allp = sorted((int(a), int(b)) for pi, pj, _, _ in parts for a, b in zip(pi, pj))
     assert allp == sorted(zip(i.tolist(), j.tolist()))
+
+
+def test_full_size_genomes_properties_and_oracle_sample(ctx):
+    """BASELINE-sized genomes (~5 Mbp, generated on the GPU like bench.py): size-independent properties on 100 genomes
+    (every within-clade pair chained and kept, nothing across clades, ANI decreasing with divergence, self-consistency
+    of the sharded run) plus field-by-field comparison with the oracle on one clade (190 pairs)."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    bases, coff, cgen, ng, host = bench.make_genomes(torch, dev, 0, 5, keep_ascii_clades=1)
+    torch.cuda.synchronize()
+    gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+    assert gs.total_bases == int(coff[-1])
+    ss = ctx.sketch_genomes(gs, sk.SketchParams(), genome_rank=np.arange(ng, dtype=np.uint32))
+    del bases
+    mp = sk.MapParams(learned_ani=True, compute_ci=True)
+    i, j, res, nch = ctx.triangle(ss, mp)
+    assert nch == 5 * 190 and len(i) == 5 * 190
+    assert ((i // 20) == (j // 20)).all()                       # only within-clade pairs survive the screen
+    assert (res["ani"] > 0.80).all() and (res["ani"] <= 1.0).all() and (res["af_ref"] > 0.25).all()
+    # sharded == whole
+    parts = [ctx.triangle(ss, mp, part=r, n_parts=4) for r in range(4)]
+    got = sorted((int(a), int(b), float(r["ani"])) for pi, pj, pr, _ in parts for a, b, r in zip(pi, pj, pr))
+    assert got == sorted((int(a), int(b), float(r["ani"])) for a, b, r in zip(i, j, res))
+    # oracle on clade 0 (host copies of the same bytes)
+    from tests.helpers import MODEL_C125
+    names = ["s%04d.fa" % k for k in range(20)]
+    osk = [ora.sketch_records(g, file_name=names[k]) for k, g in enumerate(host)]
+    for k in (0, 7, 19):
+        pc.assert_sketch_equal(ss, k, osk[k])
+    oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+    sel = (i < 20) & (j < 20)
+    assert np.array_equal(i[sel], oi) and np.array_equal(j[sel], oj)
+    for x, y in zip(res[sel], ores):
+        pc.assert_result_close(x, y)
