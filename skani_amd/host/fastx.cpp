@@ -1,0 +1,98 @@
+// fastx.cpp -- FASTA(.gz) ingest with the record semantics of needletail as used by file_io.rs:158-181.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include "host.hpp"
+
+namespace skhost {
+
+static std::string slurp(const std::string& path) {
+    gzFile f = gzopen(path.c_str(), "rb");          // transparently reads plain files too
+    if (!f) throw std::runtime_error("cannot open " + path);
+    gzbuffer(f, 1 << 20);
+    std::string data; std::vector<char> buf(1 << 22);
+    for (;;) {
+        int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n < 0) { gzclose(f); throw std::runtime_error("read error in " + path); }
+        if (n == 0) break;
+        data.append(buf.data(), (size_t)n);
+    }
+    gzclose(f);
+    return data;
+}
+
+std::vector<Record> read_fasta(const std::string& path) {
+    const std::string data = slurp(path);
+    std::vector<Record> out;
+    size_t p = 0, n = data.size();
+    while (p < n && (data[p] == '\n' || data[p] == '\r' || data[p] == ' ' || data[p] == '\t')) p++;
+    if (p == n) return out;
+    if (data[p] != '>') throw std::runtime_error(path + " is not a valid fasta file");
+    while (p < n) {
+        size_t eol = data.find('\n', p);
+        if (eol == std::string::npos) eol = n;
+        Record r;
+        r.name = data.substr(p + 1, eol - p - 1);
+        while (!r.name.empty() && r.name.back() == '\r') r.name.pop_back();
+        size_t q = eol < n ? eol + 1 : n;
+        size_t next = data.find("\n>", eol);
+        size_t end = next == std::string::npos ? n : next + 1;
+        r.seq.reserve(end - q);
+        for (size_t i = q; i < end; i++) { const char ch = data[i]; if (ch != '\n' && ch != '\r') r.seq.push_back(ch); }
+        out.push_back(std::move(r));
+        p = end;
+    }
+    return out;
+}
+
+LoadedGenomes load_genomes(const std::vector<std::string>& files_in, bool individual_contig, int threads) {
+    constexpr size_t MIN_LENGTH_CONTIG = 500;                                   // params.rs:42, file_io.rs:176
+    std::vector<std::string> files = files_in;
+    struct PerFile { std::vector<Record> recs; bool ok = true; };
+    std::vector<PerFile> per(files.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= files.size()) break;
+            try {
+                auto recs = read_fasta(files[i]);
+                for (auto& r : recs) if (r.seq.size() >= MIN_LENGTH_CONTIG) per[i].recs.push_back(std::move(r));
+            } catch (const std::exception& e) { per[i].ok = false; fprintf(stderr, "WARN %s; skipping.\n", e.what()); }
+        }
+    };
+    int nt = std::max(1, std::min<int>(threads, (int)files.size()));
+    std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(worker); for (auto& t : th) t.join();
+    // sketches sorted by (file_name, contig_order): file_io.rs:250 / types.rs:360-364
+    std::vector<size_t> order(files.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return files[a] < files[b]; });
+    LoadedGenomes lg; lg.contig_off.push_back(0);
+    for (size_t i : order) {
+        if (!per[i].ok) { lg.skipped.push_back(files[i]); continue; }
+        if (per[i].recs.empty()) { fprintf(stderr, "WARN File %s consists of only contigs < 500 bp. Skipping this file.\n", files[i].c_str()); lg.skipped.push_back(files[i]); continue; }
+        if (!individual_contig) {
+            GenomeInfo gi; gi.file_name = files[i];
+            for (auto& r : per[i].recs) {
+                gi.contigs.push_back(r.name); gi.contig_lengths.push_back((uint32_t)r.seq.size());
+                lg.bases += r.seq; lg.contig_off.push_back(lg.bases.size()); lg.contig_genome.push_back((uint32_t)lg.info.size());
+            }
+            lg.info.push_back(std::move(gi));
+        } else {
+            for (auto& r : per[i].recs) {
+                GenomeInfo gi; gi.file_name = files[i]; gi.contigs.push_back(r.name); gi.contig_lengths.push_back((uint32_t)r.seq.size());
+                lg.bases += r.seq; lg.contig_off.push_back(lg.bases.size()); lg.contig_genome.push_back((uint32_t)lg.info.size());
+                lg.info.push_back(std::move(gi));
+            }
+        }
+    }
+    return lg;
+}
+
+}  // namespace skhost

@@ -1,0 +1,194 @@
+// main.cpp -- `skani-hip {triangle,dist}`: the reference's drivers (triangle.rs:13-169, dist.rs:12-190) over the C ABI.
+// Flag names follow cli.rs; only flags that reach the hot path or the writers are implemented.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host.hpp"
+
+using namespace skhost;
+
+namespace {
+
+struct Args {
+    std::string cmd, out, list, qlist, rlist, models_dir;
+    std::vector<std::string> files, queries, refs;
+    uint32_t c = 125, k = 15, m = 1000; bool c_set = false, m_set = false;
+    double s = 0, min_af = -1, both_min_af = -1; bool min_af_set = false;
+    bool robust = false, median = false, no_learned = false, fast = false, slow = false, medium = false, small_genomes = false, faster_small = false;
+    bool sparse = false, individual = false, qi = false, ri = false, marker_index = false;
+    size_t n = 10000000; int threads = 3, device = 0, seeding_mode = SKH_SEED_AVX2;
+    OutOpts o;
+};
+
+[[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR %s\n", m.c_str()); exit(1); }
+
+std::vector<std::string> read_list(const std::string& p) {
+    std::ifstream f(p); if (!f) die("cannot read list file " + p);
+    std::vector<std::string> v; std::string l;
+    while (std::getline(f, l)) { while (!l.empty() && (l.back() == '\r' || l.back() == ' ')) l.pop_back(); if (!l.empty()) v.push_back(l); }
+    return v;
+}
+
+Args parse(int argc, char** argv) {
+    Args a;
+    if (argc < 2) die("usage: skani-hip {triangle|dist} [options] files...");
+    a.cmd = argv[1];
+    auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
+    std::vector<std::string>* sink = &a.files;
+    for (int i = 2; i < argc; i++) {
+        std::string x = argv[i];
+        if (x == "-o") { a.out = need(i); sink = &a.files; }
+        else if (x == "-l") { a.list = need(i); }
+        else if (x == "--ql") a.qlist = need(i);
+        else if (x == "--rl") a.rlist = need(i);
+        else if (x == "-q") sink = &a.queries;
+        else if (x == "-r") sink = &a.refs;
+        else if (x == "-c") { a.c = (uint32_t)atoi(need(i).c_str()); a.c_set = true; }
+        else if (x == "-k") a.k = (uint32_t)atoi(need(i).c_str());
+        else if (x == "-m") { a.m = (uint32_t)atoi(need(i).c_str()); a.m_set = true; }
+        else if (x == "-s") a.s = atof(need(i).c_str());
+        else if (x == "-n") a.n = (size_t)atoll(need(i).c_str());
+        else if (x == "-t") a.threads = atoi(need(i).c_str());
+        else if (x == "--min-af") { a.min_af = atof(need(i).c_str()); a.min_af_set = true; }
+        else if (x == "--both-min-af") a.both_min_af = atof(need(i).c_str());
+        else if (x == "--robust") a.robust = true;
+        else if (x == "--median") a.median = true;
+        else if (x == "--no-learned-ani") a.no_learned = true;
+        else if (x == "--fast") a.fast = true;
+        else if (x == "--slow") a.slow = true;
+        else if (x == "--medium") a.medium = true;
+        else if (x == "--small-genomes") a.small_genomes = true;
+        else if (x == "--faster-small") a.faster_small = true;
+        else if (x == "-E" || x == "--sparse") a.sparse = true;
+        else if (x == "--full-matrix") a.o.full_matrix = true;
+        else if (x == "--diagonal") a.o.diagonal = true;
+        else if (x == "--distance") a.o.distance = true;
+        else if (x == "--ci") a.o.ci = true;
+        else if (x == "--detailed") a.o.detailed = true;
+        else if (x == "--short-header") a.o.short_header = true;
+        else if (x == "-i") a.individual = true;
+        else if (x == "--qi") a.qi = true;
+        else if (x == "--ri") a.ri = true;
+        else if (x == "--marker-index") a.marker_index = true;
+        else if (x == "--device") a.device = atoi(need(i).c_str());
+        else if (x == "--seeding") { std::string v = need(i); a.seeding_mode = v == "scalar" ? SKH_SEED_SCALAR : SKH_SEED_AVX2; }
+        else if (x == "--models") a.models_dir = need(i);
+        else if (x == "-v" || x == "--debug" || x == "--trace") {}
+        else if (!x.empty() && x[0] == '-') die("unknown option " + x);
+        else sink->push_back(x);
+    }
+    // presets (parse.rs:820-853)
+    if (a.fast && a.slow) die("Both --slow and --fast were set. This is not allowed.");
+    if (a.fast) a.c = 200;
+    if (a.slow) a.c = 30;
+    if (a.medium) a.c = 70;
+    if (a.small_genomes) { a.c = 30; a.m = 200; }
+    if (a.c > a.m) die("We currently don't allow c > m. -m should be larger than c.");     // params.rs:183-185
+    return a;
+}
+
+struct Ctx {
+    skh_ctx* c = nullptr;
+    void check(int rc, const char* what) { if (rc != 0) die(std::string(what) + ": " + (c ? skh_last_error(c) : "no context")); }
+};
+
+std::string models_dir(const Args& a, const char* argv0) {
+    if (!a.models_dir.empty()) return a.models_dir;
+    if (const char* e = getenv("SKANI_HIP_DATA")) return e;
+    std::string p = argv0; size_t s = p.rfind('/');
+    return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/../data";
+}
+
+skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
+    skh_sketch_params sp{a.c, a.k, a.m, (uint32_t)a.seeding_mode};
+    skh_sketch_set* ss = nullptr;
+    // genome order is already the sorted file-name order => genome_rank = index (chain.rs:20-22 tie rule)
+    cx.check(skh_sketch_batch(cx.c, (const uint8_t*)lg.bases.data(), lg.contig_off.data(), lg.contig_genome.data(), (uint32_t)lg.contig_genome.size(),
+                              (uint32_t)lg.info.size(), &sp, nullptr, &ss), "skh_sketch_batch");
+    return ss;
+}
+
+void emit(const std::string& path, const std::string& text) {
+    if (path.empty()) { fwrite(text.data(), 1, text.size(), stdout); return; }
+    FILE* f = fopen(path.c_str(), "wb"); if (!f) die("cannot write " + path);
+    fwrite(text.data(), 1, text.size(), f); fclose(f);
+}
+
+skh_map_params map_params(const Args& a, bool learned) {
+    skh_map_params mp{};
+    mp.min_af = a.min_af_set ? a.min_af / 100. : 0.15;                       // D_FRAC_COVER_CUTOFF (parse.rs:860-862)
+    mp.both_min_af = a.both_min_af / 100.;                                    // default -1/100 = disabled
+    mp.robust = a.robust; mp.median = a.median; mp.learned_ani = learned; mp.compute_ci = 1;
+    return mp;
+}
+
+int run_triangle(const Args& a, Ctx& cx) {
+    std::vector<std::string> files = a.files;
+    if (!a.list.empty()) { auto l = read_list(a.list); files.insert(files.end(), l.begin(), l.end()); }
+    if (files.empty()) die("No reference inputs found.");
+    LoadedGenomes lg = load_genomes(files, a.individual, a.threads);
+    if (lg.info.empty()) die("No genomes/sketches found.");                     // triangle.rs:46-49
+    skh_sketch_set* ss = sketch(cx, lg, a);
+    const bool learned = !a.no_learned && a.c >= 70 && !a.individual && !a.median;   // regression.rs:8-10, parse.rs:885-889
+    skh_map_params mp = map_params(a, learned);
+    const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:798
+    uint32_t *oi = nullptr, *oj = nullptr; skh_ani_result* res = nullptr; uint64_t kept = 0, chained = 0;
+    cx.check(skh_triangle(cx.c, ss, a.s / 100., rescue_small, &mp, 0, 1, &oi, &oj, &res, &kept, &chained), "skh_triangle");
+    std::vector<PairResult> pr(kept);
+    for (uint64_t x = 0; x < kept; x++) pr[x] = PairResult{oi[x], oj[x], res[x]};    // ref = i, query = j (triangle.rs:98)
+    skh_free(oi); skh_free(oj); skh_free(res);
+    if (a.sparse) emit(a.out, format_sparse(lg.info, pr, a.o));
+    else {
+        std::string ani, af; format_phylip(lg.info, pr, a.individual, a.o, ani, af);
+        emit(a.out, ani); emit(a.out.empty() ? std::string("skani_matrix.af") : a.out + ".af", af);   // file_io.rs:428,467
+    }
+    skh_sketch_set_destroy(ss);
+    return 0;
+}
+
+int run_dist(const Args& a, Ctx& cx) {
+    std::vector<std::string> q = a.queries, r = a.refs;
+    if (!a.qlist.empty()) { auto l = read_list(a.qlist); q.insert(q.end(), l.begin(), l.end()); }
+    if (!a.rlist.empty()) { auto l = read_list(a.rlist); r.insert(r.end(), l.begin(), l.end()); }
+    if (q.empty() && r.empty() && a.files.size() >= 2) { q.push_back(a.files[0]); r.assign(a.files.begin() + 1, a.files.end()); }   // cli.rs:115-121
+    if (q.empty() || r.empty()) die("No reference sketches/genomes or query sketches/genomes found.");
+    LoadedGenomes lq = load_genomes(q, a.qi, a.threads), lr = load_genomes(r, a.ri, a.threads);
+    if (lq.info.empty() || lr.info.empty()) die("No reference sketches/genomes or query sketches/genomes found.");
+    skh_sketch_set* sq = sketch(cx, lq, a); skh_sketch_set* sr = sketch(cx, lr, a);
+    const bool learned = !a.no_learned && a.c >= 70 && !a.qi && !a.ri && !a.median;   // parse.rs:752-756
+    skh_map_params mp = map_params(a, learned);
+    const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:636
+    const bool index = q.size() > 50 || a.qi || a.marker_index;                 // parse.rs:750 (FULL_INDEX_THRESH)
+    uint32_t *pq = nullptr, *prf = nullptr; uint64_t np = 0;
+    cx.check(skh_screen(cx.c, sr, sq, a.s / 100., index ? SKH_SCREEN_REFS : SKH_SCREEN_QUICK, rescue_small, &pq, &prf, &np), "skh_screen");   // dist.rs:104-122
+    std::vector<skh_ani_result> res(np);
+    cx.check(skh_chain_pairs(cx.c, sr, sq, prf, pq, np, &mp, res.data(), nullptr), "skh_chain_pairs");   // chain_seeds(ref, query): dist.rs:114
+    std::vector<PairResult> pr;
+    for (uint64_t x = 0; x < np; x++) if (res[x].ani > 0.1f) pr.push_back(PairResult{prf[x], pq[x], res[x]});   // dist.rs:115
+    skh_free(pq); skh_free(prf);
+    emit(a.out, format_query_ref_list(lr.info, lq.info, pr, a.n, a.o));
+    skh_sketch_set_destroy(sq); skh_sketch_set_destroy(sr);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Args a = parse(argc, argv);
+    Ctx cx;
+    if (skh_ctx_create(a.device, &cx.c) != 0) die("no usable MI355X device (skani-hip has no CPU path)");
+    const std::string md = models_dir(a, argv[0]);
+    cx.check(skh_load_models(cx.c, (md + "/gbdt_c125.bin").c_str(), (md + "/gbdt_c200.bin").c_str()), "skh_load_models");
+    int rc;
+    if (a.cmd == "triangle") rc = run_triangle(a, cx);
+    else if (a.cmd == "dist") rc = run_dist(a, cx);
+    else die("unknown subcommand " + a.cmd + " (supported: triangle, dist)");
+    skh_ctx_destroy(cx.c);
+    return rc;
+}

@@ -1,0 +1,139 @@
+"""C++ host side (skani_amd/host): FASTA reader and the reference's text writers (file_io.rs), CPU-only via ctypes hooks;
+plus (-m gpu) the skani-hip CLI end to end."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import skani_amd as sk
+from skani_amd import _binding as B
+from skani_amd.build import build_hip, build_host
+from skani_amd.fastx import read_fasta
+from tests.helpers import GOLDEN, golden_records, mutate
+
+
+@pytest.fixture(scope="module")
+def host():
+    build_hip()
+    lib, _ = build_host()
+    L = C.CDLL(lib)
+    for f in ("skhost_fasta_summary", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
+        getattr(L, f).restype = C.c_void_p
+    return L
+
+
+def _take(L, p):
+    s = C.string_at(p).decode(); L.skhost_free(C.c_void_p(p)); return s
+
+
+def test_fasta_reader_matches_needletail_semantics(host, tmp_path):
+    for name in ("viruses.fna", "o157_plasmid.fasta", "e.coli-W.fasta.gz", "all_ns.fa", "test.fasta"):
+        path = os.path.join(GOLDEN, name)
+        want = "".join("%s\t%d\n" % (n, len(s)) for n, s in read_fasta(path))
+        assert _take(host, host.skhost_fasta_summary(path.encode(), 0)) == want
+    recs = golden_records("viruses.fna")
+    assert _take(host, host.skhost_fasta_seq(os.path.join(GOLDEN, "viruses.fna").encode(), 2)).encode() == recs[2][1]
+    # CRLF line ends, lower case kept, no trailing newline, empty file
+    p = tmp_path / "crlf.fa"; p.write_bytes(b">a desc\r\nACGT\r\nacgn\r\n>b\r\nTT")
+    assert _take(host, host.skhost_fasta_summary(str(p).encode(), 0)) == "a desc\t8\nb\t2\n"
+    assert _take(host, host.skhost_fasta_seq(str(p).encode(), 0)) == "ACGTacgn"
+    assert _take(host, host.skhost_fasta_summary(os.path.join(GOLDEN, "empty_fasta.fa").encode(), 0)) == "test\t0\ntest_1\t1\n"
+    assert _take(host, host.skhost_fasta_summary(os.path.join(GOLDEN, "empty_fasta.fa").encode(), 500)) == ""
+    q = tmp_path / "x.txt"; q.write_text("not fasta\n")
+    assert _take(host, host.skhost_fasta_summary(str(q).encode(), 0)).startswith("ERROR")
+
+
+def _res(**kw):
+    r = np.zeros(1, B.RESULT_DTYPE)[0]
+    for k, v in kw.items():
+        r[k] = v
+    return r
+
+
+def _arr(strs):
+    a = (C.c_char_p * len(strs))(*[s.encode() for s in strs]); return a
+
+
+def test_triangle_matrix_format(host):
+    """Layout of test_results_versions/0.3.0:98-103: N, then name + lower-triangular %.2f values, 0.00 for missing pairs;
+    AF matrix always full with ref AF above / query AF below the diagonal (file_io.rs:428-461)."""
+    files = ["./test_files/GCF.fna", "./test_files/e.coli-EC590.fasta", "./test_files/e.coli-W.fasta.gz", "./test_files/o157_reads.fastq"]
+    ctg = ["c0", "c1", "c2", "c3"]; tl = np.array([1, 2, 3, 4], np.uint32)
+    res = np.zeros(3, B.RESULT_DTYPE)
+    res[0] = _res(ani=0.98581, af_ref=0.9, af_query=0.8); res[1] = _res(ani=0.92809, af_ref=0.5, af_query=0.4); res[2] = _res(ani=0.93151, af_ref=0.3, af_query=0.2)
+    ri = np.array([1, 1, 2], np.uint32); qi = np.array([2, 3, 3], np.uint32)
+    args = (4, _arr(files), _arr(ctg), tl.ctypes.data_as(C.c_void_p), 3, ri.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p))
+    txt = _take(host, host.skhost_phylip(*args, 0, 0, 0))
+    assert txt == ("4\n./test_files/GCF.fna\n./test_files/e.coli-EC590.fasta\t0.00\n./test_files/e.coli-W.fasta.gz\t0.00\t98.58\n"
+                   "./test_files/o157_reads.fastq\t0.00\t92.81\t93.15\n")
+    full = _take(host, host.skhost_phylip(*args, 16, 0, 0))
+    assert full.splitlines()[2] == "./test_files/e.coli-EC590.fasta\t0.00\t100.00\t98.58\t92.81"
+    dist = _take(host, host.skhost_phylip(*args, 32, 0, 0))
+    assert dist.splitlines()[3] == "./test_files/e.coli-W.fasta.gz\t100.00\t1.42"
+    af = _take(host, host.skhost_phylip(*args, 0, 0, 1))
+    assert af.splitlines()[2] == "./test_files/e.coli-EC590.fasta\t0.00\t100.00\t90.00\t50.00"
+    assert af.splitlines()[3] == "./test_files/e.coli-W.fasta.gz\t0.00\t80.00\t100.00\t30.00"
+    names = _take(host, host.skhost_phylip(*args, 0, 1, 0))
+    assert names.splitlines()[1] == "c0"
+
+
+def test_query_ref_list_format(host):
+    """Header and row layout of test_results_versions/0.3.0:119-121; rows grouped by query contig name and sorted by ANI."""
+    rf = ["./test_files/e.coli-K12.fasta", "./test_files/MN-03.fa"]; rc = ["NC_007779.1 Escherichia coli str. K-12 substr. W3110, complete sequence", "NZ_CP081897.1 Kleb"]
+    qf = ["./test_files/e.coli-EC590.fasta"]; qc = ["NZ_CP016182.2 Escherichia coli strain EC590 chromosome, complete genome"]
+    res = np.zeros(3, B.RESULT_DTYPE)
+    res[0] = _res(ani=0.79684, af_ref=0.2621, af_query=0.2959, ci_lower=0.78, ci_upper=0.81, std=0.01, q90_r=5e6, q50_r=5e6, q10_r=5e6, q90_q=4.9e6, q50_q=4.9e6, q10_q=4.9e6,
+                  num_contigs_r=1, num_contigs_q=1, avg_chain_int_len=2813, total_bases_covered=1234567)
+    res[1] = _res(ani=0.99424, af_ref=0.94466, af_query=0.95062)
+    res[2] = _res(ani=-1.0)
+    ri = np.array([1, 0, 0], np.uint32); qi = np.array([0, 0, 0], np.uint32)
+    tl = np.array([1, 1], np.uint32)
+    def call(flags, n=10):
+        return _take(host, host.skhost_query_ref_list(2, _arr(rf), _arr(rc), tl.ctypes.data_as(C.c_void_p), 1, _arr(qf), _arr(qc), tl.ctypes.data_as(C.c_void_p), 3,
+                                                      ri.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p), C.c_uint64(n), flags))
+    txt = call(0)
+    lines = txt.splitlines()
+    assert lines[0] == "Ref_file\tQuery_file\tANI\tAlign_fraction_ref\tAlign_fraction_query\tRef_name\tQuery_name"
+    assert lines[1] == "./test_files/e.coli-K12.fasta\t./test_files/e.coli-EC590.fasta\t99.42\t94.47\t95.06\t" + rc[0] + "\t" + qc[0]
+    assert lines[2].startswith("./test_files/MN-03.fa\t./test_files/e.coli-EC590.fasta\t79.68\t26.21\t29.59\t") and len(lines) == 3
+    assert len(call(0, n=1).splitlines()) == 2
+    det = call(2).splitlines()
+    assert det[0].endswith("Avg_chain_len\tTotal_bases_covered") and det[2].endswith("\t1\t1\t78.00\t81.00\t1.00\t5000000\t5000000\t5000000\t4900000\t4900000\t4900000\t2813\t1234567")
+    assert call(1).splitlines()[0].endswith("ANI_5_percentile\tANI_95_percentile")
+    assert call(4).splitlines()[1].endswith("\tNC_007779.1\tNZ_CP016182.2")
+
+
+@pytest.mark.gpu
+def test_cli_triangle_and_dist_end_to_end(tmp_path):
+    _, exe = build_host()
+    W = golden_records("e.coli-W.fasta.gz")
+    files = []
+    for i, rate in enumerate((0.0, 0.01, 0.03)):
+        p = tmp_path / ("g%d.fa" % i); seq = W[0][1] if rate == 0 else mutate(W[0][1], rate, 40 + i)
+        data = (">" + W[0][0] + "\n").encode() + b"\n".join(seq[k:k + 80] for k in range(0, len(seq), 80)) + b"\n"
+        if i == 2:
+            p = tmp_path / "g2.fa.gz"; p.write_bytes(gzip.compress(data, 1))
+        else:
+            p.write_bytes(data)
+        files.append(str(p))
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"))
+    out = subprocess.run([exe, "triangle"] + files, capture_output=True, text=True, cwd=tmp_path, env=env)
+    assert out.returncode == 0, out.stderr
+    ctx = sk.Context(0)
+    ss = sk.fastx_to_sketches(ctx, files, sk.SketchParams())
+    i, j, res, _ = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    lines = out.stdout.splitlines()
+    assert lines[0] == "3" and lines[1] == sorted(files)[0]
+    want = {(int(a), int(b)): "%.2f" % (float(np.float32(r["ani"]) * np.float32(100))) for a, b, r in zip(i, j, res)}
+    assert lines[2].split("\t")[1:] == [want[(0, 1)]] and lines[3].split("\t")[1:] == [want[(0, 2)], want[(1, 2)]]
+    assert os.path.exists(tmp_path / "skani_matrix.af")
+    sp = subprocess.run([exe, "triangle", "-E", "--ci"] + files, capture_output=True, text=True, cwd=tmp_path, env=env)
+    assert sp.returncode == 0 and len(sp.stdout.splitlines()) == 4 and sp.stdout.splitlines()[0].endswith("ANI_95_percentile")
+    d = subprocess.run([exe, "dist", files[0], files[1], files[2]], capture_output=True, text=True, cwd=tmp_path, env=env)
+    assert d.returncode == 0, d.stderr
+    dl = d.stdout.splitlines()
+    assert dl[0].startswith("Ref_file\tQuery_file\tANI") and len(dl) == 3
+    assert all(l.split("\t")[1] == files[0] for l in dl[1:]) and float(dl[1].split("\t")[2]) >= float(dl[2].split("\t")[2])
