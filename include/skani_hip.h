@@ -99,6 +99,10 @@ int skh_sketch_batch(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off,
                      uint32_t n_contigs, uint32_t n_genomes, const skh_sketch_params*, const uint32_t* genome_rank,
                      skh_sketch_set** out);
 void skh_sketch_set_destroy(skh_sketch_set*);
+/* Optional: the genomes' file names (copied).  Only consumer: the switch_qr tie `query_file_name > ref_file_name`
+ * (chain.rs:20-22).  When both sets of a pair carry names the strings are compared; otherwise genome_rank is used, which
+ * is only meaningful between sets ranked against a common ordering. */
+int skh_sketch_set_names(skh_sketch_set*, const char* const* names);
 
 /* sizes */
 uint32_t skh_sketch_n_genomes(const skh_sketch_set*);

@@ -30,7 +30,7 @@ STATS_DTYPE = np.dtype([(n, np.uint32) for n in ("switched", "n_chunks", "n_inte
 
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_batch", "skh_sketch_set_destroy",
-           "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_screen", "skh_chain_pairs",
+           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_screen", "skh_chain_pairs",
            "skh_triangle", "skh_get_timings"]
 
 
@@ -49,6 +49,7 @@ def load(path):
     L.skh_sketch_genomes.restype = i32; L.skh_sketch_genomes.argtypes = [vp, vp, C.POINTER(SketchParams), vp, pp]
     L.skh_sketch_batch.restype = i32; L.skh_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, C.POINTER(SketchParams), vp, pp]
     L.skh_sketch_set_destroy.restype = None; L.skh_sketch_set_destroy.argtypes = [vp]
+    L.skh_sketch_set_names.restype = i32; L.skh_sketch_set_names.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.skh_sketch_n_genomes.restype = u32; L.skh_sketch_n_genomes.argtypes = [vp]
     L.skh_sketch_sizes.restype = i32
     L.skh_sketch_sizes.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]

@@ -215,6 +215,9 @@ class SketchSet:
 
     def __init__(self, ctx, h, params, names=None):
         self.ctx, self.h, self.params, self.names = ctx, h, params, names
+        if names is not None and len(names) == len(self):
+            arr = (C.c_char_p * len(names))(*[str(n).encode() for n in names])
+            ctx.check(ctx.L.skh_sketch_set_names(h, arr))
 
     def __len__(self):
         return self.ctx.L.skh_sketch_n_genomes(self.h)
@@ -240,6 +243,18 @@ class SketchSet:
             self.close()
         except Exception:
             pass
+
+
+def fastx_to_multiple_sketch_rewrite(ctx, files, params):
+    """file_io.rs:253-362 (`-i`): one sketch per kept contig, ordered by (file name, contig order)."""
+    genomes, names = [], []
+    for f in sorted(files):
+        for n, s in read_fasta(f):
+            if len(s) >= MIN_LENGTH_CONTIG:
+                genomes.append([(n, s)]); names.append(f)
+    ss = ctx.sketch_records(genomes, params, None)     # rank = position in the sorted order (same file name => contig order)
+    ss.names = names
+    return ss
 
 
 def fastx_to_sketches(ctx, files, params):

@@ -187,6 +187,11 @@ int skh_sketch_batch(skh_ctx* ctx, const uint8_t* bases, const uint64_t* contig_
 }
 
 void skh_sketch_set_destroy(skh_sketch_set* ss) { delete ss; }
+
+int skh_sketch_set_names(skh_sketch_set* ss, const char* const* names) {
+    if (!ss || !names) return SKH_ERR_INVALID;
+    return guarded(ss->ctx, [&] { ss->names.resize(ss->n_genomes); for (uint32_t g = 0; g < ss->n_genomes; g++) ss->names[g] = names[g] ? names[g] : ""; });
+}
 uint32_t skh_sketch_n_genomes(const skh_sketch_set* ss) { return ss ? ss->n_genomes : 0; }
 
 int skh_sketch_sizes(const skh_sketch_set* ss, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers, uint32_t* n_contigs, uint64_t* total_len) {

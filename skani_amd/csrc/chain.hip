@@ -739,7 +739,10 @@ bool is_switched(const skh_sketch_set* R, uint32_t r, const skh_sketch_set* Q, u
         r_proxy = (double)(R->mk_off[r + 1] - R->mk_off[r]) * (double)R->params.c;
     } else { q_proxy = (double)Q->total_len[q]; r_proxy = (double)R->total_len[r]; }
     const double sq = q_proxy * std::min(Q->mean_ctg[q], 300000.), sr = r_proxy * std::min(R->mean_ctg[r], 300000.);
-    if (sq == sr) return Q->rank[q] > R->rank[r];                                   // query_file_name > ref_file_name
+    if (sq == sr) {                                                                 // query_file_name > ref_file_name
+        if (!Q->names.empty() && !R->names.empty()) return Q->names[q] > R->names[r];
+        return Q->rank[q] > R->rank[r];
+    }
     return sq > sr;
 }
 

@@ -84,6 +84,7 @@ struct skh_sketch_set {
     std::vector<double> mean_ctg;
     std::vector<float> q10, q50, q90;
     std::vector<uint32_t> rank;
+    std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays
     skh::DBuf<uint32_t> p_seed, p_pos, p_cc;       // position order (contig, pos)
     skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)

@@ -111,6 +111,8 @@ skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
     // genome order is already the sorted file-name order => genome_rank = index (chain.rs:20-22 tie rule)
     cx.check(skh_sketch_batch(cx.c, (const uint8_t*)lg.bases.data(), lg.contig_off.data(), lg.contig_genome.data(), (uint32_t)lg.contig_genome.size(),
                               (uint32_t)lg.info.size(), &sp, nullptr, &ss), "skh_sketch_batch");
+    std::vector<const char*> names; for (auto& g : lg.info) names.push_back(g.file_name.c_str());
+    cx.check(skh_sketch_set_names(ss, names.data()), "skh_sketch_set_names");      // exact switch_qr tie-break across ref/query sets
     return ss;
 }
 

@@ -225,3 +225,42 @@ def case_degenerate_pairs(ctx):
         for x, (i, j) in enumerate(zip(pr, pq)):
             assert_result_close(res[x], ora.chain_seeds(osk[i], osk[j], **kw), (kw, i, j))
     assert np.isnan(res[0]["ani"]) and np.isnan(res[1]["ani"])
+
+
+def case_search_resident_db(ctx):
+    """search.rs:97-282 against a database resident on the GPU, sharded in two sets; both screening rules; -n; --medium (c=70)."""
+    rng = np.random.default_rng(9)
+    genomes, names = [], []
+    for cl in range(6):
+        root = random_genome(int(rng.integers(40000, 70000)), 500 + cl)
+        for m in range(5):
+            genomes.append([("r%d_%d" % (cl, m), mutate(root, float(rng.uniform(0.002, 0.05)), cl * 17 + m))]); names.append("db%03d.fa" % len(names))
+    queries = [[("q%d" % k, mutate(genomes[g][0][1], 0.01, 900 + k))] for k, g in enumerate((0, 7, 14, 29))] + [[("alien", random_genome(50000, 4242))]]
+    qnames = ["query%d.fa" % k for k in range(len(queries))]
+    for c in (70, 125):
+        params = sk.SketchParams(c=c)
+        db = sk.build_db(ctx, genomes, params, names, shard_genomes=17)
+        assert len(db.shards) == 2 and len(db) == 30
+        qs = ctx.sketch_records(queries, params, qnames)
+        orefs = [ora.sketch_records(g, c, 15, 1000, names[i]) for i, g in enumerate(genomes)]
+        oqs = [ora.sketch_records(g, c, 15, 1000, qnames[i]) for i, g in enumerate(queries)]
+        model = ora.Model(MODEL_C125) if c >= 70 else None
+        for use_index in (False, True):
+            q, r, res = sk.search(ctx, db, qs, use_index=use_index)
+            want = {}
+            for qi, oq in enumerate(oqs):
+                if use_index:
+                    cand = [int(x) for x in ora.screen_refs(orefs, oq, 0.8, 2, False)]
+                else:
+                    cand = [ri for ri in range(len(orefs)) if ora.check_markers_quickly(orefs[ri], oq, 0.8, False)]
+                for ri in cand:
+                    o = ora.chain_seeds(orefs[ri], oq, min_af=-1.0, model=model)
+                    if o.ani > 0.5:
+                        want[(qi, ri)] = o
+            assert sorted(zip(q.tolist(), r.tolist())) == sorted(want), (c, use_index)
+            for a, b, x in zip(q, r, res):
+                assert_result_close(x, want[(int(a), int(b))], (c, use_index, int(a), int(b)))
+            assert all(res["ani"][i] >= res["ani"][i + 1] for i in range(len(q) - 1) if q[i] == q[i + 1])
+        q1, r1, res1 = sk.search(ctx, db, qs, n_max=2)
+        assert max(np.bincount(q1)) <= 2 and not (q1 == 4).any()
+        db.close()

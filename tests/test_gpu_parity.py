@@ -114,3 +114,6 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
     assert np.array_equal(i[sel], oi) and np.array_equal(j[sel], oj)
     for x, y in zip(res[sel], ores):
         pc.assert_result_close(x, y)
+
+
+def test_search_resident_db(ctx): pc.case_search_resident_db(ctx)
