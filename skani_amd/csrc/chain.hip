@@ -439,11 +439,103 @@ __device__ __forceinline__ int ivl_cmp(const Interval& a, const Interval& b) {  
     return 0;
 }
 
-constexpr uint32_t GREEDY_LDS = 2048;   // sorted-index slots per wave kept in LDS; larger pairs sort in their global scratch
+constexpr uint32_t GREEDY_LDS = 2048;   // sorted-index slots per wave kept in LDS by the fallback kernel
+constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidate intervals take the all-LDS kernel
 
-// One wave per pair: bitonic-sort the pair's candidate interval indices into DESCENDING tuple order (chain.rs:1012),
-// then accept greedily (chain.rs:1017-1095).  An accepted interval is flagged in bit 31 of its sorted slot and pushed
-// on its chunk's list (good_non_overlap_intervals[chunk_id], order-free downstream).
+// Fast path (n <= GREEDY_FAST candidates): one wave per pair, two waves per workgroup, everything staged in LDS.
+//   1. bitonic sort of (key, index) with key = score(24) | anchors(20) | top 20 bits of q0; key ties (rare) fall back to
+//      the full tuple comparison -> the reference's descending order (chain.rs:1012);
+//   2. greedy acceptance 64 candidates at a time: every lane owns one candidate and sums its overlaps against the
+//      accepted list (uniform LDS broadcasts, no reductions); the 64 decisions are then resolved in order, an accepted
+//      candidate's interval being broadcast (v_readlane) to the later lanes of the same batch (chain.rs:1017-1095).
+__global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt, const Interval* ivls,
+                                                          uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    __shared__ unsigned long long lds_key[2][GREEDY_FAST];
+    __shared__ uint32_t lds_idx[2][GREEDY_FAST];
+    __shared__ uint32_t lds_acc[2][6][GREEDY_FAST];      // accepted intervals: rctg, r0, r1, qctg, q0, q1
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 2 + wv;
+    if (p >= n_pairs) return;
+    const uint32_t l = lane_id();
+    const uint32_t I0 = pi0[p];
+    uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
+    if (n > GREEDY_FAST) return;                                                    // handled by greedy_kernel
+    if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
+    uint32_t N = 1; while (N < n) N <<= 1;
+    unsigned long long* key = lds_key[wv]; uint32_t* idx = lds_idx[wv];
+    const Interval* iv = ivls + I0;
+    for (uint32_t i = l; i < N; i += 64) {
+        unsigned long long kx = 0; uint32_t ix = NONE;
+        if (i < n) { const Interval e = iv[i]; kx = ((unsigned long long)e.score << 40) | ((unsigned long long)(e.na & 0xFFFFFu) << 20) | (e.q0 >> 12); ix = i; }
+        key[i] = kx; idx[i] = ix;
+    }
+    wave_sync_mem();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = l; t < N / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;   // the t-th compare-exchange pair of this pass
+                const uint32_t a = idx[i], b = idx[x];
+                const unsigned long long ka = key[i], kb = key[x];
+                const bool up = (i & k) == 0;
+                // first/second: swap iff `first` must precede `second` in the final (descending, padding last) order
+                const uint32_t f = up ? b : a, s2 = up ? a : b;
+                const unsigned long long kf = up ? kb : ka, ks = up ? ka : kb;
+                bool sw;
+                if (f == NONE) sw = false; else if (s2 == NONE) sw = true;
+                else if (kf != ks) sw = kf > ks; else sw = ivl_cmp(iv[f], iv[s2]) > 0;
+                if (sw) { idx[i] = b; idx[x] = a; key[i] = kb; key[x] = ka; }
+            }
+            wave_sync_mem();
+        }
+    }
+    uint32_t (*acc)[GREEDY_FAST] = lds_acc[wv];
+    uint32_t nacc = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t s = base + l;
+        const bool have = s < n;
+        const uint32_t ci = have ? idx[s] : 0;
+        Interval c = iv[ci];
+        uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
+        for (uint32_t a = 0; a < nacc; a++) {                                      // uniform index: LDS broadcast
+            const uint32_t actg = acc[0][a], ar0 = acc[1][a], ar1 = acc[2][a], aqc = acc[3][a], aq0 = acc[4][a], aq1 = acc[5][a];
+            const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;             // chain.rs:1030-1045
+            const bool hq = aqc == c.qctg && aq0 < c.q1 && c.q0 < aq1;              // chain.rs:1059-1073
+            const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
+            cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+            cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+        }
+        const uint32_t nb = n - base < 64 ? n - base : 64;
+        for (uint32_t b = 0; b < nb; b++) {
+            const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+            const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
+            const int okb = wave_readlane((int)((ok_r && ok_q) ? 1 : 0), (int)b);
+            if (okb) {                                                             // wave-uniform
+                const uint32_t actg = wave_readlane(c.rctg, (int)b), ar0 = wave_readlane(c.r0, (int)b), ar1 = wave_readlane(c.r1, (int)b);
+                const uint32_t aqc = wave_readlane(c.qctg, (int)b), aq0 = wave_readlane(c.q0, (int)b), aq1 = wave_readlane(c.q1, (int)b);
+                const uint32_t bci = wave_readlane(ci, (int)b), bchunk = wave_readlane(c.chunk, (int)b);
+                if (l > b) {                                                       // later candidates of this batch see the new accepted interval
+                    const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;
+                    const bool hq = aqc == c.qctg && aq0 < c.q1 && c.q0 < aq1;
+                    const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
+                    cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+                    cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+                }
+                if (l == 0) {
+                    acc[0][nacc] = actg; acc[1][nacc] = ar0; acc[2][nacc] = ar1; acc[3][nacc] = aqc; acc[4][nacc] = aq0; acc[5][nacc] = aq1;
+                    const uint32_t slot = pc0[p] + bchunk;
+                    ivl_next[I0 + bci] = chunk_head[slot]; chunk_head[slot] = I0 + bci;   // good_non_overlap_intervals[chunk_id].push
+                }
+                nacc++;
+            }
+        }
+        wave_sync_mem();
+    }
+    if (l == 0) n_accepted[p] = nacc;
+}
+
+// Fallback for pairs with more than GREEDY_FAST candidate intervals: one wave per pair: bitonic-sort the pair's candidate
+// interval indices into DESCENDING tuple order (chain.rs:1012), then accept greedily (chain.rs:1017-1095).  An accepted
+// interval is flagged in bit 31 of its sorted slot and pushed on its chunk's list.
 __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
                                                      const Interval* ivls, uint32_t* sorted_glob, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ uint32_t lds_idx[4][GREEDY_LDS];
@@ -453,7 +545,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
-    if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
+    if (n <= GREEDY_FAST) return;                                                   // handled by greedy_fast_kernel
     uint32_t N = 1; while (N < n) N <<= 1;                                          // ps0 reserves pow2(cap) >= N slots per pair
     uint32_t* idx = N <= GREEDY_LDS ? lds_idx[wv] : sorted_glob + ps0[p];
     const Interval* iv = ivls + I0;
@@ -505,64 +597,74 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
 }
 
 // ------------------------------------------------------------------------------------------------ per-chunk ANI inputs
-// chain.rs:199-413.  One wave per chunk: walk the chunk's accepted intervals, then count the chunk's query seed
-// positions that fall inside the union of the (padded) intervals and inside the covered range.
-constexpr uint32_t STATS_MAXI = 32;   // intervals of one chunk cached in LDS (more -> slow path re-walks the list)
+// chain.rs:199-413.  One THREAD per chunk (a chunk owns ~1-3 accepted intervals and ~160 query seed positions): walk the
+// chunk's accepted intervals, then count the chunk's query seed positions that fall inside the union of the (padded)
+// intervals and inside the covered range; finally the chunk's ANI estimate and weight.
+constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more -> slow path re-walks the list per position)
 
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
                                                           const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_pos,
                                                           uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint32_t* pair_tqb, uint32_t* pair_acl,
                                                           uint32_t* pair_nchains) {
-    __shared__ uint32_t lds_lo[4][STATS_MAXI], lds_hi[4][STATS_MAXI];
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
-    const uint32_t l = lane_id();
     const uint32_t head = chunk_head[slot];
-    if (l == 0) chunk_w[slot] = NONE;                                               // NONE = no estimate from this chunk
+    chunk_w[slot] = NONE;                                                           // NONE = no estimate from this chunk
     if (head == NONE) return;                                                       // total_anchors == 0 (chain.rs:253)
     const Chunk ck = chunks[slot];
     const uint32_t p = chunk_pair[slot];
     const bool switched = (pairs[p].flags & 4u) != 0;
     uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0;
-    for (uint32_t e = head; e != NONE; e = ivl_next[e]) {                           // wave-uniform walk
+    uint32_t lo[STATS_REG], hi[STATS_REG];
+#pragma unroll
+    for (int i = 0; i < STATS_REG; i++) { lo[i] = 1; hi[i] = 0; }                   // empty
+    for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
         const Interval iv = ivls[e];
         total_anchors += iv.na;
         if (iv.q0 < rq0) rq0 = iv.q0;
         if (iv.q1 > rq1) rq1 = iv.q1;
         tbcq += (switched ? iv.r1 - iv.r0 : iv.q1 - iv.q0) + k + 2 * c;             // chain.rs:223-237
         sum_len += (iv.q1 - iv.q0) + 2 * c + k;                                     // chain.rs:245-249 (overlap is always 0, chain.rs:1091-1093)
-        if (n_int < STATS_MAXI && l == 0) { lds_lo[wv][n_int] = iv.q0 > c ? iv.q0 - c : 0; lds_hi[wv][n_int] = iv.q1 + c; }   // chain.rs:239-242
+        const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0, h0 = iv.q1 + c;              // chain.rs:239-242
+#pragma unroll
+        for (int i = 0; i < STATS_REG; i++) if (n_int == (uint32_t)i) { lo[i] = l0; hi[i] = h0; }
         n_int++;
     }
-    wave_sync_mem();
     const bool sensitive = c < 200;                                                 // chain.rs:184-190
-    if (l == 0) {
-        if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
-        atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
-    }
+    if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
+    atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
     if (rq1 - rq0 < MIN_LENGTH_COVER) return;                                       // chain.rs:257
-    if (!sensitive && l == 0) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);       // chain.rs:261-264
+    if (!sensitive) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);                 // chain.rs:261-264
     uint32_t in_u = 0, in_range = 0;
-    for (uint32_t s = ck.s_begin + l; s < ck.s_end; s += 64) {
-        const uint32_t pos = ql_pos[s];
-        bool hit = false;
-        if (n_int <= STATS_MAXI) { for (uint32_t i = 0; i < n_int; i++) hit = hit || (pos >= lds_lo[wv][i] && pos <= lds_hi[wv][i]); }
-        else for (uint32_t e = head; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t lo = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos >= lo && pos <= iv.q1 + c); }
-        in_u += hit ? 1u : 0u;                                                      // chain.rs:268-272
-        in_range += (pos >= rq0 && pos <= rq1) ? 1u : 0u;                           // chain.rs:326-332 (spacing estimates are 0)
+    // 16-byte aligned groups of four positions: one L2 request serves four positions (lanes read different chunks, so
+    // narrower loads would re-fetch every 64-byte line many times)
+    const uint4* ql4 = (const uint4*)ql_pos;
+    for (uint32_t g = ck.s_begin >> 2; g < (ck.s_end + 3) >> 2; g++) {
+        const uint4 v = ql4[g];
+        const uint32_t pos[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t s = (g << 2) + (uint32_t)u;
+            if (s < ck.s_begin || s >= ck.s_end) continue;
+            bool hit = false;
+            if (n_int <= (uint32_t)STATS_REG) {
+#pragma unroll
+                for (int i = 0; i < STATS_REG; i++) hit = hit || (pos[u] >= lo[i] && pos[u] <= hi[i]);
+            } else {
+                for (uint32_t e = head; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos[u] >= l0 && pos[u] <= iv.q1 + c); }
+            }
+            in_u += hit ? 1u : 0u;                                                  // chain.rs:268-272
+            in_range += (pos[u] >= rq0 && pos[u] <= rq1) ? 1u : 0u;                 // chain.rs:326-332 (spacing estimates are 0)
+        }
     }
-    in_u = wave_sum(in_u); in_range = wave_sum(in_range);
-    if (l == 0) {
-        uint32_t considered = ck.s_end - ck.s_begin;
-        const double inv_k = 1. / (double)k;
-        const double putative = pow((double)total_anchors / (double)in_u, inv_k);   // chain.rs:335-339
-        if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < CHUNK_SIZE * 9 / 10 && (double)considered > 1.05 * (double)in_range)
-            considered = in_range;                                                  // chain.rs:340-351
-        double ml = (double)total_anchors / (double)considered;
-        if (!(ml < 1.)) ml = 1.;                                                    // f64::min(1., x) (x = NaN or >= 1 -> 1)
-        chunk_est[slot] = pow(ml, inv_k); chunk_w[slot] = considered;               // chain.rs:363-396
-    }
+    uint32_t considered = ck.s_end - ck.s_begin;
+    const double inv_k = 1. / (double)k;
+    const double putative = pow((double)total_anchors / (double)in_u, inv_k);       // chain.rs:335-339
+    if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < CHUNK_SIZE * 9 / 10 && (double)considered > 1.05 * (double)in_range)
+        considered = in_range;                                                      // chain.rs:340-351
+    double ml = (double)total_anchors / (double)considered;
+    if (!(ml < 1.)) ml = 1.;                                                        // f64::min(1., x) (x = NaN or >= 1 -> 1)
+    chunk_est[slot] = pow(ml, inv_k); chunk_w[slot] = considered;                   // chain.rs:363-396
 }
 
 // ------------------------------------------------------------------------------------------------ per-pair result
@@ -583,6 +685,7 @@ struct FinalizeArgs {
     const GbdtModel::Node* nodes; const uint32_t* tree_off; uint32_t n_trees; float shrinkage, bias;
 };
 struct FinalizeScratch { double *u_est, *s_est; uint32_t *u_w, *s_w; uint64_t* cum; };
+constexpr uint32_t FIN_LDS = 512;
 
 // fastrand 1.9.0 WyRand stream seeded with 7 (chain.rs:62); draw number d (0-based) is a pure function of d
 __device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) {
@@ -596,13 +699,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
                                                        const double* chunk_est, const uint32_t* chunk_w, const uint32_t* pair_tqb, const uint32_t* pair_acl,
                                                        const uint32_t* pair_nchains, FinalizeScratch fs, uint32_t* n_est_out, skh_ani_result* out) {
     __shared__ double lds_boot[4][128];
+    __shared__ double lds_u[4][FIN_LDS], lds_s[4][FIN_LDS];
+    __shared__ uint64_t lds_cum[4][FIN_LDS];
+    __shared__ uint32_t lds_uw[4][FIN_LDS], lds_sw[4][FIN_LDS];
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
     if (p >= fa.n_pairs) return;
     const uint32_t l = lane_id();
     const PairDesc pd = pairs[p];
     const uint32_t C0 = pc0[p], nc = n_chunks[p];
-    double* U = fs.u_est + C0; uint32_t* UW = fs.u_w + C0; double* S = fs.s_est + C0; uint32_t* SW = fs.s_w + C0; uint64_t* CUM = fs.cum + C0;
+    // per-pair work arrays: LDS when the pair has at most FIN_LDS chunks (~10 Mbp genomes), global scratch otherwise
+    const bool in_lds = nc <= FIN_LDS;
+    double* U = in_lds ? lds_u[wv] : fs.u_est + C0; uint32_t* UW = in_lds ? lds_uw[wv] : fs.u_w + C0;
+    double* S = in_lds ? lds_s[wv] : fs.s_est + C0; uint32_t* SW = in_lds ? lds_sw[wv] : fs.s_w + C0;
+    uint64_t* CUM = in_lds ? lds_cum[wv] : fs.cum + C0;
     // 1. valid (estimate, weight) pairs in chunk order
     uint32_t n = 0;
     for (uint32_t b = 0; b < nc; b += 64) {
@@ -855,7 +965,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
             pa0[i + 1] = pa0[i] + pair_anch[p0 + i]; pq0[i + 1] = pq0[i] + pair_inq[p0 + i];
             pc0[i + 1] = pc0[i] + (pair_anch[p0 + i] ? std::min(chunk_bound[p0 + i], pair_anch[p0 + i]) : 0);
             const uint32_t icap = pair_anch[p0 + i] / MIN_ANCHORS;
-            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
+            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);   // fallback kernel's global sort scratch
         }
         const uint32_t NA = pa0[np], NQ = pq0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
@@ -906,6 +1016,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
                 check_launch("interval_emit");
             }
         }
+        SKH_LAUNCH(greedy_fast_kernel, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, (const uint32_t*)ivl_cnt,
+                   (const Interval*)ivls, ivl_next, chunk_head, n_acc);
+        check_launch("greedy_fast");
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
         check_launch("greedy");
@@ -913,7 +1026,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* pair_tqb = ctx->arena.get<uint32_t>(np); uint32_t* pair_acl = ctx->arena.get<uint32_t>(np); uint32_t* pair_nch = ctx->arena.get<uint32_t>(np);
         dzero(pair_tqb, np * 4, ctx->stream); dzero(pair_acl, np * 4, ctx->stream); dzero(pair_nch, np * 4, ctx->stream);
         if (NC) {
-            SKH_LAUNCH(chunk_stats_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
+            SKH_LAUNCH(chunk_stats_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
                        (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_pos, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
             check_launch("chunk_stats");
         }

@@ -264,3 +264,21 @@ def case_search_resident_db(ctx):
         q1, r1, res1 = sk.search(ctx, db, qs, n_max=2)
         assert max(np.bincount(q1)) <= 2 and not (q1 == 4).any()
         db.close()
+
+
+def case_large_pair(ctx):
+    """A 14 Mbp pair: > 1024 candidate chain intervals => the fallback greedy kernel, several seeding launches' worth of tiles."""
+    root = random_genome(14_000_000, 77)
+    g = [[("a", root)], [("b1", mutate(root[:9_000_000], 0.12, 5)), ("b2", mutate(root[9_000_000:], 0.12, 6))]]
+    names = ["big0.fa", "big1.fa"]
+    ss = ctx.sketch_records(g, sk.SketchParams(), names)
+    osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]
+    for k in range(2):
+        assert_sketch_equal(ss, k, osk[k])
+    res, st = ctx.chain_pairs(ss, None, [0, 1], [1, 0], sk.MapParams(compute_ci=True), stats=True)
+    for x, (i, j) in enumerate(((0, 1), (1, 0))):
+        o, so = ora.chain_seeds(osk[i], osk[j], stats=True)
+        assert_result_close(res[x], o, (i, j))
+        assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["anchor_checksum"])) == \
+            (so.n_intervals, so.n_accepted, so.n_chunks, so.anchor_checksum)
+    assert int(st[0]["n_intervals"]) > 1024

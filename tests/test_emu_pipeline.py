@@ -25,3 +25,4 @@ def test_emu_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx, params=((1
 def test_emu_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_emu_search_resident_db(ctx): pc.case_search_resident_db(ctx)
+def test_emu_large_pair(ctx): pc.case_large_pair(ctx)

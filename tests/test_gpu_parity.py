@@ -117,3 +117,4 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
 
 
 def test_search_resident_db(ctx): pc.case_search_resident_db(ctx)
+def test_large_pair(ctx): pc.case_large_pair(ctx)
