@@ -83,7 +83,10 @@ def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as ora
     names = ["s%04d.fa" % i for i in range(len(host_genomes))]
-    model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin"))
+    # regression.rs:8-28: learned ANI only for c >= 70, table chosen by |c-125| < |c-200|
+    model = None
+    if C >= 70:
+        model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin" if abs(C - 125) < abs(C - 200) else "gbdt_c200.bin"))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:     # ctypes releases the GIL: genomes are sketched in parallel like file_io.rs:147
         sks = list(ex.map(lambda a: ora.sketch_records(a[1], C, K, M, names[a[0]], 1), enumerate(host_genomes)))
@@ -124,11 +127,15 @@ def main():
     ap.add_argument("--mean-len", type=int, default=5_000_000)
     ap.add_argument("--cpu-clades", type=int, default=6, help="clades (x20 genomes) in the CPU-baseline sample; 0 disables")
     ap.add_argument("--no-ci", action="store_true")
+    ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
+    ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import skani_amd as sk
+    global C, CLADE
+    C, CLADE = args.c, args.clade
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
@@ -146,7 +153,7 @@ def main():
     n_total = n_local * world
     keep = args.cpu_clades if rank == 0 and world == 1 else 0
     bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, rank * clades_local, clades_local, mean_len=args.mean_len,
-                                                                      keep_ascii_clades=min(keep, clades_local))
+                                                                      members=CLADE, keep_ascii_clades=min(keep, clades_local))
     torch.cuda.synchronize()
     gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
     total_bases_local = int(contig_off[-1])

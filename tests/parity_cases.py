@@ -282,3 +282,44 @@ def case_large_pair(ctx):
         assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["anchor_checksum"])) == \
             (so.n_intervals, so.n_accepted, so.n_chunks, so.anchor_checksum)
     assert int(st[0]["n_intervals"]) > 1024
+
+
+def case_edge_cases_and_errors(ctx):
+    """Empty / single-genome sets, genomes without any kept contig, invalid parameters and indices: error codes, never a crash
+    (the reference panics or exits; the C ABI must return a status)."""
+    import pytest
+    # no genomes at all
+    ss0 = ctx.sketch_records([], sk.SketchParams(), [])
+    assert len(ss0) == 0
+    a, b = ctx.screen(ss0, None)
+    assert len(a) == 0
+    i, j, res, n = ctx.triangle(ss0, sk.MapParams())
+    assert len(i) == 0 and n == 0
+    # one genome: no pairs; a genome whose contigs are all < 500 bp becomes an empty sketch (chain.rs:618-620 -> NaN)
+    g = [[("a", random_genome(20000, 1))], [("short", random_genome(300, 2))]]
+    ss = ctx.sketch_records(g, sk.SketchParams(), ["a.fa", "s.fa"])
+    assert ss.sizes(1) == dict(n_pos=0, n_distinct=0, n_markers=0, n_contigs=0, total_len=0)
+    i, j, res, n = ctx.triangle(ss, sk.MapParams())
+    assert len(i) == 0
+    r = ctx.chain_pairs(ss, None, [0, 1, 1], [1, 0, 1], sk.MapParams())
+    assert np.isnan(r["ani"]).all() and (r["total_bases_covered"] == 0).all()
+    one = ctx.sketch_records(g[:1], sk.SketchParams(), ["a.fa"])
+    i, j, res, n = ctx.triangle(one, sk.MapParams())
+    assert len(i) == 0 and n == 0
+    # invalid arguments -> SkaniHipError, context stays usable
+    for bad in (sk.SketchParams(k=17), sk.SketchParams(c=2000, marker_c=1000), sk.SketchParams(c=0)):
+        with pytest.raises(sk.SkaniHipError):
+            ctx.sketch_records(g[:1], bad, ["a.fa"])
+    with pytest.raises(sk.SkaniHipError):
+        ctx.chain_pairs(ss, None, [5], [0], sk.MapParams())
+    with pytest.raises(sk.SkaniHipError):
+        ctx.screen(ss, None, 0.8, 7, True)
+    with pytest.raises(sk.SkaniHipError):                      # learned ANI needs the model tables
+        c2 = sk.Context(0, lib=ctx.L, load_models=False)
+        try:
+            s2 = c2.sketch_records(g[:1], sk.SketchParams(), ["a.fa"])
+            c2.chain_pairs(s2, None, [0], [0], sk.MapParams(learned_ani=True))
+        finally:
+            c2.close()
+    r = ctx.chain_pairs(one, None, [0], [0], sk.MapParams())
+    assert r["ani"][0] >= 1.0

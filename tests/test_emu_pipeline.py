@@ -26,3 +26,4 @@ def test_emu_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_emu_search_resident_db(ctx): pc.case_search_resident_db(ctx)
 def test_emu_large_pair(ctx): pc.case_large_pair(ctx)
+def test_emu_edge_cases(ctx): pc.case_edge_cases_and_errors(ctx)

@@ -118,3 +118,4 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
 
 def test_search_resident_db(ctx): pc.case_search_resident_db(ctx)
 def test_large_pair(ctx): pc.case_large_pair(ctx)
+def test_edge_cases(ctx): pc.case_edge_cases_and_errors(ctx)
