@@ -157,28 +157,50 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
 }
 
 // ------------------------------------------------------------------------------------------------ chunking (chain.rs:738-836)
-// One wave per pair.  All control flow is wave-uniform; lanes only differ in the element they test.
-__device__ __forceinline__ uint32_t first_anchor_break(const uint4* anc, uint32_t from, uint32_t to, uint32_t last, uint32_t end) {
-    const uint32_t l = lane_id();
-    for (uint32_t p = from; p < to; p += 64) {
-        const uint32_t i = p + l;
-        bool brk = false;
-        if (i < to) { const uint4 a = anc[i]; brk = a.w != last || a.x > end; }
-        const unsigned long long m = __ballot(brk);
-        if (m) return p + (uint32_t)__ffsll((long long)m) - 1u;
+// One wave per pair.  All control flow is wave-uniform; lanes only differ in the element they test.  Both scans (over the
+// anchors and over the query-position list) only ever move forward over contiguous memory, so each keeps the current and the
+// next 64-element block in registers (the next block's load is in flight while the current one is examined), and the values
+// the recurrence needs (the breaking anchor, the last anchor) come from the resident block through v_readlane.  The kernel
+// streams every anchor once (16 B each): ~6.4 GB per 9,500 pairs, i.e. it runs at HBM speed (~3.8 TB/s).
+struct AnchorStream {
+    const uint4* p; uint32_t hi, b; uint32_t cq, cw, nq, nw;      // current / next block: query pos (x) and query contig (w)
+    __device__ __forceinline__ void load_next() { const uint32_t i = b + 64 + lane_id(); nq = 0; nw = 0; if (i < hi) { const uint4 a = p[i]; nq = a.x; nw = a.w; } }
+    __device__ __forceinline__ void init(const uint4* p_, uint32_t lo, uint32_t hi_) {
+        p = p_; hi = hi_; b = lo; const uint32_t i = b + lane_id(); cq = 0; cw = 0; if (i < hi) { const uint4 a = p[i]; cq = a.x; cw = a.w; } load_next();
     }
-    return to;
-}
-__device__ __forceinline__ uint32_t first_seed_beyond(const uint32_t* ql_pos, const uint32_t* ql_ctg, uint32_t from, uint32_t to, uint32_t ctg, uint32_t limit) {
-    const uint32_t l = lane_id();
-    for (uint32_t p = from; p < to; p += 64) {
-        const uint32_t i = p + l;
-        const bool brk = i < to && (ql_ctg[i] != ctg || ql_pos[i] > limit);
-        const unsigned long long m = __ballot(brk);
-        if (m) return p + (uint32_t)__ffsll((long long)m) - 1u;
+    __device__ __forceinline__ void advance() { b += 64; cq = nq; cw = nw; load_next(); }
+    // first index >= from whose anchor leaves contig `last` or lies beyond `end`; hi if none (chain.rs:747)
+    __device__ __forceinline__ uint32_t first_break(uint32_t from, uint32_t last, uint32_t end) {
+        for (;;) {
+            const uint32_t i = b + lane_id();
+            const unsigned long long m = __ballot(i >= from && i < hi && (cw != last || cq > end));
+            if (m) return b + (uint32_t)__ffsll((long long)m) - 1u;
+            if (b + 64 >= hi) return hi;
+            advance();
+        }
     }
-    return to;
-}
+    __device__ __forceinline__ uint32_t q_at(uint32_t i) { return wave_readlane(cq, (int)(i - b)); }   // i inside the current block
+    __device__ __forceinline__ uint32_t w_at(uint32_t i) { return wave_readlane(cw, (int)(i - b)); }
+};
+struct SeedStream {
+    const uint32_t *pos, *ctg; uint32_t hi, b; uint32_t cp, cc, np, nc;
+    __device__ __forceinline__ void load_next() { const uint32_t i = b + 64 + lane_id(); np = 0; nc = 0; if (i < hi) { np = pos[i]; nc = ctg[i]; } }
+    __device__ __forceinline__ void init(const uint32_t* pos_, const uint32_t* ctg_, uint32_t from, uint32_t hi_) {
+        pos = pos_; ctg = ctg_; hi = hi_; b = from; const uint32_t i = b + lane_id(); cp = 0; cc = 0; if (i < hi) { cp = pos[i]; cc = ctg[i]; } load_next();
+    }
+    __device__ __forceinline__ void advance() { b += 64; cp = np; cc = nc; load_next(); }
+    // first index >= from that leaves contig `c` or lies beyond `limit`; hi if none (chain.rs:755-780, 797-817)
+    __device__ __forceinline__ uint32_t first_beyond(uint32_t from, uint32_t c, uint32_t limit) {
+        if (from < b || from >= b + 128) init(pos, ctg, from, hi);
+        for (;;) {
+            const uint32_t i = b + lane_id();
+            const unsigned long long m = __ballot(i >= from && i < hi && (cc != c || cp > limit));
+            if (m) return b + (uint32_t)__ffsll((long long)m) - 1u;
+            if (b + 64 >= hi) return hi;
+            advance();
+        }
+    }
+};
 __device__ __forceinline__ uint32_t lower_bound_ctg(const uint32_t* ql_ctg, uint32_t lo, uint32_t hi, uint32_t ctg) {   // uniform
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ql_ctg[mid] < ctg) lo = mid + 1; else hi = mid; }
     return lo;
@@ -193,25 +215,29 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint
     const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
-        const uint4 first = anc[A0];
-        uint32_t last = first.w, end = first.x + CHUNK_SIZE;                        // chain.rs:742-744
+        AnchorStream as; as.init(anc, A0, A1);
+        uint32_t last = as.w_at(A0), end = as.q_at(A0) + CHUNK_SIZE;                // chain.rs:742-744
         uint32_t rc = lower_bound_ctg(ql_ctg, Q0, Q1, last);                        // running_counter = 0 within contig `last`
+        SeedStream ss; ss.init(ql_pos, ql_ctg, rc, Q1);
         uint32_t cur = A0, scan = A0 + 1;
         for (;;) {
-            const uint32_t t = first_anchor_break(anc, scan, A1, last, end);
+            const uint32_t t = as.first_break(scan, last, end);
             Chunk ck; ck.a_begin = cur; ck.s_begin = rc;
             if (t == A1) {                                                         // final chunk: seeds <= last anchor's pos (chain.rs:794-824)
-                ck.a_end = A1; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, anc[A1 - 1].x);
+                ck.a_end = A1; ck.s_end = ss.first_beyond(rc, last, as.q_at(A1 - 1));   // the scan ended inside the block holding A1-1
             } else {                                                               // chain.rs:747-790
-                ck.a_end = t; ck.s_end = first_seed_beyond(ql_pos, ql_ctg, rc, Q1, last, end);
+                ck.a_end = t; ck.s_end = ss.first_beyond(rc, last, end);
             }
             if (C0 + nc < C1) { if (l == 0) { chunks[C0 + nc] = ck; chunk_pair[C0 + nc] = p; } }
             else if (l == 0) atomicAdd(err, 1u);
             nc++;
             if (t == A1) break;
             rc = ck.s_end; end += CHUNK_SIZE;                                      // one step only (chain.rs:782)
-            const uint4 at = anc[t];
-            if (at.w != last) { end = at.x + CHUNK_SIZE; rc = lower_bound_ctg(ql_ctg, Q0, Q1, at.w); last = at.w; }   // chain.rs:786-789
+            const uint32_t tw = as.w_at(t), tq = as.q_at(t);                        // anchor t sits in the resident block
+            if (tw != last) {                                                      // chain.rs:786-789
+                end = tq + CHUNK_SIZE; last = tw;
+                rc = lower_bound_ctg(ql_ctg, Q0, Q1, tw);                        // first_beyond refills its window when rc left it
+            }
             cur = t; scan = t + 1;
         }
     }
@@ -782,14 +808,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     // 6. percentile bootstrap (chain.rs:57-86): 100 resamples of n draws from the multiplicity-expanded list
     double ci_lo = 0., ci_hi = 1.;
     if (fa.compute_ci && n >= 10) {
+        uint32_t nsteps = 0; while ((1u << nsteps) < n) nsteps++;                  // fixed-length branch-free binary search
         for (uint32_t it = 0; it < 100; it++) {
             double s = 0.;
-            for (uint32_t j = l; j < n; j += 64) {
-                const uint64_t r = wyrand_draw((uint64_t)it * n + j);
-                const uint64_t x = __umul64hi(r, total_mult);                       // Lemire reduction; its rejection branch has probability total/2^64
-                uint32_t lo = 0, hi = n - 1;                                        // first i with CUM[i] > x
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (CUM[mid] > x) hi = mid; else lo = mid + 1; }
-                s += S[lo];
+            for (uint32_t j0 = l; j0 < n; j0 += 256) {                               // four independent searches per lane in flight
+                uint64_t x[4]; uint32_t lo[4], hi[4]; bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + 64u * (uint32_t)u;
+                    on[u] = j < n;
+                    const uint64_t r = wyrand_draw((uint64_t)it * n + (on[u] ? j : 0));
+                    x[u] = __umul64hi(r, total_mult);                               // Lemire reduction; its rejection branch has probability total/2^64
+                    lo[u] = 0; hi[u] = n - 1;                                       // first i with CUM[i] > x
+                }
+                for (uint32_t st = 0; st < nsteps; st++) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const uint32_t mid = (lo[u] + hi[u]) >> 1; const bool gt = CUM[mid] > x[u]; hi[u] = gt ? mid : hi[u]; lo[u] = gt ? lo[u] : mid + 1; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (on[u]) s += S[lo[u] < n ? lo[u] : n - 1];
             }
             s = wave_sum_f64(s);
             if (l == 0) lds_boot[wv][it] = s / (double)n;
@@ -804,8 +841,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
         wave_sync_mem();
         ci_lo = lds_boot[wv][100]; ci_hi = lds_boot[wv][101];
     }
-    if (l != 0) return;
-    // 7. aligned fractions, cut-offs, output record (chain.rs:477-554)
+    // 7. aligned fractions, cut-offs, output record (chain.rs:477-554) -- computed redundantly by every lane (wave-uniform)
     const uint32_t tqb = pair_tqb[p];
     double cov_q = (double)tqb / (double)pd.query_total_len; if (!(cov_q < 1.)) cov_q = 1.;
     double cov_r = (double)tqb / (double)pd.ref_total_len; if (!(cov_r < 1.)) cov_r = 1.;   // total_ref_range has the same numerator (chain.rs:245-246)
@@ -818,24 +854,40 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     res.num_contigs_q = pd.nctg_q; res.num_contigs_r = pd.nctg_r;
     res.avg_chain_int_len = pair_acl[p] / nchains;                                  // chain.rs:421
     res.total_bases_covered = tqb;
-    // 8. learned ANI (regression.rs:30-64; gbdt 0.1.1 LAD predict = bias + sum shrinkage * leaf, f32, tree order)
-    if (fa.learned && res.ani > 0.9f && res.total_bases_covered > REGRESS_CUTOFF) {
+    // 8. learned ANI (regression.rs:30-64; gbdt 0.1.1 LAD predict = bias + sum shrinkage * leaf, f32, tree order).
+    //    The 195 tree walks are independent: lanes walk trees lane, lane+64, ...; the f32 sum stays sequential in tree order.
+    if (fa.learned && res.ani > 0.9f && res.total_bases_covered > REGRESS_CUTOFF) { // wave-uniform condition
         float x[5];
         x[0] = res.ani * 100.f; x[1] = res.std; x[4] = (float)res.avg_chain_int_len;
         if (res.q50_r > res.q50_q) { x[2] = res.q90_r; x[3] = res.q90_q; } else { x[2] = res.q90_q; x[3] = res.q90_r; }
-        float pred = fa.bias;
-        for (uint32_t t = 0; t < fa.n_trees; t++) {
+        float* leaf = (float*)lds_boot[wv];                                         // 256 floats
+        wave_sync_mem();
+        for (uint32_t t = l; t < fa.n_trees && t < 256; t += 64) {
             const GbdtModel::Node* nd = fa.nodes + fa.tree_off[t]; int32_t i = 0;
-            while (nd[i].feat >= 0) i = x[nd[i].feat] < nd[i].thr ? nd[i].left : nd[i].right;
-            pred += fa.shrinkage * nd[i].pred;
+            while (nd[i].feat >= 0) {
+                const int32_t ft = nd[i].feat;
+                const float xv = ft == 0 ? x[0] : ft == 1 ? x[1] : ft == 2 ? x[2] : ft == 3 ? x[3] : x[4];
+                i = xv < nd[i].thr ? nd[i].left : nd[i].right;
+            }
+            leaf[t] = nd[i].pred;
         }
-        if (pred < 100.f) {
-            res.ci_upper = (res.ci_upper - res.ani) + pred / 100.f;
-            res.ci_lower = (res.ci_lower - res.ani) + pred / 100.f;
-            res.ani = pred / 100.f;
+        wave_sync_mem();
+        if (l == 0) {
+            float pred = fa.bias;
+            for (uint32_t t = 0; t < fa.n_trees; t++) {
+                float lv;
+                if (t < 256) lv = leaf[t];
+                else { const GbdtModel::Node* nd = fa.nodes + fa.tree_off[t]; int32_t i = 0; while (nd[i].feat >= 0) i = x[nd[i].feat] < nd[i].thr ? nd[i].left : nd[i].right; lv = nd[i].pred; }
+                pred += fa.shrinkage * lv;
+            }
+            if (pred < 100.f) {
+                res.ci_upper = (res.ci_upper - res.ani) + pred / 100.f;
+                res.ci_lower = (res.ci_lower - res.ani) + pred / 100.f;
+                res.ani = pred / 100.f;
+            }
         }
     }
-    out[p] = res;
+    if (l == 0) out[p] = res;
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
