@@ -120,6 +120,20 @@ int skh_sketch_import(skh_ctx*, const skh_sketch_params*, uint32_t n_genomes, co
                       const uint64_t* markers, const uint64_t* contig_off, const uint32_t* contig_lengths,
                       const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out);
 
+/* Whole-set ("flat") export / import: the exchange format between GPUs.  Totals first, then one call moves everything:
+ * the four big arrays (seed, pos, ctgcanon: position order, all genomes concatenated; markers: sorted per genome) go to /
+ * come from DEVICE memory when arrays_on_device != 0 (e.g. torch tensors handed to RCCL), host memory otherwise; the small
+ * per-genome tables (offsets with n_genomes+1 entries, contig lengths, total lengths, ranks) are always host arrays.
+ * Any output pointer may be NULL to skip that array. */
+int skh_sketch_totals(const skh_sketch_set*, uint64_t* n_pos, uint64_t* n_markers, uint64_t* n_contigs);
+int skh_sketch_export_flat(const skh_sketch_set*, int arrays_on_device, uint32_t* seed, uint32_t* pos, uint32_t* ctgcanon, uint64_t* markers,
+                           uint64_t* pos_off, uint64_t* marker_off, uint64_t* contig_off, uint32_t* contig_lengths, uint64_t* total_len,
+                           uint32_t* genome_rank);
+int skh_sketch_import_flat(skh_ctx*, const skh_sketch_params*, uint32_t n_genomes, int arrays_on_device, const uint64_t* pos_off,
+                           const uint32_t* seed, const uint32_t* pos, const uint32_t* ctgcanon, const uint64_t* marker_off,
+                           const uint64_t* markers, const uint64_t* contig_off, const uint32_t* contig_lengths, const uint64_t* total_len,
+                           const uint32_t* genome_rank, skh_sketch_set** out);
+
 /* ------------------------------------------------------------------ screen (screen.rs) */
 enum { SKH_SCREEN_REFS = 0,            /* screen_refs, screen.rs:148-189 (triangle, dist with index) */
        SKH_SCREEN_QUICK = 1,           /* check_markers_quickly, screen.rs:84-142 */

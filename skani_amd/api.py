@@ -155,6 +155,24 @@ class Context:
                                             _p(tl), _p(rank), C.byref(h)))
         return SketchSet(self, h, params, names)
 
+    def import_flat(self, params, meta, seed=None, pos=None, ctgcanon=None, markers=None, device=False, names=None):
+        """meta: dict of host numpy arrays pos_off, marker_off, contig_off (n+1, uint64), contig_lengths (uint32), total_len (uint64),
+        genome_rank (uint32).  The big arrays are numpy arrays (device=False) or raw device addresses (device=True)."""
+        ng = len(meta["total_len"])
+        po = np.ascontiguousarray(meta["pos_off"], np.uint64); mo = np.ascontiguousarray(meta["marker_off"], np.uint64)
+        co = np.ascontiguousarray(meta["contig_off"], np.uint64); cl = np.ascontiguousarray(meta["contig_lengths"], np.uint32)
+        tl = np.ascontiguousarray(meta["total_len"], np.uint64); rk = np.ascontiguousarray(meta["genome_rank"], np.uint32)
+        def ptr(a, dt):
+            if a is None:
+                return None
+            return C.c_void_p(int(a)) if device else _p(np.ascontiguousarray(a, dt))
+        keep = [np.ascontiguousarray(a, dt) if (a is not None and not device) else a for a, dt in ((seed, np.uint32), (pos, np.uint32), (ctgcanon, np.uint32), (markers, np.uint64))]
+        ptrs = [(C.c_void_p(int(a)) if device else _p(a)) if a is not None else None for a in keep]
+        h = C.c_void_p()
+        self.check(self.L.skh_sketch_import_flat(self.h, C.byref(params), ng, 1 if device else 0, _p(po), ptrs[0], ptrs[1], ptrs[2], _p(mo), ptrs[3], _p(co), _p(cl),
+                                                 _p(tl), _p(rk), C.byref(h)))
+        return SketchSet(self, h, params, names)
+
     # ---- screen / chain / triangle ------------------------------------------------------------------------------
     def screen(self, refs, queries=None, identity=0.0, rule=0, rescue_small=True):
         a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
@@ -226,6 +244,25 @@ class SketchSet:
         a, b, c_, d, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
         self.ctx.check(self.ctx.L.skh_sketch_sizes(self.h, g, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(e)))
         return dict(n_pos=a.value, n_distinct=b.value, n_markers=c_.value, n_contigs=d.value, total_len=e.value)
+
+    def totals(self):
+        a, b, c_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.L.skh_sketch_totals(self.h, C.byref(a), C.byref(b), C.byref(c_)))
+        return a.value, b.value, c_.value
+
+    def export_meta(self):
+        """Per-genome host tables of the whole set (offsets, contig lengths, total lengths, ranks)."""
+        n = len(self); P, M, NC = self.totals()
+        meta = dict(pos_off=np.zeros(n + 1, np.uint64), marker_off=np.zeros(n + 1, np.uint64), contig_off=np.zeros(n + 1, np.uint64),
+                    contig_lengths=np.zeros(NC, np.uint32), total_len=np.zeros(n, np.uint64), genome_rank=np.zeros(n, np.uint32))
+        self.ctx.check(self.ctx.L.skh_sketch_export_flat(self.h, 0, None, None, None, None, _p(meta["pos_off"]), _p(meta["marker_off"]), _p(meta["contig_off"]),
+                                                         _p(meta["contig_lengths"]), _p(meta["total_len"]), _p(meta["genome_rank"])))
+        return meta
+
+    def export_arrays(self, seed=None, pos=None, ctgcanon=None, markers=None, device=False):
+        """Copy the set's big arrays into caller buffers: numpy arrays, or raw device addresses when device=True."""
+        conv = (lambda a: C.c_void_p(int(a)) if a is not None else None) if device else (lambda a: _p(a) if a is not None else None)
+        self.ctx.check(self.ctx.L.skh_sketch_export_flat(self.h, 1 if device else 0, conv(seed), conv(pos), conv(ctgcanon), conv(markers), None, None, None, None, None, None))
 
     def export(self, g):
         s = self.sizes(g)

@@ -218,9 +218,9 @@ int skh_sketch_export(const skh_sketch_set* ss, uint32_t g, uint32_t* seed, uint
     });
 }
 
-int skh_sketch_import(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, const uint64_t* pos_off, const uint32_t* seed, const uint32_t* pos,
-                      const uint32_t* cc, const uint64_t* marker_off, const uint64_t* markers, const uint64_t* contig_off,
-                      const uint32_t* contig_lengths, const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out) {
+int skh_sketch_import_flat(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, int on_device, const uint64_t* pos_off, const uint32_t* seed,
+                           const uint32_t* pos, const uint32_t* cc, const uint64_t* marker_off, const uint64_t* markers, const uint64_t* contig_off,
+                           const uint32_t* contig_lengths, const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out) {
     if (!ctx || !out || !pos_off || !marker_off || !contig_off || !total_len) return SKH_ERR_INVALID;
     *out = nullptr;
     skh_sketch_set* ss = nullptr;
@@ -234,9 +234,10 @@ int skh_sketch_import(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, co
         finalize_metadata(ss);
         upload_contig_tables(ctx, ss);
         const uint64_t P = pos_off[ng], M = marker_off[ng];
+        if ((P && (!seed || !pos || !cc)) || (M && !markers)) throw std::invalid_argument("null sketch array");
         ss->p_seed.alloc(P); ss->p_pos.alloc(P); ss->p_cc.alloc(P); ss->markers.alloc(M);
-        h2d(ss->p_seed.p, seed, P * 4, ctx->stream); h2d(ss->p_pos.p, pos, P * 4, ctx->stream); h2d(ss->p_cc.p, cc, P * 4, ctx->stream);
-        h2d(ss->markers.p, markers, M * 8, ctx->stream);
+        auto put = [&](void* d, const void* src, size_t n) { if (on_device) d2d(d, src, n, ctx->stream); else h2d(d, src, n, ctx->stream); };
+        put(ss->p_seed.p, seed, P * 4); put(ss->p_pos.p, pos, P * 4); put(ss->p_cc.p, cc, P * 4); put(ss->markers.p, markers, M * 8);
         ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
         build_sketch_tables(ctx, ss);
     });
@@ -244,6 +245,39 @@ int skh_sketch_import(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, co
     if (rc != SKH_OK) { delete ss; return rc; }
     *out = ss;
     return SKH_OK;
+}
+
+int skh_sketch_import(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, const uint64_t* pos_off, const uint32_t* seed, const uint32_t* pos,
+                      const uint32_t* cc, const uint64_t* marker_off, const uint64_t* markers, const uint64_t* contig_off,
+                      const uint32_t* contig_lengths, const uint64_t* total_len, const uint32_t* genome_rank, skh_sketch_set** out) {
+    return skh_sketch_import_flat(ctx, sp, ng, 0, pos_off, seed, pos, cc, marker_off, markers, contig_off, contig_lengths, total_len, genome_rank, out);
+}
+
+int skh_sketch_totals(const skh_sketch_set* ss, uint64_t* n_pos, uint64_t* n_markers, uint64_t* n_contigs) {
+    if (!ss) return SKH_ERR_INVALID;
+    if (n_pos) *n_pos = ss->pos_off[ss->n_genomes];
+    if (n_markers) *n_markers = ss->mk_off[ss->n_genomes];
+    if (n_contigs) *n_contigs = ss->ctg_off[ss->n_genomes];
+    return SKH_OK;
+}
+
+int skh_sketch_export_flat(const skh_sketch_set* ss, int on_device, uint32_t* seed, uint32_t* pos, uint32_t* cc, uint64_t* markers, uint64_t* pos_off,
+                           uint64_t* marker_off, uint64_t* contig_off, uint32_t* contig_lengths, uint64_t* total_len, uint32_t* genome_rank) {
+    if (!ss) return SKH_ERR_INVALID;
+    skh_ctx* ctx = ss->ctx;
+    return guarded(ctx, [&] {
+        const uint32_t ng = ss->n_genomes;
+        const uint64_t P = ss->pos_off[ng], M = ss->mk_off[ng];
+        auto get = [&](void* dst, const void* src, size_t n) { if (!dst || !n) return; if (on_device) d2d(dst, src, n, ctx->stream); else d2h(dst, src, n, ctx->stream); };
+        get(seed, ss->p_seed.p, P * 4); get(pos, ss->p_pos.p, P * 4); get(cc, ss->p_cc.p, P * 4); get(markers, ss->markers.p, M * 8);
+        if (pos_off) memcpy(pos_off, ss->pos_off.data(), (ng + 1) * 8);
+        if (marker_off) memcpy(marker_off, ss->mk_off.data(), (ng + 1) * 8);
+        if (contig_off) memcpy(contig_off, ss->ctg_off.data(), (ng + 1) * 8);
+        if (contig_lengths && !ss->ctg_len.empty()) memcpy(contig_lengths, ss->ctg_len.data(), ss->ctg_len.size() * 4);
+        if (total_len && ng) memcpy(total_len, ss->total_len.data(), ng * 8);
+        if (genome_rank && ng) memcpy(genome_rank, ss->rank.data(), ng * 4);
+        dsync(ctx->stream);
+    });
 }
 
 int skh_screen(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,

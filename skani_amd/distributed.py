@@ -33,10 +33,42 @@ def _all_to_all_bytes(dist, torch, device, payloads):
     return out
 
 
-def _marker_record(ss, g):
-    e = ss.export(g)
-    return dict(seed=np.zeros(0, np.uint32), pos=np.zeros(0, np.uint32), ctgcanon=np.zeros(0, np.uint32), markers=e["markers"],
-                contig_lengths=e["contig_lengths"], total_len=e["total_len"])
+def _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device):
+    """All-gather of the marker sets (flat arrays, no per-genome work): returns a markers-only SketchSet of ALL genomes whose
+    genome order is rank order.  On GPUs the markers stay in device memory end to end (export -> RCCL all_gather -> import)."""
+    n_local = len(ss_local)
+    meta = ss_local.export_meta()
+    _, M, NC = ss_local.totals()
+    on_dev = device.type == "cuda"
+    sizes = torch.tensor([M, NC], dtype=torch.int64, device=device)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    Ms = [int(x[0]) for x in all_sizes]
+    max_m = max(max(Ms), 1)
+    mk = torch.zeros(max_m, dtype=torch.int64, device=device)                       # u64 bit patterns
+    if M:
+        if on_dev:
+            ss_local.export_arrays(markers=mk.data_ptr(), device=True)
+        else:
+            ss_local.export_arrays(markers=mk.numpy().view(np.uint64))
+    parts = [torch.empty_like(mk) for _ in range(world)]
+    dist.all_gather(parts, mk)
+    allmk = torch.cat([parts[r][:Ms[r]] for r in range(world)]) if sum(Ms) else torch.zeros(1, dtype=torch.int64, device=device)
+    small = [None] * world                                                          # a few KB per rank: offsets, contig lengths, total lengths
+    dist.all_gather_object(small, (meta["marker_off"], meta["contig_off"], meta["contig_lengths"], meta["total_len"]))
+    n_total = n_local * world
+    mo = np.zeros(n_total + 1, np.uint64); co = np.zeros(n_total + 1, np.uint64)
+    g = 0
+    for (m_off, c_off, _, _) in small:
+        k = len(m_off) - 1
+        mo[g + 1:g + k + 1] = mo[g] + m_off[1:]; co[g + 1:g + k + 1] = co[g] + c_off[1:]; g += k
+    gmeta = dict(pos_off=np.zeros(n_total + 1, np.uint64), marker_off=mo, contig_off=co,
+                 contig_lengths=np.concatenate([x[2] for x in small]).astype(np.uint32), total_len=np.concatenate([x[3] for x in small]).astype(np.uint64),
+                 genome_rank=np.arange(n_total, dtype=np.uint32))
+    if on_dev:
+        torch.cuda.synchronize(device)
+        return ctx.import_flat(params, gmeta, markers=allmk.data_ptr(), device=True), allmk
+    return ctx.import_flat(params, gmeta, markers=allmk.numpy().view(np.uint64)), allmk
 
 
 def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, identity=0.0, rescue_small=True, torch=None, device=None):
@@ -45,15 +77,15 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
     on the other ranks."""
     if world == 1:
         return ctx.triangle(ss_local, map_params, identity, rescue_small)
+    if torch is None:
+        import torch as _t
+        torch = _t
+    if device is None:
+        device = torch.device("cpu")
     n_local = len(ss_local)
     base = rank * n_local
-    # 1. markers + metadata of every genome, everywhere
-    mine = [_marker_record(ss_local, g) for g in range(n_local)]
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
-    allm = [d for part in gathered for d in part]
-    n_total = len(allm)
-    markers_only = ctx.import_sketches(params, allm, genome_rank=np.arange(n_total, dtype=np.uint32))
+    # 1. markers + metadata of every genome, everywhere; every rank screens the full set
+    markers_only, _keep = _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device)
     gi, gj = ctx.screen(markers_only, None, identity, 0, rescue_small)          # identical on every rank
     markers_only.close()
     owner_i = gi // n_local; owner_j = gj // n_local
@@ -63,11 +95,6 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         need = np.unique(gj[(owner_i == r) & (owner_j == rank) & (r != rank)]) if r != rank else np.zeros(0, np.uint32)
         send_lists.append(need)                                                    # my genomes that rank r needs
     payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in send_lists]
-    if torch is None:
-        import torch as _t
-        torch = _t
-    if device is None:
-        device = torch.device("cpu")
     received = _all_to_all_bytes(dist, torch, device, payloads)
     remote = {}
     for blob in received:
