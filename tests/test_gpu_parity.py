@@ -119,3 +119,31 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
 def test_search_resident_db(ctx): pc.case_search_resident_db(ctx)
 def test_large_pair(ctx): pc.case_large_pair(ctx)
 def test_edge_cases(ctx): pc.case_edge_cases_and_errors(ctx)
+
+
+def test_flat_export_import_device_roundtrip(ctx):
+    """The multi-GPU exchange format: whole-set export into torch device tensors and import from device pointers gives back
+    the same sketches (and a markers-only set screens identically)."""
+    import torch
+    genomes = pc.synthetic_clades(n_clades=2, members=3, length=80000, seed=77)
+    names = ["f%02d.fa" % i for i in range(len(genomes))]
+    ss = ctx.sketch_records(genomes, sk.SketchParams(), names)
+    P, M, NC = ss.totals(); meta = ss.export_meta()
+    dev = torch.device("cuda", 0)
+    t = {k: torch.zeros(max(P, 1), dtype=torch.int32, device=dev) for k in ("seed", "pos", "cc")}
+    mk = torch.zeros(max(M, 1), dtype=torch.int64, device=dev)
+    ss.export_arrays(seed=t["seed"].data_ptr(), pos=t["pos"].data_ptr(), ctgcanon=t["cc"].data_ptr(), markers=mk.data_ptr(), device=True)
+    torch.cuda.synchronize()
+    ss2 = ctx.import_flat(sk.SketchParams(), meta, seed=t["seed"].data_ptr(), pos=t["pos"].data_ptr(), ctgcanon=t["cc"].data_ptr(), markers=mk.data_ptr(),
+                          device=True, names=names)
+    for g in range(len(genomes)):
+        a, b = ss.export(g), ss2.export(g)
+        for k in ("seed", "pos", "ctgcanon", "markers", "contig_lengths"):
+            assert np.array_equal(a[k], b[k]), (g, k)
+    mp = sk.MapParams(learned_ani=True, compute_ci=True)
+    r1 = ctx.triangle(ss, mp); r2 = ctx.triangle(ss2, mp)
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1]) and r1[2].tobytes() == r2[2].tobytes()
+    meta0 = dict(meta); meta0["pos_off"] = np.zeros_like(meta["pos_off"])
+    mo = ctx.import_flat(sk.SketchParams(), meta0, markers=mk.data_ptr(), device=True)
+    a1 = ctx.screen(ss, None); a2 = ctx.screen(mo, None)
+    assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1])
