@@ -77,6 +77,66 @@ def make_genomes(torch, device, first_clade, n_clades, members=CLADE, mean_len=5
     return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), g_idx, host_genomes
 
 
+def make_queries(torch, device, clades, mean_len=5_000_000):
+    """One fresh member (2% substitutions) of each listed clade: the clade root is regenerated from its seed."""
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    pieces, contig_off, contig_genome = [], [0], []
+    for qi, cl in enumerate(clades):
+        gen = torch.Generator(device=device); gen.manual_seed(SEED0 + int(cl))
+        cpu_rng = np.random.default_rng(SEED0 + int(cl))
+        L = int(cpu_rng.integers(int(mean_len * 0.9), int(mean_len * 1.1) + 1))
+        root = torch.randint(0, 4, (L,), dtype=torch.uint8, device=device, generator=gen)
+        g2 = torch.Generator(device=device); g2.manual_seed(SEED0 + 10_000_000 + qi)
+        mask = torch.rand(L, device=device, generator=g2) < 0.02
+        sub = torch.randint(1, 4, (L,), dtype=torch.uint8, device=device, generator=g2)
+        pieces.append(lut[torch.where(mask, (root + sub) & 3, root).long()])
+        contig_off.append(contig_off[-1] + L); contig_genome.append(qi)
+    return torch.cat(pieces), np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), len(clades)
+
+
+def run_search(args, torch, sk, ctx, device):
+    """BASELINE config 5 (optional workload): queries vs a pre-sketched database RESIDENT in HBM, --medium preset (c=70)."""
+    params = sk.SketchParams(args.c, K, M, sk.SEED_AVX2)
+    shard = 1000
+    n_db = args.db_genomes
+    shards = []
+    t0 = time.perf_counter()
+    for a in range(0, n_db, shard):
+        n = min(shard, n_db - a)
+        bases, coff, cgen, ng, _ = make_genomes(torch, device, a // CLADE, (n + CLADE - 1) // CLADE, members=CLADE, mean_len=args.mean_len)
+        torch.cuda.synchronize()
+        gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+        del bases
+        shards.append(ctx.sketch_genomes(gs, params, genome_rank=np.arange(a, a + ng, dtype=np.uint32)))
+        gs.close(); torch.cuda.empty_cache()
+    db = sk.SketchDB(shards)
+    build_s = time.perf_counter() - t0
+    rng = np.random.default_rng(12345)
+    qclades = rng.integers(0, max(1, n_db // CLADE), args.queries)
+    qb, qoff, qgen, nq = make_queries(torch, device, qclades, args.mean_len)
+    torch.cuda.synchronize()
+    gq = ctx.pack_buffer(None, qoff, qgen, nq, sk.SEED_AVX2, device_ptr=qb.data_ptr())
+    del qb
+    qs = ctx.sketch_genomes(gq, params, genome_rank=np.arange(10_000_000, 10_000_000 + nq, dtype=np.uint32))
+    gq.close()
+    mem_gb = torch.cuda.mem_get_info(device)
+    for _ in range(args.warmup):
+        sk.search(ctx, db, qs, n_query_files=nq)
+    ctx.timings()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        q, r, res = sk.search(ctx, db, qs, n_query_files=nq)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    tm = ctx.timings()
+    own = (r // CLADE) == qclades[q]
+    print(json.dumps({"metric": "search queries/sec vs resident sketch DB", "value": nq / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                      "config": {"workload": "skani search: %d synthetic queries vs %d-genome DB (c=%d) resident in HBM" % (nq, n_db, args.c), "db_genomes": n_db,
+                                 "db_shards": len(shards), "queries": nq, "hits": int(len(q)), "hits_in_own_clade": int(own.sum()), "db_build_s": build_s,
+                                 "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9},
+                      "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None}))
+
+
 def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
     """Times the oracle (port of the reference algorithms; kind = 'port') on the sample with all host cores and, when the
     GPU triangle result is given, reports the metric's "ANI delta vs ref" on the sample's pairs."""
@@ -129,6 +189,9 @@ def main():
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
     ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
+    ap.add_argument("--workload", default="triangle", choices=["triangle", "search"], help="triangle = the headline metric; search = BASELINE config 5 (optional)")
+    ap.add_argument("--db-genomes", type=int, default=10000)
+    ap.add_argument("--queries", type=int, default=200)
     args = ap.parse_args()
 
     import torch
@@ -146,6 +209,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     ctx = sk.Context(local)
+    if args.workload == "search":
+        if world > 1:
+            raise SystemExit("the search workload is single-GPU")
+        if args.c == 125:
+            args.c = C = 70            # --medium, BASELINE config 5
+        run_search(args, torch, sk, ctx, device)
+        return
 
     n_local = args.genomes_per_gpu
     assert n_local % CLADE == 0
