@@ -980,8 +980,8 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
     dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
-    const uint64_t ANCH_BUDGET = (uint64_t)512 << 20;    // anchors per batch (~44 B of scratch each)
-    const uint32_t SUPER_TILES = 1u << 20;               // join tiles per count pass (6 KiB of probe records each)
+    const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~44 B of scratch each)
+    const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (6 KiB of probe records each)
     auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
     std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
     uint32_t sp0 = 0;

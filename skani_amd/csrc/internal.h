@@ -47,7 +47,17 @@ struct GbdtModel {  // flat table from tools/extract_gbdt_model.py (regression.r
 
 }  // namespace skh
 
+// Scratch budgets that decide how work is split into launches/batches.  The defaults suit 288 GB of HBM; tests shrink them
+// (SKH_TUNE_* environment variables, read at context creation) to drive the multi-batch paths with small inputs.
+struct skh_tunables {
+    uint64_t seed_scratch_bytes = (uint64_t)6 << 30;    // capped tile scratch per seeding launch
+    uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
+    uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
+    uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
+};
+
 struct skh_ctx {
+    skh_tunables tune;
     int device = 0;
     devStream_t stream{};
     std::string err;

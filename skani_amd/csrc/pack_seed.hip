@@ -261,7 +261,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_s = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
-    const size_t MAX_TILES = std::max<size_t>(1024, ((size_t)6 << 30) / tile_bytes);     // <= 6 GiB of tile scratch per launch
+    const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
     struct Part { DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     // first tile of every genome (tiles are ordered by genome)

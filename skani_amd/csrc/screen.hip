@@ -138,7 +138,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     sort_keys_u64(ctx, keys, M, 64);
     ScreenRule sr{powi21(identity), rule, rescue_small, tri ? 1 : 0};
     // row blocking keeps the dense count matrix within a fixed budget
-    const uint64_t budget_cells = (uint64_t)2 << 30;     // 8 GiB of u32 counters
+    const uint64_t budget_cells = ctx->tune.screen_cells;   // u32 counters per row block (default 8 GiB)
     uint32_t rows_per = (uint32_t)std::min<uint64_t>(nrows, std::max<uint64_t>(1, budget_cells / ncols));
     uint32_t* cnt = ctx->arena.get<uint32_t>((uint64_t)rows_per * ncols);
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);

@@ -27,3 +27,19 @@ def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_emu_search_resident_db(ctx): pc.case_search_resident_db(ctx)
 def test_emu_large_pair(ctx): pc.case_large_pair(ctx)
 def test_emu_edge_cases(ctx): pc.case_edge_cases_and_errors(ctx)
+
+
+def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
+    """Shrink the scratch budgets so that tiny inputs go through several seeding launches (a genome's tiles split across
+    launches), several screen row blocks, several chain super-batches and batches."""
+    monkeypatch.setenv("SKH_TUNE_SEED_SCRATCH_BYTES", "6000")        # ~2 tiles per launch
+    monkeypatch.setenv("SKH_TUNE_SCREEN_CELLS", "20")                 # 2 rows per block at 7 genomes
+    monkeypatch.setenv("SKH_TUNE_CHAIN_ANCHORS", "3000")
+    monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
+        pc.case_screen_rules(c)
+        pc.case_seeding_fixtures(c)
+    finally:
+        c.close()

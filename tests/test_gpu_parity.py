@@ -147,3 +147,18 @@ def test_flat_export_import_device_roundtrip(ctx):
     mo = ctx.import_flat(sk.SketchParams(), meta0, markers=mk.data_ptr(), device=True)
     a1 = ctx.screen(ss, None); a2 = ctx.screen(mo, None)
     assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1])
+
+
+def test_small_budgets_force_multi_batch_paths(monkeypatch):
+    monkeypatch.setenv("SKH_TUNE_SEED_SCRATCH_BYTES", "6000")
+    monkeypatch.setenv("SKH_TUNE_SCREEN_CELLS", "20")
+    monkeypatch.setenv("SKH_TUNE_CHAIN_ANCHORS", "3000")
+    monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
+    c = sk.Context(0)
+    try:
+        pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
+        pc.case_screen_rules(c)
+        pc.case_seeding_fixtures(c)
+        pc.case_w_vs_w(c)
+    finally:
+        c.close()
