@@ -85,8 +85,9 @@ LoadedGenomes load_genomes(const std::vector<std::string>& files_in, bool indivi
             }
             lg.info.push_back(std::move(gi));
         } else {
+            uint64_t j = 0;
             for (auto& r : per[i].recs) {
-                GenomeInfo gi; gi.file_name = files[i]; gi.contigs.push_back(r.name); gi.contig_lengths.push_back((uint32_t)r.seq.size());
+                GenomeInfo gi; gi.file_name = files[i]; gi.contig_order = j++; gi.contigs.push_back(r.name); gi.contig_lengths.push_back((uint32_t)r.seq.size());
                 lg.bases += r.seq; lg.contig_off.push_back(lg.bases.size()); lg.contig_genome.push_back((uint32_t)lg.info.size());
                 lg.info.push_back(std::move(gi));
             }

@@ -21,6 +21,7 @@ struct GenomeInfo {
     std::string file_name;
     std::vector<std::string> contigs;      // names of kept contigs
     std::vector<uint32_t> contig_lengths;
+    uint64_t contig_order = 0;             // -i mode: index of the contig within its file (file_io.rs:336)
 };
 
 struct LoadedGenomes {
@@ -48,5 +49,37 @@ std::string format_sparse(const std::vector<GenomeInfo>& g, const std::vector<Pa
 // file_io.rs:608-678
 std::string format_query_ref_list(const std::vector<GenomeInfo>& refs, const std::vector<GenomeInfo>& queries, const std::vector<PairResult>& res,
                                   size_t n_max, const OutOpts& o);
+
+// ---- on-disk sketch formats (formats.cpp) ----
+struct SeedRecord { uint32_t seed, pos, ctgcanon; };            // ctgcanon = contig_index << 1 | canonical (types.rs:124-143)
+struct SketchFileParams { uint64_t c = 125, k = 15, marker_c = 1000; bool use_syncs = false, use_aa = false; };   // params.rs:136-146
+struct SketchBlob {                                              // types.rs:252-277
+    std::string file_name;
+    bool has_seeds = true;                                       // false = markers-only sketch (types.rs:322-340)
+    std::vector<SeedRecord> records;                             // (contig, pos) order
+    std::vector<std::string> contigs;
+    uint64_t total_sequence_length = 0;
+    std::vector<uint32_t> contig_lengths;
+    uint64_t repetitive_kmers = 0;                               // usize::MAX in every sketch skani writes (types.rs Default)
+    std::vector<uint64_t> markers;                               // ascending
+    uint64_t marker_c = 0, c = 0, k = 0, contig_order = 0;
+    bool individual_contig = false, amino_acid = false;
+};
+struct IndexEntry { std::string file_name; uint64_t offset, length; };    // sketch_db.rs:10-15
+struct SketchDb { SketchFileParams params; std::vector<SketchBlob> markers, sketches; };   // sketches[j] belongs to markers[j]
+
+std::string encode_sketch(const SketchFileParams&, const SketchBlob&);                               // v0.3 (SketchParams, Sketch)
+// v0.3 layout, falling back to the pre-0.3 layout; *format = 3 or 2.  The whole buffer must be one blob.  Returns bytes used.
+size_t decode_sketch(const uint8_t* bytes, size_t n, SketchFileParams&, SketchBlob&, int* format);
+std::string encode_markers(const SketchFileParams&, const std::vector<SketchBlob>&);                 // markers.bin
+void decode_markers(const uint8_t* bytes, size_t n, SketchFileParams&, std::vector<SketchBlob>&);
+std::string encode_index(const std::vector<IndexEntry>&);                                            // index.db
+std::vector<IndexEntry> decode_index(const uint8_t* bytes, size_t n);
+// `skani sketch -o dir` output: sketches.db + index.db + markers.bin, or one .sketch per genome + markers.bin (sketch.rs:13-175)
+void write_sketch_db(const std::string& dir, const SketchFileParams&, const std::vector<SketchBlob>&, bool separate_files, bool individual_contig);
+// sketches_from_sketch (file_io.rs:680-729): skips markers.bin, reports and skips unreadable files, sorts by file_name
+std::vector<SketchBlob> read_sketch_files(const std::vector<std::string>& files, SketchFileParams&);
+// a `skani sketch` output folder (either flavour), all sketches loaded (search.rs:16-100 without the lazy fetch)
+SketchDb read_sketch_db(const std::string& dir_or_marker_file);
 
 }  // namespace skhost

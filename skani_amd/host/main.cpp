@@ -1,4 +1,5 @@
-// main.cpp -- `skani-hip {triangle,dist}`: the reference's drivers (triangle.rs:13-169, dist.rs:12-190) over the C ABI.
+// main.cpp -- `skani-hip {triangle,dist,sketch,search}`: the reference's drivers (triangle.rs:13-169, dist.rs:12-190,
+// sketch.rs:15-175, search.rs:16-282) over the C ABI.  Inputs may be FASTA (.gz) or skani sketch files / database folders.
 // Flag names follow cli.rs; only flags that reach the hot path or the writers are implemented.
 #include <cmath>
 #include <cstdio>
@@ -9,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "host.hpp"
 
 using namespace skhost;
@@ -16,12 +19,12 @@ using namespace skhost;
 namespace {
 
 struct Args {
-    std::string cmd, out, list, qlist, rlist, models_dir;
+    std::string cmd, out, list, qlist, rlist, models_dir, database;
     std::vector<std::string> files, queries, refs;
     uint32_t c = 125, k = 15, m = 1000; bool c_set = false, m_set = false;
     double s = 0, min_af = -1, both_min_af = -1; bool min_af_set = false;
     bool robust = false, median = false, no_learned = false, fast = false, slow = false, medium = false, small_genomes = false, faster_small = false;
-    bool sparse = false, individual = false, qi = false, ri = false, marker_index = false;
+    bool sparse = false, individual = false, qi = false, ri = false, marker_index = false, no_marker_index = false, separate_sketches = false;
     size_t n = 10000000; int threads = 3, device = 0, seeding_mode = SKH_SEED_AVX2;
     OutOpts o;
 };
@@ -37,7 +40,7 @@ std::vector<std::string> read_list(const std::string& p) {
 
 Args parse(int argc, char** argv) {
     Args a;
-    if (argc < 2) die("usage: skani-hip {triangle|dist} [options] files...");
+    if (argc < 2) die("usage: skani-hip {triangle|dist|sketch|search} [options] files...");
     a.cmd = argv[1];
     auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
     std::vector<std::string>* sink = &a.files;
@@ -76,6 +79,10 @@ Args parse(int argc, char** argv) {
         else if (x == "--qi") a.qi = true;
         else if (x == "--ri") a.ri = true;
         else if (x == "--marker-index") a.marker_index = true;
+        else if (x == "--no-marker-index") a.no_marker_index = true;
+        else if (x == "--separate-sketches") a.separate_sketches = true;
+        else if (x == "-d") a.database = need(i);
+        else if (x == "--keep-refs") {}                                        // every reference sketch is HBM-resident anyway
         else if (x == "--device") a.device = atoi(need(i).c_str());
         else if (x == "--seeding") { std::string v = need(i); a.seeding_mode = v == "scalar" ? SKH_SEED_SCALAR : SKH_SEED_AVX2; }
         else if (x == "--models") a.models_dir = need(i);
@@ -116,6 +123,73 @@ skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
     return ss;
 }
 
+bool all_sketch_files(const std::vector<std::string>& files) {                     // parse.rs:264-281
+    if (files.empty()) return false;
+    for (auto& f : files) if (f.find(".sketch") == std::string::npos && f.find("markers.bin") == std::string::npos) return false;
+    return true;
+}
+
+// sketches read from disk -> one device-resident sketch set (sketches_from_sketch + the HBM upload)
+skh_sketch_set* import_blobs(Ctx& cx, const SketchFileParams& fp, const std::vector<SketchBlob>& blobs, int seeding_mode) {
+    std::vector<uint64_t> pos_off{0}, mk_off{0}, ctg_off{0}, total;
+    std::vector<uint32_t> seed, pos, cc, clen; std::vector<uint64_t> markers;
+    for (const SketchBlob& b : blobs) {
+        for (const SeedRecord& r : b.records) { seed.push_back(r.seed); pos.push_back(r.pos); cc.push_back(r.ctgcanon); }
+        markers.insert(markers.end(), b.markers.begin(), b.markers.end());
+        clen.insert(clen.end(), b.contig_lengths.begin(), b.contig_lengths.end());
+        pos_off.push_back(seed.size()); mk_off.push_back(markers.size()); ctg_off.push_back(clen.size()); total.push_back(b.total_sequence_length);
+    }
+    skh_sketch_params sp{(uint32_t)fp.c, (uint32_t)fp.k, (uint32_t)fp.marker_c, (uint32_t)seeding_mode};
+    skh_sketch_set* ss = nullptr;
+    cx.check(skh_sketch_import(cx.c, &sp, (uint32_t)blobs.size(), pos_off.data(), seed.data(), pos.data(), cc.data(), mk_off.data(), markers.data(),
+                               ctg_off.data(), clen.data(), total.data(), nullptr, &ss), "skh_sketch_import");
+    std::vector<const char*> names; for (auto& b : blobs) names.push_back(b.file_name.c_str());
+    cx.check(skh_sketch_set_names(ss, names.data()), "skh_sketch_set_names");
+    return ss;
+}
+
+std::vector<GenomeInfo> infos_of(const std::vector<SketchBlob>& blobs) {
+    std::vector<GenomeInfo> v(blobs.size());
+    for (size_t i = 0; i < blobs.size(); i++) { v[i].file_name = blobs[i].file_name; v[i].contigs = blobs[i].contigs; v[i].contig_lengths = blobs[i].contig_lengths; v[i].contig_order = blobs[i].contig_order; }
+    return v;
+}
+
+// device-resident sketch set -> the records skani serialises (Sketch, types.rs:252-277)
+std::vector<SketchBlob> export_blobs(Ctx& cx, const skh_sketch_set* ss, const std::vector<GenomeInfo>& info, const Args& a) {
+    std::vector<SketchBlob> blobs(info.size());
+    for (uint32_t g = 0; g < info.size(); g++) {
+        uint64_t np = 0, nd = 0, nm = 0, total = 0; uint32_t nc = 0;
+        cx.check(skh_sketch_sizes(ss, g, &np, &nd, &nm, &nc, &total), "skh_sketch_sizes");
+        std::vector<uint32_t> seed(np), pos(np), cc(np), clen(nc); SketchBlob& b = blobs[g];
+        b.markers.resize(nm);
+        cx.check(skh_sketch_export(ss, g, seed.data(), pos.data(), cc.data(), b.markers.data(), clen.data()), "skh_sketch_export");
+        b.records.resize(np); for (uint64_t i = 0; i < np; i++) b.records[i] = SeedRecord{seed[i], pos[i], cc[i]};
+        b.file_name = info[g].file_name; b.contigs = info[g].contigs; b.contig_lengths = clen; b.total_sequence_length = total;
+        b.marker_c = a.c;                                                          // Sketch::new stores c in marker_c (types.rs:346)
+        b.c = a.c; b.k = a.k; b.contig_order = info[g].contig_order;
+    }
+    return blobs;
+}
+
+// One side of a comparison: FASTA files are sketched on the GPU, sketch files are uploaded.  `a.c/k/m` are replaced by the
+// files' parameters when sketches are read (dist.rs:28-52 "Using parameters from .sketch files").
+struct Side { skh_sketch_set* ss = nullptr; std::vector<GenomeInfo> info; bool from_sketch = false; };
+Side load_side(Ctx& cx, const std::vector<std::string>& files, bool individual, Args& a) {
+    Side sd;
+    if (all_sketch_files(files)) {
+        SketchFileParams fp; std::vector<SketchBlob> blobs = read_sketch_files(files, fp);
+        if (blobs.empty()) return sd;
+        for (auto& b : blobs) if (!b.has_seeds) die("sketch " + b.file_name + " holds markers only; it cannot be aligned");
+        a.c = (uint32_t)fp.c; a.k = (uint32_t)fp.k; a.m = (uint32_t)fp.marker_c;
+        sd.ss = import_blobs(cx, fp, blobs, a.seeding_mode); sd.info = infos_of(blobs); sd.from_sketch = true;
+    } else {
+        LoadedGenomes lg = load_genomes(files, individual, a.threads);
+        if (lg.info.empty()) return sd;
+        sd.ss = sketch(cx, lg, a); sd.info = std::move(lg.info);
+    }
+    return sd;
+}
+
 void emit(const std::string& path, const std::string& text) {
     if (path.empty()) { fwrite(text.data(), 1, text.size(), stdout); return; }
     FILE* f = fopen(path.c_str(), "wb"); if (!f) die("cannot write " + path);
@@ -130,13 +204,13 @@ skh_map_params map_params(const Args& a, bool learned) {
     return mp;
 }
 
-int run_triangle(const Args& a, Ctx& cx) {
+int run_triangle(Args& a, Ctx& cx) {
     std::vector<std::string> files = a.files;
     if (!a.list.empty()) { auto l = read_list(a.list); files.insert(files.end(), l.begin(), l.end()); }
     if (files.empty()) die("No reference inputs found.");
-    LoadedGenomes lg = load_genomes(files, a.individual, a.threads);
-    if (lg.info.empty()) die("No genomes/sketches found.");                     // triangle.rs:46-49
-    skh_sketch_set* ss = sketch(cx, lg, a);
+    Side sd = load_side(cx, files, a.individual, a);
+    if (sd.info.empty()) die("No genomes/sketches found.");                     // triangle.rs:46-49
+    skh_sketch_set* ss = sd.ss; struct { std::vector<GenomeInfo>& info; } lg{sd.info};
     const bool learned = !a.no_learned && a.c >= 70 && !a.individual && !a.median;   // regression.rs:8-10, parse.rs:885-889
     skh_map_params mp = map_params(a, learned);
     const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:798
@@ -154,15 +228,23 @@ int run_triangle(const Args& a, Ctx& cx) {
     return 0;
 }
 
-int run_dist(const Args& a, Ctx& cx) {
+int run_dist(Args& a, Ctx& cx) {
     std::vector<std::string> q = a.queries, r = a.refs;
     if (!a.qlist.empty()) { auto l = read_list(a.qlist); q.insert(q.end(), l.begin(), l.end()); }
     if (!a.rlist.empty()) { auto l = read_list(a.rlist); r.insert(r.end(), l.begin(), l.end()); }
     if (q.empty() && r.empty() && a.files.size() >= 2) { q.push_back(a.files[0]); r.assign(a.files.begin() + 1, a.files.end()); }   // cli.rs:115-121
     if (q.empty() || r.empty()) die("No reference sketches/genomes or query sketches/genomes found.");
-    LoadedGenomes lq = load_genomes(q, a.qi, a.threads), lr = load_genomes(r, a.ri, a.threads);
+    // sketch-file sides first: their parameters are the ones FASTA sides get sketched with (dist.rs:28-52)
+    const bool r_sk = all_sketch_files(r), q_sk = all_sketch_files(q);
+    Side lr, lq;
+    if (r_sk) lr = load_side(cx, r, a.ri, a);
+    const uint32_t rc = a.c, rk = a.k, rm = a.m;
+    if (q_sk) lq = load_side(cx, q, a.qi, a);
+    if (r_sk && q_sk && (rc != a.c || rk != a.k || rm != a.m)) die("Query sketch parameters were not equal to reference sketch parameters. Exiting.");
+    if (!r_sk) lr = load_side(cx, r, a.ri, a);
+    if (!q_sk) lq = load_side(cx, q, a.qi, a);
     if (lq.info.empty() || lr.info.empty()) die("No reference sketches/genomes or query sketches/genomes found.");
-    skh_sketch_set* sq = sketch(cx, lq, a); skh_sketch_set* sr = sketch(cx, lr, a);
+    skh_sketch_set* sq = lq.ss; skh_sketch_set* sr = lr.ss;
     const bool learned = !a.no_learned && a.c >= 70 && !a.qi && !a.ri && !a.median;   // parse.rs:752-756
     skh_map_params mp = map_params(a, learned);
     const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:636
@@ -179,6 +261,53 @@ int run_dist(const Args& a, Ctx& cx) {
     return 0;
 }
 
+int run_sketch(Args& a, Ctx& cx) {                                              // sketch.rs:15-175
+    std::vector<std::string> files = a.files;
+    if (!a.list.empty()) { auto l = read_list(a.list); files.insert(files.end(), l.begin(), l.end()); }
+    if (files.empty()) die("No reference inputs found.");
+    if (a.out.empty()) die("sketch needs -o <output folder>");
+    if (mkdir(a.out.c_str(), 0777) != 0) die("Output directory exists; output directory must not be an existing directory. Exiting.");   // sketch.rs:19-23
+    LoadedGenomes lg = load_genomes(files, a.individual, a.threads);
+    if (lg.info.empty()) die("No genomes/sketches found.");
+    skh_sketch_set* ss = sketch(cx, lg, a);
+    SketchFileParams fp; fp.c = a.c; fp.k = a.k; fp.marker_c = a.m;
+    write_sketch_db(a.out, fp, export_blobs(cx, ss, lg.info, a), a.separate_sketches, a.individual);
+    skh_sketch_set_destroy(ss);
+    return 0;
+}
+
+int run_search(Args& a, Ctx& cx) {                                              // search.rs:16-282
+    if (a.database.empty()) die("search needs -d <folder written by `sketch`>");
+    std::vector<std::string> q = a.queries; q.insert(q.end(), a.files.begin(), a.files.end());
+    if (!a.qlist.empty()) { auto l = read_list(a.qlist); q.insert(q.end(), l.begin(), l.end()); }
+    if (q.empty()) die("No query sketches/genomes found.");
+    SketchDb db;
+    try { db = read_sketch_db(a.database); } catch (const std::exception& e) { die(e.what()); }
+    if (db.sketches.empty()) die("No reference sketches found in the database folder.");
+    a.c = (uint32_t)db.params.c; a.k = (uint32_t)db.params.k; a.m = (uint32_t)db.params.marker_c;   // queries follow the database's parameters (search.rs:37,115-125)
+    // the database order is the index order; the whole thing becomes one HBM-resident set
+    skh_sketch_set* sr = import_blobs(cx, db.params, db.sketches, a.seeding_mode);
+    std::vector<GenomeInfo> rinfo = infos_of(db.sketches);
+    const uint32_t dc = a.c, dk = a.k, dm = a.m;
+    Side lq = load_side(cx, q, a.qi, a);
+    if (lq.info.empty()) die("No query sketches/genomes found.");
+    if (lq.from_sketch && (dc != a.c || dk != a.k || dm != a.m)) die("Query sketch parameters not equal to reference sketch parameters; no ANI calculated");
+    const bool learned = !a.no_learned && a.c >= 70 && !a.qi && !a.median;      // regression.rs:8-10 via search.rs:52
+    skh_map_params mp = map_params(a, learned);
+    const bool index = (q.size() > 50 || a.qi) && !a.no_marker_index;           // parse.rs:960
+    uint32_t *pq = nullptr, *prf = nullptr; uint64_t np = 0;
+    // search.rs:126-147: check_markers_quickly(query, ref, s, false) or screen_refs_indices
+    cx.check(skh_screen(cx.c, sr, lq.ss, a.s / 100., index ? SKH_SCREEN_REFS_INDICES : SKH_SCREEN_QUICK, 0, &pq, &prf, &np), "skh_screen");
+    std::vector<skh_ani_result> res(np);
+    cx.check(skh_chain_pairs(cx.c, sr, lq.ss, prf, pq, np, &mp, res.data(), nullptr), "skh_chain_pairs");
+    std::vector<PairResult> pr;
+    for (uint64_t x = 0; x < np; x++) if (res[x].ani > 0.5f) pr.push_back(PairResult{prf[x], pq[x], res[x]});   // search.rs:178
+    skh_free(pq); skh_free(prf);
+    emit(a.out, format_query_ref_list(rinfo, lq.info, pr, a.n, a.o));
+    skh_sketch_set_destroy(lq.ss); skh_sketch_set_destroy(sr);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -190,7 +319,9 @@ int main(int argc, char** argv) {
     int rc;
     if (a.cmd == "triangle") rc = run_triangle(a, cx);
     else if (a.cmd == "dist") rc = run_dist(a, cx);
-    else die("unknown subcommand " + a.cmd + " (supported: triangle, dist)");
+    else if (a.cmd == "sketch") rc = run_sketch(a, cx);
+    else if (a.cmd == "search") rc = run_search(a, cx);
+    else die("unknown subcommand " + a.cmd + " (supported: triangle, dist, sketch, search)");
     skh_ctx_destroy(cx.c);
     return rc;
 }

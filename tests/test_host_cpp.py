@@ -137,3 +137,33 @@ def test_cli_triangle_and_dist_end_to_end(tmp_path):
     dl = d.stdout.splitlines()
     assert dl[0].startswith("Ref_file\tQuery_file\tANI") and len(dl) == 3
     assert all(l.split("\t")[1] == files[0] for l in dl[1:]) and float(dl[1].split("\t")[2]) >= float(dl[2].split("\t")[2])
+
+
+@pytest.mark.gpu
+def test_cli_sketch_then_search_reproduces_the_reference_golden_rows(tmp_path):
+    """tests/integration_test.rs:59-68 + test_results_versions/0.3.0:130-135: `search --median` of the o157 sketch against
+    a database of the plasmid and W must print 100.00/99.84/1.68 and 98.39/85.46/75.97.  Both database flavours, a
+    re-read of our own .sketch output as a dist input, and `-i`."""
+    import shutil
+    _, exe = build_host()
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"))
+    for n in ("o157_plasmid.fasta", "e.coli-W.fasta.gz", "e.coli-o157.fasta.sketch", "viruses.fna"):
+        shutil.copy(os.path.join(GOLDEN, n), tmp_path / n)
+    run = lambda *a: subprocess.run([exe] + list(a), capture_output=True, text=True, cwd=tmp_path, env=env)
+    for flag, db in (((), "db"), (("--separate-sketches",), "db_sep")):
+        r = run("sketch", "o157_plasmid.fasta", "e.coli-W.fasta.gz", "-o", db, *flag); assert r.returncode == 0, r.stderr
+        assert run("sketch", "o157_plasmid.fasta", "-o", db).returncode != 0                      # existing folder refused (sketch.rs:19-23)
+        s = run("search", "-d", db, "e.coli-o157.fasta.sketch", "--median"); assert s.returncode == 0, s.stderr
+        rows = {l.split("\t")[0]: l.split("\t") for l in s.stdout.splitlines()[1:]}
+        assert rows["o157_plasmid.fasta"][1:5] == ["test_files/e.coli-o157.fasta", "100.00", "99.84", "1.68"]
+        assert rows["e.coli-W.fasta.gz"][1:5] == ["test_files/e.coli-o157.fasta", "98.39", "85.46", "75.97"]
+    # .sketch files as dist inputs on both sides == FASTA inputs
+    a = run("dist", "-q", "e.coli-o157.fasta.sketch", "-r", "db_sep/e.coli-W.fasta.gz.sketch", "--median"); assert a.returncode == 0, a.stderr
+    assert a.stdout.splitlines()[1].split("\t")[:5] == ["e.coli-W.fasta.gz", "test_files/e.coli-o157.fasta", "98.39", "85.46", "75.97"]
+    b = run("dist", "-q", "o157_plasmid.fasta", "-r", "db_sep/e.coli-W.fasta.gz.sketch"); c = run("dist", "-q", "o157_plasmid.fasta", "-r", "e.coli-W.fasta.gz")
+    assert b.returncode == 0 and b.stdout == c.stdout
+    # -i: one sketch per contig, consolidated database, searched contig by contig
+    r = run("sketch", "-i", "viruses.fna", "-o", "db_i"); assert r.returncode == 0, r.stderr
+    s = run("search", "-d", "db_i", "--qi", "viruses.fna"); t = run("dist", "--qi", "--ri", "-q", "viruses.fna", "-r", "viruses.fna")
+    assert s.returncode == 0 and t.returncode == 0, s.stderr + t.stderr
+    assert sorted(s.stdout.splitlines()) == sorted(t.stdout.splitlines()) and len(s.stdout.splitlines()) >= 1 + 3
