@@ -24,19 +24,19 @@ namespace skh {
 struct SetView {
     const uint32_t *p_seed, *p_pos, *p_cc; const uint16_t* p_cnt;
     const uint32_t *s_pos, *s_cc;
-    const uint64_t* table;
+    const uint64_t* ent; const uint32_t* dir;
 };
 static SetView view_of(const skh_sketch_set* s) {
-    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->table.p};
+    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->ent.p, s->dir.p};
 }
 
 struct PairDesc {
     uint64_t a_pos0;    // A (enumerated sketch): first entry in its set's position-order arrays
     uint64_t b_pos0;    // B (probed sketch): first entry in its set's seed-order arrays
-    uint64_t reserved0;
-    uint64_t b_tab0;    // B: first slot of its hash table
+    uint64_t b_ent0;    // B: first entry of its seed index
+    uint64_t b_dir0;    // B: first bucket of its seed directory
     uint32_t a_n;       // positions in A
-    uint32_t b_mask;    // B table size - 1
+    uint32_t b_nbk;     // B: buckets in its seed directory
     uint32_t flags;     // bit0: A lives in set 1, bit1: B lives in set 1, bit2: switched (chain.rs:649)
     uint32_t tile0;     // first join tile of this pair (global over the call)
     // finalisation inputs (ref/query in the caller's sense, NOT A/B)
@@ -65,30 +65,36 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     const PairDesc pd = pairs[p];
     const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
-    const uint64_t* tab = B.table + pd.b_tab0;
+    const uint64_t* ent = B.ent + pd.b_ent0; const uint32_t* dir = B.dir + pd.b_dir0;
     constexpr int R = JOIN_TILE / 256;
     // the four positions of this thread are probed together: their loads are independent, so they overlap
-    uint32_t seed[R], h[R]; bool live[R]; unsigned long long e[R];
+    uint32_t h[R], d0[R], d1[R]; bool live[R]; unsigned long long e[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t i = start + r * 256 + threadIdx.x;
         live[r] = i < pd.a_n;
         const uint32_t cnt = live[r] ? (uint32_t)A.p_cnt[pd.a_pos0 + i] : 0xFFFFu;
-        seed[r] = live[r] ? A.p_seed[pd.a_pos0 + i] : 0u;
+        const uint32_t seed = live[r] ? A.p_seed[pd.a_pos0 + i] : 0u;
         live[r] = live[r] && cnt <= band;                                          // chain.rs:674-676
-        h[r] = mix32(seed[r]) & pd.b_mask;
+        h[r] = mix32(seed);
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) e[r] = live[r] ? tab[h[r]] : TAB_EMPTY;
+    for (int r = 0; r < R; r++) {
+        d0[r] = 0; d1[r] = 0;
+        if (live[r]) { const uint32_t b = seed_bucket(h[r], pd.b_nbk); d0[r] = dir[b]; d1[r] = dir[b + 1]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) e[r] = d0[r] < d1[r] ? ent[d0[r]] : TAB_EMPTY;
     uint32_t na = 0, nq = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
         uint32_t n_anch = 0, inq = 0, bstart = 0;
         if (live[r]) {
-            unsigned long long x = e[r]; uint32_t hh = h[r];
-            while (x != TAB_EMPTY && (uint32_t)(x >> 32) != seed[r]) { hh = (hh + 1) & pd.b_mask; x = tab[hh]; }
-            if (x == TAB_EMPTY) inq = 1;                                           // absent in B: chain.rs:682-685
+            unsigned long long x = e[r]; uint32_t dd = d0[r];
+            // entries of a bucket ascend by hash; TAB_EMPTY (all ones) also ends the walk
+            while ((uint32_t)(x >> 32) < h[r]) { dd++; x = dd < d1[r] ? ent[dd] : TAB_EMPTY; }
+            if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) inq = 1;            // absent in B: chain.rs:682-685
             else {
                 const uint32_t cnt = (uint32_t)x & 0xFFu;
                 if (cnt <= band) { inq = 1; n_anch = cnt; bstart = ((uint32_t)x >> 8) & 0xFFFFFFu; }   // else chain.rs:694-696: dropped entirely
@@ -474,21 +480,25 @@ constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidat
 //   2. greedy acceptance 64 candidates at a time: every lane owns one candidate and sums its overlaps against the
 //      accepted list (uniform LDS broadcasts, no reductions); the 64 decisions are then resolved in order, an accepted
 //      candidate's interval being broadcast (v_readlane) to the later lanes of the same batch (chain.rs:1017-1095).
+//   LDS per wave is 36 B x CAP; the kernel is instantiated for CAP = 256 / 512 / 1024 and a pair runs in the smallest one that
+//   holds it, so that typical pairs (a few hundred candidates) leave room for 2-3 waves per SIMD: the greedy loop is a chain
+//   of dependent instructions, and other waves are the only thing that can fill its issue slots.
+struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1, pad0, pad1; };   // 32 B: two 16-byte LDS broadcasts per accepted interval
+template <uint32_t CAP>
 __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt, const Interval* ivls,
                                                           uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
-    __shared__ unsigned long long lds_key[2][GREEDY_FAST];
-    __shared__ uint32_t lds_idx[2][GREEDY_FAST];
-    __shared__ uint32_t lds_acc[2][6][GREEDY_FAST];      // accepted intervals: rctg, r0, r1, qctg, q0, q1
+    __shared__ uint32_t lds_idx[2][CAP];
+    __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t p = blockIdx.x * 2 + wv;
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
-    if (n > GREEDY_FAST) return;                                                    // handled by greedy_kernel
+    if (n > CAP || (CAP > 256 && n <= CAP / 2)) return;                              // another instantiation's (or greedy_kernel's) pair
     if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
     uint32_t N = 1; while (N < n) N <<= 1;
-    unsigned long long* key = lds_key[wv]; uint32_t* idx = lds_idx[wv];
+    unsigned long long* key = (unsigned long long*)lds_acc[wv]; uint32_t* idx = lds_idx[wv];
     const Interval* iv = ivls + I0;
     for (uint32_t i = l; i < N; i += 64) {
         unsigned long long kx = 0; uint32_t ix = NONE;
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
             wave_sync_mem();
         }
     }
-    uint32_t (*acc)[GREEDY_FAST] = lds_acc[wv];
+    AccIvl* acc = lds_acc[wv];
     uint32_t nacc = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t s = base + l;
@@ -523,7 +533,8 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
         Interval c = iv[ci];
         uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
         for (uint32_t a = 0; a < nacc; a++) {                                      // uniform index: LDS broadcast
-            const uint32_t actg = acc[0][a], ar0 = acc[1][a], ar1 = acc[2][a], aqc = acc[3][a], aq0 = acc[4][a], aq1 = acc[5][a];
+            const uint4 lo4 = *(const uint4*)&acc[a]; const uint2 hi2 = *(const uint2*)&acc[a].q0;
+            const uint32_t actg = lo4.x, ar0 = lo4.y, ar1 = lo4.z, aqc = lo4.w, aq0 = hi2.x, aq1 = hi2.y;
             const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;             // chain.rs:1030-1045
             const bool hq = aqc == c.qctg && aq0 < c.q1 && c.q0 < aq1;              // chain.rs:1059-1073
             const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                     cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
                 }
                 if (l == 0) {
-                    acc[0][nacc] = actg; acc[1][nacc] = ar0; acc[2][nacc] = ar1; acc[3][nacc] = aqc; acc[4][nacc] = aq0; acc[5][nacc] = aq1;
+                    acc[nacc] = AccIvl{actg, ar0, ar1, aqc, aq0, aq1, 0u, 0u};
                     const uint32_t slot = pc0[p] + bchunk;
                     ivl_next[I0 + bci] = chunk_head[slot]; chunk_head[slot] = I0 + bci;   // good_non_overlap_intervals[chunk_id].push
                 }
@@ -623,9 +634,12 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
 }
 
 // ------------------------------------------------------------------------------------------------ per-chunk ANI inputs
-// chain.rs:199-413.  One THREAD per chunk (a chunk owns ~1-3 accepted intervals and ~160 query seed positions): walk the
-// chunk's accepted intervals, then count the chunk's query seed positions that fall inside the union of the (padded)
-// intervals and inside the covered range; finally the chunk's ANI estimate and weight.
+// chain.rs:199-413.  A wave owns 64 consecutive chunks.  Lane j first walks chunk j's accepted intervals (1-3 of them);
+// then the wave visits the 64 chunks one after the other: chunk j's interval bounds are broadcast with v_readlane and all
+// 64 lanes stream its ~160 query seed positions as coalesced 256-byte reads, counting the positions inside the union of the
+// (padded) intervals and inside the covered range with ballots; finally lane j turns chunk j's counts into its ANI estimate
+// and weight.  (A thread-per-chunk walk of the position list touches 64 different cache lines per load and fetched the
+// list 4-5 times over.)
 constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more -> slow path re-walks the list per position)
 
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
@@ -633,57 +647,86 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
                                                           uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint32_t* pair_tqb, uint32_t* pair_acl,
                                                           uint32_t* pair_nchains) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    const uint32_t head = chunk_head[slot];
-    chunk_w[slot] = NONE;                                                           // NONE = no estimate from this chunk
-    if (head == NONE) return;                                                       // total_anchors == 0 (chain.rs:253)
-    const Chunk ck = chunks[slot];
-    const uint32_t p = chunk_pair[slot];
-    const bool switched = (pairs[p].flags & 4u) != 0;
-    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0;
+    const uint32_t l = lane_id();
+    const bool valid = slot < n_slots;
+    const uint32_t head = valid ? chunk_head[slot] : NONE;
+    if (valid) chunk_w[slot] = NONE;                                                // NONE = no estimate from this chunk
+    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0, s_begin = 0, s_end = 0;
     uint32_t lo[STATS_REG], hi[STATS_REG];
 #pragma unroll
     for (int i = 0; i < STATS_REG; i++) { lo[i] = 1; hi[i] = 0; }                   // empty
-    for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
-        const Interval iv = ivls[e];
-        total_anchors += iv.na;
-        if (iv.q0 < rq0) rq0 = iv.q0;
-        if (iv.q1 > rq1) rq1 = iv.q1;
-        tbcq += (switched ? iv.r1 - iv.r0 : iv.q1 - iv.q0) + k + 2 * c;             // chain.rs:223-237
-        sum_len += (iv.q1 - iv.q0) + 2 * c + k;                                     // chain.rs:245-249 (overlap is always 0, chain.rs:1091-1093)
-        const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0, h0 = iv.q1 + c;              // chain.rs:239-242
+    bool active = false;
+    if (head != NONE) {                                                             // else total_anchors == 0 (chain.rs:253)
+        const Chunk ck = chunks[slot];
+        const uint32_t p = chunk_pair[slot];
+        const bool switched = (pairs[p].flags & 4u) != 0;
+        s_begin = ck.s_begin; s_end = ck.s_end;
+        for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
+            const Interval iv = ivls[e];
+            total_anchors += iv.na;
+            if (iv.q0 < rq0) rq0 = iv.q0;
+            if (iv.q1 > rq1) rq1 = iv.q1;
+            tbcq += (switched ? iv.r1 - iv.r0 : iv.q1 - iv.q0) + k + 2 * c;         // chain.rs:223-237
+            sum_len += (iv.q1 - iv.q0) + 2 * c + k;                                 // chain.rs:245-249 (overlap is always 0, chain.rs:1091-1093)
+            const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0, h0 = iv.q1 + c;          // chain.rs:239-242
 #pragma unroll
-        for (int i = 0; i < STATS_REG; i++) if (n_int == (uint32_t)i) { lo[i] = l0; hi[i] = h0; }
-        n_int++;
-    }
-    const bool sensitive = c < 200;                                                 // chain.rs:184-190
-    if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
-    atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
-    if (rq1 - rq0 < MIN_LENGTH_COVER) return;                                       // chain.rs:257
-    if (!sensitive) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);                 // chain.rs:261-264
-    uint32_t in_u = 0, in_range = 0;
-    // 16-byte aligned groups of four positions: one L2 request serves four positions (lanes read different chunks, so
-    // narrower loads would re-fetch every 64-byte line many times)
-    const uint4* ql4 = (const uint4*)ql_pos;
-    for (uint32_t g = ck.s_begin >> 2; g < (ck.s_end + 3) >> 2; g++) {
-        const uint4 v = ql4[g];
-        const uint32_t pos[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t s = (g << 2) + (uint32_t)u;
-            if (s < ck.s_begin || s >= ck.s_end) continue;
-            bool hit = false;
-            if (n_int <= (uint32_t)STATS_REG) {
-#pragma unroll
-                for (int i = 0; i < STATS_REG; i++) hit = hit || (pos[u] >= lo[i] && pos[u] <= hi[i]);
-            } else {
-                for (uint32_t e = head; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos[u] >= l0 && pos[u] <= iv.q1 + c); }
-            }
-            in_u += hit ? 1u : 0u;                                                  // chain.rs:268-272
-            in_range += (pos[u] >= rq0 && pos[u] <= rq1) ? 1u : 0u;                 // chain.rs:326-332 (spacing estimates are 0)
+            for (int i = 0; i < STATS_REG; i++) if (n_int == (uint32_t)i) { lo[i] = l0; hi[i] = h0; }
+            n_int++;
         }
+        const bool sensitive = c < 200;                                             // chain.rs:184-190
+        if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
+        atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
+        active = rq1 - rq0 >= MIN_LENGTH_COVER;                                     // chain.rs:257
+        if (active && !sensitive) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);   // chain.rs:261-264
     }
-    uint32_t considered = ck.s_end - ck.s_begin;
+    uint32_t in_u = 0, in_range = 0;
+    unsigned long long todo = __ballot(active);
+    // the first 256 positions of a chunk are fetched as four independent loads, and the next chunk's are in flight while the
+    // current chunk is counted: the loop is otherwise a chain of dependent round trips to memory
+    constexpr int PF = 4;
+    uint32_t cur[PF], nxt[PF];
+    int j = -1; uint32_t sb = 0, se = 0;
+    if (todo) {
+        j = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
+        sb = wave_readlane(s_begin, j); se = wave_readlane(s_end, j);
+#pragma unroll
+        for (int u = 0; u < PF; u++) { const uint32_t s2 = sb + 64u * (uint32_t)u + l; cur[u] = s2 < se ? ql_pos[s2] : 0u; }
+    }
+    while (j >= 0) {                                                                // wave-uniform
+        int jn = -1; uint32_t sbn = 0, sen = 0;
+        if (todo) {
+            jn = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
+            sbn = wave_readlane(s_begin, jn); sen = wave_readlane(s_end, jn);
+#pragma unroll
+            for (int u = 0; u < PF; u++) { const uint32_t s2 = sbn + 64u * (uint32_t)u + l; nxt[u] = s2 < sen ? ql_pos[s2] : 0u; }
+        }
+        const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
+        uint32_t lj[STATS_REG], hj[STATS_REG];
+#pragma unroll
+        for (int i = 0; i < STATS_REG; i++) { lj[i] = wave_readlane(lo[i], j); hj[i] = wave_readlane(hi[i], j); }
+        uint32_t cu = 0, cr = 0;
+        auto count = [&](uint32_t s2, uint32_t pos) {
+            const bool on = s2 < se;
+            bool hit = false;
+            if (nj <= (uint32_t)STATS_REG) {
+#pragma unroll
+                for (int i = 0; i < STATS_REG; i++) hit = hit || (pos >= lj[i] && pos <= hj[i]);
+            } else {
+                for (uint32_t e = headj; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos >= l0 && pos <= iv.q1 + c); }
+            }
+            cu += (uint32_t)__popcll(__ballot(on && hit));                          // chain.rs:268-272
+            cr += (uint32_t)__popcll(__ballot(on && pos >= q0j && pos <= q1j));     // chain.rs:326-332 (spacing estimates are 0)
+        };
+#pragma unroll
+        for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(sb + 64u * (uint32_t)u + l, cur[u]);
+        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) { const uint32_t s2 = b2 + l; count(s2, s2 < se ? ql_pos[s2] : 0u); }
+        if ((int)l == j) { in_u = cu; in_range = cr; }
+        j = jn; sb = sbn; se = sen;
+#pragma unroll
+        for (int u = 0; u < PF; u++) cur[u] = nxt[u];
+    }
+    if (!active) return;
+    uint32_t considered = s_end - s_begin;
     const double inv_k = 1. / (double)k;
     const double putative = pow((double)total_anchors / (double)in_u, inv_k);       // chain.rs:335-339
     if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < CHUNK_SIZE * 9 / 10 && (double)considered > 1.05 * (double)in_range)
@@ -809,27 +852,53 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     double ci_lo = 0., ci_hi = 1.;
     if (fa.compute_ci && n >= 10) {
         uint32_t nsteps = 0; while ((1u << nsteps) < n) nsteps++;                  // fixed-length branch-free binary search
-        for (uint32_t it = 0; it < 100; it++) {
-            double s = 0.;
-            for (uint32_t j0 = l; j0 < n; j0 += 256) {                               // four independent searches per lane in flight
-                uint64_t x[4]; uint32_t lo[4], hi[4]; bool on[4];
+        // first i with CUM[i] > x; x < total_mult = CUM[n-1], so the answer is in [0, n-1]
+        auto search64 = [&](uint64_t x) { uint32_t lo = 0, hi = n - 1; for (uint32_t st = 0; st < nsteps; st++) { const uint32_t mid = (lo + hi) >> 1; const bool gt = CUM[mid] > x; hi = gt ? mid : hi; lo = gt ? lo : mid + 1; } return lo; };
+        if (in_lds && total_mult < 0xFFFFFFFFull) {
+            // Fast path (every realistic pair): 32-bit cumulative weights, and a 257-entry directory over the value range
+            // (bucket b = x >> sh) that narrows each search to the one or two entries whose cumulative weight falls into
+            // the draw's bucket.  Both live in LDS arrays that are dead after the sort (unsorted weights / estimates).
+            uint32_t* C32 = UW; uint32_t* T = (uint32_t*)U;
+            uint32_t sh = 0; while ((total_mult >> sh) >= 256) sh++;
+            const uint32_t nb = (uint32_t)(total_mult >> sh) + 1;                      // x < total_mult  =>  x >> sh < nb
+            for (uint32_t i = l; i < n; i += 64) C32[i] = (uint32_t)CUM[i];
+            for (uint32_t b = l; b <= nb; b += 64) T[b] = search64((uint64_t)b << sh);   // past-the-end thresholds give n-1
+            wave_sync_mem();
+            const uint32_t tot32 = (uint32_t)total_mult;
+            for (uint32_t it = 0; it < 100; it++) {
+                double s = 0.;
+                for (uint32_t j0 = l; j0 < n; j0 += 256) {
+                    uint32_t x[4], lo[4], hi[4]; bool on[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t j = j0 + 64u * (uint32_t)u;
-                    on[u] = j < n;
-                    const uint64_t r = wyrand_draw((uint64_t)it * n + (on[u] ? j : 0));
-                    x[u] = __umul64hi(r, total_mult);                               // Lemire reduction; its rejection branch has probability total/2^64
-                    lo[u] = 0; hi[u] = n - 1;                                       // first i with CUM[i] > x
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u;
+                        on[u] = j < n;
+                        const uint64_t r = wyrand_draw((uint64_t)it * n + (on[u] ? j : 0));
+                        // Lemire reduction hi64(r * total) for total < 2^32; its rejection branch has probability total/2^64
+                        x[u] = (uint32_t)(((r >> 32) * tot32 + (((r & 0xFFFFFFFFull) * tot32) >> 32)) >> 32);
+                        const uint32_t b = x[u] >> sh;
+                        lo[u] = T[b]; hi[u] = T[b + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        while (lo[u] < hi[u]) { const uint32_t mid = (lo[u] + hi[u]) >> 1; const bool gt = C32[mid] > x[u]; hi[u] = gt ? mid : hi[u]; lo[u] = gt ? lo[u] : mid + 1; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (on[u]) s += S[lo[u]];
                 }
-                for (uint32_t st = 0; st < nsteps; st++) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const uint32_t mid = (lo[u] + hi[u]) >> 1; const bool gt = CUM[mid] > x[u]; hi[u] = gt ? mid : hi[u]; lo[u] = gt ? lo[u] : mid + 1; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (on[u]) s += S[lo[u] < n ? lo[u] : n - 1];
+                s = wave_sum_f64(s);
+                if (l == 0) lds_boot[wv][it] = s / (double)n;
             }
-            s = wave_sum_f64(s);
-            if (l == 0) lds_boot[wv][it] = s / (double)n;
+        } else {
+            for (uint32_t it = 0; it < 100; it++) {
+                double s = 0.;
+                for (uint32_t j0 = l; j0 < n; j0 += 64) {
+                    const uint64_t r = wyrand_draw((uint64_t)it * n + j0);
+                    s += S[search64(__umul64hi(r, total_mult))];
+                }
+                s = wave_sum_f64(s);
+                if (l == 0) lds_boot[wv][it] = s / (double)n;
+            }
         }
         wave_sync_mem();
         for (uint32_t i = l; i < 100; i += 64) {
@@ -959,7 +1028,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
         const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
         pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.b_pos0 = B->pos_off[gb]; pd.reserved0 = 0; pd.b_tab0 = B->tab_off[gb]; pd.b_mask = B->tab_mask[gb];
+        pd.b_pos0 = B->pos_off[gb]; pd.b_ent0 = B->dist_off[gb]; pd.b_dir0 = B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb];
         pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
         pd.tile0 = (uint32_t)tile_pair.size();
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
@@ -1068,9 +1137,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
                 check_launch("interval_emit");
             }
         }
-        SKH_LAUNCH(greedy_fast_kernel, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, (const uint32_t*)ivl_cnt,
-                   (const Interval*)ivls, ivl_next, chunk_head, n_acc);
-        check_launch("greedy_fast");
+#define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, (const uint32_t*)ivl_cnt, \
+                   (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
+        SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
+#undef SKH_GREEDY
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
         check_launch("greedy");

@@ -44,6 +44,9 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     return h;
 }
 
+// bucket of a hashed seed in a genome's seed directory: monotone in the hash, any bucket count
+__host__ __device__ __forceinline__ uint32_t seed_bucket(uint32_t hash, uint32_t n_buckets) { return (uint32_t)(((uint64_t)hash * n_buckets) >> 32); }
+
 // contig descriptor inside a packed genome set
 struct ContigDesc {
     uint64_t base;      // first base in the packed stream (multiple of CONTIG_ALIGN)

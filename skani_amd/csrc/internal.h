@@ -87,8 +87,8 @@ struct skh_sketch_set {
     skh_sketch_params params{};
     uint32_t n_genomes = 0;
     // host metadata (one entry per genome unless noted)
-    std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
-    std::vector<uint32_t> tab_mask;
+    std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, dir_off;   // n_genomes+1
+    std::vector<uint32_t> n_buckets;               // buckets of each genome's seed directory
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
     std::vector<uint64_t> total_len;
     std::vector<double> mean_ctg;
@@ -99,12 +99,15 @@ struct skh_sketch_set {
     skh::DBuf<uint32_t> p_seed, p_pos, p_cc;       // position order (contig, pos)
     skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)
     skh::DBuf<uint32_t> s_pos, s_cc;               // seed order (seed, contig, pos)
-    skh::DBuf<uint64_t> table;                     // open addressing: seed << 32 | start (24 bits, in the genome's seed-order
-                                                   // arrays) << 8 | min(multiplicity, 255); TAB_EMPTY
+    // seed index (probe side): one entry per distinct seed, sorted by mix32(seed) within the genome:
+    //   mix32(seed) << 32 | start (24 bits, in the genome's seed-order arrays) << 8 | min(multiplicity, 255)
+    // and a bucket directory over the hash range: entries of bucket b = mulhi(hash, n_buckets) are ent[dir[b] .. dir[b+1])
+    skh::DBuf<uint64_t> ent;
+    skh::DBuf<uint32_t> dir;                       // n_buckets + 1 per genome, values relative to the genome's first entry
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_ctg_len;
-    skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_tab_off;
-    skh::DBuf<uint32_t> d_tab_mask;
+    skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_dir_off;
+    skh::DBuf<uint32_t> d_n_buckets;
 };
 
 namespace skh {

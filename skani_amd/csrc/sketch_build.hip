@@ -3,8 +3,11 @@
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
 //   position order : p_seed/p_pos/p_cc (+ p_cnt = multiplicity of the entry's seed in this genome)  -- enumeration side
-//   seed order     : s_pos/s_cc sorted by (seed, contig, pos)
-//   hash table     : open addressing, 64-bit slots seed << 32 | start << 8 | multiplicity, load <= 0.6       -- probe side
+//   seed order     : s_pos/s_cc sorted by (mix32(seed), contig, pos)     (mix32 is a bijection: equal hash <=> equal seed)
+//   seed index     : ent = one 64-bit entry per distinct seed in hash order, hash << 32 | start << 8 | multiplicity,
+//                    dir = bucket directory over the hash range (2 buckets per distinct seed)                -- probe side
+//                    Built by one sort + a scatter of bucket boundaries: no atomics, no empty-slot fill, and a probe of an
+//                    absent seed usually ends at its (empty) bucket after one 8-byte read.
 //   markers        : sorted unique u64
 #include <algorithm>
 
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_s
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t g = seg_of(pos_off, ng, i);
-    keys[i] = ((uint64_t)g << 32) | p_seed[i];
+    keys[i] = ((uint64_t)g << 32) | mix32(p_seed[i]);
     vals[i] = (uint32_t)(i - pos_off[g]);
 }
 
@@ -34,14 +37,16 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, u
 }
 
 __global__ __launch_bounds__(256) void distinct_kernel(const uint64_t* keys, const uint32_t* head, const uint32_t* excl, uint64_t n,
-                                                       const uint64_t* pos_off, uint32_t* u_seed, uint32_t* u_start, uint16_t* u_cnt) {
+                                                       const uint64_t* pos_off, uint64_t* ent, uint16_t* u_cnt) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !head[i]) return;
     const uint64_t key = keys[i];
     uint32_t cnt = 1;
     while (i + cnt < n && keys[i + cnt] == key) cnt++;
     const uint32_t d = excl[i], g = (uint32_t)(key >> 32);
-    u_seed[d] = (uint32_t)key; u_start[d] = (uint32_t)(i - pos_off[g]); u_cnt[d] = (uint16_t)(cnt > 65535u ? 65535u : cnt);
+    // one 8-byte entry answers a probe completely: hash | first entry in the seed-order arrays | multiplicity
+    ent[d] = ((key & 0xFFFFFFFFull) << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (cnt > 255u ? 255u : cnt);
+    u_cnt[d] = (uint16_t)(cnt > 65535u ? 65535u : cnt);
 }
 
 __global__ __launch_bounds__(256) void seed_order_gather_kernel(const uint64_t* keys, const uint32_t* vals, const uint32_t* head,
@@ -61,22 +66,19 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
     if (i < n) out[i] = src[idx[i]];
 }
 
-__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* u_seed, const uint32_t* u_start, const uint16_t* u_cnt, const uint64_t* dist_off,
-                                                           uint32_t ng, uint64_t n_dist, const uint64_t* tab_off, const uint32_t* tab_mask, uint64_t* table) {
+// Bucket directory: entry d (hash order) closes every bucket after its predecessor's up to its own; the genome's last
+// entry also closes the remaining buckets.  dir values are entry indices relative to the genome's first entry.
+__global__ __launch_bounds__(256) void dir_build_kernel(const uint64_t* ent, const uint64_t* dist_off, uint32_t ng, uint64_t n_dist, const uint64_t* dir_off,
+                                                        const uint32_t* n_buckets, uint32_t* dir) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_dist) return;
     const uint32_t g = seg_of(dist_off, ng, d);
-    const uint32_t seed = u_seed[d], mask = tab_mask[g];
-    const uint32_t cnt = u_cnt[d] > 255 ? 255u : (uint32_t)u_cnt[d];
-    // one 8-byte slot answers a probe completely: seed | first entry in the seed-order arrays | multiplicity
-    const unsigned long long entry = ((unsigned long long)seed << 32) | ((unsigned long long)(u_start[d] & 0xFFFFFFu) << 8) | cnt;
-    unsigned long long* tab = (unsigned long long*)(table + tab_off[g]);
-    uint32_t h = mix32(seed) & mask;
-    for (;;) {
-        unsigned long long prev = atomicCAS(&tab[h], (unsigned long long)TAB_EMPTY, entry);
-        if (prev == (unsigned long long)TAB_EMPTY) break;
-        h = (h + 1) & mask;
-    }
+    const uint32_t ld = (uint32_t)(d - dist_off[g]), dg = (uint32_t)(dist_off[g + 1] - dist_off[g]), nbk = n_buckets[g];
+    uint32_t* dr = dir + dir_off[g];
+    const uint32_t b = seed_bucket((uint32_t)(ent[d] >> 32), nbk);
+    uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)(ent[d - 1] >> 32), nbk) + 1u;
+    for (uint32_t x = from; x <= b; x++) dr[x] = ld;
+    if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -90,7 +92,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
     for (uint32_t g = 0; g < ng; g++)
         if (ss->pos_off[g + 1] - ss->pos_off[g] >= (1ull << 24)) throw Error("a genome with >= 2^24 seed positions does not fit the 24-bit table slot field");
     uint64_t D = 0;
-    uint32_t *u_seed = nullptr, *u_start = nullptr; uint16_t* u_cnt = nullptr;       // CSR over distinct seeds: build-time temporaries
+    uint16_t* u_cnt = nullptr;                                                        // multiplicity per distinct seed: build-time temporary
     if (P > 0) {
         if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
         uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P);
@@ -109,33 +111,35 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
         d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
         for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
         D = ss->dist_off[ng];
-        u_seed = ctx->arena.get<uint32_t>(D); u_start = ctx->arena.get<uint32_t>(D); u_cnt = ctx->arena.get<uint16_t>(D);
+        u_cnt = ctx->arena.get<uint16_t>(D);
+        ss->ent.alloc(D);
         SKH_LAUNCH(distinct_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)head, (const uint32_t*)excl, P,
-                   (const uint64_t*)ss->d_pos_off.p, u_seed, u_start, u_cnt);
+                   (const uint64_t*)ss->d_pos_off.p, ss->ent.p, u_cnt);
         check_launch("distinct");
         SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
                    (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_pos.p, (const uint32_t*)ss->p_cc.p,
                    (const uint16_t*)u_cnt, ss->s_pos.p, ss->s_cc.p, ss->p_cnt.p);
         check_launch("seed_order_gather");
     }
-    // hash tables (north-star requirement: per-sketch seed -> position tables built on device)
-    ss->tab_off.assign(ng + 1, 0); ss->tab_mask.assign(ng, 0);
+    else ss->ent.alloc(0);
+    // bucket directories (north-star requirement: per-sketch seed -> position tables built on device)
+    ss->dir_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0);
     for (uint32_t g = 0; g < ng; g++) {
-        uint64_t dg = ss->dist_off[g + 1] - ss->dist_off[g];
-        uint64_t cap = 16; while (cap * 6 < dg * 10) cap <<= 1;     // load factor <= 0.6
-        ss->tab_mask[g] = (uint32_t)(cap - 1); ss->tab_off[g + 1] = ss->tab_off[g] + cap;
+        const uint64_t dg = ss->dist_off[g + 1] - ss->dist_off[g];
+        ss->n_buckets[g] = (uint32_t)std::max<uint64_t>(16, 2 * dg);                  // dg < 2^24
+        ss->dir_off[g + 1] = ss->dir_off[g] + ss->n_buckets[g] + 1;
     }
-    const uint64_t S = ss->tab_off[ng];
-    ss->table.alloc(S);
-    dfill(ss->table.p, 0xFF, S * 8, ctx->stream);
+    ss->dir.alloc(ss->dir_off[ng]);
     ss->d_dist_off.alloc(ng + 1); h2d(ss->d_dist_off.p, ss->dist_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->d_tab_off.alloc(ng + 1); h2d(ss->d_tab_off.p, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->d_tab_mask.alloc(ng ? ng : 1); h2d(ss->d_tab_mask.p, ss->tab_mask.data(), ng * 4, ctx->stream);
+    ss->d_dir_off.alloc(ng + 1); h2d(ss->d_dir_off.p, ss->dir_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
+    bool any_empty = false;
+    for (uint32_t g = 0; g < ng; g++) any_empty = any_empty || ss->dist_off[g + 1] == ss->dist_off[g];
+    if (any_empty) dzero(ss->dir.p, ss->dir_off[ng] * 4, ctx->stream);                // genomes without seeds: every bucket empty
     if (D > 0) {
-        SKH_LAUNCH(table_insert_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)u_seed, (const uint32_t*)u_start,
-                   (const uint16_t*)u_cnt, (const uint64_t*)ss->d_dist_off.p, ng, D, (const uint64_t*)ss->d_tab_off.p, (const uint32_t*)ss->d_tab_mask.p,
-                   ss->table.p);
-        check_launch("table_insert");
+        SKH_LAUNCH(dir_build_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->ent.p, (const uint64_t*)ss->d_dist_off.p, ng, D,
+                   (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, ss->dir.p);
+        check_launch("dir_build");
     }
     dsync(ctx->stream);
 }
