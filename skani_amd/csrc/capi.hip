@@ -62,13 +62,6 @@ skh_sketch_set* new_sketch_set(skh_ctx* ctx, const skh_sketch_params& sp, uint32
     return ss;
 }
 
-void upload_contig_tables(skh_ctx* ctx, skh_sketch_set* ss) {
-    ss->d_ctg_len.alloc(ss->ctg_len.size() ? ss->ctg_len.size() : 1);
-    h2d(ss->d_ctg_len.p, ss->ctg_len.data(), ss->ctg_len.size() * 4, ctx->stream);
-    ss->d_ctg_off.alloc(ss->n_genomes + 1);
-    h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ss->n_genomes + 1) * 8, ctx->stream);
-}
-
 }  // namespace
 
 extern "C" {
@@ -92,6 +85,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.screen_cells = env("SKH_TUNE_SCREEN_CELLS", ctx->tune.screen_cells);
         ctx->tune.chain_anchors = env("SKH_TUNE_CHAIN_ANCHORS", ctx->tune.chain_anchors);
         ctx->tune.chain_super_tiles = (uint32_t)env("SKH_TUNE_CHAIN_SUPER_TILES", ctx->tune.chain_super_tiles);
+        ctx->tune.chain_dp_lds_slots = (uint32_t)env("SKH_TUNE_CHAIN_DP_LDS_SLOTS", ctx->tune.chain_dp_lds_slots);
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
     *out = ctx;
@@ -165,12 +159,11 @@ int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketc
         ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
         for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
         finalize_metadata(ss);
-        upload_contig_tables(ctx, ss);
         SeedOutput so;
         { Stopwatch sw(ctx, &ctx->timings.seed_ms); seed_genomes(ctx, gs, *sp, so); }
-        ss->p_seed = std::move(so.seed); ss->p_pos = std::move(so.pos); ss->p_cc = std::move(so.cc); ss->pos_off = so.pos_off;
+        ss->p_seed = std::move(so.seed); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
         Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
-        build_sketch_tables(ctx, ss);
+        build_sketch_tables(ctx, ss, nullptr, nullptr);
         ctx->arena.reset();
         build_markers(ctx, ss, so.markers_raw, so.mk_off);
     });
@@ -212,15 +205,21 @@ int skh_sketch_sizes(const skh_sketch_set* ss, uint32_t g, uint64_t* n_pos, uint
 int skh_sketch_export(const skh_sketch_set* ss, uint32_t g, uint32_t* seed, uint32_t* pos, uint32_t* cc, uint64_t* markers, uint32_t* contig_lengths) {
     if (!ss || g >= ss->n_genomes) return SKH_ERR_INVALID;
     skh_ctx* ctx = ss->ctx;
-    return guarded(ctx, [&] {
+    const int rc = guarded(ctx, [&] {
         const uint64_t p0 = ss->pos_off[g], np = ss->pos_off[g + 1] - p0, m0 = ss->mk_off[g], nm = ss->mk_off[g + 1] - m0;
         if (seed) d2h(seed, ss->p_seed.p + p0, np * 4, ctx->stream);
-        if (pos) d2h(pos, ss->p_pos.p + p0, np * 4, ctx->stream);
-        if (cc) d2h(cc, ss->p_cc.p + p0, np * 4, ctx->stream);
+        if ((pos || cc) && np) {
+            uint32_t* tp = ctx->arena.get<uint32_t>(np); uint32_t* tc = ctx->arena.get<uint32_t>(np);
+            unpack_positions(ctx, ss, p0, np, tp, tc);
+            if (pos) d2h(pos, tp, np * 4, ctx->stream);
+            if (cc) d2h(cc, tc, np * 4, ctx->stream);
+        }
         if (markers) d2h(markers, ss->markers.p + m0, nm * 8, ctx->stream);
         if (contig_lengths) memcpy(contig_lengths, ss->ctg_len.data() + ss->ctg_off[g], (ss->ctg_off[g + 1] - ss->ctg_off[g]) * 4);
         dsync(ctx->stream);
     });
+    ctx->arena.reset();
+    return rc;
 }
 
 int skh_sketch_import_flat(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t ng, int on_device, const uint64_t* pos_off, const uint32_t* seed,
@@ -237,14 +236,18 @@ int skh_sketch_import_flat(skh_ctx* ctx, const skh_sketch_params* sp, uint32_t n
         ss->ctg_len.assign(contig_lengths, contig_lengths + contig_off[ng]);
         ss->total_len.assign(total_len, total_len + ng);
         finalize_metadata(ss);
-        upload_contig_tables(ctx, ss);
         const uint64_t P = pos_off[ng], M = marker_off[ng];
         if ((P && (!seed || !pos || !cc)) || (M && !markers)) throw std::invalid_argument("null sketch array");
-        ss->p_seed.alloc(P); ss->p_pos.alloc(P); ss->p_cc.alloc(P); ss->markers.alloc(M);
+        ss->p_seed.alloc(P); ss->markers.alloc(M);
         auto put = [&](void* d, const void* src, size_t n) { if (on_device) d2d(d, src, n, ctx->stream); else h2d(d, src, n, ctx->stream); };
-        put(ss->p_seed.p, seed, P * 4); put(ss->p_pos.p, pos, P * 4); put(ss->p_cc.p, cc, P * 4); put(ss->markers.p, markers, M * 8);
+        put(ss->p_seed.p, seed, P * 4); put(ss->markers.p, markers, M * 8);
         ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
-        build_sketch_tables(ctx, ss);
+        const uint32_t *dpos = pos, *dcc = cc;
+        if (!on_device && P) {
+            uint32_t* tp = ctx->arena.get<uint32_t>(P); uint32_t* tc = ctx->arena.get<uint32_t>(P);
+            h2d(tp, pos, P * 4, ctx->stream); h2d(tc, cc, P * 4, ctx->stream); dpos = tp; dcc = tc;
+        }
+        build_sketch_tables(ctx, ss, dpos, dcc);
     });
     ctx->arena.reset();
     if (rc != SKH_OK) { delete ss; return rc; }
@@ -270,11 +273,19 @@ int skh_sketch_export_flat(const skh_sketch_set* ss, int on_device, uint32_t* se
                            uint64_t* marker_off, uint64_t* contig_off, uint32_t* contig_lengths, uint64_t* total_len, uint32_t* genome_rank) {
     if (!ss) return SKH_ERR_INVALID;
     skh_ctx* ctx = ss->ctx;
-    return guarded(ctx, [&] {
+    const int rc = guarded(ctx, [&] {
         const uint32_t ng = ss->n_genomes;
         const uint64_t P = ss->pos_off[ng], M = ss->mk_off[ng];
         auto get = [&](void* dst, const void* src, size_t n) { if (!dst || !n) return; if (on_device) d2d(dst, src, n, ctx->stream); else d2h(dst, src, n, ctx->stream); };
-        get(seed, ss->p_seed.p, P * 4); get(pos, ss->p_pos.p, P * 4); get(cc, ss->p_cc.p, P * 4); get(markers, ss->markers.p, M * 8);
+        get(seed, ss->p_seed.p, P * 4); get(markers, ss->markers.p, M * 8);
+        if ((pos || cc) && P) {
+            if (on_device) unpack_positions(ctx, ss, 0, P, pos, cc);
+            else {
+                uint32_t* tp = ctx->arena.get<uint32_t>(P); uint32_t* tc = ctx->arena.get<uint32_t>(P);
+                unpack_positions(ctx, ss, 0, P, tp, tc);
+                get(pos, tp, P * 4); get(cc, tc, P * 4);
+            }
+        }
         if (pos_off) memcpy(pos_off, ss->pos_off.data(), (ng + 1) * 8);
         if (marker_off) memcpy(marker_off, ss->mk_off.data(), (ng + 1) * 8);
         if (contig_off) memcpy(contig_off, ss->ctg_off.data(), (ng + 1) * 8);
@@ -283,6 +294,8 @@ int skh_sketch_export_flat(const skh_sketch_set* ss, int on_device, uint32_t* se
         if (genome_rank && ng) memcpy(genome_rank, ss->rank.data(), ng * 4);
         dsync(ctx->stream);
     });
+    ctx->arena.reset();
+    return rc;
 }
 
 int skh_screen(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,

@@ -22,12 +22,13 @@ namespace skh {
 
 // ------------------------------------------------------------------------------------------------ views & descriptors
 struct SetView {
-    const uint32_t *p_seed, *p_pos, *p_cc; const uint16_t* p_cnt;
-    const uint32_t *s_pos, *s_cc;
+    const uint32_t *p_seed, *p_g; const uint16_t* p_cnt;       // position order; p_g = padded coordinate << 1 | canonical
+    const uint32_t* s_g;                                       // hash order
     const uint64_t* ent; const uint32_t* dir;
+    const uint32_t* goff;                                      // padded contig starts (common.h CTG_PAD)
 };
 static SetView view_of(const skh_sketch_set* s) {
-    return SetView{s->p_seed.p, s->p_pos.p, s->p_cc.p, s->p_cnt.p, s->s_pos.p, s->s_cc.p, s->ent.p, s->dir.p};
+    return SetView{s->p_seed.p, s->p_g.p, s->p_cnt.p, s->s_g.p, s->ent.p, s->dir.p, s->d_goff.p};
 }
 
 struct PairDesc {
@@ -43,12 +44,17 @@ struct PairDesc {
     uint64_t ref_total_len, query_total_len;
     float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
     uint32_t nctg_q, nctg_r;
+    uint64_t a_goff0, b_goff0;   // first entry of A's / B's padded contig-start table in its set
+    uint32_t a_nctg, b_nctg;
 };
 
 constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-struct Chunk { uint32_t a_begin, a_end, s_begin, s_end; };            // batch-relative anchor / seed-list ranges
+// An anchor is 8 bytes in two arrays: anc_q = padded query coordinate, anc_r = padded ref coordinate << 1 | reverse_match
+// (chunking only needs the first).  Contigs are recovered from the padded contig-start tables where a stage needs them
+// (chunk boundaries, interval records).
+struct Chunk { uint32_t a_begin, a_end, s_begin, s_end, qoff, qctg; };   // batch-relative anchor / seed-list ranges; the chunk's query contig and its padded start
 struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };   // types.rs:508-519 field order = sort order
 
 // ------------------------------------------------------------------------------------------------ join
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
 // probe results recorded by join_count_kernel (no second probe).
 __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                         uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
-                                                        const uint16_t* pinfo_cnt, uint4* anc, uint32_t* ql_pos, uint32_t* ql_ctg) {
+                                                        const uint16_t* pinfo_cnt, uint32_t* anc_q, uint32_t* anc_r, uint32_t* ql_g) {
     __shared__ uint32_t lds[16];
     const uint32_t tile = slot_tile[blockIdx.x];
     if (tile == NONE) return;
@@ -144,17 +150,14 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
         for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds[k], y = lds[8 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
         __syncthreads();
         if (inq) {
-            const uint64_t ai = pd.a_pos0 + i;
-            const uint32_t qpos = A.p_pos[ai], qcc = A.p_cc[ai];
-            const uint32_t oq = run_q + bq + iq - 1;
-            ql_pos[oq] = qpos; ql_ctg[oq] = qcc >> 1;
+            const uint32_t qg = A.p_g[pd.a_pos0 + i];
+            ql_g[run_q + bq + iq - 1] = qg >> 1;
             if (n_anch) {
                 const uint64_t bs = pd.b_pos0 + pinfo_start[(uint64_t)tile * JOIN_TILE + o];
                 uint32_t oa = run_a + ba + ia - n_anch;
                 for (uint32_t k = 0; k < n_anch; k++, oa++) {                        // chain.rs:703-711, already in sorted order
-                    const uint32_t rcc = B.s_cc[bs + k];
-                    // anchor record: x = query pos, y = ref pos, z = ref_contig << 1 | reverse_match, w = query contig
-                    anc[oa] = make_uint4(qpos, B.s_pos[bs + k], (rcc & ~1u) | ((rcc ^ qcc) & 1u), qcc >> 1);
+                    const uint32_t rg = B.s_g[bs + k];
+                    anc_q[oa] = qg >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg) & 1u);
                 }
             }
         }
@@ -167,53 +170,52 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
 // anchors and over the query-position list) only ever move forward over contiguous memory, so each keeps the current and the
 // next 64-element block in registers (the next block's load is in flight while the current one is examined), and the values
 // the recurrence needs (the breaking anchor, the last anchor) come from the resident block through v_readlane.  The kernel
-// streams every anchor once (16 B each): ~6.4 GB per 9,500 pairs, i.e. it runs at HBM speed (~3.8 TB/s).
-struct AnchorStream {
-    const uint4* p; uint32_t hi, b; uint32_t cq, cw, nq, nw;      // current / next block: query pos (x) and query contig (w)
-    __device__ __forceinline__ void load_next() { const uint32_t i = b + 64 + lane_id(); nq = 0; nw = 0; if (i < hi) { const uint4 a = p[i]; nq = a.x; nw = a.w; } }
-    __device__ __forceinline__ void init(const uint4* p_, uint32_t lo, uint32_t hi_) {
-        p = p_; hi = hi_; b = lo; const uint32_t i = b + lane_id(); cq = 0; cw = 0; if (i < hi) { const uint4 a = p[i]; cq = a.x; cw = a.w; } load_next();
+// streams every anchor's query coordinate once (4 B each).
+// A forward-only window over a sorted u32 array: each lane holds 4 consecutive elements of the current 256-element block
+// (one 16-byte load) and of the next one (in flight while the current block is examined).
+struct Stream4 {
+    const uint32_t* p; uint32_t hi, b;          // b: first element of the current block, a multiple of 4
+    uint4 c, n;
+    __device__ __forceinline__ uint4 load(uint32_t blk) const {
+        const uint32_t i = blk + 4u * lane_id();
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i + 3 < hi) v = *(const uint4*)(p + i);
+        else { if (i < hi) v.x = p[i]; if (i + 1 < hi) v.y = p[i + 1]; if (i + 2 < hi) v.z = p[i + 2]; }
+        return v;
     }
-    __device__ __forceinline__ void advance() { b += 64; cq = nq; cw = nw; load_next(); }
-    // first index >= from whose anchor leaves contig `last` or lies beyond `end`; hi if none (chain.rs:747)
-    __device__ __forceinline__ uint32_t first_break(uint32_t from, uint32_t last, uint32_t end) {
+    __device__ __forceinline__ void init(const uint32_t* p_, uint32_t from, uint32_t hi_) { p = p_; hi = hi_; b = from & ~3u; c = load(b); n = load(b + 256); }
+    __device__ __forceinline__ void advance() { b += 256; c = n; n = load(b + 256); }
+    // first index >= from whose element exceeds lim; hi if none.  Elements are ascending from `from` on.
+    __device__ __forceinline__ uint32_t first_above(uint32_t from, uint32_t lim) {
         for (;;) {
-            const uint32_t i = b + lane_id();
-            const unsigned long long m = __ballot(i >= from && i < hi && (cw != last || cq > end));
-            if (m) return b + (uint32_t)__ffsll((long long)m) - 1u;
-            if (b + 64 >= hi) return hi;
+            const uint32_t i = b + 4u * lane_id();
+            const unsigned long long m0 = __ballot(i >= from && i < hi && c.x > lim), m1 = __ballot(i + 1 >= from && i + 1 < hi && c.y > lim);
+            const unsigned long long m2 = __ballot(i + 2 >= from && i + 2 < hi && c.z > lim), m3 = __ballot(i + 3 >= from && i + 3 < hi && c.w > lim);
+            if (m0 | m1 | m2 | m3) {
+                uint32_t best = 0xFFFFFFFFu;
+                if (m0) best = 4u * ((uint32_t)__ffsll((long long)m0) - 1u);
+                if (m1) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m1) - 1u) + 1u; best = x < best ? x : best; }
+                if (m2) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m2) - 1u) + 2u; best = x < best ? x : best; }
+                if (m3) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m3) - 1u) + 3u; best = x < best ? x : best; }
+                return b + best;
+            }
+            if (b + 256 >= hi) return hi;
             advance();
         }
     }
-    __device__ __forceinline__ uint32_t q_at(uint32_t i) { return wave_readlane(cq, (int)(i - b)); }   // i inside the current block
-    __device__ __forceinline__ uint32_t w_at(uint32_t i) { return wave_readlane(cw, (int)(i - b)); }
-};
-struct SeedStream {
-    const uint32_t *pos, *ctg; uint32_t hi, b; uint32_t cp, cc, np, nc;
-    __device__ __forceinline__ void load_next() { const uint32_t i = b + 64 + lane_id(); np = 0; nc = 0; if (i < hi) { np = pos[i]; nc = ctg[i]; } }
-    __device__ __forceinline__ void init(const uint32_t* pos_, const uint32_t* ctg_, uint32_t from, uint32_t hi_) {
-        pos = pos_; ctg = ctg_; hi = hi_; b = from; const uint32_t i = b + lane_id(); cp = 0; cc = 0; if (i < hi) { cp = pos[i]; cc = ctg[i]; } load_next();
-    }
-    __device__ __forceinline__ void advance() { b += 64; cp = np; cc = nc; load_next(); }
-    // first index >= from that leaves contig `c` or lies beyond `limit`; hi if none (chain.rs:755-780, 797-817)
-    __device__ __forceinline__ uint32_t first_beyond(uint32_t from, uint32_t c, uint32_t limit) {
-        if (from < b || from >= b + 128) init(pos, ctg, from, hi);
-        for (;;) {
-            const uint32_t i = b + lane_id();
-            const unsigned long long m = __ballot(i >= from && i < hi && (cc != c || cp > limit));
-            if (m) return b + (uint32_t)__ffsll((long long)m) - 1u;
-            if (b + 64 >= hi) return hi;
-            advance();
-        }
+    __device__ __forceinline__ uint32_t at(uint32_t i) {                              // i inside the current block (wave-uniform)
+        const uint32_t o = i - b; const int ln = (int)(o >> 2);
+        const uint32_t k = o & 3u;
+        return k == 0 ? wave_readlane(c.x, ln) : k == 1 ? wave_readlane(c.y, ln) : k == 2 ? wave_readlane(c.z, ln) : wave_readlane(c.w, ln);
     }
 };
-__device__ __forceinline__ uint32_t lower_bound_ctg(const uint32_t* ql_ctg, uint32_t lo, uint32_t hi, uint32_t ctg) {   // uniform
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ql_ctg[mid] < ctg) lo = mid + 1; else hi = mid; }
+__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* ql_g, uint32_t lo, uint32_t hi, uint32_t v) {   // uniform
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ql_g[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
-__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint32_t* pa0, const uint32_t* pq0, const uint32_t* pc0,
-                                                    const uint4* anc, const uint32_t* ql_pos, const uint32_t* ql_ctg,
+__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* goff0, const uint32_t* goff1, const uint32_t* pa0,
+                                                    const uint32_t* pq0, const uint32_t* pc0, const uint32_t* anc_q, const uint32_t* ql_g,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
@@ -221,33 +223,41 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const uint
     const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
-        AnchorStream as; as.init(anc, A0, A1);
-        uint32_t last = as.w_at(A0), end = as.q_at(A0) + CHUNK_SIZE;                // chain.rs:742-744
-        uint32_t rc = lower_bound_ctg(ql_ctg, Q0, Q1, last);                        // running_counter = 0 within contig `last`
-        SeedStream ss; ss.init(ql_pos, ql_ctg, rc, Q1);
+        const uint32_t* go = ((pairs[p].flags & 1u) ? goff1 : goff0) + pairs[p].a_goff0;
+        const uint32_t nctg = pairs[p].a_nctg;
+        Stream4 as; as.init(anc_q, A0, A1);
+        const uint32_t q_first = as.at(A0);
+        uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];   // "last_contig" and its padded range
+        uint32_t end = q_first + CHUNK_SIZE;                                        // chain.rs:742-744
+        uint32_t rc = lower_bound_g(ql_g, Q0, Q1, cstart);                          // running_counter = 0 within this contig
+        Stream4 ss; ss.init(ql_g, rc, Q1);
         uint32_t cur = A0, scan = A0 + 1;
         for (;;) {
-            const uint32_t t = as.first_break(scan, last, end);
-            Chunk ck; ck.a_begin = cur; ck.s_begin = rc;
+            const uint32_t lim = end < cnext - 1 ? end : cnext - 1;                 // beyond it: another contig, or past the window
+            const uint32_t t = as.first_above(scan, lim);                           // chain.rs:747
+            Chunk ck; ck.a_begin = cur; ck.s_begin = rc; ck.qoff = cstart; ck.qctg = ctg;
+            if (rc < ss.b || rc >= ss.b + 512) ss.init(ql_g, rc, Q1);              // the seed window was left behind by a contig change
             if (t == A1) {                                                         // final chunk: seeds <= last anchor's pos (chain.rs:794-824)
-                ck.a_end = A1; ck.s_end = ss.first_beyond(rc, last, as.q_at(A1 - 1));   // the scan ended inside the block holding A1-1
+                if (A1 - 1 < as.b) as.init(anc_q, A1 - 1, A1);                      // (cannot happen: the scan ends in the block holding A1-1)
+                ck.a_end = A1; ck.s_end = ss.first_above(rc, as.at(A1 - 1));
             } else {                                                               // chain.rs:747-790
-                ck.a_end = t; ck.s_end = ss.first_beyond(rc, last, end);
+                ck.a_end = t; ck.s_end = ss.first_above(rc, lim);
             }
             if (C0 + nc < C1) { if (l == 0) { chunks[C0 + nc] = ck; chunk_pair[C0 + nc] = p; } }
             else if (l == 0) atomicAdd(err, 1u);
             nc++;
             if (t == A1) break;
             rc = ck.s_end; end += CHUNK_SIZE;                                      // one step only (chain.rs:782)
-            const uint32_t tw = as.w_at(t), tq = as.q_at(t);                        // anchor t sits in the resident block
-            if (tw != last) {                                                      // chain.rs:786-789
-                end = tq + CHUNK_SIZE; last = tw;
-                rc = lower_bound_ctg(ql_ctg, Q0, Q1, tw);                        // first_beyond refills its window when rc left it
+            const uint32_t tq = as.at(t);                                          // anchor t sits in the resident block
+            if (tq >= cnext) {                                                     // contig change (chain.rs:786-789)
+                ctg = ctg_of(go, nctg, tq); cstart = go[ctg]; cnext = go[ctg + 1];
+                end = tq + CHUNK_SIZE;
+                rc = lower_bound_g(ql_g, Q0, Q1, cstart);
             }
             cur = t; scan = t + 1;
         }
     }
-    for (uint32_t s = C0 + nc + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0}; chunk_pair[s] = p; }
+    for (uint32_t s = C0 + nc + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0, 0, 0}; chunk_pair[s] = p; }
     if (l == 0) n_chunks[p] = nc;
 }
 
@@ -266,7 +276,7 @@ constexpr uint32_t MAX_CHUNK_ANCHORS = 1u << 20;
 struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
 
 template <int PB>
-__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint4* anc, unsigned long long* best) {
+__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* anc_q, const uint32_t* anc_r, unsigned long long* best) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
@@ -279,9 +289,9 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
         const uint32_t t = base + (uint32_t)l;
         const bool valid = t < ck.a_end;
         Blk cur;
-        uint4 av = make_uint4(0, 0, 0xFFFFFFFFu, 0);
-        if (valid) av = anc[t];
-        cur.q = av.x; cur.r = av.y; cur.cr = av.z;
+        uint2 av = make_uint2(0, 0);
+        if (valid) av = make_uint2(anc_q[t], anc_r[t]);
+        cur.q = av.x; cur.r = av.y >> 1; cur.cr = av.y & 1u;                         // cr: strand only -- different contigs are > MAX_LIN apart
         cur.score = 0; cur.root = t; cur.depth = 1;
         uint32_t ptr = t;
         const uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
@@ -343,49 +353,78 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
 //   * the last NB anchors (q, r, ref contig/strand, score, depth | component slot) in REGISTERS as a shift register, so the
 //     predecessor scan is a fully unrolled, branch-free block of integer selects;
 //   * a table of the LIVE pointer-forest components (those with an anchor still inside the ring -- only they can be extended,
-//     chain.rs:859-863) in LDS, laid out [slot][lane]: the component's argmax record (score | best index | chain length) and
-//     root << 8 | reference count.
+//     chain.rs:859-863), laid out [slot][lane]: the component's argmax record (score | best index | chain length) and
+//     root << 8 | reference count.  Up to band+1 components can be live, but more than a handful almost never are: the first
+//     DP_LDS_SLOTS (8) slots (the allocator hands out the lowest free slot) sit in LDS, the rest in a global spill table that is
+//     practically never touched.  LDS per wave drops from 12(band+1) x 64 B to 6 KB (8 slots), which triples the waves per SIMD.
 // All 64 lanes evaluate links (the sweep kernel keeps band/64 of them busy).  When the last anchor of a component leaves the
 // ring the component is final and, if it reaches 3 anchors / score 45 (chain.rs:954-977), its interval is emitted straight
 // away: the kernel writes nothing per anchor.
-__device__ __forceinline__ void dp_emit(const uint4* anc, const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b,
-                                        const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
+// the interval record of a finished chain (root anchor .. best anchor), back in contig-local coordinates (types.rs:508-519)
+struct EmitCtx { const uint32_t *anc_q, *anc_r; const PairDesc* pairs; const uint32_t *goff0, *goff1, *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
+__device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec) {
     const uint32_t sc = (uint32_t)(b >> 40), bi = (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
     if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) return;                        // chain.rs:954-957, 974-977
-    const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
-    if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); return; }
-    const uint4 ar = anc[ck.a_begin + root], ab = anc[ck.a_begin + bi];
+    const uint32_t k = atomicAdd(&ec.ivl_cnt[p], 1u);
+    if (ec.pi0[p] + k >= ec.pi0[p + 1]) { atomicAdd(ec.err, 1u); return; }
+    const uint2 ar = make_uint2(ec.anc_q[ck.a_begin + root], ec.anc_r[ck.a_begin + root]), ab = make_uint2(ec.anc_q[ck.a_begin + bi], ec.anc_r[ck.a_begin + bi]);
+    const PairDesc& pd = ec.pairs[p];
+    const uint32_t* bo = ((pd.flags & 2u) ? ec.goff1 : ec.goff0) + pd.b_goff0;
+    const uint32_t ra = ar.y >> 1, rb = ab.y >> 1;
+    const uint32_t rctg = ctg_of(bo, pd.b_nctg, ra), roff = bo[rctg];
     Interval iv;
-    iv.score = sc; iv.na = na; iv.q0 = ar.x; iv.q1 = ab.x;
-    iv.r0 = ar.y < ab.y ? ar.y : ab.y; iv.r1 = ar.y < ab.y ? ab.y : ar.y;
-    iv.rctg = ar.z >> 1; iv.qctg = ar.w; iv.chunk = slot - pc0[p]; iv.rev = ar.z & 1u;
-    ivls[pi0[p] + k] = iv;
+    iv.score = sc; iv.na = na; iv.q0 = ar.x - ck.qoff; iv.q1 = ab.x - ck.qoff;
+    iv.r0 = (ra < rb ? ra : rb) - roff; iv.r1 = (ra < rb ? rb : ra) - roff;
+    iv.rctg = rctg; iv.qctg = ck.qctg; iv.chunk = slot - ec.pc0[p]; iv.rev = ar.y & 1u;
+    ec.ivls[ec.pi0[p] + k] = iv;
 }
 
-template <int NB, int T>
-__global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, uint32_t band, const uint4* anc,
-                                                            const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
-    SKH_DYN_SMEM(smem);
+// The 64 lanes of a wave step through their chunks in lockstep, so a wave takes as long as its longest chunk: chunks are
+// handed out in order of decreasing anchor count (dp_order_keys_kernel + a 10-bit radix sort), which puts chunks of nearly equal
+// length side by side (in slot order a wave's lanes are busy only ~1/3 of the time: mean 131 anchors, longest of 64 ~350).
+__global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, const Chunk* chunks, uint64_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const uint32_t len = chunks[i].a_end - chunks[i].a_begin;
+    keys[i] = 1023u - (len >= 1023u ? 1023u : len); vals[i] = i;
+}
+
+template <int NB, int T, uint32_t DP_LDS_SLOTS>
+__global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* order, uint32_t band,
+                                                            EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr) {
+    __shared__ unsigned long long lds_best[DP_LDS_SLOTS * T];                       // [slot][lane]
+    __shared__ uint32_t lds_rr[DP_LDS_SLOTS * T];                                   // [slot][lane]: root << 8 | refcount
     const uint32_t C = band + 1, tid = threadIdx.x;
-    unsigned long long* ct_best = (unsigned long long*)smem;                        // [C][T]
-    uint32_t* ct_rr = (uint32_t*)(smem + (size_t)C * T * 8);                        // [C][T]: root << 8 | refcount
-    const uint32_t slot = blockIdx.x * T + tid;
-    Chunk ck{0, 0, 0, 0};
+    const uint32_t thr = blockIdx.x * T + tid;
+    const uint32_t slot = thr < n_slots ? order[thr] : n_slots;
+    const size_t n_thr = (size_t)gridDim.x * T;                                     // spill tables: [slot - DP_LDS_SLOTS][thread]
+    auto get_best = [&](uint32_t c) { return c < DP_LDS_SLOTS ? lds_best[c * T + tid] : spill_best[(size_t)(c - DP_LDS_SLOTS) * n_thr + thr]; };
+    auto set_best = [&](uint32_t c, unsigned long long v) { if (c < DP_LDS_SLOTS) lds_best[c * T + tid] = v; else spill_best[(size_t)(c - DP_LDS_SLOTS) * n_thr + thr] = v; };
+    auto get_rr = [&](uint32_t c) { return c < DP_LDS_SLOTS ? lds_rr[c * T + tid] : spill_rr[(size_t)(c - DP_LDS_SLOTS) * n_thr + thr]; };
+    auto set_rr = [&](uint32_t c, uint32_t v) { if (c < DP_LDS_SLOTS) lds_rr[c * T + tid] = v; else spill_rr[(size_t)(c - DP_LDS_SLOTS) * n_thr + thr] = v; };
+    Chunk ck{0, 0, 0, 0, 0, 0};
     if (slot < n_slots) ck = chunks[slot];
     const uint32_t n = ck.a_end - ck.a_begin;
-    if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(err, 1u); return; }
+    if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(ec.err, 1u); return; }
     const uint32_t p = n ? chunk_pair[slot] : 0;
     unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
     uint32_t rq[NB], rr[NB], rc[NB], rs[NB], rd[NB];                                // q, r, contig/strand, score, depth << 8 | component
 #pragma unroll
     for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rc[k] = 0xFFFFFFFFu; rs[k] = 0; rd[k] = 0; }
-    uint4 nxt = make_uint4(0, 0, 0, 0);
-    if (n) nxt = anc[ck.a_begin];
+    const uint32_t* aq = ec.anc_q + ck.a_begin; const uint32_t* arr = ec.anc_r + ck.a_begin;
+    // anchors are fetched PFD iterations ahead: with ~2 waves per SIMD an iteration's arithmetic covers only a fraction of
+    // a memory round trip, so one load in flight per lane leaves the wave waiting
+    constexpr uint32_t PFD = 4;
+    uint2 pf[PFD];
+#pragma unroll
+    for (uint32_t u = 0; u < PFD; u++) pf[u] = u < n ? make_uint2(aq[u], arr[u]) : make_uint2(0, 0);
     for (uint32_t i = 0; i < n; i++) {
-        const uint4 a = nxt;
-        if (i + 1 < n) nxt = anc[ck.a_begin + i + 1];                               // prefetch: independent of this iteration's work
-        const uint32_t q = a.x, r = a.y, cr = a.z;
-        const bool rev = (cr & 1u) != 0;
+        const uint2 a = pf[0];
+#pragma unroll
+        for (uint32_t u = 0; u + 1 < PFD; u++) pf[u] = pf[u + 1];
+        if (i + PFD < n) pf[PFD - 1] = make_uint2(aq[i + PFD], arr[i + PFD]);
+        const uint32_t q = a.x, r = a.y >> 1, cr = a.y & 1u;                         // cr: strand only -- different contigs are > MAX_LIN apart
+        const bool rev = cr != 0;
         const uint32_t nd = i < band ? i : band;
         int32_t bscore = 0; uint32_t bdc = NONE;
         // predecessors j = i-1-k for k = 0..nd-1 (downward scan; strict '>' keeps the largest j among equal maxima, chain.rs:852-880)
@@ -402,12 +441,12 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         uint32_t comp, depth;
         if (bdc != NONE) {
             comp = bdc & 0xFFu; depth = (bdc >> 8) + 1;
-            ct_rr[comp * T + tid] += 1;
+            set_rr(comp, get_rr(comp) + 1);
             const unsigned long long pay = best_payload((uint32_t)bscore, i, depth);
-            if (pay > ct_best[comp * T + tid]) ct_best[comp * T + tid] = pay;       // argmax, ties -> largest index (chain.rs:952-964)
+            if (pay > get_best(comp)) set_best(comp, pay);                          // argmax, ties -> largest index (chain.rs:952-964)
         } else {                                                                    // new root: at most `band` components are live, one slot is free
             comp = (uint32_t)__ffsll((long long)free_mask) - 1u; free_mask &= free_mask - 1ull; depth = 1;
-            ct_rr[comp * T + tid] = (i << 8) | 1u; ct_best[comp * T + tid] = best_payload(0, i, 1);
+            set_rr(comp, (i << 8) | 1u); set_best(comp, best_payload(0, i, 1));
         }
         // anchor i-band (a legal predecessor of anchor i, hence handled after the scan) leaves the ring and releases its
         // component; a component without ring members can never be extended again => it is final
@@ -416,9 +455,9 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         for (int k = 0; k < NB; k++) leaving = ((uint32_t)k == band - 1) ? rd[k] : leaving;
         if (i >= band) {
             const uint32_t c_old = leaving & 0xFFu;
-            const uint32_t v = ct_rr[c_old * T + tid] - 1u;
-            ct_rr[c_old * T + tid] = v;
-            if ((v & 0xFFu) == 0) { dp_emit(anc, ck, slot, p, v >> 8, ct_best[c_old * T + tid], pc0, pi0, ivl_cnt, ivls, err); free_mask |= 1ull << c_old; }
+            const uint32_t v = get_rr(c_old) - 1u;
+            set_rr(c_old, v);
+            if ((v & 0xFFu) == 0) { dp_emit(ck, slot, p, v >> 8, get_best(c_old), ec); free_mask |= 1ull << c_old; }
         }
 #pragma unroll
         for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rc[k] = rc[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
@@ -430,36 +469,25 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     for (int k = 0; k < NB; k++) {
         if ((uint32_t)k < live) {
             const uint32_t c_old = rd[k] & 0xFFu;
-            const uint32_t v = ct_rr[c_old * T + tid] - 1u;
-            ct_rr[c_old * T + tid] = v;
-            if ((v & 0xFFu) == 0) dp_emit(anc, ck, slot, p, v >> 8, ct_best[c_old * T + tid], pc0, pi0, ivl_cnt, ivls, err);
+            const uint32_t v = get_rr(c_old) - 1u;
+            set_rr(c_old, v);
+            if ((v & 0xFFu) == 0) dp_emit(ck, slot, p, v >> 8, get_best(c_old), ec);
         }
     }
 }
 
 // chain.rs:939-1007: one candidate interval per pointer-forest component that reaches 3 anchors / score 45
 // One wave per chunk: roots are the anchors whose argmax record is non-zero.
-__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const uint4* anc, const unsigned long long* best, const uint32_t* chunk_pair,
-                                                            const uint32_t* pc0, const uint32_t* pi0, uint32_t* ivl_cnt, Interval* ivls, uint32_t* err) {
+__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const unsigned long long* best, const uint32_t* chunk_pair, EmitCtx ec) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
     if (ck.a_end <= ck.a_begin) return;
     const uint32_t p = chunk_pair[slot];
-    if (ck.a_end - ck.a_begin >= MAX_CHUNK_ANCHORS) { if (lane_id() == 0) atomicAdd(err, 1u); return; }
+    if (ck.a_end - ck.a_begin >= MAX_CHUNK_ANCHORS) { if (lane_id() == 0) atomicAdd(ec.err, 1u); return; }
     for (uint32_t i = ck.a_begin + lane_id(); i < ck.a_end; i += 64) {
         const unsigned long long b = best[i];
-        if (b == 0) continue;                                                       // not a root
-        const uint32_t sc = (uint32_t)(b >> 40), bi = ck.a_begin + (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
-        if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) continue;                  // chain.rs:954-957, 974-977
-        const uint32_t k = atomicAdd(&ivl_cnt[p], 1u);
-        if (pi0[p] + k >= pi0[p + 1]) { atomicAdd(err, 1u); continue; }
-        const uint4 ar = anc[i], ab = anc[bi];
-        Interval iv;
-        iv.score = sc; iv.na = na; iv.q0 = ar.x; iv.q1 = ab.x;
-        iv.r0 = ar.y < ab.y ? ar.y : ab.y; iv.r1 = ar.y < ab.y ? ab.y : ar.y;
-        iv.rctg = ar.z >> 1; iv.qctg = ar.w; iv.chunk = slot - pc0[p]; iv.rev = ar.z & 1u;
-        ivls[pi0[p] + k] = iv;
+        if (b != 0) dp_emit(ck, slot, p, i - ck.a_begin, b, ec);                    // b == 0: not a root
     }
 }
 
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
 constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more -> slow path re-walks the list per position)
 
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
-                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_pos,
+                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_g,
                                                           uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint32_t* pair_tqb, uint32_t* pair_acl,
                                                           uint32_t* pair_nchains) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,7 +679,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
     const bool valid = slot < n_slots;
     const uint32_t head = valid ? chunk_head[slot] : NONE;
     if (valid) chunk_w[slot] = NONE;                                                // NONE = no estimate from this chunk
-    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0, s_begin = 0, s_end = 0;
+    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0, s_begin = 0, s_end = 0, qoff = 0;
     uint32_t lo[STATS_REG], hi[STATS_REG];
 #pragma unroll
     for (int i = 0; i < STATS_REG; i++) { lo[i] = 1; hi[i] = 0; }                   // empty
@@ -660,7 +688,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         const Chunk ck = chunks[slot];
         const uint32_t p = chunk_pair[slot];
         const bool switched = (pairs[p].flags & 4u) != 0;
-        s_begin = ck.s_begin; s_end = ck.s_end;
+        s_begin = ck.s_begin; s_end = ck.s_end; qoff = ck.qoff;
         for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
             const Interval iv = ivls[e];
             total_anchors += iv.na;
@@ -690,7 +718,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         j = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
         sb = wave_readlane(s_begin, j); se = wave_readlane(s_end, j);
 #pragma unroll
-        for (int u = 0; u < PF; u++) { const uint32_t s2 = sb + 64u * (uint32_t)u + l; cur[u] = s2 < se ? ql_pos[s2] : 0u; }
+        for (int u = 0; u < PF; u++) { const uint32_t s2 = sb + 64u * (uint32_t)u + l; cur[u] = s2 < se ? ql_g[s2] : 0u; }
     }
     while (j >= 0) {                                                                // wave-uniform
         int jn = -1; uint32_t sbn = 0, sen = 0;
@@ -698,15 +726,17 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
             jn = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
             sbn = wave_readlane(s_begin, jn); sen = wave_readlane(s_end, jn);
 #pragma unroll
-            for (int u = 0; u < PF; u++) { const uint32_t s2 = sbn + 64u * (uint32_t)u + l; nxt[u] = s2 < sen ? ql_pos[s2] : 0u; }
+            for (int u = 0; u < PF; u++) { const uint32_t s2 = sbn + 64u * (uint32_t)u + l; nxt[u] = s2 < sen ? ql_g[s2] : 0u; }
         }
         const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
+        const uint32_t qoffj = wave_readlane(qoff, j);                              // the list holds padded coordinates; intervals are contig-local
         uint32_t lj[STATS_REG], hj[STATS_REG];
 #pragma unroll
         for (int i = 0; i < STATS_REG; i++) { lj[i] = wave_readlane(lo[i], j); hj[i] = wave_readlane(hi[i], j); }
         uint32_t cu = 0, cr = 0;
-        auto count = [&](uint32_t s2, uint32_t pos) {
+        auto count = [&](uint32_t s2, uint32_t gpos) {
             const bool on = s2 < se;
+            const uint32_t pos = gpos - qoffj;
             bool hit = false;
             if (nj <= (uint32_t)STATS_REG) {
 #pragma unroll
@@ -719,7 +749,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         };
 #pragma unroll
         for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(sb + 64u * (uint32_t)u + l, cur[u]);
-        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) { const uint32_t s2 = b2 + l; count(s2, s2 < se ? ql_pos[s2] : 0u); }
+        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) { const uint32_t s2 = b2 + l; count(s2, s2 < se ? ql_g[s2] : qoffj); }
         if ((int)l == j) { in_u = cu; in_range = cr; }
         j = jn; sb = sbn; se = sen;
 #pragma unroll
@@ -977,10 +1007,15 @@ bool is_switched(const skh_sketch_set* R, uint32_t r, const skh_sketch_set* Q, u
     return sq > sr;
 }
 
-uint64_t fnv_anchors(const std::vector<uint32_t>& anc, size_t a0, size_t a1) {   // same checksum as the oracle's ora_chain_stats.anchor_checksum
+// same checksum as the oracle's ora_chain_stats.anchor_checksum: (query contig, query pos, ref contig, ref pos, reverse) per anchor
+uint64_t fnv_anchors(const std::vector<uint32_t>& anc, const std::vector<uint32_t>& anc_r, size_t a0, size_t a1, const uint32_t* a_go, uint32_t a_n, const uint32_t* b_go, uint32_t b_n) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t x) { h ^= x; h *= 1099511628211ull; };
-    for (size_t i = a0; i < a1; i++) { mix(anc[4 * i + 3]); mix(anc[4 * i]); mix(anc[4 * i + 2] >> 1); mix(anc[4 * i + 1]); mix(anc[4 * i + 2] & 1u); }
+    for (size_t i = a0; i < a1; i++) {
+        const uint32_t gq = anc[i], gr = anc_r[i] >> 1, rev = anc_r[i] & 1u;
+        const uint32_t qc = ctg_of(a_go, a_n, gq), rc = ctg_of(b_go, b_n, gr);
+        mix(qc); mix(gq - a_go[qc]); mix(rc); mix(gr - b_go[rc]); mix(rev);
+    }
     return h;
 }
 
@@ -1019,6 +1054,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     // ---- pair descriptors and join tiles
     std::vector<PairDesc> pds(NP); std::vector<uint32_t> tile_pair;
     std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
+    std::vector<const uint32_t*> host_go_a(stats ? NP : 0), host_go_b(stats ? NP : 0);
     for (uint32_t p = 0; p < NP; p++) {
         const uint32_t r = pair_ref[p], q = pair_query[p];
         if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
@@ -1034,6 +1070,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
         pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
         pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
+        pd.a_goff0 = A->ctg_off[ga] + ga; pd.b_goff0 = B->ctg_off[gb] + gb;
+        pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
+        if (stats) { host_go_a[p] = A->goff.data() + pd.a_goff0; host_go_b[p] = B->goff.data() + pd.b_goff0; }
         for (uint32_t t = 0; t * JOIN_TILE < pd.a_n; t++) tile_pair.push_back(p);
         pair_key[p] = gb;                                                           // tiles probing the same sketch share an XCD
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
@@ -1049,7 +1088,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
     dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
-    const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~44 B of scratch each)
+    const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~30 B of scratch each)
     const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (6 KiB of probe records each)
     auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
     std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
@@ -1095,45 +1134,53 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
         uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
         exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); exclusive_scan_u32(ctx, tile_inq + t0, nt, toff_q);
-        uint4* anc = ctx->arena.get<uint4>((size_t)NA + 16);
-        uint32_t* ql_pos = ctx->arena.get<uint32_t>(NQ + 64); uint32_t* ql_ctg = ctx->arena.get<uint32_t>(NQ + 64);
+        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
+        uint32_t* ql_g = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
             const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key);
             uint32_t* d_slots = upload(ctx, slots);
             SKH_LAUNCH(join_fill_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
-                       anc, ql_pos, ql_ctg);
+                       anc_q, anc_r, ql_g);
             check_launch("join_fill");
         }
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0, (const uint32_t*)d_pc0,
-                   (const uint4*)anc, (const uint32_t*)ql_pos, (const uint32_t*)ql_ctg, chunks, chunk_pair, n_chunks, d_err);
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, v0.goff, v1.goff, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0,
+                   (const uint32_t*)d_pc0, (const uint32_t*)anc_q, (const uint32_t*)ql_g, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
+        const EmitCtx ec{anc_q, anc_r, d_pairs, v0.goff, v1.goff, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
             if (band <= 40) {   // fused thread-per-chunk chaining + interval emission
                 constexpr int T = 64;
-                const size_t lds = (size_t)(band + 1) * T * 12;
                 const unsigned gt = (NC + T - 1) / T;
-#define SKH_DPT(NB) SKH_LAUNCH((chain_dp_thread_kernel<NB, T>), gt, T, lds, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, band, \
-                               (const uint4*)anc, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err)
+                const uint32_t ls = ctx->tune.chain_dp_lds_slots <= 1 ? 1u : 8u;  // 1: tests push every second live chain through the spill table
+                const size_t n_spill = band + 1 > ls ? (size_t)(band + 1 - ls) * gt * T : 1;   // written only by chunks with more live chains than LDS slots
+                unsigned long long* spill_best = ctx->arena.get<unsigned long long>(n_spill); uint32_t* spill_rr = ctx->arena.get<uint32_t>(n_spill);
+                uint64_t* okeys = ctx->arena.get<uint64_t>(NC); uint32_t* order = ctx->arena.get<uint32_t>(NC);
+                SKH_LAUNCH(dp_order_keys_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, okeys, order);
+                check_launch("dp_order_keys");
+                sort_pairs_u64_u32(ctx, okeys, order, NC, 10);
+#define SKH_DPT2(NB, LS) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr)
+#define SKH_DPT(NB) do { if (ls == 1) SKH_DPT2(NB, 1); else SKH_DPT2(NB, 8); } while (0)
                 if (band <= 12) SKH_DPT(12); else if (band <= 20) SKH_DPT(20); else if (band <= 28) SKH_DPT(28); else SKH_DPT(40);
 #undef SKH_DPT
+#undef SKH_DPT2
                 check_launch("chain_dp_thread");
             } else {            // wave-per-chunk sweep + per-anchor argmax records + emit
                 unsigned long long* best = ctx->arena.get<unsigned long long>((size_t)NA + 64);
                 dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
                 const unsigned gb = (NC + 3) / 4;
-#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint4*)anc, best)
+#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)anc_q, (const uint32_t*)anc_r, best)
                 if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
 #undef SKH_DP
                 check_launch("chain_dp");
-                SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint4*)anc, (const unsigned long long*)best,
-                           (const uint32_t*)chunk_pair, (const uint32_t*)d_pc0, (const uint32_t*)d_pi0, ivl_cnt, ivls, d_err);
+                SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const unsigned long long*)best,
+                           (const uint32_t*)chunk_pair, ec);
                 check_launch("interval_emit");
             }
         }
@@ -1149,7 +1196,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         dzero(pair_tqb, np * 4, ctx->stream); dzero(pair_acl, np * 4, ctx->stream); dzero(pair_nch, np * 4, ctx->stream);
         if (NC) {
             SKH_LAUNCH(chunk_stats_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
-                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_pos, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
+                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_g, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
             check_launch("chunk_stats");
         }
         FinalizeArgs fa{};
@@ -1166,13 +1213,13 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
             std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
             d2h(h_nc.data(), n_chunks, np * 4, ctx->stream); d2h(h_ni.data(), ivl_cnt, np * 4, ctx->stream);
             d2h(h_nacc.data(), n_acc, np * 4, ctx->stream); d2h(h_ne.data(), n_est, np * 4, ctx->stream);
-            std::vector<uint32_t> hanc((size_t)NA * 4);
-            d2h(hanc.data(), anc, (uint64_t)NA * 16, ctx->stream);
+            std::vector<uint32_t> hanc((size_t)NA), hanr((size_t)NA);
+            d2h(hanc.data(), anc_q, (uint64_t)NA * 4, ctx->stream); d2h(hanr.data(), anc_r, (uint64_t)NA * 4, ctx->stream);
             for (uint32_t i = 0; i < np; i++) {
                 skh_chain_stats& st = stats[p0 + i];
                 st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
                 st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
-                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hanc, pa0[i], pa0[i + 1]) : 0;
+                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hanc, hanr, pa0[i], pa0[i + 1], host_go_a[p0 + i], pds[p0 + i].a_nctg, host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
                 if (pair_anch[p0 + i] == 0) st.switched = 1;   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }

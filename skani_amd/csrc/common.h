@@ -44,6 +44,17 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     return h;
 }
 
+// Padded genome coordinates: a seed at (contig c, pos) lives at goff[c] + pos, where consecutive contigs are CTG_PAD apart.
+// CTG_PAD exceeds every distance the chaining DP can bridge (D_MAX_LIN_LENGTH, BP_CHAIN_BAND), so "same contig" is implied
+// by "close enough" and an anchor needs no contig field.  A position is stored as gpos << 1 | canonical-strand bit.
+constexpr uint32_t CTG_PAD = 8192;
+static_assert(CTG_PAD > (uint32_t)MAX_LIN && CTG_PAD > BP_CHAIN_BAND, "contig padding must exceed the chaining reach");
+__host__ __device__ __forceinline__ uint32_t ctg_of(const uint32_t* goff, uint32_t n_ctg, uint32_t gpos) {   // largest c with goff[c] <= gpos
+    uint32_t lo = 0, hi = n_ctg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (goff[mid] <= gpos) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // bucket of a hashed seed in a genome's seed directory: monotone in the hash, any bucket count
 __host__ __device__ __forceinline__ uint32_t seed_bucket(uint32_t hash, uint32_t n_buckets) { return (uint32_t)(((uint64_t)hash * n_buckets) >> 32); }
 
@@ -54,6 +65,8 @@ struct ContigDesc {
     uint32_t genome;    // genome id within the set
     uint32_t index;     // contig index within its genome (types.rs:124 contig_index)
     uint32_t has_n;     // set by the pack kernel when the contig contains a masked byte
+    uint32_t goff;      // padded-coordinate start of the contig within its genome (CTG_PAD)
+    uint32_t pad;
 };
 
 // one seeding workgroup's work: SEED_TILE consecutive windows of one contig

@@ -54,6 +54,7 @@ struct skh_tunables {
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
+    uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };
 
 struct skh_ctx {
@@ -90,22 +91,24 @@ struct skh_sketch_set {
     std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, dir_off;   // n_genomes+1
     std::vector<uint32_t> n_buckets;               // buckets of each genome's seed directory
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
+    std::vector<uint32_t> goff;                    // padded-coordinate start of every contig, n_contigs(g)+1 entries per genome at
+                                                   // index ctg_off[g] + g (the last one = the genome's padded span)
     std::vector<uint64_t> total_len;
     std::vector<double> mean_ctg;
     std::vector<float> q10, q50, q90;
     std::vector<uint32_t> rank;
     std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays
-    skh::DBuf<uint32_t> p_seed, p_pos, p_cc;       // position order (contig, pos)
+    skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical
     skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)
-    skh::DBuf<uint32_t> s_pos, s_cc;               // seed order (seed, contig, pos)
+    skh::DBuf<uint32_t> s_g;                       // the same records in (mix32(seed), contig, pos) order
     // seed index (probe side): one entry per distinct seed, sorted by mix32(seed) within the genome:
     //   mix32(seed) << 32 | start (24 bits, in the genome's seed-order arrays) << 8 | min(multiplicity, 255)
     // and a bucket directory over the hash range: entries of bucket b = mulhi(hash, n_buckets) are ent[dir[b] .. dir[b+1])
     skh::DBuf<uint64_t> ent;
     skh::DBuf<uint32_t> dir;                       // n_buckets + 1 per genome, values relative to the genome's first entry
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
-    skh::DBuf<uint32_t> d_ctg_len;
+    skh::DBuf<uint32_t> d_goff;
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_dir_off;
     skh::DBuf<uint32_t> d_n_buckets;
 };
@@ -122,15 +125,19 @@ void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit);
 // ---- pack_seed.hip
 void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
-    DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> markers_raw;
+    DBuf<uint32_t> seed, g; DBuf<uint64_t> markers_raw;      // g = padded coordinate << 1 | canonical (common.h CTG_PAD)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
 };
 void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out);
 
 // ---- sketch_build.hip
-void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss);                       // needs p_* and pos_off filled
+// needs p_seed, pos_off, contig tables (finalize_metadata) filled, and either p_g (pos == cc == null) or pos / cc = device
+// arrays of (position in contig, contig << 1 | canonical) in position order, which are converted into p_g
+void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
+// inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
+void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);
-void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means
+void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,

@@ -62,11 +62,14 @@ void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const 
     const uint32_t nc = gs->n_contigs;
     std::vector<uint64_t> unit_off(nc + 1, 0), src_off(nc);
     uint64_t total_src = contig_off[nc];
+    uint64_t gat = 0;
     for (uint32_t i = 0; i < nc; i++) {
         uint64_t len = contig_off[i + 1] - contig_off[i];
         if (len > 0xFFFFFFF0ull) throw Error("contig longer than 2^32 bases");
         ContigDesc& cd = gs->contigs[i];
         cd.len = (uint32_t)len; cd.base = unit_off[i] * 32; cd.has_n = 0;
+        if (cd.index == 0) gat = 0;
+        cd.goff = (uint32_t)gat; cd.pad = 0; gat += len + CTG_PAD;                  // genomes beyond 2^31 are refused when a sketch set is made (finalize_metadata)
         src_off[i] = contig_off[i];
         uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
         unit_off[i + 1] = unit_off[i] + padded / 32;
@@ -226,13 +229,12 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                                                            const uint64_t* __restrict__ t_marker, const uint32_t* __restrict__ o_seed2,
                                                            const uint16_t* __restrict__ o_loc2, const uint64_t* __restrict__ o_marker2,
                                                            const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
-                                                           uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_pos,
-                                                           uint32_t* __restrict__ o_cc, uint64_t* __restrict__ o_marker) {
+                                                           uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_g, uint64_t* __restrict__ o_marker) {
     const uint32_t lt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
     const uint32_t ln = threadIdx.x & 63;
     const SeedTile tile = tiles[lt];
-    const uint32_t cidx = contigs[tile.contig].index;
+    const uint32_t goff = contigs[tile.contig].goff;
     const uint32_t s0 = off_s[lt], ns = off_s[lt + 1] - s0, m0 = off_m[lt], nm = off_m[lt + 1] - m0;
     const uint32_t ov = ovf_idx[lt];
     const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     for (uint32_t x = ln; x < ns; x += 64) {
         const uint32_t loc = src_loc[x];
         o_seed[s0 + x] = src_seed[x];
-        o_pos[s0 + x] = (K_MARKER - 1) + tile.first * SEED_TILE + (loc & 0x1FFFu);   // pos = index of the window's last base
-        o_cc[s0 + x] = (cidx << 1) | (loc >> 15);                                     // types.rs:131-138
+        const uint32_t pos = (K_MARKER - 1) + tile.first * SEED_TILE + (loc & 0x1FFFu);  // pos = index of the window's last base
+        o_g[s0 + x] = ((goff + pos) << 1) | (loc >> 15);                              // SeedPosition (types.rs:131-138) in padded coordinates
     }
     for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = src_mk[x];
 }
@@ -262,7 +264,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
     const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
-    struct Part { DBuf<uint32_t> seed, pos, cc; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
+    struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     // first tile of every genome (tiles are ordered by genome)
     std::vector<uint32_t> g_first(ng + 1, (uint32_t)n_tiles);
@@ -325,10 +327,10 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
                        o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
         }
-        p.seed.alloc(p.ns); p.pos.alloc(p.ns); p.cc.alloc(p.ns); p.mk.alloc(p.nm);
+        p.seed.alloc(p.ns); p.g.alloc(p.ns); p.mk.alloc(p.nm);
         SKH_LAUNCH(seed_compact_kernel, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m,
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2,
-                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.pos.p, p.cc.p, p.mk.p);
+                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.g.p, p.mk.p);
         check_launch("seed_compact_kernel");
         base_s += p.ns; base_m += p.nm;
         parts.push_back(std::move(p));
@@ -339,13 +341,13 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
     const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
     if (parts.size() == 1) {
-        out.seed = std::move(parts[0].seed); out.pos = std::move(parts[0].pos); out.cc = std::move(parts[0].cc); out.markers_raw = std::move(parts[0].mk);
+        out.seed = std::move(parts[0].seed); out.g = std::move(parts[0].g); out.markers_raw = std::move(parts[0].mk);
     } else {
-        out.seed.alloc(NS); out.pos.alloc(NS); out.cc.alloc(NS); out.markers_raw.alloc(NM);
+        out.seed.alloc(NS); out.g.alloc(NS); out.markers_raw.alloc(NM);
         uint64_t so = 0, mo = 0;
         for (auto& p : parts) {
-            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.pos.p + so, p.pos.p, p.ns * 4, ctx->stream);
-            d2d(out.cc.p + so, p.cc.p, p.ns * 4, ctx->stream); d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
+            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream);
+            d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
             so += p.ns; mo += p.nm;
         }
         dsync(ctx->stream);

@@ -2,8 +2,9 @@
 //
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
-//   position order : p_seed/p_pos/p_cc (+ p_cnt = multiplicity of the entry's seed in this genome)  -- enumeration side
-//   seed order     : s_pos/s_cc sorted by (mix32(seed), contig, pos)     (mix32 is a bijection: equal hash <=> equal seed)
+//   position order : p_seed/p_g (+ p_cnt = multiplicity of the entry's seed in this genome)          -- enumeration side
+//                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
+//   seed order     : s_g = the same records sorted by (mix32(seed), contig, pos)   (mix32 is a bijection: equal hash <=> equal seed)
 //   seed index     : ent = one 64-bit entry per distinct seed in hash order, hash << 32 | start << 8 | multiplicity,
 //                    dir = bucket directory over the hash range (2 buckets per distinct seed)                -- probe side
 //                    Built by one sort + a scatter of bucket boundaries: no atomics, no empty-slot fill, and a probe of an
@@ -30,6 +31,25 @@ __global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_s
     vals[i] = (uint32_t)(i - pos_off[g]);
 }
 
+// (pos, contig << 1 | canonical) -> padded coordinate << 1 | canonical
+__global__ __launch_bounds__(256) void pack_positions_kernel(const uint32_t* pos, const uint32_t* cc, const uint64_t* pos_off, const uint64_t* ctg_off, uint32_t ng,
+                                                             uint64_t n, const uint32_t* goff, uint32_t* p_g) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = seg_of(pos_off, ng, i), c = cc[i];
+    p_g[i] = ((goff[ctg_off[g] + g + (c >> 1)] + pos[i]) << 1) | (c & 1u);
+}
+__global__ __launch_bounds__(256) void unpack_positions_kernel(const uint32_t* p_g, const uint64_t* pos_off, const uint64_t* ctg_off, uint32_t ng, uint64_t p0,
+                                                               uint64_t n, const uint32_t* goff, uint32_t* pos, uint32_t* cc) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = seg_of(pos_off, ng, p0 + i), v = p_g[p0 + i];
+    const uint32_t* go = goff + ctg_off[g] + g;
+    const uint32_t c = ctg_of(go, (uint32_t)(ctg_off[g + 1] - ctg_off[g]), v >> 1);
+    if (pos) pos[i] = (v >> 1) - go[c];
+    if (cc) cc[i] = (c << 1) | (v & 1u);
+}
+
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, uint64_t n, uint32_t* head) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -51,13 +71,12 @@ __global__ __launch_bounds__(256) void distinct_kernel(const uint64_t* keys, con
 
 __global__ __launch_bounds__(256) void seed_order_gather_kernel(const uint64_t* keys, const uint32_t* vals, const uint32_t* head,
                                                                 const uint32_t* excl, uint64_t n, const uint64_t* pos_off,
-                                                                const uint32_t* p_pos, const uint32_t* p_cc, const uint16_t* u_cnt,
-                                                                uint32_t* s_pos, uint32_t* s_cc, uint16_t* p_cnt) {
+                                                                const uint32_t* p_g, const uint16_t* u_cnt, uint32_t* s_g, uint16_t* p_cnt) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = (uint32_t)(keys[i] >> 32);
     const uint64_t src = pos_off[g] + vals[i];
-    s_pos[i] = p_pos[src]; s_cc[i] = p_cc[src];
+    s_g[i] = p_g[src];
     p_cnt[src] = u_cnt[excl[i] + head[i] - 1];
 }
 
@@ -83,11 +102,26 @@ __global__ __launch_bounds__(256) void dir_build_kernel(const uint64_t* ent, con
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
 
-void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
+void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc) {
+    if (!n || (!pos && !cc)) return;
+    SKH_LAUNCH(unpack_positions_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_g.p, (const uint64_t*)ss->d_pos_off.p,
+               (const uint64_t*)ss->d_ctg_off.p, ss->n_genomes, p0, n, (const uint32_t*)ss->d_goff.p, pos, cc);
+    check_launch("unpack_positions");
+}
+
+void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->s_pos.alloc(P); ss->s_cc.alloc(P); ss->p_cnt.alloc(P);
+    ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
+    ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->s_g.alloc(P); ss->p_cnt.alloc(P);
+    if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
+    if (P > 0 && pos && cc) {
+        SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
+        check_launch("pack_positions");
+    }
     ss->dist_off.assign(ng + 1, 0);
     for (uint32_t g = 0; g < ng; g++)
         if (ss->pos_off[g + 1] - ss->pos_off[g] >= (1ull << 24)) throw Error("a genome with >= 2^24 seed positions does not fit the 24-bit table slot field");
@@ -117,8 +151,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss) {
                    (const uint64_t*)ss->d_pos_off.p, ss->ent.p, u_cnt);
         check_launch("distinct");
         SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
-                   (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_pos.p, (const uint32_t*)ss->p_cc.p,
-                   (const uint16_t*)u_cnt, ss->s_pos.p, ss->s_cc.p, ss->p_cnt.p);
+                   (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_g.p, (const uint16_t*)u_cnt, ss->s_g.p, ss->p_cnt.p);
         check_launch("seed_order_gather");
     }
     else ss->ent.alloc(0);
@@ -187,9 +220,16 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
 }
 
 // host-only: per-genome contig statistics used by switch_qr (chain.rs:625-631) and the regression features
-// (chain.rs:519-526): sorted contig lengths at indices n*10/100, n*50/100, n*90/100.
+// (chain.rs:519-526): sorted contig lengths at indices n*10/100, n*50/100, n*90/100; and the padded contig starts.
 void finalize_metadata(skh_sketch_set* ss) {
     const uint32_t ng = ss->n_genomes;
+    ss->goff.assign(ss->ctg_len.size() + ng, 0);
+    for (uint32_t g = 0; g < ng; g++) {
+        uint64_t at = 0; const uint64_t base = ss->ctg_off[g] + g;
+        for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff[base + (c - ss->ctg_off[g])] = (uint32_t)at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; if (at >= (1ull << 31)) break; }
+        if (at >= (1ull << 31)) throw Error("a genome spans >= 2^31 padded bases (total length + 8192 per contig); it does not fit the 32-bit position records");
+        ss->goff[base + (ss->ctg_off[g + 1] - ss->ctg_off[g])] = (uint32_t)at;
+    }
     ss->mean_ctg.assign(ng, 0.); ss->q10.assign(ng, 0.f); ss->q50.assign(ng, 0.f); ss->q90.assign(ng, 0.f);
     for (uint32_t g = 0; g < ng; g++) {
         std::vector<uint32_t> v(ss->ctg_len.begin() + ss->ctg_off[g], ss->ctg_len.begin() + ss->ctg_off[g + 1]);
