@@ -1029,11 +1029,12 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 
 // slot order for the join kernels: tiles grouped by (key % 8) and interleaved so that slot b (-> XCD b % 8) serves queue b % 8
 static std::vector<uint32_t> xcd_slots(uint32_t t0, uint32_t t1, const std::vector<uint32_t>& tile_pair, const std::vector<uint32_t>& pair_key) {
-    std::vector<uint32_t> q[8];
-    for (uint32_t t = t0; t < t1; t++) q[pair_key[tile_pair[t]] & 7u].push_back(t);
-    size_t mx = 0; for (auto& v : q) mx = std::max(mx, v.size());
+    size_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t t = t0; t < t1; t++) cnt[pair_key[tile_pair[t]] & 7u]++;
+    size_t mx = 0; for (size_t v : cnt) mx = std::max(mx, v);
     std::vector<uint32_t> slots(mx * 8, NONE);
-    for (uint32_t x = 0; x < 8; x++) for (size_t i = 0; i < q[x].size(); i++) slots[i * 8 + x] = q[x][i];
+    size_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t t = t0; t < t1; t++) { const uint32_t x = pair_key[tile_pair[t]] & 7u; slots[cur[x]++ * 8 + x] = t; }
     return slots;
 }
 
@@ -1051,6 +1052,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         if (!model->loaded()) throw std::invalid_argument("learned_ani requested but skh_load_models was not called");
     }
     const uint32_t NP = (uint32_t)n_pairs_all;
+    StageTrace tr(ctx);
     // ---- pair descriptors and join tiles
     std::vector<PairDesc> pds(NP); std::vector<uint32_t> tile_pair;
     std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
@@ -1078,6 +1080,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }
+    tr.mark("host: pair descriptors");
     const SetView v0 = view_of(R), v1 = view_of(Q);
     const uint32_t NT = (uint32_t)tile_pair.size();
     PairDesc* d_pairs_all = upload(ctx, pds);
@@ -1103,15 +1106,19 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint16_t* pinfo_cnt = ctx->arena.get<uint16_t>((size_t)snt * JOIN_TILE + 1);
         // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
         uint32_t* pis = pinfo_start - (size_t)st0 * JOIN_TILE; uint16_t* pic = pinfo_cnt - (size_t)st0 * JOIN_TILE;
+        uint32_t* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         if (snt) {
             const std::vector<uint32_t> slots = xcd_slots(st0, st1, tile_pair, pair_key);
             uint32_t* d_slots = upload(ctx, slots);
+            d_super_slots = d_slots; n_super_slots = (unsigned)slots.size();
             SKH_LAUNCH(join_count_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic);
             check_launch("join_count");
         }
+        tr.mark("join_count (+slots)");
         d2h(pair_anch.data() + sp0, d_pair_anch + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
         d2h(pair_inq.data() + sp0, d_pair_inq + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
+        tr.mark("d2h pair counts");
         uint32_t p0 = sp0;
         while (p0 < sp1) {
         uint64_t na = 0; uint32_t p1 = p0;
@@ -1134,21 +1141,24 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
         uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
         exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); exclusive_scan_u32(ctx, tile_inq + t0, nt, toff_q);
+        tr.mark("host prefix + uploads + scans");
         uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
         uint32_t* ql_g = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
-            const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key);
-            uint32_t* d_slots = upload(ctx, slots);
-            SKH_LAUNCH(join_fill_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+            uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
+            if (t0 != st0 || t1 != st1) { const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key); d_slots = upload(ctx, slots); n_slots = (unsigned)slots.size(); }
+            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
                        anc_q, anc_r, ql_g);
             check_launch("join_fill");
         }
+        tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
         SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, v0.goff, v1.goff, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0,
                    (const uint32_t*)d_pc0, (const uint32_t*)anc_q, (const uint32_t*)ql_g, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
+        tr.mark("chunk");
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
@@ -1186,11 +1196,13 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         }
 #define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, (const uint32_t*)ivl_cnt, \
                    (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
+        tr.mark("dp (+order sort)");
         SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
 #undef SKH_GREEDY
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
         check_launch("greedy");
+        tr.mark("greedy");
         double* chunk_est = ctx->arena.get<double>(NC + 1); uint32_t* chunk_w = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* pair_tqb = ctx->arena.get<uint32_t>(np); uint32_t* pair_acl = ctx->arena.get<uint32_t>(np); uint32_t* pair_nch = ctx->arena.get<uint32_t>(np);
         dzero(pair_tqb, np * 4, ctx->stream); dzero(pair_acl, np * 4, ctx->stream); dzero(pair_nch, np * 4, ctx->stream);
@@ -1199,6 +1211,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
                        (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_g, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
             check_launch("chunk_stats");
         }
+        tr.mark("chunk_stats");
         FinalizeArgs fa{};
         fa.n_pairs = np; fa.c = c; fa.k = k; fa.min_af = mp.min_af; fa.both_min_af = mp.both_min_af; fa.robust = mp.robust; fa.median = mp.median;
         fa.learned = model ? 1 : 0; fa.compute_ci = mp.compute_ci;
@@ -1209,6 +1222,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         SKH_LAUNCH(finalize_kernel, (np + 3) / 4, 256, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, (const double*)chunk_est,
                    (const uint32_t*)chunk_w, (const uint32_t*)pair_tqb, (const uint32_t*)pair_acl, (const uint32_t*)pair_nch, fs, n_est, d_out + p0);
         check_launch("finalize");
+        tr.mark("finalize");
         if (stats) {   // parity/debug path: pull the stage sizes (and the anchors, for the checksum) back to the host
             std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
             d2h(h_nc.data(), n_chunks, np * 4, ctx->stream); d2h(h_ni.data(), ivl_cnt, np * 4, ctx->stream);
@@ -1233,6 +1247,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     uint32_t h_err = 0;
     d2h(&h_err, d_err, 4, ctx->stream);
     d2h(out, d_out, (uint64_t)NP * sizeof(skh_ani_result), ctx->stream);
+    tr.mark("results d2h");
     if (h_err) throw Error("internal capacity bound violated in chain pipeline (" + std::to_string(h_err) + " events)");
 }
 

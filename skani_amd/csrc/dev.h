@@ -43,8 +43,12 @@ inline void check_launch(const char*) {}
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
 }
-inline void* dmalloc(size_t n) { void* p = nullptr; hip_check(hipMalloc(&p, n ? n : 16), "hipMalloc"); return p; }
-inline void dfree(void* p) { if (p) (void)hipFree(p); }
+// Device blocks go through a small caching allocator (alloc.hip): hipMalloc / hipFree of the few-hundred-MB sketch arrays
+// cost 0.1-0.3 ms each and hipFree synchronises the device.  Every entry point of the library is synchronous, so a block is
+// idle by the time its owner releases it.
+void* dmalloc(size_t n);
+void dfree(void* p);
+void dcache_trim();                       // hand every cached block back to the driver
 inline void h2d(void* d, const void* h, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d"); }
 inline void d2h(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }
 inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "d2d"); }

@@ -1,5 +1,6 @@
 // internal.h -- host-side declarations shared by the translation units of libskani_hip.so.
 #pragma once
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -114,6 +115,19 @@ struct skh_sketch_set {
 };
 
 namespace skh {
+
+// SKH_TRACE=1: host wall-clock per stage of the host drivers on stderr (each mark synchronises the stream; diagnosis only)
+struct StageTrace {
+    skh_ctx* ctx; bool on; std::chrono::steady_clock::time_point t;
+    explicit StageTrace(skh_ctx* c) : ctx(c) { const char* v = getenv("SKH_TRACE"); on = v && *v == '1'; t = std::chrono::steady_clock::now(); }
+    void mark(const char* what) {
+        if (!on) return;
+        dsync(ctx->stream);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[skh trace] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 // ---- scan.hip
 void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t* d_out /* n+1 entries */);

@@ -258,6 +258,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint64_t thr = ~0ull / (uint64_t)sp.c, thr_m = ~0ull / (uint64_t)sp.marker_c;   // seeding.rs:258-259
     const size_t n_tiles = gs->tiles.size();
     const uint32_t ng = gs->n_genomes;
+    StageTrace tr(ctx);
     out.pos_off.assign(ng + 1, 0); out.mk_off.assign(ng + 1, 0);
     // capped tile scratch: 4x the expected hits per tile; tiles that exceed it are re-run with full capacity
     const uint32_t cap_s = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
@@ -274,6 +275,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 #ifndef SKANI_EMU
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
 #endif
+    tr.mark("seed: host tile tables");
     uint64_t base_s = 0, base_m = 0;
     for (size_t t0 = 0; t0 < n_tiles; t0 += MAX_TILES) {
         const uint32_t nt = (uint32_t)std::min(MAX_TILES, n_tiles - t0);
@@ -297,6 +299,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 #ifndef SKANI_EMU
         hip_check(hipEventRecord(e1, ctx->stream), "event record"); evs.push_back({e0, e1});
 #endif
+        tr.mark("seed: tiles kernel");
         SKH_LAUNCH(seed_overflow_kernel, (nt + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf);
         check_launch("seed_overflow");
         exclusive_scan_u32(ctx, cnt_s, nt, off_s);
@@ -315,6 +318,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         std::vector<uint32_t> got(2 * want.size() + 1);
         d2h(got.data(), d_got, got.size() * 4, ctx->stream);
         const uint32_t h_novf = got[2 * want.size()];
+        tr.mark("seed: scans + readback");
         Part p; p.ns = got[want.size() - 1]; p.nm = got[2 * want.size() - 1];
         for (size_t x = 0; x < want_g.size(); x++) { g_ns[want_g[x]] = base_s + got[x]; g_nm[want_g[x]] = base_m + got[want.size() + x]; }
         uint32_t *o_seed2 = nullptr; uint16_t* o_loc2 = nullptr; uint64_t* o_marker2 = nullptr;
@@ -332,6 +336,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2,
                    (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.g.p, p.mk.p);
         check_launch("seed_compact_kernel");
+        tr.mark("seed: overflow + alloc + compact");
         base_s += p.ns; base_m += p.nm;
         parts.push_back(std::move(p));
         dsync(ctx->stream);

@@ -128,6 +128,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     const skh_sketch_set* rowset = tri ? refs : queries;
     const uint32_t nrows = rowset->n_genomes, ncols = refs->n_genomes;
     if (nrows == 0 || ncols == 0) return;
+    StageTrace tr(ctx);
     if (ncols > ID_MASK || nrows > ID_MASK) throw Error("more than 2M genomes in one screen call");
     const uint64_t MR = refs->mk_off[ncols], MQ = tri ? 0 : queries->mk_off[nrows], M = MR + MQ;
     uint64_t* keys = ctx->arena.get<uint64_t>(M ? M : 1);
@@ -136,6 +137,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     if (MQ) { SKH_LAUNCH(screen_keys_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)queries->markers.p,
                          (const uint64_t*)queries->d_mk_off.p, nrows, MQ, 1u, keys + MR); check_launch("screen_keys"); }
     sort_keys_u64(ctx, keys, M, 64);
+    tr.mark("screen: keys + sort");
     ScreenRule sr{powi21(identity), rule, rescue_small, tri ? 1 : 0};
     // row blocking keeps the dense count matrix within a fixed budget
     const uint64_t budget_cells = ctx->tune.screen_cells;   // u32 counters per row block (default 8 GiB)
@@ -166,6 +168,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         }
     }
     dsync(ctx->stream);
+    tr.mark("screen: count + threshold");
 }
 
 }  // namespace skh

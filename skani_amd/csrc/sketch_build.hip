@@ -112,6 +112,7 @@ void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint6
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
+    StageTrace tr(ctx);
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
     ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
@@ -133,7 +134,9 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         const unsigned nb = (unsigned)((P + 255) / 256);
         SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, keys, vals);
         check_launch("make_seed_keys");
+        tr.mark("build: allocs + keys");
         sort_pairs_u64_u32(ctx, keys, vals, P, 32 + bits_for(ng));
+        tr.mark("build: sort");
         uint32_t* head = ctx->arena.get<uint32_t>(P); uint32_t* excl = ctx->arena.get<uint32_t>(P + 1);
         SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, P, head);
         check_launch("head_flags");
@@ -145,6 +148,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
         for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
         D = ss->dist_off[ng];
+        tr.mark("build: heads + scan + readback");
         u_cnt = ctx->arena.get<uint16_t>(D);
         ss->ent.alloc(D);
         SKH_LAUNCH(distinct_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)head, (const uint32_t*)excl, P,
@@ -153,6 +157,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
                    (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_g.p, (const uint16_t*)u_cnt, ss->s_g.p, ss->p_cnt.p);
         check_launch("seed_order_gather");
+        tr.mark("build: distinct + gather");
     }
     else ss->ent.alloc(0);
     // bucket directories (north-star requirement: per-sketch seed -> position tables built on device)
@@ -174,6 +179,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
                    (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, ss->dir.p);
         check_launch("dir_build");
     }
+    tr.mark("build: directory");
     dsync(ctx->stream);
 }
 
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t* key
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
+    StageTrace tr(ctx);
     ss->mk_off.assign(ng + 1, 0);
     if (ng >= (1u << 22)) throw Error("more than 4M genomes in one sketch set");
     if (M >= 0xFFFFFFF0ull) throw Error("too many markers for one build; split the batch");
@@ -217,6 +224,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
     } else ss->markers.alloc(0);
     ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
     dsync(ctx->stream);
+    tr.mark("build: markers");
 }
 
 // host-only: per-genome contig statistics used by switch_qr (chain.rs:625-631) and the regression features
