@@ -560,7 +560,8 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
         const uint32_t ci = have ? idx[s] : 0;
         Interval c = iv[ci];
         uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
-        for (uint32_t a = 0; a < nacc; a++) {                                      // uniform index: LDS broadcast
+#pragma unroll 4
+        for (uint32_t a = 0; a < nacc; a++) {                                      // uniform index: LDS broadcast (several in flight)
             const uint4 lo4 = *(const uint4*)&acc[a]; const uint2 hi2 = *(const uint2*)&acc[a].q0;
             const uint32_t actg = lo4.x, ar0 = lo4.y, ar1 = lo4.z, aqc = lo4.w, aq0 = hi2.x, aq1 = hi2.y;
             const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;             // chain.rs:1030-1045
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     for (uint32_t i = l; i < n; i += 64) {
         const double e = U[i]; const uint32_t w = UW[i];
         uint32_t rank = 0;
+#pragma unroll 4
         for (uint32_t j = 0; j < n; j++) { const double ej = U[j]; const uint32_t wj = UW[j]; rank += (ej < e || (ej == e && (wj < w || (wj == w && j < i)))) ? 1u : 0u; }
         S[rank] = e; SW[rank] = w;
     }
@@ -1028,14 +1030,42 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 }  // namespace
 
 // slot order for the join kernels: tiles grouped by (key % 8) and interleaved so that slot b (-> XCD b % 8) serves queue b % 8
-static std::vector<uint32_t> xcd_slots(uint32_t t0, uint32_t t1, const std::vector<uint32_t>& tile_pair, const std::vector<uint32_t>& pair_key) {
-    size_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t t = t0; t < t1; t++) cnt[pair_key[tile_pair[t]] & 7u]++;
-    size_t mx = 0; for (size_t v : cnt) mx = std::max(mx, v);
-    std::vector<uint32_t> slots(mx * 8, NONE);
-    size_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t t = t0; t < t1; t++) { const uint32_t x = pair_key[tile_pair[t]] & 7u; slots[cur[x]++ * 8 + x] = t; }
-    return slots;
+// Tables for the join kernels, written on the device from per-pair records: tile -> pair, and slot -> tile, where the tiles of
+// pairs [p0, p1) are dealt to eight queues by the probed sketch (queue = key % 8) and queue x owns slots x, x+8, x+16, ...
+// (-> XCD x).  The host only computes each pair's first position in its queue.
+__global__ __launch_bounds__(256) void tile_pair_kernel(uint32_t n_pairs, const PairDesc* pairs, uint32_t* tile_pair) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t nt = (pairs[p].a_n + JOIN_TILE - 1) / JOIN_TILE, t0 = pairs[p].tile0;
+    for (uint32_t t = 0; t < nt; t++) tile_pair[t0 + t] = p;
+}
+__global__ __launch_bounds__(256) void slot_tile_kernel(uint32_t p0, uint32_t p1, const PairDesc* pairs, const uint32_t* queue_pos /* (p1-p0): queue << 29 | first */,
+                                                        uint32_t* slot_tile) {
+    const uint32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    const uint32_t nt = (pairs[p].a_n + JOIN_TILE - 1) / JOIN_TILE, t0 = pairs[p].tile0, qp = queue_pos[p - p0];
+    const uint32_t x = qp >> 29, first = qp & 0x1FFFFFFFu;
+    for (uint32_t t = 0; t < nt; t++) slot_tile[(size_t)(first + t) * 8 + x] = t0 + t;
+}
+// returns the device slot table for pairs [p0, p1) and its length
+static uint32_t* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::vector<PairDesc>& pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
+                           unsigned* n_slots) {
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> qp(p1 - p0);
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t x = pair_key[p] & 7u, nt = (pds[p].a_n + JOIN_TILE - 1) / JOIN_TILE;
+        if (cnt[x] + nt >= (1u << 29)) throw Error("too many join tiles in one batch");
+        qp[p - p0] = (x << 29) | cnt[x]; cnt[x] += nt;
+    }
+    uint32_t mx = 0; for (uint32_t v : cnt) mx = std::max(mx, v);
+    *n_slots = mx * 8;
+    uint32_t* d_slots = ctx->arena.get<uint32_t>((size_t)mx * 8 + 1);
+    if (mx == 0) return d_slots;
+    dfill(d_slots, 0xFF, (size_t)mx * 8 * 4, ctx->stream);
+    uint32_t* d_qp = ctx->arena.get<uint32_t>(qp.size()); h2d(d_qp, qp.data(), qp.size() * 4, ctx->stream);
+    SKH_LAUNCH(slot_tile_kernel, (p1 - p0 + 255) / 256, 256, 0, ctx->stream, p0, p1, d_pairs_all, (const uint32_t*)d_qp, d_slots);
+    check_launch("slot_tile");
+    return d_slots;
 }
 
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q, const uint32_t* pair_ref, const uint32_t* pair_query,
@@ -1054,7 +1084,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     const uint32_t NP = (uint32_t)n_pairs_all;
     StageTrace tr(ctx);
     // ---- pair descriptors and join tiles
-    std::vector<PairDesc> pds(NP); std::vector<uint32_t> tile_pair;
+    std::vector<PairDesc> pds(NP); uint64_t n_tiles_all = 0;
     std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
     std::vector<const uint32_t*> host_go_a(stats ? NP : 0), host_go_b(stats ? NP : 0);
     for (uint32_t p = 0; p < NP; p++) {
@@ -1068,23 +1098,26 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
         pd.b_pos0 = B->pos_off[gb]; pd.b_ent0 = B->dist_off[gb]; pd.b_dir0 = B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb];
         pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
-        pd.tile0 = (uint32_t)tile_pair.size();
+        pd.tile0 = (uint32_t)n_tiles_all;
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
         pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
         pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
         pd.a_goff0 = A->ctg_off[ga] + ga; pd.b_goff0 = B->ctg_off[gb] + gb;
         pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
         if (stats) { host_go_a[p] = A->goff.data() + pd.a_goff0; host_go_b[p] = B->goff.data() + pd.b_goff0; }
-        for (uint32_t t = 0; t * JOIN_TILE < pd.a_n; t++) tile_pair.push_back(p);
+        n_tiles_all += (pd.a_n + JOIN_TILE - 1) / JOIN_TILE;
+        if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
         pair_key[p] = gb;                                                           // tiles probing the same sketch share an XCD
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }
     tr.mark("host: pair descriptors");
     const SetView v0 = view_of(R), v1 = view_of(Q);
-    const uint32_t NT = (uint32_t)tile_pair.size();
+    const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = upload(ctx, pds);
-    uint32_t* d_tile_pair = upload(ctx, tile_pair);
+    uint32_t* d_tile_pair = ctx->arena.get<uint32_t>((size_t)NT + 1);
+    SKH_LAUNCH(tile_pair_kernel, (NP + 255) / 256, 256, 0, ctx->stream, NP, (const PairDesc*)d_pairs_all, d_tile_pair);
+    check_launch("tile_pair");
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
     uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_inq = ctx->arena.get<uint32_t>((size_t)NT + 1);
@@ -1108,10 +1141,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* pis = pinfo_start - (size_t)st0 * JOIN_TILE; uint16_t* pic = pinfo_cnt - (size_t)st0 * JOIN_TILE;
         uint32_t* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         if (snt) {
-            const std::vector<uint32_t> slots = xcd_slots(st0, st1, tile_pair, pair_key);
-            uint32_t* d_slots = upload(ctx, slots);
-            d_super_slots = d_slots; n_super_slots = (unsigned)slots.size();
-            SKH_LAUNCH(join_count_kernel, (unsigned)slots.size(), 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+            uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, pair_key, &n_super_slots);
+            d_super_slots = d_slots;
+            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic);
             check_launch("join_count");
         }
@@ -1146,7 +1178,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* ql_g = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
             uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
-            if (t0 != st0 || t1 != st1) { const std::vector<uint32_t> slots = xcd_slots(t0, t1, tile_pair, pair_key); d_slots = upload(ctx, slots); n_slots = (unsigned)slots.size(); }
+            if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, pair_key, &n_slots);
             SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
                        anc_q, anc_r, ql_g);
