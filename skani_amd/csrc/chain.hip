@@ -130,34 +130,44 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
 __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                         uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
                                                         const uint16_t* pinfo_cnt, uint32_t* anc_q, uint32_t* anc_r, uint32_t* ql_g) {
-    __shared__ uint32_t lds[16];
+    constexpr int R = JOIN_TILE / 256;
+    __shared__ uint32_t lds_a[R * 4], lds_q[R * 4];
     const uint32_t tile = slot_tile[blockIdx.x];
     if (tile == NONE) return;
     const uint32_t lt = tile - tile_base, p = tile_pair[tile];
     const PairDesc pd = pairs[p];
     const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
-    uint32_t run_a = toff_a[lt], run_q = toff_q[lt];
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    for (uint32_t r = 0; r < JOIN_TILE / 256; r++) {
+    // all loads of the tile's four rounds are issued before anything depends on them; one barrier for the offsets
+    uint32_t n_anch[R], inq[R], qg[R], bst[R], ia[R], iq[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        uint32_t n_anch = 0, inq = 0;
-        if (i < pd.a_n) { const uint32_t c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; n_anch = c & 0x7FFFu; inq = c >> 15; }
-        const uint32_t ia = wave_incl_scan(n_anch), iq = wave_incl_scan(inq);
-        if (l == 63) { lds[w] = ia; lds[8 + w] = iq; }
-        __syncthreads();
+        uint32_t c = 0; qg[r] = 0; bst[r] = 0;
+        if (i < pd.a_n) { c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; qg[r] = A.p_g[pd.a_pos0 + i]; bst[r] = pinfo_start[(uint64_t)tile * JOIN_TILE + o]; }
+        n_anch[r] = c & 0x7FFFu; inq[r] = c >> 15;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        ia[r] = wave_incl_scan(n_anch[r]); iq[r] = wave_incl_scan(inq[r]);
+        if (l == 63) { lds_a[r * 4 + w] = ia[r]; lds_q[r * 4 + w] = iq[r]; }
+    }
+    __syncthreads();
+    uint32_t run_a = toff_a[lt], run_q = toff_q[lt];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         uint32_t ba = 0, bq = 0, ta = 0, tq = 0;
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds[k], y = lds[8 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
-        __syncthreads();
-        if (inq) {
-            const uint32_t qg = A.p_g[pd.a_pos0 + i];
-            ql_g[run_q + bq + iq - 1] = qg >> 1;
-            if (n_anch) {
-                const uint64_t bs = pd.b_pos0 + pinfo_start[(uint64_t)tile * JOIN_TILE + o];
-                uint32_t oa = run_a + ba + ia - n_anch;
-                for (uint32_t k = 0; k < n_anch; k++, oa++) {                        // chain.rs:703-711, already in sorted order
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds_a[r * 4 + k], y = lds_q[r * 4 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
+        if (inq[r]) {
+            ql_g[run_q + bq + iq[r] - 1] = qg[r] >> 1;
+            if (n_anch[r]) {
+                const uint64_t bs = pd.b_pos0 + bst[r];
+                uint32_t oa = run_a + ba + ia[r] - n_anch[r];
+                for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                     // chain.rs:703-711, already in sorted order
                     const uint32_t rg = B.s_g[bs + k];
-                    anc_q[oa] = qg >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg) & 1u);
+                    anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
                 }
             }
         }
@@ -408,35 +418,68 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(ec.err, 1u); return; }
     const uint32_t p = n ? chunk_pair[slot] : 0;
     unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
-    uint32_t rq[NB], rr[NB], rc[NB], rs[NB], rd[NB];                                // q, r, contig/strand, score, depth << 8 | component
+    // ring of the last NB anchors: q, strand-signed r, score + ANCHOR_SCORE, depth << 8 | component.
+    //  * r is kept as s = reverse ? ~r : r.  For two anchors of the same strand s_i - s_j is the forward distance on that strand
+    //    (chain.rs:573-586); for different strands it is >= 2 * CTG_PAD away from 0 in both directions because every padded
+    //    coordinate lies in [CTG_PAD, 2^31 - CTG_PAD) -- the same-contig and the same-strand tests are both implied by the gap test.
+    //  * empty slots hold q = 0, which is more than BP_CHAIN_BAND below any real coordinate.
+    uint32_t rq[NB], rr[NB], rs[NB], rd[NB];
 #pragma unroll
-    for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rc[k] = 0xFFFFFFFFu; rs[k] = 0; rd[k] = 0; }
-    const uint32_t* aq = ec.anc_q + ck.a_begin; const uint32_t* arr = ec.anc_r + ck.a_begin;
-    // anchors are fetched PFD iterations ahead: with ~2 waves per SIMD an iteration's arithmetic covers only a fraction of
-    // a memory round trip, so one load in flight per lane leaves the wave waiting
-    constexpr uint32_t PFD = 4;
-    uint2 pf[PFD];
+    for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rs[k] = 0; rd[k] = 0; }
+    // Anchor fetch.  A lane walks its own chunk, so a plain per-lane load touches 64 different cache lines per instruction and
+    // uses 4 bytes of each; with ~50k such streams per XCD the lines are evicted before their next element is wanted and every
+    // anchor costs a 64-byte HBM fetch (measured: 15 GB read for 2.4 GB of anchors).  Instead every lane pulls whole 64-byte
+    // lines (16 anchors of one array) as four 16-byte loads, one line ahead of use, and parks the current line in its own LDS
+    // column [element][lane].  All lanes use the same element index: a lane's walk starts at its chunk's 64-byte-aligned
+    // predecessor ("virtual" index v; elements before the chunk are skipped), which keeps the LDS reads conflict-free and
+    // the refill branch wave-uniform.
+    __shared__ uint32_t lds_q[16 * T], lds_r[16 * T];
+    const uint32_t voff = ck.a_begin & 15u;
+    const uint32_t vtot = n ? n + voff : 0;
+    const uint32_t* line_q = ec.anc_q + (ck.a_begin - voff); const uint32_t* line_r = ec.anc_r + (ck.a_begin - voff);
+    uint4 pq[4], pr[4];
 #pragma unroll
-    for (uint32_t u = 0; u < PFD; u++) pf[u] = u < n ? make_uint2(aq[u], arr[u]) : make_uint2(0, 0);
-    for (uint32_t i = 0; i < n; i++) {
-        const uint2 a = pf[0];
+    for (int j = 0; j < 4; j++) { pq[j] = make_uint4(0, 0, 0, 0); pr[j] = make_uint4(0, 0, 0, 0); }
+    if (vtot) {
 #pragma unroll
-        for (uint32_t u = 0; u + 1 < PFD; u++) pf[u] = pf[u + 1];
-        if (i + PFD < n) pf[PFD - 1] = make_uint2(aq[i + PFD], arr[i + PFD]);
-        const uint32_t q = a.x, r = a.y >> 1, cr = a.y & 1u;                         // cr: strand only -- different contigs are > MAX_LIN apart
-        const bool rev = cr != 0;
-        const uint32_t nd = i < band ? i : band;
+        for (int j = 0; j < 4; j++) { pq[j] = *(const uint4*)(line_q + 4 * j); pr[j] = *(const uint4*)(line_r + 4 * j); }
+    }
+    for (uint32_t v = 0;; v++) {
+        const uint32_t kk = v & 15u;
+        if (kk == 0) {                                                              // wave-uniform
+            if (__ballot(v < vtot) == 0) break;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lds_q[(4 * j + 0) * T + tid] = pq[j].x; lds_q[(4 * j + 1) * T + tid] = pq[j].y; lds_q[(4 * j + 2) * T + tid] = pq[j].z; lds_q[(4 * j + 3) * T + tid] = pq[j].w;
+                lds_r[(4 * j + 0) * T + tid] = pr[j].x; lds_r[(4 * j + 1) * T + tid] = pr[j].y; lds_r[(4 * j + 2) * T + tid] = pr[j].z; lds_r[(4 * j + 3) * T + tid] = pr[j].w;
+            }
+            if (v + 16 < vtot) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { pq[j] = *(const uint4*)(line_q + v + 16 + 4 * j); pr[j] = *(const uint4*)(line_r + v + 16 + 4 * j); }
+            }
+        }
+        if (v < voff || v >= vtot) continue;
+        const uint32_t i = v - voff;
+        const uint2 a = make_uint2(lds_q[kk * T + tid], lds_r[kk * T + tid]);
+        const uint32_t q = a.x, r = (a.y & 1u) ? ~(a.y >> 1) : (a.y >> 1);
         int32_t bscore = 0; uint32_t bdc = NONE;
-        // predecessors j = i-1-k for k = 0..nd-1 (downward scan; strict '>' keeps the largest j among equal maxima, chain.rs:852-880)
+        // predecessors j = i-1-k for k = 0..band-1 (downward scan; strict '>' keeps the largest j among equal maxima, chain.rs:852-880).
+        // Anchors ascend in q, so once the slot just examined is out of reach for every lane the older ones are too: the scan
+        // stops there (checked every four slots; chunks are dealt out by length, so a wave's lanes agree on how far to look).
+        bool stop = false;
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const uint32_t dq = q - rq[k];
-            const uint32_t dr = rev ? rr[k] - r : r - rr[k];                        // wrong direction wraps to a huge value
-            const int32_t gap = (int32_t)dr > (int32_t)dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-            const int32_t sc = ANCHOR_SCORE - gap + (int32_t)rs[k];
-            const bool ok = ((uint32_t)k < nd) & (rc[k] == cr) & (dq - 1u < BP_CHAIN_BAND) & (dr - 1u < (uint32_t)MAX_LIN) & ((uint32_t)gap <= (uint32_t)MAX_GAP) &
-                            (sc > bscore);                                          // chain.rs:856-863, 564-597
-            bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
+            if (k > 0 && (k & 3) == 0 && !stop) stop = __ballot(q - rq[k - 1] <= BP_CHAIN_BAND) == 0;
+            if (!stop && (uint32_t)k < band) {
+                const uint32_t dq = q - rq[k];
+                const int32_t dr = (int32_t)(r - rr[k]);                            // 0 < dr: same strand, ref coordinate advances along it
+                const int32_t d = dr - (int32_t)dq;
+                const int32_t gap = d < 0 ? -d : d;
+                const int32_t sc = (int32_t)rs[k] - gap;
+                // 0 < dq <= 2500 and gap <= 300 bound dr by 2800 < D_MAX_LIN_LENGTH (chain.rs:856-863, 564-597)
+                const bool ok = (dq - 1u < BP_CHAIN_BAND) & (dr > 0) & (gap <= MAX_GAP) & (sc > bscore);
+                bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
+            }
         }
         uint32_t comp, depth;
         if (bdc != NONE) {
@@ -460,8 +503,8 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
             if ((v & 0xFFu) == 0) { dp_emit(ck, slot, p, v >> 8, get_best(c_old), ec); free_mask |= 1ull << c_old; }
         }
 #pragma unroll
-        for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rc[k] = rc[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
-        rq[0] = q; rr[0] = r; rc[0] = cr; rs[0] = (uint32_t)bscore; rd[0] = (depth << 8) | comp;
+        for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
+        rq[0] = q; rr[0] = r; rs[0] = (uint32_t)(bscore + ANCHOR_SCORE); rd[0] = (depth << 8) | comp;
     }
     // chunk end: every component still referenced by the ring is final now
     const uint32_t live = n < band ? n : band;

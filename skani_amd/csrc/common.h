@@ -44,9 +44,11 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     return h;
 }
 
-// Padded genome coordinates: a seed at (contig c, pos) lives at goff[c] + pos, where consecutive contigs are CTG_PAD apart.
+// Padded genome coordinates: a seed at (contig c, pos) lives at goff[c] + pos, where the first contig starts at CTG_PAD and
+// consecutive contigs are CTG_PAD apart; a genome's padded span must stay below 2^31 - CTG_PAD.
 // CTG_PAD exceeds every distance the chaining DP can bridge (D_MAX_LIN_LENGTH, BP_CHAIN_BAND), so "same contig" is implied
-// by "close enough" and an anchor needs no contig field.  A position is stored as gpos << 1 | canonical-strand bit.
+// by "close enough" and an anchor needs no contig field; the margins at both ends of the coordinate range let the DP fold
+// the strand test into the same comparison (chain.hip).  A position is stored as gpos << 1 | canonical-strand bit.
 constexpr uint32_t CTG_PAD = 8192;
 static_assert(CTG_PAD > (uint32_t)MAX_LIN && CTG_PAD > BP_CHAIN_BAND, "contig padding must exceed the chaining reach");
 __host__ __device__ __forceinline__ uint32_t ctg_of(const uint32_t* goff, uint32_t n_ctg, uint32_t gpos) {   // largest c with goff[c] <= gpos

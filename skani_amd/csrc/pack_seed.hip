@@ -68,7 +68,7 @@ void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const 
         if (len > 0xFFFFFFF0ull) throw Error("contig longer than 2^32 bases");
         ContigDesc& cd = gs->contigs[i];
         cd.len = (uint32_t)len; cd.base = unit_off[i] * 32; cd.has_n = 0;
-        if (cd.index == 0) gat = 0;
+        if (cd.index == 0) gat = CTG_PAD;
         cd.goff = (uint32_t)gat; cd.pad = 0; gat += len + CTG_PAD;                  // genomes beyond 2^31 are refused when a sketch set is made (finalize_metadata)
         src_off[i] = contig_off[i];
         uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;

@@ -233,9 +233,9 @@ void finalize_metadata(skh_sketch_set* ss) {
     const uint32_t ng = ss->n_genomes;
     ss->goff.assign(ss->ctg_len.size() + ng, 0);
     for (uint32_t g = 0; g < ng; g++) {
-        uint64_t at = 0; const uint64_t base = ss->ctg_off[g] + g;
-        for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff[base + (c - ss->ctg_off[g])] = (uint32_t)at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; if (at >= (1ull << 31)) break; }
-        if (at >= (1ull << 31)) throw Error("a genome spans >= 2^31 padded bases (total length + 8192 per contig); it does not fit the 32-bit position records");
+        uint64_t at = CTG_PAD; const uint64_t base = ss->ctg_off[g] + g, lim = (1ull << 31) - CTG_PAD;
+        for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff[base + (c - ss->ctg_off[g])] = (uint32_t)at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; if (at >= lim) break; }
+        if (at >= lim) throw Error("a genome spans >= 2^31 padded bases (total length + 8192 per contig); it does not fit the 32-bit position records");
         ss->goff[base + (ss->ctg_off[g + 1] - ss->ctg_off[g])] = (uint32_t)at;
     }
     ss->mean_ctg.assign(ng, 0.); ss->q10.assign(ng, 0.f); ss->q50.assign(ng, 0.f); ss->q90.assign(ng, 0.f);
