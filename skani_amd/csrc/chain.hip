@@ -716,8 +716,7 @@ constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more
 
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
                                                           const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_g,
-                                                          uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint32_t* pair_tqb, uint32_t* pair_acl,
-                                                          uint32_t* pair_nchains) {
+                                                          uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint4* chunk_sums) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t l = lane_id();
     const bool valid = slot < n_slots;
@@ -746,11 +745,12 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
             n_int++;
         }
         const bool sensitive = c < 200;                                             // chain.rs:184-190
-        if (sensitive) atomicAdd(&pair_tqb[p], sum_len);
-        atomicAdd(&pair_acl[p], sum_len); atomicAdd(&pair_nchains[p], n_int);
         active = rq1 - rq0 >= MIN_LENGTH_COVER;                                     // chain.rs:257
-        if (active && !sensitive) atomicAdd(&pair_tqb[p], rq1 - rq0 + 2 * c + k);   // chain.rs:261-264
-    }
+        // the chunk's share of the pair totals (summed per pair by finalize_kernel; per-pair atomics from 245 chunks cost more
+        // than the rest of this kernel): x = covered-length sum, y = accepted intervals, z = total_query_bases share
+        // (chain.rs:184-190: sensitive -> interval lengths, else the chunk's covered range, chain.rs:261-264)
+        chunk_sums[slot] = make_uint4(sum_len, n_int, sensitive ? sum_len : (active ? rq1 - rq0 + 2 * c + k : 0u), 0u);
+    } else if (valid) chunk_sums[slot] = make_uint4(0, 0, 0, 0);
     uint32_t in_u = 0, in_range = 0;
     unsigned long long todo = __ballot(active);
     // the first 256 positions of a chunk are fetched as four independent loads, and the next chunk's are in flight while the
@@ -828,7 +828,6 @@ struct FinalizeArgs {
     const GbdtModel::Node* nodes; const uint32_t* tree_off; uint32_t n_trees; float shrinkage, bias;
 };
 struct FinalizeScratch { double *u_est, *s_est; uint32_t *u_w, *s_w; uint64_t* cum; };
-constexpr uint32_t FIN_LDS = 512;
 
 // fastrand 1.9.0 WyRand stream seeded with 7 (chain.rs:62); draw number d (0-based) is a pure function of d
 __device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) {
@@ -837,10 +836,14 @@ __device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) {
     return (s * b) ^ __umul64hi(s, b);
 }
 
-// chain.rs:414-555 + regression.rs:30-64.  One wave per pair.
+// chain.rs:414-555 + regression.rs:30-64.  One wave per pair.  The per-pair work arrays (one entry per chunk) live in LDS;
+// the kernel is instantiated for FIN_LDS = 320 (genomes up to ~6 Mbp: 11 KB per wave, 3 waves per SIMD) and 1024 entries and
+// a pair runs in the smaller one that holds it; beyond 1024 chunks the arrays spill to global scratch.  The kernel is a chain
+// of dependent LDS reads, shuffles and f64 arithmetic -- other waves are what fills its issue slots.
+template <uint32_t FIN_LDS, uint32_t FIN_MIN>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
-                                                       const double* chunk_est, const uint32_t* chunk_w, const uint32_t* pair_tqb, const uint32_t* pair_acl,
-                                                       const uint32_t* pair_nchains, FinalizeScratch fs, uint32_t* n_est_out, skh_ani_result* out) {
+                                                       const double* chunk_est, const uint32_t* chunk_w, const uint4* chunk_sums, FinalizeScratch fs,
+                                                       uint32_t* n_est_out, skh_ani_result* out) {
     __shared__ double lds_boot[4][128];
     __shared__ double lds_u[4][FIN_LDS], lds_s[4][FIN_LDS];
     __shared__ uint64_t lds_cum[4][FIN_LDS];
@@ -851,15 +854,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     const uint32_t l = lane_id();
     const PairDesc pd = pairs[p];
     const uint32_t C0 = pc0[p], nc = n_chunks[p];
-    // per-pair work arrays: LDS when the pair has at most FIN_LDS chunks (~10 Mbp genomes), global scratch otherwise
+    if (nc < FIN_MIN || (FIN_LDS < 1024 && nc > FIN_LDS)) return;                   // the other instantiation's pair
     const bool in_lds = nc <= FIN_LDS;
     double* U = in_lds ? lds_u[wv] : fs.u_est + C0; uint32_t* UW = in_lds ? lds_uw[wv] : fs.u_w + C0;
     double* S = in_lds ? lds_s[wv] : fs.s_est + C0; uint32_t* SW = in_lds ? lds_sw[wv] : fs.s_w + C0;
     uint64_t* CUM = in_lds ? lds_cum[wv] : fs.cum + C0;
     // 1. valid (estimate, weight) pairs in chunk order
-    uint32_t n = 0;
+    uint32_t n = 0, acl = 0, nchains = 0, tqb = 0;
     for (uint32_t b = 0; b < nc; b += 64) {
         const uint32_t s = C0 + b + l;
+        if (b + l < nc) { const uint4 cs = chunk_sums[s]; acl += cs.x; nchains += cs.y; tqb += cs.z; }
         const bool v = b + l < nc && chunk_w[s] != NONE;
         const unsigned long long m = __ballot(v);
         if (v) { const uint32_t o = n + (uint32_t)__popcll(m & ((1ull << l) - 1ull)); U[o] = chunk_est[s]; UW[o] = chunk_w[s]; }
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     if (l == 0) n_est_out[p] = n;
     skh_ani_result res;
     memset(&res, 0, sizeof res);
-    const uint32_t nchains = pair_nchains[p];
+    acl = wave_sum(acl); nchains = wave_sum(nchains); tqb = wave_sum(tqb);
     if (n == 0 || nchains == 0) {                                                   // chain.rs:416-420: AniEstResult::default() with ani = NaN
         res.ani = __builtin_nanf("");
         if (l == 0) out[p] = res;
@@ -986,7 +990,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
         ci_lo = lds_boot[wv][100]; ci_hi = lds_boot[wv][101];
     }
     // 7. aligned fractions, cut-offs, output record (chain.rs:477-554) -- computed redundantly by every lane (wave-uniform)
-    const uint32_t tqb = pair_tqb[p];
     double cov_q = (double)tqb / (double)pd.query_total_len; if (!(cov_q < 1.)) cov_q = 1.;
     double cov_r = (double)tqb / (double)pd.ref_total_len; if (!(cov_r < 1.)) cov_r = 1.;   // total_ref_range has the same numerator (chain.rs:245-246)
     const double cutoff = fa.min_af < 0. ? 0.15 : fa.min_af;                        // chain.rs:100-107
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     res.ci_lower = (float)ci_lo; res.ci_upper = (float)ci_hi; res.std = (float)sd;
     res.q90_q = pd.q90_q; res.q90_r = pd.q90_r; res.q50_q = pd.q50_q; res.q50_r = pd.q50_r; res.q10_q = pd.q10_q; res.q10_r = pd.q10_r;
     res.num_contigs_q = pd.nctg_q; res.num_contigs_r = pd.nctg_r;
-    res.avg_chain_int_len = pair_acl[p] / nchains;                                  // chain.rs:421
+    res.avg_chain_int_len = acl / nchains;                                          // chain.rs:421
     res.total_bases_covered = tqb;
     // 8. learned ANI (regression.rs:30-64; gbdt 0.1.1 LAD predict = bias + sum shrinkage * leaf, f32, tree order).
     //    The 195 tree walks are independent: lanes walk trees lane, lane+64, ...; the f32 sum stays sequential in tree order.
@@ -1279,11 +1282,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         check_launch("greedy");
         tr.mark("greedy");
         double* chunk_est = ctx->arena.get<double>(NC + 1); uint32_t* chunk_w = ctx->arena.get<uint32_t>(NC + 1);
-        uint32_t* pair_tqb = ctx->arena.get<uint32_t>(np); uint32_t* pair_acl = ctx->arena.get<uint32_t>(np); uint32_t* pair_nch = ctx->arena.get<uint32_t>(np);
-        dzero(pair_tqb, np * 4, ctx->stream); dzero(pair_acl, np * 4, ctx->stream); dzero(pair_nch, np * 4, ctx->stream);
+        uint4* chunk_sums = ctx->arena.get<uint4>(NC + 1);
         if (NC) {
             SKH_LAUNCH(chunk_stats_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
-                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_g, c, k, chunk_est, chunk_w, pair_tqb, pair_acl, pair_nch);
+                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_g, c, k, chunk_est, chunk_w, chunk_sums);
             check_launch("chunk_stats");
         }
         tr.mark("chunk_stats");
@@ -1294,9 +1296,11 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         FinalizeScratch fs{ctx->arena.get<double>(NC + 1), ctx->arena.get<double>(NC + 1), ctx->arena.get<uint32_t>(NC + 1), ctx->arena.get<uint32_t>(NC + 1),
                            ctx->arena.get<uint64_t>(NC + 1)};
         uint32_t* n_est = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(finalize_kernel, (np + 3) / 4, 256, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, (const double*)chunk_est,
-                   (const uint32_t*)chunk_w, (const uint32_t*)pair_tqb, (const uint32_t*)pair_acl, (const uint32_t*)pair_nch, fs, n_est, d_out + p0);
-        check_launch("finalize");
+#define SKH_FIN(CAP, MIN) SKH_LAUNCH((finalize_kernel<CAP, MIN>), (np + 3) / 4, 256, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
+                   (const double*)chunk_est, (const uint32_t*)chunk_w, (const uint4*)chunk_sums, fs, n_est, d_out + p0); \
+        check_launch("finalize")
+        SKH_FIN(320, 0); SKH_FIN(1024, 321);
+#undef SKH_FIN
         tr.mark("finalize");
         if (stats) {   // parity/debug path: pull the stage sizes (and the anchors, for the checksum) back to the host
             std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
