@@ -212,6 +212,48 @@ def case_screen_rules(ctx):
             assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri")
 
 
+def fragmented(root, seed, rate, lo=700, hi=9000, drop=0.1):
+    """root cut into many contigs of lo..hi bases, a tenth dropped, the rest shuffled, every other one reverse-complemented."""
+    rng = np.random.default_rng(seed)
+    s = mutate(root, rate, seed + 1)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ctgs, at = [], 0
+    while at < len(s):
+        n = int(rng.integers(lo, hi)); piece = s[at:at + n]; at += n
+        if rng.random() < drop:
+            continue
+        if rng.random() < 0.5:
+            piece = piece.translate(comp)[::-1]
+        ctgs.append(piece)
+    order = rng.permutation(len(ctgs))
+    return [("ctg%d" % i, ctgs[j]) for i, j in enumerate(order)]
+
+
+def case_fragmented_genomes(ctx):
+    """Draft-assembly shaped inputs: dozens of short contigs in arbitrary order and orientation, so that contig changes
+    (chain.rs:786-789), per-contig seed lists (chain.rs:755-780) and both strands occur every few kb on both sides of a pair.
+    Exercises the padded-coordinate <-> contig mapping of every stage against the oracle, stage by stage."""
+    root = random_genome(260000, 5)
+    genomes = [fragmented(root, 10, 0.0), fragmented(root, 20, 0.02), fragmented(root, 30, 0.05, lo=500, hi=3000),
+               [("whole", mutate(root, 0.01, 77))], fragmented(random_genome(150000, 6), 40, 0.0)]
+    names = ["frag%d.fa" % i for i in range(len(genomes))]
+    for mode, c in ((1, 125), (0, 70), (1, 30)):
+        ss = ctx.sketch_records(genomes, sk.SketchParams(c=c, seeding_mode=mode), names)
+        osk = [ora.sketch_records(g, c, 15, 1000, names[i], mode) for i, g in enumerate(genomes)]
+        for g in range(len(genomes)):
+            assert_sketch_equal(ss, g, osk[g])
+        pr = [0, 0, 0, 1, 1, 2, 3, 0, 2]; pq = [1, 2, 3, 2, 3, 3, 0, 4, 2]
+        mp = sk.MapParams(compute_ci=True)
+        res, st = ctx.chain_pairs(ss, None, pr, pq, mp, stats=True)
+        for x, (i, j) in enumerate(zip(pr, pq)):
+            r, s = ora.chain_seeds(osk[i], osk[j], stats=True)
+            assert_result_close(res[x], r, (c, i, j))
+            assert (int(st[x]["n_anchors"]), int(st[x]["n_qpos"]), int(st[x]["anchor_checksum"]), int(st[x]["n_chunks"]), int(st[x]["n_intervals"]),
+                    int(st[x]["n_accepted"]), int(st[x]["n_estimates"])) == \
+                (s.n_anchors, s.n_qpos, s.anchor_checksum, s.n_chunks, s.n_intervals, s.n_accepted, s.n_estimates), (c, i, j)
+        assert 0.96 < res[0]["ani"] < 0.995 and res[0]["af_ref"] > 0.7 and np.isnan(res[7]["ani"]) and res[8]["ani"] >= 1.0
+
+
 def case_degenerate_pairs(ctx):
     """empty sketches, unrelated genomes (no anchors -> NaN), both-min-af and min-af cut-offs (-1)."""
     g = [[("a", random_genome(50000, 1))], [("b", random_genome(50000, 2))], [("n", b"N" * 3000)],
