@@ -6,10 +6,11 @@ import os
 from . import _binding
 from .api import (SEED_AVX2, SEED_SCALAR, Context, GenomeSet, MapParams, SketchParams, SketchSet, SkaniHipError,
                   fastx_to_multiple_sketch_rewrite, fastx_to_sketches, use_learned_ani)
-from .search import SketchDB, build_db, search
+from .formats import load_database, load_sketch_files, save_database
+from .search import SketchDB, build_db, open_db, search
 
-__all__ = ["Context", "GenomeSet", "SketchSet", "SketchParams", "MapParams", "SkaniHipError", "fastx_to_sketches",
-           "fastx_to_multiple_sketch_rewrite", "SketchDB", "build_db", "search",
+__all__ = ["load_database", "load_sketch_files", "save_database", "Context", "GenomeSet", "SketchSet", "SketchParams", "MapParams", "SkaniHipError", "fastx_to_sketches",
+           "fastx_to_multiple_sketch_rewrite", "SketchDB", "open_db", "build_db", "search",
            "use_learned_ani", "SEED_SCALAR", "SEED_AVX2", "library_path"]
 
 

@@ -28,6 +28,14 @@ class SketchDB:
             s.close()
 
 
+def open_db(ctx, folder, seeding_mode=1):
+    """A folder written by `skani sketch` / `skani-hip sketch` / save_database, made resident as one shard (search.rs:31-100)."""
+    from .formats import load_database
+    ss, infos = load_database(ctx, folder, seeding_mode)
+    db = SketchDB([ss], [i["file_name"] for i in infos]); db.infos = infos
+    return db
+
+
 def build_db(ctx, genomes, params, names=None, shard_genomes=None):
     """genomes: list of lists of (name, seq) records.  shard_genomes bounds the genomes per shard (None = by size)."""
     if shard_genomes is None:

@@ -365,3 +365,37 @@ def case_edge_cases_and_errors(ctx):
             c2.close()
     r = ctx.chain_pairs(one, None, [0], [0], sk.MapParams())
     assert r["ani"][0] >= 1.0
+
+
+def case_database_formats(ctx, tmp):
+    """skani database folders through the Python binding: the reference's bundled (pre-0.3) o157 sketch file loads into HBM and
+    reproduces the pinned rows; a resident set saved as a database (both flavours) comes back identical, array by array."""
+    import os
+    from tests.helpers import GOLDEN
+    o157, info = sk.load_sketch_files(ctx, [os.path.join(GOLDEN, "e.coli-o157.fasta.sketch")])
+    assert info[0]["file_name"] == "test_files/e.coli-o157.fasta" and len(info[0]["contigs"]) == 2 and o157.sizes(0)["n_pos"] == 44127
+    names = ["test_files/e.coli-W.fasta", "test_files/o157_plasmid.fasta"]
+    refs = ctx.sketch_records([golden_records("e.coli-W.fasta.gz"), golden_records("o157_plasmid.fasta")], sk.SketchParams(), names)
+    res = ctx.chain_pairs(refs, o157, [1, 0], [0, 0], sk.MapParams(median=True))
+    got = [("%.2f" % (r["ani"] * 100), "%.2f" % (r["af_ref"] * 100), "%.2f" % (r["af_query"] * 100)) for r in res]
+    assert got == [("100.00", "99.84", "1.68"), ("98.39", "85.46", "75.97")], got
+    w_name = golden_records("e.coli-W.fasta.gz")[0][0]
+    infos = [dict(file_name=names[0], contigs=[w_name.decode() if isinstance(w_name, bytes) else w_name], contig_order=0),
+             dict(file_name=names[1], contigs=["plasmid"], contig_order=0)]
+    for sep in (False, True):
+        d = os.path.join(tmp, "db_sep" if sep else "db")
+        sk.save_database(refs, d, infos, separate_files=sep)
+        back, binfo = sk.load_database(ctx, d)
+        assert [i["file_name"] for i in binfo] == names and binfo[1]["contigs"] == ["plasmid"] and (back.params.c, back.params.k, back.params.marker_c) == (125, 15, 1000)
+        for g in range(2):
+            a, b = refs.export(g), back.export(g)
+            for key in ("seed", "pos", "ctgcanon", "markers", "contig_lengths"):
+                assert np.array_equal(a[key], b[key]), (sep, g, key)
+            assert a["total_len"] == b["total_len"]
+        res2 = ctx.chain_pairs(back, o157, [1, 0], [0, 0], sk.MapParams(median=True))
+        assert np.array_equal(res2["ani"], res["ani"]) and np.array_equal(res2["af_ref"], res["af_ref"])
+    import pytest
+    with pytest.raises(FileExistsError):
+        sk.save_database(refs, d)
+    with pytest.raises(sk.SkaniHipError):
+        sk.load_database(ctx, os.path.join(tmp, "nothing_here"))

@@ -25,6 +25,7 @@ def test_emu_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx, params=((1
 def test_emu_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_emu_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
+def test_emu_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
 def test_emu_search_resident_db(ctx): pc.case_search_resident_db(ctx)
 def test_emu_large_pair(ctx): pc.case_large_pair(ctx)
 def test_emu_edge_cases(ctx): pc.case_edge_cases_and_errors(ctx)

@@ -35,6 +35,7 @@ def test_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx)
 def test_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
+def test_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
 
 
 def test_w_derivatives_triangle(ctx):
