@@ -2,12 +2,13 @@
 
 The path shards: sketching is per genome, chaining per pair.  Genomes are block-distributed; every rank
 sketches its own block.  Exchange steps:
-  1. all-gather of the MARKER sets + per-genome metadata only (~40 KB per 5 Mbp genome) -> every rank runs the screen
-     over the full set and obtains the same global candidate pair list;
+  1. all-gather of the MARKER sets + per-genome metadata only (~40 KB per 5 Mbp genome); every rank then screens ITS OWN
+     rows against all genomes (an n_local x N count matrix: the per-rank screening cost stays flat as ranks are added);
   2. pair (i, j), i < j, is owned by the rank that owns genome i; a rank therefore needs the full sketch of a remote
-     genome j only when a candidate pair crosses blocks.  Exactly those sketches travel point-to-point (all-to-all of
-     variable-size buffers).  For clade-structured collections almost nothing moves; in the worst case (every pair
-     crosses) it degenerates to an all-gather of the raw sketches.
+     genome j only when a candidate pair crosses blocks.  The ranks tell each other which genomes they need (one small
+     all-to-all) and exactly those sketches travel point-to-point (all-to-all of variable-size buffers).  For
+     clade-structured collections almost nothing moves; in the worst case (every pair crosses) it degenerates to an
+     all-gather of the raw sketches.
 No collective inside the pair pipeline; the (small) results are gathered on rank 0."""
 import pickle
 
@@ -84,17 +85,18 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         device = torch.device("cpu")
     n_local = len(ss_local)
     base = rank * n_local
-    # 1. markers + metadata of every genome, everywhere; every rank screens the full set
+    # 1. markers + metadata of every genome, everywhere; this rank screens its rows (local genomes) against all columns.
+    #    screen_refs is evaluated with the row sketch as the query (triangle.rs:76), which is what the two-set call does.
     markers_only, _keep = _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device)
-    gi, gj = ctx.screen(markers_only, None, identity, 0, rescue_small)          # identical on every rank
+    lq, gr = ctx.screen(markers_only, ss_local, identity, 0, rescue_small)      # (local row, global column)
     markers_only.close()
-    owner_i = gi // n_local; owner_j = gj // n_local
-    # 2. sketches of remote partners j of my rows i, fetched point-to-point
-    send_lists = []
-    for r in range(world):
-        need = np.unique(gj[(owner_i == r) & (owner_j == rank) & (r != rank)]) if r != rank else np.zeros(0, np.uint32)
-        send_lists.append(need)                                                    # my genomes that rank r needs
-    payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in send_lists]
+    upper = gr.astype(np.int64) > lq.astype(np.int64) + base                    # triangle.rs:90: j > i
+    gi, gj = (lq[upper].astype(np.int64) + base).astype(np.uint32), gr[upper]
+    owner_j = gj // n_local
+    # 2. sketches of remote partners j of my rows i: requests out, sketches back
+    requests = [pickle.dumps(np.unique(gj[owner_j == r]) if r != rank else np.zeros(0, np.uint32), protocol=4) for r in range(world)]
+    wanted = [pickle.loads(b) for b in _all_to_all_bytes(dist, torch, device, requests)]      # wanted[r]: my genomes that rank r needs
+    payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in wanted]
     received = _all_to_all_bytes(dist, torch, device, payloads)
     remote = {}
     for blob in received:
@@ -102,11 +104,10 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
             remote[g] = rec
     rem_ids = sorted(remote)
     rem_index = {g: k for k, g in enumerate(rem_ids)}
-    my = owner_i == rank
-    li, lj = gi[my], gj[my]
+    li, lj = gi, gj
     local_pair = (lj // n_local) == rank
     res_parts = []
-    n_chained = int(my.sum())
+    n_chained = int(len(gi))
     if local_pair.any():
         r = ctx.chain_pairs(ss_local, None, li[local_pair] - base, lj[local_pair] - base, map_params)
         res_parts.append((li[local_pair], lj[local_pair], r))
