@@ -152,6 +152,12 @@ int skh_chain_pairs(skh_ctx*, const skh_sketch_set* refs, const skh_sketch_set* 
                     const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params*, skh_ani_result* out,
                     skh_chain_stats* stats);
 
+/* The triangle's screen (triangle.rs:55-90) for rows i in [row0, row0 + n_rows) only: pairs (i, j), j > i, of one set that
+ * pass screen_refs with sketch i as the query.  This is one GPU's share when the rows of a large collection are
+ * block-distributed over several GPUs that all hold the marker sets. */
+int skh_screen_rows(skh_ctx*, const skh_sketch_set* set, uint32_t row0, uint32_t n_rows, double identity, int rescue_small,
+                    uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs);
+
 /* ------------------------------------------------------------------ triangle body (triangle.rs:55-105):
  * screen rows, chain pairs j>i, keep ani > 0.1.  part/n_parts shard the screened pair list round-robin
  * across GPUs (part r takes pairs r, r+n_parts, ...); results come back sorted by (i,j). */

@@ -185,6 +185,17 @@ class Context:
             self.L.skh_free(a); self.L.skh_free(b)
         return first, second
 
+    def screen_rows(self, sketches, row0, n_rows, identity=0.0, rescue_small=True):
+        """The triangle's screen for rows [row0, row0 + n_rows): pairs (i, j), j > i (one GPU's share of a distributed triangle)."""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.check(self.L.skh_screen_rows(self.h, sketches.h, row0, n_rows, identity, int(rescue_small), C.byref(a), C.byref(b), C.byref(n)))
+        try:
+            first = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+            second = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+        finally:
+            self.L.skh_free(a); self.L.skh_free(b)
+        return first, second
+
     def chain_pairs(self, refs, queries, pair_ref, pair_query, map_params, stats=False):
         """chain_seeds(refs[pair_ref[p]], queries[pair_query[p]], map_params_from_sketch(ref)) for every p (chain.rs:144)."""
         pr = np.ascontiguousarray(pair_ref, np.uint32); pq = np.ascontiguousarray(pair_query, np.uint32)

@@ -315,6 +315,23 @@ int skh_screen(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* q
     return rc;
 }
 
+int skh_screen_rows(skh_ctx* ctx, const skh_sketch_set* set, uint32_t row0, uint32_t n_rows, double identity, int rescue_small, uint32_t** pair_i,
+                    uint32_t** pair_j, uint64_t* n_pairs) {
+    if (!ctx || !set || !pair_i || !pair_j || !n_pairs) return SKH_ERR_INVALID;
+    *pair_i = *pair_j = nullptr; *n_pairs = 0;
+    int rc = guarded(ctx, [&] {
+        if (row0 > set->n_genomes || n_rows > set->n_genomes - row0) throw std::invalid_argument("row range outside the sketch set");
+        std::vector<uint32_t> a, b;
+        { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, set, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b, row0, row0 + n_rows); }
+        uint32_t* pa = (uint32_t*)malloc((a.size() + 1) * 4); uint32_t* pb = (uint32_t*)malloc((b.size() + 1) * 4);
+        if (!pa || !pb) { free(pa); free(pb); throw std::bad_alloc(); }
+        memcpy(pa, a.data(), a.size() * 4); memcpy(pb, b.data(), b.size() * 4);
+        *pair_i = pa; *pair_j = pb; *n_pairs = a.size();
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
 int skh_chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref, const uint32_t* pair_query,
                     uint64_t n_pairs, const skh_map_params* mp, skh_ani_result* out, skh_chain_stats* stats) {
     if (!ctx || !refs || !mp || (n_pairs && (!pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;

@@ -155,7 +155,8 @@ void finalize_metadata(skh_sketch_set* ss);                                     
 
 // ---- screen.hip
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
-                  int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second);
+                  int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
+                  uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)
 
 // ---- chain.hip
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref,

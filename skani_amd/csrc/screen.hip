@@ -121,7 +121,7 @@ static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __p
 }
 
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
-                  std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
+                  std::vector<uint32_t>& first, std::vector<uint32_t>& second, uint32_t row_begin, uint32_t row_end) {
     first.clear(); second.clear();
     if (identity == 0.) identity = 0.80;                                          // triangle.rs:34-42, SEARCH_ANI_CUTOFF_DEFAULT
     const bool tri = queries == nullptr;
@@ -141,11 +141,12 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     ScreenRule sr{powi21(identity), rule, rescue_small, tri ? 1 : 0};
     // row blocking keeps the dense count matrix within a fixed budget
     const uint64_t budget_cells = ctx->tune.screen_cells;   // u32 counters per row block (default 8 GiB)
-    uint32_t rows_per = (uint32_t)std::min<uint64_t>(nrows, std::max<uint64_t>(1, budget_cells / ncols));
+    uint32_t rows_per = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1, std::min(row_end, nrows) - std::min(row_begin, nrows)), std::max<uint64_t>(1, budget_cells / ncols));
     uint32_t* cnt = ctx->arena.get<uint32_t>((uint64_t)rows_per * ncols);
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
-    for (uint32_t row0 = 0; row0 < nrows; row0 += rows_per) {
-        const uint32_t rows = std::min(rows_per, nrows - row0);
+    row_end = std::min(row_end, nrows);
+    for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
+        const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, (uint64_t)rows * ncols * 4, ctx->stream);
         if (M) {
             if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((M + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)keys, M, row0, rows, ncols, cnt);

@@ -85,13 +85,11 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         device = torch.device("cpu")
     n_local = len(ss_local)
     base = rank * n_local
-    # 1. markers + metadata of every genome, everywhere; this rank screens its rows (local genomes) against all columns.
-    #    screen_refs is evaluated with the row sketch as the query (triangle.rs:76), which is what the two-set call does.
+    # 1. markers + metadata of every genome, everywhere; this rank screens its rows (local genomes i) against all later
+    #    genomes j > i: an n_local x N block of the triangle's screen (triangle.rs:55-90)
     markers_only, _keep = _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device)
-    lq, gr = ctx.screen(markers_only, ss_local, identity, 0, rescue_small)      # (local row, global column)
+    gi, gj = ctx.screen_rows(markers_only, base, n_local, identity, rescue_small)
     markers_only.close()
-    upper = gr.astype(np.int64) > lq.astype(np.int64) + base                    # triangle.rs:90: j > i
-    gi, gj = (lq[upper].astype(np.int64) + base).astype(np.uint32), gr[upper]
     owner_j = gj // n_local
     # 2. sketches of remote partners j of my rows i: requests out, sketches back
     requests = [pickle.dumps(np.unique(gj[owner_j == r]) if r != rank else np.zeros(0, np.uint32), protocol=4) for r in range(world)]

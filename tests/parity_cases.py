@@ -177,6 +177,9 @@ def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200)), 
         a, b = ctx.screen(ss, None, 0.0, 0, True)
         exp = [(i, int(j)) for i in range(len(osk) - 1) for j in ora.screen_refs(osk, osk[i], 0.8, 0, True) if j > i]
         assert list(zip(a.tolist(), b.tolist())) == sorted(exp)
+        for r0, nr in ((0, len(osk)), (1, 3), (len(osk) - 1, 1), (2, 0)):             # row blocks of the same screen
+            a2, b2 = ctx.screen_rows(ss, r0, nr, 0.0, True)
+            assert list(zip(a2.tolist(), b2.tolist())) == [e for e in sorted(exp) if r0 <= e[0] < r0 + nr]
         learned = sk.use_learned_ani(c)
         model = ora.Model(MODEL_C125 if abs(c - 125) < abs(c - 200) else MODEL_C200) if learned else None
         for kw in (dict(), dict(robust=True), dict(median=True)):
