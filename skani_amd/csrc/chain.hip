@@ -24,11 +24,11 @@ namespace skh {
 struct SetView {
     const uint32_t *p_seed, *p_g; const uint16_t* p_cnt;       // position order; p_g = padded coordinate << 1 | canonical
     const uint32_t* s_g;                                       // hash order
-    const uint64_t* ent; const uint32_t* dir;
+    const uint64_t* ent; const uint32_t* dir; const uint32_t* bmap;
     const uint32_t* goff;                                      // padded contig starts (common.h CTG_PAD)
 };
 static SetView view_of(const skh_sketch_set* s) {
-    return SetView{s->p_seed.p, s->p_g.p, s->p_cnt.p, s->s_g.p, s->ent.p, s->dir.p, s->d_goff.p};
+    return SetView{s->p_seed.p, s->p_g.p, s->p_cnt.p, s->s_g.p, s->ent.p, s->dir.p, s->bmap.p, s->d_goff.p};
 }
 
 struct PairDesc {
@@ -46,6 +46,7 @@ struct PairDesc {
     uint32_t nctg_q, nctg_r;
     uint64_t a_goff0, b_goff0;   // first entry of A's / B's padded contig-start table in its set
     uint32_t a_nctg, b_nctg;
+    uint64_t b_bmap0;            // B: first word of its bucket-occupancy bitmap
 };
 
 constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
@@ -63,8 +64,10 @@ struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };
 // table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
 __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                          uint32_t band, uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq,
-                                                         uint32_t* pinfo_start, uint16_t* pinfo_cnt) {
+                                                         uint32_t* pinfo_start, uint16_t* pinfo_cnt, uint32_t lds_words) {
     __shared__ uint32_t lds[16];
+    SKH_DYN_SMEM(smem);
+    uint32_t* bm = (uint32_t*)smem;
     const uint32_t tile = slot_tile[blockIdx.x];
     if (tile == NONE) return;
     const uint32_t p = tile_pair[tile];
@@ -73,6 +76,16 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     const uint64_t* ent = B.ent + pd.b_ent0; const uint32_t* dir = B.dir + pd.b_dir0;
     constexpr int R = JOIN_TILE / 256;
+    // B's bucket-occupancy bitmap (1 bit per directory bucket, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of the
+    // buckets are empty, and a probe of an empty bucket then costs no memory request at all.  The kernel runs at the L2's
+    // request rate (one 64-byte slot per random 8-byte read), so requests are what to save.
+    const uint32_t bm_words = ((pd.b_nbk + 31) / 32 + 3) / 4 * 4;
+    const bool use_bm = bm_words <= lds_words;
+    if (use_bm) {
+        const uint4* src = (const uint4*)(B.bmap + pd.b_bmap0);
+        for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += 256) ((uint4*)bm)[w4] = src[w4];
+        __syncthreads();
+    }
     // the four positions of this thread are probed together: their loads are independent, so they overlap
     uint32_t h[R], d0[R], d1[R]; bool live[R]; unsigned long long e[R];
 #pragma unroll
@@ -87,7 +100,10 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
 #pragma unroll
     for (int r = 0; r < R; r++) {
         d0[r] = 0; d1[r] = 0;
-        if (live[r]) { const uint32_t b = seed_bucket(h[r], pd.b_nbk); d0[r] = dir[b]; d1[r] = dir[b + 1]; }
+        if (live[r]) {
+            const uint32_t b = seed_bucket(h[r], pd.b_nbk);
+            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) { d0[r] = dir[b]; d1[r] = dir[b + 1]; }
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) e[r] = d0[r] < d1[r] ? ent[d0[r]] : TAB_EMPTY;
@@ -1142,7 +1158,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
         const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
         pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.b_pos0 = B->pos_off[gb]; pd.b_ent0 = B->dist_off[gb]; pd.b_dir0 = B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb];
+        pd.b_pos0 = B->pos_off[gb]; pd.b_ent0 = B->dist_off[gb]; pd.b_dir0 = B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb]; pd.b_bmap0 = B->bmap_off[gb];
         pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
         pd.tile0 = (uint32_t)n_tiles_all;
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
@@ -1189,8 +1205,11 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         if (snt) {
             uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, pair_key, &n_super_slots);
             d_super_slots = d_slots;
-            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
-                       (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic);
+            uint32_t bm_words = 0;                                                 // LDS for the largest bitmap of the batch, up to 32 KB
+            for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
+            if (bm_words > 8192) bm_words = 8192;
+            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+                       (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic, bm_words);
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");

@@ -91,6 +91,7 @@ struct skh_sketch_set {
     // host metadata (one entry per genome unless noted)
     std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, dir_off;   // n_genomes+1
     std::vector<uint32_t> n_buckets;               // buckets of each genome's seed directory
+    std::vector<uint64_t> bmap_off;                // n_genomes+1: first 32-bit word of each genome's bucket-occupancy bitmap
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
     std::vector<uint32_t> goff;                    // padded-coordinate start of every contig, n_contigs(g)+1 entries per genome at
                                                    // index ctg_off[g] + g (the last one = the genome's padded span)
@@ -108,6 +109,7 @@ struct skh_sketch_set {
     // and a bucket directory over the hash range: entries of bucket b = mulhi(hash, n_buckets) are ent[dir[b] .. dir[b+1])
     skh::DBuf<uint64_t> ent;
     skh::DBuf<uint32_t> dir;                       // n_buckets + 1 per genome, values relative to the genome's first entry
+    skh::DBuf<uint32_t> bmap;                      // 1 bit per bucket: bucket non-empty (10 KB per 5 Mbp genome: staged in LDS by the join)
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_goff;
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_dir_off;

@@ -100,6 +100,25 @@ __global__ __launch_bounds__(256) void dir_build_kernel(const uint64_t* ent, con
     if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
 }
 
+// bucket-occupancy bitmap: bit b of a genome's bitmap = bucket b holds at least one entry.  A wave turns 64 consecutive
+// buckets into two words with one ballot (coalesced reads of the directory); it handles 32 such groups in a row.
+__global__ __launch_bounds__(256) void bmap_build_kernel(const uint32_t* dir, const uint64_t* dir_off, const uint32_t* n_buckets, const uint64_t* bmap_off, uint32_t ng,
+                                                         uint64_t n_words, uint32_t* bmap) {
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t l = lane_id();
+    uint64_t w = wave * 64;                                                          // first word of this wave's 32 word pairs
+    if (w >= n_words) return;
+    uint32_t g = seg_of(bmap_off, ng, w);
+    for (uint32_t it = 0; it < 32 && w < n_words; it++, w += 2) {
+        while (w >= bmap_off[g + 1]) g++;                                            // genomes own whole groups of four words
+        const uint32_t b = (uint32_t)(w - bmap_off[g]) * 32u + l, nbk = n_buckets[g];
+        const uint32_t* dr = dir + dir_off[g];
+        const bool occ = b < nbk && dr[b + 1] > dr[b];
+        const unsigned long long m = __ballot(occ);
+        if (l == 0) { bmap[w] = (uint32_t)m; bmap[w + 1] = (uint32_t)(m >> 32); }
+    }
+}
+
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
 
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc) {
@@ -178,6 +197,16 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         SKH_LAUNCH(dir_build_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->ent.p, (const uint64_t*)ss->d_dist_off.p, ng, D,
                    (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, ss->dir.p);
         check_launch("dir_build");
+    }
+    ss->bmap_off.assign(ng + 1, 0);
+    for (uint32_t g = 0; g < ng; g++) ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)ss->n_buckets[g] + 31) / 32 + 3) / 4 * 4;   // whole 16-byte groups
+    const uint64_t BW = ss->bmap_off[ng];
+    ss->bmap.alloc(BW ? BW : 1);
+    if (BW) {
+        uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
+        SKH_LAUNCH(bmap_build_kernel, (unsigned)((BW / 64 + 1 + 3) / 4), 256, 0, ctx->stream, (const uint32_t*)ss->dir.p, (const uint64_t*)ss->d_dir_off.p,
+                   (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_bo, ng, BW, ss->bmap.p);
+        check_launch("bmap_build");
     }
     tr.mark("build: directory");
     dsync(ctx->stream);
