@@ -86,6 +86,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.chain_anchors = env("SKH_TUNE_CHAIN_ANCHORS", ctx->tune.chain_anchors);
         ctx->tune.chain_super_tiles = (uint32_t)env("SKH_TUNE_CHAIN_SUPER_TILES", ctx->tune.chain_super_tiles);
         ctx->tune.chain_dp_lds_slots = (uint32_t)env("SKH_TUNE_CHAIN_DP_LDS_SLOTS", ctx->tune.chain_dp_lds_slots);
+        ctx->tune.build_hash_bits = (uint32_t)env("SKH_TUNE_BUILD_HASH_BITS", ctx->tune.build_hash_bits);
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
     *out = ctx;

@@ -3,16 +3,17 @@
 // Reference stages and their GPU formulation (all integer until the final pow/mean; bit-exact stage outputs):
 //   get_anchors join      chain.rs:608-737  -> join_count_kernel / join_fill_kernel
 //        The enumerated sketch ("chain-query", A) is walked in POSITION order and every position probes the other
-//        sketch's (B) hash table.  Because A is in (contig,pos) order and B's seed-order arrays are in
-//        (seed,contig,pos) order, anchors are PRODUCED in the reference's sorted order
+//        sketch's (B) seed index.  Because A is in (contig,pos) order and B's hash-order array is in
+//        (hash(seed),contig,pos) order, anchors are PRODUCED in the reference's sorted order
 //        (query_contig, query_pos, ref_contig, ref_pos, reverse) -- the reference's sort (chain.rs:721) disappears,
 //        and query_positions_all (chain.rs:682-700,722-724) is just the filtered position list.
-//   chunking              chain.rs:738-836  -> chunk_kernel: one wave per pair walks the anchors with 64-wide ballots
-//   chain_anchors_ani     chain.rs:838-896  -> chain_dp_kernel: one wave per chunk; lanes own 64 consecutive anchors,
-//        sources are swept in order and broadcast with v_readlane; each lane keeps (score, ptr, root, depth)
-//   get_chain_intervals   chain.rs:939-1007 -> per-component argmax by 64-bit atomicMax(score<<32|index), interval_emit_kernel
-//   get_nonoverlapping    chain.rs:1008-1099-> greedy_kernel: one wave per pair, bitonic sort of interval indices + greedy
+//   chunking              chain.rs:738-836  -> chunk_kernel: one wave per pair streams the anchors' query coordinates
+//   chain_anchors_ani     chain.rs:838-896  -> chain_dp_thread_kernel (band <= 40): one lane per chunk, fused with
+//   get_chain_intervals   chain.rs:939-1007    the interval emission; chain_dp_kernel + interval_emit_kernel (wider bands):
+//                                              one wave per chunk, per-component argmax by 64-bit atomicMax
+//   get_nonoverlapping    chain.rs:1008-1099-> greedy_fast_kernel / greedy_kernel: one wave per pair, bitonic sort + greedy
 //   calculate_ani         chain.rs:173-555  -> chunk_stats_kernel (per chunk) + finalize_kernel (per pair, incl. CI and GBDT)
+// Coordinates are padded genome coordinates (common.h CTG_PAD) throughout; contig ids reappear in the interval records.
 #include <algorithm>
 #include <cmath>
 

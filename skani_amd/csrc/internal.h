@@ -55,6 +55,7 @@ struct skh_tunables {
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
+    uint32_t build_hash_bits = 0;                       // leading hash bits in the seed-order sort key (0 = as many as fit; tests use few)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };
 
@@ -136,6 +137,7 @@ void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t
 
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
 void sort_pairs_u64_u32(skh_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int end_bit);
+void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t* keys, uint32_t* vals, uint64_t n, int end_bit);
 void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit);
 
 // ---- pack_seed.hip

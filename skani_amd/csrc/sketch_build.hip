@@ -22,13 +22,63 @@ __device__ __forceinline__ uint32_t seg_of(const uint64_t* off, uint32_t n_seg, 
     return lo;
 }
 
-__global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n,
-                                                             uint64_t* keys, uint32_t* vals) {
+// Seed order = (genome, mix32(seed), contig, pos).  The device-wide radix sort works on 32-bit keys holding the genome and as
+// many leading hash bits as fit beside it (stable, so equal keys stay in position order): four passes over 8-byte records
+// instead of six over 12-byte ones.  The full 64-bit keys (genome << 32 | hash) are rebuilt afterwards and the rare runs that
+// still mix several hashes under one 32-bit key are put in order in place (fixup_runs_kernel).
+__global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
+                                                             uint32_t* keys32, uint32_t* vals) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t g = seg_of(pos_off, ng, i);
-    keys[i] = ((uint64_t)g << 32) | mix32(p_seed[i]);
+    keys32[i] = hash_bits >= 32 ? mix32(p_seed[i]) : ((g << hash_bits) | (mix32(p_seed[i]) >> (32u - hash_bits)));
     vals[i] = (uint32_t)(i - pos_off[g]);
+}
+__global__ __launch_bounds__(256) void full_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
+                                                        const uint32_t* keys32, const uint32_t* vals, uint64_t* keys) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = hash_bits >= 32 ? 0u : keys32[i] >> hash_bits;
+    keys[i] = ((uint64_t)g << 32) | mix32(p_seed[pos_off[g] + vals[i]]);
+}
+// One thread per run of equal 32-bit keys: orders the run by (full key, position index).  Runs are almost always one seed
+// (already in order); insertion sort costs one pass then.  Long runs that do mix hashes get an in-place heapsort.
+__device__ __forceinline__ bool kv_less(uint64_t ka, uint32_t va, uint64_t kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); }
+__global__ __launch_bounds__(256) void fixup_runs_kernel(const uint32_t* keys32, uint64_t n, uint64_t* keys, uint32_t* vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (i > 0 && keys32[i] == keys32[i - 1])) return;
+    const uint32_t k32 = keys32[i];
+    uint64_t e = i + 1;
+    while (e < n && keys32[e] == k32) e++;
+    const uint64_t len = e - i;
+    if (len == 1) return;
+    uint64_t* K = keys + i; uint32_t* V = vals + i;
+    bool sorted = true;
+    for (uint64_t x = 1; x < len && sorted; x++) sorted = !kv_less(K[x], V[x], K[x - 1], V[x - 1]);
+    if (sorted) return;
+    if (len <= 64) {
+        for (uint64_t x = 1; x < len; x++) {
+            const uint64_t kx = K[x]; const uint32_t vx = V[x]; uint64_t y = x;
+            while (y > 0 && kv_less(kx, vx, K[y - 1], V[y - 1])) { K[y] = K[y - 1]; V[y] = V[y - 1]; y--; }
+            K[y] = kx; V[y] = vx;
+        }
+        return;
+    }
+    auto sift = [&](uint64_t root, uint64_t end) {                                   // max-heap on (key, val)
+        for (;;) {
+            uint64_t c = 2 * root + 1;
+            if (c >= end) break;
+            if (c + 1 < end && kv_less(K[c], V[c], K[c + 1], V[c + 1])) c++;
+            if (!kv_less(K[root], V[root], K[c], V[c])) break;
+            const uint64_t tk = K[root]; K[root] = K[c]; K[c] = tk; const uint32_t tv = V[root]; V[root] = V[c]; V[c] = tv;
+            root = c;
+        }
+    };
+    for (uint64_t st = len / 2; st-- > 0;) sift(st, len);
+    for (uint64_t end = len - 1; end > 0; end--) {
+        const uint64_t tk = K[0]; K[0] = K[end]; K[end] = tk; const uint32_t tv = V[0]; V[0] = V[end]; V[end] = tv;
+        sift(0, end);
+    }
 }
 
 // (pos, contig << 1 | canonical) -> padded coordinate << 1 | canonical
@@ -149,12 +199,21 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     uint16_t* u_cnt = nullptr;                                                        // multiplicity per distinct seed: build-time temporary
     if (P > 0) {
         if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
-        uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P);
+        uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P); uint32_t* keys32 = ctx->arena.get<uint32_t>(P);
         const unsigned nb = (unsigned)((P + 255) / 256);
-        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, keys, vals);
+        const uint32_t gbits = ng > 1 ? (uint32_t)bits_for(ng) : 0u;
+        const uint32_t hash_bits = std::max<uint32_t>(ctx->tune.build_hash_bits ? std::min<uint32_t>(ctx->tune.build_hash_bits, 32u - gbits) : 32u - gbits, 1u);
+        if (gbits >= 32) throw Error("too many genomes in one sketch set");
+        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, keys32, vals);
         check_launch("make_seed_keys");
         tr.mark("build: allocs + keys");
-        sort_pairs_u64_u32(ctx, keys, vals, P, 32 + bits_for(ng));
+        sort_pairs_u32_u32(ctx, keys32, vals, P, (int)(hash_bits >= 32 ? 32 : hash_bits + gbits));
+        SKH_LAUNCH(full_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, (const uint32_t*)keys32, (const uint32_t*)vals, keys);
+        check_launch("full_keys");
+        if (hash_bits < 32) {
+            SKH_LAUNCH(fixup_runs_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)keys32, P, keys, vals);
+            check_launch("fixup_runs");
+        }
         tr.mark("build: sort");
         uint32_t* head = ctx->arena.get<uint32_t>(P); uint32_t* excl = ctx->arena.get<uint32_t>(P + 1);
         SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, P, head);

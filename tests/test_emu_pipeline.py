@@ -39,6 +39,7 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_CHAIN_ANCHORS", "3000")
     monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
     monkeypatch.setenv("SKH_TUNE_CHAIN_DP_LDS_SLOTS", "1")
+    monkeypatch.setenv("SKH_TUNE_BUILD_HASH_BITS", "3")                 # long mixed runs: exercises the run fix-up incl. its heapsort
     c = sk.Context(0, lib=emu_lib())
     try:
         pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
