@@ -1,6 +1,7 @@
 // internal.h -- host-side declarations shared by the translation units of libskani_hip.so.
 #pragma once
 #include <chrono>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -113,6 +114,11 @@ struct skh_sketch_set {
     skh::DBuf<uint32_t> bmap;                      // 1 bit per bucket: bucket non-empty (10 KB per 5 Mbp genome: staged in LDS by the join)
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_goff;
+    // lazily built by the first two-set screen that uses this set as the reference side: its (marker, genome) incidences
+    // sorted by marker (screen.hip).  The set is otherwise immutable; the mutex makes the one-time build safe when several
+    // contexts share the set.
+    mutable skh::DBuf<uint64_t> screen_keys;
+    mutable std::mutex cache_mu;
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_dir_off;
     skh::DBuf<uint32_t> d_n_buckets;
 };

@@ -45,21 +45,22 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
     }
 }
 
-// two sets: a query incidence (m, q) pairs with every ref incidence (m, r); refs sort before queries within a marker
-__global__ __launch_bounds__(256) void screen_count_qr_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
-                                                              uint32_t* cnt) {
+// two sets, separately sorted key arrays: a query incidence (m, q) finds m's run in the refs' keys by binary search.  The refs'
+// sorted keys are cached in the sketch set (a database is screened many times; its index is built once).
+__global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* qkeys, uint64_t nq, const uint64_t* rkeys, uint64_t nr, uint32_t row0, uint32_t rows,
+                                                               uint32_t ncols, uint32_t* cnt) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const uint64_t key = keys[e];
-    if (!((key >> ID_BITS) & 1ull)) return;
-    const uint64_t marker = key >> (ID_BITS + 1);
+    if (e >= nq) return;
+    const uint64_t key = qkeys[e], marker = key >> (ID_BITS + 1);
     const uint32_t q = (uint32_t)(key & ID_MASK);
     if (q < row0 || q >= row0 + rows) return;
+    uint64_t lo = 0, hi = nr;                                                        // first ref key with marker >= m
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((rkeys[mid] >> (ID_BITS + 1)) < marker) lo = mid + 1; else hi = mid; }
     uint32_t* row = cnt + (uint64_t)(q - row0) * ncols;
-    for (uint64_t f = e; f-- > 0;) {
-        const uint64_t k2 = keys[f];
+    for (uint64_t f = lo; f < nr; f++) {
+        const uint64_t k2 = rkeys[f];
         if ((k2 >> (ID_BITS + 1)) != marker) break;
-        if (!((k2 >> ID_BITS) & 1ull)) atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+        atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
     }
 }
 
@@ -131,12 +132,27 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     StageTrace tr(ctx);
     if (ncols > ID_MASK || nrows > ID_MASK) throw Error("more than 2M genomes in one screen call");
     const uint64_t MR = refs->mk_off[ncols], MQ = tri ? 0 : queries->mk_off[nrows], M = MR + MQ;
-    uint64_t* keys = ctx->arena.get<uint64_t>(M ? M : 1);
-    if (MR) { SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)refs->markers.p,
-                         (const uint64_t*)refs->d_mk_off.p, ncols, MR, 0u, keys); check_launch("screen_keys"); }
-    if (MQ) { SKH_LAUNCH(screen_keys_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)queries->markers.p,
-                         (const uint64_t*)queries->d_mk_off.p, nrows, MQ, 1u, keys + MR); check_launch("screen_keys"); }
-    sort_keys_u64(ctx, keys, M, 64);
+    const uint64_t* keys = nullptr;      // triangle: the one sorted incidence list; two sets: the queries' list
+    const uint64_t* rkeys = nullptr;     // two sets: the refs' sorted incidence list (cached in the set)
+    auto make_keys = [&](const skh_sketch_set* set, uint32_t n_genomes, uint64_t n, uint32_t is_query, uint64_t* out) {
+        if (!n) return;
+        SKH_LAUNCH(screen_keys_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, n_genomes, n,
+                   is_query, out);
+        check_launch("screen_keys");
+        sort_keys_u64(ctx, out, n, 64);
+    };
+    if (tri) {
+        uint64_t* k = ctx->arena.get<uint64_t>(MR ? MR : 1);
+        make_keys(refs, ncols, MR, 0u, k); keys = k;
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(refs->cache_mu);
+            if (refs->screen_keys.n != MR || MR == 0) { refs->screen_keys.alloc(MR ? MR : 1); make_keys(refs, ncols, MR, 0u, refs->screen_keys.p); dsync(ctx->stream); }
+        }
+        rkeys = refs->screen_keys.p;
+        uint64_t* k = ctx->arena.get<uint64_t>(MQ ? MQ : 1);
+        make_keys(queries, nrows, MQ, 1u, k); keys = k;
+    }
     tr.mark("screen: keys + sort");
     ScreenRule sr{powi21(identity), rule, rescue_small, tri ? 1 : 0};
     // row blocking keeps the dense count matrix within a fixed budget
@@ -149,8 +165,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, (uint64_t)rows * ncols * 4, ctx->stream);
         if (M) {
-            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((M + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)keys, M, row0, rows, ncols, cnt);
-            else SKH_LAUNCH(screen_count_qr_kernel, (unsigned)((M + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)keys, M, row0, rows, ncols, cnt);
+            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt);
+            else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
         }
         SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,

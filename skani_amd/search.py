@@ -23,7 +23,30 @@ class SketchDB:
     def __len__(self):
         return int(self.offsets[-1])
 
+    def marker_index(self, ctx):
+        """Markers-only sketch set over ALL genomes of the database (global genome order), screened with one call; the library
+        caches its sorted (marker, genome) incidence list inside the set, so the index is built once per database
+        (markers.bin's role in search.rs:37-60)."""
+        if getattr(self, "_marker_index", None) is None:
+            if len(self.shards) == 1:
+                self._marker_index = self.shards[0]
+            else:
+                metas = [s.export_meta() for s in self.shards]
+                mks = []
+                for s in self.shards:
+                    _, M, _ = s.totals(); a = np.zeros(M, np.uint64); s.export_arrays(markers=a); mks.append(a)
+                n = len(self)
+                cat = lambda key: np.concatenate([[0]] + [m[key][1:] + off for m, off in zip(metas, np.cumsum([0] + [int(m[key][-1]) for m in metas[:-1]]))]).astype(np.uint64)
+                meta = dict(pos_off=np.zeros(n + 1, np.uint64), marker_off=cat("marker_off"), contig_off=cat("contig_off"),
+                            contig_lengths=np.concatenate([m["contig_lengths"] for m in metas]).astype(np.uint32),
+                            total_len=np.concatenate([m["total_len"] for m in metas]).astype(np.uint64), genome_rank=np.arange(n, dtype=np.uint32))
+                self._marker_index = ctx.import_flat(self.shards[0].params, meta, markers=np.concatenate(mks))
+        return self._marker_index
+
     def close(self):
+        mi = getattr(self, "_marker_index", None)
+        if mi is not None and all(mi is not s for s in self.shards):
+            mi.close()
         for s in self.shards:
             s.close()
 
@@ -58,10 +81,16 @@ def search(ctx, db, queries, screen_val=0.0, n_query_files=None, use_index=None,
         use_index = (n_query_files if n_query_files is not None else len(queries)) > FULL_INDEX_THRESH    # parse.rs:960
     mp = MapParams(min_af=min_af, robust=robust, median=median, learned_ani=learned_ani, compute_ci=compute_ci)
     qs, rs, res = [], [], []
+    if not db.shards:
+        return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
+    # one screen of all queries against the whole database's markers, then chaining shard by shard
+    q_all, r_all = ctx.screen(db.marker_index(ctx), queries, screen_val, SCREEN_REFS_INDICES if use_index else SCREEN_QUICK, False)
+    shard_of = np.searchsorted(db.offsets, r_all, side="right") - 1
     for k, shard in enumerate(db.shards):
-        q, r = ctx.screen(shard, queries, screen_val, SCREEN_REFS_INDICES if use_index else SCREEN_QUICK, False)
-        if len(q) == 0:
+        sel = shard_of == k
+        if not sel.any():
             continue
+        q = q_all[sel]; r = (r_all[sel].astype(np.int64) - db.offsets[k]).astype(np.uint32)
         out = ctx.chain_pairs(shard, queries, r, q, mp)                            # chain_seeds(ref_sketch, query_sketch): search.rs:175
         keep = out["ani"] > ani_min                                                # search.rs:176
         qs.append(q[keep]); rs.append(r[keep].astype(np.int64) + db.offsets[k]); res.append(out[keep])
