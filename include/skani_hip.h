@@ -152,6 +152,12 @@ int skh_chain_pairs(skh_ctx*, const skh_sketch_set* refs, const skh_sketch_set* 
                     const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params*, skh_ani_result* out,
                     skh_chain_stats* stats);
 
+/* Same, for a database kept as several resident sketch sets (shards): pair p = (ref_sets[pair_set[p]][pair_ref[p]],
+ * queries[pair_query[p]]).  One call chains hits from every shard (search.rs:150-180 with all references resident). */
+int skh_chain_pairs_multi(skh_ctx*, const skh_sketch_set* const* ref_sets, uint32_t n_ref_sets, const skh_sketch_set* queries,
+                          const uint32_t* pair_set, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs,
+                          const skh_map_params*, skh_ani_result* out);
+
 /* The triangle's screen (triangle.rs:55-90) for rows i in [row0, row0 + n_rows) only: pairs (i, j), j > i, of one set that
  * pass screen_refs with sketch i as the query.  This is one GPU's share when the rows of a large collection are
  * block-distributed over several GPUs that all hold the marker sets. */

@@ -30,7 +30,7 @@ STATS_DTYPE = np.dtype([(n, np.uint32) for n in ("switched", "n_chunks", "n_inte
 
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_batch", "skh_sketch_set_destroy",
-           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs",
+           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
            "skh_triangle", "skh_get_timings"]
 
 
@@ -63,6 +63,7 @@ def load(path):
     L.skh_screen.restype = i32; L.skh_screen.argtypes = [vp, vp, vp, dbl, i32, i32, pp, pp, C.POINTER(u64)]
     L.skh_screen_rows.restype = i32; L.skh_screen_rows.argtypes = [vp, vp, u32, u32, dbl, i32, pp, pp, C.POINTER(u64)]
     L.skh_chain_pairs.restype = i32; L.skh_chain_pairs.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp, vp]
+    L.skh_chain_pairs_multi.restype = i32; L.skh_chain_pairs_multi.argtypes = [vp, vp, u32, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp]
     L.skh_triangle.restype = i32
     L.skh_triangle.argtypes = [vp, vp, dbl, i32, C.POINTER(MapParams), u32, u32, pp, pp, pp, C.POINTER(u64), C.POINTER(u64)]
     L.skh_get_timings.restype = i32; L.skh_get_timings.argtypes = [vp, C.POINTER(Timings)]

@@ -204,6 +204,14 @@ class Context:
                                           C.byref(map_params), _p(out), _p(st)))
         return (out, st) if stats else out
 
+    def chain_pairs_multi(self, ref_sets, queries, pair_set, pair_ref, pair_query, map_params):
+        """chain_seeds(ref_sets[pair_set[p]][pair_ref[p]], queries[pair_query[p]]) for every p: hits from all shards of a database in one call."""
+        ps = np.ascontiguousarray(pair_set, np.uint32); pr = np.ascontiguousarray(pair_ref, np.uint32); pq = np.ascontiguousarray(pair_query, np.uint32)
+        out = np.zeros(len(pr), B.RESULT_DTYPE)
+        arr = (C.c_void_p * len(ref_sets))(*[s.h for s in ref_sets])
+        self.check(self.L.skh_chain_pairs_multi(self.h, arr, len(ref_sets), queries.h, _p(ps), _p(pr), _p(pq), len(pr), C.byref(map_params), _p(out)))
+        return out
+
     def triangle(self, sketches, map_params, identity=0.0, rescue_small=True, part=0, n_parts=1):
         oi, oj, orr, n, nch = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
         self.check(self.L.skh_triangle(self.h, sketches.h, identity, int(rescue_small), C.byref(map_params), part, n_parts,

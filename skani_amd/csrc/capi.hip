@@ -338,7 +338,18 @@ int skh_chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_s
     if (!ctx || !refs || !mp || (n_pairs && (!pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;
     int rc = guarded(ctx, [&] {
         Stopwatch sw(ctx, &ctx->timings.chain_ms);
-        chain_pairs(ctx, refs, queries ? queries : refs, pair_ref, pair_query, n_pairs, *mp, out, stats);
+        chain_pairs(ctx, &refs, 1, nullptr, queries ? queries : refs, pair_ref, pair_query, n_pairs, *mp, out, stats);
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_chain_pairs_multi(skh_ctx* ctx, const skh_sketch_set* const* ref_sets, uint32_t n_ref_sets, const skh_sketch_set* queries, const uint32_t* pair_set,
+                          const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params* mp, skh_ani_result* out) {
+    if (!ctx || !ref_sets || !n_ref_sets || !queries || !mp || (n_pairs && (!pair_set || !pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;
+    int rc = guarded(ctx, [&] {
+        Stopwatch sw(ctx, &ctx->timings.chain_ms);
+        chain_pairs(ctx, ref_sets, n_ref_sets, pair_set, queries, pair_ref, pair_query, n_pairs, *mp, out, nullptr);
     });
     ctx->arena.reset();
     return rc;
@@ -355,7 +366,7 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
         std::vector<uint32_t> pi, pj;
         for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
         std::vector<skh_ani_result> res(pi.size());
-        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, ss, ss, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
+        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &ss, 1, nullptr, ss, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
         if (n_chained) *n_chained = pi.size();
         size_t kept = 0;
         for (auto& r : res) if (r.ani > 0.1f) kept++;                                                      // triangle.rs:99

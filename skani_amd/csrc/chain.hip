@@ -22,32 +22,23 @@
 namespace skh {
 
 // ------------------------------------------------------------------------------------------------ views & descriptors
-struct SetView {
-    const uint32_t *p_seed, *p_g; const uint16_t* p_cnt;       // position order; p_g = padded coordinate << 1 | canonical
-    const uint32_t* s_g;                                       // hash order
-    const uint64_t* ent; const uint32_t* dir; const uint32_t* bmap;
-    const uint32_t* goff;                                      // padded contig starts (common.h CTG_PAD)
-};
-static SetView view_of(const skh_sketch_set* s) {
-    return SetView{s->p_seed.p, s->p_g.p, s->p_cnt.p, s->s_g.p, s->ent.p, s->dir.p, s->bmap.p, s->d_goff.p};
-}
-
+// One record per genome pair.  It carries direct pointers to the two sketches' arrays (already advanced to the genome's first
+// element), so the pairs of one call may draw their sketches from any number of resident sketch sets (a sharded database).
 struct PairDesc {
-    uint64_t a_pos0;    // A (enumerated sketch): first entry in its set's position-order arrays
-    uint64_t b_pos0;    // B (probed sketch): first entry in its set's seed-order arrays
-    uint64_t b_ent0;    // B: first entry of its seed index
-    uint64_t b_dir0;    // B: first bucket of its seed directory
+    // A = enumerated sketch (position order); p_g = padded coordinate << 1 | canonical
+    const uint32_t *a_seed, *a_g; const uint16_t* a_cnt;
+    // B = probed sketch: hash-order positions, seed index (entries, bucket directory, bucket-occupancy bitmap)
+    const uint32_t* b_sg; const uint64_t* b_ent; const uint32_t *b_dir, *b_bmap;
+    const uint32_t *a_goff, *b_goff;   // padded contig starts (common.h CTG_PAD), a_nctg + 1 / b_nctg + 1 entries
     uint32_t a_n;       // positions in A
     uint32_t b_nbk;     // B: buckets in its seed directory
-    uint32_t flags;     // bit0: A lives in set 1, bit1: B lives in set 1, bit2: switched (chain.rs:649)
+    uint32_t flags;     // bit2: switched (chain.rs:649)
     uint32_t tile0;     // first join tile of this pair (global over the call)
+    uint32_t a_nctg, b_nctg;
     // finalisation inputs (ref/query in the caller's sense, NOT A/B)
+    uint32_t nctg_q, nctg_r;
     uint64_t ref_total_len, query_total_len;
     float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
-    uint32_t nctg_q, nctg_r;
-    uint64_t a_goff0, b_goff0;   // first entry of A's / B's padded contig-start table in its set
-    uint32_t a_nctg, b_nctg;
-    uint64_t b_bmap0;            // B: first word of its bucket-occupancy bitmap
 };
 
 constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
@@ -63,7 +54,7 @@ struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };
 // Workgroups are launched in "slots": slot b runs logical tile slot_tile[b] (or nothing).  The host interleaves the
 // tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
 // table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
-__global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+__global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                          uint32_t band, uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq,
                                                          uint32_t* pinfo_start, uint16_t* pinfo_cnt, uint32_t lds_words) {
     __shared__ uint32_t lds[16];
@@ -73,9 +64,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     if (tile == NONE) return;
     const uint32_t p = tile_pair[tile];
     const PairDesc pd = pairs[p];
-    const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
-    const uint64_t* ent = B.ent + pd.b_ent0; const uint32_t* dir = B.dir + pd.b_dir0;
+    const uint64_t* ent = pd.b_ent; const uint32_t* dir = pd.b_dir;
     constexpr int R = JOIN_TILE / 256;
     // B's bucket-occupancy bitmap (1 bit per directory bucket, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of the
     // buckets are empty, and a probe of an empty bucket then costs no memory request at all.  The kernel runs at the L2's
@@ -83,7 +73,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     const uint32_t bm_words = ((pd.b_nbk + 31) / 32 + 3) / 4 * 4;
     const bool use_bm = bm_words <= lds_words;
     if (use_bm) {
-        const uint4* src = (const uint4*)(B.bmap + pd.b_bmap0);
+        const uint4* src = (const uint4*)pd.b_bmap;
         for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += 256) ((uint4*)bm)[w4] = src[w4];
         __syncthreads();
     }
@@ -93,8 +83,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
     for (int r = 0; r < R; r++) {
         const uint32_t i = start + r * 256 + threadIdx.x;
         live[r] = i < pd.a_n;
-        const uint32_t cnt = live[r] ? (uint32_t)A.p_cnt[pd.a_pos0 + i] : 0xFFFFu;
-        const uint32_t seed = live[r] ? A.p_seed[pd.a_pos0 + i] : 0u;
+        const uint32_t cnt = live[r] ? (uint32_t)pd.a_cnt[i] : 0xFFFFu;
+        const uint32_t seed = live[r] ? pd.a_seed[i] : 0u;
         live[r] = live[r] && cnt <= band;                                          // chain.rs:674-676
         h[r] = mix32(seed);
     }
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(SetView s0, SetView s1,
 
 // Emits anchors and the query-position list of one tile at the offsets given by the tile scans, from the per-position
 // probe results recorded by join_count_kernel (no second probe).
-__global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+__global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                         uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
                                                         const uint16_t* pinfo_cnt, uint32_t* anc_q, uint32_t* anc_r, uint32_t* ql_g) {
     constexpr int R = JOIN_TILE / 256;
@@ -153,7 +143,6 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
     if (tile == NONE) return;
     const uint32_t lt = tile - tile_base, p = tile_pair[tile];
     const PairDesc pd = pairs[p];
-    const SetView& A = (pd.flags & 1u) ? s1 : s0; const SetView& B = (pd.flags & 2u) ? s1 : s0;
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // all loads of the tile's four rounds are issued before anything depends on them; one barrier for the offsets
@@ -162,7 +151,7 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
         uint32_t c = 0; qg[r] = 0; bst[r] = 0;
-        if (i < pd.a_n) { c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; qg[r] = A.p_g[pd.a_pos0 + i]; bst[r] = pinfo_start[(uint64_t)tile * JOIN_TILE + o]; }
+        if (i < pd.a_n) { c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; bst[r] = pinfo_start[(uint64_t)tile * JOIN_TILE + o]; }
         n_anch[r] = c & 0x7FFFu; inq[r] = c >> 15;
     }
 #pragma unroll
@@ -180,10 +169,10 @@ __global__ __launch_bounds__(256) void join_fill_kernel(SetView s0, SetView s1, 
         if (inq[r]) {
             ql_g[run_q + bq + iq[r] - 1] = qg[r] >> 1;
             if (n_anch[r]) {
-                const uint64_t bs = pd.b_pos0 + bst[r];
+                const uint32_t* bs = pd.b_sg + bst[r];
                 uint32_t oa = run_a + ba + ia[r] - n_anch[r];
                 for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                     // chain.rs:703-711, already in sorted order
-                    const uint32_t rg = B.s_g[bs + k];
+                    const uint32_t rg = bs[k];
                     anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
                 }
             }
@@ -241,7 +230,7 @@ __device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* ql_g, uint32_t
     return lo;
 }
 
-__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* goff0, const uint32_t* goff1, const uint32_t* pa0,
+__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0,
                                                     const uint32_t* pq0, const uint32_t* pc0, const uint32_t* anc_q, const uint32_t* ql_g,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -250,7 +239,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
     const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
-        const uint32_t* go = ((pairs[p].flags & 1u) ? goff1 : goff0) + pairs[p].a_goff0;
+        const uint32_t* go = pairs[p].a_goff;
         const uint32_t nctg = pairs[p].a_nctg;
         Stream4 as; as.init(anc_q, A0, A1);
         const uint32_t q_first = as.at(A0);
@@ -388,7 +377,7 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
 // ring the component is final and, if it reaches 3 anchors / score 45 (chain.rs:954-977), its interval is emitted straight
 // away: the kernel writes nothing per anchor.
 // the interval record of a finished chain (root anchor .. best anchor), back in contig-local coordinates (types.rs:508-519)
-struct EmitCtx { const uint32_t *anc_q, *anc_r; const PairDesc* pairs; const uint32_t *goff0, *goff1, *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
+struct EmitCtx { const uint32_t *anc_q, *anc_r; const PairDesc* pairs; const uint32_t *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
 __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec) {
     const uint32_t sc = (uint32_t)(b >> 40), bi = (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
     if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) return;                        // chain.rs:954-957, 974-977
@@ -396,7 +385,7 @@ __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t
     if (ec.pi0[p] + k >= ec.pi0[p + 1]) { atomicAdd(ec.err, 1u); return; }
     const uint2 ar = make_uint2(ec.anc_q[ck.a_begin + root], ec.anc_r[ck.a_begin + root]), ab = make_uint2(ec.anc_q[ck.a_begin + bi], ec.anc_r[ck.a_begin + bi]);
     const PairDesc& pd = ec.pairs[p];
-    const uint32_t* bo = ((pd.flags & 2u) ? ec.goff1 : ec.goff0) + pd.b_goff0;
+    const uint32_t* bo = pd.b_goff;
     const uint32_t ra = ar.y >> 1, rb = ab.y >> 1;
     const uint32_t rctg = ctg_of(bo, pd.b_nctg, ra), roff = bo[rctg];
     Interval iv;
@@ -1131,12 +1120,14 @@ static uint32_t* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::ve
     return d_slots;
 }
 
-void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q, const uint32_t* pair_ref, const uint32_t* pair_query,
-                 uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats) {
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* Q, const uint32_t* pair_ref,
+                 const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats) {
     if (n_pairs_all == 0) return;
     if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
-    if (R->params.c != Q->params.c || R->params.k != Q->params.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
-    const uint32_t c = R->params.c, k = R->params.k;
+    if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
+    for (uint32_t x = 0; x < n_rsets; x++)
+        if (!Rsets[x] || Rsets[x]->params.c != Q->params.c || Rsets[x]->params.k != Q->params.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    const uint32_t c = Q->params.c, k = Q->params.k;
     const uint32_t band = BP_CHAIN_BAND / c;                                        // chain.rs:111-112 index_chain_band (ref sketch's c)
     if (band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
     const GbdtModel* model = nullptr;
@@ -1151,6 +1142,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
     std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
     std::vector<const uint32_t*> host_go_a(stats ? NP : 0), host_go_b(stats ? NP : 0);
     for (uint32_t p = 0; p < NP; p++) {
+        const uint32_t rs = pair_rset ? pair_rset[p] : 0u;
+        if (rs >= n_rsets) throw std::invalid_argument("pair names a reference set that was not passed");
+        const skh_sketch_set* R = Rsets[rs];
         const uint32_t r = pair_ref[p], q = pair_query[p];
         if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
         PairDesc& pd = pds[p];
@@ -1158,24 +1152,25 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         const bool sw = is_switched(R, r, Q, q);
         const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
         const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
-        pd.a_pos0 = A->pos_off[ga]; pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.b_pos0 = B->pos_off[gb]; pd.b_ent0 = B->dist_off[gb]; pd.b_dir0 = B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb]; pd.b_bmap0 = B->bmap_off[gb];
-        pd.flags = (A == Q && Q != R ? 1u : 0u) | (B == Q && Q != R ? 2u : 0u) | (sw ? 4u : 0u);
+        pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
+        pd.a_seed = A->p_seed.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_cnt = A->p_cnt.p + A->pos_off[ga];
+        pd.b_sg = B->s_g.p + B->pos_off[gb]; pd.b_ent = B->ent.p + B->dist_off[gb]; pd.b_dir = B->dir.p + B->dir_off[gb]; pd.b_nbk = B->n_buckets[gb];
+        pd.b_bmap = B->bmap.p + B->bmap_off[gb];
+        pd.flags = sw ? 4u : 0u;
         pd.tile0 = (uint32_t)n_tiles_all;
         pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
         pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
         pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
-        pd.a_goff0 = A->ctg_off[ga] + ga; pd.b_goff0 = B->ctg_off[gb] + gb;
+        pd.a_goff = A->d_goff.p + A->ctg_off[ga] + ga; pd.b_goff = B->d_goff.p + B->ctg_off[gb] + gb;
         pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
-        if (stats) { host_go_a[p] = A->goff.data() + pd.a_goff0; host_go_b[p] = B->goff.data() + pd.b_goff0; }
+        if (stats) { host_go_a[p] = A->goff.data() + A->ctg_off[ga] + ga; host_go_b[p] = B->goff.data() + B->ctg_off[gb] + gb; }
         n_tiles_all += (pd.a_n + JOIN_TILE - 1) / JOIN_TILE;
         if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
-        pair_key[p] = gb;                                                           // tiles probing the same sketch share an XCD
+        pair_key[p] = gb + 3u * (B == Q ? n_rsets : rs);                             // tiles probing the same sketch share an XCD
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }
     tr.mark("host: pair descriptors");
-    const SetView v0 = view_of(R), v1 = view_of(Q);
     const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = upload(ctx, pds);
     uint32_t* d_tile_pair = ctx->arena.get<uint32_t>((size_t)NT + 1);
@@ -1209,7 +1204,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
             uint32_t bm_words = 0;                                                 // LDS for the largest bitmap of the batch, up to 32 KB
             for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
             if (bm_words > 8192) bm_words = 8192;
-            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic, bm_words);
             check_launch("join_count");
         }
@@ -1245,7 +1240,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         if (nt) {
             uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
             if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, pair_key, &n_slots);
-            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, v0, v1, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
+            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
                        anc_q, anc_r, ql_g);
             check_launch("join_fill");
@@ -1253,7 +1248,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, v0.goff, v1.goff, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0,
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0,
                    (const uint32_t*)d_pc0, (const uint32_t*)anc_q, (const uint32_t*)ql_g, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         tr.mark("chunk");
@@ -1261,7 +1256,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* R, const skh_sketch_set* Q,
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
-        const EmitCtx ec{anc_q, anc_r, d_pairs, v0.goff, v1.goff, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
+        const EmitCtx ec{anc_q, anc_r, d_pairs, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
             if (band <= 40) {   // fused thread-per-chunk chaining + interval emission
                 constexpr int T = 64;

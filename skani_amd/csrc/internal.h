@@ -169,8 +169,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)
 
 // ---- chain.hip
-void chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, const uint32_t* pair_ref,
-                 const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats);
+// chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] (pair_rset == nullptr: set 0) and its query from Q
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* Q, const uint32_t* pair_ref,
+                 const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats);
 
 }  // namespace skh

@@ -85,15 +85,13 @@ def search(ctx, db, queries, screen_val=0.0, n_query_files=None, use_index=None,
         return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
     # one screen of all queries against the whole database's markers, then chaining shard by shard
     q_all, r_all = ctx.screen(db.marker_index(ctx), queries, screen_val, SCREEN_REFS_INDICES if use_index else SCREEN_QUICK, False)
-    shard_of = np.searchsorted(db.offsets, r_all, side="right") - 1
-    for k, shard in enumerate(db.shards):
-        sel = shard_of == k
-        if not sel.any():
-            continue
-        q = q_all[sel]; r = (r_all[sel].astype(np.int64) - db.offsets[k]).astype(np.uint32)
-        out = ctx.chain_pairs(shard, queries, r, q, mp)                            # chain_seeds(ref_sketch, query_sketch): search.rs:175
-        keep = out["ani"] > ani_min                                                # search.rs:176
-        qs.append(q[keep]); rs.append(r[keep].astype(np.int64) + db.offsets[k]); res.append(out[keep])
+    if len(q_all) == 0:
+        return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
+    shard_of = (np.searchsorted(db.offsets, r_all, side="right") - 1).astype(np.uint32)
+    local = (r_all.astype(np.int64) - db.offsets[shard_of]).astype(np.uint32)
+    out = ctx.chain_pairs_multi(db.shards, queries, shard_of, local, q_all, mp)    # chain_seeds(ref_sketch, query_sketch): search.rs:175
+    keep = out["ani"] > ani_min                                                    # search.rs:176
+    qs.append(q_all[keep]); rs.append(r_all[keep].astype(np.int64)); res.append(out[keep])
     if not qs:
         return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
     q = np.concatenate(qs); r = np.concatenate(rs); o = np.concatenate(res)
