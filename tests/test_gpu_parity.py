@@ -166,3 +166,21 @@ def test_small_budgets_force_multi_batch_paths(monkeypatch):
         pc.case_w_vs_w(c)
     finally:
         c.close()
+
+
+def test_long_genome_pair(ctx):
+    """A 26 Mbp pair at 3 % divergence: > 1024 chunks per pair, so finalize's per-pair work arrays leave LDS for the global scratch,
+    and the pair alone fills several join super-batches' worth of tiles at a small budget."""
+    from tests.helpers import random_genome, mutate, ora
+    root = random_genome(26_000_000, 123)
+    g = [[("a", root)], [("b", mutate(root, 0.03, 9))]]
+    names = ["long0.fa", "long1.fa"]
+    ss = ctx.sketch_records(g, sk.SketchParams(), names)
+    osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]
+    res, st = ctx.chain_pairs(ss, None, [0, 1], [1, 0], sk.MapParams(compute_ci=True), stats=True)
+    for x, (i, j) in enumerate(((0, 1), (1, 0))):
+        o, so = ora.chain_seeds(osk[i], osk[j], stats=True)
+        pc.assert_result_close(res[x], o, (i, j))
+        assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["n_estimates"]), int(st[x]["anchor_checksum"])) == \
+            (so.n_intervals, so.n_accepted, so.n_chunks, so.n_estimates, so.anchor_checksum)
+    assert int(st[0]["n_chunks"]) > 1024 and 0.96 < res[0]["ani"] < 0.98
