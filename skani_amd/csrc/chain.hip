@@ -182,52 +182,28 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
 }
 
 // ------------------------------------------------------------------------------------------------ chunking (chain.rs:738-836)
-// One wave per pair.  All control flow is wave-uniform; lanes only differ in the element they test.  Both scans (over the
-// anchors and over the query-position list) only ever move forward over contiguous memory, so each keeps the current and the
-// next 64-element block in registers (the next block's load is in flight while the current one is examined), and the values
-// the recurrence needs (the breaking anchor, the last anchor) come from the resident block through v_readlane.  The kernel
-// streams every anchor's query coordinate once (4 B each).
-// A forward-only window over a sorted u32 array: each lane holds 4 consecutive elements of the current 256-element block
-// (one 16-byte load) and of the next one (in flight while the current block is examined).
-struct Stream4 {
-    const uint32_t* p; uint32_t hi, b;          // b: first element of the current block, a multiple of 4
-    uint4 c, n;
-    __device__ __forceinline__ uint4 load(uint32_t blk) const {
-        const uint32_t i = blk + 4u * lane_id();
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i + 3 < hi) v = *(const uint4*)(p + i);
-        else { if (i < hi) v.x = p[i]; if (i + 1 < hi) v.y = p[i + 1]; if (i + 2 < hi) v.z = p[i + 2]; }
-        return v;
-    }
-    __device__ __forceinline__ void init(const uint32_t* p_, uint32_t from, uint32_t hi_) { p = p_; hi = hi_; b = from & ~3u; c = load(b); n = load(b + 256); }
-    __device__ __forceinline__ void advance() { b += 256; c = n; n = load(b + 256); }
-    // first index >= from whose element exceeds lim; hi if none.  Elements are ascending from `from` on.
-    __device__ __forceinline__ uint32_t first_above(uint32_t from, uint32_t lim) {
-        for (;;) {
-            const uint32_t i = b + 4u * lane_id();
-            const unsigned long long m0 = __ballot(i >= from && i < hi && c.x > lim), m1 = __ballot(i + 1 >= from && i + 1 < hi && c.y > lim);
-            const unsigned long long m2 = __ballot(i + 2 >= from && i + 2 < hi && c.z > lim), m3 = __ballot(i + 3 >= from && i + 3 < hi && c.w > lim);
-            if (m0 | m1 | m2 | m3) {
-                uint32_t best = 0xFFFFFFFFu;
-                if (m0) best = 4u * ((uint32_t)__ffsll((long long)m0) - 1u);
-                if (m1) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m1) - 1u) + 1u; best = x < best ? x : best; }
-                if (m2) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m2) - 1u) + 2u; best = x < best ? x : best; }
-                if (m3) { const uint32_t x = 4u * ((uint32_t)__ffsll((long long)m3) - 1u) + 3u; best = x < best ? x : best; }
-                return b + best;
-            }
-            if (b + 256 >= hi) return hi;
-            advance();
-        }
-    }
-    __device__ __forceinline__ uint32_t at(uint32_t i) {                              // i inside the current block (wave-uniform)
-        const uint32_t o = i - b; const int ln = (int)(o >> 2);
-        const uint32_t k = o & 3u;
-        return k == 0 ? wave_readlane(c.x, ln) : k == 1 ? wave_readlane(c.y, ln) : k == 2 ? wave_readlane(c.z, ln) : wave_readlane(c.w, ln);
-    }
-};
-__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* ql_g, uint32_t lo, uint32_t hi, uint32_t v) {   // uniform
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ql_g[mid] < v) lo = mid + 1; else hi = mid; }
+// The reference walks the anchors once: a chunk ends at the first later anchor that leaves the contig or lies beyond the running
+// end point, and a break advances the end point by exactly one CHUNK_SIZE (chain.rs:747-790); a contig change restarts it at the
+// breaking anchor.  Inside one contig the end points are therefore an arithmetic progression fixed by the contig's first anchor,
+//     lim_k = min(q_first + k * CHUNK_SIZE, last coordinate of the contig),            k = 1, 2, ...
+// and the chunk boundaries obey  t_0 = first anchor,  t_k = max(t_{k-1} + 1, b_k)  with b_k = first anchor beyond lim_k -- an
+// independent binary search per k.  Substituting u_k = t_k - k turns the recurrence into a running maximum, u_k = max(u_{k-1}, b_k - k),
+// i.e. a prefix-max scan: one wave per pair handles 64 chunk boundaries per step instead of streaming every anchor.  The seed-list
+// boundary of chunk k is simply the first listed position beyond lim_k (chain.rs:755-780); the pair's very last chunk takes the
+// positions up to its last anchor instead (chain.rs:794-824).
+__device__ __forceinline__ uint32_t first_above(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {   // first index in [lo, hi) with a[i] > v, else hi
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] > v) hi = mid; else lo = mid + 1; }
     return lo;
+}
+__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {  // first index with a[i] >= v
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v = t > v ? t : v; }
+    return v;
 }
 
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0,
@@ -241,40 +217,46 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
     if (A1 > A0) {
         const uint32_t* go = pairs[p].a_goff;
         const uint32_t nctg = pairs[p].a_nctg;
-        Stream4 as; as.init(anc_q, A0, A1);
-        const uint32_t q_first = as.at(A0);
-        uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];   // "last_contig" and its padded range
-        uint32_t end = q_first + CHUNK_SIZE;                                        // chain.rs:742-744
-        uint32_t rc = lower_bound_g(ql_g, Q0, Q1, cstart);                          // running_counter = 0 within this contig
-        Stream4 ss; ss.init(ql_g, rc, Q1);
-        uint32_t cur = A0, scan = A0 + 1;
-        for (;;) {
-            const uint32_t lim = end < cnext - 1 ? end : cnext - 1;                 // beyond it: another contig, or past the window
-            const uint32_t t = as.first_above(scan, lim);                           // chain.rs:747
-            Chunk ck; ck.a_begin = cur; ck.s_begin = rc; ck.qoff = cstart; ck.qctg = ctg;
-            if (rc < ss.b || rc >= ss.b + 512) ss.init(ql_g, rc, Q1);              // the seed window was left behind by a contig change
-            if (t == A1) {                                                         // final chunk: seeds <= last anchor's pos (chain.rs:794-824)
-                if (A1 - 1 < as.b) as.init(anc_q, A1 - 1, A1);                      // (cannot happen: the scan ends in the block holding A1-1)
-                ck.a_end = A1; ck.s_end = ss.first_above(rc, as.at(A1 - 1));
-            } else {                                                               // chain.rs:747-790
-                ck.a_end = t; ck.s_end = ss.first_above(rc, lim);
+        const uint32_t q_pair_last = anc_q[A1 - 1];
+        uint32_t a = A0;
+        while (a < A1) {                                                           // one query contig per round (wave-uniform)
+            const uint32_t q_first = anc_q[a];
+            const uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];
+            const uint32_t e = lower_bound_g(anc_q, a, A1, cnext);                  // anchors [a, e) lie in this contig
+            const uint32_t q_last = anc_q[e - 1];
+            const uint32_t rc0 = lower_bound_g(ql_g, Q0, Q1, cstart);               // running_counter = 0 within this contig (chain.rs:742-744)
+            const uint32_t k_max = (q_last - q_first) / CHUNK_SIZE + 1;             // lim_k reaches the last anchor no later than this
+            int32_t carry = (int32_t)a;                                             // u_0 = t_0 - 0
+            uint32_t t_prev_carry = a, s_prev_carry = rc0;                         // t_{k-1}, seed boundary of chunk k-1 for the batch's first lane
+            for (uint32_t kb = 0; kb < k_max && t_prev_carry < e; kb += 64) {
+                const uint32_t k = kb + l + 1;
+                const uint64_t end64 = (uint64_t)q_first + (uint64_t)k * CHUNK_SIZE;
+                const uint32_t lim = end64 < (uint64_t)(cnext - 1) ? (uint32_t)end64 : cnext - 1;   // beyond it: another contig, or past the window
+                const uint32_t b = first_above(anc_q, a, e, lim);                   // <= e
+                const uint32_t sb = first_above(ql_g, rc0, Q1, lim);                // seed list boundary after chunk k
+                const int32_t u = wave_incl_max((int32_t)b - (int32_t)k);
+                const int32_t uu = u > carry ? u : carry;
+                const uint32_t t = (uint32_t)(uu + (int32_t)k);                     // t_k (may run past e: the chunk is then cut at e)
+                uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
+                if (l == 0) { t_prev = t_prev_carry; s_prev = s_prev_carry; }
+                const bool valid = t_prev < e;                                      // chunk k exists
+                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e ? t : e; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cstart; ck.qctg = ctg;
+                if (valid && ck.a_end == A1) ck.s_end = first_above(ql_g, s_prev, Q1, q_pair_last);   // the pair's final chunk
+                const unsigned long long vm = __ballot(valid);
+                const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
+                if (valid) {
+                    if (slot < C1) { chunks[slot] = ck; chunk_pair[slot] = p; }
+                    else atomicAdd(err, 1u);
+                }
+                nc += (uint32_t)__popcll(vm);
+                carry = __shfl(uu, 63, 64); t_prev_carry = __shfl(t, 63, 64); s_prev_carry = __shfl(sb, 63, 64);
             }
-            if (C0 + nc < C1) { if (l == 0) { chunks[C0 + nc] = ck; chunk_pair[C0 + nc] = p; } }
-            else if (l == 0) atomicAdd(err, 1u);
-            nc++;
-            if (t == A1) break;
-            rc = ck.s_end; end += CHUNK_SIZE;                                      // one step only (chain.rs:782)
-            const uint32_t tq = as.at(t);                                          // anchor t sits in the resident block
-            if (tq >= cnext) {                                                     // contig change (chain.rs:786-789)
-                ctg = ctg_of(go, nctg, tq); cstart = go[ctg]; cnext = go[ctg + 1];
-                end = tq + CHUNK_SIZE;
-                rc = lower_bound_g(ql_g, Q0, Q1, cstart);
-            }
-            cur = t; scan = t + 1;
+            a = e;
         }
     }
-    for (uint32_t s = C0 + nc + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0, 0, 0}; chunk_pair[s] = p; }
-    if (l == 0) n_chunks[p] = nc;
+    const uint32_t used = nc < C1 - C0 ? nc : C1 - C0;
+    for (uint32_t s = C0 + used + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0, 0, 0}; chunk_pair[s] = p; }
+    if (l == 0) n_chunks[p] = used;
 }
 
 // Per-component argmax record kept at the component's ROOT anchor: score (24 bits) | index of the best anchor inside its

@@ -49,6 +49,7 @@ def _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device):
     mk = torch.zeros(max_m, dtype=torch.int64, device=device)                       # u64 bit patterns
     if M:
         if on_dev:
+            torch.cuda.synchronize(device)                                          # the library copies on its own stream: torch's fill must have landed
             ss_local.export_arrays(markers=mk.data_ptr(), device=True)
         else:
             ss_local.export_arrays(markers=mk.numpy().view(np.uint64))
