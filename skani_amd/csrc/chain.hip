@@ -55,8 +55,8 @@ struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };
 // tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
 // table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
 __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
-                                                         uint32_t band, uint32_t* tile_anch, uint32_t* tile_inq, uint32_t* pair_anch, uint32_t* pair_inq,
-                                                         uint32_t* pinfo_start, uint16_t* pinfo_cnt, uint32_t lds_words) {
+                                                         uint32_t band, uint32_t* tile_anch, uint32_t* pair_anch, uint32_t* pair_inq,
+                                                         uint32_t* pinfo, unsigned long long* inq_mask, uint32_t lds_words) {
     __shared__ uint32_t lds[16];
     SKH_DYN_SMEM(smem);
     uint32_t* bm = (uint32_t*)smem;
@@ -113,10 +113,11 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
                 if (cnt <= band) { inq = 1; n_anch = cnt; bstart = ((uint32_t)x >> 8) & 0xFFFFFFu; }   // else chain.rs:694-696: dropped entirely
             }
         }
-        if (i < pd.a_n) {
-            pinfo_start[(uint64_t)tile * JOIN_TILE + o] = bstart;
-            pinfo_cnt[(uint64_t)tile * JOIN_TILE + o] = (uint16_t)(n_anch | (inq << 15));
-        }
+        // probe record: first hit in B's hash-order array << 8 | hits (<= band <= 250); and one bit per position: "listed in
+        // query_positions_all" (chain.rs:682-700), 64 positions per word straight from the ballot
+        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = (bstart << 8) | n_anch;
+        const unsigned long long m = __ballot(inq != 0);
+        if ((threadIdx.x & 63) == 0) inq_mask[(uint64_t)tile * (JOIN_TILE / 64) + (o >> 6)] = m;
         na += n_anch; nq += inq;
     }
     na = wave_sum(na); nq = wave_sum(nq);
@@ -126,19 +127,18 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     if (threadIdx.x == 0) {
         uint32_t ta = 0, tq = 0;
         for (uint32_t i = 0; i < 4; i++) { ta += lds[i]; tq += lds[8 + i]; }
-        tile_anch[tile] = ta; tile_inq[tile] = tq;
+        tile_anch[tile] = ta;
         if (ta) atomicAdd(&pair_anch[p], ta);
         if (tq) atomicAdd(&pair_inq[p], tq);
     }
 }
 
-// Emits anchors and the query-position list of one tile at the offsets given by the tile scans, from the per-position
-// probe results recorded by join_count_kernel (no second probe).
+// Emits the anchors of one tile at the offsets given by the tile scan, from the per-position probe results recorded by
+// join_count_kernel (no second probe).
 __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
-                                                        uint32_t tile_base, const uint32_t* toff_a, const uint32_t* toff_q, const uint32_t* pinfo_start,
-                                                        const uint16_t* pinfo_cnt, uint32_t* anc_q, uint32_t* anc_r, uint32_t* ql_g) {
+                                                        uint32_t tile_base, const uint32_t* toff_a, const uint32_t* pinfo, uint32_t* anc_q, uint32_t* anc_r) {
     constexpr int R = JOIN_TILE / 256;
-    __shared__ uint32_t lds_a[R * 4], lds_q[R * 4];
+    __shared__ uint32_t lds_a[R * 4];
     const uint32_t tile = slot_tile[blockIdx.x];
     if (tile == NONE) return;
     const uint32_t lt = tile - tile_base, p = tile_pair[tile];
@@ -146,38 +146,35 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // all loads of the tile's four rounds are issued before anything depends on them; one barrier for the offsets
-    uint32_t n_anch[R], inq[R], qg[R], bst[R], ia[R], iq[R];
+    uint32_t n_anch[R], qg[R], bst[R], ia[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        uint32_t c = 0; qg[r] = 0; bst[r] = 0;
-        if (i < pd.a_n) { c = pinfo_cnt[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; bst[r] = pinfo_start[(uint64_t)tile * JOIN_TILE + o]; }
-        n_anch[r] = c & 0x7FFFu; inq[r] = c >> 15;
+        uint32_t c = 0; qg[r] = 0;
+        if (i < pd.a_n) { c = pinfo[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; }
+        n_anch[r] = c & 0xFFu; bst[r] = c >> 8;
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        ia[r] = wave_incl_scan(n_anch[r]); iq[r] = wave_incl_scan(inq[r]);
-        if (l == 63) { lds_a[r * 4 + w] = ia[r]; lds_q[r * 4 + w] = iq[r]; }
+        ia[r] = wave_incl_scan(n_anch[r]);
+        if (l == 63) lds_a[r * 4 + w] = ia[r];
     }
     __syncthreads();
-    uint32_t run_a = toff_a[lt], run_q = toff_q[lt];
+    uint32_t run_a = toff_a[lt];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        uint32_t ba = 0, bq = 0, ta = 0, tq = 0;
+        uint32_t ba = 0, ta = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds_a[r * 4 + k], y = lds_q[r * 4 + k]; if (k < w) { ba += x; bq += y; } ta += x; tq += y; }
-        if (inq[r]) {
-            ql_g[run_q + bq + iq[r] - 1] = qg[r] >> 1;
-            if (n_anch[r]) {
-                const uint32_t* bs = pd.b_sg + bst[r];
-                uint32_t oa = run_a + ba + ia[r] - n_anch[r];
-                for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                     // chain.rs:703-711, already in sorted order
-                    const uint32_t rg = bs[k];
-                    anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
-                }
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds_a[r * 4 + k]; if (k < w) ba += x; ta += x; }
+        if (n_anch[r]) {
+            const uint32_t* bs = pd.b_sg + bst[r];
+            uint32_t oa = run_a + ba + ia[r] - n_anch[r];
+            for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                         // chain.rs:703-711, already in sorted order
+                const uint32_t rg = bs[k];
+                anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
             }
         }
-        run_a += ta; run_q += tq;
+        run_a += ta;
     }
 }
 
@@ -189,14 +186,25 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
 // and the chunk boundaries obey  t_0 = first anchor,  t_k = max(t_{k-1} + 1, b_k)  with b_k = first anchor beyond lim_k -- an
 // independent binary search per k.  Substituting u_k = t_k - k turns the recurrence into a running maximum, u_k = max(u_{k-1}, b_k - k),
 // i.e. a prefix-max scan: one wave per pair handles 64 chunk boundaries per step instead of streaming every anchor.  The seed-list
-// boundary of chunk k is simply the first listed position beyond lim_k (chain.rs:755-780); the pair's very last chunk takes the
-// positions up to its last anchor instead (chain.rs:794-824).
+// boundary of chunk k is simply the first position beyond lim_k (chain.rs:755-780); the pair's very last chunk takes the
+// positions up to its last anchor instead (chain.rs:794-824).  query_positions_all is not materialised: it is the enumerated
+// sketch's own position array (coordinates ascend) filtered by the join's one-bit-per-position mask, so a chunk records a range
+// of POSITION indices and chunk_stats_kernel applies the mask.
 __device__ __forceinline__ uint32_t first_above(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {   // first index in [lo, hi) with a[i] > v, else hi
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] > v) hi = mid; else lo = mid + 1; }
     return lo;
 }
 __device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {  // first index with a[i] >= v
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// the same two searches over a sketch's position array, whose entries are coordinate << 1 | canonical
+__device__ __forceinline__ uint32_t pos_first_above(const uint32_t* g1, uint32_t lo, uint32_t hi, uint32_t v) {
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((g1[mid] >> 1) > v) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__device__ __forceinline__ uint32_t pos_lower_bound(const uint32_t* g1, uint32_t lo, uint32_t hi, uint32_t v) {
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((g1[mid] >> 1) < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
 __device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
@@ -207,16 +215,17 @@ __device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
 }
 
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0,
-                                                    const uint32_t* pq0, const uint32_t* pc0, const uint32_t* anc_q, const uint32_t* ql_g,
+                                                    const uint32_t* pc0, const uint32_t* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();
-    const uint32_t A0 = pa0[p], A1 = pa0[p + 1], Q0 = pq0[p], Q1 = pq0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
+    const uint32_t A0 = pa0[p], A1 = pa0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
         const uint32_t* go = pairs[p].a_goff;
         const uint32_t nctg = pairs[p].a_nctg;
+        const uint32_t* ag = pairs[p].a_g; const uint32_t Q1 = pairs[p].a_n;         // the enumerated sketch's positions
         const uint32_t q_pair_last = anc_q[A1 - 1];
         uint32_t a = A0;
         while (a < A1) {                                                           // one query contig per round (wave-uniform)
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
             const uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];
             const uint32_t e = lower_bound_g(anc_q, a, A1, cnext);                  // anchors [a, e) lie in this contig
             const uint32_t q_last = anc_q[e - 1];
-            const uint32_t rc0 = lower_bound_g(ql_g, Q0, Q1, cstart);               // running_counter = 0 within this contig (chain.rs:742-744)
+            const uint32_t rc0 = pos_lower_bound(ag, 0, Q1, cstart);                // running_counter = 0 within this contig (chain.rs:742-744)
             const uint32_t k_max = (q_last - q_first) / CHUNK_SIZE + 1;             // lim_k reaches the last anchor no later than this
             int32_t carry = (int32_t)a;                                             // u_0 = t_0 - 0
             uint32_t t_prev_carry = a, s_prev_carry = rc0;                         // t_{k-1}, seed boundary of chunk k-1 for the batch's first lane
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 const uint64_t end64 = (uint64_t)q_first + (uint64_t)k * CHUNK_SIZE;
                 const uint32_t lim = end64 < (uint64_t)(cnext - 1) ? (uint32_t)end64 : cnext - 1;   // beyond it: another contig, or past the window
                 const uint32_t b = first_above(anc_q, a, e, lim);                   // <= e
-                const uint32_t sb = first_above(ql_g, rc0, Q1, lim);                // seed list boundary after chunk k
+                const uint32_t sb = pos_first_above(ag, rc0, Q1, lim);              // seed list boundary after chunk k
                 const int32_t u = wave_incl_max((int32_t)b - (int32_t)k);
                 const int32_t uu = u > carry ? u : carry;
                 const uint32_t t = (uint32_t)(uu + (int32_t)k);                     // t_k (may run past e: the chunk is then cut at e)
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 if (l == 0) { t_prev = t_prev_carry; s_prev = s_prev_carry; }
                 const bool valid = t_prev < e;                                      // chunk k exists
                 Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e ? t : e; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cstart; ck.qctg = ctg;
-                if (valid && ck.a_end == A1) ck.s_end = first_above(ql_g, s_prev, Q1, q_pair_last);   // the pair's final chunk
+                if (valid && ck.a_end == A1) ck.s_end = pos_first_above(ag, s_prev, Q1, q_pair_last);   // the pair's final chunk
                 const unsigned long long vm = __ballot(valid);
                 const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
                 if (valid) {
@@ -696,14 +705,14 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
 // ------------------------------------------------------------------------------------------------ per-chunk ANI inputs
 // chain.rs:199-413.  A wave owns 64 consecutive chunks.  Lane j first walks chunk j's accepted intervals (1-3 of them);
 // then the wave visits the 64 chunks one after the other: chunk j's interval bounds are broadcast with v_readlane and all
-// 64 lanes stream its ~160 query seed positions as coalesced 256-byte reads, counting the positions inside the union of the
-// (padded) intervals and inside the covered range with ballots; finally lane j turns chunk j's counts into its ANI estimate
-// and weight.  (A thread-per-chunk walk of the position list touches 64 different cache lines per load and fetched the
+// 64 lanes stream its ~160 query seed positions (the enumerated sketch's position array, masked by the join's "listed" bits) as
+// coalesced 256-byte reads, counting the listed positions, those inside the union of the (padded) intervals and those inside
+// the covered range with ballots; finally lane j turns chunk j's counts into its ANI estimate and weight.  (A thread-per-chunk walk of the position list touches 64 different cache lines per load and fetched the
 // list 4-5 times over.)
 constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more -> slow path re-walks the list per position)
 
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
-                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const uint32_t* ql_g,
+                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const unsigned long long* inq_mask,
                                                           uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint4* chunk_sums) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t l = lane_id();
@@ -715,10 +724,12 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
 #pragma unroll
     for (int i = 0; i < STATS_REG; i++) { lo[i] = 1; hi[i] = 0; }                   // empty
     bool active = false;
+    const uint32_t* ag = nullptr; const unsigned long long* mk = nullptr;           // the chunk's pair: position array and "listed" bits
     if (head != NONE) {                                                             // else total_anchors == 0 (chain.rs:253)
         const Chunk ck = chunks[slot];
         const uint32_t p = chunk_pair[slot];
         const bool switched = (pairs[p].flags & 4u) != 0;
+        ag = pairs[p].a_g; mk = inq_mask + (uint64_t)pairs[p].tile0 * (JOIN_TILE / 64);
         s_begin = ck.s_begin; s_end = ck.s_end; qoff = ck.qoff;
         for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
             const Interval iv = ivls[e];
@@ -739,36 +750,51 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         // (chain.rs:184-190: sensitive -> interval lengths, else the chunk's covered range, chain.rs:261-264)
         chunk_sums[slot] = make_uint4(sum_len, n_int, sensitive ? sum_len : (active ? rq1 - rq0 + 2 * c + k : 0u), 0u);
     } else if (valid) chunk_sums[slot] = make_uint4(0, 0, 0, 0);
-    uint32_t in_u = 0, in_range = 0;
+    uint32_t in_u = 0, in_range = 0, in_list = 0;
     unsigned long long todo = __ballot(active);
     // the first 256 positions of a chunk are fetched as four independent loads, and the next chunk's are in flight while the
-    // current chunk is counted: the loop is otherwise a chain of dependent round trips to memory
+    // current chunk is counted: the loop is otherwise a chain of dependent round trips to memory.  A fetched value is
+    // coordinate << 1 | listed.  (Assembling the 64 "listed" bits of a block from two wave-uniform loads instead of one load
+    // per lane is slower: 1.27 vs 0.79 ms -- the scalar loads sit in the dependent chain.)
     constexpr int PF = 4;
     uint32_t cur[PF], nxt[PF];
+    auto fetch = [&](const uint32_t* ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> uint32_t {
+        if (s2 >= se_j) return 0u;
+        return (ag_j[s2] & ~1u) | (uint32_t)((mk_j[s2 >> 6] >> (s2 & 63u)) & 1ull);
+    };
+    auto bcast_ptr = [&](const void* ptr, int src) -> const void* {
+        const unsigned long long v = (unsigned long long)ptr;
+        const uint32_t lo32 = wave_readlane((uint32_t)v, src), hi32 = wave_readlane((uint32_t)(v >> 32), src);
+        return (const void*)(((unsigned long long)hi32 << 32) | lo32);
+    };
     int j = -1; uint32_t sb = 0, se = 0;
+    const uint32_t* agj = nullptr; const unsigned long long* mkj = nullptr;
     if (todo) {
         j = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
         sb = wave_readlane(s_begin, j); se = wave_readlane(s_end, j);
+        agj = (const uint32_t*)bcast_ptr(ag, j); mkj = (const unsigned long long*)bcast_ptr(mk, j);
 #pragma unroll
-        for (int u = 0; u < PF; u++) { const uint32_t s2 = sb + 64u * (uint32_t)u + l; cur[u] = s2 < se ? ql_g[s2] : 0u; }
+        for (int u = 0; u < PF; u++) cur[u] = fetch(agj, mkj, sb + 64u * (uint32_t)u + l, se);
     }
     while (j >= 0) {                                                                // wave-uniform
         int jn = -1; uint32_t sbn = 0, sen = 0;
+        const uint32_t* agn = nullptr; const unsigned long long* mkn = nullptr;
         if (todo) {
             jn = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
             sbn = wave_readlane(s_begin, jn); sen = wave_readlane(s_end, jn);
+            agn = (const uint32_t*)bcast_ptr(ag, jn); mkn = (const unsigned long long*)bcast_ptr(mk, jn);
 #pragma unroll
-            for (int u = 0; u < PF; u++) { const uint32_t s2 = sbn + 64u * (uint32_t)u + l; nxt[u] = s2 < sen ? ql_g[s2] : 0u; }
+            for (int u = 0; u < PF; u++) nxt[u] = fetch(agn, mkn, sbn + 64u * (uint32_t)u + l, sen);
         }
         const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
-        const uint32_t qoffj = wave_readlane(qoff, j);                              // the list holds padded coordinates; intervals are contig-local
+        const uint32_t qoffj = wave_readlane(qoff, j);                              // positions are padded coordinates; intervals are contig-local
         uint32_t lj[STATS_REG], hj[STATS_REG];
 #pragma unroll
         for (int i = 0; i < STATS_REG; i++) { lj[i] = wave_readlane(lo[i], j); hj[i] = wave_readlane(hi[i], j); }
-        uint32_t cu = 0, cr = 0;
-        auto count = [&](uint32_t s2, uint32_t gpos) {
-            const bool on = s2 < se;
-            const uint32_t pos = gpos - qoffj;
+        uint32_t cu = 0, cr = 0, cl = 0;
+        auto count = [&](uint32_t v) {
+            const bool on = (v & 1u) != 0;                                          // listed in query_positions_all (0 beyond the chunk)
+            const uint32_t pos = (v >> 1) - qoffj;
             bool hit = false;
             if (nj <= (uint32_t)STATS_REG) {
 #pragma unroll
@@ -776,19 +802,20 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
             } else {
                 for (uint32_t e = headj; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos >= l0 && pos <= iv.q1 + c); }
             }
+            cl += (uint32_t)__popcll(__ballot(on));                                 // chain.rs:755-780: seeds of the chunk
             cu += (uint32_t)__popcll(__ballot(on && hit));                          // chain.rs:268-272
             cr += (uint32_t)__popcll(__ballot(on && pos >= q0j && pos <= q1j));     // chain.rs:326-332 (spacing estimates are 0)
         };
 #pragma unroll
-        for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(sb + 64u * (uint32_t)u + l, cur[u]);
-        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) { const uint32_t s2 = b2 + l; count(s2, s2 < se ? ql_g[s2] : qoffj); }
-        if ((int)l == j) { in_u = cu; in_range = cr; }
-        j = jn; sb = sbn; se = sen;
+        for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(cur[u]);
+        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) count(fetch(agj, mkj, b2 + l, se));
+        if ((int)l == j) { in_u = cu; in_range = cr; in_list = cl; }
+        j = jn; sb = sbn; se = sen; agj = agn; mkj = mkn;
 #pragma unroll
         for (int u = 0; u < PF; u++) cur[u] = nxt[u];
     }
     if (!active) return;
-    uint32_t considered = s_end - s_begin;
+    uint32_t considered = in_list;
     const double inv_k = 1. / (double)k;
     const double putative = pow((double)total_anchors / (double)in_u, inv_k);       // chain.rs:335-339
     if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < CHUNK_SIZE * 9 / 10 && (double)considered > 1.05 * (double)in_range)
@@ -1160,7 +1187,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     check_launch("tile_pair");
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
-    uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_inq = ctx->arena.get<uint32_t>((size_t)NT + 1);
+    uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1);
     uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
     dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
@@ -1175,10 +1202,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         while (sp1 < NP && (sp1 == sp0 || (sp1 + 1 < NP ? pds[sp1 + 1].tile0 : NT) - pds[sp0].tile0 <= SUPER_TILES)) sp1++;
         const uint32_t st0 = pds[sp0].tile0, st1 = sp1 < NP ? pds[sp1].tile0 : NT, snt = st1 - st0;
         const std::vector<size_t> super_mark = ctx->arena.mark();
-        uint32_t* pinfo_start = ctx->arena.get<uint32_t>((size_t)snt * JOIN_TILE + 1);
-        uint16_t* pinfo_cnt = ctx->arena.get<uint16_t>((size_t)snt * JOIN_TILE + 1);
+        uint32_t* pinfo = ctx->arena.get<uint32_t>((size_t)snt * JOIN_TILE + 1);
+        unsigned long long* inq_mask = ctx->arena.get<unsigned long long>((size_t)snt * (JOIN_TILE / 64) + 1);
         // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
-        uint32_t* pis = pinfo_start - (size_t)st0 * JOIN_TILE; uint16_t* pic = pinfo_cnt - (size_t)st0 * JOIN_TILE;
+        uint32_t* pis = pinfo - (size_t)st0 * JOIN_TILE; unsigned long long* imk = inq_mask - (size_t)st0 * (JOIN_TILE / 64);
         uint32_t* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         if (snt) {
             uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, pair_key, &n_super_slots);
@@ -1187,7 +1214,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
             if (bm_words > 8192) bm_words = 8192;
             SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
-                       (const uint32_t*)d_tile_pair, band, tile_anch, tile_inq, d_pair_anch, d_pair_inq, pis, pic, bm_words);
+                       (const uint32_t*)d_tile_pair, band, tile_anch, d_pair_anch, d_pair_inq, pis, imk, bm_words);
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");
@@ -1202,36 +1229,34 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         const std::vector<size_t> arena_mark = ctx->arena.mark();
         if (na >= 0xFFFFFFF0ull) throw Error("a single genome pair produces more than 2^32 anchors");
         // per-pair prefix arrays (batch-relative)
-        std::vector<uint32_t> pa0(np + 1, 0), pq0(np + 1, 0), pc0(np + 1, 0), pi0(np + 1, 0), ps0(np + 1, 0);
+        std::vector<uint32_t> pa0(np + 1, 0), pc0(np + 1, 0), pi0(np + 1, 0), ps0(np + 1, 0);
         for (uint32_t i = 0; i < np; i++) {
-            pa0[i + 1] = pa0[i] + pair_anch[p0 + i]; pq0[i + 1] = pq0[i] + pair_inq[p0 + i];
+            pa0[i + 1] = pa0[i] + pair_anch[p0 + i];
             pc0[i + 1] = pc0[i] + (pair_anch[p0 + i] ? std::min(chunk_bound[p0 + i], pair_anch[p0 + i]) : 0);
             const uint32_t icap = pair_anch[p0 + i] / MIN_ANCHORS;
             pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);   // fallback kernel's global sort scratch
         }
-        const uint32_t NA = pa0[np], NQ = pq0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
+        const uint32_t NA = pa0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
         const PairDesc* d_pairs = d_pairs_all + p0;
-        uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pq0 = upload(ctx, pq0); uint32_t* d_pc0 = upload(ctx, pc0);
+        uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pc0 = upload(ctx, pc0);
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
-        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1); uint32_t* toff_q = ctx->arena.get<uint32_t>(nt + 1);
-        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); exclusive_scan_u32(ctx, tile_inq + t0, nt, toff_q);
+        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1);
+        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
         tr.mark("host prefix + uploads + scans");
         uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
-        uint32_t* ql_g = ctx->arena.get<uint32_t>(NQ + 64);
         if (nt) {
             uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
             if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, pair_key, &n_slots);
             SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
-                       (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)toff_q, (const uint32_t*)pis, (const uint16_t*)pic,
-                       anc_q, anc_r, ql_g);
+                       (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)pis, anc_q, anc_r);
             check_launch("join_fill");
         }
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)d_pq0,
-                   (const uint32_t*)d_pc0, (const uint32_t*)anc_q, (const uint32_t*)ql_g, chunks, chunk_pair, n_chunks, d_err);
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0,
+                   (const uint32_t*)d_pc0, (const uint32_t*)anc_q, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         tr.mark("chunk");
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
@@ -1282,7 +1307,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         uint4* chunk_sums = ctx->arena.get<uint4>(NC + 1);
         if (NC) {
             SKH_LAUNCH(chunk_stats_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
-                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const uint32_t*)ql_g, c, k, chunk_est, chunk_w, chunk_sums);
+                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const unsigned long long*)imk, c, k, chunk_est, chunk_w, chunk_sums);
             check_launch("chunk_stats");
         }
         tr.mark("chunk_stats");
