@@ -106,48 +106,100 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, u
     head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void distinct_kernel(const uint64_t* keys, const uint32_t* head, const uint32_t* excl, uint64_t n,
-                                                       const uint64_t* pos_off, uint64_t* ent, uint16_t* u_cnt) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !head[i]) return;
-    const uint64_t key = keys[i];
-    uint32_t cnt = 1;
-    while (i + cnt < n && keys[i + cnt] == key) cnt++;
-    const uint32_t d = excl[i], g = (uint32_t)(key >> 32);
-    // one 8-byte entry answers a probe completely: hash | first entry in the seed-order arrays | multiplicity
-    ent[d] = ((key & 0xFFFFFFFFull) << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (cnt > 255u ? 255u : cnt);
-    u_cnt[d] = (uint16_t)(cnt > 65535u ? 65535u : cnt);
-}
-
-__global__ __launch_bounds__(256) void seed_order_gather_kernel(const uint64_t* keys, const uint32_t* vals, const uint32_t* head,
-                                                                const uint32_t* excl, uint64_t n, const uint64_t* pos_off,
-                                                                const uint32_t* p_g, const uint16_t* u_cnt, uint32_t* s_g, uint16_t* p_cnt) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t g = (uint32_t)(keys[i] >> 32);
-    const uint64_t src = pos_off[g] + vals[i];
-    s_g[i] = p_g[src];
-    p_cnt[src] = u_cnt[excl[i] + head[i] - 1];
-}
-
 __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
 }
 
-// Bucket directory: entry d (hash order) closes every bucket after its predecessor's up to its own; the genome's last
-// entry also closes the remaining buckets.  dir values are entry indices relative to the genome's first entry.
-__global__ __launch_bounds__(256) void dir_build_kernel(const uint64_t* ent, const uint64_t* dist_off, uint32_t ng, uint64_t n_dist, const uint64_t* dir_off,
-                                                        const uint32_t* n_buckets, uint32_t* dir) {
-    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n_dist) return;
-    const uint32_t g = seg_of(dist_off, ng, d);
-    const uint32_t ld = (uint32_t)(d - dist_off[g]), dg = (uint32_t)(dist_off[g + 1] - dist_off[g]), nbk = n_buckets[g];
-    uint32_t* dr = dir + dir_off[g];
-    const uint32_t b = seed_bucket((uint32_t)(ent[d] >> 32), nbk);
-    uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)(ent[d - 1] >> 32), nbk) + 1u;
-    for (uint32_t x = from; x <= b; x++) dr[x] = ld;
-    if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
+// ---- from the sorted records to the sketch tables, in tiles of 1024 records (256 threads x 4 consecutive records)
+constexpr uint32_t BT = 1024;
+// distinct (genome, hash) keys that START inside each tile
+__global__ __launch_bounds__(256) void tile_heads_kernel(const uint64_t* keys, uint64_t n, uint32_t* tile_cnt) {
+    __shared__ uint32_t lds[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * BT + 4u * threadIdx.x;
+    uint32_t c = 0;
+    if (i0 < n) {
+        uint64_t prev = i0 ? keys[i0 - 1] : ~keys[0];
+        for (uint32_t j = 0; j < 4 && i0 + j < n; j++) { const uint64_t k = keys[i0 + j]; c += k != prev ? 1u : 0u; prev = k; }
+    }
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+// number of distinct keys before each genome's first record
+__global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* keys, const uint32_t* tile_off, const uint64_t* pos_off, uint32_t ng, uint32_t* out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > ng) return;
+    const uint64_t x = pos_off[g], t0 = x / BT * BT;
+    uint32_t c = tile_off[x / BT];
+    for (uint64_t i = t0; i < x; i++) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    out[g] = c;
+}
+// One pass over the sorted records emits everything the probe side and the enumeration side need: the index entry of every
+// distinct seed (hash | first record | multiplicity), its directory buckets, the hash-order position array, and the per-position
+// multiplicity.  (Was: head flags + a device-wide scan over all records + three more passes.)
+__global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* tile_off, const uint64_t* pos_off,
+                                                          const uint64_t* dist_off, const uint64_t* dir_off, const uint32_t* n_buckets, const uint32_t* p_g,
+                                                          uint64_t* ent, uint32_t* dir, uint32_t* s_g, uint16_t* p_cnt) {
+    __shared__ uint32_t lds_scan[4];
+    __shared__ uint32_t run_cnt[BT + 1];                     // multiplicity of the run that starts at local distinct index x (slot BT: the run cut by the tile start)
+    const uint64_t i0 = (uint64_t)blockIdx.x * BT + 4u * threadIdx.x;
+    uint64_t k[4]; bool head[4]; uint32_t nh = 0;
+    {
+        uint64_t prev = (i0 && i0 < n) ? keys[i0 - 1] : 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            k[j] = i0 + j < n ? keys[i0 + j] : 0; head[j] = i0 + j < n && (i0 + j == 0 || k[j] != prev); prev = k[j]; nh += head[j] ? 1u : 0u;
+        }
+    }
+    const uint32_t incl = wave_incl_scan(nh), wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) lds_scan[wv] = incl;
+    // the run that reaches into this tile from the previous one: its multiplicity, found by one thread (runs are short; the
+    // count saturates at 65535 like p_cnt does)
+    if (threadIdx.x == 0 && i0 < n && !head[0]) {
+        uint64_t b = i0; uint32_t c = 0;
+        while (b > 0 && keys[b - 1] == k[0] && c < 65535u) { b--; c++; }
+        uint64_t e = i0; while (e < n && keys[e] == k[0] && c < 65535u) { e++; c++; }
+        run_cnt[BT] = c;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < wv; q++) before += lds_scan[q];
+    uint32_t li = before + incl - nh;                         // local index of this thread's first head
+    const uint32_t d0 = tile_off[blockIdx.x];
+    uint32_t lidx[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        if (head[j]) {
+            const uint64_t i = i0 + j;
+            uint32_t c = 1; while (i + c < n && keys[i + c] == k[j] && c < 65535u) c++;
+            run_cnt[li] = c;
+            const uint32_t g = (uint32_t)(k[j] >> 32), hash = (uint32_t)k[j];
+            const uint64_t d = (uint64_t)d0 + li;
+            // one 8-byte entry answers a probe completely: hash | first record in the hash-order array | multiplicity
+            ent[d] = ((uint64_t)hash << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (c > 255u ? 255u : c);
+            // directory: this entry closes every bucket after its predecessor's up to its own; the genome's last entry the rest
+            const uint32_t ld = (uint32_t)(d - dist_off[g]), dg = (uint32_t)(dist_off[g + 1] - dist_off[g]), nbk = n_buckets[g];
+            uint32_t* dr = dir + dir_off[g];
+            const uint32_t b = seed_bucket(hash, nbk);
+            const uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)keys[i - 1], nbk) + 1u;      // record i-1 belongs to the previous distinct seed
+            for (uint32_t x = from; x <= b; x++) dr[x] = ld;
+            if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
+            li++;
+        }
+        lidx[j] = li;                                         // heads seen so far in the tile (this record's run = lidx - 1; 0 = the cut run)
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint64_t i = i0 + j;
+        if (i >= n) break;
+        const uint32_t g = (uint32_t)(k[j] >> 32);
+        const uint64_t src = pos_off[g] + vals[i];
+        const uint32_t c = run_cnt[lidx[j] ? lidx[j] - 1 : BT];
+        s_g[i] = p_g[src]; p_cnt[src] = (uint16_t)c;
+    }
 }
 
 // bucket-occupancy bitmap: bit b of a genome's bitmap = bucket b holds at least one entry.  A wave turns 64 consecutive
@@ -196,7 +248,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     for (uint32_t g = 0; g < ng; g++)
         if (ss->pos_off[g + 1] - ss->pos_off[g] >= (1ull << 24)) throw Error("a genome with >= 2^24 seed positions does not fit the 24-bit table slot field");
     uint64_t D = 0;
-    uint16_t* u_cnt = nullptr;                                                        // multiplicity per distinct seed: build-time temporary
+    const uint64_t* sorted_keys = nullptr; const uint32_t* sorted_vals = nullptr; const uint32_t* sorted_tile_off = nullptr; uint32_t n_sorted_tiles = 0;
     if (P > 0) {
         if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
         uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P); uint32_t* keys32 = ctx->arena.get<uint32_t>(P);
@@ -215,29 +267,22 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
             check_launch("fixup_runs");
         }
         tr.mark("build: sort");
-        uint32_t* head = ctx->arena.get<uint32_t>(P); uint32_t* excl = ctx->arena.get<uint32_t>(P + 1);
-        SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, P, head);
-        check_launch("head_flags");
-        exclusive_scan_u32(ctx, head, P, excl);
+        const uint32_t n_bt = (uint32_t)((P + BT - 1) / BT);
+        uint32_t* tile_cnt = ctx->arena.get<uint32_t>(n_bt); uint32_t* tile_off = ctx->arena.get<uint32_t>(n_bt + 1);
+        SKH_LAUNCH(tile_heads_kernel, n_bt, 256, 0, ctx->stream, (const uint64_t*)keys, P, tile_cnt);
+        check_launch("tile_heads");
+        exclusive_scan_u32(ctx, tile_cnt, n_bt, tile_off);
         uint32_t* d_do = ctx->arena.get<uint32_t>(ng + 1);
-        SKH_LAUNCH(gather_u32_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)excl, (const uint64_t*)ss->d_pos_off.p, ng + 1, d_do);
-        check_launch("gather_u32");
+        SKH_LAUNCH(genome_dist_off_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)tile_off, (const uint64_t*)ss->d_pos_off.p, ng, d_do);
+        check_launch("genome_dist_off");
         std::vector<uint32_t> h_do(ng + 1);
         d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
         for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
         D = ss->dist_off[ng];
         tr.mark("build: heads + scan + readback");
-        u_cnt = ctx->arena.get<uint16_t>(D);
-        ss->ent.alloc(D);
-        SKH_LAUNCH(distinct_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)head, (const uint32_t*)excl, P,
-                   (const uint64_t*)ss->d_pos_off.p, ss->ent.p, u_cnt);
-        check_launch("distinct");
-        SKH_LAUNCH(seed_order_gather_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)vals, (const uint32_t*)head,
-                   (const uint32_t*)excl, P, (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->p_g.p, (const uint16_t*)u_cnt, ss->s_g.p, ss->p_cnt.p);
-        check_launch("seed_order_gather");
-        tr.mark("build: distinct + gather");
+        sorted_keys = keys; sorted_vals = vals; sorted_tile_off = tile_off; n_sorted_tiles = n_bt;
     }
-    else ss->ent.alloc(0);
+    ss->ent.alloc(D);
     // bucket directories (north-star requirement: per-sketch seed -> position tables built on device)
     ss->dir_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0);
     for (uint32_t g = 0; g < ng; g++) {
@@ -252,11 +297,13 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     bool any_empty = false;
     for (uint32_t g = 0; g < ng; g++) any_empty = any_empty || ss->dist_off[g + 1] == ss->dist_off[g];
     if (any_empty) dzero(ss->dir.p, ss->dir_off[ng] * 4, ctx->stream);                // genomes without seeds: every bucket empty
-    if (D > 0) {
-        SKH_LAUNCH(dir_build_kernel, (unsigned)((D + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->ent.p, (const uint64_t*)ss->d_dist_off.p, ng, D,
-                   (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, ss->dir.p);
-        check_launch("dir_build");
+    if (P > 0) {
+        SKH_LAUNCH(emit_tables_kernel, n_sorted_tiles, 256, 0, ctx->stream, sorted_keys, sorted_vals, P, sorted_tile_off, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)ss->p_g.p, ss->ent.p, ss->dir.p,
+                   ss->s_g.p, ss->p_cnt.p);
+        check_launch("emit_tables");
     }
+    tr.mark("build: entries + directory + gather");
     ss->bmap_off.assign(ng + 1, 0);
     for (uint32_t g = 0; g < ng; g++) ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)ss->n_buckets[g] + 31) / 32 + 3) / 4 * 4;   // whole 16-byte groups
     const uint64_t BW = ss->bmap_off[ng];
