@@ -127,14 +127,15 @@ __global__ __launch_bounds__(256) void tile_heads_kernel(const uint64_t* keys, u
     __syncthreads();
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
-// number of distinct keys before each genome's first record
+// number of distinct keys before each genome's first record (one wave per genome boundary)
 __global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* keys, const uint32_t* tile_off, const uint64_t* pos_off, uint32_t ng, uint32_t* out) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g > ng) return;
     const uint64_t x = pos_off[g], t0 = x / BT * BT;
-    uint32_t c = tile_off[x / BT];
-    for (uint64_t i = t0; i < x; i++) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-    out[g] = c;
+    uint32_t c = 0;
+    for (uint64_t i = t0 + lane_id(); i < x; i += 64) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    c = wave_sum(c);
+    if (lane_id() == 0) out[g] = c + tile_off[x / BT];
 }
 // One pass over the sorted records emits everything the probe side and the enumeration side need: the index entry of every
 // distinct seed (hash | first record | multiplicity), its directory buckets, the hash-order position array, and the per-position
@@ -273,7 +274,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         check_launch("tile_heads");
         exclusive_scan_u32(ctx, tile_cnt, n_bt, tile_off);
         uint32_t* d_do = ctx->arena.get<uint32_t>(ng + 1);
-        SKH_LAUNCH(genome_dist_off_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)tile_off, (const uint64_t*)ss->d_pos_off.p, ng, d_do);
+        SKH_LAUNCH(genome_dist_off_kernel, (ng + 1 + 3) / 4, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)tile_off, (const uint64_t*)ss->d_pos_off.p, ng, d_do);
         check_launch("genome_dist_off");
         std::vector<uint32_t> h_do(ng + 1);
         d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
