@@ -143,63 +143,66 @@ __global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* ke
 __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* tile_off, const uint64_t* pos_off,
                                                           const uint64_t* dist_off, const uint64_t* dir_off, const uint32_t* n_buckets, const uint32_t* p_g,
                                                           uint64_t* ent, uint32_t* dir, uint32_t* s_g, uint16_t* p_cnt) {
-    __shared__ uint32_t lds_scan[4];
+    constexpr int R = BT / 256;
+    __shared__ uint32_t lds_scan[R * 4];
     __shared__ uint32_t run_cnt[BT + 1];                     // multiplicity of the run that starts at local distinct index x (slot BT: the run cut by the tile start)
-    const uint64_t i0 = (uint64_t)blockIdx.x * BT + 4u * threadIdx.x;
-    uint64_t k[4]; bool head[4]; uint32_t nh = 0;
-    {
-        uint64_t prev = (i0 && i0 < n) ? keys[i0 - 1] : 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * BT;
+    const uint32_t wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // record (r, thread) = t0 + 256 r + thread: every load below is coalesced and the four rounds' loads are independent
+    uint64_t k[R], kp[R]; uint32_t head[R], incl[R];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            k[j] = i0 + j < n ? keys[i0 + j] : 0; head[j] = i0 + j < n && (i0 + j == 0 || k[j] != prev); prev = k[j]; nh += head[j] ? 1u : 0u;
-        }
+    for (int r = 0; r < R; r++) {
+        const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
+        k[r] = i < n ? keys[i] : 0; kp[r] = (i > 0 && i < n) ? keys[i - 1] : 0;
+        head[r] = (i < n && (i == 0 || k[r] != kp[r])) ? 1u : 0u;
     }
-    const uint32_t incl = wave_incl_scan(nh), wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) lds_scan[wv] = incl;
+#pragma unroll
+    for (int r = 0; r < R; r++) { incl[r] = wave_incl_scan(head[r]); if (l == 63) lds_scan[r * 4 + wv] = incl[r]; }
     // the run that reaches into this tile from the previous one: its multiplicity, found by one thread (runs are short; the
     // count saturates at 65535 like p_cnt does)
-    if (threadIdx.x == 0 && i0 < n && !head[0]) {
-        uint64_t b = i0; uint32_t c = 0;
+    if (threadIdx.x == 0 && t0 < n && !head[0]) {
+        uint64_t b = t0; uint32_t c = 0;
         while (b > 0 && keys[b - 1] == k[0] && c < 65535u) { b--; c++; }
-        uint64_t e = i0; while (e < n && keys[e] == k[0] && c < 65535u) { e++; c++; }
+        uint64_t e = t0; while (e < n && keys[e] == k[0] && c < 65535u) { e++; c++; }
         run_cnt[BT] = c;
     }
     __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t q = 0; q < wv; q++) before += lds_scan[q];
-    uint32_t li = before + incl - nh;                         // local index of this thread's first head
     const uint32_t d0 = tile_off[blockIdx.x];
-    uint32_t lidx[4];
+    uint32_t lidx[R], base = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        if (head[j]) {
-            const uint64_t i = i0 + j;
-            uint32_t c = 1; while (i + c < n && keys[i + c] == k[j] && c < 65535u) c++;
-            run_cnt[li] = c;
-            const uint32_t g = (uint32_t)(k[j] >> 32), hash = (uint32_t)k[j];
-            const uint64_t d = (uint64_t)d0 + li;
+    for (int r = 0; r < R; r++) {
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { const uint32_t x = lds_scan[r * 4 + q]; if (q < wv) before += x; tot += x; }
+        lidx[r] = base + before + incl[r];                    // heads up to and including this record (this record's run = lidx - 1; 0 = the cut run)
+        base += tot;
+        if (head[r]) {
+            const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
+            uint32_t c = 1; while (i + c < n && keys[i + c] == k[r] && c < 65535u) c++;
+            run_cnt[lidx[r] - 1] = c;
+            const uint32_t g = (uint32_t)(k[r] >> 32), hash = (uint32_t)k[r];
+            const uint64_t d = (uint64_t)d0 + lidx[r] - 1;
             // one 8-byte entry answers a probe completely: hash | first record in the hash-order array | multiplicity
             ent[d] = ((uint64_t)hash << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (c > 255u ? 255u : c);
             // directory: this entry closes every bucket after its predecessor's up to its own; the genome's last entry the rest
             const uint32_t ld = (uint32_t)(d - dist_off[g]), dg = (uint32_t)(dist_off[g + 1] - dist_off[g]), nbk = n_buckets[g];
             uint32_t* dr = dir + dir_off[g];
             const uint32_t b = seed_bucket(hash, nbk);
-            const uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)keys[i - 1], nbk) + 1u;      // record i-1 belongs to the previous distinct seed
+            const uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)kp[r], nbk) + 1u;       // record i-1 belongs to the previous distinct seed
             for (uint32_t x = from; x <= b; x++) dr[x] = ld;
             if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
-            li++;
         }
-        lidx[j] = li;                                         // heads seen so far in the tile (this record's run = lidx - 1; 0 = the cut run)
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        const uint64_t i = i0 + j;
-        if (i >= n) break;
-        const uint32_t g = (uint32_t)(k[j] >> 32);
-        const uint64_t src = pos_off[g] + vals[i];
-        const uint32_t c = run_cnt[lidx[j] ? lidx[j] - 1 : BT];
-        s_g[i] = p_g[src]; p_cnt[src] = (uint16_t)c;
+    for (int r = 0; r < R; r++) {
+        const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
+        if (i < n) {
+            const uint32_t g = (uint32_t)(k[r] >> 32);
+            const uint64_t src = pos_off[g] + vals[i];
+            const uint32_t c = run_cnt[lidx[r] ? lidx[r] - 1 : BT];
+            s_g[i] = p_g[src]; p_cnt[src] = (uint16_t)c;
+        }
     }
 }
 
