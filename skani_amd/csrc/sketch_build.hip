@@ -26,20 +26,33 @@ __device__ __forceinline__ uint32_t seg_of(const uint64_t* off, uint32_t n_seg, 
 // many leading hash bits as fit beside it (stable, so equal keys stay in position order): four passes over 8-byte records
 // instead of six over 12-byte ones.  The full 64-bit keys (genome << 32 | hash) are rebuilt afterwards and the rare runs that
 // still mix several hashes under one 32-bit key are put in order in place (fixup_runs_kernel).
+// When the position index needs few bits (idx_bits), the hash bits that do not fit the 32-bit key ride in the value's upper
+// bits (carry = 1), so the full hash comes back after the sort without a gather: value = low hash bits << idx_bits | index.
 __global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
-                                                             uint32_t* keys32, uint32_t* vals) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                             uint32_t idx_bits, uint32_t carry, uint32_t* keys32, uint32_t* vals) {
+    __shared__ uint32_t g0;
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) g0 = seg_of(pos_off, ng, i0);                              // one search per workgroup; its records span few genomes
+    __syncthreads();
+    const uint64_t i = i0 + threadIdx.x;
     if (i >= n) return;
-    uint32_t g = seg_of(pos_off, ng, i);
-    keys32[i] = hash_bits >= 32 ? mix32(p_seed[i]) : ((g << hash_bits) | (mix32(p_seed[i]) >> (32u - hash_bits)));
-    vals[i] = (uint32_t)(i - pos_off[g]);
+    uint32_t g = g0;
+    while (i >= pos_off[g + 1]) g++;
+    const uint32_t h = mix32(p_seed[i]), idx = (uint32_t)(i - pos_off[g]);
+    keys32[i] = hash_bits >= 32 ? h : ((g << hash_bits) | (h >> (32u - hash_bits)));
+    vals[i] = carry ? (((h & ((1u << (32u - hash_bits)) - 1u)) << idx_bits) | idx) : idx;
 }
 __global__ __launch_bounds__(256) void full_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
-                                                        const uint32_t* keys32, const uint32_t* vals, uint64_t* keys) {
+                                                        uint32_t idx_bits, uint32_t carry, const uint32_t* keys32, uint32_t* vals, uint64_t* keys) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t g = hash_bits >= 32 ? 0u : keys32[i] >> hash_bits;
-    keys[i] = ((uint64_t)g << 32) | mix32(p_seed[pos_off[g] + vals[i]]);
+    const uint32_t k32 = keys32[i], v = vals[i];
+    const uint32_t g = hash_bits >= 32 ? 0u : k32 >> hash_bits;
+    uint32_t h;
+    if (hash_bits >= 32) h = k32;
+    else if (carry) { h = ((k32 & ((1u << hash_bits) - 1u)) << (32u - hash_bits)) | (v >> idx_bits); vals[i] = v & ((1u << idx_bits) - 1u); }
+    else h = mix32(p_seed[pos_off[g] + v]);
+    keys[i] = ((uint64_t)g << 32) | h;
 }
 // One thread per run of equal 32-bit keys: orders the run by (full key, position index).  Runs are almost always one seed
 // (already in order); insertion sort costs one pass then.  Long runs that do mix hashes get an in-place heapsort.
@@ -260,11 +273,14 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         const uint32_t gbits = ng > 1 ? (uint32_t)bits_for(ng) : 0u;
         const uint32_t hash_bits = std::max<uint32_t>(ctx->tune.build_hash_bits ? std::min<uint32_t>(ctx->tune.build_hash_bits, 32u - gbits) : 32u - gbits, 1u);
         if (gbits >= 32) throw Error("too many genomes in one sketch set");
-        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, keys32, vals);
+        uint64_t max_pos = 1; for (uint32_t g = 0; g < ng; g++) max_pos = std::max<uint64_t>(max_pos, ss->pos_off[g + 1] - ss->pos_off[g]);
+        const uint32_t idx_bits = (uint32_t)bits_for(max_pos);
+        const uint32_t carry = (hash_bits < 32 && idx_bits + (32u - hash_bits) <= 32u && !ctx->tune.build_hash_bits) ? 1u : 0u;
+        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, idx_bits, carry, keys32, vals);
         check_launch("make_seed_keys");
         tr.mark("build: allocs + keys");
         sort_pairs_u32_u32(ctx, keys32, vals, P, (int)(hash_bits >= 32 ? 32 : hash_bits + gbits));
-        SKH_LAUNCH(full_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, (const uint32_t*)keys32, (const uint32_t*)vals, keys);
+        SKH_LAUNCH(full_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, idx_bits, carry, (const uint32_t*)keys32, vals, keys);
         check_launch("full_keys");
         if (hash_bits < 32) {
             SKH_LAUNCH(fixup_runs_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)keys32, P, keys, vals);
