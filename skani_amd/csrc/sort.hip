@@ -34,17 +34,17 @@ void sort_pairs_u64_u32(skh_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n
 #endif
 }
 
-void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t* keys, uint32_t* vals, uint64_t n, int end_bit) {
+void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit) {
     if (n < 2) return;
 #ifndef SKANI_EMU
+    // sorted output lands in fresh arena arrays; the caller's pointers are redirected instead of copying 8 B per record back
     uint32_t* keys_out = ctx->arena.get<uint32_t>(n);
     uint32_t* vals_out = ctx->arena.get<uint32_t>(n);
     size_t tmp_bytes = 0;
     hip_check(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, end_bit, ctx->stream), "radix_sort_pairs size");
     void* tmp = ctx->arena.take(tmp_bytes);
     hip_check(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, end_bit, ctx->stream), "radix_sort_pairs");
-    d2d(keys, keys_out, n * sizeof(uint32_t), ctx->stream);
-    d2d(vals, vals_out, n * sizeof(uint32_t), ctx->stream);
+    keys = keys_out; vals = vals_out;
 #else
     (void)ctx; (void)end_bit;
     std::vector<uint64_t> idx(n); std::iota(idx.begin(), idx.end(), 0);
