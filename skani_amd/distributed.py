@@ -2,14 +2,16 @@
 
 The path shards: sketching is per genome, chaining per pair.  Genomes are block-distributed; every rank
 sketches its own block.  Exchange steps:
-  1. all-gather of the MARKER sets + per-genome metadata only (~40 KB per 5 Mbp genome); every rank then screens ITS OWN
-     rows against all genomes (an n_local x N count matrix: the per-rank screening cost stays flat as ranks are added);
+  1. all-gather of the MARKER sets + two numbers per genome (~40 KB per 5 Mbp genome); every rank then screens ITS OWN
+     rows against all later genomes (an n_local x N block of the triangle's screen: the per-rank screening cost stays
+     nearly flat as ranks are added);
   2. pair (i, j), i < j, is owned by the rank that owns genome i; a rank therefore needs the full sketch of a remote
-     genome j only when a candidate pair crosses blocks.  The ranks tell each other which genomes they need (one small
-     all-to-all) and exactly those sketches travel point-to-point (all-to-all of variable-size buffers).  For
-     clade-structured collections almost nothing moves; in the worst case (every pair crosses) it degenerates to an
-     all-gather of the raw sketches.
-No collective inside the pair pipeline; the (small) results are gathered on rank 0."""
+     genome j only when a candidate pair crosses blocks.  One all-reduce tells whether any pair does; only then do the ranks
+     tell each other which genomes they need and exactly those sketches travel point-to-point (all-to-all of
+     variable-size buffers).  For clade-structured collections nothing moves; in the worst case (every pair crosses) it
+     degenerates to an all-gather of the raw sketches.
+No collective inside the pair pipeline; the (small) results are all-gathered at the end.  Every collective is a tensor
+collective (all_gather / all_reduce / all_to_all_single): five per triangle in the common case."""
 import pickle
 
 import numpy as np
@@ -34,39 +36,44 @@ def _all_to_all_bytes(dist, torch, device, payloads):
     return out
 
 
+def _all_gather_padded(dist, torch, device, t, sizes):
+    """all-gather of 1-D tensors of different lengths (sizes[r] known everywhere): pad to the longest, gather, cut."""
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=device)
+    if t.numel():
+        pad[:t.numel()] = t
+    parts = [torch.empty_like(pad) for _ in sizes]
+    dist.all_gather(parts, pad)
+    return [parts[r][:sizes[r]] for r in range(len(sizes))]
+
+
 def _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device):
-    """All-gather of the marker sets (flat arrays, no per-genome work): returns a markers-only SketchSet of ALL genomes whose
-    genome order is rank order.  On GPUs the markers stay in device memory end to end (export -> RCCL all_gather -> import)."""
+    """All-gather of the marker sets: returns a markers-only SketchSet of ALL genomes (genome order = rank order) for the
+    screen.  On GPUs the markers stay in device memory end to end (export -> RCCL all_gather -> import).  Contig tables are
+    not needed for screening: every genome is entered as one contig of its total length."""
     n_local = len(ss_local)
     meta = ss_local.export_meta()
-    _, M, NC = ss_local.totals()
+    _, M, _ = ss_local.totals()
     on_dev = device.type == "cuda"
-    sizes = torch.tensor([M, NC], dtype=torch.int64, device=device)
-    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    Ms = [int(x[0]) for x in all_sizes]
-    max_m = max(max(Ms), 1)
-    mk = torch.zeros(max_m, dtype=torch.int64, device=device)                       # u64 bit patterns
+    mine = torch.from_numpy(np.concatenate([np.diff(meta["marker_off"]).astype(np.int64), meta["total_len"].astype(np.int64)])).to(device)
+    allmeta = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allmeta, mine)                                                   # collective 1: marker counts + total lengths
+    allmeta = [m.cpu().numpy() for m in allmeta]
+    counts = np.concatenate([m[:n_local] for m in allmeta]).astype(np.uint64); total_len = np.concatenate([m[n_local:] for m in allmeta]).astype(np.uint64)
+    Ms = [int(m[:n_local].sum()) for m in allmeta]
+    mk = torch.zeros(max(M, 1), dtype=torch.int64, device=device)                   # u64 bit patterns
     if M:
         if on_dev:
             torch.cuda.synchronize(device)                                          # the library copies on its own stream: torch's fill must have landed
             ss_local.export_arrays(markers=mk.data_ptr(), device=True)
         else:
             ss_local.export_arrays(markers=mk.numpy().view(np.uint64))
-    parts = [torch.empty_like(mk) for _ in range(world)]
-    dist.all_gather(parts, mk)
-    allmk = torch.cat([parts[r][:Ms[r]] for r in range(world)]) if sum(Ms) else torch.zeros(1, dtype=torch.int64, device=device)
-    small = [None] * world                                                          # a few KB per rank: offsets, contig lengths, total lengths
-    dist.all_gather_object(small, (meta["marker_off"], meta["contig_off"], meta["contig_lengths"], meta["total_len"]))
+    parts = _all_gather_padded(dist, torch, device, mk[:M], Ms)                      # collective 2: the markers
+    allmk = torch.cat(parts) if sum(Ms) else torch.zeros(1, dtype=torch.int64, device=device)
     n_total = n_local * world
-    mo = np.zeros(n_total + 1, np.uint64); co = np.zeros(n_total + 1, np.uint64)
-    g = 0
-    for (m_off, c_off, _, _) in small:
-        k = len(m_off) - 1
-        mo[g + 1:g + k + 1] = mo[g] + m_off[1:]; co[g + 1:g + k + 1] = co[g] + c_off[1:]; g += k
-    gmeta = dict(pos_off=np.zeros(n_total + 1, np.uint64), marker_off=mo, contig_off=co,
-                 contig_lengths=np.concatenate([x[2] for x in small]).astype(np.uint32), total_len=np.concatenate([x[3] for x in small]).astype(np.uint64),
-                 genome_rank=np.arange(n_total, dtype=np.uint32))
+    mo = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    gmeta = dict(pos_off=np.zeros(n_total + 1, np.uint64), marker_off=mo, contig_off=np.arange(n_total + 1, dtype=np.uint64),
+                 contig_lengths=np.minimum(total_len, np.uint64(0x7FFF0000)).astype(np.uint32), total_len=total_len, genome_rank=np.arange(n_total, dtype=np.uint32))
     if on_dev:
         torch.cuda.synchronize(device)
         return ctx.import_flat(params, gmeta, markers=allmk.data_ptr(), device=True), allmk
@@ -86,35 +93,37 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         device = torch.device("cpu")
     n_local = len(ss_local)
     base = rank * n_local
-    # 1. markers + metadata of every genome, everywhere; this rank screens its rows (local genomes i) against all later
-    #    genomes j > i: an n_local x N block of the triangle's screen (triangle.rs:55-90)
+    # 1. markers of every genome, everywhere; this rank screens its rows (local genomes i) against all later genomes j > i:
+    #    an n_local x N block of the triangle's screen (triangle.rs:55-90)
     markers_only, _keep = _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device)
     gi, gj = ctx.screen_rows(markers_only, base, n_local, identity, rescue_small)
     markers_only.close()
     owner_j = gj // n_local
-    # 2. sketches of remote partners j of my rows i: requests out, sketches back
-    requests = [pickle.dumps(np.unique(gj[owner_j == r]) if r != rank else np.zeros(0, np.uint32), protocol=4) for r in range(world)]
-    wanted = [pickle.loads(b) for b in _all_to_all_bytes(dist, torch, device, requests)]      # wanted[r]: my genomes that rank r needs
-    payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in wanted]
-    received = _all_to_all_bytes(dist, torch, device, payloads)
+    # 2. sketches of remote partners j of my rows i -- only if some pair, anywhere, crosses blocks
+    need = [np.unique(gj[owner_j == r]) if r != rank else np.zeros(0, np.uint32) for r in range(world)]
+    crossing = torch.tensor([sum(len(x) for x in need)], dtype=torch.int64, device=device)
+    dist.all_reduce(crossing)                                                        # collective 3
     remote = {}
-    for blob in received:
-        for g, rec in pickle.loads(blob):
-            remote[g] = rec
+    if int(crossing.item()) > 0:
+        requests = [pickle.dumps(x, protocol=4) for x in need]
+        wanted = [pickle.loads(b) for b in _all_to_all_bytes(dist, torch, device, requests)]      # wanted[r]: my genomes that rank r needs
+        payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in wanted]
+        for blob in _all_to_all_bytes(dist, torch, device, payloads):
+            for g, rec in pickle.loads(blob):
+                remote[g] = rec
     rem_ids = sorted(remote)
     rem_index = {g: k for k, g in enumerate(rem_ids)}
-    li, lj = gi, gj
-    local_pair = (lj // n_local) == rank
+    local_pair = owner_j == rank
     res_parts = []
     n_chained = int(len(gi))
     if local_pair.any():
-        r = ctx.chain_pairs(ss_local, None, li[local_pair] - base, lj[local_pair] - base, map_params)
-        res_parts.append((li[local_pair], lj[local_pair], r))
+        r = ctx.chain_pairs(ss_local, None, gi[local_pair] - base, gj[local_pair] - base, map_params)
+        res_parts.append((gi[local_pair], gj[local_pair], r))
     if (~local_pair).any():
         ss_rem = ctx.import_sketches(params, [remote[g] for g in rem_ids], genome_rank=np.array(rem_ids, dtype=np.uint32))
-        qi = np.array([rem_index[int(g)] for g in lj[~local_pair]], dtype=np.uint32)
-        r = ctx.chain_pairs(ss_local, ss_rem, li[~local_pair] - base, qi, map_params)      # ref = genome i (local), query = genome j (remote)
-        res_parts.append((li[~local_pair], lj[~local_pair], r))
+        qi = np.array([rem_index[int(g)] for g in gj[~local_pair]], dtype=np.uint32)
+        r = ctx.chain_pairs(ss_local, ss_rem, gi[~local_pair] - base, qi, map_params)      # ref = genome i (local), query = genome j (remote)
+        res_parts.append((gi[~local_pair], gj[~local_pair], r))
         ss_rem.close()
     if res_parts:
         ai = np.concatenate([p[0] for p in res_parts]); aj = np.concatenate([p[1] for p in res_parts]); ar = np.concatenate([p[2] for p in res_parts])
@@ -122,11 +131,19 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         ai, aj, ar = ai[keep], aj[keep], ar[keep]
     else:
         ai = np.zeros(0, np.uint32); aj = np.zeros(0, np.uint32); ar = np.zeros(0, B.RESULT_DTYPE)
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object((ai, aj, ar, n_chained), parts, dst=0)
+    # 3. results: (i, j, record) rows as bytes, all-gathered
+    rec = np.zeros(len(ai), np.dtype([("i", np.uint32), ("j", np.uint32), ("r", B.RESULT_DTYPE)]))
+    rec["i"] = ai; rec["j"] = aj; rec["r"] = ar
+    counts = torch.tensor([rec.nbytes, n_chained], dtype=torch.int64, device=device)
+    allc = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)                                                    # collective 4
+    allc = [c.cpu().numpy() for c in allc]
+    payload = torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy()).to(device) if rec.nbytes else torch.zeros(0, dtype=torch.uint8, device=device)
+    parts = _all_gather_padded(dist, torch, device, payload, [int(c[0]) for c in allc])    # collective 5
+    n_total_chained = int(sum(int(c[1]) for c in allc))
     if rank != 0:
-        return None, None, None, n_chained
-    ai = np.concatenate([p[0] for p in parts]); aj = np.concatenate([p[1] for p in parts])
-    ar = np.concatenate([p[2] for p in parts]).view(B.RESULT_DTYPE)
-    order = np.lexsort((aj, ai))
-    return ai[order].astype(np.uint32), aj[order].astype(np.uint32), ar[order], sum(p[3] for p in parts)
+        return None, None, None, n_total_chained
+    allrec = np.concatenate([np.frombuffer(p.cpu().numpy().tobytes(), rec.dtype) for p in parts])
+    order = np.lexsort((allrec["j"], allrec["i"]))
+    allrec = allrec[order]
+    return allrec["i"].astype(np.uint32), allrec["j"].astype(np.uint32), allrec["r"].copy(), n_total_chained

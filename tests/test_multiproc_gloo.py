@@ -15,14 +15,17 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _test_genomes():
-    """3 clades x 4 members, interleaved so that most candidate pairs cross the two rank blocks."""
+def _test_genomes(interleave=True):
+    """interleave: 3 clades x 4 members dealt out so that most candidate pairs cross the two rank blocks (sketches travel);
+    otherwise 2 clades x 6, one per rank: no pair crosses and the exchange of sketches is skipped altogether."""
     from tests.parity_cases import synthetic_clades
+    if not interleave:
+        return synthetic_clades(n_clades=2, members=6, length=60000, seed=61, tiny=False)
     g = synthetic_clades(n_clades=3, members=4, length=60000, seed=51, tiny=False)
     return [g[(k % 3) * 4 + k // 3] for k in range(12)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, interleave=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -33,7 +36,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ctx = sk.Context(0, lib=emu_lib())
-        genomes = _test_genomes()
+        genomes = _test_genomes(interleave)
         per = len(genomes) // world
         mine = genomes[rank * per:(rank + 1) * per]
         params = sk.SketchParams()
@@ -46,7 +49,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_triangle_matches_single_process():
+@pytest.mark.parametrize("interleave", [True, False])
+def test_two_rank_triangle_matches_single_process(interleave):
     import multiprocessing as mp
     import skani_amd as sk
     from tests.emu_lib import emu_lib
@@ -55,13 +59,13 @@ def test_two_rank_triangle_matches_single_process():
     emu_lib()   # build once before forking workers
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue(); port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
     for p in procs:
         p.start()
     i, j, res, n = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60); assert p.exitcode == 0
-    genomes = _test_genomes()
+    genomes = _test_genomes(interleave)
     # oracle: genome ranks are the global indices (names sort like indices)
     osk = [ora.sketch_records(g, file_name="g%03d" % k) for k, g in enumerate(genomes)]
     oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
