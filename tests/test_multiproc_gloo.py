@@ -77,3 +77,48 @@ def test_two_rank_triangle_matches_single_process(interleave):
     ss = ctx.sketch_records(genomes, sk.SketchParams(), None)
     si, sj, sres, sn = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
     assert np.array_equal(si, i) and np.array_equal(sj, j) and sres.tobytes() == res.tobytes()
+
+
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import skani_amd as sk
+    from skani_amd.distributed import distributed_triangle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        ctx = sk.Context(0)
+        genomes = _test_genomes(interleave=False)
+        per = len(genomes) // world
+        mine = genomes[rank * per:(rank + 1) * per]
+        params = sk.SketchParams()
+        gs = ctx.pack_genomes([[s for _, s in g] for g in mine], params.seeding_mode)
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(rank * per, (rank + 1) * per)))
+        i, j, res, n = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, torch=torch, device=dev)
+        if rank == 0:
+            q.put((i, j, res, n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_device_tensors_on_one_gpu():
+    """The device-memory path of the exchange (export into torch CUDA tensors -> all_gather -> import from the gathered tensor,
+    results gathered as CUDA byte tensors): two processes share the one GPU, collectives by gloo (RCCL needs one GPU per rank)."""
+    import multiprocessing as mp
+    import skani_amd as sk
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue(); port = _free_port()
+    procs = [ctxm.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    i, j, res, n = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120); assert p.exitcode == 0
+    genomes = _test_genomes(interleave=False)
+    ctx = sk.Context(0)
+    ss = ctx.sketch_records(genomes, sk.SketchParams(), None)
+    si, sj, sres, sn = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    assert sn == n and np.array_equal(si, i) and np.array_equal(sj, j) and sres.tobytes() == res.tobytes() and len(i) > 0
