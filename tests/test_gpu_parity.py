@@ -157,6 +157,7 @@ def test_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_CHAIN_ANCHORS", "3000")
     monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
     monkeypatch.setenv("SKH_TUNE_CHAIN_DP_LDS_SLOTS", "1")
+    monkeypatch.setenv("SKH_TUNE_JOIN_BITMAP_WORDS", "8")                # genomes with more than 256 buckets probe without the staged bitmap
     monkeypatch.setenv("SKH_TUNE_BUILD_HASH_BITS", "3")                 # long mixed runs: exercises the run fix-up incl. its heapsort
     c = sk.Context(0)
     try:
