@@ -551,15 +551,23 @@ constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidat
 //   LDS per wave is 36 B x CAP; the kernel is instantiated for CAP = 256 / 512 / 1024 and a pair runs in the smallest one that
 //   holds it, so that typical pairs (a few hundred candidates) leave room for 2-3 waves per SIMD: the greedy loop is a chain
 //   of dependent instructions, and other waves are the only thing that can fill its issue slots.
+//   Pairs are handed out by decreasing candidate count (greedy_order_keys_kernel + a 16-bit radix sort): the kernel ends when its
+//   slowest wave does, so the long ones start first.
 struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1, pad0, pad1; };   // 32 B: two 16-byte LDS broadcasts per accepted interval
+__global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint64_t* keys, uint32_t* vals) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t n = ivl_cnt[p];
+    keys[p] = 0xFFFFu - (n > 0xFFFFu ? 0xFFFFu : n); vals[p] = p;
+}
 template <uint32_t CAP>
-__global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt, const Interval* ivls,
-                                                          uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+__global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                          const Interval* ivls, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ uint32_t lds_idx[2][CAP];
     __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t p = blockIdx.x * 2 + wv;
-    if (p >= n_pairs) return;
+    if (blockIdx.x * 2 + wv >= n_pairs) return;
+    const uint32_t p = order[blockIdx.x * 2 + wv];
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
@@ -1294,9 +1302,13 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 check_launch("interval_emit");
             }
         }
-#define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, (const uint32_t*)ivl_cnt, \
-                   (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
+#define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
+                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
         tr.mark("dp (+order sort)");
+        uint64_t* g_keys = ctx->arena.get<uint64_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
+        SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);
+        check_launch("greedy_order_keys");
+        sort_pairs_u64_u32(ctx, g_keys, g_order, np, 16);
         SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
 #undef SKH_GREEDY
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
