@@ -290,14 +290,25 @@ def main():
         "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence), -c %d -k %d -m %d -s 80, learned ANI on"
                                % (n_total, args.mean_len / 1e6, CLADE, C, K, M),
                    "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
-                   "kept_pairs": kept, "parallelism": "genomes block-sharded for sketching, pairs round-robin for chaining, 1 all-gather"},
+                   "kept_pairs": kept, "parallelism": "genomes block-sharded; every rank screens and chains the pairs of its own rows; markers all-gathered"},
         "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms")},
         "roofline": {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": traffic, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch, "launches_per_step": launches / args.steps,
                      "note": "0.354 algorithmic B/base; kernel is VALU-bound (64-bit hash mix per base), see DESIGN.md"},
     }
+    # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
+    # (~0.96 MB per pair of 5 Mbp genomes at c=125)
+    chain_s = tm["chain_ms"] / args.steps * 1e-3
+    if chain_s > 0 and chained:
+        chain_bytes = 12.0 * 2.0 * (total_bases_local / max(n_local, 1) / C) * (chained / world)
+        out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate (8 kernels)", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
+                                 "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes,
+                                 "note": "irregular, latency-bound stages: per-kernel traffic and occupancy in profiles/r01_pmc_v9.md"}
     if host_genomes:
         out["cpu_baseline"] = cpu_baseline(host_genomes, n_total, chained, os.cpu_count() or 1, last.get("result"))
+        # skani's default thread count (-t 3, cli.rs:243) on one clade of the same sample, for a like-for-like default
+        few = cpu_baseline(host_genomes[:CLADE], n_total, chained, 3, None)
+        out["cpu_baseline"]["default_threads"] = {"cores": 3, "value": few["value"], "sample": few["sample"]}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
