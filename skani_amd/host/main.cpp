@@ -26,6 +26,7 @@ struct Args {
     bool robust = false, median = false, no_learned = false, fast = false, slow = false, medium = false, small_genomes = false, faster_small = false;
     bool sparse = false, individual = false, qi = false, ri = false, marker_index = false, no_marker_index = false, separate_sketches = false;
     size_t n = 10000000; int threads = 3, device = 0, seeding_mode = SKH_SEED_AVX2;
+    uint64_t shard_positions = 1500000000ull;                                     // seed positions per resident database shard (search)
     OutOpts o;
 };
 
@@ -82,6 +83,7 @@ Args parse(int argc, char** argv) {
         else if (x == "--no-marker-index") a.no_marker_index = true;
         else if (x == "--separate-sketches") a.separate_sketches = true;
         else if (x == "-d") a.database = need(i);
+        else if (x == "--shard-positions") a.shard_positions = (uint64_t)atoll(need(i).c_str());
         else if (x == "--keep-refs") {}                                        // every reference sketch is HBM-resident anyway
         else if (x == "--device") a.device = atoi(need(i).c_str());
         else if (x == "--seeding") { std::string v = need(i); a.seeding_mode = v == "scalar" ? SKH_SEED_SCALAR : SKH_SEED_AVX2; }
@@ -285,9 +287,27 @@ int run_search(Args& a, Ctx& cx) {                                              
     try { db = read_sketch_db(a.database); } catch (const std::exception& e) { die(e.what()); }
     if (db.sketches.empty()) die("No reference sketches found in the database folder.");
     a.c = (uint32_t)db.params.c; a.k = (uint32_t)db.params.k; a.m = (uint32_t)db.params.marker_c;   // queries follow the database's parameters (search.rs:37,115-125)
-    // the database order is the index order; the whole thing becomes one HBM-resident set
-    skh_sketch_set* sr = import_blobs(cx, db.params, db.sketches, a.seeding_mode);
+    // the database order is the index order.  The sketches become HBM-resident shards (one sketch-set build handles < 2^32
+    // seed positions; --shard-positions bounds a shard), the markers of the whole database one markers-only set that is screened
+    // with a single call, and the hits of all shards are chained in one batch.
     std::vector<GenomeInfo> rinfo = infos_of(db.sketches);
+    std::vector<skh_sketch_set*> shards; std::vector<uint32_t> shard_of(db.sketches.size()), local_of(db.sketches.size());
+    {
+        std::vector<SketchBlob> part; uint64_t npos = 0;
+        auto flush = [&]() { if (part.empty()) return; shards.push_back(import_blobs(cx, db.params, part, a.seeding_mode)); part.clear(); npos = 0; };
+        for (size_t g = 0; g < db.sketches.size(); g++) {
+            if (!part.empty() && npos + db.sketches[g].records.size() > a.shard_positions) flush();
+            shard_of[g] = (uint32_t)shards.size(); local_of[g] = (uint32_t)part.size();
+            npos += db.sketches[g].records.size();
+            part.push_back(std::move(db.sketches[g]));
+        }
+        flush();
+    }
+    skh_sketch_set* marker_index = shards.size() == 1 ? shards[0] : nullptr;
+    if (!marker_index) {
+        for (auto& m : db.markers) { m.has_seeds = true; m.records.clear(); m.contig_lengths.assign(1, (uint32_t)std::min<uint64_t>(m.total_sequence_length, 0x7FFF0000ull)); }
+        marker_index = import_blobs(cx, db.params, db.markers, a.seeding_mode);   // markers.bin: every genome entered as one contig of its total length
+    }
     const uint32_t dc = a.c, dk = a.k, dm = a.m;
     Side lq = load_side(cx, q, a.qi, a);
     if (lq.info.empty()) die("No query sketches/genomes found.");
@@ -297,14 +317,18 @@ int run_search(Args& a, Ctx& cx) {                                              
     const bool index = (q.size() > 50 || a.qi) && !a.no_marker_index;           // parse.rs:960
     uint32_t *pq = nullptr, *prf = nullptr; uint64_t np = 0;
     // search.rs:126-147: check_markers_quickly(query, ref, s, false) or screen_refs_indices
-    cx.check(skh_screen(cx.c, sr, lq.ss, a.s / 100., index ? SKH_SCREEN_REFS_INDICES : SKH_SCREEN_QUICK, 0, &pq, &prf, &np), "skh_screen");
+    cx.check(skh_screen(cx.c, marker_index, lq.ss, a.s / 100., index ? SKH_SCREEN_REFS_INDICES : SKH_SCREEN_QUICK, 0, &pq, &prf, &np), "skh_screen");
     std::vector<skh_ani_result> res(np);
-    cx.check(skh_chain_pairs(cx.c, sr, lq.ss, prf, pq, np, &mp, res.data(), nullptr), "skh_chain_pairs");
+    std::vector<uint32_t> pset(np), pref(np);
+    for (uint64_t x = 0; x < np; x++) { pset[x] = shard_of[prf[x]]; pref[x] = local_of[prf[x]]; }
+    cx.check(skh_chain_pairs_multi(cx.c, shards.data(), (uint32_t)shards.size(), lq.ss, pset.data(), pref.data(), pq, np, &mp, res.data()), "skh_chain_pairs_multi");
     std::vector<PairResult> pr;
     for (uint64_t x = 0; x < np; x++) if (res[x].ani > 0.5f) pr.push_back(PairResult{prf[x], pq[x], res[x]});   // search.rs:178
     skh_free(pq); skh_free(prf);
     emit(a.out, format_query_ref_list(rinfo, lq.info, pr, a.n, a.o));
-    skh_sketch_set_destroy(lq.ss); skh_sketch_set_destroy(sr);
+    skh_sketch_set_destroy(lq.ss);
+    if (shards.size() > 1) skh_sketch_set_destroy(marker_index);
+    for (auto* sh : shards) skh_sketch_set_destroy(sh);
     return 0;
 }
 

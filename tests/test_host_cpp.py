@@ -157,6 +157,9 @@ def test_cli_sketch_then_search_reproduces_the_reference_golden_rows(tmp_path):
         rows = {l.split("\t")[0]: l.split("\t") for l in s.stdout.splitlines()[1:]}
         assert rows["o157_plasmid.fasta"][1:5] == ["test_files/e.coli-o157.fasta", "100.00", "99.84", "1.68"]
         assert rows["e.coli-W.fasta.gz"][1:5] == ["test_files/e.coli-o157.fasta", "98.39", "85.46", "75.97"]
+    # the database split into two resident shards: one screen over all markers, one chain batch over both shards
+    s2 = run("search", "-d", "db", "e.coli-o157.fasta.sketch", "--median", "--shard-positions", "30000"); assert s2.returncode == 0, s2.stderr
+    assert sorted(s2.stdout.splitlines()) == sorted(s.stdout.splitlines())
     # .sketch files as dist inputs on both sides == FASTA inputs
     a = run("dist", "-q", "e.coli-o157.fasta.sketch", "-r", "db_sep/e.coli-W.fasta.gz.sketch", "--median"); assert a.returncode == 0, a.stderr
     assert a.stdout.splitlines()[1].split("\t")[:5] == ["e.coli-W.fasta.gz", "test_files/e.coli-o157.fasta", "98.39", "85.46", "75.97"]
