@@ -368,6 +368,21 @@ def case_edge_cases_and_errors(ctx):
             c2.close()
     r = ctx.chain_pairs(one, None, [0], [0], sk.MapParams())
     assert r["ani"][0] >= 1.0
+    # row-block screen and multi-set chaining: range / set index checks
+    with pytest.raises(sk.SkaniHipError):
+        ctx.screen_rows(ss, 1, 5)
+    with pytest.raises(sk.SkaniHipError):
+        ctx.chain_pairs_multi([ss, one], one, [2], [0], [0], sk.MapParams())
+    r = ctx.chain_pairs_multi([ss, one], one, [1, 0], [0, 0], [0, 0], sk.MapParams())
+    assert r["ani"][0] >= 1.0 and r["ani"][1] >= 1.0
+    # a genome whose padded span (length + 8192 per contig) does not fit 31 bits is refused when the set is made
+    e = one.export(0)
+    big = dict(e); big["contig_lengths"] = np.array([0x7FFFF000], np.uint32); big["total_len"] = 0x7FFFF000
+    with pytest.raises(sk.SkaniHipError, match="padded"):
+        ctx.import_sketches(sk.SketchParams(), [big])
+    many = dict(e); many["contig_lengths"] = np.full(300000, 1000, np.uint32); many["total_len"] = 300000 * 1000
+    with pytest.raises(sk.SkaniHipError, match="padded"):
+        ctx.import_sketches(sk.SketchParams(), [many])
 
 
 def case_database_formats(ctx, tmp):
