@@ -1347,7 +1347,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
                 st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
                 st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hanc, hanr, pa0[i], pa0[i + 1], host_go_a[p0 + i], pds[p0 + i].a_nctg, host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
-                if (pair_anch[p0 + i] == 0) st.switched = 1;   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
+                if (pair_anch[p0 + i] == 0) { st.switched = 1; st.n_qpos = 0; }   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
         dsync(ctx->stream);
