@@ -1,5 +1,6 @@
 """Runs the parity cases against the kernel sources compiled for the CPU simulator (tests/emu).  This is a
 debugging aid for a container without a GPU -- NOT a parity claim (those are the -m gpu tests)."""
+import numpy as np
 import pytest
 
 import skani_amd as sk
@@ -48,3 +49,12 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
         pc.case_seeding_fixtures(c)
     finally:
         c.close()
+
+
+def test_emu_randomised_differential(ctx):
+    """a few rounds of tools/fuzz_parity.py through the simulator"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(7)
+    assert sum(fz.one_round(ctx, rng, r) for r in range(4)) > 20

