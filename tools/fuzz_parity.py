@@ -81,10 +81,18 @@ def one_round(ctx, rng, rnd):
                int(st[x]["n_accepted"]), int(st[x]["n_estimates"]))
         want = (so.n_anchors, so.n_qpos, so.anchor_checksum, so.n_chunks, so.n_intervals, so.n_accepted, so.n_estimates)
         assert got == want, (rnd, c, k, m, mode, kw, i, j, got, want)
-    # the screens
-    a, b = ctx.screen(ss, None, 0.0, 0, True)
-    exp = sorted((i, int(j)) for i in range(n_genomes - 1) for j in ora.screen_refs(osk, osk[i], 0.8, 0, True) if j > i)
-    assert list(zip(a.tolist(), b.tolist())) == exp, (rnd, "screen")
+    # the screens: triangle form, and the three query-vs-reference rules with this set on both sides, at a random cut-off
+    ident = float(rng.choice([0.0, 0.8, 0.9, 0.97])); rescue = bool(rng.integers(0, 2)); eff = ident if ident else 0.8
+    a, b = ctx.screen(ss, None, ident, 0, rescue)
+    exp = sorted((i, int(j)) for i in range(n_genomes - 1) for j in ora.screen_refs(osk, osk[i], eff, 0, rescue) if j > i)
+    assert list(zip(a.tolist(), b.tolist())) == exp, (rnd, "screen tri", ident, rescue)
+    for rule in (0, 2):
+        a, b = ctx.screen(ss, ss, ident, rule, rescue)
+        exp = sorted((q, int(r)) for q in range(n_genomes) for r in ora.screen_refs(osk, osk[q], eff, rule, rescue))
+        assert list(zip(a.tolist(), b.tolist())) == exp, (rnd, "screen rule", rule, ident, rescue)
+    a, b = ctx.screen(ss, ss, ident, 1, rescue)
+    exp = sorted((q, r) for q in range(n_genomes) for r in range(n_genomes) if ora.check_markers_quickly(osk[r], osk[q], eff, rescue))
+    assert list(zip(a.tolist(), b.tolist())) == exp, (rnd, "screen quick", ident, rescue)
     return len(pr)
 
 
