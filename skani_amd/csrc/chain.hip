@@ -227,30 +227,47 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         const uint32_t nctg = pairs[p].a_nctg;
         const uint32_t* ag = pairs[p].a_g; const uint32_t Q1 = pairs[p].a_n;         // the enumerated sketch's positions
         const uint32_t q_pair_last = anc_q[A1 - 1];
+        const uint32_t s_final = pos_first_above(ag, 0, Q1, q_pair_last);           // the pair's final chunk ends its seed range here (chain.rs:794-824)
         uint32_t a = A0;
         while (a < A1) {                                                           // one query contig per round (wave-uniform)
             const uint32_t q_first = anc_q[a];
             const uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];
-            const uint32_t e = lower_bound_g(anc_q, a, A1, cnext);                  // anchors [a, e) lie in this contig
-            const uint32_t q_last = anc_q[e - 1];
-            const uint32_t rc0 = pos_lower_bound(ag, 0, Q1, cstart);                // running_counter = 0 within this contig (chain.rs:742-744)
-            const uint32_t k_max = (q_last - q_first) / CHUNK_SIZE + 1;             // lim_k reaches the last anchor no later than this
+            uint32_t e = A1, rc0 = 0, q_last = 0, k_max = 1;
             int32_t carry = (int32_t)a;                                             // u_0 = t_0 - 0
-            uint32_t t_prev_carry = a, s_prev_carry = rc0;                         // t_{k-1}, seed boundary of chunk k-1 for the batch's first lane
+            uint32_t t_prev_carry = a, s_prev_carry = 0;                           // t_{k-1}, seed boundary of chunk k-1 for the batch's first lane
             for (uint32_t kb = 0; kb < k_max && t_prev_carry < e; kb += 64) {
                 const uint32_t k = kb + l + 1;
                 const uint64_t end64 = (uint64_t)q_first + (uint64_t)k * CHUNK_SIZE;
                 const uint32_t lim = end64 < (uint64_t)(cnext - 1) ? (uint32_t)end64 : cnext - 1;   // beyond it: another contig, or past the window
-                const uint32_t b = first_above(anc_q, a, e, lim);                   // <= e
-                const uint32_t sb = pos_first_above(ag, rc0, Q1, lim);              // seed list boundary after chunk k
+                // four binary searches advance together, one probe each per step, so that their memory round trips overlap:
+                //   b  = first anchor beyond lim (per lane; searching all of the pair's later anchors gives the same answer as
+                //        searching the contig, because the contig's successor already lies beyond lim)
+                //   sb = first position beyond lim (per lane) = seed list boundary after chunk k
+                //   e  = first anchor of the next contig, rc0 = first position of this contig (wave-uniform; first batch only)
+                uint32_t lo_b = a, hi_b = A1, lo_s = 0, hi_s = Q1, lo_e = a, hi_e = kb ? a : A1, lo_r = 0, hi_r = kb ? 0 : Q1;
+                while (__ballot(lo_b < hi_b || lo_s < hi_s) != 0ull || lo_e < hi_e || lo_r < hi_r) {
+                    const uint32_t mb = (lo_b + hi_b) >> 1, ms = (lo_s + hi_s) >> 1, me = (lo_e + hi_e) >> 1, mr = (lo_r + hi_r) >> 1;
+                    const uint32_t vb = lo_b < hi_b ? anc_q[mb] : 0u, vs = lo_s < hi_s ? ag[ms] >> 1 : 0u;
+                    const uint32_t ve = lo_e < hi_e ? anc_q[me] : 0u, vr = lo_r < hi_r ? ag[mr] >> 1 : 0u;
+                    if (lo_b < hi_b) { if (vb > lim) hi_b = mb; else lo_b = mb + 1; }
+                    if (lo_s < hi_s) { if (vs > lim) hi_s = ms; else lo_s = ms + 1; }
+                    if (lo_e < hi_e) { if (ve < cnext) lo_e = me + 1; else hi_e = me; }
+                    if (lo_r < hi_r) { if (vr < cstart) lo_r = mr + 1; else hi_r = mr; }
+                }
+                if (kb == 0) {
+                    e = lo_e; rc0 = lo_r; s_prev_carry = rc0;                       // running_counter = 0 within this contig (chain.rs:742-744)
+                    q_last = anc_q[e - 1];
+                    k_max = (q_last - q_first) / CHUNK_SIZE + 1;                    // lim_k reaches the last anchor no later than this
+                }
+                const uint32_t b = lo_b, sb = lo_s;
                 const int32_t u = wave_incl_max((int32_t)b - (int32_t)k);
                 const int32_t uu = u > carry ? u : carry;
                 const uint32_t t = (uint32_t)(uu + (int32_t)k);                     // t_k (may run past e: the chunk is then cut at e)
                 uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
                 if (l == 0) { t_prev = t_prev_carry; s_prev = s_prev_carry; }
-                const bool valid = t_prev < e;                                      // chunk k exists
+                const bool valid = t_prev < e && k <= k_max;                        // chunk k exists
                 Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e ? t : e; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cstart; ck.qctg = ctg;
-                if (valid && ck.a_end == A1) ck.s_end = pos_first_above(ag, s_prev, Q1, q_pair_last);   // the pair's final chunk
+                if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
                 const unsigned long long vm = __ballot(valid);
                 const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
                 if (valid) {
