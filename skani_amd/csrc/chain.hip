@@ -413,6 +413,9 @@ __global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, co
     keys[i] = 1023u - (len >= 1023u ? 1023u : len); vals[i] = i;
 }
 
+#ifndef DP_LINE
+#define DP_LINE 8     // anchors per fetched line: 8 (32 B) measured best (2.04 ms; 16: 2.44 ms, 4: 2.06 ms) -- less LDS, one more wave per SIMD
+#endif
 template <int NB, int T, uint32_t DP_LDS_SLOTS>
 __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* order, uint32_t band,
                                                             EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr) {
@@ -442,34 +445,36 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rs[k] = 0; rd[k] = 0; }
     // Anchor fetch.  A lane walks its own chunk, so a plain per-lane load touches 64 different cache lines per instruction and
     // uses 4 bytes of each; with ~50k such streams per XCD the lines are evicted before their next element is wanted and every
-    // anchor costs a 64-byte HBM fetch (measured: 15 GB read for 2.4 GB of anchors).  Instead every lane pulls whole 64-byte
-    // lines (16 anchors of one array) as four 16-byte loads, one line ahead of use, and parks the current line in its own LDS
+    // anchor costs a 64-byte HBM fetch (measured: 15 GB read for 2.4 GB of anchors).  Instead every lane pulls whole lines
+    // (DP_LINE anchors of one array) as 16-byte loads, one line ahead of use, and parks the current line in its own LDS
     // column [element][lane].  All lanes use the same element index: a lane's walk starts at its chunk's 64-byte-aligned
     // predecessor ("virtual" index v; elements before the chunk are skipped), which keeps the LDS reads conflict-free and
     // the refill branch wave-uniform.
-    __shared__ uint32_t lds_q[16 * T], lds_r[16 * T];
-    const uint32_t voff = ck.a_begin & 15u;
+    constexpr uint32_t LINE = DP_LINE;                       // anchors per fetched line (16 = 64 bytes)
+    constexpr int LQ = LINE / 4;
+    __shared__ uint32_t lds_q[LINE * T], lds_r[LINE * T];
+    const uint32_t voff = ck.a_begin & (LINE - 1);
     const uint32_t vtot = n ? n + voff : 0;
     const uint32_t* line_q = ec.anc_q + (ck.a_begin - voff); const uint32_t* line_r = ec.anc_r + (ck.a_begin - voff);
-    uint4 pq[4], pr[4];
+    uint4 pq[LQ], pr[LQ];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { pq[j] = make_uint4(0, 0, 0, 0); pr[j] = make_uint4(0, 0, 0, 0); }
+    for (int j = 0; j < LQ; j++) { pq[j] = make_uint4(0, 0, 0, 0); pr[j] = make_uint4(0, 0, 0, 0); }
     if (vtot) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { pq[j] = *(const uint4*)(line_q + 4 * j); pr[j] = *(const uint4*)(line_r + 4 * j); }
+        for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + 4 * j); pr[j] = *(const uint4*)(line_r + 4 * j); }
     }
     for (uint32_t v = 0;; v++) {
-        const uint32_t kk = v & 15u;
+        const uint32_t kk = v & (LINE - 1);
         if (kk == 0) {                                                              // wave-uniform
             if (__ballot(v < vtot) == 0) break;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < LQ; j++) {
                 lds_q[(4 * j + 0) * T + tid] = pq[j].x; lds_q[(4 * j + 1) * T + tid] = pq[j].y; lds_q[(4 * j + 2) * T + tid] = pq[j].z; lds_q[(4 * j + 3) * T + tid] = pq[j].w;
                 lds_r[(4 * j + 0) * T + tid] = pr[j].x; lds_r[(4 * j + 1) * T + tid] = pr[j].y; lds_r[(4 * j + 2) * T + tid] = pr[j].z; lds_r[(4 * j + 3) * T + tid] = pr[j].w;
             }
-            if (v + 16 < vtot) {
+            if (v + LINE < vtot) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) { pq[j] = *(const uint4*)(line_q + v + 16 + 4 * j); pr[j] = *(const uint4*)(line_r + v + 16 + 4 * j); }
+                for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + v + LINE + 4 * j); pr[j] = *(const uint4*)(line_r + v + LINE + 4 * j); }
             }
         }
         if (v < voff || v >= vtot) continue;
