@@ -102,6 +102,7 @@ void skh_ctx_destroy(skh_ctx* ctx) {
 #endif
     ctx->arena.release_all();
     ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel();
+    dcache_trim();                                   // hand the allocator's idle blocks back to the driver
 #ifndef SKANI_EMU
     (void)hipStreamDestroy(ctx->stream);
 #endif

@@ -32,6 +32,7 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 #ifdef SKANI_EMU
 inline void* dmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); return p; }
 inline void dfree(void* p) { free(p); }
+inline void dcache_trim() {}
 inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
 inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
 inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }
