@@ -139,7 +139,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         SKH_LAUNCH(screen_keys_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, n_genomes, n,
                    is_query, out);
         check_launch("screen_keys");
-        sort_keys_u64(ctx, out, n, 64);
+        sort_keys_u64(ctx, out, n, 64);     // all 64 bits: (marker, side, genome) are distinct keys, so the order does not lean on the sort being stable
+                                             // (rocPRIM's path for mid-sized inputs is not: sorting bits [22, 64) only scrambled equal markers at 28k keys)
     };
     if (tri) {
         uint64_t* k = ctx->arena.get<uint64_t>(MR ? MR : 1);

@@ -282,10 +282,10 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         sort_pairs_u32_u32(ctx, keys32, vals, P, (int)(hash_bits >= 32 ? 32 : hash_bits + gbits));
         SKH_LAUNCH(full_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, idx_bits, carry, (const uint32_t*)keys32, vals, keys);
         check_launch("full_keys");
-        if (hash_bits < 32) {
-            SKH_LAUNCH(fixup_runs_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)keys32, P, keys, vals);
-            check_launch("fixup_runs");
-        }
+        // always: besides separating hashes that share a 32-bit key it puts equal seeds into position order, which must not
+        // depend on the device sort being stable (rocPRIM's path for mid-sized inputs is not)
+        SKH_LAUNCH(fixup_runs_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)keys32, P, keys, vals);
+        check_launch("fixup_runs");
         tr.mark("build: sort");
         const uint32_t n_bt = (uint32_t)((P + BT - 1) / BT);
         uint32_t* tile_cnt = ctx->arena.get<uint32_t>(n_bt); uint32_t* tile_off = ctx->arena.get<uint32_t>(n_bt + 1);

@@ -55,18 +55,19 @@ void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t
 #endif
 }
 
-void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit) {
+void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int begin_bit) {
     if (n < 2) return;
 #ifndef SKANI_EMU
     uint64_t* keys_out = ctx->arena.get<uint64_t>(n);
     size_t tmp_bytes = 0;
-    hip_check(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys_out, n, 0, end_bit, ctx->stream), "radix_sort_keys size");
+    hip_check(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys_out, n, begin_bit, end_bit, ctx->stream), "radix_sort_keys size");
     void* tmp = ctx->arena.take(tmp_bytes);
-    hip_check(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys_out, n, 0, end_bit, ctx->stream), "radix_sort_keys");
+    hip_check(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys_out, n, begin_bit, end_bit, ctx->stream), "radix_sort_keys");
     d2d(keys, keys_out, n * sizeof(uint64_t), ctx->stream);
 #else
     (void)ctx; (void)end_bit;
-    std::sort(keys, keys + n);
+    const uint64_t mask = begin_bit ? ~((1ull << begin_bit) - 1ull) : ~0ull;         // stable on the selected bits, like the radix sort
+    std::stable_sort(keys, keys + n, [&](uint64_t a, uint64_t b) { return (a & mask) < (b & mask); });
 #endif
 }
 
