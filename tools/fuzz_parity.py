@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test: GPU path (through the C ABI) vs the CPU oracle on many small random genome pairs.
-usage (on a GPU box): python tools/fuzz_parity.py [n_rounds] [seed]     -- prints a summary line; exits 1 on the first mismatch.
+usage (on a GPU box): python tools/fuzz_parity.py [n_rounds] [seed] [big]     -- prints a summary line; exits 1 on the first mismatch.
 Covers what the fixed parity cases only touch in a few places: repeats (tandem / dispersed duplications), inversions, N runs,
 many short contigs, contigs below the 500-bp cut, all compression factors / k / both seeding semantics, robust / median / CI."""
 import os
@@ -53,12 +53,12 @@ def contigs_of(seq, rng):
     return [out[i] for i in order]
 
 
-def one_round(ctx, rng, rnd):
+def one_round(ctx, rng, rnd, big=False):
     c = int(rng.choice([30, 70, 125, 125, 200])); k = int(rng.choice([14, 15, 15, 16])); m = int(rng.choice([200, 1000])); mode = int(rng.integers(0, 2))
     if c > m:
         m = 1000
-    n_genomes = int(rng.integers(2, 7))
-    root = random_genome(int(rng.integers(3000, 250000)), int(rng.integers(0, 2**31)))
+    n_genomes = int(rng.integers(1, 4)) if big else int(rng.integers(2, 7))
+    root = random_genome(int(rng.integers(400000, 4000000)) if big else int(rng.integers(3000, 250000)), int(rng.integers(0, 2**31)))
     genomes = []
     for g in range(n_genomes):
         base = root if rng.random() < 0.8 else random_genome(int(rng.integers(1000, 100000)), int(rng.integers(0, 2**31)))
@@ -99,6 +99,7 @@ def one_round(ctx, rng, rnd):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"       # Mbp-sized genomes, 1-3 per set (mid-sized sorts, many tiles per pair)
     lib = None
     if os.environ.get("SKANI_FUZZ_EMU"):
         from tests.emu_lib import emu_lib
@@ -108,7 +109,7 @@ def main():
     pairs = 0
     for r in range(rounds):
         try:
-            pairs += one_round(ctx, rng, r)
+            pairs += one_round(ctx, rng, r, big)
         except AssertionError as e:
             print("MISMATCH in round %d (seed %d): %s" % (r, seed, str(e)[:600]))
             sys.exit(1)
