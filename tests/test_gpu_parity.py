@@ -197,3 +197,34 @@ def test_randomised_differential(ctx):
     rng = np.random.default_rng(2024)
     pairs = sum(fz.one_round(ctx, rng, r) for r in range(40))
     assert pairs > 300
+
+
+def test_two_contexts_share_a_sketch_set_across_threads(ctx):
+    """Threading contract of the C ABI: a context is driven by one thread, distinct contexts are independent, sketch sets may be
+    shared read-only.  Two host threads with their own contexts screen (lazy index cache) and chain the same set at the same time."""
+    import threading
+    genomes = pc.synthetic_clades(n_clades=3, members=4, length=150000, seed=91, tiny=False)
+    names = ["t%02d.fa" % i for i in range(len(genomes))]
+    ss = ctx.sketch_records(genomes, sk.SketchParams(), names)
+    qs = ctx.sketch_records(genomes[:5], sk.SketchParams(), names[:5])
+    mp = sk.MapParams(learned_ani=True, compute_ci=True)
+    a0, b0 = ctx.screen(ss, qs, 0.0, 0, True)
+    want = ctx.chain_pairs(ss, qs, b0, a0, mp)
+    other = sk.Context(0)
+    out, errs = {}, []
+    def work(c, key):
+        try:
+            for _ in range(6):
+                a, b = c.screen(ss, qs, 0.0, 0, True)
+                r = c.chain_pairs(ss, qs, b, a, mp)
+                assert np.array_equal(a, a0) and np.array_equal(b, b0) and r.tobytes() == want.tobytes()
+            out[key] = True
+        except Exception as e:                                 # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(ctx, "a")), threading.Thread(target=work, args=(other, "b"))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    other.close()
+    assert not errs and out == {"a": True, "b": True}, errs
