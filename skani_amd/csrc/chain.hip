@@ -318,8 +318,14 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
         cur.q = av.x; cur.r = av.y >> 1; cur.cr = av.y & 1u;                         // cr: strand only -- different contigs are > MAX_LIN apart
         cur.score = 0; cur.root = t; cur.depth = 1;
         uint32_t ptr = t;
-        const uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
+        uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
         const uint32_t jhi = ck.a_end < base + 64 ? ck.a_end : base + 64;
+        {   // anchors ascend in q: sources more than BP_CHAIN_BAND below this block's first target cannot link to any of its targets
+            const uint32_t q_base = anc_q[base];
+            uint32_t lo = jlo, hi = base;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (anc_q[mid] + BP_CHAIN_BAND < q_base) lo = mid + 1; else hi = mid; }
+            jlo = lo;
+        }
         for (uint32_t j = jlo; j < jhi; j++) {
             uint32_t qj, rj, crj; int32_t sj;
             if (j >= base) {
