@@ -1301,7 +1301,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
         const EmitCtx ec{anc_q, anc_r, d_pairs, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
-            if (band <= 40) {   // fused thread-per-chunk chaining + interval emission
+            if (band <= 84) {   // fused thread-per-chunk chaining + interval emission
                 constexpr int T = 64;
                 const unsigned gt = (NC + T - 1) / T;
                 const uint32_t ls = ctx->tune.chain_dp_lds_slots <= 1 ? 1u : 8u;  // 1: tests push every second live chain through the spill table
@@ -1313,7 +1313,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 sort_pairs_u64_u32(ctx, okeys, order, NC, 10);
 #define SKH_DPT2(NB, LS) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr)
 #define SKH_DPT(NB) do { if (ls == 1) SKH_DPT2(NB, 1); else SKH_DPT2(NB, 8); } while (0)
-                if (band <= 12) SKH_DPT(12); else if (band <= 20) SKH_DPT(20); else if (band <= 28) SKH_DPT(28); else SKH_DPT(40);
+                if (band <= 12) SKH_DPT(12); else if (band <= 20) SKH_DPT(20); else if (band <= 28) SKH_DPT(28); else if (band <= 40) SKH_DPT(40); else SKH_DPT(84);
 #undef SKH_DPT
 #undef SKH_DPT2
                 check_launch("chain_dp_thread");
