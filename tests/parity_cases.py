@@ -166,9 +166,9 @@ def synthetic_clades(n_clades=2, members=3, length=200000, seed=11, tiny=True):
     return genomes
 
 
-def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200)), length=200000):
+def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200), (0, 20)), length=200000):
     """triangle.rs:55-105 on synthetic clades: screen pass set, chained pairs, all result fields, learned ANI on/off,
-    robust/median windows."""
+    robust/median windows.  c = 20 (band 125) goes through the wave-sweep chaining kernels, the others through the thread-per-chunk one."""
     genomes = synthetic_clades(length=length)
     names = ["g%02d.fa" % i for i in range(len(genomes))]
     for mode, c in params:

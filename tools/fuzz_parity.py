@@ -54,7 +54,7 @@ def contigs_of(seq, rng):
 
 
 def one_round(ctx, rng, rnd, big=False):
-    c = int(rng.choice([30, 70, 125, 125, 200])); k = int(rng.choice([14, 15, 15, 16])); m = int(rng.choice([200, 1000])); mode = int(rng.integers(0, 2))
+    c = int(rng.choice([20, 30, 70, 125, 125, 200])); k = int(rng.choice([14, 15, 15, 16])); m = int(rng.choice([200, 1000])); mode = int(rng.integers(0, 2))
     if c > m:
         m = 1000
     n_genomes = int(rng.integers(1, 4)) if big else int(rng.integers(2, 7))
