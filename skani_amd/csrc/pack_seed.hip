@@ -111,6 +111,47 @@ __device__ __forceinline__ uint64_t rev2_64(uint64_t x) {   // reverse the order
     return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
 }
 
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {   // reverse the order of the 16 two-bit groups
+    uint32_t y = __brev(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+// The hot loop of the seeding kernel is bound by VALU issue.  Measured on gfx950 (tools/exp/valu_rates.hip, profiles/r01_valu_rates.md): every
+// integer instruction it can be built from -- v_mad_u64_u32, v_lshrrev_b64, v_lshl_add_u64, v_cmp_gt_u64, v_alignbit_b32 ... -- issues at the same
+// rate, so what counts is the NUMBER of instructions per window.  hipcc turns the multiplications of the Thomas Wang mix into pairs of
+// v_mad_u64_u32 glued with v_mov (registers pairs must be even-aligned) and the hit masks into cmp + cndmask + or: 45 instructions per window.
+// The helpers below pin the cheaper forms (25 per window).  SKANI_EMU (the CPU kernel simulator of the test suite) gets the plain C++ meaning.
+#ifdef SKANI_EMU
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+__device__ __forceinline__ uint64_t seed_hash(uint32_t seed) { return mm_hash64((uint64_t)seed); }
+__device__ __forceinline__ void push_less(uint32_t& bits, uint64_t h, uint64_t thr) { bits = (bits << 1) | (h < thr ? 1u : 0u); }
+#else
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+template <int SH> __device__ __forceinline__ uint64_t shl_add_u64(uint64_t a, uint64_t b) {          // (a << SH) + b, SH <= 4, one instruction
+    uint64_t d; asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH)); return d;
+}
+// mm_hash64 (types.rs:86-96) of a 32-bit key in 16 instructions
+__device__ __forceinline__ uint64_t seed_hash(uint32_t seed) {
+    const uint64_t p = (uint64_t)seed * 0x200001ull;                   // key + (key << 21) < 2^54; the NOT of step 1 is folded into step 2:
+    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);       //   ~p ^ (~p >> 24) = p ^ (p >> 24) ^ 0xFFFFFF0000000000, and (phi >> 24) = 0
+    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
+    // step 3 (x 265): the high word of step 2, phi ^ 0xFFFFFF00 with phi < 2^22, is a small NEGATIVE number that fits a signed 24-bit operand,
+    // so "hi * 265 + carry word of the low product" is a single 24-bit multiply-add
+    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
+    const uint64_t q = (uint64_t)lo2 * 265u;
+    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
+    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
+    key ^= key >> 14;
+    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
+    key ^= key >> 28;
+    return shl_add_u64<0>(key << 31, key);
+}
+// bits = bits << 1 | (h < thr): compare into vcc, add-with-carry shifts it in
+__device__ __forceinline__ void push_less(uint32_t& bits, uint64_t h, uint64_t thr) {
+    asm("v_cmp_gt_u64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(h), "s"(thr) : "vcc");
+}
+#endif
+
 // Slow path, taken only by contigs that contain an N: bit j set = window j of this thread is suppressed.
 // scalar (seeding.rs:272-275,300): an N/n at p (p >= 20) suppresses windows i in [p, p+k).
 // avx2 (avx2_seeding.rs:63-81,115-126,181): lanes are substrings of length len4 = (L-20)/4; only an 'N' seen in the
@@ -155,23 +196,24 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     const uint32_t a0 = lds_w[2 * tid], a1 = lds_w[2 * tid + 1], a2 = lds_w[2 * tid + 2], a3 = lds_w[2 * tid + 3];
     const uint64_t M42 = (1ull << 42) - 1;
     const uint32_t smask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
-    // state after the 20 warm-up bases (seeding.rs:260-269): f = the 20 bases, r = reversed complement, newest at bits 40..41
-    uint64_t f = ((uint64_t)a0 << 8) | (a1 >> 24);
-    uint64_t r = (rev2_64(~f & ((1ull << 40) - 1)) >> 24) << 2;
+    // The rolled 21-mers of seeding.rs:278-283 are never materialised in the hot loop.  Both seed candidates are bit fields of the packed bases:
+    //   f & mask(2k) = the k newest bases of the window, newest lowest  = bits [s, s+2k) of a0:a1:a2:a3, s = 126 - 2x (x = the window's last base);
+    //   r & mask(2k) = complement of the k OLDEST bases, oldest lowest = bits [2(x-20), ..) of the complemented, group-reversed string w2:w1:w0.
+    // One funnel shift + one AND each, with compile-time shifts (the loop is fully unrolled).
+    const uint32_t w0 = rev2_32(~a0), w1 = rev2_32(~a1), w2 = rev2_32(~a2);
     uint32_t hits = 0, mhits = 0;
 #pragma unroll
     for (uint32_t j = 0; j < SEED_RUN; j++) {
-        const uint32_t x = 20 + j;                           // base index within the thread's 52-base string
-        const uint32_t word = x < 32 ? a1 : (x < 48 ? a2 : a3);
-        const uint32_t nf = (word >> (30 - 2 * (x & 15))) & 3u;
-        f = ((f << 2) | nf) & M42;                                               // seeding.rs:278-280
-        r = (r >> 2) | ((uint64_t)(3u - nf) << 40);                              // seeding.rs:281-283
-        const uint32_t fs = (uint32_t)f & smask, rs = (uint32_t)r & smask;       // seeding.rs:288-289
-        const uint32_t seed = fs < rs ? fs : rs;                                 // seeding.rs:290-296
-        const uint64_t h = mm_hash64((uint64_t)seed);
-        hits |= (h < thr ? 1u : 0u) << j;                                        // seeding.rs:300
-        mhits |= (h < thr_m ? 1u : 0u) << j;                                     // seeding.rs:318
+        const uint32_t s = 86u - 2u * j;                                           // 126 - 2*(20 + j)
+        const uint32_t fw = s >= 64 ? funnel_shr(a0, a1, s - 64) : (s >= 32 ? funnel_shr(a1, a2, s - 32) : funnel_shr(a2, a3, s));
+        const uint32_t rw = 2 * j < 32 ? funnel_shr(w1, w0, 2 * j) : funnel_shr(w2, w1, 2 * j - 32);
+        const uint32_t fs = fw & smask, rs = rw & smask;                           // seeding.rs:288-289
+        const uint32_t seed = fs < rs ? fs : rs;                                   // seeding.rs:290-296
+        const uint64_t h = seed_hash(seed);
+        push_less(hits, h, thr);                                                   // seeding.rs:300
+        push_less(mhits, h, thr_m);                                                // seeding.rs:318
     }
+    hits = __brev(hits); mhits = __brev(mhits);                                    // push_less shifts in from the right: window 0 ended up at bit 31
     const uint32_t i0 = (K_MARKER - 1) + tile.first * SEED_TILE + SEED_RUN * tid;   // i of this thread's window 0
     uint32_t nvalid = iend > i0 ? iend - i0 : 0;
     const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
