@@ -174,6 +174,22 @@ __device__ uint32_t n_suppress_mask(const uint32_t* nmask, const ContigDesc& cd,
     return out;
 }
 
+// One hit window, re-derived from the owning thread's 128 packed bits (a0:a1:a2:a3, 52 bases MSB first): window j ends at base 20 + j.
+struct HitRecord { uint32_t seed; bool canonical; uint64_t kmer; };
+__device__ __forceinline__ HitRecord derive_hit(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t j, uint32_t smask) {
+    const uint64_t hi = ((uint64_t)a0 << 32) | a1, lo = ((uint64_t)a2 << 32) | a3;
+    const uint32_t s = 86u - 2u * j;                                                   // 128 - 2*(j+21)
+    uint64_t ff = s >= 64 ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));        // forward 21-mer, newest base lowest (seeding.rs:278-280)
+    ff &= (1ull << 42) - 1;
+    const uint64_t rr = rev2_64(~ff) >> 22;                                            // reverse complement (seeding.rs:281-283)
+    const uint32_t fs = (uint32_t)ff & smask, rs = (uint32_t)rr & smask;               // seeding.rs:288-289
+    HitRecord hr;
+    hr.canonical = fs < rs;                                                            // seeding.rs:290-296
+    hr.seed = hr.canonical ? fs : rs;
+    hr.kmer = ff < rr ? ff : rr;                                                       // seeding.rs:311-316
+    return hr;
+}
+
 __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                                                          const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
                                                          const uint32_t* __restrict__ tile_ids, uint32_t k, uint64_t thr, uint64_t thr_m,
@@ -183,6 +199,9 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ cnt_m) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[SEED_TILE / 16 + 8];
     __shared__ uint32_t lds_scan[16];
+    __shared__ uint32_t lds_nm;
+    SKH_DYN_SMEM(dyn_smem);
+    uint16_t* lds_hit = (uint16_t*)dyn_smem;                 // cap_s entries
     const uint32_t tid = threadIdx.x;
     const SeedTile tile = tiles[tile_ids ? tile_ids[blockIdx.x] : blockIdx.x];
     const ContigDesc cd = contigs[tile.contig];
@@ -194,14 +213,13 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     __syncthreads();
     // this thread: bases [32*tid, 32*tid+52) of the tile = 20 warm-up bases + 32 windows
     const uint32_t a0 = lds_w[2 * tid], a1 = lds_w[2 * tid + 1], a2 = lds_w[2 * tid + 2], a3 = lds_w[2 * tid + 3];
-    const uint64_t M42 = (1ull << 42) - 1;
     const uint32_t smask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
     // The rolled 21-mers of seeding.rs:278-283 are never materialised in the hot loop.  Both seed candidates are bit fields of the packed bases:
     //   f & mask(2k) = the k newest bases of the window, newest lowest  = bits [s, s+2k) of a0:a1:a2:a3, s = 126 - 2x (x = the window's last base);
     //   r & mask(2k) = complement of the k OLDEST bases, oldest lowest = bits [2(x-20), ..) of the complemented, group-reversed string w2:w1:w0.
     // One funnel shift + one AND each, with compile-time shifts (the loop is fully unrolled).
     const uint32_t w0 = rev2_32(~a0), w1 = rev2_32(~a1), w2 = rev2_32(~a2);
-    uint32_t hits = 0, mhits = 0;
+    uint32_t hits = 0;
 #pragma unroll
     for (uint32_t j = 0; j < SEED_RUN; j++) {
         const uint32_t s = 86u - 2u * j;                                           // 126 - 2*(20 + j)
@@ -211,47 +229,51 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
         const uint32_t seed = fs < rs ? fs : rs;                                   // seeding.rs:290-296
         const uint64_t h = seed_hash(seed);
         push_less(hits, h, thr);                                                   // seeding.rs:300
-        push_less(mhits, h, thr_m);                                                // seeding.rs:318
     }
-    hits = __brev(hits); mhits = __brev(mhits);                                    // push_less shifts in from the right: window 0 ended up at bit 31
+    hits = __brev(hits);                                                           // push_less shifts in from the right: window 0 ended up at bit 31
     const uint32_t i0 = (K_MARKER - 1) + tile.first * SEED_TILE + SEED_RUN * tid;   // i of this thread's window 0
     uint32_t nvalid = iend > i0 ? iend - i0 : 0;
     const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
     hits &= vmask;
     if (cd.has_n) hits &= ~n_suppress_mask(nmask, cd, i0, iend, k, mode);
-    mhits &= hits;
-    // workgroup prefix sum of (seed count | marker count << 16)
-    const uint32_t c = (uint32_t)__popc(hits) | ((uint32_t)__popc(mhits) << 16);
+    // workgroup prefix sum of the hit counts
+    const uint32_t c = (uint32_t)__popc(hits);
     uint32_t incl = wave_incl_scan(c);
     const uint32_t wv = tid >> 6, ln = tid & 63;
     if (ln == 63) lds_scan[wv] = incl;
+    if (tid == 0) lds_nm = 0;
     __syncthreads();
     uint32_t base = 0, tot = 0;
     for (uint32_t q = 0; q < SEED_THREADS / 64; q++) { uint32_t t = lds_scan[q]; if (q < wv) base += t; tot += t; }
-    const uint32_t excl = base + incl - c;
-    uint32_t so = excl & 0xFFFFu, mo = excl >> 16;
-    if (tid == 0) { cnt_s[blockIdx.x] = tot & 0xFFFFu; cnt_m[blockIdx.x] = tot >> 16; }
-    // emit hits in window order; values re-derived by extracting the 21-mer from the thread's 104 packed bits
-    const uint64_t hi = ((uint64_t)a0 << 32) | a1, lo = ((uint64_t)a2 << 32) | a3;
-    // tile scratch holds cap_s seeds / cap_m markers; a tile that needs more (low-complexity sequence) is re-run
-    // by the host with full capacity -- the counts above are exact either way
+    // Hits are 1/c of the windows, scattered over the lanes: deriving their records lane by lane would keep a whole wave busy for as many
+    // rounds as its unluckiest lane has hits.  Instead every thread appends (thread << 5 | window) for its hits to a list in LDS (window order,
+    // from the prefix sum) and the list is worked off densely, one hit per thread: seed, strand and -- by hashing the seed once more, which is
+    // cheaper than a second compare in the hot loop -- whether the window is a marker (seeding.rs:311-319).  Marker slots are handed out by an
+    // LDS counter; their order is irrelevant (marker_seeds is a set, built by sorting: sketch_build.hip).
+    // The tile scratch holds cap_s seeds / cap_m markers; a tile that needs more (low-complexity sequence) is re-run by the host with full
+    // capacity -- the two counts are exact either way.
     const uint64_t obase = (uint64_t)blockIdx.x * cap_s, mbase = (uint64_t)blockIdx.x * cap_m;
-    uint32_t hm = hits;
-    while (hm) {
-        const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
-        const uint32_t s = 86u - 2u * j;                       // 128 - 2*(j+21)
-        uint64_t ff = s >= 64 ? (hi >> (s - 64)) : ((hi << (64 - s)) | (lo >> s));
-        ff &= M42;
-        const uint64_t rr = rev2_64(~ff) >> 22;
-        const uint32_t fs = (uint32_t)ff & smask, rs = (uint32_t)rr & smask;
-        const bool canon = fs < rs;
-        if (so < cap_s) {
-            t_seed[obase + so] = canon ? fs : rs;
-            t_loc[obase + so] = (uint16_t)((SEED_RUN * tid + j) | (canon ? 0x8000u : 0u));
+    if (tot <= cap_s) {
+        uint32_t so = base + incl - c, hm = hits;
+        while (hm) { const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; lds_hit[so++] = (uint16_t)((tid << 5) | j); }
+        __syncthreads();
+        for (uint32_t x = tid; x < tot; x += SEED_THREADS) {
+            const uint32_t code = lds_hit[x], src = code >> 5;
+            const HitRecord hr = derive_hit(lds_w[2 * src], lds_w[2 * src + 1], lds_w[2 * src + 2], lds_w[2 * src + 3], code & 31u, smask);
+            t_seed[obase + x] = hr.seed;
+            t_loc[obase + x] = (uint16_t)(code | (hr.canonical ? 0x8000u : 0u));        // code = SEED_RUN * thread + window
+            if (seed_hash(hr.seed) < thr_m) { const uint32_t mo = atomicAdd(&lds_nm, 1u); if (mo < cap_m) t_marker[mbase + mo] = hr.kmer; }
         }
-        so++;
-        if ((mhits >> j) & 1u) { if (mo < cap_m) t_marker[mbase + mo] = ff < rr ? ff : rr; mo++; }   // seeding.rs:311-319
+    } else {                                                                               // only the counts matter
+        uint32_t hm = hits, nm = 0;
+        while (hm) {
+            const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
+            if (seed_hash(derive_hit(a0, a1, a2, a3, j, smask).seed) < thr_m) nm++;
+        }
+        if (nm) atomicAdd(&lds_nm, nm);
     }
+    __syncthreads();
+    if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; }
 }
 
 // tiles whose counts exceed the capped scratch get a slot in the full-capacity overflow scratch
@@ -334,7 +356,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         hipEvent_t e0, e1; hip_check(hipEventCreate(&e0), "event"); hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, ctx->stream), "event record");
 #endif
-        SKH_LAUNCH(seed_tiles_kernel, nt, SEED_THREADS, 0, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+        SKH_LAUNCH(seed_tiles_kernel, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
                    t_seed, t_loc, t_marker, cnt_s, cnt_m);
         check_launch("seed_tiles_kernel");
@@ -368,7 +390,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
             o_seed2 = ctx->arena.get<uint32_t>((size_t)h_novf * SEED_TILE); o_loc2 = ctx->arena.get<uint16_t>((size_t)h_novf * SEED_TILE);
             o_marker2 = ctx->arena.get<uint64_t>((size_t)h_novf * SEED_TILE);
             uint32_t* c2 = ctx->arena.get<uint32_t>(2 * (size_t)h_novf);
-            SKH_LAUNCH(seed_tiles_kernel, h_novf, SEED_THREADS, 0, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+            SKH_LAUNCH(seed_tiles_kernel, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                        (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
                        o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
