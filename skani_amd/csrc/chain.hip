@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, co
 #ifndef DP_LINE
 #define DP_LINE 8     // anchors per fetched line: 8 (32 B) measured best (2.04 ms; 16: 2.44 ms, 4: 2.06 ms) -- less LDS, one more wave per SIMD
 #endif
-template <int NB, int T, uint32_t DP_LDS_SLOTS>
+template <int NB, int T, uint32_t DP_LDS_SLOTS, bool EXACT>   // EXACT: band == NB (the presets' bands), no per-slot band test
 __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* order, uint32_t band,
                                                             EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr) {
     __shared__ unsigned long long lds_best[DP_LDS_SLOTS * T];                       // [slot][lane]
@@ -441,11 +441,14 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(ec.err, 1u); return; }
     const uint32_t p = n ? chunk_pair[slot] : 0;
     unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
-    // ring of the last NB anchors: q, strand-signed r, score + ANCHOR_SCORE, depth << 8 | component.
+    // ring of the last NB anchors: q + 1, strand-signed r + 1, score + ANCHOR_SCORE, depth << 8 | component.
     //  * r is kept as s = reverse ? ~r : r.  For two anchors of the same strand s_i - s_j is the forward distance on that strand
     //    (chain.rs:573-586); for different strands it is >= 2 * CTG_PAD away from 0 in both directions because every padded
     //    coordinate lies in [CTG_PAD, 2^31 - CTG_PAD) -- the same-contig and the same-strand tests are both implied by the gap test.
-    //  * empty slots hold q = 0, which is more than BP_CHAIN_BAND below any real coordinate.
+    //  * both coordinates are stored + 1, so that the differences come out as dq - 1 and dr - 1: "0 < dq <= band" is ONE unsigned compare,
+    //    the gap |dr - dq| is unchanged, and taken as an UNSIGNED absolute difference (v_sad_u32) it also rejects dr <= 0: with
+    //    0 <= dq - 1 < 2500 a negative dr - 1 is >= 2^31 as unsigned and the difference far above MAX_GAP.
+    //  * empty slots hold 0, which is more than BP_CHAIN_BAND below any real coordinate.
     uint32_t rq[NB], rr[NB], rs[NB], rd[NB];
 #pragma unroll
     for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rs[k] = 0; rd[k] = 0; }
@@ -493,17 +496,20 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         // stops there (checked every four slots; chunks are dealt out by length, so a wave's lanes agree on how far to look).
         bool stop = false;
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            if (k > 0 && (k & 3) == 0 && !stop) stop = __ballot(q - rq[k - 1] <= BP_CHAIN_BAND) == 0;
-            if (!stop && (uint32_t)k < band) {
-                const uint32_t dq = q - rq[k];
-                const int32_t dr = (int32_t)(r - rr[k]);                            // 0 < dr: same strand, ref coordinate advances along it
-                const int32_t d = dr - (int32_t)dq;
-                const int32_t gap = d < 0 ? -d : d;
-                const int32_t sc = (int32_t)rs[k] - gap;
-                // 0 < dq <= 2500 and gap <= 300 bound dr by 2800 < D_MAX_LIN_LENGTH (chain.rs:856-863, 564-597)
-                const bool ok = (dq - 1u < BP_CHAIN_BAND) & (dr > 0) & (gap <= MAX_GAP) & (sc > bscore);
-                bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
+        for (int g = 0; g < NB; g += 4) {
+            if (g > 0 && !stop) stop = __ballot((int32_t)(q - rq[g - 1]) < (int32_t)BP_CHAIN_BAND) == 0;   // dq - 1 = -1 (equal q) keeps scanning
+            if (!stop) {
+#pragma unroll
+                for (int k = g; k < g + 4 && k < NB; k++) {
+                    if (EXACT || (uint32_t)k < band) {
+                        const uint32_t dq1 = q - rq[k], dr1 = r - rr[k];            // dq - 1, dr - 1
+                        const uint32_t gap = abs_diff_u32(dr1, dq1);
+                        const int32_t sc = (int32_t)(rs[k] - gap);
+                        // 0 < dq <= 2500 and gap <= 300 bound dr by 2800 < D_MAX_LIN_LENGTH (chain.rs:856-863, 564-597)
+                        const bool ok = (dq1 < BP_CHAIN_BAND) & (gap <= (uint32_t)MAX_GAP) & (sc > bscore);
+                        bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
+                    }
+                }
             }
         }
         uint32_t comp, depth;
@@ -518,9 +524,11 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         }
         // anchor i-band (a legal predecessor of anchor i, hence handled after the scan) leaves the ring and releases its
         // component; a component without ring members can never be extended again => it is final
-        uint32_t leaving = 0;
+        uint32_t leaving = rd[NB - 1];
+        if (!EXACT) {
 #pragma unroll
-        for (int k = 0; k < NB; k++) leaving = ((uint32_t)k == band - 1) ? rd[k] : leaving;
+            for (int k = 0; k < NB; k++) leaving = ((uint32_t)k == band - 1) ? rd[k] : leaving;
+        }
         if (i >= band) {
             const uint32_t c_old = leaving & 0xFFu;
             const uint32_t v = get_rr(c_old) - 1u;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         }
 #pragma unroll
         for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
-        rq[0] = q; rr[0] = r; rs[0] = (uint32_t)(bscore + ANCHOR_SCORE); rd[0] = (depth << 8) | comp;
+        rq[0] = q + 1u; rr[0] = r + 1u; rs[0] = (uint32_t)(bscore + ANCHOR_SCORE); rd[0] = (depth << 8) | comp;
     }
     // chunk end: every component still referenced by the ring is final now
     const uint32_t live = n < band ? n : band;
@@ -1311,9 +1319,11 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 SKH_LAUNCH(dp_order_keys_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, okeys, order);
                 check_launch("dp_order_keys");
                 sort_pairs_u64_u32(ctx, okeys, order, NC, 10);
-#define SKH_DPT2(NB, LS) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr)
-#define SKH_DPT(NB) do { if (ls == 1) SKH_DPT2(NB, 1); else SKH_DPT2(NB, 8); } while (0)
-                if (band <= 12) SKH_DPT(12); else if (band <= 20) SKH_DPT(20); else if (band <= 28) SKH_DPT(28); else if (band <= 40) SKH_DPT(40); else SKH_DPT(84);
+#define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr)
+#define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)
+                // the presets' bands (2500 / c for c = 200, 125, 70, 30) get kernels with exactly that many ring slots
+                if (band == 12) SKH_DPT(12, true); else if (band == 20) SKH_DPT(20, true); else if (band == 35) SKH_DPT(35, true); else if (band == 83) SKH_DPT(83, true);
+                else if (band <= 12) SKH_DPT(12, false); else if (band <= 20) SKH_DPT(20, false); else if (band <= 28) SKH_DPT(28, false); else if (band <= 40) SKH_DPT(40, false); else SKH_DPT(84, false);
 #undef SKH_DPT
 #undef SKH_DPT2
                 check_launch("chain_dp_thread");

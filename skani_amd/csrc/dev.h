@@ -105,6 +105,14 @@ __device__ __forceinline__ void wave_sync_mem() {
     __builtin_amdgcn_wave_barrier();
 #endif
 }
+// |a - b| of two unsigned numbers in one instruction (v_sad_u32)
+__device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) {
+#ifdef SKANI_EMU
+    return a > b ? a - b : b - a;
+#else
+    uint32_t d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d;      // hipcc expands __usad to min/max/sub
+#endif
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
     unsigned l = lane_id();
