@@ -294,7 +294,7 @@ def main():
         "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms")},
         "roofline": {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": traffic, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch, "launches_per_step": launches / args.steps,
-                     "note": "0.354 algorithmic B/base; kernel is VALU-bound (64-bit hash mix per base), see DESIGN.md"},
+                     "note": "0.354 algorithmic B/base; kernel is bound by VALU issue (23 instructions per window, 64-bit hash mix per base), see DESIGN.md and profiles/r01_valu_rates.md"},
     }
     # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
     # (~0.96 MB per pair of 5 Mbp genomes at c=125)
