@@ -82,6 +82,7 @@ struct skh_genome_set {
     skh::DBuf<uint32_t> nmask;                     // 1 bit per base, LSB-first, 32 bases per word
     skh::DBuf<skh::ContigDesc> d_contigs;
     std::vector<skh::SeedTile> tiles;              // host tile list, ordered by (genome, contig, first)
+    std::vector<uint32_t> genome_first_tile;       // n_genomes + 1: index of each genome's first tile (genomes without tiles: their successor's)
     std::vector<uint32_t> tile_cached_for;         // {mode} the tile list was built for
     skh::DBuf<skh::SeedTile> d_tiles;
 };

@@ -100,6 +100,11 @@ void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const 
         uint32_t nwin = iend - (K_MARKER - 1);
         for (uint32_t t = 0; t * SEED_TILE < nwin; t++) gs->tiles.push_back(SeedTile{i, t});
     }
+    // first tile of every genome (tiles are ordered by genome); genomes without tiles point at their successor's
+    const size_t n_tiles = gs->tiles.size(); const uint32_t ng = gs->n_genomes;
+    gs->genome_first_tile.assign(ng + 1, (uint32_t)n_tiles);
+    for (size_t t = n_tiles; t-- > 0;) gs->genome_first_tile[gs->contigs[gs->tiles[t].contig].genome] = (uint32_t)t;
+    for (uint32_t g = ng; g-- > 0;) gs->genome_first_tile[g] = std::min(gs->genome_first_tile[g], gs->genome_first_tile[g + 1]);
     gs->d_tiles.alloc(gs->tiles.size() ? gs->tiles.size() : 1);
     h2d(gs->d_tiles.p, gs->tiles.data(), gs->tiles.size() * sizeof(SeedTile), ctx->stream);
     dsync(ctx->stream);
@@ -331,10 +336,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
     struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
-    // first tile of every genome (tiles are ordered by genome)
-    std::vector<uint32_t> g_first(ng + 1, (uint32_t)n_tiles);
-    for (size_t t = n_tiles; t-- > 0;) g_first[gs->contigs[gs->tiles[t].contig].genome] = (uint32_t)t;
-    for (uint32_t g = ng; g-- > 0;) if (g_first[g] == (uint32_t)n_tiles || g_first[g] > g_first[g + 1]) g_first[g] = std::min(g_first[g], g_first[g + 1]);
+    const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
     std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);   // running totals at genome starts
 #ifndef SKANI_EMU
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
