@@ -7,33 +7,14 @@ sketches its own block.  Exchange steps:
      nearly flat as ranks are added);
   2. pair (i, j), i < j, is owned by the rank that owns genome i; a rank therefore needs the full sketch of a remote
      genome j only when a candidate pair crosses blocks.  One all-reduce tells whether any pair does; only then do the ranks
-     tell each other which genomes they need and exactly those sketches travel point-to-point (all-to-all of
-     variable-size buffers).  For clade-structured collections nothing moves; in the worst case (every pair crosses) it
+     tell each other which genomes they need and exactly those sketches travel point-to-point, as device tensors
+     (all_to_all_single with variable splits).  For clade-structured collections nothing moves; in the worst case (every pair crosses) it
      degenerates to an all-gather of the raw sketches.
 No collective inside the pair pipeline; the (small) results are all-gathered at the end.  Every collective is a tensor
 collective (all_gather / all_reduce / all_to_all_single): five per triangle in the common case."""
-import pickle
-
 import numpy as np
 
 from . import _binding as B
-
-
-def _all_to_all_bytes(dist, torch, device, payloads):
-    """payloads[r] = bytes for rank r -> list of bytes received from every rank."""
-    world = len(payloads)
-    sizes = torch.tensor([len(p) for p in payloads], dtype=torch.int64, device=device)
-    rsizes = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_to_all_single(rsizes, sizes)
-    rs = [int(x) for x in rsizes.cpu()]
-    send = torch.frombuffer(bytearray(b"".join(payloads)) or bytearray(1), dtype=torch.uint8)[:sum(len(p) for p in payloads)].to(device)
-    recv = torch.empty(sum(rs), dtype=torch.uint8, device=device)
-    dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[len(p) for p in payloads])
-    buf = recv.cpu().numpy().tobytes()
-    out, o = [], 0
-    for n in rs:
-        out.append(buf[o:o + n]); o += n
-    return out
 
 
 def _all_gather_padded(dist, torch, device, t, sizes):
@@ -45,6 +26,87 @@ def _all_gather_padded(dist, torch, device, t, sizes):
     parts = [torch.empty_like(pad) for _ in sizes]
     dist.all_gather(parts, pad)
     return [parts[r][:sizes[r]] for r in range(len(sizes))]
+
+
+def _all_to_all_tensor(dist, torch, device, send, send_counts):
+    """send: 1-D tensor laid out by destination rank, send_counts[r] elements for rank r -> (received tensor, counts per source)."""
+    world = len(send_counts)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
+    rc = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(rc, sc)
+    rcs = [int(x) for x in rc.cpu()]
+    recv = torch.empty(sum(rcs), dtype=send.dtype, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rcs, input_split_sizes=[int(x) for x in send_counts])
+    return recv, rcs
+
+
+def _exchange_sketches(ctx, ss_local, params, need, base, dist, rank, world, torch, device):
+    """Point-to-point exchange of whole sketches: need[r] = sorted global ids of rank r's genomes this rank chains against.
+    Returns (SketchSet of the received genomes in increasing global id, their ids).  The sketch arrays travel as device tensors
+    (export_flat -> slices -> all_to_all_single over RCCL -> import_flat): three payload collectives -- the 32-bit arrays
+    (seed | position | contig-and-strand per genome block), the 64-bit markers, and a small 64-bit header with the per-genome sizes."""
+    on_dev = device.type == "cuda"
+    # which of MY genomes every other rank wants (control plane: a few ids)
+    req = torch.from_numpy(np.concatenate([np.asarray(x, np.int64) for x in need]) if sum(len(x) for x in need) else np.zeros(0, np.int64)).to(device)
+    got, got_counts = _all_to_all_tensor(dist, torch, device, req, [len(x) for x in need])
+    got = got.cpu().numpy(); o = np.concatenate([[0], np.cumsum(got_counts)]).astype(np.int64)
+    wanted = [got[o[r]:o[r + 1]] - base for r in range(world)]                               # local indices, ascending
+    # my arrays, exported once into tensors
+    meta = ss_local.export_meta(); P, M, _ = ss_local.totals()
+    a32 = torch.zeros(max(3 * P, 1), dtype=torch.int32, device=device); m64 = torch.zeros(max(M, 1), dtype=torch.int64, device=device)
+    if on_dev:
+        torch.cuda.synchronize(device)
+        ss_local.export_arrays(seed=a32.data_ptr(), pos=a32.data_ptr() + 4 * P, ctgcanon=a32.data_ptr() + 8 * P, markers=m64.data_ptr(), device=True)
+    else:
+        v = a32.numpy().view(np.uint32)
+        ss_local.export_arrays(seed=v[0:P], pos=v[P:2 * P], ctgcanon=v[2 * P:3 * P], markers=m64.numpy().view(np.uint64))
+    po, mo, co = (meta[k].astype(np.int64) for k in ("pos_off", "marker_off", "contig_off"))
+    s32, s64, hdr, c32, c64, ch = [], [], [], [], [], []
+    for r in range(world):
+        loc = wanted[r]
+        h = [np.array([len(loc)], np.int64)]
+        for g in loc:
+            h.append(np.array([po[g + 1] - po[g], mo[g + 1] - mo[g], co[g + 1] - co[g], meta["total_len"][g]], np.int64))
+            h.append(meta["contig_lengths"][co[g]:co[g + 1]].astype(np.int64))
+        h = np.concatenate(h); hdr.append(h); ch.append(len(h))
+        parts = [a32[k * P + po[g]:k * P + po[g + 1]] for k in range(3) for g in loc]       # all seeds, then all positions, then all contig/strand words
+        s32.append(torch.cat(parts) if parts else a32[:0]); c32.append(int(s32[-1].numel()))
+        parts = [m64[mo[g]:mo[g + 1]] for g in loc]
+        s64.append(torch.cat(parts) if parts else m64[:0]); c64.append(int(s64[-1].numel()))
+    r32, n32 = _all_to_all_tensor(dist, torch, device, torch.cat(s32), c32)
+    r64, n64 = _all_to_all_tensor(dist, torch, device, torch.cat(s64), c64)
+    rh, nh = _all_to_all_tensor(dist, torch, device, torch.from_numpy(np.concatenate(hdr)).to(device), ch)
+    rh = rh.cpu().numpy()
+    # assemble one flat set of all received genomes: sources in rank order = increasing global id
+    ids, npos, nmk, nct, tl, cl = [], [], [], [], [], []
+    oh = 0
+    for r in range(world):
+        h = rh[oh:oh + nh[r]]; oh += nh[r]
+        if not len(h):
+            continue
+        k = int(h[0]); x = 1
+        assert k == len(need[r])
+        for g in range(k):
+            npos.append(int(h[x])); nmk.append(int(h[x + 1])); nct.append(int(h[x + 2])); tl.append(int(h[x + 3])); x += 4
+            cl.append(h[x:x + nct[-1]]); x += nct[-1]
+        ids.extend(int(v) for v in need[r])
+    o32 = np.concatenate([[0], np.cumsum(n32)]).astype(np.int64)
+    seeds, poss, ccs = [], [], []
+    for r in range(world):
+        blk = r32[o32[r]:o32[r + 1]]; t = blk.numel() // 3
+        seeds.append(blk[0:t]); poss.append(blk[t:2 * t]); ccs.append(blk[2 * t:3 * t])
+    seed_t, pos_t, cc_t = (torch.cat(x).contiguous() if x else a32[:0] for x in (seeds, poss, ccs))
+    cum = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+    gmeta = dict(pos_off=cum(npos), marker_off=cum(nmk), contig_off=cum(nct), contig_lengths=(np.concatenate(cl) if cl else np.zeros(0, np.int64)).astype(np.uint32),
+                 total_len=np.array(tl, np.uint64), genome_rank=np.array(ids, np.uint32))
+    if on_dev:
+        torch.cuda.synchronize(device)
+        keep = [t_ if t_.numel() else torch.zeros(1, dtype=t_.dtype, device=device) for t_ in (seed_t, pos_t, cc_t, r64)]
+        ss = ctx.import_flat(params, gmeta, seed=keep[0].data_ptr(), pos=keep[1].data_ptr(), ctgcanon=keep[2].data_ptr(), markers=keep[3].data_ptr(), device=True)
+    else:
+        ss = ctx.import_flat(params, gmeta, seed=seed_t.numpy().view(np.uint32), pos=pos_t.numpy().view(np.uint32), ctgcanon=cc_t.numpy().view(np.uint32),
+                             markers=r64.numpy().view(np.uint64))
+    return ss, np.array(ids, np.uint32)
 
 
 def _gather_markers(ctx, ss_local, params, dist, rank, world, torch, device):
@@ -103,16 +165,10 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
     need = [np.unique(gj[owner_j == r]) if r != rank else np.zeros(0, np.uint32) for r in range(world)]
     crossing = torch.tensor([sum(len(x) for x in need)], dtype=torch.int64, device=device)
     dist.all_reduce(crossing)                                                        # collective 3
-    remote = {}
+    ss_rem, rem_ids = None, np.zeros(0, np.uint32)
     if int(crossing.item()) > 0:
-        requests = [pickle.dumps(x, protocol=4) for x in need]
-        wanted = [pickle.loads(b) for b in _all_to_all_bytes(dist, torch, device, requests)]      # wanted[r]: my genomes that rank r needs
-        payloads = [pickle.dumps([(int(g), ss_local.export(int(g) - base)) for g in lst], protocol=4) for lst in wanted]
-        for blob in _all_to_all_bytes(dist, torch, device, payloads):
-            for g, rec in pickle.loads(blob):
-                remote[g] = rec
-    rem_ids = sorted(remote)
-    rem_index = {g: k for k, g in enumerate(rem_ids)}
+        ss_rem, rem_ids = _exchange_sketches(ctx, ss_local, params, need, base, dist, rank, world, torch, device)
+    rem_index = {int(g): k for k, g in enumerate(rem_ids)}
     local_pair = owner_j == rank
     res_parts = []
     n_chained = int(len(gi))
@@ -120,10 +176,10 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
         r = ctx.chain_pairs(ss_local, None, gi[local_pair] - base, gj[local_pair] - base, map_params)
         res_parts.append((gi[local_pair], gj[local_pair], r))
     if (~local_pair).any():
-        ss_rem = ctx.import_sketches(params, [remote[g] for g in rem_ids], genome_rank=np.array(rem_ids, dtype=np.uint32))
         qi = np.array([rem_index[int(g)] for g in gj[~local_pair]], dtype=np.uint32)
         r = ctx.chain_pairs(ss_local, ss_rem, gi[~local_pair] - base, qi, map_params)      # ref = genome i (local), query = genome j (remote)
         res_parts.append((gi[~local_pair], gj[~local_pair], r))
+    if ss_rem is not None:
         ss_rem.close()
     if res_parts:
         ai = np.concatenate([p[0] for p in res_parts]); aj = np.concatenate([p[1] for p in res_parts]); ar = np.concatenate([p[2] for p in res_parts])

@@ -79,7 +79,7 @@ def test_two_rank_triangle_matches_single_process(interleave):
     assert np.array_equal(si, i) and np.array_equal(sj, j) and sres.tobytes() == res.tobytes()
 
 
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, interleave=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -90,7 +90,7 @@ def _gpu_worker(rank, world, port, q):
     try:
         dev = torch.device("cuda:0")
         ctx = sk.Context(0)
-        genomes = _test_genomes(interleave=False)
+        genomes = _test_genomes(interleave)
         per = len(genomes) // world
         mine = genomes[rank * per:(rank + 1) * per]
         params = sk.SketchParams()
@@ -104,20 +104,22 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_device_tensors_on_one_gpu():
+@pytest.mark.parametrize("interleave", [False, True])
+def test_two_ranks_device_tensors_on_one_gpu(interleave):
     """The device-memory path of the exchange (export into torch CUDA tensors -> all_gather -> import from the gathered tensor,
-    results gathered as CUDA byte tensors): two processes share the one GPU, collectives by gloo (RCCL needs one GPU per rank)."""
+    results gathered as CUDA byte tensors; interleave: pairs cross the rank blocks, so whole sketches travel as CUDA tensors through
+    all_to_all_single): two processes share the one GPU, collectives by gloo (RCCL needs one GPU per rank)."""
     import multiprocessing as mp
     import skani_amd as sk
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue(); port = _free_port()
-    procs = [ctxm.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctxm.Process(target=_gpu_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
     for p in procs:
         p.start()
     i, j, res, n = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120); assert p.exitcode == 0
-    genomes = _test_genomes(interleave=False)
+    genomes = _test_genomes(interleave)
     ctx = sk.Context(0)
     ss = ctx.sketch_records(genomes, sk.SketchParams(), None)
     si, sj, sres, sn = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
