@@ -589,7 +589,14 @@ constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidat
 //   of dependent instructions, and other waves are the only thing that can fill its issue slots.
 //   Pairs are handed out by decreasing candidate count (greedy_order_keys_kernel + a 16-bit radix sort): the kernel ends when its
 //   slowest wave does, so the long ones start first.
-struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1, pad0, pad1; };   // 32 B: two 16-byte LDS broadcasts per accepted interval
+// Accepted interval, 32 B (two 16-byte LDS reads), threaded on up to three lists: the accepted intervals of its chunk (query axis) and
+// those of the one or two GREEDY_BIN-sized bins of the reference axis it touches (intervals spanning more go on a separate short list)
+struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1; uint16_t qnext, rnext0, rnext1, cand; };   // cand = the interval's index among the pair's candidates
+constexpr uint32_t GREEDY_BIN_SHIFT = 15;       // 32 kb reference bins: a chain interval of a 20 kb chunk touches one or two
+constexpr uint32_t GREEDY_BUCKETS = 256;        // list heads per axis (hashed chunk id / hashed (contig, bin)); 1 KB per wave keeps four workgroups of the 512 class on a CU
+constexpr uint32_t GREEDY_LONG = 64;            // accepted intervals spanning more than two bins (beyond that: every candidate scans the whole list)
+__device__ __forceinline__ uint32_t greedy_rhash(uint32_t rctg, uint32_t bin) { return (rctg * 37u + bin) & (GREEDY_BUCKETS - 1u); }
+__device__ __forceinline__ uint32_t greedy_last_bin(uint32_t r0, uint32_t r1) { const uint32_t b0 = r0 >> GREEDY_BIN_SHIFT, b1 = (r1 ? r1 - 1u : 0u) >> GREEDY_BIN_SHIFT; return b1 > b0 ? b1 : b0; }
 __global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint64_t* keys, uint32_t* vals) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
@@ -601,6 +608,7 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                                                           const Interval* ivls, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ uint32_t lds_idx[2][CAP];
     __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
+    __shared__ uint16_t lds_qh[2][GREEDY_BUCKETS], lds_rh[2][GREEDY_BUCKETS], lds_long[2][GREEDY_LONG];
     const uint32_t wv = threadIdx.x >> 6;
     if (blockIdx.x * 2 + wv >= n_pairs) return;
     const uint32_t p = order[blockIdx.x * 2 + wv];
@@ -637,22 +645,47 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
         }
     }
     AccIvl* acc = lds_acc[wv];
-    uint32_t nacc = 0;
+    uint16_t* qh = lds_qh[wv]; uint16_t* rh = lds_rh[wv]; uint16_t* lng = lds_long[wv];
+    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = 0xFFFFu; rh[i] = 0xFFFFu; }
+    wave_sync_mem();
+    uint32_t nacc = 0, nlong = 0;
+    bool long_overflow = false;                                                     // more than GREEDY_LONG wide intervals: fall back to scanning everything
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t s = base + l;
         const bool have = s < n;
         const uint32_t ci = have ? idx[s] : 0;
         Interval c = iv[ci];
         uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
-#pragma unroll 4
-        for (uint32_t a = 0; a < nacc; a++) {                                      // uniform index: LDS broadcast (several in flight)
-            const uint4 lo4 = *(const uint4*)&acc[a]; const uint2 hi2 = *(const uint2*)&acc[a].q0;
-            const uint32_t actg = lo4.x, ar0 = lo4.y, ar1 = lo4.z, aqc = lo4.w, aq0 = hi2.x, aq1 = hi2.y;
-            const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;             // chain.rs:1030-1045
-            const bool hq = aqc == c.qctg && aq0 < c.q1 && c.q0 < aq1;              // chain.rs:1059-1073
-            const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
+        auto add_r = [&](const AccIvl& a) {                                        // chain.rs:1030-1045
+            const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a.r1;
+            const uint32_t xr = c.r1 - a.r0, yr = a.r1 - c.r0;
             cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+        };
+        auto add_q = [&](const AccIvl& a) {                                        // chain.rs:1059-1073
+            const bool hq = a.qctg == c.qctg && a.q0 < c.q1 && c.q0 < a.q1;
+            const uint32_t xq = c.q1 - a.q0, yq = a.q1 - c.q0;
             cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+        };
+        if (long_overflow) {
+            for (uint32_t a = 0; a < nacc; a++) { const AccIvl e = acc[a]; add_r(e); add_q(e); }   // uniform index: LDS broadcast
+        } else {
+            // Accepted intervals that can overlap this candidate: on the query axis those of its own chunk (chunks are disjoint ranges of one
+            // contig), on the reference axis those sharing a bin with it.  An interval listed in two bins is counted in the bin that holds
+            // max(candidate start, interval start), a point of the overlap if there is one.
+            for (uint32_t a = qh[c.chunk & (GREEDY_BUCKETS - 1u)]; a != 0xFFFFu;) { const AccIvl e = acc[a]; add_q(e); a = e.qnext; }
+            const uint32_t c0 = c.r0 >> GREEDY_BIN_SHIFT, c1 = greedy_last_bin(c.r0, c.r1);
+            for (uint32_t x = c0; x <= c1; x++) {
+                const uint32_t h = greedy_rhash(c.rctg, x);
+                for (uint32_t a = rh[h]; a != 0xFFFFu;) {
+                    const AccIvl e = acc[a];
+                    const uint32_t e0 = e.r0 >> GREEDY_BIN_SHIFT;
+                    const bool first = greedy_rhash(e.rctg, e0) == h;               // which of the interval's (at most two, consecutive) bins hangs on this head
+                    const uint32_t eb = first ? e0 : e0 + 1u;
+                    if (e.rctg == c.rctg && eb == x && x == (c0 > e0 ? c0 : e0)) add_r(e);
+                    a = first ? e.rnext0 : e.rnext1;
+                }
+            }
+            for (uint32_t t = 0; t < nlong; t++) add_r(acc[lng[t]]);
         }
         const uint32_t nb = n - base < 64 ? n - base : 64;
         for (uint32_t b = 0; b < nb; b++) {
@@ -670,15 +703,33 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                     cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
                     cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
                 }
+                const uint32_t b0 = ar0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(ar0, ar1);
+                const bool wide = b1 - b0 >= 2u;                                   // wave-uniform, like everything about the accepted interval
                 if (l == 0) {
-                    acc[nacc] = AccIvl{actg, ar0, ar1, aqc, aq0, aq1, 0u, 0u};
-                    const uint32_t slot = pc0[p] + bchunk;
-                    ivl_next[I0 + bci] = chunk_head[slot]; chunk_head[slot] = I0 + bci;   // good_non_overlap_intervals[chunk_id].push
+                    AccIvl e{actg, ar0, ar1, aqc, aq0, aq1, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0u};
+                    const uint32_t qb = bchunk & (GREEDY_BUCKETS - 1u);
+                    e.qnext = qh[qb]; qh[qb] = (uint16_t)nacc;
+                    if (!wide) {
+                        const uint32_t h0 = greedy_rhash(actg, b0);
+                        e.rnext0 = rh[h0]; rh[h0] = (uint16_t)nacc;
+                        if (b1 > b0) { const uint32_t h1 = greedy_rhash(actg, b1); e.rnext1 = rh[h1]; rh[h1] = (uint16_t)nacc; }
+                    } else if (nlong < GREEDY_LONG) lng[nlong] = (uint16_t)nacc;
+                    e.cand = (uint16_t)bci;
+                    acc[nacc] = e;
                 }
+                if (wide) { if (nlong < GREEDY_LONG) nlong++; else long_overflow = true; }
                 nacc++;
             }
         }
         wave_sync_mem();
+    }
+    // good_non_overlap_intervals[chunk_id].push (chain.rs:1086-1094) for all accepted intervals at once: the per-chunk lists are only ever
+    // summed over (chunk_stats_kernel), so their order is free -- and a push from inside the loop above would put a global-memory round trip
+    // (read the chunk's head) into every one of the ~400 sequential steps of a pair
+    for (uint32_t a = l; a < nacc; a += 64) {
+        const uint32_t bci = acc[a].cand;
+        const uint32_t slot = pc0[p] + iv[bci].chunk;
+        ivl_next[I0 + bci] = atomicExch(&chunk_head[slot], I0 + bci);
     }
     if (l == 0) n_accepted[p] = nacc;
 }
