@@ -596,6 +596,13 @@ constexpr uint32_t GREEDY_BIN_SHIFT = 15;       // 32 kb reference bins: a chain
 constexpr uint32_t GREEDY_BUCKETS = 256;        // list heads per axis (hashed chunk id / hashed (contig, bin)); 1 KB per wave keeps four workgroups of the 512 class on a CU
 constexpr uint32_t GREEDY_LONG = 64;            // accepted intervals spanning more than two bins (beyond that: every candidate scans the whole list)
 __device__ __forceinline__ uint32_t greedy_rhash(uint32_t rctg, uint32_t bin) { return (rctg * 37u + bin) & (GREEDY_BUCKETS - 1u); }
+// heads[bucket] <- value, returns the previous head; the 16-bit heads are exchanged through a compare-and-swap on their 32-bit word
+__device__ __forceinline__ uint32_t greedy_push(uint16_t* heads, uint32_t bucket, uint32_t value) {
+    unsigned* w = (unsigned*)heads + (bucket >> 1); const uint32_t sh = (bucket & 1u) * 16u;
+    unsigned seen = *w, prev;
+    do { prev = seen; seen = atomicCAS(w, prev, (prev & ~(0xFFFFu << sh)) | (value << sh)); } while (seen != prev);
+    return (prev >> sh) & 0xFFFFu;
+}
 __device__ __forceinline__ uint32_t greedy_last_bin(uint32_t r0, uint32_t r1) { const uint32_t b0 = r0 >> GREEDY_BIN_SHIFT, b1 = (r1 ? r1 - 1u : 0u) >> GREEDY_BIN_SHIFT; return b1 > b0 ? b1 : b0; }
 __global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint64_t* keys, uint32_t* vals) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,7 +615,8 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                                                           const Interval* ivls, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ uint32_t lds_idx[2][CAP];
     __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
-    __shared__ uint16_t lds_qh[2][GREEDY_BUCKETS], lds_rh[2][GREEDY_BUCKETS], lds_long[2][GREEDY_LONG];
+    __shared__ __attribute__((aligned(4))) uint16_t lds_qh[2][GREEDY_BUCKETS], lds_rh[2][GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
+    __shared__ uint16_t lds_long[2][GREEDY_LONG];
     const uint32_t wv = threadIdx.x >> 6;
     if (blockIdx.x * 2 + wv >= n_pairs) return;
     const uint32_t p = order[blockIdx.x * 2 + wv];
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
             }
             for (uint32_t t = 0; t < nlong; t++) add_r(acc[lng[t]]);
         }
-        const uint32_t nb = n - base < 64 ? n - base : 64;
+        const uint32_t nb = n - base < 64 ? n - base : 64, nacc0 = nacc;
         for (uint32_t b = 0; b < nb; b++) {
             const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
             const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
@@ -705,20 +713,24 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                 }
                 const uint32_t b0 = ar0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(ar0, ar1);
                 const bool wide = b1 - b0 >= 2u;                                   // wave-uniform, like everything about the accepted interval
-                if (l == 0) {
-                    AccIvl e{actg, ar0, ar1, aqc, aq0, aq1, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0u};
-                    const uint32_t qb = bchunk & (GREEDY_BUCKETS - 1u);
-                    e.qnext = qh[qb]; qh[qb] = (uint16_t)nacc;
-                    if (!wide) {
-                        const uint32_t h0 = greedy_rhash(actg, b0);
-                        e.rnext0 = rh[h0]; rh[h0] = (uint16_t)nacc;
-                        if (b1 > b0) { const uint32_t h1 = greedy_rhash(actg, b1); e.rnext1 = rh[h1]; rh[h1] = (uint16_t)nacc; }
-                    } else if (nlong < GREEDY_LONG) lng[nlong] = (uint16_t)nacc;
-                    e.cand = (uint16_t)bci;
-                    acc[nacc] = e;
+                if (l == 0) {                                                      // stores only: nothing in this loop waits for LDS
+                    acc[nacc] = AccIvl{actg, ar0, ar1, aqc, aq0, aq1, (uint16_t)(bchunk & (GREEDY_BUCKETS - 1u)) /* its query-axis list, until it is linked */,
+                                       0xFFFFu, 0xFFFFu, (uint16_t)bci};
+                    if (wide && nlong < GREEDY_LONG) lng[nlong] = (uint16_t)nacc;
                 }
                 if (wide) { if (nlong < GREEDY_LONG) nlong++; else long_overflow = true; }
                 nacc++;
+            }
+        }
+        wave_sync_mem();
+        // link this batch's accepted intervals into the lists, one per lane (the lists' order is free)
+        if (nacc0 + l < nacc) {
+            AccIvl* e = &acc[nacc0 + l];
+            e->qnext = (uint16_t)greedy_push(qh, e->qnext, nacc0 + l);
+            const uint32_t b0 = e->r0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(e->r0, e->r1);
+            if (b1 - b0 < 2u) {
+                e->rnext0 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b0), nacc0 + l);
+                if (b1 > b0) e->rnext1 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b1), nacc0 + l);
             }
         }
         wave_sync_mem();
