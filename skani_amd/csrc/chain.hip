@@ -392,10 +392,13 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
 // away: the kernel writes nothing per anchor.
 // the interval record of a finished chain (root anchor .. best anchor), back in contig-local coordinates (types.rs:508-519)
 struct EmitCtx { const uint32_t *anc_q, *anc_r; const PairDesc* pairs; const uint32_t *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
-__device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec) {
+__device__ __forceinline__ bool dp_keep(unsigned long long b) {                  // chain.rs:954-957, 974-977
+    const uint32_t sc = (uint32_t)(b >> 40), na = (uint32_t)(b & 0xFFFFFu);
+    return na >= MIN_ANCHORS && (int32_t)sc >= MIN_SCORE;
+}
+// writes the record of a kept chain as the pair's k-th candidate interval
+__device__ __forceinline__ void dp_write(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec, uint32_t k) {
     const uint32_t sc = (uint32_t)(b >> 40), bi = (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
-    if (na < MIN_ANCHORS || (int32_t)sc < MIN_SCORE) return;                        // chain.rs:954-957, 974-977
-    const uint32_t k = atomicAdd(&ec.ivl_cnt[p], 1u);
     if (ec.pi0[p] + k >= ec.pi0[p + 1]) { atomicAdd(ec.err, 1u); return; }
     const uint2 ar = make_uint2(ec.anc_q[ck.a_begin + root], ec.anc_r[ck.a_begin + root]), ab = make_uint2(ec.anc_q[ck.a_begin + bi], ec.anc_r[ck.a_begin + bi]);
     const PairDesc& pd = ec.pairs[p];
@@ -408,6 +411,9 @@ __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t
     iv.rctg = rctg; iv.qctg = ck.qctg; iv.chunk = slot - ec.pc0[p]; iv.rev = ar.y & 1u;
     ec.ivls[ec.pi0[p] + k] = iv;
 }
+__device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec) {
+    if (dp_keep(b)) dp_write(ck, slot, p, root, b, ec, atomicAdd(&ec.ivl_cnt[p], 1u));
+}
 
 // The 64 lanes of a wave step through their chunks in lockstep, so a wave takes as long as its longest chunk: chunks are
 // handed out in order of decreasing anchor count (dp_order_keys_kernel + a 10-bit radix sort), which puts chunks of nearly equal
@@ -419,12 +425,15 @@ __global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, co
     keys[i] = 1023u - (len >= 1023u ? 1023u : len); vals[i] = i;
 }
 
+#ifndef DP_EMIT_Q
+#define DP_EMIT_Q 6    // parked chains per chunk (16 B each in a global queue)
+#endif
 #ifndef DP_LINE
 #define DP_LINE 8     // anchors per fetched line: 8 (32 B) measured best (2.04 ms; 16: 2.44 ms, 4: 2.06 ms) -- less LDS, one more wave per SIMD
 #endif
 template <int NB, int T, uint32_t DP_LDS_SLOTS, bool EXACT>   // EXACT: band == NB (the presets' bands), no per-slot band test
 __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* order, uint32_t band,
-                                                            EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr) {
+                                                            EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr, uint4* emit_q, uint32_t emit_cap) {
     __shared__ unsigned long long lds_best[DP_LDS_SLOTS * T];                       // [slot][lane]
     __shared__ uint32_t lds_rr[DP_LDS_SLOTS * T];                                   // [slot][lane]: root << 8 | refcount
     const uint32_t C = band + 1, tid = threadIdx.x;
@@ -440,6 +449,16 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     const uint32_t n = ck.a_end - ck.a_begin;
     if (n >= MAX_CHUNK_ANCHORS) { atomicAdd(ec.err, 1u); return; }
     const uint32_t p = n ? chunk_pair[slot] : 0;
+    // A finished chain is not turned into its interval record on the spot: that is a chain of dependent global round trips (reserve a slot,
+    // fetch two anchors, search the contig table) during which the other 63 lanes of the wave would wait, once for every chain of every lane.
+    // The lane parks (root, best) in its column of a global queue -- a store, nothing to wait for -- and all lanes write their records
+    // together after the scan.  DP_EMIT_Q chains per chunk fit (mean 2); further ones are written directly.
+    uint32_t nq = 0;
+    auto emit = [&](uint32_t root, unsigned long long b) {
+        if (!dp_keep(b)) return;
+        if (nq < emit_cap) { emit_q[(size_t)nq * n_thr + thr] = make_uint4(root, (uint32_t)b, (uint32_t)(b >> 32), 0u); nq++; }
+        else dp_emit(ck, slot, p, root, b, ec);
+    };
     unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
     // ring of the last NB anchors: q + 1, strand-signed r + 1, score + ANCHOR_SCORE, depth << 8 | component.
     //  * r is kept as s = reverse ? ~r : r.  For two anchors of the same strand s_i - s_j is the forward distance on that strand
@@ -533,7 +552,7 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
             const uint32_t c_old = leaving & 0xFFu;
             const uint32_t v = get_rr(c_old) - 1u;
             set_rr(c_old, v);
-            if ((v & 0xFFu) == 0) { dp_emit(ck, slot, p, v >> 8, get_best(c_old), ec); free_mask |= 1ull << c_old; }
+            if ((v & 0xFFu) == 0) { emit(v >> 8, get_best(c_old)); free_mask |= 1ull << c_old; }
         }
 #pragma unroll
         for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
@@ -547,7 +566,14 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
             const uint32_t c_old = rd[k] & 0xFFu;
             const uint32_t v = get_rr(c_old) - 1u;
             set_rr(c_old, v);
-            if ((v & 0xFFu) == 0) dp_emit(ck, slot, p, v >> 8, get_best(c_old), ec);
+            if ((v & 0xFFu) == 0) emit(v >> 8, get_best(c_old));
+        }
+    }
+    if (nq) {
+        const uint32_t k0 = atomicAdd(&ec.ivl_cnt[p], nq);
+        for (uint32_t e = 0; e < nq; e++) {
+            const uint4 r = emit_q[(size_t)e * n_thr + thr];
+            dp_write(ck, slot, p, r.x, ((unsigned long long)r.z << 32) | r.y, ec, k0 + e);
         }
     }
 }
@@ -1378,11 +1404,12 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 const uint32_t ls = ctx->tune.chain_dp_lds_slots <= 1 ? 1u : 8u;  // 1: tests push every second live chain through the spill table
                 const size_t n_spill = band + 1 > ls ? (size_t)(band + 1 - ls) * gt * T : 1;   // written only by chunks with more live chains than LDS slots
                 unsigned long long* spill_best = ctx->arena.get<unsigned long long>(n_spill); uint32_t* spill_rr = ctx->arena.get<uint32_t>(n_spill);
+                uint4* emit_q = ctx->arena.get<uint4>((size_t)DP_EMIT_Q * gt * T);
                 uint64_t* okeys = ctx->arena.get<uint64_t>(NC); uint32_t* order = ctx->arena.get<uint32_t>(NC);
                 SKH_LAUNCH(dp_order_keys_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, okeys, order);
                 check_launch("dp_order_keys");
                 sort_pairs_u64_u32(ctx, okeys, order, NC, 10);
-#define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr)
+#define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
 #define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)
                 // the presets' bands (2500 / c for c = 200, 125, 70, 30) get kernels with exactly that many ring slots
                 if (band == 12) SKH_DPT(12, true); else if (band == 20) SKH_DPT(20, true); else if (band == 35) SKH_DPT(35, true); else if (band == 83) SKH_DPT(83, true);
