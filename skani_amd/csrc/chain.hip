@@ -214,9 +214,25 @@ __device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
     return v;
 }
 
+// Two-level search: every CHUNK_SAMPLE-th key of the pair's anchor / position arrays is copied to LDS once; a search first narrows its
+// range [lo, hi) to one sample interval there (LDS round trips) and only the last log2(CHUNK_SAMPLE) probes go to memory.
+// UPPER: first index whose key is > v; otherwise first index whose key is >= v.  samp[t] = key(array[org + t * CHUNK_SAMPLE]), t < ns.
+constexpr uint32_t CHUNK_SAMPLE = 128, CHUNK_SAMPLES = 512;     // 2 x 2 KB of LDS per wave; arrays beyond 65,536 entries are searched directly
+template <bool UPPER>
+__device__ __forceinline__ void narrow_by_samples(const uint32_t* samp, uint32_t ns, uint32_t org, uint32_t v, uint32_t& lo, uint32_t& hi) {
+    if (lo >= hi) return;
+    const uint32_t t0 = (lo - org + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE;
+    uint32_t t1 = (hi - org + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE; if (t1 > ns) t1 = ns;
+    uint32_t a = t0, b = t1;                                                        // first sample in [t0, t1) for which the predicate holds
+    while (a < b) { const uint32_t m = (a + b) >> 1; const uint32_t x = samp[m]; if (UPPER ? x > v : x >= v) b = m; else a = m + 1; }
+    if (a > t0) { const uint32_t f = org + (a - 1) * CHUNK_SAMPLE + 1; lo = f > lo ? f : lo; }     // sample a-1 fails: the answer lies beyond it
+    if (a < t1) { const uint32_t t = org + a * CHUNK_SAMPLE; hi = t < hi ? t : hi; }               // sample a holds: the answer is at or before it
+}
+
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0,
                                                     const uint32_t* pc0, const uint32_t* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
+    __shared__ uint32_t lds_samp[4][2][CHUNK_SAMPLES];
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();
@@ -227,7 +243,17 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         const uint32_t nctg = pairs[p].a_nctg;
         const uint32_t* ag = pairs[p].a_g; const uint32_t Q1 = pairs[p].a_n;         // the enumerated sketch's positions
         const uint32_t q_pair_last = anc_q[A1 - 1];
-        const uint32_t s_final = pos_first_above(ag, 0, Q1, q_pair_last);           // the pair's final chunk ends its seed range here (chain.rs:794-824)
+        const uint32_t ns_a = (A1 - A0 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE, ns_s = (Q1 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE;
+        const bool sampled = ns_a <= CHUNK_SAMPLES && ns_s <= CHUNK_SAMPLES;
+        uint32_t* sa = lds_samp[threadIdx.x >> 6][0]; uint32_t* ss = lds_samp[threadIdx.x >> 6][1];
+        if (sampled) {
+            for (uint32_t t = l; t < ns_a; t += 64) sa[t] = anc_q[A0 + t * CHUNK_SAMPLE];
+            for (uint32_t t = l; t < ns_s; t += 64) ss[t] = ag[t * CHUNK_SAMPLE] >> 1;
+            wave_sync_mem();
+        }
+        uint32_t sf_lo = 0, sf_hi = Q1;
+        if (sampled) narrow_by_samples<true>(ss, ns_s, 0, q_pair_last, sf_lo, sf_hi);
+        const uint32_t s_final = pos_first_above(ag, sf_lo, sf_hi, q_pair_last);    // the pair's final chunk ends its seed range here (chain.rs:794-824)
         uint32_t a = A0;
         while (a < A1) {                                                           // one query contig per round (wave-uniform)
             const uint32_t q_first = anc_q[a];
@@ -245,6 +271,10 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 //   sb = first position beyond lim (per lane) = seed list boundary after chunk k
                 //   e  = first anchor of the next contig, rc0 = first position of this contig (wave-uniform; first batch only)
                 uint32_t lo_b = a, hi_b = A1, lo_s = 0, hi_s = Q1, lo_e = a, hi_e = kb ? a : A1, lo_r = 0, hi_r = kb ? 0 : Q1;
+                if (sampled) {
+                    narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s);
+                    narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e); narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
+                }
                 while (__ballot(lo_b < hi_b || lo_s < hi_s) != 0ull || lo_e < hi_e || lo_r < hi_r) {
                     const uint32_t mb = (lo_b + hi_b) >> 1, ms = (lo_s + hi_s) >> 1, me = (lo_e + hi_e) >> 1, mr = (lo_r + hi_r) >> 1;
                     const uint32_t vb = lo_b < hi_b ? anc_q[mb] : 0u, vs = lo_s < hi_s ? ag[ms] >> 1 : 0u;
