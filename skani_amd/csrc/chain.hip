@@ -254,49 +254,67 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         uint32_t sf_lo = 0, sf_hi = Q1;
         if (sampled) narrow_by_samples<true>(ss, ns_s, 0, q_pair_last, sf_lo, sf_hi);
         const uint32_t s_final = pos_first_above(ag, sf_lo, sf_hi, q_pair_last);    // the pair's final chunk ends its seed range here (chain.rs:794-824)
-        uint32_t a = A0;
-        while (a < A1) {                                                           // one query contig per round (wave-uniform)
-            const uint32_t q_first = anc_q[a];
-            const uint32_t ctg = ctg_of(go, nctg, q_first), cstart = go[ctg], cnext = go[ctg + 1];
-            uint32_t e = A1, rc0 = 0, q_last = 0, k_max = 1;
-            int32_t carry = (int32_t)a;                                             // u_0 = t_0 - 0
-            uint32_t t_prev_carry = a, s_prev_carry = 0;                           // t_{k-1}, seed boundary of chunk k-1 for the batch's first lane
-            for (uint32_t kb = 0; kb < k_max && t_prev_carry < e; kb += 64) {
-                const uint32_t k = kb + l + 1;
-                const uint64_t end64 = (uint64_t)q_first + (uint64_t)k * CHUNK_SIZE;
-                const uint32_t lim = end64 < (uint64_t)(cnext - 1) ? (uint32_t)end64 : cnext - 1;   // beyond it: another contig, or past the window
-                // four binary searches advance together, one probe each per step, so that their memory round trips overlap:
-                //   b  = first anchor beyond lim (per lane; searching all of the pair's later anchors gives the same answer as
-                //        searching the contig, because the contig's successor already lies beyond lim)
-                //   sb = first position beyond lim (per lane) = seed list boundary after chunk k
-                //   e  = first anchor of the next contig, rc0 = first position of this contig (wave-uniform; first batch only)
-                uint32_t lo_b = a, hi_b = A1, lo_s = 0, hi_s = Q1, lo_e = a, hi_e = kb ? a : A1, lo_r = 0, hi_r = kb ? 0 : Q1;
-                if (sampled) {
-                    narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s);
-                    narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e); narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
-                }
-                while (__ballot(lo_b < hi_b || lo_s < hi_s) != 0ull || lo_e < hi_e || lo_r < hi_r) {
-                    const uint32_t mb = (lo_b + hi_b) >> 1, ms = (lo_s + hi_s) >> 1, me = (lo_e + hi_e) >> 1, mr = (lo_r + hi_r) >> 1;
+        // 64 query contigs per round, one per lane: the contig's anchor range [ca, ce), its first position rc0 and its number of end points;
+        // then the (contig, k) items of the round are worked off 64 at a time -- a genome in a thousand contigs costs rounds of searches by the
+        // sixty-fourth of its contigs, not by the contig
+        uint32_t carry_cid = NONE, carry_t = 0, carry_s = 0; int32_t carry_uu = 0;
+        for (uint32_t c0 = 0; c0 < nctg; c0 += 64) {
+            const uint32_t cl = c0 + l; const bool cv = cl < nctg;
+            const uint32_t cstart = cv ? go[cl] : 0xFFFFFFFFu, cnext = cv ? go[cl + 1] : 0xFFFFFFFFu;
+            uint32_t lo_a = A0, hi_a = cv ? A1 : A0, lo_e = A0, hi_e = cv ? A1 : A0, lo_r = 0, hi_r = cv ? Q1 : 0;
+            if (sampled) {
+                narrow_by_samples<false>(sa, ns_a, A0, cstart, lo_a, hi_a); narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e);
+                narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
+            }
+            while (__ballot(lo_a < hi_a || lo_e < hi_e || lo_r < hi_r) != 0ull) {  // the three searches advance together: their round trips overlap
+                const uint32_t ma = (lo_a + hi_a) >> 1, me = (lo_e + hi_e) >> 1, mr = (lo_r + hi_r) >> 1;
+                const uint32_t va = lo_a < hi_a ? anc_q[ma] : 0u, ve = lo_e < hi_e ? anc_q[me] : 0u, vr = lo_r < hi_r ? ag[mr] >> 1 : 0u;
+                if (lo_a < hi_a) { if (va < cstart) lo_a = ma + 1; else hi_a = ma; }
+                if (lo_e < hi_e) { if (ve < cnext) lo_e = me + 1; else hi_e = me; }
+                if (lo_r < hi_r) { if (vr < cstart) lo_r = mr + 1; else hi_r = mr; }
+            }
+            const uint32_t ca = lo_a, ce = lo_e, rc0 = lo_r;                        // running_counter = 0 within the contig starts at rc0 (chain.rs:742-744)
+            const bool has = cv && ce > ca;
+            const uint32_t q_first = has ? anc_q[ca] : 0u, q_last = has ? anc_q[ce - 1] : 0u;
+            const uint32_t kmax = has ? (q_last - q_first) / CHUNK_SIZE + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
+            const uint32_t P = wave_incl_scan(kmax), M = __shfl(P, 63, 64);
+            for (uint32_t j0 = 0; j0 < M; j0 += 64) {
+                const uint32_t j = j0 + l; const bool iv = j < M;
+                uint32_t slo = 0, shi = 63;                                        // the lane (contig) that owns item j: first with P > j
+#pragma unroll
+                for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; const uint32_t pm = __shfl(P, (int)mid, 64); if (pm > j) shi = mid; else slo = mid + 1; }
+                const int src = (int)(iv ? slo : 63u);
+                const uint32_t o_kmax = __shfl(kmax, src, 64), o_P = __shfl(P, src, 64), a_c = __shfl(ca, src, 64), e_c = __shfl(ce, src, 64), r_c = __shfl(rc0, src, 64);
+                const uint32_t qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64), cs = __shfl(cstart, src, 64);
+                const uint32_t k = j - (o_P - o_kmax) + 1u;
+                const uint64_t end64 = (uint64_t)qf + (uint64_t)k * CHUNK_SIZE;
+                const uint32_t lim = end64 < (uint64_t)(cn - 1) ? (uint32_t)end64 : cn - 1;   // beyond it: another contig, or past the window
+                //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
+                //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
+                uint32_t lo_b = a_c, hi_b = iv ? A1 : a_c, lo_s = 0, hi_s = iv ? Q1 : 0;
+                if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
+                while (__ballot(lo_b < hi_b || lo_s < hi_s) != 0ull) {
+                    const uint32_t mb = (lo_b + hi_b) >> 1, ms = (lo_s + hi_s) >> 1;
                     const uint32_t vb = lo_b < hi_b ? anc_q[mb] : 0u, vs = lo_s < hi_s ? ag[ms] >> 1 : 0u;
-                    const uint32_t ve = lo_e < hi_e ? anc_q[me] : 0u, vr = lo_r < hi_r ? ag[mr] >> 1 : 0u;
                     if (lo_b < hi_b) { if (vb > lim) hi_b = mb; else lo_b = mb + 1; }
                     if (lo_s < hi_s) { if (vs > lim) hi_s = ms; else lo_s = ms + 1; }
-                    if (lo_e < hi_e) { if (ve < cnext) lo_e = me + 1; else hi_e = me; }
-                    if (lo_r < hi_r) { if (vr < cstart) lo_r = mr + 1; else hi_r = mr; }
                 }
-                if (kb == 0) {
-                    e = lo_e; rc0 = lo_r; s_prev_carry = rc0;                       // running_counter = 0 within this contig (chain.rs:742-744)
-                    q_last = anc_q[e - 1];
-                    k_max = (q_last - q_first) / CHUNK_SIZE + 1;                    // lim_k reaches the last anchor no later than this
+                const uint32_t bnd = lo_b, sb = lo_s;
+                const uint32_t cid = iv ? c0 + (uint32_t)src : 0xFFFFFF00u + l;    // lanes without an item: segments of their own
+                int32_t v = (int32_t)bnd - (int32_t)k;                              // u_k
+                if (k == 1) v = v > (int32_t)a_c ? v : (int32_t)a_c;                // u_0 = t_0 = the contig's first anchor
+                if (l == 0 && cid == carry_cid) v = v > carry_uu ? v : carry_uu;    // the contig continues from the previous batch
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {                                  // running maximum within the contig
+                    const int32_t tv = __shfl_up(v, d, 64); const uint32_t tc = __shfl_up(cid, d, 64);
+                    if (l >= (uint32_t)d && tc == cid) v = tv > v ? tv : v;
                 }
-                const uint32_t b = lo_b, sb = lo_s;
-                const int32_t u = wave_incl_max((int32_t)b - (int32_t)k);
-                const int32_t uu = u > carry ? u : carry;
-                const uint32_t t = (uint32_t)(uu + (int32_t)k);                     // t_k (may run past e: the chunk is then cut at e)
+                const uint32_t t = (uint32_t)(v + (int32_t)k);                      // t_k (may run past e: the chunk is then cut at e)
                 uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
-                if (l == 0) { t_prev = t_prev_carry; s_prev = s_prev_carry; }
-                const bool valid = t_prev < e && k <= k_max;                        // chunk k exists
-                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e ? t : e; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cstart; ck.qctg = ctg;
+                if (l == 0) { t_prev = carry_t; s_prev = carry_s; }
+                if (k == 1) { t_prev = a_c; s_prev = r_c; }
+                const bool valid = iv && t_prev < e_c;                              // chunk k exists
+                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cs; ck.qctg = c0 + (uint32_t)src;
                 if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
                 const unsigned long long vm = __ballot(valid);
                 const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
@@ -305,9 +323,8 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                     else atomicAdd(err, 1u);
                 }
                 nc += (uint32_t)__popcll(vm);
-                carry = __shfl(uu, 63, 64); t_prev_carry = __shfl(t, 63, 64); s_prev_carry = __shfl(sb, 63, 64);
+                carry_cid = __shfl(cid, 63, 64); carry_uu = __shfl(v, 63, 64); carry_t = __shfl(t, 63, 64); carry_s = __shfl(sb, 63, 64);
             }
-            a = e;
         }
     }
     const uint32_t used = nc < C1 - C0 ? nc : C1 - C0;
