@@ -503,7 +503,8 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     uint32_t nq = 0;
     auto emit = [&](uint32_t root, unsigned long long b) {
         if (!dp_keep(b)) return;
-        if (nq < emit_cap) { emit_q[(size_t)nq * n_thr + thr] = make_uint4(root, (uint32_t)b, (uint32_t)(b >> 32), 0u); nq++; }
+        // (the widest rings have no register to spare for the queue: with it the NB = 83 kernel spills)
+        if (NB <= 40 && nq < emit_cap) { emit_q[(size_t)nq * n_thr + thr] = make_uint4(root, (uint32_t)b, (uint32_t)(b >> 32), 0u); nq++; }
         else dp_emit(ck, slot, p, root, b, ec);
     };
     unsigned long long free_mask = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
             if ((v & 0xFFu) == 0) emit(v >> 8, get_best(c_old));
         }
     }
-    if (nq) {
+    if (NB <= 40 && nq) {
         const uint32_t k0 = atomicAdd(&ec.ivl_cnt[p], nq);
         for (uint32_t e = 0; e < nq; e++) {
             const uint4 r = emit_q[(size_t)e * n_thr + thr];
