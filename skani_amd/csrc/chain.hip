@@ -1026,11 +1026,19 @@ struct FinalizeArgs {
 struct FinalizeScratch { double *u_est, *s_est; uint32_t *u_w, *s_w; uint64_t* cum; };
 
 // fastrand 1.9.0 WyRand stream seeded with 7 (chain.rs:62); draw number d (0-based) is a pure function of d
-__device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) {
-    const uint64_t s = 7ull + (d + 1ull) * 0xA0761D6478BD642Full;
+constexpr uint64_t WYRAND_STEP = 0xA0761D6478BD642Full;
+// output for generator state s: low ^ high half of the 128-bit product s * (s ^ c), from four 32x32+64 multiply-adds
+__device__ __forceinline__ uint64_t wyrand_mix(uint64_t s) {
     const uint64_t b = s ^ 0xE7037ED1A0B428DBull;
-    return (s * b) ^ __umul64hi(s, b);
+    const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)s0 * b0;
+    const uint64_t p01 = (uint64_t)s0 * b1 + (p00 >> 32);
+    const uint64_t p10 = (uint64_t)s1 * b0 + (uint32_t)p01;
+    const uint64_t p11 = (uint64_t)s1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return ((p10 << 32) | (uint32_t)p00) ^ p11;
 }
+__device__ __forceinline__ uint64_t wyrand_state(uint64_t d) { return 7ull + (d + 1ull) * WYRAND_STEP; }   // state after d + 1 steps from seed 7
+__device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) { return wyrand_mix(wyrand_state(d)); }
 
 // chain.rs:414-555 + regression.rs:30-64.  One wave per pair.  The per-pair work arrays (one entry per chunk) live in LDS;
 // the kernel is instantiated for FIN_LDS = 320 (genomes up to ~6 Mbp: 11 KB per wave, 3 waves per SIMD) and 1024 entries and
@@ -1140,17 +1148,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
             for (uint32_t b = l; b <= nb; b += 64) T[b] = search64((uint64_t)b << sh);   // past-the-end thresholds give n-1
             wave_sync_mem();
             const uint32_t tot32 = (uint32_t)total_mult;
+            // generator states of this lane's draws j = l + 64 u (+ 256 m) of resample `it`: advanced by n steps per resample instead of
+            // being recomputed from the draw number (a 64-bit multiply per draw)
+            uint64_t st[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) st[u] = wyrand_state((uint64_t)l + 64u * (uint32_t)u);
+            const uint64_t step_it = (uint64_t)n * WYRAND_STEP, step_256 = 256ull * WYRAND_STEP;
             for (uint32_t it = 0; it < 100; it++) {
                 double s = 0.;
+                uint64_t sm[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { sm[u] = st[u]; st[u] += step_it; }
                 for (uint32_t j0 = l; j0 < n; j0 += 256) {
                     uint32_t x[4], lo[4], hi[4]; bool on[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t j = j0 + 64u * (uint32_t)u;
                         on[u] = j < n;
-                        const uint64_t r = wyrand_draw((uint64_t)it * n + (on[u] ? j : 0));
+                        const uint64_t r = wyrand_mix(sm[u]); sm[u] += step_256;
                         // Lemire reduction hi64(r * total) for total < 2^32; its rejection branch has probability total/2^64
-                        x[u] = (uint32_t)(((r >> 32) * tot32 + (((r & 0xFFFFFFFFull) * tot32) >> 32)) >> 32);
+                        x[u] = (uint32_t)(((uint64_t)(uint32_t)(r >> 32) * tot32 + __umulhi((uint32_t)r, tot32)) >> 32);
                         const uint32_t b = x[u] >> sh;
                         lo[u] = T[b]; hi[u] = T[b + 1];
                     }
