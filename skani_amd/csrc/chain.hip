@@ -1154,7 +1154,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
 #pragma unroll
             for (int u = 0; u < 4; u++) st[u] = wyrand_state((uint64_t)l + 64u * (uint32_t)u);
             const uint64_t step_it = (uint64_t)n * WYRAND_STEP, step_256 = 256ull * WYRAND_STEP;
-            for (uint32_t it = 0; it < 100; it++) {
+            // resamples in groups of four: the four wave reductions (six dependent shuffle steps each) then run interleaved
+            for (uint32_t it0 = 0; it0 < 100; it0 += 4) {
+              double sg[4];
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
                 double s = 0.;
                 uint64_t sm[4];
 #pragma unroll
@@ -1178,8 +1182,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
 #pragma unroll
                     for (int u = 0; u < 4; u++) if (on[u]) s += S[lo[u]];
                 }
-                s = wave_sum_f64(s);
-                if (l == 0) lds_boot[wv][it] = s / (double)n;
+                sg[g] = s;
+              }
+#pragma unroll
+              for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+                  for (int g = 0; g < 4; g++) sg[g] += __shfl_xor(sg[g], d, 64);
+              }
+              if (l == 0) {
+#pragma unroll
+                  for (int g = 0; g < 4; g++) lds_boot[wv][it0 + g] = sg[g] / (double)n;
+              }
             }
         } else {
             for (uint32_t it = 0; it < 100; it++) {
