@@ -1138,14 +1138,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
         // first i with CUM[i] > x; x < total_mult = CUM[n-1], so the answer is in [0, n-1]
         auto search64 = [&](uint64_t x) { uint32_t lo = 0, hi = n - 1; for (uint32_t st = 0; st < nsteps; st++) { const uint32_t mid = (lo + hi) >> 1; const bool gt = CUM[mid] > x; hi = gt ? mid : hi; lo = gt ? lo : mid + 1; } return lo; };
         if (in_lds && total_mult < 0xFFFFFFFFull) {
-            // Fast path (every realistic pair): 32-bit cumulative weights, and a 257-entry directory over the value range
-            // (bucket b = x >> sh) that narrows each search to the one or two entries whose cumulative weight falls into
-            // the draw's bucket.  Both live in LDS arrays that are dead after the sort (unsorted weights / estimates).
+            // Fast path (every realistic pair): 32-bit cumulative weights, and a 512-entry directory over the value range
+            // (bucket b = x >> sh; entry = first | last candidate << 16, one LDS read) that narrows each search to the one or two entries
+            // whose cumulative weight falls into the draw's bucket.  Both live in LDS arrays that are dead after the sort (unsorted
+            // weights / estimates; 512 x 4 B fit the smaller instantiation's 320 doubles).
             uint32_t* C32 = UW; uint32_t* T = (uint32_t*)U;
-            uint32_t sh = 0; while ((total_mult >> sh) >= 256) sh++;
-            const uint32_t nb = (uint32_t)(total_mult >> sh) + 1;                      // x < total_mult  =>  x >> sh < nb
+            uint32_t sh = 0; while ((total_mult >> sh) >= 512) sh++;
+            const uint32_t nb = (uint32_t)(total_mult >> sh) + 1;                      // x < total_mult  =>  x >> sh < nb <= 512
             for (uint32_t i = l; i < n; i += 64) C32[i] = (uint32_t)CUM[i];
-            for (uint32_t b = l; b <= nb; b += 64) T[b] = search64((uint64_t)b << sh);   // past-the-end thresholds give n-1
+            for (uint32_t b = l; b < nb; b += 64) T[b] = search64((uint64_t)b << sh) | (search64((uint64_t)(b + 1) << sh) << 16);   // past-the-end thresholds give n-1
             wave_sync_mem();
             const uint32_t tot32 = (uint32_t)total_mult;
             // generator states of this lane's draws j = l + 64 u (+ 256 m) of resample `it`: advanced by n steps per resample instead of
@@ -1172,8 +1173,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
                         const uint64_t r = wyrand_mix(sm[u]); sm[u] += step_256;
                         // Lemire reduction hi64(r * total) for total < 2^32; its rejection branch has probability total/2^64
                         x[u] = (uint32_t)(((uint64_t)(uint32_t)(r >> 32) * tot32 + __umulhi((uint32_t)r, tot32)) >> 32);
-                        const uint32_t b = x[u] >> sh;
-                        lo[u] = T[b]; hi[u] = T[b + 1];
+                        const uint32_t tb = T[x[u] >> sh];
+                        lo[u] = tb & 0xFFFFu; hi[u] = tb >> 16;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
