@@ -1,0 +1,131 @@
+// chain_join.h -- get_anchors join (chain.rs:608-737): join_count_kernel / join_fill_kernel.
+// Device code of chain.hip (one translation unit: the kernels are launched by chain_pairs() there); included inside namespace skh.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ join
+// Workgroups are launched in "slots": slot b runs logical tile slot_tile[b] (or nothing).  The host interleaves the
+// tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
+// table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
+__global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+                                                         uint32_t band, uint32_t* tile_anch, uint32_t* pair_anch, uint32_t* pair_inq,
+                                                         uint32_t* pinfo, unsigned long long* inq_mask, uint32_t lds_words) {
+    __shared__ uint32_t lds[16];
+    SKH_DYN_SMEM(smem);
+    uint32_t* bm = (uint32_t*)smem;
+    const uint32_t tile = slot_tile[blockIdx.x];
+    if (tile == NONE) return;
+    const uint32_t p = tile_pair[tile];
+    const PairDesc pd = pairs[p];
+    const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
+    const uint64_t* ent = pd.b_ent; const uint32_t* dir = pd.b_dir;
+    constexpr int R = JOIN_TILE / 256;
+    // B's bucket-occupancy bitmap (1 bit per directory bucket, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of the
+    // buckets are empty, and a probe of an empty bucket then costs no memory request at all.  The kernel runs at the L2's
+    // request rate (one 64-byte slot per random 8-byte read), so requests are what to save.
+    const uint32_t bm_words = ((pd.b_nbk + 31) / 32 + 3) / 4 * 4;
+    const bool use_bm = bm_words <= lds_words;
+    if (use_bm) {
+        const uint4* src = (const uint4*)pd.b_bmap;
+        for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += 256) ((uint4*)bm)[w4] = src[w4];
+        __syncthreads();
+    }
+    // the four positions of this thread are probed together: their loads are independent, so they overlap
+    uint32_t h[R], d0[R], d1[R]; bool live[R]; unsigned long long e[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = start + r * 256 + threadIdx.x;
+        live[r] = i < pd.a_n;
+        const uint32_t cnt = live[r] ? (uint32_t)pd.a_cnt[i] : 0xFFFFu;
+        const uint32_t seed = live[r] ? pd.a_seed[i] : 0u;
+        live[r] = live[r] && cnt <= band;                                          // chain.rs:674-676
+        h[r] = mix32(seed);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        d0[r] = 0; d1[r] = 0;
+        if (live[r]) {
+            const uint32_t b = seed_bucket(h[r], pd.b_nbk);
+            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) { d0[r] = dir[b]; d1[r] = dir[b + 1]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) e[r] = d0[r] < d1[r] ? ent[d0[r]] : TAB_EMPTY;
+    uint32_t na = 0, nq = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t o = r * 256 + threadIdx.x, i = start + o;
+        uint32_t n_anch = 0, inq = 0, bstart = 0;
+        if (live[r]) {
+            unsigned long long x = e[r]; uint32_t dd = d0[r];
+            // entries of a bucket ascend by hash; TAB_EMPTY (all ones) also ends the walk
+            while ((uint32_t)(x >> 32) < h[r]) { dd++; x = dd < d1[r] ? ent[dd] : TAB_EMPTY; }
+            if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) inq = 1;            // absent in B: chain.rs:682-685
+            else {
+                const uint32_t cnt = (uint32_t)x & 0xFFu;
+                if (cnt <= band) { inq = 1; n_anch = cnt; bstart = ((uint32_t)x >> 8) & 0xFFFFFFu; }   // else chain.rs:694-696: dropped entirely
+            }
+        }
+        // probe record: first hit in B's hash-order array << 8 | hits (<= band <= 250); and one bit per position: "listed in
+        // query_positions_all" (chain.rs:682-700), 64 positions per word straight from the ballot
+        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = (bstart << 8) | n_anch;
+        const unsigned long long m = __ballot(inq != 0);
+        if ((threadIdx.x & 63) == 0) inq_mask[(uint64_t)tile * (JOIN_TILE / 64) + (o >> 6)] = m;
+        na += n_anch; nq += inq;
+    }
+    na = wave_sum(na); nq = wave_sum(nq);
+    const uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds[w] = na; lds[8 + w] = nq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tq = 0;
+        for (uint32_t i = 0; i < 4; i++) { ta += lds[i]; tq += lds[8 + i]; }
+        tile_anch[tile] = ta;
+        if (ta) atomicAdd(&pair_anch[p], ta);
+        if (tq) atomicAdd(&pair_inq[p], tq);
+    }
+}
+
+// Emits the anchors of one tile at the offsets given by the tile scan, from the per-position probe results recorded by
+// join_count_kernel (no second probe).
+__global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
+                                                        uint32_t tile_base, const uint32_t* toff_a, const uint32_t* pinfo, uint32_t* anc_q, uint32_t* anc_r) {
+    constexpr int R = JOIN_TILE / 256;
+    __shared__ uint32_t lds_a[R * 4];
+    const uint32_t tile = slot_tile[blockIdx.x];
+    if (tile == NONE) return;
+    const uint32_t lt = tile - tile_base, p = tile_pair[tile];
+    const PairDesc pd = pairs[p];
+    const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // all loads of the tile's four rounds are issued before anything depends on them; one barrier for the offsets
+    uint32_t n_anch[R], qg[R], bst[R], ia[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t o = r * 256 + threadIdx.x, i = start + o;
+        uint32_t c = 0; qg[r] = 0;
+        if (i < pd.a_n) { c = pinfo[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; }
+        n_anch[r] = c & 0xFFu; bst[r] = c >> 8;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        ia[r] = wave_incl_scan(n_anch[r]);
+        if (l == 63) lds_a[r * 4 + w] = ia[r];
+    }
+    __syncthreads();
+    uint32_t run_a = toff_a[lt];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t ba = 0, ta = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds_a[r * 4 + k]; if (k < w) ba += x; ta += x; }
+        if (n_anch[r]) {
+            const uint32_t* bs = pd.b_sg + bst[r];
+            uint32_t oa = run_a + ba + ia[r] - n_anch[r];
+            for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                         // chain.rs:703-711, already in sorted order
+                const uint32_t rg = bs[k];
+                anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
+            }
+        }
+        run_a += ta;
+    }
+}

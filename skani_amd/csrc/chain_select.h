@@ -1,0 +1,245 @@
+// chain_select.h -- get_nonoverlapping_chains (chain.rs:1008-1099): greedy_fast_kernel / greedy_kernel.
+// Device code of chain.hip (one translation unit: the kernels are launched by chain_pairs() there); included inside namespace skh.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ greedy selection
+__device__ __forceinline__ int ivl_cmp(const Interval& a, const Interval& b) {     // derived PartialOrd over the field order
+#define SKH_CMP(f) if (a.f != b.f) return a.f < b.f ? -1 : 1;
+    SKH_CMP(score) SKH_CMP(na) SKH_CMP(q0) SKH_CMP(q1) SKH_CMP(r0) SKH_CMP(r1) SKH_CMP(rctg) SKH_CMP(qctg) SKH_CMP(chunk) SKH_CMP(rev)
+#undef SKH_CMP
+    return 0;
+}
+
+constexpr uint32_t GREEDY_LDS = 2048;   // sorted-index slots per wave kept in LDS by the fallback kernel
+constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidate intervals take the all-LDS kernel
+
+// Fast path (n <= GREEDY_FAST candidates): one wave per pair, two waves per workgroup, everything staged in LDS.
+//   1. bitonic sort of (key, index) with key = score(24) | anchors(20) | top 20 bits of q0; key ties (rare) fall back to
+//      the full tuple comparison -> the reference's descending order (chain.rs:1012);
+//   2. greedy acceptance 64 candidates at a time: every lane owns one candidate and sums its overlaps against the
+//      accepted list (uniform LDS broadcasts, no reductions); the 64 decisions are then resolved in order, an accepted
+//      candidate's interval being broadcast (v_readlane) to the later lanes of the same batch (chain.rs:1017-1095).
+//   LDS per wave is 36 B x CAP; the kernel is instantiated for CAP = 256 / 512 / 1024 and a pair runs in the smallest one that
+//   holds it, so that typical pairs (a few hundred candidates) leave room for 2-3 waves per SIMD: the greedy loop is a chain
+//   of dependent instructions, and other waves are the only thing that can fill its issue slots.
+//   Pairs are handed out by decreasing candidate count (greedy_order_keys_kernel + a 16-bit radix sort): the kernel ends when its
+//   slowest wave does, so the long ones start first.
+// Accepted interval, 32 B (two 16-byte LDS reads), threaded on up to three lists: the accepted intervals of its chunk (query axis) and
+// those of the one or two GREEDY_BIN-sized bins of the reference axis it touches (intervals spanning more go on a separate short list)
+struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1; uint16_t qnext, rnext0, rnext1, cand; };   // cand = the interval's index among the pair's candidates
+constexpr uint32_t GREEDY_BIN_SHIFT = 15;       // 32 kb reference bins: a chain interval of a 20 kb chunk touches one or two
+constexpr uint32_t GREEDY_BUCKETS = 256;        // list heads per axis (hashed chunk id / hashed (contig, bin)); 1 KB per wave keeps four workgroups of the 512 class on a CU
+constexpr uint32_t GREEDY_LONG = 64;            // accepted intervals spanning more than two bins (beyond that: every candidate scans the whole list)
+__device__ __forceinline__ uint32_t greedy_rhash(uint32_t rctg, uint32_t bin) { return (rctg * 37u + bin) & (GREEDY_BUCKETS - 1u); }
+// heads[bucket] <- value, returns the previous head; the 16-bit heads are exchanged through a compare-and-swap on their 32-bit word
+__device__ __forceinline__ uint32_t greedy_push(uint16_t* heads, uint32_t bucket, uint32_t value) {
+    unsigned* w = (unsigned*)heads + (bucket >> 1); const uint32_t sh = (bucket & 1u) * 16u;
+    unsigned seen = *w, prev;
+    do { prev = seen; seen = atomicCAS(w, prev, (prev & ~(0xFFFFu << sh)) | (value << sh)); } while (seen != prev);
+    return (prev >> sh) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t greedy_last_bin(uint32_t r0, uint32_t r1) { const uint32_t b0 = r0 >> GREEDY_BIN_SHIFT, b1 = (r1 ? r1 - 1u : 0u) >> GREEDY_BIN_SHIFT; return b1 > b0 ? b1 : b0; }
+__global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint64_t* keys, uint32_t* vals) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t n = ivl_cnt[p];
+    keys[p] = 0xFFFFu - (n > 0xFFFFu ? 0xFFFFu : n); vals[p] = p;
+}
+template <uint32_t CAP>
+__global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                          const Interval* ivls, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    __shared__ uint32_t lds_idx[2][CAP];
+    __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
+    __shared__ __attribute__((aligned(4))) uint16_t lds_qh[2][GREEDY_BUCKETS], lds_rh[2][GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
+    __shared__ uint16_t lds_long[2][GREEDY_LONG];
+    const uint32_t wv = threadIdx.x >> 6;
+    if (blockIdx.x * 2 + wv >= n_pairs) return;
+    const uint32_t p = order[blockIdx.x * 2 + wv];
+    const uint32_t l = lane_id();
+    const uint32_t I0 = pi0[p];
+    uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
+    if (n > CAP || (CAP > 256 && n <= CAP / 2)) return;                              // another instantiation's (or greedy_kernel's) pair
+    if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
+    uint32_t N = 1; while (N < n) N <<= 1;
+    unsigned long long* key = (unsigned long long*)lds_acc[wv]; uint32_t* idx = lds_idx[wv];
+    const Interval* iv = ivls + I0;
+    for (uint32_t i = l; i < N; i += 64) {
+        unsigned long long kx = 0; uint32_t ix = NONE;
+        if (i < n) { const Interval e = iv[i]; kx = ((unsigned long long)e.score << 40) | ((unsigned long long)(e.na & 0xFFFFFu) << 20) | (e.q0 >> 12); ix = i; }
+        key[i] = kx; idx[i] = ix;
+    }
+    wave_sync_mem();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = l; t < N / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;   // the t-th compare-exchange pair of this pass
+                const uint32_t a = idx[i], b = idx[x];
+                const unsigned long long ka = key[i], kb = key[x];
+                const bool up = (i & k) == 0;
+                // first/second: swap iff `first` must precede `second` in the final (descending, padding last) order
+                const uint32_t f = up ? b : a, s2 = up ? a : b;
+                const unsigned long long kf = up ? kb : ka, ks = up ? ka : kb;
+                bool sw;
+                if (f == NONE) sw = false; else if (s2 == NONE) sw = true;
+                else if (kf != ks) sw = kf > ks; else sw = ivl_cmp(iv[f], iv[s2]) > 0;
+                if (sw) { idx[i] = b; idx[x] = a; key[i] = kb; key[x] = ka; }
+            }
+            wave_sync_mem();
+        }
+    }
+    AccIvl* acc = lds_acc[wv];
+    uint16_t* qh = lds_qh[wv]; uint16_t* rh = lds_rh[wv]; uint16_t* lng = lds_long[wv];
+    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = 0xFFFFu; rh[i] = 0xFFFFu; }
+    wave_sync_mem();
+    uint32_t nacc = 0, nlong = 0;
+    bool long_overflow = false;                                                     // more than GREEDY_LONG wide intervals: fall back to scanning everything
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t s = base + l;
+        const bool have = s < n;
+        const uint32_t ci = have ? idx[s] : 0;
+        Interval c = iv[ci];
+        uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
+        auto add_r = [&](const AccIvl& a) {                                        // chain.rs:1030-1045
+            const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a.r1;
+            const uint32_t xr = c.r1 - a.r0, yr = a.r1 - c.r0;
+            cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+        };
+        auto add_q = [&](const AccIvl& a) {                                        // chain.rs:1059-1073
+            const bool hq = a.qctg == c.qctg && a.q0 < c.q1 && c.q0 < a.q1;
+            const uint32_t xq = c.q1 - a.q0, yq = a.q1 - c.q0;
+            cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+        };
+        if (long_overflow) {
+            for (uint32_t a = 0; a < nacc; a++) { const AccIvl e = acc[a]; add_r(e); add_q(e); }   // uniform index: LDS broadcast
+        } else {
+            // Accepted intervals that can overlap this candidate: on the query axis those of its own chunk (chunks are disjoint ranges of one
+            // contig), on the reference axis those sharing a bin with it.  An interval listed in two bins is counted in the bin that holds
+            // max(candidate start, interval start), a point of the overlap if there is one.
+            for (uint32_t a = qh[c.chunk & (GREEDY_BUCKETS - 1u)]; a != 0xFFFFu;) { const AccIvl e = acc[a]; add_q(e); a = e.qnext; }
+            const uint32_t c0 = c.r0 >> GREEDY_BIN_SHIFT, c1 = greedy_last_bin(c.r0, c.r1);
+            for (uint32_t x = c0; x <= c1; x++) {
+                const uint32_t h = greedy_rhash(c.rctg, x);
+                for (uint32_t a = rh[h]; a != 0xFFFFu;) {
+                    const AccIvl e = acc[a];
+                    const uint32_t e0 = e.r0 >> GREEDY_BIN_SHIFT;
+                    const bool first = greedy_rhash(e.rctg, e0) == h;               // which of the interval's (at most two, consecutive) bins hangs on this head
+                    const uint32_t eb = first ? e0 : e0 + 1u;
+                    if (e.rctg == c.rctg && eb == x && x == (c0 > e0 ? c0 : e0)) add_r(e);
+                    a = first ? e.rnext0 : e.rnext1;
+                }
+            }
+            for (uint32_t t = 0; t < nlong; t++) add_r(acc[lng[t]]);
+        }
+        const uint32_t nb = n - base < 64 ? n - base : 64, nacc0 = nacc;
+        for (uint32_t b = 0; b < nb; b++) {
+            const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+            const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
+            const int okb = wave_readlane((int)((ok_r && ok_q) ? 1 : 0), (int)b);
+            if (okb) {                                                             // wave-uniform
+                const uint32_t actg = wave_readlane(c.rctg, (int)b), ar0 = wave_readlane(c.r0, (int)b), ar1 = wave_readlane(c.r1, (int)b);
+                const uint32_t aqc = wave_readlane(c.qctg, (int)b), aq0 = wave_readlane(c.q0, (int)b), aq1 = wave_readlane(c.q1, (int)b);
+                const uint32_t bci = wave_readlane(ci, (int)b), bchunk = wave_readlane(c.chunk, (int)b);
+                if (l > b) {                                                       // later candidates of this batch see the new accepted interval
+                    const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;
+                    const bool hq = aqc == c.qctg && aq0 < c.q1 && c.q0 < aq1;
+                    const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
+                    cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+                    cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+                }
+                const uint32_t b0 = ar0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(ar0, ar1);
+                const bool wide = b1 - b0 >= 2u;                                   // wave-uniform, like everything about the accepted interval
+                if (l == 0) {                                                      // stores only: nothing in this loop waits for LDS
+                    acc[nacc] = AccIvl{actg, ar0, ar1, aqc, aq0, aq1, (uint16_t)(bchunk & (GREEDY_BUCKETS - 1u)) /* its query-axis list, until it is linked */,
+                                       0xFFFFu, 0xFFFFu, (uint16_t)bci};
+                    if (wide && nlong < GREEDY_LONG) lng[nlong] = (uint16_t)nacc;
+                }
+                if (wide) { if (nlong < GREEDY_LONG) nlong++; else long_overflow = true; }
+                nacc++;
+            }
+        }
+        wave_sync_mem();
+        // link this batch's accepted intervals into the lists, one per lane (the lists' order is free)
+        if (nacc0 + l < nacc) {
+            AccIvl* e = &acc[nacc0 + l];
+            e->qnext = (uint16_t)greedy_push(qh, e->qnext, nacc0 + l);
+            const uint32_t b0 = e->r0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(e->r0, e->r1);
+            if (b1 - b0 < 2u) {
+                e->rnext0 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b0), nacc0 + l);
+                if (b1 > b0) e->rnext1 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b1), nacc0 + l);
+            }
+        }
+        wave_sync_mem();
+    }
+    // good_non_overlap_intervals[chunk_id].push (chain.rs:1086-1094) for all accepted intervals at once: the per-chunk lists are only ever
+    // summed over (chunk_stats_kernel), so their order is free -- and a push from inside the loop above would put a global-memory round trip
+    // (read the chunk's head) into every one of the ~400 sequential steps of a pair
+    for (uint32_t a = l; a < nacc; a += 64) {
+        const uint32_t bci = acc[a].cand;
+        const uint32_t slot = pc0[p] + iv[bci].chunk;
+        ivl_next[I0 + bci] = atomicExch(&chunk_head[slot], I0 + bci);
+    }
+    if (l == 0) n_accepted[p] = nacc;
+}
+
+// Fallback for pairs with more than GREEDY_FAST candidate intervals: one wave per pair: bitonic-sort the pair's candidate
+// interval indices into DESCENDING tuple order (chain.rs:1012), then accept greedily (chain.rs:1017-1095).  An accepted
+// interval is flagged in bit 31 of its sorted slot and pushed on its chunk's list.
+__global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                     const Interval* ivls, uint32_t* sorted_glob, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    __shared__ uint32_t lds_idx[4][GREEDY_LDS];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (p >= n_pairs) return;
+    const uint32_t l = lane_id();
+    const uint32_t I0 = pi0[p];
+    uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
+    if (n <= GREEDY_FAST) return;                                                   // handled by greedy_fast_kernel
+    uint32_t N = 1; while (N < n) N <<= 1;                                          // ps0 reserves pow2(cap) >= N slots per pair
+    uint32_t* idx = N <= GREEDY_LDS ? lds_idx[wv] : sorted_glob + ps0[p];
+    const Interval* iv = ivls + I0;
+    for (uint32_t i = l; i < N; i += 64) idx[i] = i < n ? i : NONE;
+    wave_sync_mem();
+    // before(a,b): a precedes b in the final order (greater tuple first; padding last)
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = l; i < N; i += 64) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = idx[i], b = idx[x];
+                    const bool up = (i & k) == 0;
+                    const uint32_t first = up ? b : a, second = up ? a : b;          // swap iff `first` must precede `second`
+                    const bool sw = first != NONE && (second == NONE || ivl_cmp(iv[first], iv[second]) > 0);
+                    if (sw) { idx[i] = b; idx[x] = a; }
+                }
+            }
+            wave_sync_mem();
+        }
+    }
+    uint32_t nacc = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint32_t ci = idx[s] & 0x7FFFFFFFu;
+        const Interval c = iv[ci];
+        uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
+        for (uint32_t t = l; t < s; t += 64) {
+            const uint32_t e = idx[t];
+            if (e & 0x80000000u) {
+                const Interval o = iv[e & 0x7FFFFFFFu];
+                if (o.rctg == c.rctg && o.r0 < c.r1 && c.r0 < o.r1) { cnt_r++; const uint32_t x = c.r1 - o.r0, y = o.r1 - c.r0; sum_r += x < y ? x : y; }   // chain.rs:1036-1045
+                if (o.qctg == c.qctg && o.q0 < c.q1 && c.q0 < o.q1) { cnt_q++; const uint32_t x = c.q1 - o.q0, y = o.q1 - c.q0; sum_q += x < y ? x : y; }   // chain.rs:1065-1073
+            }
+        }
+        sum_r = wave_sum(sum_r); sum_q = wave_sum(sum_q); cnt_r = wave_sum(cnt_r); cnt_q = wave_sum(cnt_q);
+        const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;      // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+        const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;      // chain.rs:1075
+        if (ok_r && ok_q) {
+            if (l == 0) {
+                idx[s] = ci | 0x80000000u;
+                const uint32_t slot = pc0[p] + c.chunk;
+                ivl_next[I0 + ci] = chunk_head[slot]; chunk_head[slot] = I0 + ci;
+            }
+            nacc++;
+        }
+        wave_sync_mem();
+    }
+    if (l == 0) n_accepted[p] = nacc;
+}

@@ -1,0 +1,32 @@
+// chain_types.h -- PairDesc, Chunk, Interval: the records the chaining kernels pass to each other.
+// Device code of chain.hip (one translation unit: the kernels are launched by chain_pairs() there); included inside namespace skh.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ views & descriptors
+// One record per genome pair.  It carries direct pointers to the two sketches' arrays (already advanced to the genome's first
+// element), so the pairs of one call may draw their sketches from any number of resident sketch sets (a sharded database).
+struct PairDesc {
+    // A = enumerated sketch (position order); p_g = padded coordinate << 1 | canonical
+    const uint32_t *a_seed, *a_g; const uint16_t* a_cnt;
+    // B = probed sketch: hash-order positions, seed index (entries, bucket directory, bucket-occupancy bitmap)
+    const uint32_t* b_sg; const uint64_t* b_ent; const uint32_t *b_dir, *b_bmap;
+    const uint32_t *a_goff, *b_goff;   // padded contig starts (common.h CTG_PAD), a_nctg + 1 / b_nctg + 1 entries
+    uint32_t a_n;       // positions in A
+    uint32_t b_nbk;     // B: buckets in its seed directory
+    uint32_t flags;     // bit2: switched (chain.rs:649)
+    uint32_t tile0;     // first join tile of this pair (global over the call)
+    uint32_t a_nctg, b_nctg;
+    // finalisation inputs (ref/query in the caller's sense, NOT A/B)
+    uint32_t nctg_q, nctg_r;
+    uint64_t ref_total_len, query_total_len;
+    float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
+};
+
+constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// An anchor is 8 bytes in two arrays: anc_q = padded query coordinate, anc_r = padded ref coordinate << 1 | reverse_match
+// (chunking only needs the first).  Contigs are recovered from the padded contig-start tables where a stage needs them
+// (chunk boundaries, interval records).
+struct Chunk { uint32_t a_begin, a_end, s_begin, s_end, qoff, qctg; };   // batch-relative anchor / seed-list ranges; the chunk's query contig and its padded start
+struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };   // types.rs:508-519 field order = sort order
