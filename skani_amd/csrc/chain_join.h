@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
         if (i < pd.a_n) { c = pinfo[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; }
         n_anch[r] = c & 0xFFu; bst[r] = c >> 8;
     }
+    // the first hit of every round is fetched right away (most positions have at most one): the four round trips to B's position array
+    // overlap each other and the offset scan instead of following one another after it
+    uint32_t first[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) first[r] = n_anch[r] ? pd.b_sg[bst[r]] : 0u;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         ia[r] = wave_incl_scan(n_anch[r]);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
             const uint32_t* bs = pd.b_sg + bst[r];
             uint32_t oa = run_a + ba + ia[r] - n_anch[r];
             for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                         // chain.rs:703-711, already in sorted order
-                const uint32_t rg = bs[k];
+                const uint32_t rg = k ? bs[k] : first[r];
                 anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
             }
         }
