@@ -195,6 +195,7 @@ __device__ __forceinline__ HitRecord derive_hit(uint32_t a0, uint32_t a1, uint32
     return hr;
 }
 
+template <bool K15>   // k = 15 (every preset): one instruction less per window
 __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                                                          const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
                                                          const uint32_t* __restrict__ tile_ids, uint32_t k, uint64_t thr, uint64_t thr_m,
@@ -228,10 +229,20 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
 #pragma unroll
     for (uint32_t j = 0; j < SEED_RUN; j++) {
         const uint32_t s = 86u - 2u * j;                                           // 126 - 2*(20 + j)
-        const uint32_t fw = s >= 64 ? funnel_shr(a0, a1, s - 64) : (s >= 32 ? funnel_shr(a1, a2, s - 32) : funnel_shr(a2, a3, s));
-        const uint32_t rw = 2 * j < 32 ? funnel_shr(w1, w0, 2 * j) : funnel_shr(w2, w1, 2 * j - 32);
-        const uint32_t fs = fw & smask, rs = rw & smask;                           // seeding.rs:288-289
-        const uint32_t seed = fs < rs ? fs : rs;                                   // seeding.rs:290-296
+        uint32_t seed;
+        if (K15) {
+            // the 30-bit fields are taken left-aligned (bits 2..31): the two bits below them can only decide between EQUAL fields, so
+            // min + one shift replaces mask, mask, min
+            const uint32_t s2 = s - 2u, t2 = 2u * j - 2u;
+            const uint32_t fw = s2 >= 64 ? funnel_shr(a0, a1, s2 - 64) : (s2 >= 32 ? funnel_shr(a1, a2, s2 - 32) : funnel_shr(a2, a3, s2));
+            const uint32_t rw = j == 0 ? (w0 << 2) : (t2 < 32 ? funnel_shr(w1, w0, t2) : funnel_shr(w2, w1, t2 - 32));
+            seed = (fw < rw ? fw : rw) >> 2;                                       // seeding.rs:288-296
+        } else {
+            const uint32_t fw = s >= 64 ? funnel_shr(a0, a1, s - 64) : (s >= 32 ? funnel_shr(a1, a2, s - 32) : funnel_shr(a2, a3, s));
+            const uint32_t rw = 2 * j < 32 ? funnel_shr(w1, w0, 2 * j) : funnel_shr(w2, w1, 2 * j - 32);
+            const uint32_t fs = fw & smask, rs = rw & smask;                       // seeding.rs:288-289
+            seed = fs < rs ? fs : rs;                                              // seeding.rs:290-296
+        }
         const uint64_t h = seed_hash(seed);
         push_less(hits, h, thr);                                                   // seeding.rs:300
     }
@@ -358,7 +369,10 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         hipEvent_t e0, e1; hip_check(hipEventCreate(&e0), "event"); hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, ctx->stream), "event record");
 #endif
-        SKH_LAUNCH(seed_tiles_kernel, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+        if (sp.k == 15) SKH_LAUNCH(seed_tiles_kernel<true>, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+                   (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
+                   t_seed, t_loc, t_marker, cnt_s, cnt_m);
+        else SKH_LAUNCH(seed_tiles_kernel<false>, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
                    t_seed, t_loc, t_marker, cnt_s, cnt_m);
         check_launch("seed_tiles_kernel");
@@ -392,7 +406,10 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
             o_seed2 = ctx->arena.get<uint32_t>((size_t)h_novf * SEED_TILE); o_loc2 = ctx->arena.get<uint16_t>((size_t)h_novf * SEED_TILE);
             o_marker2 = ctx->arena.get<uint64_t>((size_t)h_novf * SEED_TILE);
             uint32_t* c2 = ctx->arena.get<uint32_t>(2 * (size_t)h_novf);
-            SKH_LAUNCH(seed_tiles_kernel, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+            if (sp.k == 15) SKH_LAUNCH(seed_tiles_kernel<true>, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
+                       (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
+                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
+            else SKH_LAUNCH(seed_tiles_kernel<false>, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                        (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
                        o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
