@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     for (int r = 0; r < R; r++) {
         const uint32_t i = start + r * 256 + threadIdx.x;
         live[r] = i < pd.a_n;
-        const uint32_t cnt = live[r] ? (uint32_t)pd.a_cnt[i] : 0xFFFFu;
+        const uint32_t gi = pd.a_pos0 + i;
+        const uint32_t rep = live[r] ? (pd.a_rep[gi >> 5] >> (gi & 31u)) & 1u : 1u;
         const uint32_t seed = live[r] ? pd.a_seed[i] : 0u;
-        live[r] = live[r] && cnt <= band;                                          // chain.rs:674-676
+        live[r] = live[r] && !rep;                                                 // chain.rs:674-676: more than `band` positions in A
         h[r] = mix32(seed);
     }
 #pragma unroll

@@ -106,7 +106,7 @@ struct skh_sketch_set {
     std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays
     skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical
-    skh::DBuf<uint16_t> p_cnt;                     // multiplicity of the entry's seed within its genome (clamped)
+    skh::DBuf<uint32_t> p_rep;                     // 1 bit per position (set-wide position index): its seed occurs more than 2500 / c times in its genome (chain.rs:674-676)
     skh::DBuf<uint32_t> s_g;                       // the same records in (mix32(seed), contig, pos) order
     // seed index (probe side): one entry per distinct seed, sorted by mix32(seed) within the genome:
     //   mix32(seed) << 32 | start (24 bits, in the genome's seed-order arrays) << 8 | min(multiplicity, 255)

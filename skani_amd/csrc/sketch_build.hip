@@ -2,7 +2,7 @@
 //
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
-//   position order : p_seed/p_g (+ p_cnt = multiplicity of the entry's seed in this genome)          -- enumeration side
+//   position order : p_seed/p_g (+ p_rep = 1 bit per position: its seed occurs more than index_chain_band times in this genome) -- enumeration side
 //                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
 //   seed order     : s_g = the same records sorted by (mix32(seed), contig, pos)   (mix32 is a bijection: equal hash <=> equal seed)
 //   seed index     : ent = one 64-bit entry per distinct seed in hash order, hash << 32 | start << 8 | multiplicity,
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* ke
 }
 // One pass over the sorted records emits everything the probe side and the enumeration side need: the index entry of every
 // distinct seed (hash | first record | multiplicity), its directory buckets, the hash-order position array, and the per-position
-// multiplicity.  (Was: head flags + a device-wide scan over all records + three more passes.)
+// "repetitive seed" bit.  (Was: head flags + a device-wide scan over all records + three more passes.)
 __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* tile_off, const uint64_t* pos_off,
                                                           const uint64_t* dist_off, const uint64_t* dir_off, const uint32_t* n_buckets, const uint32_t* p_g,
-                                                          uint64_t* ent, uint32_t* dir, uint32_t* s_g, uint16_t* p_cnt) {
+                                                          uint64_t* ent, uint32_t* dir, uint32_t* s_g, uint32_t* p_rep, uint32_t band) {
     constexpr int R = BT / 256;
     __shared__ uint32_t lds_scan[R * 4];
     __shared__ uint32_t run_cnt[BT + 1];                     // multiplicity of the run that starts at local distinct index x (slot BT: the run cut by the tile start)
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, 
 #pragma unroll
     for (int r = 0; r < R; r++) { incl[r] = wave_incl_scan(head[r]); if (l == 63) lds_scan[r * 4 + wv] = incl[r]; }
     // the run that reaches into this tile from the previous one: its multiplicity, found by one thread (runs are short; the
-    // count saturates at 65535 like p_cnt does)
+    // count saturates at 65535)
     if (threadIdx.x == 0 && t0 < n && !head[0]) {
         uint64_t b = t0; uint32_t c = 0;
         while (b > 0 && keys[b - 1] == k[0] && c < 65535u) { b--; c++; }
@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, 
             const uint32_t g = (uint32_t)(k[r] >> 32);
             const uint64_t src = pos_off[g] + vals[i];
             const uint32_t c = run_cnt[lidx[r] ? lidx[r] - 1 : BT];
-            s_g[i] = p_g[src]; p_cnt[src] = (uint16_t)c;
+            s_g[i] = p_g[src];
+            if (c > band) atomicOr(&p_rep[src >> 5], 1u << (src & 31u));             // rare: the join skips these positions (chain.rs:674-676)
         }
     }
 }
@@ -254,7 +255,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
     ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->s_g.alloc(P); ss->p_cnt.alloc(P);
+    ss->s_g.alloc(P); ss->p_rep.alloc(P / 32 + 1); dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
     if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
     if (P > 0 && pos && cc) {
         SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
@@ -320,7 +321,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     if (P > 0) {
         SKH_LAUNCH(emit_tables_kernel, n_sorted_tiles, 256, 0, ctx->stream, sorted_keys, sorted_vals, P, sorted_tile_off, (const uint64_t*)ss->d_pos_off.p,
                    (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)ss->p_g.p, ss->ent.p, ss->dir.p,
-                   ss->s_g.p, ss->p_cnt.p);
+                   ss->s_g.p, ss->p_rep.p, BP_CHAIN_BAND / ss->params.c);
         check_launch("emit_tables");
     }
     tr.mark("build: entries + directory + gather");
