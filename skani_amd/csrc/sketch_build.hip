@@ -222,20 +222,35 @@ __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, 
 
 // bucket-occupancy bitmap: bit b of a genome's bitmap = bucket b holds at least one entry.  A wave turns 64 consecutive
 // buckets into two words with one ballot (coalesced reads of the directory); it handles 32 such groups in a row.
-__global__ __launch_bounds__(256) void bmap_build_kernel(const uint32_t* dir, const uint64_t* dir_off, const uint32_t* n_buckets, const uint64_t* bmap_off, uint32_t ng,
-                                                         uint64_t n_words, uint32_t* bmap) {
+__global__ __launch_bounds__(256) void bmap_build_kernel(const uint32_t* __restrict__ dir, const uint64_t* __restrict__ dir_off, const uint32_t* __restrict__ n_buckets,
+                                                         const uint64_t* __restrict__ bmap_off, uint32_t ng, uint64_t n_words, uint32_t* __restrict__ bmap) {
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t l = lane_id();
     uint64_t w = wave * 64;                                                          // first word of this wave's 32 word pairs
     if (w >= n_words) return;
     uint32_t g = seg_of(bmap_off, ng, w);
-    for (uint32_t it = 0; it < 32 && w < n_words; it++, w += 2) {
-        while (w >= bmap_off[g + 1]) g++;                                            // genomes own whole groups of four words
-        const uint32_t b = (uint32_t)(w - bmap_off[g]) * 32u + l, nbk = n_buckets[g];
-        const uint32_t* dr = dir + dir_off[g];
-        const bool occ = b < nbk && dr[b + 1] > dr[b];
-        const unsigned long long m = __ballot(occ);
-        if (l == 0) { bmap[w] = (uint32_t)m; bmap[w + 1] = (uint32_t)(m >> 32); }
+    uint64_t g_begin = bmap_off[g], g_end = bmap_off[g + 1]; const uint32_t* dr = dir + dir_off[g]; uint32_t nbk = n_buckets[g];
+    constexpr int U = 8;                                                             // groups whose directory reads are in flight together
+    for (uint32_t it = 0; it < 32 && w < n_words; it += U, w += 2 * U) {
+        uint32_t d0[U], d1[U]; bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t wu = w + 2u * (uint32_t)u;
+            in[u] = wu < n_words; d0[u] = 0; d1[u] = 0;
+            if (in[u]) {
+                if (wu >= g_end) {                                                   // next genome (genomes own whole groups of four words): rare
+                    while (wu >= bmap_off[g + 1]) g++;
+                    g_begin = bmap_off[g]; g_end = bmap_off[g + 1]; dr = dir + dir_off[g]; nbk = n_buckets[g];
+                }
+                const uint32_t b = (uint32_t)(wu - g_begin) * 32u + l;
+                if (b < nbk) { d0[u] = dr[b]; d1[u] = dr[b + 1]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned long long m = __ballot(d1[u] > d0[u]);
+            if (in[u] && l == 0) { bmap[w + 2u * (uint32_t)u] = (uint32_t)m; bmap[w + 2u * (uint32_t)u + 1] = (uint32_t)(m >> 32); }
+        }
     }
 }
 
