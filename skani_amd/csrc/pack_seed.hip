@@ -320,11 +320,21 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
     const uint16_t* src_loc = ov == 0xFFFFFFFFu ? t_loc + (uint64_t)lt * cap_s : o_loc2 + (uint64_t)ov * SEED_TILE;
     const uint64_t* src_mk = ov == 0xFFFFFFFFu ? t_marker + (uint64_t)lt * cap_m : o_marker2 + (uint64_t)ov * SEED_TILE;
-    for (uint32_t x = ln; x < ns; x += 64) {
-        const uint32_t loc = src_loc[x];
-        o_seed[s0 + x] = src_seed[x];
-        const uint32_t pos = (K_MARKER - 1) + tile.first * SEED_TILE + (loc & 0x1FFFu);  // pos = index of the window's last base
-        o_g[s0 + x] = ((goff + pos) << 1) | (loc >> 15);                              // SeedPosition (types.rs:131-138) in padded coordinates
+    // a tile holds ~65 seeds and ~8 markers: the loads of up to four rounds (and the markers') are issued before the first store
+    const uint32_t pos0 = (K_MARKER - 1) + tile.first * SEED_TILE;
+    for (uint32_t x0 = 0; x0 < ns; x0 += 256) {
+        uint32_t loc[4], sd[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t x = x0 + 64u * (uint32_t)u + ln; loc[u] = x < ns ? src_loc[x] : 0u; sd[u] = x < ns ? src_seed[x] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t x = x0 + 64u * (uint32_t)u + ln;
+            if (x < ns) {
+                o_seed[s0 + x] = sd[u];
+                const uint32_t pos = pos0 + (loc[u] & 0x1FFFu);                         // pos = index of the window's last base
+                o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                     // SeedPosition (types.rs:131-138) in padded coordinates
+            }
+        }
     }
     for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = src_mk[x];
 }
