@@ -30,18 +30,36 @@ __global__ __launch_bounds__(256) void screen_keys_kernel(const uint64_t* marker
 }
 
 // triangle: incidence (m, a) pairs with every later incidence (m, b), b > a  ->  count[a - row0][b]
+// The counters are kept once per XCD (planes): a device-scope atomic leaves the XCD's L2 for the fabric (~20 M of them per step at 24 G/s),
+// while an atomic on memory that only this XCD touches during the kernel can stay in its L2 (workgroup scope = no sc1 write-through; the L2
+// itself is what makes it atomic among the XCD's CUs).  The plane is chosen by the hardware's XCC id, not by the block number.  The
+// threshold kernel adds the planes up.
+__device__ __forceinline__ uint32_t xcc_id() {
+#ifdef SKANI_EMU
+    return 0;
+#else
+    uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xFu;
+#endif
+}
+__device__ __forceinline__ void count_local(uint32_t* p) {
+#ifdef SKANI_EMU
+    atomicAdd(p, 1u);
+#else
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
-                                                               uint32_t* cnt) {
+                                                               uint32_t* cnt, uint32_t n_planes, uint64_t plane) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const uint64_t key = keys[e], marker = key >> (ID_BITS + 1);
     const uint32_t a = (uint32_t)(key & ID_MASK);
     if (a < row0 || a >= row0 + rows) return;
-    uint32_t* row = cnt + (uint64_t)(a - row0) * ncols;
+    uint32_t* row = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull) + (uint64_t)(a - row0) * ncols;
     for (uint64_t f = e + 1; f < n; f++) {
         const uint64_t k2 = keys[f];
         if ((k2 >> (ID_BITS + 1)) != marker) break;
-        atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+        if (n_planes > 1) count_local(&row[(uint32_t)(k2 & ID_MASK)]); else atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
     }
 }
 
@@ -84,7 +102,7 @@ __device__ __forceinline__ bool cell_passes(const ScreenRule& sr, uint32_t count
 }
 
 // one workgroup per row: pass 0 counts passing cells, pass 1 writes them in column order
-__global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* cnt, uint32_t row0, uint32_t ncols, ScreenRule sr,
+__global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t ncols, ScreenRule sr,
                                                                const uint64_t* mk_off_rows, const uint64_t* mk_off_cols, int pass,
                                                                uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second) {
     __shared__ uint32_t lds[16];
@@ -98,7 +116,11 @@ __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* c
     for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
         const uint32_t col = c0 + threadIdx.x;
         bool ok = false;
-        if (col < ncols) ok = cell_passes(sr, crow[col], m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
+        if (col < ncols) {
+            uint32_t count = 0;
+            for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + col];
+            ok = cell_passes(sr, count, m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
+        }
         // workgroup exclusive scan of the flags
         uint32_t incl = wave_incl_scan(ok ? 1u : 0u);
         const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -159,18 +181,23 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     // row blocking keeps the dense count matrix within a fixed budget
     const uint64_t budget_cells = ctx->tune.screen_cells;   // u32 counters per row block (default 8 GiB)
     uint32_t rows_per = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1, std::min(row_end, nrows) - std::min(row_begin, nrows)), std::max<uint64_t>(1, budget_cells / ncols));
-    uint32_t* cnt = ctx->arena.get<uint32_t>((uint64_t)rows_per * ncols);
+    // triangle: one plane of counters per XCD while that stays small (8 x 4 MB for 1000 genomes); the two-set screen of a large database
+    // keeps the single device-scope plane
+    const uint64_t plane = (uint64_t)rows_per * ncols;
+    const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
+    const uint32_t n_planes = (tri && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
+    uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
     row_end = std::min(row_end, nrows);
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
         const uint32_t rows = std::min(rows_per, row_end - row0);
-        dzero(cnt, (uint64_t)rows * ncols * 4, ctx->stream);
+        dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
-            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt);
+            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane);
             else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
         }
-        SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
+        SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
                    (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr);
         check_launch("screen_threshold0");
         exclusive_scan_u32(ctx, row_cnt, rows, row_off);
@@ -178,7 +205,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         d2h(&total, row_off + rows, 4, ctx->stream);
         if (total) {
             uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total);
-            SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
+            SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
                        (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os);
             check_launch("screen_threshold1");
             size_t old = first.size(); first.resize(old + total); second.resize(old + total);

@@ -228,3 +228,24 @@ def test_two_contexts_share_a_sketch_set_across_threads(ctx):
         t.join()
     other.close()
     assert not errs and out == {"a": True, "b": True}, errs
+
+
+def test_screen_counter_planes_agree(monkeypatch):
+    """The triangle screen keeps one copy of its count matrix per XCD and updates it with XCD-local atomics.  Near-threshold identities
+    make the pass set sensitive to every single increment: it must equal the one from a single device-scope matrix."""
+    from tests.parity_cases import synthetic_clades
+    genomes = synthetic_clades(n_clades=6, members=16, length=150000, seed=97, tiny=False)
+    got = {}
+    for planes in ("8", "1"):
+        monkeypatch.setenv("SKH_TUNE_SCREEN_PLANES", planes)
+        c = sk.Context(0)
+        try:
+            ss = c.sketch_records(genomes, sk.SketchParams(marker_c=200), None)    # ~750 markers per genome: dense rows
+            got[planes] = [c.screen(ss, None, identity=x) for x in (0.80, 0.93, 0.96, 0.98, 0.995)]
+        finally:
+            c.close()
+    for a, b in zip(got["8"], got["1"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    sizes = [len(a[0]) for a in got["8"]]
+    assert sizes[0] > 0 and sizes[0] > sizes[-1] and len(set(sizes)) >= 3, sizes      # the identities do separate the pairs
+
