@@ -14,28 +14,10 @@
 // positions up to its last anchor instead (chain.rs:794-824).  query_positions_all is not materialised: it is the enumerated
 // sketch's own position array (coordinates ascend) filtered by the join's one-bit-per-position mask, so a chunk records a range
 // of POSITION indices and chunk_stats_kernel applies the mask.
-__device__ __forceinline__ uint32_t first_above(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {   // first index in [lo, hi) with a[i] > v, else hi
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] > v) hi = mid; else lo = mid + 1; }
-    return lo;
-}
-__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t v) {  // first index with a[i] >= v
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-// the same two searches over a sketch's position array, whose entries are coordinate << 1 | canonical
+// first index in [lo, hi) of a sketch's position array (entries are coordinate << 1 | canonical) whose coordinate is > v, else hi
 __device__ __forceinline__ uint32_t pos_first_above(const uint32_t* g1, uint32_t lo, uint32_t hi, uint32_t v) {
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((g1[mid] >> 1) > v) hi = mid; else lo = mid + 1; }
     return lo;
-}
-__device__ __forceinline__ uint32_t pos_lower_bound(const uint32_t* g1, uint32_t lo, uint32_t hi, uint32_t v) {
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((g1[mid] >> 1) < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-__device__ __forceinline__ int32_t wave_incl_max(int32_t v) {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v = t > v ? t : v; }
-    return v;
 }
 
 // Two-level search: every CHUNK_SAMPLE-th key of the pair's anchor / position arrays is copied to LDS once; a search first narrows its

@@ -88,13 +88,6 @@ __device__ __forceinline__ int wave_readlane(int v, int uniform_lane) {
 #endif
 }
 __device__ __forceinline__ unsigned wave_readlane(unsigned v, int uniform_lane) { return (unsigned)wave_readlane((int)v, uniform_lane); }
-__device__ __forceinline__ int wave_first(int v) {
-#ifdef SKANI_EMU
-    return emu::readfirstlane(v);
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
 // Point where lanes of ONE wave exchange data through LDS/global memory: orders the memory operations and
 // keeps the compiler from moving accesses across it (the lanes themselves run in lockstep on hardware).
 __device__ __forceinline__ void wave_sync_mem() {
@@ -123,11 +116,6 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { unsigned long long t = __shfl_xor(v, d, 64); v = t > v ? t : v; }
     return v;
 }
 
