@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two processes, gloo backend, the sharded triangle of skani_amd.distributed.  Compute goes through
+"""N>1 path on CPU: two and four processes, gloo backend, the sharded triangle of skani_amd.distributed.  Compute goes through
 the kernel simulator build (no GPU in this container); the point of the test is the sharding / exchange / gather logic:
 the union of the two ranks' work must equal the single-process triangle and the oracle."""
 import os
@@ -49,8 +49,8 @@ def _worker(rank, world, port, q, interleave=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("interleave", [True, False])
-def test_two_rank_triangle_matches_single_process(interleave):
+@pytest.mark.parametrize("interleave,world", [(True, 2), (False, 2), (True, 4)])
+def test_multi_rank_triangle_matches_single_process(interleave, world):
     import multiprocessing as mp
     import skani_amd as sk
     from tests.emu_lib import emu_lib
@@ -59,7 +59,7 @@ def test_two_rank_triangle_matches_single_process(interleave):
     emu_lib()   # build once before forking workers
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue(); port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, interleave)) for r in range(world)]
     for p in procs:
         p.start()
     i, j, res, n = q.get(timeout=300)
