@@ -249,10 +249,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                 const size_t n_spill = band + 1 > ls ? (size_t)(band + 1 - ls) * gt * T : 1;   // written only by chunks with more live chains than LDS slots
                 unsigned long long* spill_best = ctx->arena.get<unsigned long long>(n_spill); uint32_t* spill_rr = ctx->arena.get<uint32_t>(n_spill);
                 uint4* emit_q = ctx->arena.get<uint4>((size_t)DP_EMIT_Q * gt * T);
-                uint64_t* okeys = ctx->arena.get<uint64_t>(NC); uint32_t* order = ctx->arena.get<uint32_t>(NC);
+                uint32_t* okeys = ctx->arena.get<uint32_t>(NC); uint32_t* order = ctx->arena.get<uint32_t>(NC);
                 SKH_LAUNCH(dp_order_keys_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, okeys, order);
                 check_launch("dp_order_keys");
-                sort_pairs_u64_u32(ctx, okeys, order, NC, 10);
+                sort_pairs_u32_u32(ctx, okeys, order, NC, 10);                      // redirects `order` to the sorted array
 #define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
 #define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)
                 // the presets' bands (2500 / c for c = 200, 125, 70, 30) get kernels with exactly that many ring slots
@@ -277,10 +277,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
 #define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
         tr.mark("dp (+order sort)");
-        uint64_t* g_keys = ctx->arena.get<uint64_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
+        uint32_t* g_keys = ctx->arena.get<uint32_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
         SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);
         check_launch("greedy_order_keys");
-        sort_pairs_u64_u32(ctx, g_keys, g_order, np, 16);
+        sort_pairs_u32_u32(ctx, g_keys, g_order, np, 16);
         SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
 #undef SKH_GREEDY
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,

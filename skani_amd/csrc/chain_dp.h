@@ -127,7 +127,7 @@ __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t
 // The 64 lanes of a wave step through their chunks in lockstep, so a wave takes as long as its longest chunk: chunks are
 // handed out in order of decreasing anchor count (dp_order_keys_kernel + a 10-bit radix sort), which puts chunks of nearly equal
 // length side by side (in slot order a wave's lanes are busy only ~1/3 of the time: mean 131 anchors, longest of 64 ~350).
-__global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, const Chunk* chunks, uint64_t* keys, uint32_t* vals) {
+__global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     const uint32_t len = chunks[i].a_end - chunks[i].a_begin;

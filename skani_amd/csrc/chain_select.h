@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t greedy_push(uint16_t* heads, uint32_t bucket
     return (prev >> sh) & 0xFFFFu;
 }
 __device__ __forceinline__ uint32_t greedy_last_bin(uint32_t r0, uint32_t r1) { const uint32_t b0 = r0 >> GREEDY_BIN_SHIFT, b1 = (r1 ? r1 - 1u : 0u) >> GREEDY_BIN_SHIFT; return b1 > b0 ? b1 : b0; }
-__global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint64_t* keys, uint32_t* vals) {
+__global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint32_t* keys, uint32_t* vals) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t n = ivl_cnt[p];

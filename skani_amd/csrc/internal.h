@@ -145,7 +145,6 @@ struct StageTrace {
 void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t* d_out /* n+1 entries */);
 
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
-void sort_pairs_u64_u32(skh_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int end_bit);
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit);   // may redirect the pointers to the sorted arrays (arena)
 void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int begin_bit = 0);   // stable on bits [begin_bit, end_bit)
 

@@ -13,27 +13,6 @@
 
 namespace skh {
 
-void sort_pairs_u64_u32(skh_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int end_bit) {
-    if (n < 2) return;
-#ifndef SKANI_EMU
-    uint64_t* keys_out = ctx->arena.get<uint64_t>(n);
-    uint32_t* vals_out = ctx->arena.get<uint32_t>(n);
-    size_t tmp_bytes = 0;
-    hip_check(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, end_bit, ctx->stream), "radix_sort_pairs size");
-    void* tmp = ctx->arena.take(tmp_bytes);
-    hip_check(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, vals, vals_out, n, 0, end_bit, ctx->stream), "radix_sort_pairs");
-    d2d(keys, keys_out, n * sizeof(uint64_t), ctx->stream);
-    d2d(vals, vals_out, n * sizeof(uint32_t), ctx->stream);
-#else
-    (void)ctx; (void)end_bit;
-    std::vector<uint64_t> idx(n); std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return keys[a] < keys[b]; });
-    std::vector<uint64_t> k(n); std::vector<uint32_t> v(n);
-    for (uint64_t i = 0; i < n; i++) { k[i] = keys[idx[i]]; v[i] = vals[idx[i]]; }
-    memcpy(keys, k.data(), n * 8); memcpy(vals, v.data(), n * 4);
-#endif
-}
-
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit) {
     if (n < 2) return;
 #ifndef SKANI_EMU
