@@ -93,11 +93,15 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
     wave_sync_mem();
     uint32_t nacc = 0, nlong = 0;
     bool long_overflow = false;                                                     // more than GREEDY_LONG wide intervals: fall back to scanning everything
+    // the next batch's candidate records are fetched while the current batch is decided (a round trip to memory per batch otherwise)
+    uint32_t ci_next = l < n ? idx[l] : 0;
+    Interval c_next = iv[ci_next];
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t s = base + l;
         const bool have = s < n;
-        const uint32_t ci = have ? idx[s] : 0;
-        Interval c = iv[ci];
+        const uint32_t ci = ci_next;
+        const Interval c = c_next;
+        if (base + 64 < n) { ci_next = s + 64 < n ? idx[s + 64] : 0; c_next = iv[ci_next]; }
         uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
         auto add_r = [&](const AccIvl& a) {                                        // chain.rs:1030-1045
             const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a.r1;
