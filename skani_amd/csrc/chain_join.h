@@ -17,11 +17,12 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     const uint32_t p = tile_pair[tile];
     const PairDesc pd = pairs[p];
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
-    const uint64_t* ent = pd.b_ent; const uint32_t* dir = pd.b_dir;
+    const uint64_t* tab = pd.b_tab;
     constexpr int R = JOIN_TILE / 256;
-    // B's bucket-occupancy bitmap (1 bit per directory bucket, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of the
-    // buckets are empty, and a probe of an empty bucket then costs no memory request at all.  The kernel runs at the L2's
-    // request rate (one 64-byte slot per random 8-byte read), so requests are what to save.
+    // B's bucket-occupancy bitmap (1 bit per home slot of its seed table, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of
+    // the buckets are nobody's home, and a probe of one costs no memory request at all; the others read their home slot -- the entry
+    // itself, or the head of the short sorted cluster it sits in (sketch_build.hip place_tables_kernel).  The kernel runs at the L2's
+    // request rate (one 64-byte line per random 8-byte read), so requests are what to save.
     const uint32_t bm_words = ((pd.b_nbk + 31) / 32 + 3) / 4 * 4;
     const bool use_bm = bm_words <= lds_words;
     if (use_bm) {
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
         __syncthreads();
     }
     // the four positions of this thread are probed together: their loads are independent, so they overlap
-    uint32_t h[R], d0[R], d1[R]; bool live[R]; unsigned long long e[R];
+    uint32_t h[R], sl[R]; bool live[R]; unsigned long long e[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t i = start + r * 256 + threadIdx.x;
@@ -43,23 +44,22 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        d0[r] = 0; d1[r] = 0;
+        sl[r] = 0; e[r] = TAB_EMPTY;
         if (live[r]) {
             const uint32_t b = seed_bucket(h[r], pd.b_nbk);
-            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) { d0[r] = dir[b]; d1[r] = dir[b + 1]; }
+            sl[r] = b;
+            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) e[r] = tab[b];
         }
     }
-#pragma unroll
-    for (int r = 0; r < R; r++) e[r] = d0[r] < d1[r] ? ent[d0[r]] : TAB_EMPTY;
     uint32_t na = 0, nq = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
         uint32_t n_anch = 0, inq = 0, bstart = 0;
         if (live[r]) {
-            unsigned long long x = e[r]; uint32_t dd = d0[r];
-            // entries of a bucket ascend by hash; TAB_EMPTY (all ones) also ends the walk
-            while ((uint32_t)(x >> 32) < h[r]) { dd++; x = dd < d1[r] ? ent[dd] : TAB_EMPTY; }
+            unsigned long long x = e[r]; uint32_t dd = sl[r];
+            // a cluster ascends by hash from the home slot on; TAB_EMPTY (all ones, also the table's last slot) ends every walk
+            while ((uint32_t)(x >> 32) < h[r]) x = tab[++dd];
             if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) inq = 1;            // absent in B: chain.rs:682-685
             else {
                 const uint32_t cnt = (uint32_t)x & 0xFFu;

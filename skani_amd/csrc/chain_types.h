@@ -8,12 +8,12 @@
 struct PairDesc {
     // A = enumerated sketch (position order); p_g = padded coordinate << 1 | canonical
     const uint32_t *a_seed, *a_g; const uint32_t* a_rep;   // a_rep: the set's "repetitive seed" bits; bit a_pos0 + i belongs to position i
-    // B = probed sketch: hash-order positions, seed index (entries, bucket directory, bucket-occupancy bitmap)
-    const uint32_t* b_sg; const uint64_t* b_ent; const uint32_t *b_dir, *b_bmap;
+    // B = probed sketch: hash-order positions, seed table (entries inline, sketch_build.hip place_tables_kernel), bucket-occupancy bitmap
+    const uint32_t* b_sg; const uint64_t* b_tab; const uint32_t* b_bmap;
     const uint32_t *a_goff, *b_goff;   // padded contig starts (common.h CTG_PAD), a_nctg + 1 / b_nctg + 1 entries
     uint32_t a_n;       // positions in A
     uint32_t a_pos0;    // A's first position in its set's position numbering
-    uint32_t b_nbk;     // B: buckets in its seed directory
+    uint32_t b_nbk;     // B: buckets (home slots) of its seed table
     uint32_t flags;     // bit2: switched (chain.rs:649)
     uint32_t tile0;     // first join tile of this pair (global over the call)
     uint32_t a_nctg, b_nctg;

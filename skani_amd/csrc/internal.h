@@ -94,7 +94,7 @@ struct skh_sketch_set {
     skh_sketch_params params{};
     uint32_t n_genomes = 0;
     // host metadata (one entry per genome unless noted)
-    std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, dir_off;   // n_genomes+1
+    std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
     std::vector<uint32_t> n_buckets;               // buckets of each genome's seed directory
     std::vector<uint64_t> bmap_off;                // n_genomes+1: first 32-bit word of each genome's bucket-occupancy bitmap
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
@@ -111,9 +111,8 @@ struct skh_sketch_set {
     skh::DBuf<uint32_t> s_g;                       // the same records in (mix32(seed), contig, pos) order
     // seed index (probe side): one entry per distinct seed, sorted by mix32(seed) within the genome:
     //   mix32(seed) << 32 | start (24 bits, in the genome's seed-order arrays) << 8 | min(multiplicity, 255)
-    // and a bucket directory over the hash range: entries of bucket b = mulhi(hash, n_buckets) are ent[dir[b] .. dir[b+1])
-    skh::DBuf<uint64_t> ent;
-    skh::DBuf<uint32_t> dir;                       // n_buckets + 1 per genome, values relative to the genome's first entry
+    // per-genome open-addressing seed table, the entries (hash << 32 | first record << 8 | multiplicity) in the slots, clusters sorted by hash; TAB_EMPTY = free
+    skh::DBuf<uint64_t> tab;                       // tab_off[g] .. : n_buckets[g] + slack slots (sketch_build.hip place_tables_kernel)
     skh::DBuf<uint32_t> bmap;                      // 1 bit per bucket: bucket non-empty (10 KB per 5 Mbp genome: staged in LDS by the join)
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_goff;
@@ -122,7 +121,7 @@ struct skh_sketch_set {
     // contexts share the set.
     mutable skh::DBuf<uint64_t> screen_keys;
     mutable std::mutex cache_mu;
-    skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off, d_dir_off;
+    skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off;
     skh::DBuf<uint32_t> d_n_buckets;
 };
 

@@ -6,7 +6,7 @@
 //                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
 //   seed order     : s_g = the same records sorted by (mix32(seed), contig, pos)   (mix32 is a bijection: equal hash <=> equal seed)
 //   seed index     : ent = one 64-bit entry per distinct seed in hash order, hash << 32 | start << 8 | multiplicity,
-//                    dir = bucket directory over the hash range (2 buckets per distinct seed)                -- probe side
+//                    tab = open-addressing table with the entries inline (2 buckets per distinct seed + slack)  -- probe side
 //                    Built by one sort + a scatter of bucket boundaries: no atomics, no empty-slot fill, and a probe of an
 //                    absent seed usually ends at its (empty) bucket after one 8-byte read.
 //   markers        : sorted unique u64
@@ -150,12 +150,11 @@ __global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* ke
     c = wave_sum(c);
     if (lane_id() == 0) out[g] = c + tile_off[x / BT];
 }
-// One pass over the sorted records emits everything the probe side and the enumeration side need: the index entry of every
-// distinct seed (hash | first record | multiplicity), its directory buckets, the hash-order position array, and the per-position
+// One pass over the sorted records emits the index entry of every distinct seed (hash | first record | multiplicity; compact, in hash
+// order -- place_tables_kernel spreads them over the genome's table), the hash-order position array, and the per-position
 // "repetitive seed" bit.  (Was: head flags + a device-wide scan over all records + three more passes.)
 __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* tile_off, const uint64_t* pos_off,
-                                                          const uint64_t* dist_off, const uint64_t* dir_off, const uint32_t* n_buckets, const uint32_t* p_g,
-                                                          uint64_t* ent, uint32_t* dir, uint32_t* s_g, uint32_t* p_rep, uint32_t band) {
+                                                          const uint32_t* p_g, uint64_t* ent, uint32_t* s_g, uint32_t* p_rep, uint32_t band) {
     constexpr int R = BT / 256;
     __shared__ uint32_t lds_scan[R * 4];
     __shared__ uint32_t run_cnt[BT + 1];                     // multiplicity of the run that starts at local distinct index x (slot BT: the run cut by the tile start)
@@ -197,13 +196,6 @@ __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, 
             const uint64_t d = (uint64_t)d0 + lidx[r] - 1;
             // one 8-byte entry answers a probe completely: hash | first record in the hash-order array | multiplicity
             ent[d] = ((uint64_t)hash << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (c > 255u ? 255u : c);
-            // directory: this entry closes every bucket after its predecessor's up to its own; the genome's last entry the rest
-            const uint32_t ld = (uint32_t)(d - dist_off[g]), dg = (uint32_t)(dist_off[g + 1] - dist_off[g]), nbk = n_buckets[g];
-            uint32_t* dr = dir + dir_off[g];
-            const uint32_t b = seed_bucket(hash, nbk);
-            const uint32_t from = ld == 0 ? 0u : seed_bucket((uint32_t)kp[r], nbk) + 1u;       // record i-1 belongs to the previous distinct seed
-            for (uint32_t x = from; x <= b; x++) dr[x] = ld;
-            if (ld == dg - 1) for (uint32_t x = b + 1; x <= nbk; x++) dr[x] = dg;
         }
     }
     __syncthreads();
@@ -220,38 +212,75 @@ __global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, 
     }
 }
 
-// bucket-occupancy bitmap: bit b of a genome's bitmap = bucket b holds at least one entry.  A wave turns 64 consecutive
-// buckets into two words with one ballot (coalesced reads of the directory); it handles 32 such groups in a row.
-__global__ __launch_bounds__(256) void bmap_build_kernel(const uint32_t* __restrict__ dir, const uint64_t* __restrict__ dir_off, const uint32_t* __restrict__ n_buckets,
-                                                         const uint64_t* __restrict__ bmap_off, uint32_t ng, uint64_t n_words, uint32_t* __restrict__ bmap) {
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t l = lane_id();
-    uint64_t w = wave * 64;                                                          // first word of this wave's 32 word pairs
-    if (w >= n_words) return;
-    uint32_t g = seg_of(bmap_off, ng, w);
-    uint64_t g_begin = bmap_off[g], g_end = bmap_off[g + 1]; const uint32_t* dr = dir + dir_off[g]; uint32_t nbk = n_buckets[g];
-    constexpr int U = 8;                                                             // groups whose directory reads are in flight together
-    for (uint32_t it = 0; it < 32 && w < n_words; it += U, w += 2 * U) {
-        uint32_t d0[U], d1[U]; bool in[U];
+// Seed table of a genome: open addressing with the entries themselves in the slots, so that a probe costs ONE memory request
+// (one 64-byte line) where a directory + entry array cost two dependent ones.  The entries arrive sorted by hash, and a monotone
+// bucket function (common.h seed_bucket) makes their home slots ascend with them: linear-probing placement is then simply
+//     slot_i = max(home_i, slot_{i-1} + 1)        <=>        slot_i - i = running maximum of (home_i - i),
+// a prefix-max scan -- no atomics, no retries, and every cluster stays sorted by hash, so a probe walks from its home slot while the
+// slot's hash is smaller than its own (an empty slot is all ones and ends every walk).  One workgroup per genome writes the whole table
+// densely (entry or empty, ascending) and collects the bucket-occupancy bitmap (bit b = some entry's home is b: staged in LDS by the join to
+// answer most absent seeds without a memory request) in LDS.  The table has n_buckets + slack slots; an entry pushed beyond them -- tens
+// of thousands of seeds hashing into the last buckets -- raises `err`.
+constexpr uint32_t PLACE_THREADS = 1024;
+__global__ __launch_bounds__(1024) void place_tables_kernel(const uint64_t* __restrict__ ent, const uint64_t* __restrict__ dist_off, const uint64_t* __restrict__ tab_off,
+                                                            const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ bmap_off, uint32_t lds_words,
+                                                            uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* __restrict__ err) {
+    __shared__ int32_t wmax[PLACE_THREADS / 64];
+    SKH_DYN_SMEM(smem);
+    uint32_t* lbm = (uint32_t*)smem;
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    const uint64_t e0 = dist_off[g]; const uint32_t nd = (uint32_t)(dist_off[g + 1] - e0), nbk = n_buckets[g];
+    uint64_t* T = tab + tab_off[g]; const uint32_t L = (uint32_t)(tab_off[g + 1] - tab_off[g]);
+    uint32_t* gbm = bmap + bmap_off[g]; const uint32_t bm_words = (uint32_t)(bmap_off[g + 1] - bmap_off[g]);
+    const bool in_lds = bm_words <= lds_words;
+    for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) { if (in_lds) lbm[x] = 0; else gbm[x] = 0; }
+    __syncthreads();
+    constexpr int32_t NEG = -(1 << 30);
+    constexpr uint32_t K = 4;                                                        // consecutive entries per thread and round
+    int32_t carry = NEG;                                                             // running maximum of home - index over all earlier entries
+    for (uint32_t base = 0; base < nd; base += PLACE_THREADS * K) {
+        const uint32_t i0 = base + tid * K;
+        uint64_t x[K]; uint32_t home[K]; int32_t m[K];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t wu = w + 2u * (uint32_t)u;
-            in[u] = wu < n_words; d0[u] = 0; d1[u] = 0;
-            if (in[u]) {
-                if (wu >= g_end) {                                                   // next genome (genomes own whole groups of four words): rare
-                    while (wu >= bmap_off[g + 1]) g++;
-                    g_begin = bmap_off[g]; g_end = bmap_off[g + 1]; dr = dir + dir_off[g]; nbk = n_buckets[g];
+        for (uint32_t j = 0; j < K; j++) x[j] = i0 + j < nd ? ent[e0 + i0 + j] : 0;
+        int32_t run = NEG;
+#pragma unroll
+        for (uint32_t j = 0; j < K; j++) {
+            home[j] = seed_bucket((uint32_t)(x[j] >> 32), nbk);
+            const int32_t v = i0 + j < nd ? (int32_t)home[j] - (int32_t)(i0 + j) : NEG;
+            run = v > run ? v : run; m[j] = run;                                     // maximum over this thread's entries up to j
+        }
+        int32_t v = run;                                                             // inclusive maximum over the wave's threads up to this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v = t > v ? t : v; }
+        if (l == 63) wmax[w] = v;
+        __syncthreads();
+        int32_t pre = carry, all = carry;
+        for (uint32_t q = 0; q < PLACE_THREADS / 64; q++) { const int32_t t = wmax[q]; if (q < w) pre = t > pre ? t : pre; all = t > all ? t : all; }
+        int32_t before = __shfl_up(v, 1, 64); if (l == 0) before = NEG;               // maximum over the wave's earlier threads
+        before = before > pre ? before : pre;                                        // ... and everything before the wave
+#pragma unroll
+        for (uint32_t j = 0; j < K; j++) {
+            const uint32_t i = i0 + j;
+            if (i < nd) {
+                const int32_t u = m[j] > before ? m[j] : before;                         // u_i
+                const int32_t up = j ? (m[j - 1] > before ? m[j - 1] : before) : before;   // u_{i-1}
+                const uint32_t slot = (uint32_t)(u + (int32_t)i);
+                const uint32_t first = i == 0 ? 0u : (uint32_t)(up + (int32_t)i);       // slot_{i-1} + 1
+                if (slot + 1u >= L) atomicAdd(err, 1u);                              // the last slot stays empty: walks end inside the table
+                else {
+                    for (uint32_t sft = first; sft < slot; sft++) T[sft] = TAB_EMPTY;
+                    T[slot] = x[j];
+                    if (in_lds) atomicOr(&lbm[home[j] >> 5], 1u << (home[j] & 31u)); else atomicOr(&gbm[home[j] >> 5], 1u << (home[j] & 31u));
                 }
-                const uint32_t b = (uint32_t)(wu - g_begin) * 32u + l;
-                if (b < nbk) { d0[u] = dr[b]; d1[u] = dr[b + 1]; }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const unsigned long long m = __ballot(d1[u] > d0[u]);
-            if (in[u] && l == 0) { bmap[w + 2u * (uint32_t)u] = (uint32_t)m; bmap[w + 2u * (uint32_t)u + 1] = (uint32_t)(m >> 32); }
-        }
+        carry = all;
+        __syncthreads();
     }
+    const uint32_t tail = nd ? (uint32_t)(carry + (int32_t)(nd - 1)) + 1u : 0u;      // first slot after the last entry
+    for (uint32_t sft = tail + tid; sft < L; sft += PLACE_THREADS) T[sft] = TAB_EMPTY;
+    if (in_lds) { for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) gbm[x] = lbm[x]; }
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -318,40 +347,42 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         tr.mark("build: heads + scan + readback");
         sorted_keys = keys; sorted_vals = vals; sorted_tile_off = tile_off; n_sorted_tiles = n_bt;
     }
-    ss->ent.alloc(D);
-    // bucket directories (north-star requirement: per-sketch seed -> position tables built on device)
-    ss->dir_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0);
+    uint64_t* ent = ctx->arena.get<uint64_t>(D + 1);                                 // compact entries, hash order: input of the placement only
+    // seed tables (north-star requirement: per-sketch seed -> position tables built on device): 2 buckets per distinct seed + slack
+    ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0);
+    uint64_t max_bm_words = 0;
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t dg = ss->dist_off[g + 1] - ss->dist_off[g];
         ss->n_buckets[g] = (uint32_t)std::max<uint64_t>(16, 2 * dg);                  // dg < 2^24
-        ss->dir_off[g + 1] = ss->dir_off[g] + ss->n_buckets[g] + 1;
+        ss->tab_off[g + 1] = ss->tab_off[g] + ss->n_buckets[g] + std::max<uint64_t>(64, dg / 8);
+        const uint64_t bw = (((uint64_t)ss->n_buckets[g] + 31) / 32 + 3) / 4 * 4;       // whole 16-byte groups
+        ss->bmap_off[g + 1] = ss->bmap_off[g] + bw; max_bm_words = std::max(max_bm_words, bw);
     }
-    ss->dir.alloc(ss->dir_off[ng]);
+    ss->tab.alloc(ss->tab_off[ng] ? ss->tab_off[ng] : 1);
     ss->d_dist_off.alloc(ng + 1); h2d(ss->d_dist_off.p, ss->dist_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->d_dir_off.alloc(ng + 1); h2d(ss->d_dir_off.p, ss->dir_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
-    bool any_empty = false;
-    for (uint32_t g = 0; g < ng; g++) any_empty = any_empty || ss->dist_off[g + 1] == ss->dist_off[g];
-    if (any_empty) dzero(ss->dir.p, ss->dir_off[ng] * 4, ctx->stream);                // genomes without seeds: every bucket empty
     if (P > 0) {
         SKH_LAUNCH(emit_tables_kernel, n_sorted_tiles, 256, 0, ctx->stream, sorted_keys, sorted_vals, P, sorted_tile_off, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)ss->d_dir_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)ss->p_g.p, ss->ent.p, ss->dir.p,
-                   ss->s_g.p, ss->p_rep.p, BP_CHAIN_BAND / ss->params.c);
+                   (const uint32_t*)ss->p_g.p, ent, ss->s_g.p, ss->p_rep.p, BP_CHAIN_BAND / ss->params.c);
         check_launch("emit_tables");
     }
-    tr.mark("build: entries + directory + gather");
-    ss->bmap_off.assign(ng + 1, 0);
-    for (uint32_t g = 0; g < ng; g++) ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)ss->n_buckets[g] + 31) / 32 + 3) / 4 * 4;   // whole 16-byte groups
+    tr.mark("build: entries + gather");
     const uint64_t BW = ss->bmap_off[ng];
     ss->bmap.alloc(BW ? BW : 1);
-    if (BW) {
+    uint32_t h_err = 0;
+    if (ng) {
+        uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
-        SKH_LAUNCH(bmap_build_kernel, (unsigned)((BW / 64 + 1 + 3) / 4), 256, 0, ctx->stream, (const uint32_t*)ss->dir.p, (const uint64_t*)ss->d_dir_off.p,
-                   (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_bo, ng, BW, ss->bmap.p);
-        check_launch("bmap_build");
+        uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
+        const uint32_t lds_words = (uint32_t)std::min<uint64_t>(max_bm_words, 16384);    // 64 KB of LDS for the bitmap; longer ones are set in memory
+        SKH_LAUNCH(place_tables_kernel, ng, PLACE_THREADS, (size_t)lds_words * 4, ctx->stream, (const uint64_t*)ent, (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)d_to,
+                   (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_bo, lds_words, ss->tab.p, ss->bmap.p, d_err);
+        check_launch("place_tables");
+        d2h(&h_err, d_err, 4, ctx->stream);                                            // synchronises
     }
-    tr.mark("build: directory");
+    tr.mark("build: tables");
     dsync(ctx->stream);
+    if (h_err) throw Error("seed table overflow: a genome's seeds crowd the end of the hash range");
 }
 
 // ---- markers: sort by (genome, marker), drop duplicates (marker_seeds is a set: seeding.rs:318, types.rs:272)
