@@ -189,7 +189,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             d_super_slots = d_slots;
             uint32_t bm_words = 0;                                                 // LDS for the largest bitmap of the batch, up to 32 KB
             for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
-            if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the directory directly
+            if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the table directly
             SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, band, tile_anch, d_pair_anch, d_pair_inq, pis, imk, bm_words);
             check_launch("join_count");

@@ -57,7 +57,7 @@ __host__ __device__ __forceinline__ uint32_t ctg_of(const uint32_t* goff, uint32
     return lo;
 }
 
-// bucket of a hashed seed in a genome's seed directory: monotone in the hash, any bucket count
+// home slot (bucket) of a hashed seed in a genome's seed table: monotone in the hash, any bucket count
 __host__ __device__ __forceinline__ uint32_t seed_bucket(uint32_t hash, uint32_t n_buckets) { return (uint32_t)(((uint64_t)hash * n_buckets) >> 32); }
 
 // contig descriptor inside a packed genome set

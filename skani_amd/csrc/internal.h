@@ -95,7 +95,7 @@ struct skh_sketch_set {
     uint32_t n_genomes = 0;
     // host metadata (one entry per genome unless noted)
     std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
-    std::vector<uint32_t> n_buckets;               // buckets of each genome's seed directory
+    std::vector<uint32_t> n_buckets;               // home slots (buckets) of each genome's seed table
     std::vector<uint64_t> bmap_off;                // n_genomes+1: first 32-bit word of each genome's bucket-occupancy bitmap
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
     std::vector<uint32_t> goff;                    // padded-coordinate start of every contig, n_contigs(g)+1 entries per genome at

@@ -5,10 +5,10 @@
 //   position order : p_seed/p_g (+ p_rep = 1 bit per position: its seed occurs more than index_chain_band times in this genome) -- enumeration side
 //                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
 //   seed order     : s_g = the same records sorted by (mix32(seed), contig, pos)   (mix32 is a bijection: equal hash <=> equal seed)
-//   seed index     : ent = one 64-bit entry per distinct seed in hash order, hash << 32 | start << 8 | multiplicity,
-//                    tab = open-addressing table with the entries inline (2 buckets per distinct seed + slack)  -- probe side
-//                    Built by one sort + a scatter of bucket boundaries: no atomics, no empty-slot fill, and a probe of an
-//                    absent seed usually ends at its (empty) bucket after one 8-byte read.
+//   seed index     : one 64-bit entry per distinct seed, hash << 32 | first record in s_g << 8 | multiplicity, stored in
+//                    tab = the genome's open-addressing table (2 home slots per distinct seed + slack)        -- probe side
+//                    Built by one sort + a prefix-max placement of the hash-ordered entries (place_tables_kernel): no atomics, and a
+//                    probe of an absent seed usually ends at the LDS bitmap or at its home slot after one 8-byte read.
 //   markers        : sorted unique u64
 #include <algorithm>
 
