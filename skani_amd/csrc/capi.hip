@@ -89,6 +89,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.build_hash_bits = (uint32_t)env("SKH_TUNE_BUILD_HASH_BITS", ctx->tune.build_hash_bits);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
+        ctx->tune.place_lds_words = (uint32_t)env("SKH_TUNE_PLACE_LDS_WORDS", ctx->tune.place_lds_words);
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
     *out = ctx;

@@ -56,6 +56,7 @@ struct skh_tunables {
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
+    uint32_t place_lds_words = 16384;                   // LDS words (64 KB) the table placement may spend on a genome's bucket bitmap; longer bitmaps (genomes beyond ~33 Mbp at c = 125) are set in memory
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
     uint32_t build_hash_bits = 0;                       // leading hash bits in the seed-order sort key (0 = as many as fit; tests use few)

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(1024) void place_tables_kernel(const uint64_t* __re
     uint64_t* T = tab + tab_off[g]; const uint32_t L = (uint32_t)(tab_off[g + 1] - tab_off[g]);
     uint32_t* gbm = bmap + bmap_off[g]; const uint32_t bm_words = (uint32_t)(bmap_off[g + 1] - bmap_off[g]);
     const bool in_lds = bm_words <= lds_words;
-    for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) { if (in_lds) lbm[x] = 0; else gbm[x] = 0; }
+    if (in_lds) for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) lbm[x] = 0;      // (the bitmap in memory was zeroed by the host before the launch)
     __syncthreads();
     constexpr int32_t NEG = -(1 << 30);
     constexpr uint32_t K = 4;                                                        // consecutive entries per thread and round
@@ -374,7 +374,8 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
         uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
-        const uint32_t lds_words = (uint32_t)std::min<uint64_t>(max_bm_words, 16384);    // 64 KB of LDS for the bitmap; longer ones are set in memory
+        const uint32_t lds_words = (uint32_t)std::min<uint64_t>(max_bm_words, ctx->tune.place_lds_words);   // LDS for the bitmap; longer ones are set in memory
+        dzero(ss->bmap.p, BW * 4, ctx->stream);
         SKH_LAUNCH(place_tables_kernel, ng, PLACE_THREADS, (size_t)lds_words * 4, ctx->stream, (const uint64_t*)ent, (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)d_to,
                    (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_bo, lds_words, ss->tab.p, ss->bmap.p, d_err);
         check_launch("place_tables");
