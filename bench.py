@@ -6,14 +6,15 @@ One "step" = one full pass of the hot path over the resident batch: FracMinHash 
 2-bit packed bases already in HBM, sketch-table construction, marker screen of all N(N-1)/2 pairs, chaining +
 ANI/AF (+ learned ANI) of every pair that passes the screen.  Default -c 125 -k 15 -m 1000 -s 80.
 
-Workload at N GPUs (weak scaling): 1000 genomes per GPU in clades of 20 (config 4's
-10k-genome triangle is the 8-GPU point at 8000 genomes).  Every rank sketches its own 1000 genomes, the sketches
-are all-gathered (RCCL), each rank screens the full set and chains its round-robin share of the passing pairs,
-results are gathered on rank 0.  value = N_total*(N_total-1)/2 / step time.
+Workload: N = 1: 1000 genomes in clades of 20 (BASELINE config 3).  N > 1 (weak scaling): 1250 genomes per GPU -- 10,000 on 8 GPUs is
+BASELINE config 4 -- in SHUFFLED order (files sort by name, not by clade: file_io.rs:250), so the members of a clade sit on different
+GPUs.  Every rank sketches its own genomes; skh_triangle_distributed (csrc/dist.hip, RCCL below the C ABI) all-gathers the marker sets,
+screens a share of the rows on every rank, assigns the candidate pairs to ranks cluster by cluster (balanced, order-independent), moves
+exactly the sketches that are needed point-to-point and gathers the results.  value = N_total (N_total - 1) / 2 / step time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (seeding kernel, HBM bound per
-SURVEY 8d: 0.354 algorithmic bytes/base) and `cpu_baseline` (the C++ oracle = a port of the reference algorithms,
-timed on this box's host cores on a bounded sample; the Rust reference cannot be built here).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (seeding kernel, HBM bound per SURVEY 8d: 0.354 algorithmic
+bytes/base; plus the VALU issue fraction that actually binds it) and `cpu_baseline` (the C++ oracle = a port of the reference algorithms,
+run on this box's host cores on the same, full workload -- about 10 s; the Rust reference cannot be built here).
 """
 import argparse
 import json
@@ -31,57 +32,83 @@ CLADE = 20
 SEED0 = 0x5EED0000
 
 
-def make_genomes(torch, device, first_clade, n_clades, members=CLADE, mean_len=5_000_000, keep_ascii_clades=0):
-    """Deterministic synthetic genomes generated ON THE GPU: clade root = i.i.d. ACGT of length
-    U(0.9,1.1)*mean_len; member = root with substitution rate U(0.005,0.08), 0-5 deletions of 10-50 kb, split into
-    1-20 contigs (>= 10 kb).  Returns (ascii uint8 device tensor, contig_off, contig_genome, n_genomes, host copies)."""
+def genome_order(n_total, order):
+    """Global genome index -> canonical id (clade * CLADE + member).  'clade': the collection is listed clade by clade; 'shuffled': in the
+    order a directory of unrelated file names would sort (file_io.rs:250 sorts by NAME) -- members of a clade end up on different ranks."""
+    if order == "clade":
+        return np.arange(n_total, dtype=np.int64)
+    return np.random.default_rng(SEED0 ^ 0x0F11E5).permutation(n_total).astype(np.int64)
+
+
+def make_genomes(torch, device, wanted, members=CLADE, mean_len=5_000_000, keep_host=False):
+    """Deterministic synthetic genomes generated ON THE GPU: clade root = i.i.d. ACGT of length U(0.9,1.1)*mean_len; member = root
+    with substitution rate U(0.005,0.08), 0-5 deletions of 10-50 kb, split into 1-20 contigs (>= 10 kb).  `wanted` lists canonical ids
+    (clade * members + member) in the order the caller wants them; a genome is a pure function of its id (the clade's random streams are
+    replayed up to the member), so any rank can generate any subset.  Returns (ascii uint8 device tensor, contig_off, contig_genome,
+    n_genomes, host copies [list of (name, uint8 array) per genome] when keep_host)."""
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    pieces, contig_off, contig_genome = [], [0], []
-    host_genomes = []
-    g_idx = 0
-    for cl in range(first_clade, first_clade + n_clades):
+    wanted = [int(x) for x in wanted]
+    by_clade = {}
+    for pos, cid in enumerate(wanted):
+        by_clade.setdefault(cid // members, {})[cid % members] = pos
+    pieces, bounds_of, host_of = [None] * len(wanted), [None] * len(wanted), [None] * len(wanted)
+    min_ctg = 10_000 if mean_len >= 1_000_000 else 2_000
+    for cl in sorted(by_clade):
+        want = by_clade[cl]
         gen = torch.Generator(device=device); gen.manual_seed(SEED0 + cl)
         cpu_rng = np.random.default_rng(SEED0 + cl)
         L = int(cpu_rng.integers(int(mean_len * 0.9), int(mean_len * 1.1) + 1))
         root = torch.randint(0, 4, (L,), dtype=torch.uint8, device=device, generator=gen)
-        for m in range(members):
+        for m in range(max(want) + 1):
             d = float(cpu_rng.uniform(0.005, 0.08))
             mask = torch.rand(L, device=device, generator=gen) < d
             sub = torch.randint(1, 4, (L,), dtype=torch.uint8, device=device, generator=gen)
-            codes = torch.where(mask, (root + sub) & 3, root)
-            keep = torch.ones(L, dtype=torch.bool, device=device)
+            dels = []
             for _ in range(int(cpu_rng.integers(0, 6))):
                 dl = int(cpu_rng.integers(10_000, 50_001)) * mean_len // 5_000_000 if mean_len < 5_000_000 else int(cpu_rng.integers(10_000, 50_001))
                 dl = max(dl, 1)
-                s = int(cpu_rng.integers(0, max(1, L - dl)))
-                keep[s:s + dl] = False
-            codes = codes[keep]
-            asc = lut[codes.long()]
-            n = asc.numel()
-            min_ctg = 10_000 if mean_len >= 1_000_000 else 2_000
+                st = int(cpu_rng.integers(0, max(1, L - dl)))
+                dels.append((st, min(L, st + dl)))
+            covered, end = 0, 0                                   # length of the union of the deleted intervals
+            for a_, b_ in sorted(dels):
+                if b_ > end:
+                    covered += b_ - max(a_, end); end = b_
+            n = L - covered
             n_ctg = int(cpu_rng.integers(1, 21))
             n_ctg = max(1, min(n_ctg, n // (2 * min_ctg)))
             if n_ctg > 1:
                 cuts = np.sort(cpu_rng.choice(np.arange(1, n // min_ctg), n_ctg - 1, replace=False)) * min_ctg
             else:
                 cuts = np.array([], dtype=np.int64)
-            bounds = [0] + [int(c) for c in cuts] + [n]
-            for a, b in zip(bounds[:-1], bounds[1:]):
-                contig_off.append(contig_off[-1] + (b - a)); contig_genome.append(g_idx)
-            pieces.append(asc)
-            if cl - first_clade < keep_ascii_clades:
-                h = asc.cpu().numpy().tobytes()
-                host_genomes.append([("c%d" % i, h[a:b]) for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:]))])
-            g_idx += 1
-    bases = torch.cat(pieces)
-    return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), g_idx, host_genomes
+            if m not in want:
+                continue
+            codes = torch.where(mask, (root + sub) & 3, root)
+            if dels:
+                keep = torch.ones(L, dtype=torch.bool, device=device)
+                for a_, b_ in dels:
+                    keep[a_:b_] = False
+                codes = codes[keep]
+            asc = lut[codes.long()]
+            assert asc.numel() == n
+            pos = want[m]
+            pieces[pos] = asc
+            bounds_of[pos] = [0] + [int(c) for c in cuts] + [n]
+            if keep_host:
+                h = asc.cpu().numpy()
+                host_of[pos] = [("c%d" % i, h[a_:b_]) for i, (a_, b_) in enumerate(zip(bounds_of[pos][:-1], bounds_of[pos][1:]))]
+    contig_off, contig_genome = [0], []
+    for g, bnd in enumerate(bounds_of):
+        for a_, b_ in zip(bnd[:-1], bnd[1:]):
+            contig_off.append(contig_off[-1] + (b_ - a_)); contig_genome.append(g)
+    bases = torch.cat(pieces) if pieces else torch.zeros(1, dtype=torch.uint8, device=device)
+    return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), len(wanted), (host_of if keep_host else [])
 
 
-def make_queries(torch, device, clades, mean_len=5_000_000):
-    """One fresh member (2% substitutions) of each listed clade: the clade root is regenerated from its seed."""
+def make_queries(torch, device, clades, mean_len=5_000_000, first=0):
+    """One fresh member (2% substitutions) of each listed clade: the clade root is regenerated from its seed.  Query number first + x belongs to clades[x]."""
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     pieces, contig_off, contig_genome = [], [0], []
-    for qi, cl in enumerate(clades):
+    for qi, cl in enumerate(clades, start=first):
         gen = torch.Generator(device=device); gen.manual_seed(SEED0 + int(cl))
         cpu_rng = np.random.default_rng(SEED0 + int(cl))
         L = int(cpu_rng.integers(int(mean_len * 0.9), int(mean_len * 1.1) + 1))
@@ -90,7 +117,7 @@ def make_queries(torch, device, clades, mean_len=5_000_000):
         mask = torch.rand(L, device=device, generator=g2) < 0.02
         sub = torch.randint(1, 4, (L,), dtype=torch.uint8, device=device, generator=g2)
         pieces.append(lut[torch.where(mask, (root + sub) & 3, root).long()])
-        contig_off.append(contig_off[-1] + L); contig_genome.append(qi)
+        contig_off.append(contig_off[-1] + L); contig_genome.append(qi - first)
     return torch.cat(pieces), np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), len(clades)
 
 
@@ -103,7 +130,7 @@ def run_search(args, torch, sk, ctx, device):
     t0 = time.perf_counter()
     for a in range(0, n_db, shard):
         n = min(shard, n_db - a)
-        bases, coff, cgen, ng, _ = make_genomes(torch, device, a // CLADE, (n + CLADE - 1) // CLADE, members=CLADE, mean_len=args.mean_len)
+        bases, coff, cgen, ng, _ = make_genomes(torch, device, np.arange(a, a + n), members=CLADE, mean_len=args.mean_len)
         torch.cuda.synchronize()
         gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
         del bases
@@ -129,20 +156,24 @@ def run_search(args, torch, sk, ctx, device):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     tm = ctx.timings()
     own = (r // CLADE) == qclades[q]
-    print(json.dumps({"metric": "search queries/sec vs resident sketch DB", "value": nq / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    db.close(); qs.close()
+    return ({"metric": "search queries/sec vs resident sketch DB", "value": nq / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "skani search: %d synthetic queries vs %d-genome DB (c=%d) resident in HBM" % (nq, n_db, args.c), "db_genomes": n_db,
                                  "db_shards": len(shards), "queries": nq, "hits": int(len(q)), "hits_in_own_clade": int(own.sum()), "db_build_s": build_s,
                                  "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9},
-                      "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None}))
+                      "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None},
+            (q, r, res, qclades))
 
 
-def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
-    """Times the oracle (port of the reference algorithms; kind = 'port') on the sample with all host cores and, when the
-    GPU triangle result is given, reports the metric's "ANI delta vs ref" on the sample's pairs."""
+def cpu_baseline(host_genomes, threads, gpu_result=None, n_gpu_genomes=None):
+    """The oracle (a C++ restatement of the reference algorithms; kind = 'port', the Rust reference cannot be built here) timed on this box's
+    host cores on the genomes given -- by default the FULL workload the GPU ran -- phase by phase as BASELINE.md section 2 lists them: sketch,
+    marker index + screen of all pairs, chain of the passing pairs.  With the GPU triangle's result it also reports the metric's "ANI delta vs
+    ref" over every chained pair."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as ora
-    names = ["s%04d.fa" % i for i in range(len(host_genomes))]
+    names = ["s%05d.fa" % i for i in range(len(host_genomes))]
     # regression.rs:8-28: learned ANI only for c >= 70, table chosen by |c-125| < |c-200|
     model = None
     if C >= 70:
@@ -153,11 +184,10 @@ def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
     t1 = time.perf_counter()
     oi, oj, res, n_chained, n_pass = ora.triangle(sks, model=model, threads=threads)
     t2 = time.perf_counter()
+    index_s, screen_s, chain_s = ora.triangle_phases()
     n = len(host_genomes); pairs = n * (n - 1) // 2
     bases = sum(len(s) for g in host_genomes for _, s in g)
-    sketch_s, chain_s = t1 - t0, t2 - t1
-    # per-unit costs -> the same workload the GPU ran (sketching is linear in genomes, chaining in chained pairs)
-    est_full = sketch_s / n * n_full + chain_s / max(n_chained, 1) * chained_full
+    sketch_s = t1 - t0
     delta = None
     if gpu_result is not None:
         gi, gj, gres = gpu_result
@@ -170,12 +200,19 @@ def cpu_baseline(host_genomes, n_full, chained_full, threads, gpu_result=None):
             for f in ("ani", "af_ref", "af_query"):
                 delta["max_abs_d_" + f] = float(np.max(np.abs(g[f].astype(np.float64) - res[f].astype(np.float64))))
             delta["int_fields_equal"] = bool(all(np.array_equal(g[f], res[f]) for f in ("avg_chain_int_len", "total_bases_covered", "num_contigs_q", "num_contigs_r")))
-    return {"value": (n_full * (n_full - 1) // 2) / est_full, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "delta_vs_oracle": delta,
-            "sample": "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + screen/chain of %d pairs (%d chained) %.2f s on %d threads; "
-                      "value = full-workload pairs / (per-genome sketch cost x %d + per-chained-pair cost x %d)" %
-                      (n, n // CLADE, CLADE, bases / 1e6, sketch_s, pairs, n_chained, chain_s, threads, n_full, chained_full),
-            "sample_pairs_per_s": pairs / (t2 - t0), "sample_sketch_mbases_per_s": bases / 1e6 / sketch_s,
-            "sample_chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None}
+    full = n_gpu_genomes is None or n == n_gpu_genomes
+    return {"value": pairs / (t2 - t0), "unit": "genome-pairs/s", "cores": threads, "kind": "port", "delta_vs_oracle": delta,
+            "sample": ("the full workload, measured: " if full else "a sample, measured: ") +
+                      "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + marker index %.2f s + screen of %d pairs %.2f s + chain of %d pairs %.2f s "
+                      "on %d threads; value = pairs / wall time of the four phases" % (n, n // CLADE, CLADE, bases / 1e6, sketch_s, index_s, pairs, screen_s, n_chained, chain_s, threads),
+            "seconds": {"sketch": sketch_s, "marker_index": index_s, "screen": screen_s, "chain": chain_s, "total": t2 - t0},
+            "sketch_mbases_per_s": bases / 1e6 / sketch_s, "screen_pairs_per_s": pairs / max(index_s + screen_s, 1e-9),
+            "chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None, "chained_pairs": int(n_chained)}
+
+
+def file_sha(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def main():
@@ -183,15 +220,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes-per-gpu", type=int, default=1000)
+    ap.add_argument("--genomes-per-gpu", type=int, default=0, help="default: 1000 on one GPU (BASELINE config 3), 1250 per GPU on several (config 4 = 10,000 on 8)")
     ap.add_argument("--mean-len", type=int, default=5_000_000)
-    ap.add_argument("--cpu-clades", type=int, default=6, help="clades (x20 genomes) in the CPU-baseline sample; 0 disables")
+    ap.add_argument("--order", default="", choices=["", "clade", "shuffled"], help="order of the collection: clade by clade, or shuffled like unrelated file names "
+                    "(default on several GPUs: members of a clade sit on different ranks and their sketches have to travel)")
+    ap.add_argument("--cpu-clades", type=int, default=-1, help="clades (x20 genomes) the CPU baseline runs on; default -1 = the full workload, 0 disables")
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
     ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
     ap.add_argument("--workload", default="triangle", choices=["triangle", "search"], help="triangle = the headline metric; search = BASELINE config 5 (optional)")
     ap.add_argument("--db-genomes", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=200)
+    ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")
     args = ap.parse_args()
 
     import torch
@@ -205,25 +246,29 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     ctx = sk.Context(local)
     if args.workload == "search":
         if world > 1:
             raise SystemExit("the search workload is single-GPU")
         if args.c == 125:
             args.c = C = 70            # --medium, BASELINE config 5
-        run_search(args, torch, sk, ctx, device)
+        print(json.dumps(run_search(args, torch, sk, ctx, device)[0]))
         return
 
-    n_local = args.genomes_per_gpu
-    assert n_local % CLADE == 0
-    clades_local = n_local // CLADE
+    n_local = args.genomes_per_gpu or (1000 if world == 1 else 1250)
     n_total = n_local * world
-    keep = args.cpu_clades if rank == 0 and world == 1 else 0
-    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, rank * clades_local, clades_local, mean_len=args.mean_len,
-                                                                      members=CLADE, keep_ascii_clades=min(keep, clades_local))
+    assert n_total % CLADE == 0, "the collection must consist of whole clades"
+    order = args.order or ("clade" if world == 1 else "shuffled")
+    canon = genome_order(n_total, order)                               # global genome index -> canonical id
+    mine = canon[rank * n_local:(rank + 1) * n_local]
+    n_cpu = 0
+    if rank == 0 and world == 1 and args.cpu_clades != 0:
+        n_cpu = n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE)
+    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=n_cpu > 0)
+    host_genomes = host_genomes[:n_cpu]
     torch.cuda.synchronize()
     gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
     total_bases_local = int(contig_off[-1])
@@ -233,14 +278,22 @@ def main():
     mp = sk.MapParams(learned_ani=sk.use_learned_ani(C), compute_ci=not args.no_ci)
     ctx.timings()
 
-    from skani_amd.distributed import distributed_triangle
+    from skani_amd.distributed import Comm
+    comm = None
+    if world > 1 or args.force_dist:
+        comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device) if args.transport == "rccl" else Comm.host(ctx, dist, rank, world, torch=torch)
     last = {}
 
     def step():
+        # genome_rank = global index: the collection's names sort like its indices
         ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32))
-        i, j, res, n_chained = distributed_triangle(ctx, ss_local, params, mp, dist, rank, world, torch=torch, device=device)
+        if comm is None:
+            i, j, res, n_chained = ctx.triangle(ss_local, mp)
+        else:
+            i, j, res, n_chained, last["stats"] = comm.triangle(ss_local, mp)
+        ss_local.close()
         last["result"] = (i, j, res)
-        return (len(i) if i is not None else 0), n_chained
+        return len(i), n_chained
 
     for _ in range(args.warmup):
         step()
@@ -257,14 +310,19 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
-    if world > 1:
+    per_rank = None
+    if comm is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        c2 = torch.tensor([chained if rank != 0 else 0, kept], dtype=torch.int64, device=device)
-        if rank == 0:
-            c2[0] = chained      # rank 0 already holds the total (gathered); the others report their own share
-        dist.broadcast(c2, src=0); chained, kept = int(c2[0]), int(c2[1])
+        st = last["stats"]
+        mine_t = torch.tensor([st["n_pairs_mine"], st["n_genomes_received"], st["bytes_received"], int(tm["chain_ms"] * 1000), int(tm["exchange_ms"] * 1000),
+                               int(tm["seed_ms"] * 1000), int(tm["sketch_build_ms"] * 1000), int(tm["screen_ms"] * 1000)], dtype=torch.int64, device=device)
+        allt = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        per_rank = [[int(x) for x in a.cpu()] for a in allt]
     if rank != 0:
-        if world > 1:
+        if comm is not None:
+            comm.close()
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     ms_per_step = dt / args.steps * 1e3
@@ -276,43 +334,72 @@ def main():
     seed_ms_per_launch = tm["seed_kernel_ms"] / launches
     bytes_per_launch = alg_bytes_per_base * total_bases_local * args.steps / launches
     achieved = bytes_per_launch / (seed_ms_per_launch * 1e-3) / 1e9 if seed_ms_per_launch > 0 else 0.0
-    traffic = None
+    # counters that were measured offline (separate rocprofv3 --pmc passes) are only quoted while the kernel source they were measured on is unchanged
+    seed_src_sha = file_sha(os.path.join(ROOT, "skani_amd", "csrc", "pack_seed.hip"))
+    traffic, traffic_note, valu = None, "no profiles/seed_traffic.json", None
     tpath = os.path.join(ROOT, "profiles", "seed_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha256_16") == seed_src_sha:
+                traffic = tj.get("hbm_bytes_per_launch"); traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s (%s)" % (tj.get("commit"), tj.get("source"))
+                valu = tj.get("valu")
+            else:
+                traffic_note = "profiles/seed_traffic.json was measured on another version of pack_seed.hip (%s, now %s): not quoted" % (tj.get("kernel_source_sha256_16"), seed_src_sha)
+        except Exception as e:
+            traffic_note = "unreadable profiles/seed_traffic.json: %r" % (e,)
+    elif os.path.exists(tpath):
+        traffic_note = "counters were measured on the default workload only"
+    roof = {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "traffic_source": traffic_note, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch,
+            "launches_per_step": launches / args.steps,
+            "note": "0.354 algorithmic B/base; the kernel is bound by VALU issue, not by HBM: see valu_frac and profiles/r02_valu_rates.md"}
+    if valu:
+        # VALU issue cycles the kernel's instructions need (static count per wave x measured cycles per instruction class, tools/isa_mix.py) over the
+        # SIMD cycles its launch had: 1024 SIMDs x shader clock x kernel time
+        simd_cycles = 1024 * valu["clock_ghz"] * 1e9 * seed_ms_per_launch * 1e-3
+        waves = total_bases_local / 8192.0 * 4.0                        # one workgroup of 4 waves per 8192 windows (lower bound: tiles are per contig)
+        roof["valu_frac"] = waves * valu["issue_cycles_per_wave"] / simd_cycles
+        roof["valu"] = valu
     out = {
         "metric": "genome-pairs/sec (triangle, ~5 Mbp genomes)", "value": value, "unit": "genome-pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence), -c %d -k %d -m %d -s 80, learned ANI on"
-                               % (n_total, args.mean_len / 1e6, CLADE, C, K, M),
+        "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence, %s), -c %d -k %d -m %d -s 80, learned ANI on%s"
+                               % (n_total, args.mean_len / 1e6, CLADE, "listed clade by clade" if order == "clade" else "file order shuffled: clades span the GPUs", C, K, M,
+                                  "" if world == 1 else ", tiled across %d GPUs (%d genomes each) via RCCL" % (world, n_local)),
                    "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
-                   "kept_pairs": kept, "parallelism": "genomes block-sharded; every rank screens and chains the pairs of its own rows; markers all-gathered"},
-        "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms")},
-        "roofline": {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch, "launches_per_step": launches / args.steps,
-                     "note": "0.354 algorithmic B/base; kernel is bound by VALU issue (23 instructions per window, 64-bit hash mix per base), see DESIGN.md and profiles/r01_valu_rates.md"},
+                   "kept_pairs": kept, "order": order,
+                   "parallelism": "single GPU" if world == 1 else
+                                  "one process per GPU; every rank sketches its genomes; markers all-gathered, screen sharded by rows, candidate pairs assigned "
+                                  "to ranks cluster by cluster (balanced, order-independent), only the needed sketches travel point-to-point, results all-gathered"},
+        "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "exchange_ms")},
+        "roofline": roof,
     }
+    if per_rank:
+        names = ("chained_pairs", "sketches_received", "bytes_received", "chain_us", "exchange_us", "seed_us", "sketch_build_us", "screen_us")
+        out["per_rank"] = {nm: [r[x] // (args.steps if nm.endswith("_us") else 1) for r in per_rank] for x, nm in enumerate(names)}
     # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
     # (~0.96 MB per pair of 5 Mbp genomes at c=125)
     chain_s = tm["chain_ms"] / args.steps * 1e-3
     if chain_s > 0 and chained:
         chain_bytes = 12.0 * 2.0 * (total_bases_local / max(n_local, 1) / C) * (chained / world)
-        out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate (8 kernels)", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
+        out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes,
-                                 "note": "irregular, latency-bound stages: per-kernel traffic and occupancy in profiles/r01_pmc_v9.md"}
+                                 "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in the latest profiles/r*_pmc_*.md"}
     if host_genomes:
-        out["cpu_baseline"] = cpu_baseline(host_genomes, n_total, chained, os.cpu_count() or 1, last.get("result"))
-        # skani's default thread count (-t 3, cli.rs:243) on one clade of the same sample, for a like-for-like default
-        few = cpu_baseline(host_genomes[:CLADE], n_total, chained, 3, None)
-        out["cpu_baseline"]["default_threads"] = {"cores": 3, "value": few["value"], "sample": few["sample"]}
+        threads = os.cpu_count() or 1
+        out["cpu_baseline"] = cpu_baseline(host_genomes, threads, last.get("result"), n_total)
+        # skani's default thread count (-t 3, cli.rs:243) on one clade of the same collection, for a like-for-like default
+        few = cpu_baseline(host_genomes[:CLADE], 3, None, n_total)
+        out["cpu_baseline"]["default_threads"] = {"cores": 3, "value": few["value"], "sample": few["sample"], "seconds": few["seconds"],
+                                                  "chained_pairs_per_s": few["chained_pairs_per_s"], "sketch_mbases_per_s": few["sketch_mbases_per_s"]}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
+    if comm is not None:
+        comm.close()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

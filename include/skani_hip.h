@@ -171,8 +171,58 @@ int skh_triangle(skh_ctx*, const skh_sketch_set*, double identity, int rescue_sm
                  uint32_t part, uint32_t n_parts, uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res,
                  uint64_t* n_kept, uint64_t* n_chained);
 
+/* ------------------------------------------------------------------ the triangle over several GPUs (one process per GPU)
+ * The reference parallelises triangle.rs:71-105 with a work-stealing thread pool over one shared Vec<Sketch>.  Here every GPU (rank) sketches
+ * its own block of the genomes and skh_triangle_distributed() does the rest below this boundary:
+ *   1. the marker sets of all ranks are all-gathered (device memory); every rank screens an equal share of the triangle's cells;
+ *   2. the candidate pair lists are all-gathered (host memory) and every rank computes the SAME assignment of pairs to ranks: connected
+ *      components of the candidate graph (clusters of related genomes) are kept whole, components too large for an even split are cut into
+ *      (row-block x column-block) tiles, and the units are dealt out by estimated cost, longest first -- the balanced stand-in for the
+ *      reference's work stealing; it does not depend on the order of the genomes;
+ *   3. every rank receives, point-to-point, exactly the sketches its units need and it does not own (seed + position arrays, device memory),
+ *      builds their seed tables, and chains its pairs; 4. the result rows are all-gathered, so every rank returns the whole triangle.
+ * Global genome index = (number of genomes on lower ranks) + local index; ranks may hold different numbers of genomes (also none).
+ * genome_rank of the local set must be the genome's rank in ONE ordering common to all ranks (switch_qr tie, chain.rs:20-22).
+ * A communicator either runs on RCCL (device buffers over xGMI; the library loads librccl.so.1 itself) or on host-memory collectives the
+ * caller supplies (MPI, gloo, ...: the library stages device data through host buffers) -- the latter is what the CPU tests use. */
+typedef struct skh_comm skh_comm;
+#define SKH_COMM_ID_BYTES 128
+/* rank 0 creates the id and hands it to the other ranks by its own means (the host's launcher / MPI / a file) */
+int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES]);
+int skh_comm_create_rccl(skh_ctx*, const uint8_t id[SKH_COMM_ID_BYTES], int rank, int world, skh_comm** out);
+/* host-memory collectives: all_gather -- every rank contributes `bytes` bytes, recv gets world * bytes in rank order;
+ * all_to_all_v -- send_cnt[r] bytes at send + send_off[r] go to rank r, recv_cnt[r] bytes from rank r land at recv + recv_off[r].
+ * Both return 0 on success. */
+typedef struct {
+    void* user;
+    int (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
+    int (*all_to_all_v)(void* user, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                        const uint64_t* recv_off);
+} skh_host_collectives;
+int skh_comm_create_host(skh_ctx*, const skh_host_collectives*, int rank, int world, skh_comm** out);
+void skh_comm_destroy(skh_comm*);
+/* what this rank did in the last distributed triangle (balance / traffic, for tests and bench.py) */
+typedef struct {
+    uint64_t n_genomes_total, n_candidate_pairs_total;   /* the whole collection */
+    uint64_t n_pairs_mine, n_units_mine, n_units_total;  /* this rank's share of the chaining */
+    uint64_t cost_mine, cost_total;                      /* estimated chaining cost (sum of both genomes' marker counts per pair) */
+    uint64_t n_genomes_received, bytes_received, bytes_sent;   /* sketches that crossed ranks */
+    uint64_t screen_row_begin, screen_row_end;           /* this rank's rows of the screen */
+} skh_dist_stats;
+/* Collective: every rank of the communicator calls it with its own local set.  Results (global indices, sorted by (i, j), ani > 0.1 as
+ * triangle.rs:99) are returned on EVERY rank; n_chained = candidate pairs chained over all ranks.  stats may be NULL. */
+int skh_triangle_distributed(skh_ctx*, skh_comm*, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params*,
+                             uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained,
+                             skh_dist_stats* stats);
+
+/* The assignment step of skh_triangle_distributed on its own (host only, no communicator): owner[p] = rank that would chain candidate pair
+ * (pair_i[p], pair_j[p]); weight[g] = cost proxy of genome g (the distributed triangle uses the marker count); holder[g] = rank whose GPU
+ * holds genome g's sketch (NULL: no preference).  Lets a host inspect balance and traffic before committing GPUs to a collection. */
+int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs, const uint64_t* weight, const uint32_t* holder,
+                   int world, uint8_t* owner);
+
 /* last-call timing breakdown in milliseconds (HIP events on the library's stream), for bench.py */
-typedef struct { float pack_ms, seed_ms, sketch_build_ms, screen_ms, chain_ms, seed_kernel_ms; uint32_t seed_kernel_launches; uint32_t pad; } skh_timings;
+typedef struct { float pack_ms, seed_ms, sketch_build_ms, screen_ms, chain_ms, seed_kernel_ms; uint32_t seed_kernel_launches; float exchange_ms; } skh_timings;
 int skh_get_timings(const skh_ctx*, skh_timings* out);
 
 #ifdef __cplusplus

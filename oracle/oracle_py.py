@@ -70,6 +70,7 @@ def lib():
         L.ora_screen_refs.restype = u64; L.ora_screen_refs.argtypes = [vp, u32, vp, dbl, i32, i32, vp]
         L.ora_triangle.restype = u64
         L.ora_triangle.argtypes = [vp, u32, dbl, i32, C.POINTER(MapOpts), vp, i32, vp, vp, vp, u64, vp, vp]
+        L.ora_triangle_phases.restype = None; L.ora_triangle_phases.argtypes = [C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
         L.ora_mm_hash64.restype = u64; L.ora_mm_hash64.argtypes = [u64]
         L.ora_powi.restype = dbl; L.ora_powi.argtypes = [dbl, i32]
         _LIB = L
@@ -171,3 +172,10 @@ def triangle(sketches, screen_val=0.0, rescue_small=True, min_af=0.15, both_min_
     kept = lib().ora_triangle(arr, n, screen_val, int(rescue_small), C.byref(mo), model.h if model else None, threads,
                               _p(oi), _p(oj), _p(res), cap, C.byref(nch), C.byref(nsp))
     return oi[:kept].copy(), oj[:kept].copy(), res[:kept].copy(), nch.value, nsp.value
+
+
+def triangle_phases():
+    """(index_s, screen_s, chain_s) of the last triangle() call."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().ora_triangle_phases(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -720,13 +721,19 @@ uint64_t ora_screen_refs(const ora_sketch* const* refs, uint32_t n_refs, const o
     return out.size();
 }
 
+// wall-clock of the three phases of the last ora_triangle call (inverted index, screen, chain) -- bench.py's cpu_baseline reports them
+static double g_tri_phase[3] = {0, 0, 0};
+void ora_triangle_phases(double* index_s, double* screen_s, double* chain_s) { *index_s = g_tri_phase[0]; *screen_s = g_tri_phase[1]; *chain_s = g_tri_phase[2]; }
+
 // triangle.rs:33-105
 uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val, int rescue_small, const ora_map_opts* mo,
                       const ora_model* model, int threads, uint32_t* out_i, uint32_t* out_j, ora_ani_result* out_res, uint64_t cap,
                       uint64_t* n_chained, uint64_t* n_screen_pass) {
     if (screen_val == 0.) screen_val = 0.80;                            // triangle.rs:33-42
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    const auto t_start = std::chrono::steady_clock::now();
     InvIndex ix; ix.build(sk, n);                                       // triangle.rs:55
+    const auto t_index = std::chrono::steady_clock::now();
     std::vector<std::vector<uint32_t>> pass(n);
     std::atomic<uint32_t> next{0};
     auto screen_worker = [&]() {
@@ -739,6 +746,7 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
     std::vector<std::pair<uint32_t, uint32_t>> pairs;
     for (uint32_t i = 0; i < n; i++) for (uint32_t j : pass[i]) pairs.push_back({i, j});
     if (n_screen_pass) *n_screen_pass = pairs.size();
+    const auto t_screen = std::chrono::steady_clock::now();
     std::vector<ora_ani_result> res(pairs.size());
     std::atomic<uint64_t> nextp{0};
     auto chain_worker = [&]() {
@@ -747,6 +755,9 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
     };
     { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(chain_worker); for (auto& t : th) t.join(); }
     if (n_chained) *n_chained = pairs.size();
+    const auto t_chain = std::chrono::steady_clock::now();
+    g_tri_phase[0] = std::chrono::duration<double>(t_index - t_start).count(); g_tri_phase[1] = std::chrono::duration<double>(t_screen - t_index).count();
+    g_tri_phase[2] = std::chrono::duration<double>(t_chain - t_screen).count();
     uint64_t kept = 0;
     for (size_t p = 0; p < pairs.size(); p++)
         if (res[p].ani > 0.1f) { if (kept < cap) { out_i[kept] = pairs[p].first; out_j[kept] = pairs[p].second; out_res[kept] = res[p]; } kept++; }  // triangle.rs:99

@@ -90,6 +90,8 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
                       const ora_map_opts*, const ora_model*, int threads,
                       uint32_t* out_i, uint32_t* out_j, ora_ani_result* out_res, uint64_t cap,
                       uint64_t* n_chained, uint64_t* n_screen_pass);
+/* wall-clock seconds of the last ora_triangle call: marker index build, screen of all rows, chaining of the passing pairs */
+void ora_triangle_phases(double* index_s, double* screen_s, double* chain_s);
 
 /* pure helpers exposed for known-answer tests */
 uint64_t ora_mm_hash64(uint64_t key);               /* types.rs:86-96 */

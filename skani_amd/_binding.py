@@ -17,7 +17,7 @@ class MapParams(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("pack_ms", "seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "seed_kernel_ms")] + \
-               [("seed_kernel_launches", C.c_uint32), ("pad", C.c_uint32)]
+               [("seed_kernel_launches", C.c_uint32), ("exchange_ms", C.c_float)]
 
 
 RESULT_DTYPE = np.dtype([(n, np.float32) for n in
@@ -28,10 +28,26 @@ RESULT_DTYPE = np.dtype([(n, np.float32) for n in
 STATS_DTYPE = np.dtype([(n, np.uint32) for n in ("switched", "n_chunks", "n_intervals", "n_accepted", "n_estimates", "reserved")] +
                        [(n, np.uint64) for n in ("n_anchors", "n_qpos", "anchor_checksum")])
 
+class DistStats(C.Structure):
+    """skh_dist_stats"""
+    _fields_ = [(n, C.c_uint64) for n in ("n_genomes_total", "n_candidate_pairs_total", "n_pairs_mine", "n_units_mine", "n_units_total", "cost_mine", "cost_total",
+                                          "n_genomes_received", "bytes_received", "bytes_sent", "screen_row_begin", "screen_row_end")]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+
+class HostCollectives(C.Structure):
+    """skh_host_collectives"""
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_to_all_v", ALL_TO_ALL_V_FN)]
+
+
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_batch", "skh_sketch_set_destroy",
            "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
-           "skh_triangle", "skh_get_timings"]
+           "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_triangle_distributed", "skh_plan_pairs"]
+RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
 
 
 def load(path):
@@ -67,4 +83,12 @@ def load(path):
     L.skh_triangle.restype = i32
     L.skh_triangle.argtypes = [vp, vp, dbl, i32, C.POINTER(MapParams), u32, u32, pp, pp, pp, C.POINTER(u64), C.POINTER(u64)]
     L.skh_get_timings.restype = i32; L.skh_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.skh_comm_create_host.restype = i32; L.skh_comm_create_host.argtypes = [vp, C.POINTER(HostCollectives), i32, i32, pp]
+    L.skh_comm_destroy.restype = None; L.skh_comm_destroy.argtypes = [vp]
+    L.skh_triangle_distributed.restype = i32
+    L.skh_triangle_distributed.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(MapParams), pp, pp, pp, C.POINTER(u64), C.POINTER(u64), C.POINTER(DistStats)]
+    L.skh_plan_pairs.restype = i32; L.skh_plan_pairs.argtypes = [u32, vp, vp, u64, vp, vp, i32, vp]
+    if hasattr(L, "skh_comm_create_rccl"):
+        L.skh_comm_unique_id.restype = i32; L.skh_comm_unique_id.argtypes = [vp]
+        L.skh_comm_create_rccl.restype = i32; L.skh_comm_create_rccl.argtypes = [vp, vp, i32, i32, pp]
     return L

@@ -27,17 +27,6 @@ void check_params(const skh_sketch_params* p) {
     if (p->seeding_mode > 1) throw std::invalid_argument("bad seeding_mode");
 }
 
-struct Stopwatch {   // wall-clock around stream-synchronous phases
-    skh_ctx* ctx; float* dst;
-#ifndef SKANI_EMU
-    hipEvent_t e0, e1;
-    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
-    ~Stopwatch() { (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *dst += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-#else
-    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) {}
-#endif
-};
-
 void load_model(skh_ctx* ctx, const char* path, GbdtModel& m) {
     FILE* f = fopen(path, "rb");
     if (!f) throw std::invalid_argument(std::string("cannot open model table ") + path);
@@ -342,7 +331,8 @@ int skh_chain_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_s
     if (!ctx || !refs || !mp || (n_pairs && (!pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;
     int rc = guarded(ctx, [&] {
         Stopwatch sw(ctx, &ctx->timings.chain_ms);
-        chain_pairs(ctx, &refs, 1, nullptr, queries ? queries : refs, pair_ref, pair_query, n_pairs, *mp, out, stats);
+        const skh_sketch_set* q = queries ? queries : refs;
+        chain_pairs(ctx, &refs, 1, nullptr, &q, 1, nullptr, pair_ref, pair_query, n_pairs, *mp, out, stats);
     });
     ctx->arena.reset();
     return rc;
@@ -353,7 +343,7 @@ int skh_chain_pairs_multi(skh_ctx* ctx, const skh_sketch_set* const* ref_sets, u
     if (!ctx || !ref_sets || !n_ref_sets || !queries || !mp || (n_pairs && (!pair_set || !pair_ref || !pair_query || !out))) return SKH_ERR_INVALID;
     int rc = guarded(ctx, [&] {
         Stopwatch sw(ctx, &ctx->timings.chain_ms);
-        chain_pairs(ctx, ref_sets, n_ref_sets, pair_set, queries, pair_ref, pair_query, n_pairs, *mp, out, nullptr);
+        chain_pairs(ctx, ref_sets, n_ref_sets, pair_set, &queries, 1, nullptr, pair_ref, pair_query, n_pairs, *mp, out, nullptr);
     });
     ctx->arena.reset();
     return rc;
@@ -370,7 +360,7 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
         std::vector<uint32_t> pi, pj;
         for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
         std::vector<skh_ani_result> res(pi.size());
-        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &ss, 1, nullptr, ss, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
+        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
         if (n_chained) *n_chained = pi.size();
         size_t kept = 0;
         for (auto& r : res) if (r.ani > 0.1f) kept++;                                                      // triangle.rs:99
@@ -379,6 +369,49 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
         if (!oi || !oj || !orr) { free(oi); free(oj); free(orr); throw std::bad_alloc(); }
         size_t q = 0;
         for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) { oi[q] = pi[p]; oj[q] = pj[p]; orr[q] = res[p]; q++; }
+        *out_i = oi; *out_j = oj; *out_res = orr; *n_kept = kept;
+    });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_comm_create_host(skh_ctx* ctx, const skh_host_collectives* hc, int rank, int world, skh_comm** out) {
+    if (!ctx || !hc || !out) return SKH_ERR_INVALID;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("bad rank / world size");
+        skh_comm* c = new skh_comm(); c->t = make_host_transport(hc, rank, world); *out = c;
+    });
+}
+
+void skh_comm_destroy(skh_comm* c) { delete c; }
+
+int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs, const uint64_t* weight, const uint32_t* holder, int world,
+                   uint8_t* owner) {
+    if ((n_pairs && (!pair_i || !pair_j || !owner)) || !weight || world < 1 || world > 255) return SKH_ERR_INVALID;
+    try {
+        for (uint64_t p = 0; p < n_pairs; p++) if (pair_i[p] >= n_genomes || pair_j[p] >= n_genomes) return SKH_ERR_INVALID;
+        std::vector<uint32_t> pi(pair_i, pair_i + n_pairs), pj(pair_j, pair_j + n_pairs); std::vector<uint64_t> w(weight, weight + n_genomes), units, load;
+        std::vector<uint8_t> own; std::vector<int> hold;
+        if (holder) { hold.resize(n_genomes); for (uint32_t g = 0; g < n_genomes; g++) { if (holder[g] >= (uint32_t)world) return SKH_ERR_INVALID; hold[g] = (int)holder[g]; } }
+        assign_pairs(n_genomes, pi, pj, w, hold, world, own, units, load);
+        if (n_pairs) memcpy(owner, own.data(), n_pairs);
+        return SKH_OK;
+    } catch (...) { return SKH_ERR_INTERNAL; }
+}
+
+int skh_triangle_distributed(skh_ctx* ctx, skh_comm* comm, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params* mp,
+                             uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained, skh_dist_stats* stats) {
+    if (!ctx || !comm || !comm->t || !local || !mp || !out_i || !out_j || !out_res || !n_kept) return SKH_ERR_INVALID;
+    *out_i = *out_j = nullptr; *out_res = nullptr; *n_kept = 0;
+    int rc = guarded(ctx, [&] {
+        std::vector<uint32_t> a, b; std::vector<skh_ani_result> r;
+        triangle_distributed(ctx, *comm->t, local, identity, rescue_small, *mp, a, b, r, n_chained, stats);
+        const size_t kept = a.size();
+        uint32_t* oi = (uint32_t*)malloc((kept + 1) * 4); uint32_t* oj = (uint32_t*)malloc((kept + 1) * 4);
+        skh_ani_result* orr = (skh_ani_result*)malloc((kept + 1) * sizeof(skh_ani_result));
+        if (!oi || !oj || !orr) { free(oi); free(oj); free(orr); throw std::bad_alloc(); }
+        memcpy(oi, a.data(), kept * 4); memcpy(oj, b.data(), kept * 4); memcpy(orr, r.data(), kept * sizeof(skh_ani_result));
         *out_i = oi; *out_j = oj; *out_res = orr; *n_kept = kept;
     });
     ctx->arena.reset();

@@ -106,14 +106,18 @@ static uint32_t* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::ve
     return d_slots;
 }
 
-void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* Q, const uint32_t* pair_ref,
-                 const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats) {
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
+                 const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out,
+                 skh_chain_stats* stats) {
     if (n_pairs_all == 0) return;
     if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
     if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
+    if (n_qsets == 0 || !Qsets[0]) throw std::invalid_argument("no query sketch set");
+    const uint32_t c = Qsets[0]->params.c, k = Qsets[0]->params.k;
     for (uint32_t x = 0; x < n_rsets; x++)
-        if (!Rsets[x] || Rsets[x]->params.c != Q->params.c || Rsets[x]->params.k != Q->params.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
-    const uint32_t c = Q->params.c, k = Q->params.k;
+        if (!Rsets[x] || Rsets[x]->params.c != c || Rsets[x]->params.k != k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    for (uint32_t x = 0; x < n_qsets; x++)
+        if (!Qsets[x] || Qsets[x]->params.c != c || Qsets[x]->params.k != k) throw std::invalid_argument("ref and query sketches were built with different c/k");
     const uint32_t band = BP_CHAIN_BAND / c;                                        // chain.rs:111-112 index_chain_band (ref sketch's c)
     if (band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
     const GbdtModel* model = nullptr;
@@ -128,9 +132,9 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
     std::vector<const uint32_t*> host_go_a(stats ? NP : 0), host_go_b(stats ? NP : 0);
     for (uint32_t p = 0; p < NP; p++) {
-        const uint32_t rs = pair_rset ? pair_rset[p] : 0u;
-        if (rs >= n_rsets) throw std::invalid_argument("pair names a reference set that was not passed");
-        const skh_sketch_set* R = Rsets[rs];
+        const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
+        if (rs >= n_rsets || qs >= n_qsets) throw std::invalid_argument("pair names a sketch set that was not passed");
+        const skh_sketch_set* R = Rsets[rs]; const skh_sketch_set* Q = Qsets[qs];
         const uint32_t r = pair_ref[p], q = pair_query[p];
         if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
         PairDesc& pd = pds[p];
@@ -152,7 +156,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         if (stats) { host_go_a[p] = A->goff.data() + A->ctg_off[ga] + ga; host_go_b[p] = B->goff.data() + B->ctg_off[gb] + gb; }
         n_tiles_all += (pd.a_n + JOIN_TILE - 1) / JOIN_TILE;
         if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
-        pair_key[p] = gb + 3u * (B == Q ? n_rsets : rs);                             // tiles probing the same sketch share an XCD
+        pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                            // tiles probing the same sketch share an XCD
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }

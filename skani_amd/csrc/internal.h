@@ -73,6 +73,9 @@ struct skh_ctx {
     skh_timings timings{};
 };
 
+namespace skh { struct Transport; }
+struct skh_comm { skh::Transport* t = nullptr; ~skh_comm(); };   // destructor in dist.hip (Transport is defined below)
+
 struct skh_genome_set {
     skh_ctx* ctx = nullptr;
     int seeding_mode = 0;
@@ -128,6 +131,19 @@ struct skh_sketch_set {
 
 namespace skh {
 
+// Collectives under the distributed triangle (dist.hip).  Two implementations: RCCL on device buffers (rccl_transport.hip) and caller-supplied
+// host-memory collectives (device data staged through host buffers).  Every call returns when the data has arrived.
+struct Transport {
+    int rank = 0, world = 1;
+    virtual ~Transport() {}
+    // every rank contributes `bytes` bytes; recv gets world * bytes in rank order.  device: both buffers are device memory.
+    virtual void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) = 0;
+    // send_cnt[r] bytes at send + send_off[r] go to rank r; recv_cnt[r] bytes from rank r land at recv + recv_off[r]
+    virtual void all_to_all_v(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                              const uint64_t* recv_off, bool device) = 0;
+};
+Transport* make_host_transport(const skh_host_collectives* hc, int rank, int world);    // dist.hip (the RCCL transport and its two entry points: rccl_transport.hip)
+
 // SKH_TRACE=1: host wall-clock per stage of the host drivers on stderr (each mark synchronises the stream; diagnosis only)
 struct StageTrace {
     skh_ctx* ctx; bool on; std::chrono::steady_clock::time_point t;
@@ -139,6 +155,18 @@ struct StageTrace {
         fprintf(stderr, "[skh trace] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
         t = n;
     }
+};
+
+// adds the stream time between construction and destruction to *dst (HIP events on the context's stream; synchronises at the end)
+struct Stopwatch {   // wall-clock around stream-synchronous phases
+    skh_ctx* ctx; float* dst;
+#ifndef SKANI_EMU
+    hipEvent_t e0, e1;
+    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
+    ~Stopwatch() { (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *dst += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+#else
+    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) {}
+#endif
 };
 
 // ---- scan.hip
@@ -170,9 +198,16 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)
 
+// ---- dist.hip
+void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std::vector<uint32_t>& pj, const std::vector<uint64_t>& weight, const std::vector<int>& holder,
+                  int world, std::vector<uint8_t>& owner, std::vector<uint64_t>& units_of, std::vector<uint64_t>& load);
+void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params& mp,
+                          std::vector<uint32_t>& out_i, std::vector<uint32_t>& out_j, std::vector<skh_ani_result>& out_res, uint64_t* n_chained, skh_dist_stats* stats);
+
 // ---- chain.hip
-// chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] (pair_rset == nullptr: set 0) and its query from Q
-void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* Q, const uint32_t* pair_ref,
-                 const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out, skh_chain_stats* stats);
+// chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
+                 const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
+                 skh_chain_stats* stats);
 
 }  // namespace skh

@@ -1,0 +1,124 @@
+// rccl_transport.hip -- the collectives of the distributed triangle (dist.hip) on RCCL: device buffers, xGMI between the GPUs of a node.
+//
+// librccl.so.1 is loaded on first use (dlopen): single-GPU users of libskani_hip.so do not need it, and a process that already carries an RCCL
+// (PyTorch ships one under the same soname) keeps using that copy.  The communicator runs on the context's stream.  xGMI is point-to-point
+// (7 links per GPU), so the sketch exchange is one grouped send/recv per peer -- every link carries exactly the sketches its peer needs -- and
+// the all-gathers (marker sets, small tables) are RCCL's ring/tree collectives.  Host-memory buffers of the small table exchanges are staged
+// through device scratch: RCCL moves device memory only.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "internal.h"
+
+namespace skh {
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& api() {
+    static RcclApi a;
+    if (a.lib) return a;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw Error(std::string("cannot load librccl.so.1: ") + dlerror());
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw Error(std::string("librccl lacks ") + n); return p; };
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.Send = (decltype(a.Send))sym("ncclSend");
+    a.Recv = (decltype(a.Recv))sym("ncclRecv");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    a.lib = h;
+    return a;
+}
+
+void rccl_check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw Error(std::string(what) + ": " + api().GetErrorString(r));
+}
+
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr;
+    ~RcclTransport() override { if (comm) (void)api().CommDestroy(comm); }
+    void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) override {
+        if (!bytes) return;
+        const void* s = send; void* r = recv; DBuf<char> ds, dr;
+        if (!device) { ds.alloc(bytes); dr.alloc(bytes * world); h2d(ds.p, send, bytes, ctx->stream); s = ds.p; r = dr.p; }
+        rccl_check(api().AllGather(s, r, bytes, ncclUint8, comm, ctx->stream), "ncclAllGather");
+        if (!device) d2h(recv, dr.p, bytes * world, ctx->stream);                    // synchronises
+        else dsync(ctx->stream);
+    }
+    void all_to_all_v(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                      const uint64_t* recv_off, bool device) override {
+        uint64_t sb = 0, rb = 0;
+        for (int r = 0; r < world; r++) { sb = std::max(sb, send_off[r] + send_cnt[r]); rb = std::max(rb, recv_off[r] + recv_cnt[r]); }
+        const char* s = (const char*)send; char* rv = (char*)recv; DBuf<char> ds, dr;
+        if (!device) { ds.alloc(sb + 1); dr.alloc(rb + 1); h2d(ds.p, send, sb, ctx->stream); s = ds.p; rv = dr.p; }
+        if (send_cnt[rank]) {                                                       // own share: a device copy, not a message
+            if (send_cnt[rank] != recv_cnt[rank]) throw Error("all_to_all_v: own send and receive sizes differ");
+            d2d(rv + recv_off[rank], s + send_off[rank], send_cnt[rank], ctx->stream);
+        }
+        rccl_check(api().GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < world; r++) {
+            if (r == rank) continue;
+            if (send_cnt[r]) rccl_check(api().Send(s + send_off[r], send_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclSend");
+            if (recv_cnt[r]) rccl_check(api().Recv(rv + recv_off[r], recv_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclRecv");
+        }
+        rccl_check(api().GroupEnd(), "ncclGroupEnd");
+        if (!device) d2h(recv, dr.p, rb, ctx->stream);
+        else dsync(ctx->stream);
+    }
+};
+
+}  // namespace
+
+}  // namespace skh
+
+using namespace skh;
+
+extern "C" {
+
+int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == SKH_COMM_ID_BYTES, "RCCL unique id size");
+    if (!id) return SKH_ERR_INVALID;
+    try {
+        ncclUniqueId u;
+        rccl_check(api().GetUniqueId(&u), "ncclGetUniqueId");
+        memcpy(id, &u, sizeof(u));
+        return SKH_OK;
+    } catch (...) { return SKH_ERR_DEVICE; }
+}
+
+int skh_comm_create_rccl(skh_ctx* ctx, const uint8_t id[SKH_COMM_ID_BYTES], int rank, int world, skh_comm** out) {
+    if (!ctx || !id || !out) return SKH_ERR_INVALID;
+    *out = nullptr;
+    try {
+        if (world < 1 || rank < 0 || rank >= world) { ctx->err = "bad rank / world size"; return SKH_ERR_INVALID; }
+        hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+        std::unique_ptr<RcclTransport> t(new RcclTransport());
+        t->rank = rank; t->world = world;
+        ncclUniqueId u; memcpy(&u, id, sizeof(u));
+        rccl_check(api().CommInitRank(&t->comm, world, u, rank), "ncclCommInitRank");
+        skh_comm* c = new skh_comm(); c->t = t.release();
+        *out = c;
+        return SKH_OK;
+    } catch (const std::exception& e) { ctx->err = e.what(); return SKH_ERR_DEVICE; }
+    catch (...) { ctx->err = "unknown error"; return SKH_ERR_INTERNAL; }
+}
+
+}  // extern "C"

@@ -90,7 +90,8 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
     import torch
     import bench
     dev = torch.device("cuda", 0)
-    bases, coff, cgen, ng, host = bench.make_genomes(torch, dev, 0, 5, keep_ascii_clades=1)
+    bases, coff, cgen, ng, host = bench.make_genomes(torch, dev, np.arange(100), keep_host=True)
+    host = host[:20]
     torch.cuda.synchronize()
     gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
     assert gs.total_bases == int(coff[-1])
@@ -116,6 +117,70 @@ def test_full_size_genomes_properties_and_oracle_sample(ctx):
     assert np.array_equal(i[sel], oi) and np.array_equal(j[sel], oj)
     for x, y in zip(res[sel], ores):
         pc.assert_result_close(x, y)
+
+
+def test_config3_full_size(ctx):
+    """BASELINE config 3 at its full size: the triangle over 1,000 synthetic ~5 Mbp genomes (what bench.py times).  Size-independent
+    properties on the whole result -- 9,500 pairs pass the screen, all inside clades, all kept -- plus field-by-field comparison with the
+    oracle on one clade from the middle of the collection (190 pairs, ~2 s of CPU)."""
+    import torch
+    import bench
+    from tests.helpers import MODEL_C125
+    dev = torch.device("cuda", 0)
+    bases, coff, cgen, ng, _ = bench.make_genomes(torch, dev, np.arange(1000))
+    torch.cuda.synchronize()
+    gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+    del bases
+    ss = ctx.sketch_genomes(gs, sk.SketchParams(), genome_rank=np.arange(ng, dtype=np.uint32))
+    gs.close()
+    i, j, res, nch = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    assert nch == 9500 and len(i) == 9500 and ((i // 20) == (j // 20)).all() and (i < j).all()
+    assert (res["ani"] > 0.80).all() and (res["ani"] <= 1.0).all() and (res["ci_lower"] <= res["ci_upper"]).all()
+    clade = 23
+    _, _, _, _, host = bench.make_genomes(torch, dev, np.arange(clade * 20, clade * 20 + 20), keep_host=True)
+    osk = [ora.sketch_records(g, file_name="s%05d.fa" % (clade * 20 + k)) for k, g in enumerate(host)]
+    for k in (0, 11):
+        pc.assert_sketch_equal(ss, clade * 20 + k, osk[k])
+    oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+    sel = (i // 20) == clade
+    assert np.array_equal(i[sel] - clade * 20, oi) and np.array_equal(j[sel] - clade * 20, oj)
+    for x, y in zip(res[sel], ores):
+        pc.assert_result_close(x, y)
+    ss.close()
+    torch.cuda.empty_cache()
+
+
+def test_config5_full_size():
+    """BASELINE config 5 at its full size: 1,000 queries against a 65,000-genome database (c = 70, --medium) resident in HBM (~165 GB;
+    building it takes ~20 s).  Properties: every query finds exactly the 20 members of its own clade and nothing else; the results of 20 sampled
+    (query, hit) pairs are compared field by field with the oracle, which sketches the same bytes on the host."""
+    import argparse
+    import torch
+    import bench
+    from tests.helpers import MODEL_C125
+    dev = torch.device("cuda", 0)
+    c = sk.Context(0)
+    try:
+        bench.C, bench.CLADE = 70, 20
+        args = argparse.Namespace(c=70, db_genomes=65000, queries=1000, mean_len=5_000_000, steps=1, warmup=0)
+        line, (q, r, res, qclades) = bench.run_search(args, torch, sk, c, dev)
+        assert line["config"]["hits"] == 20000 and line["config"]["hits_in_own_clade"] == 20000 and len(q) == 20000
+        assert np.array_equal(np.bincount(q, minlength=1000), np.full(1000, 20)) and ((r // 20) == qclades[q]).all()
+        assert (res["ani"] > 0.8).all()
+        rng = np.random.default_rng(5)
+        model = ora.Model(MODEL_C125)                                             # c = 70: |70 - 125| < |70 - 200| (regression.rs:15-22)
+        for x in rng.choice(len(q), 20, replace=False):
+            _, _, _, _, hr = bench.make_genomes(torch, dev, [int(r[x])], keep_host=True)
+            qb, qoff, _, _ = bench.make_queries(torch, dev, [int(qclades[q[x]])], first=int(q[x]))
+            qh = qb.cpu().numpy()
+            oref = ora.sketch_records(hr[0], 70, 15, 1000, "s%07d.fa" % int(r[x]))
+            oq = ora.sketch_records([("q", qh)], 70, 15, 1000, "t%07d.fa" % int(q[x]))           # query names sort after every database name
+            want = ora.chain_seeds(oref, oq, model=model)
+            pc.assert_result_close(res[x], want, (int(q[x]), int(r[x])))
+    finally:
+        bench.C, bench.CLADE = 125, 20
+        c.close()
+        torch.cuda.empty_cache()
 
 
 def test_search_resident_db(ctx): pc.case_search_resident_db(ctx)

@@ -6,7 +6,7 @@ import skani_amd as sk
 import bench
 dev = torch.device("cuda:0")
 ctx = sk.Context(0)
-bases, contig_off, contig_genome, ng, _ = bench.make_genomes(torch, dev, 0, 50, mean_len=5_000_000, members=20, keep_ascii_clades=0)
+bases, contig_off, contig_genome, ng, _ = bench.make_genomes(torch, dev, np.arange(1000), mean_len=5_000_000, members=20)
 gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
 params = sk.SketchParams(125, 15, 1000, sk.SEED_AVX2)
 ss = ctx.sketch_genomes(gs, params, genome_rank=np.arange(ng, dtype=np.uint32))
