@@ -75,10 +75,9 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.chain_anchors = env("SKH_TUNE_CHAIN_ANCHORS", ctx->tune.chain_anchors);
         ctx->tune.chain_super_tiles = (uint32_t)env("SKH_TUNE_CHAIN_SUPER_TILES", ctx->tune.chain_super_tiles);
         ctx->tune.chain_dp_lds_slots = (uint32_t)env("SKH_TUNE_CHAIN_DP_LDS_SLOTS", ctx->tune.chain_dp_lds_slots);
-        ctx->tune.build_hash_bits = (uint32_t)env("SKH_TUNE_BUILD_HASH_BITS", ctx->tune.build_hash_bits);
+        ctx->tune.build_match_cap = (uint32_t)env("SKH_TUNE_BUILD_MATCH_CAP", ctx->tune.build_match_cap);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
-        ctx->tune.place_lds_words = (uint32_t)env("SKH_TUNE_PLACE_LDS_WORDS", ctx->tune.place_lds_words);
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
     *out = ctx;

@@ -143,8 +143,8 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
         const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
         pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.a_seed = A->p_seed.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_rep = A->p_rep.p; pd.a_pos0 = (uint32_t)A->pos_off[ga];
-        pd.b_sg = B->s_g.p + B->pos_off[gb]; pd.b_tab = B->tab.p + B->tab_off[gb]; pd.b_nbk = B->n_buckets[gb];
+        pd.a_hash = A->p_hash.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_rep = A->p_rep.p; pd.a_pos0 = (uint32_t)A->pos_off[ga];
+        pd.b_ms = B->ms.p + B->ms_off[gb]; pd.b_tab = B->tab.p + B->tab_off[gb]; pd.b_nbk = B->n_buckets[gb];
         pd.b_bmap = B->bmap.p + B->bmap_off[gb];
         pd.flags = sw ? 4u : 0u;
         pd.tile0 = (uint32_t)n_tiles_all;

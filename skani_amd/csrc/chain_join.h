@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     constexpr int R = JOIN_TILE / 256;
     // B's bucket-occupancy bitmap (1 bit per home slot of its seed table, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of
     // the buckets are nobody's home, and a probe of one costs no memory request at all; the others read their home slot -- the entry
-    // itself, or the head of the short sorted cluster it sits in (sketch_build.hip place_tables_kernel).  The kernel runs at the L2's
+    // itself, or the head of the short cluster it sits in (sketch_build.hip build_tables_kernel).  The kernel runs at the L2's
     // request rate (one 64-byte line per random 8-byte read), so requests are what to save.
     const uint32_t bm_words = ((pd.b_nbk + 31) / 32 + 3) / 4 * 4;
     const bool use_bm = bm_words <= lds_words;
@@ -38,37 +38,40 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
         live[r] = i < pd.a_n;
         const uint32_t gi = pd.a_pos0 + i;
         const uint32_t rep = live[r] ? (pd.a_rep[gi >> 5] >> (gi & 31u)) & 1u : 1u;
-        const uint32_t seed = live[r] ? pd.a_seed[i] : 0u;
+        h[r] = live[r] ? pd.a_hash[i] : 0u;
         live[r] = live[r] && !rep;                                                 // chain.rs:674-676: more than `band` positions in A
-        h[r] = mix32(seed);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         sl[r] = 0; e[r] = TAB_EMPTY;
         if (live[r]) {
             const uint32_t b = seed_bucket(h[r], pd.b_nbk);
-            sl[r] = b;
-            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) e[r] = tab[b];
+            sl[r] = tab_slot(b);
+            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) e[r] = tab[sl[r]];
         }
     }
     uint32_t na = 0, nq = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        uint32_t n_anch = 0, inq = 0, bstart = 0;
+        uint32_t n_anch = 0, inq = 0, rec = TAB_REPETITIVE;
         if (live[r]) {
             unsigned long long x = e[r]; uint32_t dd = sl[r];
-            // a cluster ascends by hash from the home slot on; TAB_EMPTY (all ones, also the table's last slot) ends every walk
+            // a cluster ascends by hash from the home slot on; TAB_EMPTY (all ones; the slack slots behind every slice end with one) ends every walk
             while ((uint32_t)(x >> 32) < h[r]) x = tab[++dd];
             if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) inq = 1;            // absent in B: chain.rs:682-685
             else {
-                const uint32_t cnt = (uint32_t)x & 0xFFu;
-                if (cnt <= band) { inq = 1; n_anch = cnt; bstart = ((uint32_t)x >> 8) & 0xFFFFFFu; }   // else chain.rs:694-696: dropped entirely
+                const uint32_t xl = (uint32_t)x;
+                if (xl != TAB_REPETITIVE) {                                          // else chain.rs:694-696: dropped entirely
+                    inq = 1; rec = xl;
+                    const uint32_t code = tab_list_code(xl);
+                    n_anch = !(xl & TAB_LISTED) ? 1u : (code ? code + 1u : pd.b_ms[xl & TAB_OFF_MASK]);   // long lists: the count heads the list
+                }
             }
         }
-        // probe record: first hit in B's hash-order array << 8 | hits (<= band <= 250); and one bit per position: "listed in
-        // query_positions_all" (chain.rs:682-700), 64 positions per word straight from the ballot
-        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = (bstart << 8) | n_anch;
+        // probe record = the slot's payload (B's position itself, or the reference to the seed's position list; TAB_REPETITIVE = no anchors); and
+        // one bit per position: "listed in query_positions_all" (chain.rs:682-700), 64 positions per word straight from the ballot
+        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = rec;
         const unsigned long long m = __ballot(inq != 0);
         if ((threadIdx.x & 63) == 0) inq_mask[(uint64_t)tile * (JOIN_TILE / 64) + (o >> 6)] = m;
         na += n_anch; nq += inq;
@@ -99,19 +102,18 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // all loads of the tile's four rounds are issued before anything depends on them; one barrier for the offsets
-    uint32_t n_anch[R], qg[R], bst[R], ia[R];
+    uint32_t n_anch[R], qg[R], rec[R], ia[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        uint32_t c = 0; qg[r] = 0;
-        if (i < pd.a_n) { c = pinfo[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; }
-        n_anch[r] = c & 0xFFu; bst[r] = c >> 8;
+        rec[r] = TAB_REPETITIVE; qg[r] = 0;
+        if (i < pd.a_n) { rec[r] = pinfo[(uint64_t)tile * JOIN_TILE + o]; qg[r] = pd.a_g[i]; }
     }
-    // the first hit of every round is fetched right away (most positions have at most one): the four round trips to B's position array
-    // overlap each other and the offset scan instead of following one another after it
-    uint32_t first[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) first[r] = n_anch[r] ? pd.b_sg[bst[r]] : 0u;
+    for (int r = 0; r < R; r++) {
+        const uint32_t code = tab_list_code(rec[r]);
+        n_anch[r] = rec[r] == TAB_REPETITIVE ? 0u : (!(rec[r] & TAB_LISTED) ? 1u : (code ? code + 1u : pd.b_ms[rec[r] & TAB_OFF_MASK]));
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         ia[r] = wave_incl_scan(n_anch[r]);
@@ -125,11 +127,14 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) { const uint32_t x = lds_a[r * 4 + k]; if (k < w) ba += x; ta += x; }
         if (n_anch[r]) {
-            const uint32_t* bs = pd.b_sg + bst[r];
             uint32_t oa = run_a + ba + ia[r] - n_anch[r];
-            for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                         // chain.rs:703-711, already in sorted order
-                const uint32_t rg = k ? bs[k] : first[r];
-                anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
+            if (!(rec[r] & TAB_LISTED)) { anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rec[r] & ~1u) | ((rec[r] ^ qg[r]) & 1u); }
+            else {
+                const uint32_t* bs = pd.b_ms + (rec[r] & TAB_OFF_MASK) + 1;
+                for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                     // chain.rs:703-711, already in sorted order
+                    const uint32_t rg = bs[k];
+                    anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);
+                }
             }
         }
         run_a += ta;

@@ -77,6 +77,18 @@ struct SeedTile {
     uint32_t first;     // tile index within the contig: windows i in [20 + first*SEED_TILE, ...)
 };
 
+// Seed table of a genome (sketch_build.hip build_tables_kernel): open addressing, n_buckets home slots cut into slices of TAB_SLICE; every slice is
+// followed by TAB_SLACK overflow slots of its own, so a probe that starts in a slice ends in it.  Every run of occupied slots ascends by hash: a probe
+// walks from its home slot while the slot's hash is smaller than its own (an empty slot is all ones and ends every walk).  Slot = mix32(seed) << 32 | x:
+//   x <  TAB_LISTED              the seed occurs once in the genome: x IS its position (padded coordinate << 1 | strand) -- no second request
+//   x = TAB_LISTED | code << 29 | offset   2 .. band occurrences (or one beyond 2^31): list storage of the genome at `offset`: count, then the positions
+//                                ascending; code = count - 1 for 2..4 occurrences (most lists: the join then needs no look at the list head), else 0
+//   x = TAB_REPETITIVE           more than band occurrences: the join drops the seed entirely (chain.rs:694-696)
 constexpr uint64_t TAB_EMPTY = ~0ull;
+constexpr uint32_t TAB_SLICE_SHIFT = 12, TAB_SLICE = 1u << TAB_SLICE_SHIFT, TAB_SLACK = 128;
+constexpr uint32_t TAB_LISTED = 0x80000000u, TAB_REPETITIVE = 0xFFFFFFFDu, TAB_OFF_BITS = 29, TAB_OFF_MASK = (1u << TAB_OFF_BITS) - 1u;   // list offsets stay below TAB_OFF_MASK - 8: no payload equals
+                                                                                                                          // TAB_REPETITIVE or all ones (hash 0xFFFFFFFF | all ones would read as an empty slot)
+__host__ __device__ __forceinline__ uint32_t tab_list_code(uint32_t x) { return (x >> TAB_OFF_BITS) & 3u; }   // 0: count at the list head, else count - 1
+__host__ __device__ __forceinline__ uint32_t tab_slot(uint32_t home) { return home + (home >> TAB_SLICE_SHIFT) * TAB_SLACK; }   // physical slot of a home slot
 
 }  // namespace skh

@@ -98,12 +98,37 @@ __device__ __forceinline__ void wave_sync_mem() {
     __builtin_amdgcn_wave_barrier();
 #endif
 }
+// Orders this thread's memory operations for the other threads of its WORKGROUP (use with __syncthreads()).  Not __threadfence(): an agent-scope
+// fence on a multi-XCD part writes back / invalidates the XCD's L2 -- measured in round 2 at hundreds of microseconds per workgroup.
+__device__ __forceinline__ void block_fence() {
+#ifdef SKANI_EMU
+    __threadfence_block();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+}
 // |a - b| of two unsigned numbers in one instruction (v_sad_u32)
 __device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) {
 #ifdef SKANI_EMU
     return a > b ? a - b : b - a;
 #else
     uint32_t d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d;      // hipcc expands __usad to min/max/sub
+#endif
+}
+// value of the next / previous lane of the wave (lane 63 / lane 0 keep their own): one DPP move (wave_shl:1 / wave_shr:1) instead of a trip through the
+// LDS crossbar -- for dependent chains of neighbour exchanges (sketch_build.hip cluster sort)
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) {
+#ifdef SKANI_EMU
+    const int l = (int)emu::lane(); return emu::shfl(v, l < 63 ? l + 1 : l);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false);
+#endif
+}
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) {
+#ifdef SKANI_EMU
+    const int l = (int)emu::lane(); return emu::shfl(v, l > 0 ? l - 1 : l);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
 #endif
 }
 // inclusive prefix sum across the wave

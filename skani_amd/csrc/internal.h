@@ -56,10 +56,9 @@ struct skh_tunables {
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
-    uint32_t place_lds_words = 16384;                   // LDS words (64 KB) the table placement may spend on a genome's bucket bitmap; longer bitmaps (genomes beyond ~33 Mbp at c = 125) are set in memory
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
-    uint32_t build_hash_bits = 0;                       // leading hash bits in the seed-order sort key (0 = as many as fit; tests use few)
+    uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };
 
@@ -101,6 +100,7 @@ struct skh_sketch_set {
     std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
     std::vector<uint32_t> n_buckets;               // home slots (buckets) of each genome's seed table
     std::vector<uint64_t> bmap_off;                // n_genomes+1: first 32-bit word of each genome's bucket-occupancy bitmap
+    std::vector<uint64_t> ms_off;                  // n_genomes+1: first word of each genome's seed-list storage
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
     std::vector<uint32_t> goff;                    // padded-coordinate start of every contig, n_contigs(g)+1 entries per genome at
                                                    // index ctg_off[g] + g (the last one = the genome's padded span)
@@ -112,11 +112,11 @@ struct skh_sketch_set {
     // device arrays
     skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical
     skh::DBuf<uint32_t> p_rep;                     // 1 bit per position (set-wide position index): its seed occurs more than 2500 / c times in its genome (chain.rs:674-676)
-    skh::DBuf<uint32_t> s_g;                       // the same records in (mix32(seed), contig, pos) order
-    // seed index (probe side): one entry per distinct seed, sorted by mix32(seed) within the genome:
-    //   mix32(seed) << 32 | start (24 bits, in the genome's seed-order arrays) << 8 | min(multiplicity, 255)
-    // per-genome open-addressing seed table, the entries (hash << 32 | first record << 8 | multiplicity) in the slots, clusters sorted by hash; TAB_EMPTY = free
-    skh::DBuf<uint64_t> tab;                       // tab_off[g] .. : n_buckets[g] + slack slots (sketch_build.hip place_tables_kernel)
+    skh::DBuf<uint32_t> p_hash;                    // mix32(p_seed): what the join enumerates and probes with
+    // seed table (probe side), common.h: per genome n_buckets home slots in slices of TAB_SLICE, each followed by TAB_SLACK overflow slots;
+    // slot = mix32(seed) << 32 | position (single seeds) / list reference / "repetitive"; TAB_EMPTY = free
+    skh::DBuf<uint64_t> tab;                       // tab_off[g] .. (sketch_build.hip build_tables_kernel)
+    skh::DBuf<uint32_t> ms;                        // list storage of the seeds with several positions: ms_off[g] + offset -> count, positions ascending
     skh::DBuf<uint32_t> bmap;                      // 1 bit per bucket: bucket non-empty (10 KB per 5 Mbp genome: staged in LDS by the join)
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_goff;

@@ -2,13 +2,12 @@
 //
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
-//   position order : p_seed/p_g (+ p_rep = 1 bit per position: its seed occurs more than index_chain_band times in this genome) -- enumeration side
+//   position order : p_seed / p_hash (= mix32(seed), a bijection: equal hash <=> equal seed) / p_g, + p_rep = 1 bit per position: its seed occurs
+//                    more than index_chain_band times in this genome -- the enumeration side of the join
 //                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
-//   seed order     : s_g = the same records sorted by (mix32(seed), contig, pos)   (mix32 is a bijection: equal hash <=> equal seed)
-//   seed index     : one 64-bit entry per distinct seed, hash << 32 | first record in s_g << 8 | multiplicity, stored in
-//                    tab = the genome's open-addressing table (2 home slots per distinct seed + slack)        -- probe side
-//                    Built by one sort + a prefix-max placement of the hash-ordered entries (place_tables_kernel): no atomics, and a
-//                    probe of an absent seed usually ends at the LDS bitmap or at its home slot after one 8-byte read.
+//   seed table     : open addressing over n_buckets = 2 x positions home slots, slot = hash << 32 | position (seeds that occur once: 95 %) or
+//                    | a reference into the genome's list storage `ms` (count, positions ascending) -- the probe side: ONE memory request per hit.
+//                    Built slice by slice in LDS (build_tables_kernel): no sort, no global scatter.  + 1 bit per home slot: occupied.
 //   markers        : sorted unique u64
 #include <algorithm>
 
@@ -20,78 +19,6 @@ __device__ __forceinline__ uint32_t seg_of(const uint64_t* off, uint32_t n_seg, 
     uint32_t lo = 0, hi = n_seg;
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
     return lo;
-}
-
-// Seed order = (genome, mix32(seed), contig, pos).  The device-wide radix sort works on 32-bit keys holding the genome and as
-// many leading hash bits as fit beside it (stable, so equal keys stay in position order): four passes over 8-byte records
-// instead of six over 12-byte ones.  The full 64-bit keys (genome << 32 | hash) are rebuilt afterwards and the rare runs that
-// still mix several hashes under one 32-bit key are put in order in place (fixup_runs_kernel).
-// When the position index needs few bits (idx_bits), the hash bits that do not fit the 32-bit key ride in the value's upper
-// bits (carry = 1), so the full hash comes back after the sort without a gather: value = low hash bits << idx_bits | index.
-__global__ __launch_bounds__(256) void make_seed_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
-                                                             uint32_t idx_bits, uint32_t carry, uint32_t* keys32, uint32_t* vals) {
-    __shared__ uint32_t g0;
-    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) g0 = seg_of(pos_off, ng, i0);                              // one search per workgroup; its records span few genomes
-    __syncthreads();
-    const uint64_t i = i0 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t g = g0;
-    while (i >= pos_off[g + 1]) g++;
-    const uint32_t h = mix32(p_seed[i]), idx = (uint32_t)(i - pos_off[g]);
-    keys32[i] = hash_bits >= 32 ? h : ((g << hash_bits) | (h >> (32u - hash_bits)));
-    vals[i] = carry ? (((h & ((1u << (32u - hash_bits)) - 1u)) << idx_bits) | idx) : idx;
-}
-__global__ __launch_bounds__(256) void full_keys_kernel(const uint32_t* p_seed, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t hash_bits,
-                                                        uint32_t idx_bits, uint32_t carry, const uint32_t* keys32, uint32_t* vals, uint64_t* keys) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k32 = keys32[i], v = vals[i];
-    const uint32_t g = hash_bits >= 32 ? 0u : k32 >> hash_bits;
-    uint32_t h;
-    if (hash_bits >= 32) h = k32;
-    else if (carry) { h = ((k32 & ((1u << hash_bits) - 1u)) << (32u - hash_bits)) | (v >> idx_bits); vals[i] = v & ((1u << idx_bits) - 1u); }
-    else h = mix32(p_seed[pos_off[g] + v]);
-    keys[i] = ((uint64_t)g << 32) | h;
-}
-// One thread per run of equal 32-bit keys: orders the run by (full key, position index).  Runs are almost always one seed
-// (already in order); insertion sort costs one pass then.  Long runs that do mix hashes get an in-place heapsort.
-__device__ __forceinline__ bool kv_less(uint64_t ka, uint32_t va, uint64_t kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); }
-__global__ __launch_bounds__(256) void fixup_runs_kernel(const uint32_t* keys32, uint64_t n, uint64_t* keys, uint32_t* vals) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (i > 0 && keys32[i] == keys32[i - 1])) return;
-    const uint32_t k32 = keys32[i];
-    uint64_t e = i + 1;
-    while (e < n && keys32[e] == k32) e++;
-    const uint64_t len = e - i;
-    if (len == 1) return;
-    uint64_t* K = keys + i; uint32_t* V = vals + i;
-    bool sorted = true;
-    for (uint64_t x = 1; x < len && sorted; x++) sorted = !kv_less(K[x], V[x], K[x - 1], V[x - 1]);
-    if (sorted) return;
-    if (len <= 64) {
-        for (uint64_t x = 1; x < len; x++) {
-            const uint64_t kx = K[x]; const uint32_t vx = V[x]; uint64_t y = x;
-            while (y > 0 && kv_less(kx, vx, K[y - 1], V[y - 1])) { K[y] = K[y - 1]; V[y] = V[y - 1]; y--; }
-            K[y] = kx; V[y] = vx;
-        }
-        return;
-    }
-    auto sift = [&](uint64_t root, uint64_t end) {                                   // max-heap on (key, val)
-        for (;;) {
-            uint64_t c = 2 * root + 1;
-            if (c >= end) break;
-            if (c + 1 < end && kv_less(K[c], V[c], K[c + 1], V[c + 1])) c++;
-            if (!kv_less(K[root], V[root], K[c], V[c])) break;
-            const uint64_t tk = K[root]; K[root] = K[c]; K[c] = tk; const uint32_t tv = V[root]; V[root] = V[c]; V[c] = tv;
-            root = c;
-        }
-    };
-    for (uint64_t st = len / 2; st-- > 0;) sift(st, len);
-    for (uint64_t end = len - 1; end > 0; end--) {
-        const uint64_t tk = K[0]; K[0] = K[end]; K[end] = tk; const uint32_t tv = V[0]; V[0] = V[end]; V[end] = tv;
-        sift(0, end);
-    }
 }
 
 // (pos, contig << 1 | canonical) -> padded coordinate << 1 | canonical
@@ -124,163 +51,216 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
     if (i < n) out[i] = src[idx[i]];
 }
 
-// ---- from the sorted records to the sketch tables, in tiles of 1024 records (256 threads x 4 consecutive records)
-constexpr uint32_t BT = 1024;
-// distinct (genome, hash) keys that START inside each tile
-__global__ __launch_bounds__(256) void tile_heads_kernel(const uint64_t* keys, uint64_t n, uint32_t* tile_cnt) {
-    __shared__ uint32_t lds[4];
-    const uint64_t i0 = (uint64_t)blockIdx.x * BT + 4u * threadIdx.x;
-    uint32_t c = 0;
-    if (i0 < n) {
-        uint64_t prev = i0 ? keys[i0 - 1] : ~keys[0];
-        for (uint32_t j = 0; j < 4 && i0 + j < n; j++) { const uint64_t k = keys[i0 + j]; c += k != prev ? 1u : 0u; prev = k; }
-    }
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-}
-// number of distinct keys before each genome's first record (one wave per genome boundary)
-__global__ __launch_bounds__(256) void genome_dist_off_kernel(const uint64_t* keys, const uint32_t* tile_off, const uint64_t* pos_off, uint32_t ng, uint32_t* out) {
-    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g > ng) return;
-    const uint64_t x = pos_off[g], t0 = x / BT * BT;
-    uint32_t c = 0;
-    for (uint64_t i = t0 + lane_id(); i < x; i += 64) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-    c = wave_sum(c);
-    if (lane_id() == 0) out[g] = c + tile_off[x / BT];
-}
-// One pass over the sorted records emits the index entry of every distinct seed (hash | first record | multiplicity; compact, in hash
-// order -- place_tables_kernel spreads them over the genome's table), the hash-order position array, and the per-position
-// "repetitive seed" bit.  (Was: head flags + a device-wide scan over all records + three more passes.)
-__global__ __launch_bounds__(256) void emit_tables_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* tile_off, const uint64_t* pos_off,
-                                                          const uint32_t* p_g, uint64_t* ent, uint32_t* s_g, uint32_t* p_rep, uint32_t band) {
-    constexpr int R = BT / 256;
-    __shared__ uint32_t lds_scan[R * 4];
-    __shared__ uint32_t run_cnt[BT + 1];                     // multiplicity of the run that starts at local distinct index x (slot BT: the run cut by the tile start)
-    const uint64_t t0 = (uint64_t)blockIdx.x * BT;
-    const uint32_t wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    // record (r, thread) = t0 + 256 r + thread: every load below is coalesced and the four rounds' loads are independent
-    uint64_t k[R], kp[R]; uint32_t head[R], incl[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
-        k[r] = i < n ? keys[i] : 0; kp[r] = (i > 0 && i < n) ? keys[i - 1] : 0;
-        head[r] = (i < n && (i == 0 || k[r] != kp[r])) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) { incl[r] = wave_incl_scan(head[r]); if (l == 63) lds_scan[r * 4 + wv] = incl[r]; }
-    // the run that reaches into this tile from the previous one: its multiplicity, found by one thread (runs are short; the
-    // count saturates at 65535)
-    if (threadIdx.x == 0 && t0 < n && !head[0]) {
-        uint64_t b = t0; uint32_t c = 0;
-        while (b > 0 && keys[b - 1] == k[0] && c < 65535u) { b--; c++; }
-        uint64_t e = t0; while (e < n && keys[e] == k[0] && c < 65535u) { e++; c++; }
-        run_cnt[BT] = c;
-    }
-    __syncthreads();
-    const uint32_t d0 = tile_off[blockIdx.x];
-    uint32_t lidx[R], base = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        uint32_t before = 0, tot = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) { const uint32_t x = lds_scan[r * 4 + q]; if (q < wv) before += x; tot += x; }
-        lidx[r] = base + before + incl[r];                    // heads up to and including this record (this record's run = lidx - 1; 0 = the cut run)
-        base += tot;
-        if (head[r]) {
-            const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
-            uint32_t c = 1; while (i + c < n && keys[i + c] == k[r] && c < 65535u) c++;
-            run_cnt[lidx[r] - 1] = c;
-            const uint32_t g = (uint32_t)(k[r] >> 32), hash = (uint32_t)k[r];
-            const uint64_t d = (uint64_t)d0 + lidx[r] - 1;
-            // one 8-byte entry answers a probe completely: hash | first record in the hash-order array | multiplicity
-            ent[d] = ((uint64_t)hash << 32) | ((uint64_t)((uint32_t)(i - pos_off[g]) & 0xFFFFFFu) << 8) | (c > 255u ? 255u : c);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint64_t i = t0 + 256u * (uint32_t)r + threadIdx.x;
-        if (i < n) {
-            const uint32_t g = (uint32_t)(k[r] >> 32);
-            const uint64_t src = pos_off[g] + vals[i];
-            const uint32_t c = run_cnt[lidx[r] ? lidx[r] - 1 : BT];
-            s_g[i] = p_g[src];
-            if (c > band) atomicOr(&p_rep[src >> 5], 1u << (src & 31u));             // rare: the join skips these positions (chain.rs:674-676)
-        }
-    }
+// ---- seed tables, built per genome in LDS
+// A genome's table is cut into slices of TAB_SLICE home slots (common.h); one workgroup builds one slice entirely in LDS and writes it out
+// densely, so the build needs no sort, no global scatter and no partial-line stores (round 1 sorted all records of the batch by (genome, hash)
+// with four device-wide radix passes and then emitted / placed the entries: 2.9 ms per 1000 genomes against ~0.4 ms now).
+//   pass A  every position whose seed's home slot falls into the slice is inserted by linear probing with 64-bit LDS compare-and-swap:
+//           slot = hash << 32 | multiplicity (the same seed again only bumps the count);
+//   pass B  slots are classified: single / listed (2 .. band occurrences: count + 1 words of the genome's list storage, handed out by a
+//           workgroup scan + one global atomic) / repetitive (more than band: the join drops the seed, chain.rs:694-696);
+//   pass C  the positions are visited again: a single seed's position goes INTO its slot (a probe hit then needs no second memory request),
+//           listed seeds append to their list, positions of repetitive seeds get their 'repetitive' bit (chain.rs:674-676);
+//   pass D  the short lists are put into ascending order (anchors must come out in (ref contig, ref pos) order for one query position);
+//   then the slice, its share of the bucket-occupancy bitmap and the number of distinct seeds are written out.
+// Clusters are not sorted by hash (insertion order is whatever the LDS atomics made it): a probe walks to its hash or to an empty slot.  The
+// outcome -- which positions a seed has, in which order -- does not depend on that order.
+constexpr uint32_t BUILD_THREADS = 1024;
+constexpr uint32_t SLOT_PENDING = 0xFFFFFFFEu;          // pass B -> pass C: single seed whose position is still to be filled in
+
+__global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restrict__ p_seed, uint64_t n, uint32_t* __restrict__ p_hash) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p_hash[i] = mix32(p_seed[i]);
 }
 
-// Seed table of a genome: open addressing with the entries themselves in the slots, so that a probe costs ONE memory request
-// (one 64-byte line) where a directory + entry array cost two dependent ones.  The entries arrive sorted by hash, and a monotone
-// bucket function (common.h seed_bucket) makes their home slots ascend with them: linear-probing placement is then simply
-//     slot_i = max(home_i, slot_{i-1} + 1)        <=>        slot_i - i = running maximum of (home_i - i),
-// a prefix-max scan -- no atomics, no retries, and every cluster stays sorted by hash, so a probe walks from its home slot while the
-// slot's hash is smaller than its own (an empty slot is all ones and ends every walk).  One workgroup per genome writes the whole table
-// densely (entry or empty, ascending) and collects the bucket-occupancy bitmap (bit b = some entry's home is b: staged in LDS by the join to
-// answer most absent seeds without a memory request) in LDS.  The table has n_buckets + slack slots; an entry pushed beyond them -- tens
-// of thousands of seeds hashing into the last buckets -- raises `err`.
-constexpr uint32_t PLACE_THREADS = 1024;
-__global__ __launch_bounds__(1024) void place_tables_kernel(const uint64_t* __restrict__ ent, const uint64_t* __restrict__ dist_off, const uint64_t* __restrict__ tab_off,
-                                                            const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ bmap_off, uint32_t lds_words,
-                                                            uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* __restrict__ err) {
-    __shared__ int32_t wmax[PLACE_THREADS / 64];
+__global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
+                                                            const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ tab_off,
+                                                            const uint64_t* __restrict__ bmap_off, const uint64_t* __restrict__ ms_off, uint32_t band, uint32_t match_cap,
+                                                            uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* ms, uint32_t* ms_used, uint32_t* n_distinct,
+                                                            uint32_t* p_rep, uint32_t* err) {
     SKH_DYN_SMEM(smem);
-    uint32_t* lbm = (uint32_t*)smem;
-    const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
-    const uint64_t e0 = dist_off[g]; const uint32_t nd = (uint32_t)(dist_off[g + 1] - e0), nbk = n_buckets[g];
-    uint64_t* T = tab + tab_off[g]; const uint32_t L = (uint32_t)(tab_off[g + 1] - tab_off[g]);
-    uint32_t* gbm = bmap + bmap_off[g]; const uint32_t bm_words = (uint32_t)(bmap_off[g + 1] - bmap_off[g]);
-    const bool in_lds = bm_words <= lds_words;
-    if (in_lds) for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) lbm[x] = 0;      // (the bitmap in memory was zeroed by the host before the launch)
+    unsigned long long* slots = (unsigned long long*)smem;                          // TAB_SLICE + TAB_SLACK
+    uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // TAB_SLICE / 32 words
+    uint32_t* mlist = lbm + TAB_SLICE / 32;                                         // match_cap position indices (the positions whose seed lives in this slice)
+    __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
+    __shared__ uint32_t ms_base, distinct, n_match;
+    const uint2 gs = blk[blockIdx.x];
+    if (gs.x == 0xFFFFFFFFu) return;
+    const uint32_t g = gs.x, sl = gs.y, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
+    const uint32_t h0 = sl * TAB_SLICE, nh = (NB - h0 < TAB_SLICE ? NB - h0 : TAB_SLICE), phys = nh + TAB_SLACK;   // home slots / physical slots of this slice
+    const uint64_t ms0 = ms_off[g]; const uint32_t ms_cap = (uint32_t)(ms_off[g + 1] - ms0);
+    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) slots[a] = TAB_EMPTY;
+    for (uint32_t x = tid; x < TAB_SLICE / 32; x += BUILD_THREADS) lbm[x] = 0;
+    if (tid == 0) { distinct = 0; n_match = 0; }
     __syncthreads();
-    constexpr int32_t NEG = -(1 << 30);
-    constexpr uint32_t K = 4;                                                        // consecutive entries per thread and round
-    int32_t carry = NEG;                                                             // running maximum of home - index over all earlier entries
-    for (uint32_t base = 0; base < nd; base += PLACE_THREADS * K) {
-        const uint32_t i0 = base + tid * K;
-        uint64_t x[K]; uint32_t home[K]; int32_t m[K];
+    // ---- scan: every slice reads all of the genome's hashes (coalesced, four loads in flight per thread, served by the XCD's L2 after the first
+    // slice) and lists the positions that belong to it -- the passes below then run densely over that list, one listed position per thread
+    for (uint32_t i0 = 0; i0 < P; i0 += BUILD_THREADS * 4) {
+        uint32_t hh[4]; bool m[4];
 #pragma unroll
-        for (uint32_t j = 0; j < K; j++) x[j] = i0 + j < nd ? ent[e0 + i0 + j] : 0;
-        int32_t run = NEG;
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS + tid; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
 #pragma unroll
-        for (uint32_t j = 0; j < K; j++) {
-            home[j] = seed_bucket((uint32_t)(x[j] >> 32), nbk);
-            const int32_t v = i0 + j < nd ? (int32_t)home[j] - (int32_t)(i0 + j) : NEG;
-            run = v > run ? v : run; m[j] = run;                                     // maximum over this thread's entries up to j
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * BUILD_THREADS + tid;
+            m[u] = i < P && seed_bucket(hh[u], NB) - h0 < nh;                         // (unsigned: also home < h0)
+            const unsigned long long bal = __ballot(m[u]);
+            uint32_t base = 0;
+            if (l == 0 && bal) base = atomicAdd(&n_match, (uint32_t)__popcll(bal));
+            base = wave_bcast(base, 0);
+            if (m[u]) { const uint32_t o = base + (uint32_t)__popcll(bal & ((1ull << l) - 1ull)); if (o < match_cap) mlist[o] = i; }
         }
-        int32_t v = run;                                                             // inclusive maximum over the wave's threads up to this one
+    }
+    __syncthreads();
+    // a slice with more positions than the list holds (sequence with very few distinct seeds): the passes re-scan all positions instead
+    const bool dense = n_match <= match_cap;
+    const uint32_t NM = dense ? n_match : P;
+    constexpr uint32_t MAX_OWN = 4;                                                  // listed positions per thread in dense mode (match_cap <= 4096)
+    uint32_t own[MAX_OWN];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v = t > v ? t : v; }
-        if (l == 63) wmax[w] = v;
+    for (uint32_t u = 0; u < MAX_OWN; u++) own[u] = (dense && tid + u * BUILD_THREADS < NM) ? mlist[tid + u * BUILD_THREADS] : 0xFFFFFFFFu;
+    const uint32_t n_round = dense ? MAX_OWN : (P + BUILD_THREADS - 1) / BUILD_THREADS;
+    // ---- pass A
+    for (uint32_t u = 0; u < n_round; u++) {
+        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
+        if (i >= P) continue;
+        const uint32_t h = p_hash[pos0 + i], home = seed_bucket(h, NB);
+        if (home - h0 >= nh) continue;
+        uint32_t a = home - h0;
+        for (;;) {
+            unsigned long long cur = slots[a];
+            if (cur == TAB_EMPTY) {
+                cur = atomicCAS(&slots[a], (unsigned long long)TAB_EMPTY, ((unsigned long long)h << 32) | 1ull);
+                if (cur == TAB_EMPTY) { atomicOr(&lbm[(home - h0) >> 5], 1u << ((home - h0) & 31u)); break; }
+            }
+            if ((uint32_t)(cur >> 32) == h) { atomicAdd(&slots[a], 1ull); break; }
+            if (++a >= phys) { atomicAdd(err, 1u); break; }                          // more than TAB_SLACK entries pushed past the slice's end
+        }
+    }
+    __syncthreads();
+    // ---- clusters into ascending hash order.  Homes ascend with the hash, and in a run of occupied slots the k-th smallest home is never beyond the
+    // k-th slot, so the sorted run is still a valid linear-probing layout -- and a probe may stop at the first larger hash instead of walking to the
+    // run's end (the join's count pass: 2.5 ms against 4.3 ms with clusters in insertion order).  Sorting by rank: every occupied slot finds its
+    // cluster's first slot and counts the smaller entries of the cluster (reads only, clusters are short: two slots on average at load 0.5, the
+    // longest of a slice around thirty), then all entries move at once.  (A thread per cluster sorting by insertion: +0.9 ms per 1000 genomes.)
+    {
+        constexpr uint32_t MAX_SLOTS = (TAB_SLICE + TAB_SLACK + BUILD_THREADS - 1) / BUILD_THREADS;
+        unsigned long long mine[MAX_SLOTS]; uint32_t dest[MAX_SLOTS];
+#pragma unroll
+        for (uint32_t u = 0; u < MAX_SLOTS; u++) {
+            const uint32_t a = tid + u * BUILD_THREADS;
+            mine[u] = a < phys ? slots[a] : TAB_EMPTY; dest[u] = a;
+            if (mine[u] == TAB_EMPTY) continue;
+            uint32_t first = a, smaller = 0;
+            while (first > 0) { const unsigned long long x = slots[first - 1]; if (x == TAB_EMPTY) break; smaller += x < mine[u] ? 1u : 0u; first--; }
+            for (uint32_t y = a + 1; y < phys; y++) { const unsigned long long x = slots[y]; if (x == TAB_EMPTY) break; smaller += x < mine[u] ? 1u : 0u; }
+            dest[u] = first + smaller;
+        }
         __syncthreads();
-        int32_t pre = carry, all = carry;
-        for (uint32_t q = 0; q < PLACE_THREADS / 64; q++) { const int32_t t = wmax[q]; if (q < w) pre = t > pre ? t : pre; all = t > all ? t : all; }
-        int32_t before = __shfl_up(v, 1, 64); if (l == 0) before = NEG;               // maximum over the wave's earlier threads
-        before = before > pre ? before : pre;                                        // ... and everything before the wave
 #pragma unroll
-        for (uint32_t j = 0; j < K; j++) {
-            const uint32_t i = i0 + j;
-            if (i < nd) {
-                const int32_t u = m[j] > before ? m[j] : before;                         // u_i
-                const int32_t up = j ? (m[j - 1] > before ? m[j - 1] : before) : before;   // u_{i-1}
-                const uint32_t slot = (uint32_t)(u + (int32_t)i);
-                const uint32_t first = i == 0 ? 0u : (uint32_t)(up + (int32_t)i);       // slot_{i-1} + 1
-                if (slot + 1u >= L) atomicAdd(err, 1u);                              // the last slot stays empty: walks end inside the table
-                else {
-                    for (uint32_t sft = first; sft < slot; sft++) T[sft] = TAB_EMPTY;
-                    T[slot] = x[j];
-                    if (in_lds) atomicOr(&lbm[home[j] >> 5], 1u << (home[j] & 31u)); else atomicOr(&gbm[home[j] >> 5], 1u << (home[j] & 31u));
+        for (uint32_t u = 0; u < MAX_SLOTS; u++) if (mine[u] != TAB_EMPTY) slots[dest[u]] = mine[u];
+    }
+    __syncthreads();
+    // ---- pass B: thread t owns slots t, t + 1024, ... ; list storage by a workgroup scan
+    uint32_t need = 0, nd = 0;
+    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+        const unsigned long long v = slots[a];
+        if (v == TAB_EMPTY) continue;
+        const uint32_t c = (uint32_t)v; nd++;
+        if (c >= 2 && c <= band) need += c + 1;
+    }
+    uint32_t incl = wave_incl_scan(need);
+    if (l == 63) lds_scan[w] = incl;
+    nd = wave_sum(nd);
+    if (l == 0 && nd) atomicAdd(&distinct, nd);
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (uint32_t q = 0; q < BUILD_THREADS / 64; q++) { const uint32_t t = lds_scan[q]; if (q < w) before += t; tot += t; }
+    if (tid == 0) {
+        ms_base = tot ? atomicAdd(&ms_used[g], tot) : 0u;
+        if (distinct) atomicAdd(&n_distinct[g], distinct);
+    }
+    __syncthreads();
+    const uint32_t base = ms_base;
+    uint32_t off = base + before + incl - need;
+    const bool ms_ok = base + tot <= ms_cap && base + tot < TAB_OFF_MASK - 8;
+    if (!ms_ok && tid == 0) atomicAdd(err, 1u);
+    // the lists of this slice are filled and ordered in LDS (the position list's space: every thread holds its positions in registers by now)
+    // and copied out whole; only a slice with more list words than that space fills them in memory
+    uint32_t* stage = mlist;
+    const bool staged = tot <= match_cap;
+    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+        const unsigned long long v = slots[a];
+        if (v == TAB_EMPTY) continue;
+        const uint32_t c = (uint32_t)v; uint32_t x;
+        if (c == 1) x = SLOT_PENDING;
+        else if (c > band || !ms_ok) x = TAB_REPETITIVE;
+        else {                                                                        // list head = fill cursor now, the count in the end
+            x = TAB_LISTED | ((c <= 4 ? c - 1 : 0u) << TAB_OFF_BITS) | off;
+            if (staged) stage[off - base] = 0; else ms[ms0 + off] = 0;
+            off += c + 1;
+        }
+        slots[a] = (v & 0xFFFFFFFF00000000ull) | x;
+    }
+    block_fence();
+    __syncthreads();
+    // ---- pass C
+    for (uint32_t u = 0; u < n_round; u++) {
+        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
+        if (i >= P) continue;
+        const uint32_t h = p_hash[pos0 + i], pg = p_g[pos0 + i];
+        uint32_t a = seed_bucket(h, NB) - h0;
+        if (a >= nh) continue;
+        unsigned long long v = slots[a];
+        while ((uint32_t)(v >> 32) != h && a + 1 < phys) v = slots[++a];             // present by construction (unless the slice overflowed: err is set)
+        if ((uint32_t)(v >> 32) != h) continue;
+        const uint32_t x = (uint32_t)v;
+        if (x == TAB_REPETITIVE) { const uint64_t gi = pos0 + i; atomicOr(&p_rep[gi >> 5], 1u << (gi & 31u)); }
+        else if (x == SLOT_PENDING) {
+            if (pg < TAB_LISTED) slots[a] = ((unsigned long long)h << 32) | pg;
+            else {                                                                    // a position beyond 2^31 does not fit beside the flag bit: list of one
+                const uint32_t o = atomicAdd(&ms_used[g], 2u);
+                if (o + 2 <= ms_cap && o + 2 < TAB_OFF_MASK - 8) { ms[ms0 + o] = 1; ms[ms0 + o + 1] = pg; slots[a] = ((unsigned long long)h << 32) | TAB_LISTED | o; }
+                else { atomicAdd(err, 1u); slots[a] = ((unsigned long long)h << 32) | TAB_REPETITIVE; }
+            }
+        } else if (x & TAB_LISTED) {
+            const uint32_t o = x & TAB_OFF_MASK;
+            if (staged) { const uint32_t q = atomicAdd(&stage[o - base], 1u); stage[o - base + 1 + q] = pg; }
+            else { const uint32_t q = atomicAdd(&ms[ms0 + o], 1u); ms[ms0 + o + 1 + q] = pg; }
+        }
+    }
+    block_fence();
+    __syncthreads();
+    // ---- pass D (lists into ascending order: anchors of one query position must come out by reference position) + write-out
+    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+        const unsigned long long v = slots[a];
+        const uint32_t x = (uint32_t)v;
+        if (v != TAB_EMPTY && (x & TAB_LISTED) && x != TAB_REPETITIVE && x != SLOT_PENDING) {
+            const uint32_t o = x & TAB_OFF_MASK;
+            if (staged && o >= base && o - base < tot) {
+                uint32_t* L = stage + (o - base);
+                const uint32_t n = L[0];
+                for (uint32_t u = 2; u <= n; u++) {                                  // insertion sort of L[1..n] (n <= band)
+                    const uint32_t key = L[u]; uint32_t y = u;
+                    while (y > 1 && L[y - 1] > key) { L[y] = L[y - 1]; y--; }
+                    L[y] = key;
+                }
+                for (uint32_t u = 0; u <= n; u++) ms[ms0 + o + u] = L[u];
+            } else if (!staged) {
+                // filled with atomics and stores of other threads; lists of other slices may share the cache lines: read and write past the L1
+                uint32_t* L = ms + ms0 + o;
+                const uint32_t n = __atomic_load_n(&L[0], __ATOMIC_RELAXED);
+                for (uint32_t u = 2; u <= n; u++) {
+                    const uint32_t key = __atomic_load_n(&L[u], __ATOMIC_RELAXED); uint32_t y = u;
+                    while (y > 1) { const uint32_t prev = __atomic_load_n(&L[y - 1], __ATOMIC_RELAXED); if (prev <= key) break; __atomic_store_n(&L[y], prev, __ATOMIC_RELAXED); y--; }
+                    __atomic_store_n(&L[y], key, __ATOMIC_RELAXED);
                 }
             }
         }
-        carry = all;
-        __syncthreads();
+        tab[tab_off[g] + (uint64_t)sl * (TAB_SLICE + TAB_SLACK) + a] = v;
     }
-    const uint32_t tail = nd ? (uint32_t)(carry + (int32_t)(nd - 1)) + 1u : 0u;      // first slot after the last entry
-    for (uint32_t sft = tail + tid; sft < L; sft += PLACE_THREADS) T[sft] = TAB_EMPTY;
-    if (in_lds) { for (uint32_t x = tid; x < bm_words; x += PLACE_THREADS) gbm[x] = lbm[x]; }
+    uint32_t* gbm = bmap + bmap_off[g] + sl * (TAB_SLICE / 32);
+    for (uint32_t x = tid; x < (nh + 31) / 32; x += BUILD_THREADS) gbm[x] = lbm[x];
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -299,91 +279,71 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
     ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->s_g.alloc(P); ss->p_rep.alloc(P / 32 + 1); dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
+    ss->p_rep.alloc(P / 32 + 1); dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
     if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
+    if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
     if (P > 0 && pos && cc) {
         SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
                    (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
         check_launch("pack_positions");
     }
-    ss->dist_off.assign(ng + 1, 0);
-    for (uint32_t g = 0; g < ng; g++)
-        if (ss->pos_off[g + 1] - ss->pos_off[g] >= (1ull << 24)) throw Error("a genome with >= 2^24 seed positions does not fit the 24-bit table slot field");
-    uint64_t D = 0;
-    const uint64_t* sorted_keys = nullptr; const uint32_t* sorted_vals = nullptr; const uint32_t* sorted_tile_off = nullptr; uint32_t n_sorted_tiles = 0;
-    if (P > 0) {
-        if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
-        uint64_t* keys = ctx->arena.get<uint64_t>(P); uint32_t* vals = ctx->arena.get<uint32_t>(P); uint32_t* keys32 = ctx->arena.get<uint32_t>(P);
-        const unsigned nb = (unsigned)((P + 255) / 256);
-        const uint32_t gbits = ng > 1 ? (uint32_t)bits_for(ng) : 0u;
-        const uint32_t hash_bits = std::max<uint32_t>(ctx->tune.build_hash_bits ? std::min<uint32_t>(ctx->tune.build_hash_bits, 32u - gbits) : 32u - gbits, 1u);
-        if (gbits >= 32) throw Error("too many genomes in one sketch set");
-        uint64_t max_pos = 1; for (uint32_t g = 0; g < ng; g++) max_pos = std::max<uint64_t>(max_pos, ss->pos_off[g + 1] - ss->pos_off[g]);
-        const uint32_t idx_bits = (uint32_t)bits_for(max_pos);
-        const uint32_t carry = (hash_bits < 32 && idx_bits + (32u - hash_bits) <= 32u && !ctx->tune.build_hash_bits) ? 1u : 0u;
-        SKH_LAUNCH(make_seed_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, idx_bits, carry, keys32, vals);
-        check_launch("make_seed_keys");
-        tr.mark("build: allocs + keys");
-        sort_pairs_u32_u32(ctx, keys32, vals, P, (int)(hash_bits >= 32 ? 32 : hash_bits + gbits));
-        SKH_LAUNCH(full_keys_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint64_t*)ss->d_pos_off.p, ng, P, hash_bits, idx_bits, carry, (const uint32_t*)keys32, vals, keys);
-        check_launch("full_keys");
-        // always: besides separating hashes that share a 32-bit key it puts equal seeds into position order, which must not
-        // depend on the device sort being stable (rocPRIM's path for mid-sized inputs is not)
-        SKH_LAUNCH(fixup_runs_kernel, nb, 256, 0, ctx->stream, (const uint32_t*)keys32, P, keys, vals);
-        check_launch("fixup_runs");
-        tr.mark("build: sort");
-        const uint32_t n_bt = (uint32_t)((P + BT - 1) / BT);
-        uint32_t* tile_cnt = ctx->arena.get<uint32_t>(n_bt); uint32_t* tile_off = ctx->arena.get<uint32_t>(n_bt + 1);
-        SKH_LAUNCH(tile_heads_kernel, n_bt, 256, 0, ctx->stream, (const uint64_t*)keys, P, tile_cnt);
-        check_launch("tile_heads");
-        exclusive_scan_u32(ctx, tile_cnt, n_bt, tile_off);
-        uint32_t* d_do = ctx->arena.get<uint32_t>(ng + 1);
-        SKH_LAUNCH(genome_dist_off_kernel, (ng + 1 + 3) / 4, 256, 0, ctx->stream, (const uint64_t*)keys, (const uint32_t*)tile_off, (const uint64_t*)ss->d_pos_off.p, ng, d_do);
-        check_launch("genome_dist_off");
-        std::vector<uint32_t> h_do(ng + 1);
-        d2h(h_do.data(), d_do, (ng + 1) * 4, ctx->stream);
-        for (uint32_t g = 0; g <= ng; g++) ss->dist_off[g] = h_do[g];
-        D = ss->dist_off[ng];
-        tr.mark("build: heads + scan + readback");
-        sorted_keys = keys; sorted_vals = vals; sorted_tile_off = tile_off; n_sorted_tiles = n_bt;
+    ss->p_hash.alloc(P ? P : 1);
+    if (P) {
+        SKH_LAUNCH(hash_seeds_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, P, ss->p_hash.p);
+        check_launch("hash_seeds");
     }
-    uint64_t* ent = ctx->arena.get<uint64_t>(D + 1);                                 // compact entries, hash order: input of the placement only
-    // seed tables (north-star requirement: per-sketch seed -> position tables built on device): 2 buckets per distinct seed + slack
-    ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0);
-    uint64_t max_bm_words = 0;
-    for (uint32_t g = 0; g < ng; g++) {
-        const uint64_t dg = ss->dist_off[g + 1] - ss->dist_off[g];
-        ss->n_buckets[g] = (uint32_t)std::max<uint64_t>(16, 2 * dg);                  // dg < 2^24
-        ss->tab_off[g + 1] = ss->tab_off[g] + ss->n_buckets[g] + std::max<uint64_t>(64, dg / 8);
-        const uint64_t bw = (((uint64_t)ss->n_buckets[g] + 31) / 32 + 3) / 4 * 4;       // whole 16-byte groups
-        ss->bmap_off[g + 1] = ss->bmap_off[g] + bw; max_bm_words = std::max(max_bm_words, bw);
+    // table geometry from the position counts alone (two home slots per POSITION, at least as many as per distinct seed): nothing has to come back
+    // from the device before the tables are allocated
+    ss->dist_off.assign(ng + 1, 0); ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0); ss->ms_off.assign(ng + 1, 0);
+    std::vector<uint2> blocks[8];                                                   // (genome, slice), dealt to eight queues by genome: the slices of a genome
+    for (uint32_t g = 0; g < ng; g++) {                                             // run on one XCD and share its seed arrays through that L2
+        const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
+        if (pg >= (1ull << 30)) throw Error("a genome with >= 2^30 seed positions does not fit the seed table's 32-bit slot fields");
+        const uint32_t nb = (uint32_t)std::max<uint64_t>(64, 2 * pg);
+        const uint32_t n_sl = (nb + TAB_SLICE - 1) / TAB_SLICE;
+        ss->n_buckets[g] = nb;
+        ss->tab_off[g + 1] = ss->tab_off[g] + nb + (uint64_t)n_sl * TAB_SLACK;
+        ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / 32) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
+        // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
+        // coordinates pass 2^30 may need two words for a single position
+        const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];
+        ss->ms_off[g + 1] = ss->ms_off[g] + (span >= (1ull << 30) ? 2 * pg : pg + pg / 2) + 16;
+        if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
+        for (uint32_t s = 0; s < n_sl; s++) blocks[g & 7u].push_back(make_uint2(g, s));
     }
-    ss->tab.alloc(ss->tab_off[ng] ? ss->tab_off[ng] : 1);
-    ss->d_dist_off.alloc(ng + 1); h2d(ss->d_dist_off.p, ss->dist_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->tab.alloc(ss->tab_off[ng] ? ss->tab_off[ng] : 1); ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
     ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
-    if (P > 0) {
-        SKH_LAUNCH(emit_tables_kernel, n_sorted_tiles, 256, 0, ctx->stream, sorted_keys, sorted_vals, P, sorted_tile_off, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint32_t*)ss->p_g.p, ent, ss->s_g.p, ss->p_rep.p, BP_CHAIN_BAND / ss->params.c);
-        check_launch("emit_tables");
-    }
-    tr.mark("build: entries + gather");
-    const uint64_t BW = ss->bmap_off[ng];
-    ss->bmap.alloc(BW ? BW : 1);
-    uint32_t h_err = 0;
+    std::vector<uint32_t> back(2 * (size_t)ng + 1, 0);                               // err, distinct seeds per genome, list words used per genome
     if (ng) {
+        size_t mx = 0; for (auto& q : blocks) mx = std::max(mx, q.size());
+        std::vector<uint2> blk(mx * 8, make_uint2(0xFFFFFFFFu, 0));
+        for (uint32_t x = 0; x < 8; x++) for (size_t k = 0; k < blocks[x].size(); k++) blk[k * 8 + x] = blocks[x][k];
+        uint2* d_blk = ctx->arena.get<uint2>(blk.size() ? blk.size() : 1); h2d(d_blk, blk.data(), blk.size() * sizeof(uint2), ctx->stream);
         uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
-        uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
-        const uint32_t lds_words = (uint32_t)std::min<uint64_t>(max_bm_words, ctx->tune.place_lds_words);   // LDS for the bitmap; longer ones are set in memory
-        dzero(ss->bmap.p, BW * 4, ctx->stream);
-        SKH_LAUNCH(place_tables_kernel, ng, PLACE_THREADS, (size_t)lds_words * 4, ctx->stream, (const uint64_t*)ent, (const uint64_t*)ss->d_dist_off.p, (const uint64_t*)d_to,
-                   (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_bo, lds_words, ss->tab.p, ss->bmap.p, d_err);
-        check_launch("place_tables");
-        d2h(&h_err, d_err, 4, ctx->stream);                                            // synchronises
+        uint64_t* d_mo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_mo, ss->ms_off.data(), (ng + 1) * 8, ctx->stream);
+        uint32_t* d_back = ctx->arena.get<uint32_t>(back.size()); dzero(d_back, back.size() * 4, ctx->stream);
+        dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
+        // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
+        // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
+        const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TAB_SLICE, 4 * BUILD_THREADS);
+        if (!blk.empty()) {
+            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / 8 + (size_t)match_cap * 4;
+#ifndef SKANI_EMU
+            static size_t attr_lds = 0;
+            if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
+#endif
+            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), BUILD_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
+                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
+                       BP_CHAIN_BAND / ss->params.c, match_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
+            check_launch("build_tables");
+        }
+        d2h(back.data(), d_back, back.size() * 4, ctx->stream);                       // the build's one read-back (synchronises)
     }
-    tr.mark("build: tables");
+    for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + back[1 + g];
+    tr.mark("build: seed tables");
     dsync(ctx->stream);
-    if (h_err) throw Error("seed table overflow: a genome's seeds crowd the end of the hash range");
+    if (back[0]) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range");
 }
 
 // ---- markers: sort by (genome, marker), drop duplicates (marker_seeds is a set: seeding.rs:318, types.rs:272)

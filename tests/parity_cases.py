@@ -340,17 +340,17 @@ def case_edge_cases_and_errors(ctx):
     assert len(a) == 0
     i, j, res, n = ctx.triangle(ss0, sk.MapParams())
     assert len(i) == 0 and n == 0
-    # a sketch whose seeds all hash into the very end of the 32-bit range cannot be placed in its table (n_buckets + slack slots): a loud
-    # error, not a silent drop.  (mix32 is a bijection; these seeds are its preimages of the 4000 largest hashes.)  The same number of
-    # seeds from the middle of the range is fine.
+    # a sketch whose seeds all hash into one narrow stretch of the 32-bit range cannot be placed in its table (a slice of home slots + its slack
+    # slots): a loud error, not a silent drop.  (mix32 is a bijection; these seeds are its preimages of 4000 consecutive hashes.)  The same
+    # number of seeds spread over the range is fine.
     def unmix32(h):
         M = 0xFFFFFFFF
         h ^= h >> 16; h = (h * pow(0xc2b2ae35, -1, 1 << 32)) & M
         h ^= (h >> 13) ^ (h >> 26); h = (h * pow(0x85ebca6b, -1, 1 << 32)) & M
         h ^= h >> 16
         return h
-    for top, ok in ((0xFFFFFFFF, False), (0x80000000, True)):
-        seeds = np.array([unmix32(top - x) for x in range(4000)], np.uint32)
+    for top, step, ok in ((0xFFFFFFFF, 1, False), (0x80000000, 1, False), (0xFFFFFFFF, 1000003, True)):
+        seeds = np.array([unmix32(top - x * step) for x in range(4000)], np.uint32)
         rec = dict(seed=seeds, pos=np.arange(4000, dtype=np.uint32) * 50, ctgcanon=np.zeros(4000, np.uint32), markers=np.arange(10, dtype=np.uint64),
                    contig_lengths=np.array([250000], np.uint32), total_len=250000)
         if ok:
