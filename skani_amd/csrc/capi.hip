@@ -67,6 +67,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
         hip_check(hipSetDevice(device), "hipSetDevice");
         hip_check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking), "hipStreamCreate");
 #endif
         ctx->device = device;
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
@@ -89,12 +90,14 @@ void skh_ctx_destroy(skh_ctx* ctx) {
 #ifndef SKANI_EMU
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
 #endif
     ctx->arena.release_all();
     ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel();
     dcache_trim();                                   // hand the allocator's idle blocks back to the driver
 #ifndef SKANI_EMU
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
 #endif
     delete ctx;
 }
@@ -156,9 +159,13 @@ int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketc
         { Stopwatch sw(ctx, &ctx->timings.seed_ms); seed_genomes(ctx, gs, *sp, so); }
         ss->p_seed = std::move(so.seed); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
         Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
-        build_sketch_tables(ctx, ss, nullptr, nullptr);
-        ctx->arena.reset();
-        build_markers(ctx, ss, so.markers_raw, so.mk_off);
+        // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) are built on
+        // the second stream meanwhile: neither fills the GPU, together they take as long as the tables alone
+        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
+        std::swap(ctx->stream, ctx->stream2);
+        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); } catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
+        std::swap(ctx->stream, ctx->stream2);
+        build_sketch_tables_finish(ctx, ss, tb);
     });
     ctx->arena.reset();
     if (rc != SKH_OK) { delete ss; return rc; }

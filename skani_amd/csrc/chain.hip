@@ -106,61 +106,30 @@ static uint32_t* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::ve
     return d_slots;
 }
 
-void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
-                 const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats) {
-    if (n_pairs_all == 0) return;
-    if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
-    if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
-    if (n_qsets == 0 || !Qsets[0]) throw std::invalid_argument("no query sketch set");
-    const uint32_t c = Qsets[0]->params.c, k = Qsets[0]->params.k;
-    for (uint32_t x = 0; x < n_rsets; x++)
-        if (!Rsets[x] || Rsets[x]->params.c != c || Rsets[x]->params.k != k) throw std::invalid_argument("ref and query sketches were built with different c/k");
-    for (uint32_t x = 0; x < n_qsets; x++)
-        if (!Qsets[x] || Qsets[x]->params.c != c || Qsets[x]->params.k != k) throw std::invalid_argument("ref and query sketches were built with different c/k");
-    const uint32_t band = BP_CHAIN_BAND / c;                                        // chain.rs:111-112 index_chain_band (ref sketch's c)
-    if (band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
+namespace {
+
+struct ChainJob {                                        // what one run over a list of pairs needs (chain_pairs fills it)
+    std::vector<PairDesc> pds; std::vector<uint32_t> chunk_bound, pair_key;
+    std::vector<const uint32_t*> host_go_a, host_go_b;   // only with stats
+    uint32_t c = 0, k = 0, band = 0;
     const GbdtModel* model = nullptr;
-    if (mp.learned_ani) {
-        model = std::abs((int)c - 125) < std::abs((int)c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22
-        if (!model->loaded()) throw std::invalid_argument("learned_ani requested but skh_load_models was not called");
-    }
-    const uint32_t NP = (uint32_t)n_pairs_all;
+    skh_map_params mp{};
+};
+
+// Runs the chaining pipeline over all pairs of the job.
+void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats* stats) {
+    // (A join that walks all tiles of a pair in one workgroup and writes the anchors in one pass -- no probe records, no pair counts on the host -- was
+    //  built and measured in round 2: 4.7 ms against 3.4 ms for count + fill; long-lived workgroups hide the probe latency worse.  DESIGN.md section 5.)
+    std::vector<PairDesc>& pds = job.pds;
+    const uint32_t NP = (uint32_t)pds.size(), band = job.band, c = job.c, k = job.k;
+    const GbdtModel* model = job.model; const skh_map_params& mp = job.mp;
     StageTrace tr(ctx);
-    // ---- pair descriptors and join tiles
-    std::vector<PairDesc> pds(NP); uint64_t n_tiles_all = 0;
-    std::vector<uint32_t> chunk_bound(NP), pair_key(NP);
-    std::vector<const uint32_t*> host_go_a(stats ? NP : 0), host_go_b(stats ? NP : 0);
+    uint64_t n_tiles_all = 0;
     for (uint32_t p = 0; p < NP; p++) {
-        const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
-        if (rs >= n_rsets || qs >= n_qsets) throw std::invalid_argument("pair names a sketch set that was not passed");
-        const skh_sketch_set* R = Rsets[rs]; const skh_sketch_set* Q = Qsets[qs];
-        const uint32_t r = pair_ref[p], q = pair_query[p];
-        if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
-        PairDesc& pd = pds[p];
-        const bool empty = R->ctg_off[r + 1] == R->ctg_off[r] || Q->ctg_off[q + 1] == Q->ctg_off[q];   // chain.rs:618-620
-        const bool sw = is_switched(R, r, Q, q);
-        const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
-        const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
-        pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.a_hash = A->p_hash.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_rep = A->p_rep.p; pd.a_pos0 = (uint32_t)A->pos_off[ga];
-        pd.b_ms = B->ms.p + B->ms_off[gb]; pd.b_tab = B->tab.p + B->tab_off[gb]; pd.b_nbk = B->n_buckets[gb];
-        pd.b_bmap = B->bmap.p + B->bmap_off[gb];
-        pd.flags = sw ? 4u : 0u;
-        pd.tile0 = (uint32_t)n_tiles_all;
-        pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
-        pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
-        pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
-        pd.a_goff = A->d_goff.p + A->ctg_off[ga] + ga; pd.b_goff = B->d_goff.p + B->ctg_off[gb] + gb;
-        pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
-        if (stats) { host_go_a[p] = A->goff.data() + A->ctg_off[ga] + ga; host_go_b[p] = B->goff.data() + B->ctg_off[gb] + gb; }
-        n_tiles_all += (pd.a_n + JOIN_TILE - 1) / JOIN_TILE;
+        pds[p].tile0 = (uint32_t)n_tiles_all;
+        n_tiles_all += (pds[p].a_n + JOIN_TILE - 1) / JOIN_TILE;
         if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
-        pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                            // tiles probing the same sketch share an XCD
-        // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
-        chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
     }
-    tr.mark("host: pair descriptors");
     const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = upload(ctx, pds);
     uint32_t* d_tile_pair = ctx->arena.get<uint32_t>((size_t)NT + 1);
@@ -173,12 +142,12 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
     const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~30 B of scratch each)
-    const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (6 KiB of probe records each)
+    const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (4 KiB of probe records each)
     auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
     std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
     uint32_t sp0 = 0;
     while (sp0 < NP) {
-        // ---- super-batch: pairs [sp0, sp1) = tiles [st0, st1); count pass records one probe result per position
+        // ---- super-batch: pairs [sp0, sp1) = tiles [st0, st1); the count pass records one probe result per position
         uint32_t sp1 = sp0;
         while (sp1 < NP && (sp1 == sp0 || (sp1 + 1 < NP ? pds[sp1 + 1].tile0 : NT) - pds[sp0].tile0 <= SUPER_TILES)) sp1++;
         const uint32_t st0 = pds[sp0].tile0, st1 = sp1 < NP ? pds[sp1].tile0 : NT, snt = st1 - st0;
@@ -188,19 +157,19 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
         uint32_t* pis = pinfo - (size_t)st0 * JOIN_TILE; unsigned long long* imk = inq_mask - (size_t)st0 * (JOIN_TILE / 64);
         uint32_t* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
+        uint32_t bm_words = 0;                                                     // LDS for the largest bitmap of the batch, up to 32 KB
+        for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
+        if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the table directly
         if (snt) {
-            uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, pair_key, &n_super_slots);
+            uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, job.pair_key, &n_super_slots);
             d_super_slots = d_slots;
-            uint32_t bm_words = 0;                                                 // LDS for the largest bitmap of the batch, up to 32 KB
-            for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
-            if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the table directly
             SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, band, tile_anch, d_pair_anch, d_pair_inq, pis, imk, bm_words);
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");
         d2h(pair_anch.data() + sp0, d_pair_anch + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
-        d2h(pair_inq.data() + sp0, d_pair_inq + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
+        if (stats) d2h(pair_inq.data() + sp0, d_pair_inq + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
         tr.mark("d2h pair counts");
         uint32_t p0 = sp0;
         while (p0 < sp1) {
@@ -209,26 +178,27 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         const uint32_t np = p1 - p0;
         const std::vector<size_t> arena_mark = ctx->arena.mark();
         if (na >= 0xFFFFFFF0ull) throw Error("a single genome pair produces more than 2^32 anchors");
-        // per-pair prefix arrays (batch-relative)
+        // per-pair prefix arrays (batch-relative): anchors, chunks, candidate intervals, global sort scratch of the fallback selection kernel
         std::vector<uint32_t> pa0(np + 1, 0), pc0(np + 1, 0), pi0(np + 1, 0), ps0(np + 1, 0);
         for (uint32_t i = 0; i < np; i++) {
-            pa0[i + 1] = pa0[i] + pair_anch[p0 + i];
-            pc0[i + 1] = pc0[i] + (pair_anch[p0 + i] ? std::min(chunk_bound[p0 + i], pair_anch[p0 + i]) : 0);
-            const uint32_t icap = pair_anch[p0 + i] / MIN_ANCHORS;
-            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);   // fallback kernel's global sort scratch
+            const uint32_t an = pair_anch[p0 + i];
+            pa0[i + 1] = pa0[i] + an;
+            pc0[i + 1] = pc0[i] + (an ? std::min(job.chunk_bound[p0 + i], an) : 0);
+            const uint32_t icap = an / MIN_ANCHORS;
+            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
         }
         const uint32_t NA = pa0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
         const PairDesc* d_pairs = d_pairs_all + p0;
         uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pc0 = upload(ctx, pc0);
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
+        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
         uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1);
         exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
         tr.mark("host prefix + uploads + scans");
-        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
         if (nt) {
             uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
-            if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, pair_key, &n_slots);
+            if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
             SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
                        (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)pis, anc_q, anc_r);
             check_launch("join_fill");
@@ -236,7 +206,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0,
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)(d_pair_anch + p0),
                    (const uint32_t*)d_pc0, (const uint32_t*)anc_q, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         tr.mark("chunk");
@@ -320,9 +290,10 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             d2h(hanc.data(), anc_q, (uint64_t)NA * 4, ctx->stream); d2h(hanr.data(), anc_r, (uint64_t)NA * 4, ctx->stream);
             for (uint32_t i = 0; i < np; i++) {
                 skh_chain_stats& st = stats[p0 + i];
+                const uint32_t an = std::min(pair_anch[p0 + i], pa0[i + 1] - pa0[i]);
                 st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
                 st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
-                st.anchor_checksum = pair_anch[p0 + i] ? fnv_anchors(hanc, hanr, pa0[i], pa0[i + 1], host_go_a[p0 + i], pds[p0 + i].a_nctg, host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
+                st.anchor_checksum = an ? fnv_anchors(hanc, hanr, pa0[i], pa0[i] + an, job.host_go_a[p0 + i], pds[p0 + i].a_nctg, job.host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
                 if (pair_anch[p0 + i] == 0) { st.switched = 1; st.n_qpos = 0; }   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
@@ -338,6 +309,63 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     d2h(out, d_out, (uint64_t)NP * sizeof(skh_ani_result), ctx->stream);
     tr.mark("results d2h");
     if (h_err) throw Error("internal capacity bound violated in chain pipeline (" + std::to_string(h_err) + " events)");
+}
+
+}  // namespace
+
+void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
+                 const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out,
+                 skh_chain_stats* stats) {
+    if (n_pairs_all == 0) return;
+    if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
+    if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
+    if (n_qsets == 0 || !Qsets[0]) throw std::invalid_argument("no query sketch set");
+    ChainJob job;
+    job.c = Qsets[0]->params.c; job.k = Qsets[0]->params.k; job.mp = mp;
+    for (uint32_t x = 0; x < n_rsets; x++)
+        if (!Rsets[x] || Rsets[x]->params.c != job.c || Rsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    for (uint32_t x = 0; x < n_qsets; x++)
+        if (!Qsets[x] || Qsets[x]->params.c != job.c || Qsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    job.band = BP_CHAIN_BAND / job.c;                                               // chain.rs:111-112 index_chain_band (ref sketch's c)
+    if (job.band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
+    if (mp.learned_ani) {
+        job.model = std::abs((int)job.c - 125) < std::abs((int)job.c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22
+        if (!job.model->loaded()) throw std::invalid_argument("learned_ani requested but skh_load_models was not called");
+    }
+    const uint32_t NP = (uint32_t)n_pairs_all;
+    StageTrace tr(ctx);
+    // ---- pair descriptors
+    job.pds.resize(NP); job.chunk_bound.resize(NP); job.pair_key.resize(NP);
+    if (stats) { job.host_go_a.resize(NP); job.host_go_b.resize(NP); }
+    for (uint32_t p = 0; p < NP; p++) {
+        const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
+        if (rs >= n_rsets || qs >= n_qsets) throw std::invalid_argument("pair names a sketch set that was not passed");
+        const skh_sketch_set* R = Rsets[rs]; const skh_sketch_set* Q = Qsets[qs];
+        const uint32_t r = pair_ref[p], q = pair_query[p];
+        if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
+        PairDesc& pd = job.pds[p];
+        const bool empty = R->ctg_off[r + 1] == R->ctg_off[r] || Q->ctg_off[q + 1] == Q->ctg_off[q];   // chain.rs:618-620
+        const bool sw = is_switched(R, r, Q, q);
+        const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
+        const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
+        pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
+        pd.a_hash = A->p_hash.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_rep = A->p_rep.p; pd.a_pos0 = (uint32_t)A->pos_off[ga];
+        pd.b_ms = B->ms.p + B->ms_off[gb]; pd.b_tab = B->tab.p + B->tab_off[gb]; pd.b_nbk = B->n_buckets[gb];
+        pd.b_bmap = B->bmap.p + B->bmap_off[gb];
+        pd.flags = sw ? 4u : 0u;
+        pd.tile0 = 0;
+        pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
+        pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
+        pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
+        pd.a_goff = A->d_goff.p + A->ctg_off[ga] + ga; pd.b_goff = B->d_goff.p + B->ctg_off[gb] + gb;
+        pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
+        if (stats) { job.host_go_a[p] = A->goff.data() + A->ctg_off[ga] + ga; job.host_go_b[p] = B->goff.data() + B->ctg_off[gb] + gb; }
+        job.pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                        // tiles probing the same sketch share an XCD
+        // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
+        job.chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
+    }
+    tr.mark("host: pair descriptors");
+    chain_run(ctx, job, out, stats);
 }
 
 }  // namespace skh

@@ -35,14 +35,16 @@ __device__ __forceinline__ void narrow_by_samples(const uint32_t* samp, uint32_t
     if (a < t1) { const uint32_t t = org + a * CHUNK_SAMPLE; hi = t < hi ? t : hi; }               // sample a holds: the answer is at or before it
 }
 
-__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0,
+__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0, const uint32_t* pan,
                                                     const uint32_t* pc0, const uint32_t* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
     __shared__ uint32_t lds_samp[4][2][CHUNK_SAMPLES];
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();
-    const uint32_t A0 = pa0[p], A1 = pa0[p + 1], C0 = pc0[p], C1 = pc0[p + 1];
+    // the pair's anchors: pan[p] of them from pa0[p] on (its stretch of the batch arrays may be longer; a pair that overflowed its stretch is
+    // re-run by the host, here it is merely kept inside it)
+    const uint32_t A0 = pa0[p], A1 = A0 + (pan[p] < pa0[p + 1] - A0 ? pan[p] : pa0[p + 1] - A0), C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
         const uint32_t* go = pairs[p].a_goff;

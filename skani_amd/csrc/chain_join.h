@@ -6,6 +6,51 @@
 // Workgroups are launched in "slots": slot b runs logical tile slot_tile[b] (or nothing).  The host interleaves the
 // tiles so that all tiles probing the same sketch B land on the same XCD (block b -> XCD b % 8 on MI355X): B's hash
 // table and seed-order arrays then stay in that XCD's 4 MiB L2 instead of being fetched by all eight.
+// Probes of one tile: R positions per thread.  Everything that can be in flight together is: the R home-slot loads, then the cluster walks in
+// lockstep (one more load for every probe that still needs one, as long as any lane of the wave does), then the list heads of the few long lists.
+// On return: rec[r] = the slot's payload (TAB_REPETITIVE: no anchors), n_anch[r] = anchors of the position, inq[r] = listed in query_positions_all.
+template <int R>
+__device__ __forceinline__ void probe_tile(const PairDesc& pd, const uint32_t* bm, bool use_bm, const uint32_t (&h)[R], const bool (&live)[R],
+                                           uint32_t (&rec)[R], uint32_t (&n_anch)[R], uint32_t (&inq)[R]) {
+    const uint64_t* tab = pd.b_tab;
+    uint32_t sl[R]; unsigned long long e[R]; bool more[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        sl[r] = 0; e[r] = TAB_EMPTY;
+        if (live[r]) {
+            const uint32_t b = seed_bucket(h[r], pd.b_nbk);
+            sl[r] = tab_slot(b);
+            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) e[r] = tab[sl[r]];
+        }
+    }
+    // a cluster ascends by hash from the home slot on; TAB_EMPTY (all ones; the slack slots behind every slice end with one) ends every walk
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) { more[r] = (uint32_t)(e[r] >> 32) < h[r]; any = any || more[r]; }
+    while (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) if (more[r]) e[r] = tab[++sl[r]];
+        any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) { more[r] = more[r] && (uint32_t)(e[r] >> 32) < h[r]; any = any || more[r]; }
+    }
+    uint32_t head[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        rec[r] = TAB_REPETITIVE; n_anch[r] = 0; inq[r] = 0; head[r] = 0;
+        if (!live[r]) continue;
+        const unsigned long long x = e[r];
+        if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) { inq[r] = 1; continue; }   // absent in B: chain.rs:682-685
+        const uint32_t xl = (uint32_t)x;
+        if (xl == TAB_REPETITIVE) continue;                                            // chain.rs:694-696: dropped entirely
+        inq[r] = 1; rec[r] = xl;
+        const uint32_t code = tab_list_code(xl);
+        if (!(xl & TAB_LISTED)) n_anch[r] = 1u; else if (code) n_anch[r] = code + 1u; else head[r] = 1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) if (head[r]) n_anch[r] = pd.b_ms[rec[r] & TAB_OFF_MASK];   // long lists (more than four positions): the count heads the list
+}
+
 __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, const uint32_t* slot_tile, const uint32_t* tile_pair,
                                                          uint32_t band, uint32_t* tile_anch, uint32_t* pair_anch, uint32_t* pair_inq,
                                                          uint32_t* pinfo, unsigned long long* inq_mask, uint32_t lds_words) {
@@ -17,7 +62,6 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     const uint32_t p = tile_pair[tile];
     const PairDesc pd = pairs[p];
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
-    const uint64_t* tab = pd.b_tab;
     constexpr int R = JOIN_TILE / 256;
     // B's bucket-occupancy bitmap (1 bit per home slot of its seed table, ~10 KB) is staged in LDS with coalesced 16-byte loads: 61 % of
     // the buckets are nobody's home, and a probe of one costs no memory request at all; the others read their home slot -- the entry
@@ -31,7 +75,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
         __syncthreads();
     }
     // the four positions of this thread are probed together: their loads are independent, so they overlap
-    uint32_t h[R], sl[R]; bool live[R]; unsigned long long e[R];
+    uint32_t h[R]; bool live[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t i = start + r * 256 + threadIdx.x;
@@ -41,40 +85,18 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
         h[r] = live[r] ? pd.a_hash[i] : 0u;
         live[r] = live[r] && !rep;                                                 // chain.rs:674-676: more than `band` positions in A
     }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        sl[r] = 0; e[r] = TAB_EMPTY;
-        if (live[r]) {
-            const uint32_t b = seed_bucket(h[r], pd.b_nbk);
-            sl[r] = tab_slot(b);
-            if (!use_bm || ((bm[b >> 5] >> (b & 31u)) & 1u)) e[r] = tab[sl[r]];
-        }
-    }
+    uint32_t rec[R], n_anch[R], inq[R];
+    probe_tile<R>(pd, bm, use_bm, h, live, rec, n_anch, inq);
     uint32_t na = 0, nq = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t o = r * 256 + threadIdx.x, i = start + o;
-        uint32_t n_anch = 0, inq = 0, rec = TAB_REPETITIVE;
-        if (live[r]) {
-            unsigned long long x = e[r]; uint32_t dd = sl[r];
-            // a cluster ascends by hash from the home slot on; TAB_EMPTY (all ones; the slack slots behind every slice end with one) ends every walk
-            while ((uint32_t)(x >> 32) < h[r]) x = tab[++dd];
-            if (x == TAB_EMPTY || (uint32_t)(x >> 32) != h[r]) inq = 1;            // absent in B: chain.rs:682-685
-            else {
-                const uint32_t xl = (uint32_t)x;
-                if (xl != TAB_REPETITIVE) {                                          // else chain.rs:694-696: dropped entirely
-                    inq = 1; rec = xl;
-                    const uint32_t code = tab_list_code(xl);
-                    n_anch = !(xl & TAB_LISTED) ? 1u : (code ? code + 1u : pd.b_ms[xl & TAB_OFF_MASK]);   // long lists: the count heads the list
-                }
-            }
-        }
         // probe record = the slot's payload (B's position itself, or the reference to the seed's position list; TAB_REPETITIVE = no anchors); and
         // one bit per position: "listed in query_positions_all" (chain.rs:682-700), 64 positions per word straight from the ballot
-        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = rec;
-        const unsigned long long m = __ballot(inq != 0);
+        if (i < pd.a_n) pinfo[(uint64_t)tile * JOIN_TILE + o] = rec[r];
+        const unsigned long long m = __ballot(inq[r] != 0);
         if ((threadIdx.x & 63) == 0) inq_mask[(uint64_t)tile * (JOIN_TILE / 64) + (o >> 6)] = m;
-        na += n_anch; nq += inq;
+        na += n_anch[r]; nq += inq[r];
     }
     na = wave_sum(na); nq = wave_sum(nq);
     const uint32_t w = threadIdx.x >> 6;
@@ -140,3 +162,4 @@ __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, c
         run_a += ta;
     }
 }
+

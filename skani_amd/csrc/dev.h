@@ -40,6 +40,7 @@ inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
 inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
 inline void dsync(devStream_t) {}
 inline void check_launch(const char*) {}
+inline int hipDeviceSynchronizeCompat() { return 0; }
 #else
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
@@ -57,6 +58,7 @@ inline void dzero(void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemset
 inline void dfill(void* d, int byte, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, byte, n, s), "memset"); }
 inline void dsync(devStream_t s) { hip_check(hipStreamSynchronize(s), "stream sync"); }
 inline void check_launch(const char* what) { hip_check(hipGetLastError(), what); }
+inline int hipDeviceSynchronizeCompat() { return (int)hipDeviceSynchronize(); }
 #endif
 
 // RAII device buffer

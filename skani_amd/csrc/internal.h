@@ -66,6 +66,7 @@ struct skh_ctx {
     skh_tunables tune;
     int device = 0;
     devStream_t stream{};
+    devStream_t stream2{};                               // second queue: the marker sets are built there while the seed tables are built on `stream`
     std::string err;
     skh::Arena arena;
     skh::GbdtModel model_c125, model_c200;
@@ -188,6 +189,9 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 // needs p_seed, pos_off, contig tables (finalize_metadata) filled, and either p_g (pos == cc == null) or pos / cc = device
 // arrays of (position in contig, contig << 1 | canonical) in position order, which are converted into p_g
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
+struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                    // a table build that is queued but not yet waited for
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
+void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);

@@ -273,6 +273,12 @@ void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint6
 }
 
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
+    TableBuild tb = build_sketch_tables_begin(ctx, ss, pos, cc);
+    build_sketch_tables_finish(ctx, ss, tb);
+}
+
+// queues the whole table build on the context's stream and returns without waiting; _finish reads the counts back
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
@@ -313,7 +319,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     }
     ss->tab.alloc(ss->tab_off[ng] ? ss->tab_off[ng] : 1); ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
     ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
-    std::vector<uint32_t> back(2 * (size_t)ng + 1, 0);                               // err, distinct seeds per genome, list words used per genome
+    TableBuild tb; tb.n = 2 * (size_t)ng + 1;                                        // err, distinct seeds per genome, list words used per genome
     if (ng) {
         size_t mx = 0; for (auto& q : blocks) mx = std::max(mx, q.size());
         std::vector<uint2> blk(mx * 8, make_uint2(0xFFFFFFFFu, 0));
@@ -322,7 +328,8 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
         uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_mo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_mo, ss->ms_off.data(), (ng + 1) * 8, ctx->stream);
-        uint32_t* d_back = ctx->arena.get<uint32_t>(back.size()); dzero(d_back, back.size() * 4, ctx->stream);
+        uint32_t* d_back = ctx->arena.get<uint32_t>(tb.n); dzero(d_back, tb.n * 4, ctx->stream);
+        tb.d_back = d_back;
         dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
         // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
@@ -338,11 +345,17 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
                        BP_CHAIN_BAND / ss->params.c, match_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
             check_launch("build_tables");
         }
-        d2h(back.data(), d_back, back.size() * 4, ctx->stream);                       // the build's one read-back (synchronises)
     }
+    tr.mark("build: seed tables queued");
+    return tb;
+}
+
+void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb) {
+    const uint32_t ng = ss->n_genomes;
+    std::vector<uint32_t> back(tb.n, 0);
+    if (tb.d_back) d2h(back.data(), tb.d_back, tb.n * 4, ctx->stream);               // the build's one read-back (synchronises)
+    else dsync(ctx->stream);
     for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + back[1 + g];
-    tr.mark("build: seed tables");
-    dsync(ctx->stream);
     if (back[0]) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range");
 }
 

@@ -1,9 +1,13 @@
 """GPU parity tests proper: the HIP path (libskani_hip.so through the C ABI) against the CPU oracle and the
 reference's golden vectors, on an MI355X.  `python -m pytest tests -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
 import skani_amd as sk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from tests import parity_cases as pc
 from tests.helpers import mutate, ora, random_genome
 
