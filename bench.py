@@ -336,14 +336,14 @@ def main():
     achieved = bytes_per_launch / (seed_ms_per_launch * 1e-3) / 1e9 if seed_ms_per_launch > 0 else 0.0
     # counters that were measured offline (separate rocprofv3 --pmc passes) are only quoted while the kernel source they were measured on is unchanged
     seed_src_sha = file_sha(os.path.join(ROOT, "skani_amd", "csrc", "pack_seed.hip"))
-    traffic, traffic_note, valu = None, "no profiles/seed_traffic.json", None
+    traffic, traffic_note, valu, valu_waves = None, "no profiles/seed_traffic.json", None, None
     tpath = os.path.join(ROOT, "profiles", "seed_traffic.json")
     if os.path.exists(tpath) and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha256_16") == seed_src_sha:
                 traffic = tj.get("hbm_bytes_per_launch"); traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s (%s)" % (tj.get("commit"), tj.get("source"))
-                valu = tj.get("valu")
+                valu = tj.get("valu"); valu_waves = tj.get("waves_per_launch")
             else:
                 traffic_note = "profiles/seed_traffic.json was measured on another version of pack_seed.hip (%s, now %s): not quoted" % (tj.get("kernel_source_sha256_16"), seed_src_sha)
         except Exception as e:
@@ -358,7 +358,7 @@ def main():
         # VALU issue cycles the kernel's instructions need (static count per wave x measured cycles per instruction class, tools/isa_mix.py) over the
         # SIMD cycles its launch had: 1024 SIMDs x shader clock x kernel time
         simd_cycles = 1024 * valu["clock_ghz"] * 1e9 * seed_ms_per_launch * 1e-3
-        waves = total_bases_local / 8192.0 * 4.0                        # one workgroup of 4 waves per 8192 windows (lower bound: tiles are per contig)
+        waves = valu_waves or total_bases_local / 8192.0 * 4.0          # SQ_WAVES of the launch (else: one workgroup of 4 waves per 8192 windows)
         roof["valu_frac"] = waves * valu["issue_cycles_per_wave"] / simd_cycles
         roof["valu"] = valu
     out = {

@@ -308,7 +308,11 @@ def fastx_to_multiple_sketch_rewrite(ctx, files, params):
         for n, s in read_fasta(f):
             if len(s) >= MIN_LENGTH_CONTIG:
                 genomes.append([(n, s)]); names.append(f)
-    ss = ctx.sketch_records(genomes, params, None)     # rank = position in the sorted order (same file name => contig order)
+    # the file name of every per-contig sketch goes into the set (skh_sketch_set_names): contigs of ONE file tie on it in switch_qr (chain.rs:20-22,
+    # query_file_name > ref_file_name is false for equal names); rank = position in the (file, contig) order for sets without names
+    ss = ctx.sketch_records(genomes, params, None)
+    arr = (C.c_char_p * len(names))(*[str(n).encode() for n in names])
+    ctx.check(ctx.L.skh_sketch_set_names(ss.h, arr))
     ss.names = names
     return ss
 

@@ -239,8 +239,9 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 unsigned long long* best = ctx->arena.get<unsigned long long>((size_t)NA + 64);
                 dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
                 const unsigned gb = (NC + 3) / 4;
-#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)anc_q, (const uint32_t*)anc_r, best)
-                if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else SKH_DP(4);
+                uint32_t* dp_state = band > 256 ? ctx->arena.get<uint32_t>(3 * (size_t)NA + 4) : nullptr;   // c < 10: earlier anchors' state goes through memory
+#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)anc_q, (const uint32_t*)anc_r, best, dp_state)
+                if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else if (band <= 256) SKH_DP(4); else SKH_DP(0);
 #undef SKH_DP
                 check_launch("chain_dp");
                 SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const unsigned long long*)best,
@@ -327,7 +328,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     for (uint32_t x = 0; x < n_qsets; x++)
         if (!Qsets[x] || Qsets[x]->params.c != job.c || Qsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
     job.band = BP_CHAIN_BAND / job.c;                                               // chain.rs:111-112 index_chain_band (ref sketch's c)
-    if (job.band > 256) throw std::invalid_argument("c < 10 (chain band > 256) is not supported by the GPU chaining kernel");
     if (mp.learned_ani) {
         job.model = std::abs((int)job.c - 125) < std::abs((int)job.c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22
         if (!job.model->loaded()) throw std::invalid_argument("learned_ani requested but skh_load_models was not called");

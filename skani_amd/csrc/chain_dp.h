@@ -8,16 +8,19 @@
 // All values are integers (positions, 20, gap) => int32 is exact where the reference uses f64.
 struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
 
+// PB = number of earlier 64-anchor blocks kept in registers (band <= 64 PB).  PB = 0: any band (c < 10: up to 2500 anchors) -- the state of earlier
+// anchors (score, root, depth) goes through a per-anchor record array in memory instead; read past the L1, the same wave wrote it a block ago.
 template <int PB>
-__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* anc_q, const uint32_t* anc_r, unsigned long long* best) {
+__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* anc_q, const uint32_t* anc_r, unsigned long long* best,
+                                                       uint32_t* st /* PB == 0: 3 words per anchor */) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
     if (ck.a_end <= ck.a_begin) return;
     const int l = (int)lane_id();
-    Blk prev[PB];
+    Blk prev[PB > 0 ? PB : 1];
 #pragma unroll
-    for (int b = 0; b < PB; b++) prev[b] = Blk{0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < (PB > 0 ? PB : 1); b++) prev[b] = Blk{0, 0, 0, 0, 0, 0};
     for (uint32_t base = ck.a_begin; base < ck.a_end; base += 64) {
         const uint32_t t = base + (uint32_t)l;
         const bool valid = t < ck.a_end;
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
                 uint32_t rootj = j, depthj = 1;
                 if (pj != j) {
                     if (pj >= base) { rootj = wave_readlane(cur.root, (int)(pj - base)); depthj = wave_readlane(cur.depth, (int)(pj - base)) + 1; }
+                    else if (PB == 0) { rootj = __atomic_load_n(&st[3 * (size_t)pj + 1], __ATOMIC_RELAXED); depthj = __atomic_load_n(&st[3 * (size_t)pj + 2], __ATOMIC_RELAXED) + 1; }
                     else {
 #pragma unroll
                         for (int b = 0; b < PB; b++) {
@@ -54,6 +58,9 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
                 }
                 if (l == ln) { cur.root = rootj; cur.depth = depthj; }
                 qj = wave_readlane(cur.q, ln); rj = wave_readlane(cur.r, ln); crj = wave_readlane(cur.cr, ln); sj = wave_readlane(cur.score, ln);
+            } else if (PB == 0) {
+                const uint32_t rr = anc_r[j];
+                qj = anc_q[j]; rj = rr >> 1; crj = rr & 1u; sj = (int32_t)__atomic_load_n(&st[3 * (size_t)j], __ATOMIC_RELAXED);
             } else {
                 qj = rj = crj = 0; sj = 0;
 #pragma unroll
@@ -81,6 +88,10 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
             }
         }
         if (valid) atomicMax(&best[cur.root], best_payload((uint32_t)cur.score, t - ck.a_begin, cur.depth));   // chain.rs:952-964
+        if (PB == 0) {
+            if (valid) { __atomic_store_n(&st[3 * (size_t)t], (uint32_t)cur.score, __ATOMIC_RELAXED); __atomic_store_n(&st[3 * (size_t)t + 1], cur.root, __ATOMIC_RELAXED); __atomic_store_n(&st[3 * (size_t)t + 2], cur.depth, __ATOMIC_RELAXED); }
+            wave_sync_mem();
+        }
 #pragma unroll
         for (int b = PB - 1; b > 0; b--) prev[b] = prev[b - 1];
         prev[0] = cur;

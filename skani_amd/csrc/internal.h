@@ -71,6 +71,7 @@ struct skh_ctx {
     skh::Arena arena;
     skh::GbdtModel model_c125, model_c200;
     skh_timings timings{};
+    bool screen_planes_checked = false;                  // the per-XCD count planes of the triangle screen passed their self-test (screen.hip)
 };
 
 namespace skh { struct Transport; }

@@ -48,6 +48,15 @@ __device__ __forceinline__ void count_local(uint32_t* p) {
     __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
+// Self-test of the per-XCD planes, run once per context before they are used: 512 workgroups add into 64 counters of "their" plane with the same
+// XCD-local atomic; the planes must add up to exactly the number of increments.  The HIP memory model does not promise that workgroup-scope
+// atomics of different workgroups see each other -- on gfx950 they do, because an XCD performs them in its one L2 -- so the planes are only used
+// after this hardware / driver / partition mode has shown that it behaves that way (otherwise: one device-scope plane).
+__global__ __launch_bounds__(256) void screen_planes_selftest_kernel(uint32_t* cnt, uint32_t n_planes) {
+    uint32_t* plane = cnt + (size_t)(xcc_id() % n_planes) * 64;
+    for (uint32_t r = 0; r < 4; r++) count_local(&plane[(threadIdx.x + r) & 63u]);
+}
+
 __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
                                                                uint32_t* cnt, uint32_t n_planes, uint64_t plane) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,6 +193,17 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     // triangle: one plane of counters per XCD while that stays small (8 x 4 MB for 1000 genomes); the two-set screen of a large database
     // keeps the single device-scope plane
     const uint64_t plane = (uint64_t)rows_per * ncols;
+    if (tri && ctx->tune.screen_planes > 1 && !ctx->screen_planes_checked) {
+        const uint32_t np = std::min<uint32_t>(ctx->tune.screen_planes, 8u), blocks = 512;
+        uint32_t* d = ctx->arena.get<uint32_t>((size_t)np * 64); dzero(d, (size_t)np * 64 * 4, ctx->stream);
+        SKH_LAUNCH(screen_planes_selftest_kernel, blocks, 256, 0, ctx->stream, d, np);
+        check_launch("screen_planes_selftest");
+        std::vector<uint32_t> h((size_t)np * 64);
+        d2h(h.data(), d, h.size() * 4, ctx->stream);
+        uint64_t sum = 0; for (uint32_t v : h) sum += v;
+        if (sum != (uint64_t)blocks * 256 * 4) ctx->tune.screen_planes = 1;          // increments were lost: XCD-local atomics are not safe here
+        ctx->screen_planes_checked = true;
+    }
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (tri && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);

@@ -1,4 +1,4 @@
-// fastx.cpp -- FASTA(.gz) ingest with the record semantics of needletail as used by file_io.rs:158-181.
+// fastx.cpp -- FASTA / FASTQ (.gz) ingest with the record semantics of needletail as used by file_io.rs:158-181.
 #include <zlib.h>
 
 #include <algorithm>
@@ -33,7 +33,30 @@ std::vector<Record> read_fasta(const std::string& path) {
     size_t p = 0, n = data.size();
     while (p < n && (data[p] == '\n' || data[p] == '\r' || data[p] == ' ' || data[p] == '\t')) p++;
     if (p == n) return out;
-    if (data[p] != '>') throw std::runtime_error(path + " is not a valid fasta file");
+    if (data[p] == '@') {   // FASTQ (needletail's parse_fastx_file takes both, file_io.rs:158): @name / sequence line(s) / +[name] / quality of the same length
+        while (p < n) {
+            while (p < n && (data[p] == '\n' || data[p] == '\r')) p++;
+            if (p >= n) break;
+            if (data[p] != '@') throw std::runtime_error(path + " is not a valid fastq file");
+            size_t eol = data.find('\n', p); if (eol == std::string::npos) eol = n;
+            Record r; r.name = data.substr(p + 1, eol - p - 1);
+            while (!r.name.empty() && r.name.back() == '\r') r.name.pop_back();
+            p = eol < n ? eol + 1 : n;
+            while (p < n && data[p] != '+') {                                       // sequence lines up to the separator
+                eol = data.find('\n', p); if (eol == std::string::npos) eol = n;
+                for (size_t i = p; i < eol; i++) if (data[i] != '\r') r.seq.push_back(data[i]);
+                p = eol < n ? eol + 1 : n;
+            }
+            if (p >= n) throw std::runtime_error(path + " is a truncated fastq file");
+            eol = data.find('\n', p); p = eol == std::string::npos ? n : eol + 1;    // the '+' line
+            size_t q = 0;                                                           // quality: as many characters as the sequence has (may contain '@' and '+')
+            while (p < n && q < r.seq.size()) { if (data[p] != '\n' && data[p] != '\r') q++; p++; }
+            if (q < r.seq.size()) throw std::runtime_error(path + " is a truncated fastq file");
+            out.push_back(std::move(r));
+        }
+        return out;
+    }
+    if (data[p] != '>') throw std::runtime_error(path + " is not a valid fasta/fastq file");
     while (p < n) {
         size_t eol = data.find('\n', p);
         if (eol == std::string::npos) eol = n;

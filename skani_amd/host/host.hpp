@@ -60,7 +60,7 @@ struct SketchBlob {                                              // types.rs:252
     std::vector<std::string> contigs;
     uint64_t total_sequence_length = 0;
     std::vector<uint32_t> contig_lengths;
-    uint64_t repetitive_kmers = 0;                               // usize::MAX in every sketch skani writes (types.rs Default)
+    uint64_t repetitive_kmers = 0;                               // 0 in every sketch skani writes (types.rs Default)
     std::vector<uint64_t> markers;                               // ascending
     uint64_t marker_c = 0, c = 0, k = 0, contig_order = 0;
     bool individual_contig = false, amino_acid = false;

@@ -250,7 +250,7 @@ int run_dist(Args& a, Ctx& cx) {
     const bool learned = !a.no_learned && a.c >= 70 && !a.qi && !a.ri && !a.median;   // parse.rs:752-756
     skh_map_params mp = map_params(a, learned);
     const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:636
-    const bool index = q.size() > 50 || a.qi || a.marker_index;                 // parse.rs:750 (FULL_INDEX_THRESH)
+    const bool index = ((q.size() > 50 || a.qi) && !a.no_marker_index) || a.marker_index;   // parse.rs:750 (FULL_INDEX_THRESH; --marker-index: the pre-0.3 spelling forces it on)
     uint32_t *pq = nullptr, *prf = nullptr; uint64_t np = 0;
     cx.check(skh_screen(cx.c, sr, sq, a.s / 100., index ? SKH_SCREEN_REFS : SKH_SCREEN_QUICK, rescue_small, &pq, &prf, &np), "skh_screen");   // dist.rs:104-122
     std::vector<skh_ani_result> res(np);

@@ -36,6 +36,7 @@ def test_pinned_triples(ctx): pc.case_pinned_triples(ctx)
 def test_w_vs_w(ctx): pc.case_w_vs_w(ctx)
 def test_viruses(ctx): pc.case_viruses_individual(ctx)
 def test_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx)
+def test_triangle_dense_sketches(ctx): pc.case_triangle_synthetic(ctx, params=((1, 8), (0, 3)), length=60000)   # c < 10: chain band beyond 256 anchors
 def test_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)

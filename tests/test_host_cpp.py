@@ -42,6 +42,15 @@ def test_fasta_reader_matches_needletail_semantics(host, tmp_path):
     assert _take(host, host.skhost_fasta_seq(str(p).encode(), 0)) == "ACGTacgn"
     assert _take(host, host.skhost_fasta_summary(os.path.join(GOLDEN, "empty_fasta.fa").encode(), 0)) == "test\t0\ntest_1\t1\n"
     assert _take(host, host.skhost_fasta_summary(os.path.join(GOLDEN, "empty_fasta.fa").encode(), 500)) == ""
+    # FASTQ (needletail's parse_fastx_file takes both): four-line and wrapped records, quality lines that start with '@' or '+', gzip
+    fq = tmp_path / "r.fq"; fq.write_bytes(b"@r1 first\nACGTAC\n+\n@+IIII\n@r2\nGGCC\nTTAA\n+r2\n+III\nIIII\n")
+    assert _take(host, host.skhost_fasta_summary(str(fq).encode(), 0)) == "r1 first\t6\nr2\t8\n"
+    assert _take(host, host.skhost_fasta_seq(str(fq).encode(), 1)) == "GGCCTTAA"
+    import gzip
+    fqz = tmp_path / "r.fq.gz"; fqz.write_bytes(gzip.compress(fq.read_bytes()))
+    assert _take(host, host.skhost_fasta_summary(str(fqz).encode(), 0)) == "r1 first\t6\nr2\t8\n"
+    bad = tmp_path / "t.fq"; bad.write_bytes(b"@r1\nACGT\n+\nII")
+    assert _take(host, host.skhost_fasta_summary(str(bad).encode(), 0)).startswith("ERROR")
     q = tmp_path / "x.txt"; q.write_text("not fasta\n")
     assert _take(host, host.skhost_fasta_summary(str(q).encode(), 0)).startswith("ERROR")
 
