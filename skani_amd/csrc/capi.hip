@@ -360,13 +360,17 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
     if (!ctx || !ss || !mp || !out_i || !out_j || !out_res || !n_kept || n_parts == 0 || part >= n_parts) return SKH_ERR_INVALID;
     *out_i = *out_j = nullptr; *out_res = nullptr; *n_kept = 0;
     int rc = guarded(ctx, [&] {
+        StageTrace tr(ctx);
         std::vector<uint32_t> a, b;
         { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, ss, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b); }
         ctx->arena.reset();
+        tr.mark("triangle: screen");
         std::vector<uint32_t> pi, pj;
         for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
         std::vector<skh_ani_result> res(pi.size());
+        tr.mark("triangle: pair list");
         { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
+        tr.mark("triangle: chain");
         if (n_chained) *n_chained = pi.size();
         size_t kept = 0;
         for (auto& r : res) if (r.ani > 0.1f) kept++;                                                      // triangle.rs:99

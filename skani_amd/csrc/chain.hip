@@ -67,39 +67,32 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 
 }  // namespace
 
-// slot order for the join kernels: tiles grouped by (key % 8) and interleaved so that slot b (-> XCD b % 8) serves queue b % 8
-// Tables for the join kernels, written on the device from per-pair records: tile -> pair, and slot -> tile, where the tiles of
-// pairs [p0, p1) are dealt to eight queues by the probed sketch (queue = key % 8) and queue x owns slots x, x+8, x+16, ...
-// (-> XCD x).  The host only computes each pair's first position in its queue.
-__global__ __launch_bounds__(256) void tile_pair_kernel(uint32_t n_pairs, const PairDesc* pairs, uint32_t* tile_pair) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint32_t nt = (pairs[p].a_n + JOIN_TILE - 1) / JOIN_TILE, t0 = pairs[p].tile0;
-    for (uint32_t t = 0; t < nt; t++) tile_pair[t0 + t] = p;
-}
+// Slot table of the join kernels, written on the device from per-pair records: workgroup b runs the JOIN_GROUP tiles from (tile, pair) = slot[b] on; the tile groups of pairs
+// [p0, p1) are dealt to eight queues by the probed sketch (queue = key % 8) and queue x owns slots x, x + 8, x + 16, ... (-> XCD x on MI355X), so
+// all tiles probing one sketch run on the XCD whose L2 holds its table.  The host only computes each pair's first position in its queue.
 __global__ __launch_bounds__(256) void slot_tile_kernel(uint32_t p0, uint32_t p1, const PairDesc* pairs, const uint32_t* queue_pos /* (p1-p0): queue << 29 | first */,
-                                                        uint32_t* slot_tile) {
+                                                        uint2* slot_tile) {
     const uint32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= p1) return;
-    const uint32_t nt = (pairs[p].a_n + JOIN_TILE - 1) / JOIN_TILE, t0 = pairs[p].tile0, qp = queue_pos[p - p0];
+    const uint32_t nt = (pairs[p].a_n + JOIN_TILE - 1) / JOIN_TILE, ngr = (nt + JOIN_GROUP - 1) / JOIN_GROUP, t0 = pairs[p].tile0, qp = queue_pos[p - p0];
     const uint32_t x = qp >> 29, first = qp & 0x1FFFFFFFu;
-    for (uint32_t t = 0; t < nt; t++) slot_tile[(size_t)(first + t) * 8 + x] = t0 + t;
+    for (uint32_t t = 0; t < ngr; t++) slot_tile[(size_t)(first + t) * 8 + x] = make_uint2(t0 + t * JOIN_GROUP, p);
 }
 // returns the device slot table for pairs [p0, p1) and its length
-static uint32_t* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::vector<PairDesc>& pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
-                           unsigned* n_slots) {
+static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::vector<PairDesc>& pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
+                        unsigned* n_slots) {
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> qp(p1 - p0);
     for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t x = pair_key[p] & 7u, nt = (pds[p].a_n + JOIN_TILE - 1) / JOIN_TILE;
+        const uint32_t x = pair_key[p] & 7u, nt = ((pds[p].a_n + JOIN_TILE - 1) / JOIN_TILE + JOIN_GROUP - 1) / JOIN_GROUP;   // tile groups = workgroups
         if (cnt[x] + nt >= (1u << 29)) throw Error("too many join tiles in one batch");
         qp[p - p0] = (x << 29) | cnt[x]; cnt[x] += nt;
     }
     uint32_t mx = 0; for (uint32_t v : cnt) mx = std::max(mx, v);
     *n_slots = mx * 8;
-    uint32_t* d_slots = ctx->arena.get<uint32_t>((size_t)mx * 8 + 1);
+    uint2* d_slots = ctx->arena.get<uint2>((size_t)mx * 8 + 1);
     if (mx == 0) return d_slots;
-    dfill(d_slots, 0xFF, (size_t)mx * 8 * 4, ctx->stream);
+    dfill(d_slots, 0xFF, (size_t)mx * 8 * sizeof(uint2), ctx->stream);
     uint32_t* d_qp = ctx->arena.get<uint32_t>(qp.size()); h2d(d_qp, qp.data(), qp.size() * 4, ctx->stream);
     SKH_LAUNCH(slot_tile_kernel, (p1 - p0 + 255) / 256, 256, 0, ctx->stream, p0, p1, d_pairs_all, (const uint32_t*)d_qp, d_slots);
     check_launch("slot_tile");
@@ -132,17 +125,14 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     }
     const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = upload(ctx, pds);
-    uint32_t* d_tile_pair = ctx->arena.get<uint32_t>((size_t)NT + 1);
-    SKH_LAUNCH(tile_pair_kernel, (NP + 255) / 256, 256, 0, ctx->stream, NP, (const PairDesc*)d_pairs_all, d_tile_pair);
-    check_launch("tile_pair");
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
-    uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1);
+    uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_hits = ctx->arena.get<uint32_t>((size_t)NT + 1);
     uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
     dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
 
     const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~30 B of scratch each)
-    const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (4 KiB of probe records each)
+    const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (up to 8 KiB of hit records each)
     auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
     std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
     uint32_t sp0 = 0;
@@ -152,19 +142,19 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         while (sp1 < NP && (sp1 == sp0 || (sp1 + 1 < NP ? pds[sp1 + 1].tile0 : NT) - pds[sp0].tile0 <= SUPER_TILES)) sp1++;
         const uint32_t st0 = pds[sp0].tile0, st1 = sp1 < NP ? pds[sp1].tile0 : NT, snt = st1 - st0;
         const std::vector<size_t> super_mark = ctx->arena.mark();
-        uint32_t* pinfo = ctx->arena.get<uint32_t>((size_t)snt * JOIN_TILE + 1);
+        uint2* hit_rec = ctx->arena.get<uint2>((size_t)snt * JOIN_TILE + 1);          // a tile's hit records: up to one per position, written densely from the tile's start
         unsigned long long* inq_mask = ctx->arena.get<unsigned long long>((size_t)snt * (JOIN_TILE / 64) + 1);
         // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
-        uint32_t* pis = pinfo - (size_t)st0 * JOIN_TILE; unsigned long long* imk = inq_mask - (size_t)st0 * (JOIN_TILE / 64);
-        uint32_t* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
+        uint2* pis = hit_rec - (size_t)st0 * JOIN_TILE; unsigned long long* imk = inq_mask - (size_t)st0 * (JOIN_TILE / 64);
+        uint2* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         uint32_t bm_words = 0;                                                     // LDS for the largest bitmap of the batch, up to 32 KB
-        for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + 31) / 32 + 3) / 4 * 4);
+        for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES + 3) / 4 * 4);
         if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the table directly
         if (snt) {
-            uint32_t* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, job.pair_key, &n_super_slots);
+            uint2* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, job.pair_key, &n_super_slots);
             d_super_slots = d_slots;
-            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
-                       (const uint32_t*)d_tile_pair, band, tile_anch, d_pair_anch, d_pair_inq, pis, imk, bm_words);
+            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
+                       band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words);
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");
@@ -197,10 +187,10 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
         tr.mark("host prefix + uploads + scans");
         if (nt) {
-            uint32_t* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
+            uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
             if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
-            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint32_t*)d_slots,
-                       (const uint32_t*)d_tile_pair, t0, (const uint32_t*)toff_a, (const uint32_t*)pis, anc_q, anc_r);
+            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
+                       t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q, anc_r);
             check_launch("join_fill");
         }
         tr.mark("join_fill (+slots)");

@@ -23,7 +23,8 @@ struct PairDesc {
     float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
 };
 
-constexpr uint32_t JOIN_TILE = 1024;    // positions per join workgroup (256 threads x 4 rounds)
+constexpr uint32_t JOIN_TILE = 1024;    // positions per join tile (one wave: 4 rounds x 4 probes per lane)
+constexpr uint32_t JOIN_GROUP = 4;      // tiles per join workgroup (one wave each)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // An anchor is 8 bytes in two arrays: anc_q = padded query coordinate, anc_r = padded ref coordinate << 1 | reverse_match

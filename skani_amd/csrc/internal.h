@@ -148,11 +148,11 @@ Transport* make_host_transport(const skh_host_collectives* hc, int rank, int wor
 
 // SKH_TRACE=1: host wall-clock per stage of the host drivers on stderr (each mark synchronises the stream; diagnosis only)
 struct StageTrace {
-    skh_ctx* ctx; bool on; std::chrono::steady_clock::time_point t;
-    explicit StageTrace(skh_ctx* c) : ctx(c) { const char* v = getenv("SKH_TRACE"); on = v && *v == '1'; t = std::chrono::steady_clock::now(); }
-    void mark(const char* what) {
+    skh_ctx* ctx; bool on, sync; std::chrono::steady_clock::time_point t;
+    explicit StageTrace(skh_ctx* c) : ctx(c) { const char* v = getenv("SKH_TRACE"); on = v && (*v == '1' || *v == '2'); sync = on && *v == '1'; t = std::chrono::steady_clock::now(); }
+    void mark(const char* what) {                        // SKH_TRACE=2: host time between marks without synchronising (where the host itself spends its time)
         if (!on) return;
-        dsync(ctx->stream);
+        if (sync) dsync(ctx->stream);
         const auto n = std::chrono::steady_clock::now();
         fprintf(stderr, "[skh trace] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
         t = n;

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
                                                             uint32_t* p_rep, uint32_t* err) {
     SKH_DYN_SMEM(smem);
     unsigned long long* slots = (unsigned long long*)smem;                          // TAB_SLICE + TAB_SLACK
-    uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // TAB_SLICE / 32 words
-    uint32_t* mlist = lbm + TAB_SLICE / 32;                                         // match_cap position indices (the positions whose seed lives in this slice)
+    uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // the slice's filter words (common.h): TAB_SLICE / TAB_FILTER_HOMES
+    uint32_t* mlist = lbm + TAB_SLICE / TAB_FILTER_HOMES;                                         // match_cap position indices (the positions whose seed lives in this slice)
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
     __shared__ uint32_t ms_base, distinct, n_match;
     const uint2 gs = blk[blockIdx.x];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     const uint32_t h0 = sl * TAB_SLICE, nh = (NB - h0 < TAB_SLICE ? NB - h0 : TAB_SLICE), phys = nh + TAB_SLACK;   // home slots / physical slots of this slice
     const uint64_t ms0 = ms_off[g]; const uint32_t ms_cap = (uint32_t)(ms_off[g + 1] - ms0);
     for (uint32_t a = tid; a < phys; a += BUILD_THREADS) slots[a] = TAB_EMPTY;
-    for (uint32_t x = tid; x < TAB_SLICE / 32; x += BUILD_THREADS) lbm[x] = 0;
+    for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += BUILD_THREADS) lbm[x] = 0;
     if (tid == 0) { distinct = 0; n_match = 0; }
     __syncthreads();
     // ---- scan: every slice reads all of the genome's hashes (coalesced, four loads in flight per thread, served by the XCD's L2 after the first
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
             unsigned long long cur = slots[a];
             if (cur == TAB_EMPTY) {
                 cur = atomicCAS(&slots[a], (unsigned long long)TAB_EMPTY, ((unsigned long long)h << 32) | 1ull);
-                if (cur == TAB_EMPTY) { atomicOr(&lbm[(home - h0) >> 5], 1u << ((home - h0) & 31u)); break; }
+                if (cur == TAB_EMPTY) { atomicOr(&lbm[(home - h0) >> TAB_FILTER_SHIFT], tab_filter_bits(h)); break; }
             }
             if ((uint32_t)(cur >> 32) == h) { atomicAdd(&slots[a], 1ull); break; }
             if (++a >= phys) { atomicAdd(err, 1u); break; }                          // more than TAB_SLACK entries pushed past the slice's end
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
         }
         tab[tab_off[g] + (uint64_t)sl * (TAB_SLICE + TAB_SLACK) + a] = v;
     }
-    uint32_t* gbm = bmap + bmap_off[g] + sl * (TAB_SLICE / 32);
-    for (uint32_t x = tid; x < (nh + 31) / 32; x += BUILD_THREADS) gbm[x] = lbm[x];
+    uint32_t* gbm = bmap + bmap_off[g] + sl * (TAB_SLICE / TAB_FILTER_HOMES);
+    for (uint32_t x = tid; x < (nh + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES; x += BUILD_THREADS) gbm[x] = lbm[x];
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -305,11 +305,11 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     for (uint32_t g = 0; g < ng; g++) {                                             // run on one XCD and share its seed arrays through that L2
         const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
         if (pg >= (1ull << 30)) throw Error("a genome with >= 2^30 seed positions does not fit the seed table's 32-bit slot fields");
-        const uint32_t nb = (uint32_t)std::max<uint64_t>(64, 2 * pg);
+        const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
         const uint32_t n_sl = (nb + TAB_SLICE - 1) / TAB_SLICE;
         ss->n_buckets[g] = nb;
         ss->tab_off[g + 1] = ss->tab_off[g] + nb + (uint64_t)n_sl * TAB_SLACK;
-        ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / 32) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
+        ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / TAB_FILTER_HOMES) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
         // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
         // coordinates pass 2^30 may need two words for a single position
         const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];
@@ -335,7 +335,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
         const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TAB_SLICE, 4 * BUILD_THREADS);
         if (!blk.empty()) {
-            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / 8 + (size_t)match_cap * 4;
+            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)match_cap * 4;
 #ifndef SKANI_EMU
             static size_t attr_lds = 0;
             if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
