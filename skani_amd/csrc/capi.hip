@@ -157,7 +157,7 @@ int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketc
         finalize_metadata(ss);
         SeedOutput so;
         { Stopwatch sw(ctx, &ctx->timings.seed_ms); seed_genomes(ctx, gs, *sp, so); }
-        ss->p_seed = std::move(so.seed); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
+        ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
         Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
         // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) are built on
         // the second stream meanwhile: neither fills the GPU, together they take as long as the tables alone

@@ -101,22 +101,23 @@ void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std
                 const uint32_t T = (uint32_t)std::min<double>(std::max(1.0, t), (double)comp_n[r]);
                 gsize[r] = (comp_n[r] + T - 1) / T;
             }
-    // unit key: whole component = root << 32 | all ones; tile = root << 32 | row group << 16 | column group
+    // units: a light component is one unit (looked up by its root); the tiles of a heavy one are keyed (root, row group, column group)
     std::vector<uint32_t> unit_of(NP);
-    std::unordered_map<uint64_t, uint32_t> unit_id; unit_id.reserve(NP / 4 + 16);
+    std::vector<int32_t> comp_unit(n_genomes, -1);
+    std::unordered_map<uint64_t, uint32_t> tile_unit;
     std::vector<uint64_t> ukey, ucost; std::vector<uint32_t> aff;                   // aff[u * world + r]: pair end points of unit u whose sketch rank r holds
+    auto new_unit = [&](uint64_t k) { ukey.push_back(k); ucost.push_back(0); if (!holder.empty()) aff.resize(aff.size() + world, 0); return (uint32_t)(ukey.size() - 1); };
     for (size_t p = 0; p < NP; p++) {
         const uint32_t r = dsu.find(pi[p]);
-        uint64_t k = ((uint64_t)r << 32) | 0xFFFFFFFFull;
-        if (gsize[r]) {
+        uint32_t u;
+        if (!gsize[r]) { if (comp_unit[r] < 0) comp_unit[r] = (int32_t)new_unit(((uint64_t)r << 32) | 0xFFFFFFFFull); u = (uint32_t)comp_unit[r]; }
+        else {
             uint32_t a = pos_in[pi[p]] / gsize[r], b = pos_in[pj[p]] / gsize[r];
             if (a > b) std::swap(a, b);
-            k = ((uint64_t)r << 32) | ((uint64_t)std::min(a, 0xFFFEu) << 16) | std::min(b, 0xFFFEu);
+            const uint64_t k = ((uint64_t)r << 32) | ((uint64_t)std::min(a, 0xFFFEu) << 16) | std::min(b, 0xFFFEu);
+            auto it = tile_unit.find(k);
+            if (it == tile_unit.end()) { u = new_unit(k); tile_unit.emplace(k, u); } else u = it->second;
         }
-        auto it = unit_id.find(k);
-        uint32_t u;
-        if (it == unit_id.end()) { u = (uint32_t)ukey.size(); unit_id.emplace(k, u); ukey.push_back(k); ucost.push_back(0); if (!holder.empty()) aff.resize(aff.size() + world, 0); }
-        else u = it->second;
         unit_of[p] = u; ucost[u] += pair_cost(p);
         if (!holder.empty()) { aff[(size_t)u * world + holder[pi[p]]]++; aff[(size_t)u * world + holder[pj[p]]]++; }
     }
@@ -277,7 +278,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     // remote set: the genomes this rank receives, in ascending global index (= source rank order)
     std::vector<uint32_t> rem_ids; for (int r = 0; r < W; r++) rem_ids.insert(rem_ids.end(), recv_from[r].begin(), recv_from[r].end());
     const uint32_t nR = (uint32_t)rem_ids.size();
-    std::unordered_map<uint32_t, uint32_t> rem_index; rem_index.reserve(nR * 2 + 1);
+    std::vector<uint32_t> rem_index(N, 0xFFFFFFFFu);                                // global genome -> index in the received set
     for (uint32_t x = 0; x < nR; x++) rem_index[rem_ids[x]] = x;
     st.n_genomes_received = nR;
     std::unique_ptr<skh_sketch_set> Rm;
@@ -348,8 +349,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         const uint32_t i = pi[p], j = pj[p];
         const bool il = rank_of[i] == me, jl = rank_of[j] == me;
         c_i.push_back(i); c_j.push_back(j);
-        c_rs.push_back(il ? 0u : 1u); c_r.push_back(il ? (uint32_t)(i - base[me]) : rem_index.at(i));
-        c_qs.push_back(jl ? 0u : 1u); c_q.push_back(jl ? (uint32_t)(j - base[me]) : rem_index.at(j));
+        c_rs.push_back(il ? 0u : 1u); c_r.push_back(il ? (uint32_t)(i - base[me]) : rem_index[i]);
+        c_qs.push_back(jl ? 0u : 1u); c_q.push_back(jl ? (uint32_t)(j - base[me]) : rem_index[j]);
     }
     st.n_pairs_mine = c_i.size();
     std::vector<skh_ani_result> res(c_i.size());

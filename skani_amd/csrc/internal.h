@@ -181,7 +181,7 @@ void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int be
 // ---- pack_seed.hip
 void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
-    DBuf<uint32_t> seed, g; DBuf<uint64_t> markers_raw;      // g = padded coordinate << 1 | canonical (common.h CTG_PAD)
+    DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> markers_raw; // hash = mix32(seed); g = padded coordinate << 1 | canonical (common.h CTG_PAD)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
 };
 void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out);

@@ -293,10 +293,12 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
                    (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
         check_launch("pack_positions");
     }
-    ss->p_hash.alloc(P ? P : 1);
+    if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
+        ss->p_hash.alloc(P ? P : 1);
     if (P) {
         SKH_LAUNCH(hash_seeds_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, P, ss->p_hash.p);
         check_launch("hash_seeds");
+    }
     }
     // table geometry from the position counts alone (two home slots per POSITION, at least as many as per distinct seed): nothing has to come back
     // from the device before the tables are allocated
