@@ -210,6 +210,26 @@ def cpu_baseline(host_genomes, threads, gpu_result=None, n_gpu_genomes=None):
             "chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None, "chained_pairs": int(n_chained)}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner through C stdio on stdout when its first communicator is made; the contract is ONE JSON line on stdout.  While this is
+    active, file descriptor 1 points at stderr; on exit C's buffers are flushed there and stdout is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1); os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1); os.close(self.saved)
+        return False
+
+
 def file_sha(path):
     import hashlib
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -248,7 +268,8 @@ def main():
     device = torch.device("cuda", local)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     ctx = sk.Context(local)
     if args.workload == "search":
         if world > 1:
@@ -281,7 +302,8 @@ def main():
     from skani_amd.distributed import Comm
     comm = None
     if world > 1 or args.force_dist:
-        comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device) if args.transport == "rccl" else Comm.host(ctx, dist, rank, world, torch=torch)
+        with stdout_to_stderr():
+            comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device) if args.transport == "rccl" else Comm.host(ctx, dist, rank, world, torch=torch)
     last = {}
 
     def step():
@@ -295,8 +317,11 @@ def main():
         last["result"] = (i, j, res)
         return len(i), n_chained
 
-    for _ in range(args.warmup):
-        step()
+    with stdout_to_stderr():                      # (the first collective may still print)
+        for _ in range(args.warmup):
+            step()
+        if comm is not None and args.warmup == 0:
+            dist.barrier()
     ctx.timings()
     if world > 1:
         dist.barrier()
