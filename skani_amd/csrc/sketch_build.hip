@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
                 if (cur == TAB_EMPTY) { atomicOr(&lbm[(home - h0) >> TAB_FILTER_SHIFT], tab_filter_bits(h)); break; }
             }
             if ((uint32_t)(cur >> 32) == h) { atomicAdd(&slots[a], 1ull); break; }
-            if (++a >= phys) { atomicAdd(err, 1u); break; }                          // more than TAB_SLACK entries pushed past the slice's end
+            if (++a + 1 >= phys) { atomicAdd(err, 1u); break; }                      // more than TAB_SLACK entries pushed past the slice's end (its last slot stays empty: it ends every walk)
         }
     }
     __syncthreads();
@@ -319,7 +319,8 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
         for (uint32_t s = 0; s < n_sl; s++) blocks[g & 7u].push_back(make_uint2(g, s));
     }
-    ss->tab.alloc(ss->tab_off[ng] ? ss->tab_off[ng] : 1); ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
+    ss->tab.alloc(ss->tab_off[ng] + 8);                                              // (slack behind the last table)
+    ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
     ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
     TableBuild tb; tb.n = 2 * (size_t)ng + 1;                                        // err, distinct seeds per genome, list words used per genome
     if (ng) {

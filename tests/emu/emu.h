@@ -36,6 +36,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 struct uint3_ { unsigned x, y, z; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+struct ulonglong2 { unsigned long long x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
