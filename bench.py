@@ -308,7 +308,8 @@ def main():
 
     def step():
         # genome_rank = global index: the collection's names sort like its indices
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32))
+        # several GPUs: seed tables deferred -- every rank indexes only the sketches it ends up chaining (its own that stay + the ones it receives)
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32), defer_tables=comm is not None)
         if comm is None:
             i, j, res, n_chained = ctx.triangle(ss_local, mp)
         else:

@@ -94,6 +94,13 @@ uint64_t skh_genomes_total_bases(const skh_genome_set*);
  * (chain.rs:20-22); NULL = genome index. */
 int skh_sketch_genomes(skh_ctx*, const skh_genome_set*, const skh_sketch_params*, const uint32_t* genome_rank,
                        skh_sketch_set** out);
+/* Same with flags.  SKH_SKETCH_DEFER_TABLES: seeding + marker sets only; the per-genome seed tables are built on first use (skh_chain_pairs*, skh_triangle*,
+ * skh_sketch_sizes' n_distinct) or by skh_sketch_build_tables.  A rank of a distributed triangle sketches with this flag: it then indexes only the
+ * sketches it ends up chaining (its own that stay + the ones it receives), not every genome it happened to read. */
+enum { SKH_SKETCH_DEFER_TABLES = 1 };
+int skh_sketch_genomes_ex(skh_ctx*, const skh_genome_set*, const skh_sketch_params*, const uint32_t* genome_rank, uint32_t flags,
+                          skh_sketch_set** out);
+int skh_sketch_build_tables(skh_ctx*, skh_sketch_set*);   /* no-op when they exist */
 /* convenience = skh_genomes_pack + skh_sketch_genomes (the fastx_to_sketches body, file_io.rs:141-252) */
 int skh_sketch_batch(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome,
                      uint32_t n_contigs, uint32_t n_genomes, const skh_sketch_params*, const uint32_t* genome_rank,

@@ -44,7 +44,7 @@ class HostCollectives(C.Structure):
 
 
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
-           "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_batch", "skh_sketch_set_destroy",
+           "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
            "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
            "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_triangle_distributed", "skh_plan_pairs"]
 RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
@@ -63,6 +63,8 @@ def load(path):
     L.skh_genomes_destroy.restype = None; L.skh_genomes_destroy.argtypes = [vp]
     L.skh_genomes_total_bases.restype = u64; L.skh_genomes_total_bases.argtypes = [vp]
     L.skh_sketch_genomes.restype = i32; L.skh_sketch_genomes.argtypes = [vp, vp, C.POINTER(SketchParams), vp, pp]
+    L.skh_sketch_genomes_ex.restype = i32; L.skh_sketch_genomes_ex.argtypes = [vp, vp, C.POINTER(SketchParams), vp, u32, pp]
+    L.skh_sketch_build_tables.restype = i32; L.skh_sketch_build_tables.argtypes = [vp, vp]
     L.skh_sketch_batch.restype = i32; L.skh_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, C.POINTER(SketchParams), vp, pp]
     L.skh_sketch_set_destroy.restype = None; L.skh_sketch_set_destroy.argtypes = [vp]
     L.skh_sketch_set_names.restype = i32; L.skh_sketch_set_names.argtypes = [vp, C.POINTER(C.c_char_p)]

@@ -109,10 +109,11 @@ class Context:
         return GenomeSet(self, h, seeding_mode, contig_off, contig_genome, n_genomes)
 
     # ---- sketch -------------------------------------------------------------------------------------------------
-    def sketch_genomes(self, gs, params, genome_rank=None, names=None):
+    def sketch_genomes(self, gs, params, genome_rank=None, names=None, defer_tables=False):
+        """defer_tables: seeding + marker sets only; the seed tables are built on first use (a rank of a distributed triangle indexes only what it chains)."""
         h = C.c_void_p()
         rank = np.ascontiguousarray(genome_rank, np.uint32) if genome_rank is not None else None
-        self.check(self.L.skh_sketch_genomes(self.h, gs.h, C.byref(params), _p(rank), C.byref(h)))
+        self.check(self.L.skh_sketch_genomes_ex(self.h, gs.h, C.byref(params), _p(rank), 1 if defer_tables else 0, C.byref(h)))
         return SketchSet(self, h, params, names)
 
     def sketch_records(self, genomes, params, names=None):

@@ -143,6 +143,17 @@ void skh_genomes_destroy(skh_genome_set* gs) { delete gs; }
 uint64_t skh_genomes_total_bases(const skh_genome_set* gs) { return gs ? gs->total_bases : 0; }
 
 int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketch_params* sp, const uint32_t* genome_rank, skh_sketch_set** out) {
+    return skh_sketch_genomes_ex(ctx, gs_c, sp, genome_rank, 0, out);
+}
+
+int skh_sketch_build_tables(skh_ctx* ctx, skh_sketch_set* ss) {
+    if (!ctx || !ss) return SKH_ERR_INVALID;
+    const int rc = guarded(ctx, [&] { Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, ss); });
+    ctx->arena.reset();
+    return rc;
+}
+
+int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketch_params* sp, const uint32_t* genome_rank, uint32_t flags, skh_sketch_set** out) {
     if (!ctx || !gs_c || !out) return SKH_ERR_INVALID;
     *out = nullptr;
     skh_genome_set* gs = const_cast<skh_genome_set*>(gs_c);
@@ -161,6 +172,12 @@ int skh_sketch_genomes(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sketc
         Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
         // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) are built on
         // the second stream meanwhile: neither fills the GPU, together they take as long as the tables alone
+        if (flags & SKH_SKETCH_DEFER_TABLES) {                                       // markers only; the tables are built where (and if) the sketches are chained
+            ss->dist_off.assign(ss->n_genomes + 1, 0);
+            upload_set_offsets(ctx, ss);
+            build_markers(ctx, ss, so.markers_raw, so.mk_off);
+            return;
+        }
         TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
         std::swap(ctx->stream, ctx->stream2);
         try { build_markers(ctx, ss, so.markers_raw, so.mk_off); } catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
@@ -194,6 +211,7 @@ uint32_t skh_sketch_n_genomes(const skh_sketch_set* ss) { return ss ? ss->n_geno
 
 int skh_sketch_sizes(const skh_sketch_set* ss, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers, uint32_t* n_contigs, uint64_t* total_len) {
     if (!ss || g >= ss->n_genomes) return SKH_ERR_INVALID;
+    if (n_distinct && !ss->tables_built) { const int rc = skh_sketch_build_tables(ss->ctx, const_cast<skh_sketch_set*>(ss)); if (rc != SKH_OK) return rc; }   // the distinct-seed counts come out of the table build
     if (n_pos) *n_pos = ss->pos_off[g + 1] - ss->pos_off[g];
     if (n_distinct) *n_distinct = ss->dist_off[g + 1] - ss->dist_off[g];
     if (n_markers) *n_markers = ss->mk_off[g + 1] - ss->mk_off[g];

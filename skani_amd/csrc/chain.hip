@@ -317,6 +317,8 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         if (!Rsets[x] || Rsets[x]->params.c != job.c || Rsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
     for (uint32_t x = 0; x < n_qsets; x++)
         if (!Qsets[x] || Qsets[x]->params.c != job.c || Qsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
+    for (uint32_t x = 0; x < n_rsets; x++) ensure_tables(ctx, Rsets[x]);            // (sets created with deferred tables)
+    for (uint32_t x = 0; x < n_qsets; x++) ensure_tables(ctx, Qsets[x]);
     job.band = BP_CHAIN_BAND / job.c;                                               // chain.rs:111-112 index_chain_band (ref sketch's c)
     if (mp.learned_ani) {
         job.model = std::abs((int)job.c - 125) < std::abs((int)job.c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22

@@ -263,100 +263,105 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     st.cost_mine = load[me]; st.n_units_mine = units_of[me];
     for (int r = 0; r < W; r++) { st.cost_total += load[r]; st.n_units_total += units_of[r]; }
     tr.mark("dist: pairs gathered + assigned");
-    // ---- 6. which sketches move: needed[r][g] = rank r chains a pair with genome g
+    // ---- 6. which sketches move: mark[g][r] = rank r chains a pair with genome g
     std::vector<std::vector<uint32_t>> send_to(W), recv_from(W);                   // global ids, ascending
+    std::vector<uint32_t> wk_ids;                                                   // the genomes THIS rank chains (its own that stay + the ones it receives), ascending
     {
         std::vector<uint8_t> mark((size_t)N * W, 0);
         for (size_t p = 0; p < NP; p++) { mark[(size_t)pi[p] * W + owner[p]] = 1; mark[(size_t)pj[p] * W + owner[p]] = 1; }
-        for (uint32_t g = 0; g < N; g++)
+        for (uint32_t g = 0; g < N; g++) {
+            if (mark[(size_t)g * W + me]) wk_ids.push_back(g);
             for (int r = 0; r < W; r++)
                 if (mark[(size_t)g * W + r] && rank_of[g] != r) {
                     if (rank_of[g] == me) send_to[r].push_back(g);
                     if (r == me) recv_from[rank_of[g]].push_back(g);
                 }
+        }
     }
-    // remote set: the genomes this rank receives, in ascending global index (= source rank order)
-    std::vector<uint32_t> rem_ids; for (int r = 0; r < W; r++) rem_ids.insert(rem_ids.end(), recv_from[r].begin(), recv_from[r].end());
-    const uint32_t nR = (uint32_t)rem_ids.size();
-    std::vector<uint32_t> rem_index(N, 0xFFFFFFFFu);                                // global genome -> index in the received set
-    for (uint32_t x = 0; x < nR; x++) rem_index[rem_ids[x]] = x;
+    uint32_t nR = 0; for (int r = 0; r < W; r++) nR += (uint32_t)recv_from[r].size();
     st.n_genomes_received = nR;
-    std::unique_ptr<skh_sketch_set> Rm;
+    // The work set: when sketches arrive, ONE set is made of the genomes this rank chains -- the local ones copied, the received ones from the
+    // exchange buffer, in ascending global index -- and its seed tables are built once.  A local sketch whose clusters went to other ranks is never
+    // indexed here (with deferred tables: skh_sketch_genomes_ex), a sketch that travels is indexed only where it arrives.  Nothing received: the local
+    // set itself is chained.
+    std::unique_ptr<skh_sketch_set> Wk;
+    std::vector<uint32_t> wk_index(N, 0xFFFFFFFFu);                                 // global genome -> index in the chained set
     ex_begin();
     {
         // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words)
-        std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg;
+        std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g;
         uint64_t sw = 0;
         for (int r = 0; r < W; r++) {
             uint64_t words = 0; for (uint32_t g : send_to[r]) words += g_npos[g];
             s_off[r] = sw * 4; s_cnt[r] = words * 2 * 4;
             uint64_t at = sw;
-            for (uint32_t g : send_to[r]) { const uint64_t lp = L->pos_off[g - base[me]]; seg.insert(seg.end(), {lp, at, g_npos[g]}); at += g_npos[g]; }
+            for (uint32_t g : send_to[r]) {
+                const uint64_t lp = L->pos_off[g - base[me]];
+                seg_s.insert(seg_s.end(), {lp, at, g_npos[g]}); seg_g.insert(seg_g.end(), {lp, at + words, g_npos[g]});   // the position halves follow the seed halves
+                at += g_npos[g];
+            }
             sw += words * 2;
         }
         uint64_t rw = 0; std::vector<uint64_t> r_words(W, 0);
-        for (int r = 0; r < W; r++) { for (uint32_t g : recv_from[r]) r_words[r] += g_npos[g]; r_off[r] = rw * 4; r_cnt[r] = r_words[r] * 2 * 4; rw += r_words[r] * 2; }
+        std::vector<uint64_t> recv_at(N, 0);                                        // word offset of a received genome's seeds inside its source's block
+        for (int r = 0; r < W; r++) {
+            for (uint32_t g : recv_from[r]) { recv_at[g] = r_words[r]; r_words[r] += g_npos[g]; }
+            r_off[r] = rw * 4; r_cnt[r] = r_words[r] * 2 * 4; rw += r_words[r] * 2;
+        }
         st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
         uint32_t* d_send = ctx->arena.get<uint32_t>(sw + 1); uint32_t* d_recv = ctx->arena.get<uint32_t>(rw + 1);
-        copy_segments(ctx, L->p_seed.p, d_send, seg);
-        for (int r = 0; r < W; r++) {                                               // the position halves follow the seed halves
-            uint64_t words = s_cnt[r] / 8;
-            if (!words) continue;
-            for (size_t x = 0; x < seg.size(); x += 3) if (seg[x + 1] >= s_off[r] / 4 && seg[x + 1] < s_off[r] / 4 + words) seg[x + 1] += words;
-        }
-        copy_segments(ctx, L->p_g.p, d_send, seg);
+        copy_segments(ctx, L->p_seed.p, d_send, seg_s);
+        copy_segments(ctx, L->p_g.p, d_send, seg_g);
         dsync(ctx->stream);
         T.all_to_all_v(ctx, d_send, s_cnt.data(), s_off.data(), d_recv, r_cnt.data(), r_off.data(), true);
         if (nR) {
-            Rm.reset(new skh_sketch_set());
-            Rm->ctx = ctx; Rm->params = L->params; Rm->n_genomes = nR;
-            Rm->rank.resize(nR); Rm->pos_off.assign(nR + 1, 0); Rm->mk_off.assign(nR + 1, 0); Rm->ctg_off.assign(nR + 1, 0); Rm->total_len.resize(nR);
-            for (uint32_t x = 0; x < nR; x++) {
-                const uint32_t g = rem_ids[x];
-                Rm->rank[x] = (uint32_t)g_rank[g]; Rm->total_len[x] = g_len[g];
-                Rm->pos_off[x + 1] = Rm->pos_off[x] + g_npos[g]; Rm->mk_off[x + 1] = Rm->mk_off[x] + g_nmk[g]; Rm->ctg_off[x + 1] = Rm->ctg_off[x] + g_nctg[g];
-                for (uint64_t c = 0; c < g_nctg[g]; c++) Rm->ctg_len.push_back(cl_all[g_ctg0[g] + c]);
+            const uint32_t nW = (uint32_t)wk_ids.size();
+            Wk.reset(new skh_sketch_set());
+            Wk->ctx = ctx; Wk->params = L->params; Wk->n_genomes = nW;
+            Wk->rank.resize(nW); Wk->pos_off.assign(nW + 1, 0); Wk->mk_off.assign(nW + 1, 0); Wk->ctg_off.assign(nW + 1, 0); Wk->total_len.resize(nW);
+            for (uint32_t x = 0; x < nW; x++) {
+                const uint32_t g = wk_ids[x];
+                wk_index[g] = x;
+                Wk->rank[x] = (uint32_t)g_rank[g]; Wk->total_len[x] = g_len[g];
+                Wk->pos_off[x + 1] = Wk->pos_off[x] + g_npos[g]; Wk->mk_off[x + 1] = Wk->mk_off[x] + g_nmk[g]; Wk->ctg_off[x + 1] = Wk->ctg_off[x] + g_nctg[g];
+                for (uint64_t c = 0; c < g_nctg[g]; c++) Wk->ctg_len.push_back(cl_all[g_ctg0[g] + c]);
             }
-            finalize_metadata(Rm.get());
-            const uint64_t PR = Rm->pos_off[nR], MR = Rm->mk_off[nR];
-            Rm->p_seed.alloc(PR ? PR : 1); Rm->p_g.alloc(PR); Rm->markers.alloc(MR ? MR : 1);
-            uint64_t at = 0;
-            for (int r = 0; r < W; r++) {
-                if (!r_words[r]) continue;
-                d2d(Rm->p_seed.p + at, d_recv + r_off[r] / 4, r_words[r] * 4, ctx->stream);
-                d2d(Rm->p_g.p + at, d_recv + r_off[r] / 4 + r_words[r], r_words[r] * 4, ctx->stream);
-                at += r_words[r];
+            finalize_metadata(Wk.get());
+            const uint64_t PW = Wk->pos_off[nW], MW = Wk->mk_off[nW];
+            Wk->p_seed.alloc(PW ? PW : 1); Wk->p_g.alloc(PW); Wk->markers.alloc(MW ? MW : 1);
+            std::vector<uint64_t> ls, lg, rs, rg, mseg;                             // local / received seed and position segments; markers: already here (step 2), 64-bit = two words
+            for (uint32_t x = 0; x < nW; x++) {
+                const uint32_t g = wk_ids[x]; const uint64_t n = g_npos[g], dst = Wk->pos_off[x];
+                if (rank_of[g] == me) { const uint64_t lp = L->pos_off[g - base[me]]; ls.insert(ls.end(), {lp, dst, n}); lg.insert(lg.end(), {lp, dst, n}); }
+                else { const uint64_t b0 = r_off[rank_of[g]] / 4; rs.insert(rs.end(), {b0 + recv_at[g], dst, n}); rg.insert(rg.end(), {b0 + r_words[rank_of[g]] + recv_at[g], dst, n}); }
+                mseg.insert(mseg.end(), {S.mk_off[g] * 2, Wk->mk_off[x] * 2, g_nmk[g] * 2});
             }
-            std::vector<uint64_t> mseg;                                            // markers of the received genomes: already here (step 2); 64-bit = two words
-            for (uint32_t x = 0; x < nR; x++) mseg.insert(mseg.end(), {S.mk_off[rem_ids[x]] * 2, Rm->mk_off[x] * 2, g_nmk[rem_ids[x]] * 2});
-            copy_segments(ctx, (const uint32_t*)S.markers.p, (uint32_t*)Rm->markers.p, mseg);
-            Rm->d_mk_off.alloc(nR + 1); h2d(Rm->d_mk_off.p, Rm->mk_off.data(), (nR + 1) * 8, ctx->stream);
+            copy_segments(ctx, L->p_seed.p, Wk->p_seed.p, ls); copy_segments(ctx, L->p_g.p, Wk->p_g.p, lg);
+            copy_segments(ctx, d_recv, Wk->p_seed.p, rs); copy_segments(ctx, d_recv, Wk->p_g.p, rg);
+            copy_segments(ctx, (const uint32_t*)S.markers.p, (uint32_t*)Wk->markers.p, mseg);
+            Wk->d_mk_off.alloc(nW + 1); h2d(Wk->d_mk_off.p, Wk->mk_off.data(), (nW + 1) * 8, ctx->stream);
             dsync(ctx->stream);
-        }
+        } else for (uint32_t g : wk_ids) wk_index[g] = (uint32_t)(g - base[me]);
     }
     ex_end();
     ctx->arena.reset();
     tr.mark("dist: sketches exchanged");
-    if (Rm) {
-        { Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); build_sketch_tables(ctx, Rm.get(), nullptr, nullptr); }
+    const skh_sketch_set* CS = Wk ? Wk.get() : L;                                   // the set that is chained
+    if (!wk_ids.empty()) {
+        { Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, CS); }
         ctx->arena.reset();
-        tr.mark("dist: remote seed tables");
+        tr.mark("dist: seed tables of the chained set");
     }
-    // ---- 7. chain this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98); either may be local (set 0) or received (set 1)
-    std::vector<uint32_t> c_i, c_j, c_rs, c_qs, c_r, c_q;
+    // ---- 7. chain this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98)
+    std::vector<uint32_t> c_i, c_j, c_r, c_q;
     for (size_t p = 0; p < NP; p++) {
         if (owner[p] != me) continue;
-        const uint32_t i = pi[p], j = pj[p];
-        const bool il = rank_of[i] == me, jl = rank_of[j] == me;
-        c_i.push_back(i); c_j.push_back(j);
-        c_rs.push_back(il ? 0u : 1u); c_r.push_back(il ? (uint32_t)(i - base[me]) : rem_index[i]);
-        c_qs.push_back(jl ? 0u : 1u); c_q.push_back(jl ? (uint32_t)(j - base[me]) : rem_index[j]);
+        c_i.push_back(pi[p]); c_j.push_back(pj[p]); c_r.push_back(wk_index[pi[p]]); c_q.push_back(wk_index[pj[p]]);
     }
     st.n_pairs_mine = c_i.size();
     std::vector<skh_ani_result> res(c_i.size());
     if (c_i.size()) {
-        const skh_sketch_set* sets[2] = {L, Rm ? Rm.get() : L};
-        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, sets, 2, c_rs.data(), sets, 2, c_qs.data(), c_r.data(), c_q.data(), c_i.size(), mp, res.data(), nullptr); }
+        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &CS, 1, nullptr, &CS, 1, nullptr, c_r.data(), c_q.data(), c_i.size(), mp, res.data(), nullptr); }
         ctx->arena.reset();
     }
     tr.mark("dist: chain");

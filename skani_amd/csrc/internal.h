@@ -127,6 +127,8 @@ struct skh_sketch_set {
     // contexts share the set.
     mutable skh::DBuf<uint64_t> screen_keys;
     mutable std::mutex cache_mu;
+    bool tables_built = false;                     // seed tables / filter / list storage exist (skh_sketch_genomes_ex may defer them: a rank of a distributed
+                                                   // triangle indexes only the sketches it ends up chaining; ensure_tables builds them on first use)
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off;
     skh::DBuf<uint32_t> d_n_buckets;
 };
@@ -193,6 +195,8 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
 struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                    // a table build that is queued but not yet waited for
 TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
 void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);
+void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
+void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);

@@ -272,6 +272,15 @@ void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint6
     check_launch("unpack_positions");
 }
 
+// the small per-genome tables the position kernels need on the device (export / import work without the seed tables)
+void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss) {
+    const uint32_t ng = ss->n_genomes;
+    if (ss->d_pos_off.n == ng + 1 && ss->d_ctg_off.n == ng + 1) return;
+    ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
+    ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
+    ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
+}
+
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     TableBuild tb = build_sketch_tables_begin(ctx, ss, pos, cc);
     build_sketch_tables_finish(ctx, ss, tb);
@@ -282,9 +291,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
-    ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
-    ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
-    ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
+    upload_set_offsets(ctx, ss);
     ss->p_rep.alloc(P / 32 + 1); dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
     if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
     if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
@@ -360,6 +367,15 @@ void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb
     else dsync(ctx->stream);
     for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + back[1 + g];
     if (back[0]) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range");
+    ss->tables_built = true;
+}
+
+void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss_c) {
+    if (ss_c->tables_built) return;
+    skh_sketch_set* ss = const_cast<skh_sketch_set*>(ss_c);
+    std::lock_guard<std::mutex> lk(ss->cache_mu);
+    if (ss->tables_built) return;
+    build_sketch_tables(ctx, ss, nullptr, nullptr);
 }
 
 // ---- markers: sort by (genome, marker), drop duplicates (marker_seeds is a set: seeding.rs:318, types.rs:272)

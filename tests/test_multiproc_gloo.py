@@ -48,7 +48,8 @@ def _worker(rank, world, port, q, case):
         mine = genomes[base:base + held[rank]]
         params = sk.SketchParams()
         gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in mine], params.seeding_mode)      # file_io.rs:176
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])))
+        # half of the cases sketch with deferred seed tables (what bench.py does on several GPUs): a rank then indexes only the sketches it chains
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks"))
         i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, with_stats=True)
         q.put((rank, i, j, res, n, st))
     finally:
