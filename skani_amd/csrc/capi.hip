@@ -180,7 +180,8 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         }
         TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
         std::swap(ctx->stream, ctx->stream2);
-        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); } catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
+        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
+        catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         build_sketch_tables_finish(ctx, ss, tb);
     });

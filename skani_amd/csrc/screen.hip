@@ -152,6 +152,22 @@ static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __p
     return r;
 }
 
+// fills the set's cache of sorted (marker, genome) incidences on the context's current stream (no-op when present)
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set) {
+    const uint32_t ng = set->n_genomes;
+    if (!ng || ng > ID_MASK) return;
+    const uint64_t MR = set->mk_off[ng];
+    std::lock_guard<std::mutex> lk(set->cache_mu);
+    if (set->screen_keys.n == MR && MR) return;
+    set->screen_keys.alloc(MR ? MR : 1);
+    if (MR) {
+        SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, set->screen_keys.p);
+        check_launch("screen_keys");
+        sort_keys_u64(ctx, set->screen_keys.p, MR, 64);
+    }
+    dsync(ctx->stream);
+}
+
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
                   std::vector<uint32_t>& first, std::vector<uint32_t>& second, uint32_t row_begin, uint32_t row_end) {
     first.clear(); second.clear();
@@ -173,14 +189,14 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         sort_keys_u64(ctx, out, n, 64);     // all 64 bits: (marker, side, genome) are distinct keys, so the order does not lean on the sort being stable
                                              // (rocPRIM's path for mid-sized inputs is not: sorting bits [22, 64) only scrambled equal markers at 28k keys)
     };
-    if (tri) {
-        uint64_t* k = ctx->arena.get<uint64_t>(MR ? MR : 1);
-        make_keys(refs, ncols, MR, 0u, k); keys = k;
-    } else {
-        {
-            std::lock_guard<std::mutex> lk(refs->cache_mu);
-            if (refs->screen_keys.n != MR || MR == 0) { refs->screen_keys.alloc(MR ? MR : 1); make_keys(refs, ncols, MR, 0u, refs->screen_keys.p); dsync(ctx->stream); }
-        }
+    // the set's (marker, genome) incidences sorted by marker are cached in the set: built on first use, or ahead of time by prepare_screen_keys
+    // (skh_sketch_genomes does that on its second stream while the seed tables are built, which takes the sort off the triangle's critical path)
+    {
+        std::lock_guard<std::mutex> lk(refs->cache_mu);
+        if (refs->screen_keys.n != MR || MR == 0) { refs->screen_keys.alloc(MR ? MR : 1); make_keys(refs, ncols, MR, 0u, refs->screen_keys.p); dsync(ctx->stream); }
+    }
+    if (tri) keys = refs->screen_keys.p;
+    else {
         rkeys = refs->screen_keys.p;
         uint64_t* k = ctx->arena.get<uint64_t>(MQ ? MQ : 1);
         make_keys(queries, nrows, MQ, 1u, k); keys = k;
