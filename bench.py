@@ -269,7 +269,8 @@ def main():
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+            # RCCL for device tensors; gloo beside it so that the host-collective transport stays available if the library's own communicator cannot be made
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=device, rank=rank, world_size=world)
     ctx = sk.Context(local)
     if args.workload == "search":
         if world > 1:
@@ -300,10 +301,24 @@ def main():
     ctx.timings()
 
     from skani_amd.distributed import Comm
-    comm = None
+    comm, transport = None, None
     if world > 1 or args.force_dist:
         with stdout_to_stderr():
-            comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device) if args.transport == "rccl" else Comm.host(ctx, dist, rank, world, torch=torch)
+            transport, why = args.transport, None
+            if transport == "rccl":
+                try:
+                    comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device)
+                except Exception as e:               # e.g. no librccl for dlopen: every rank must take the same way out
+                    why = repr(e)
+                failed = torch.tensor([1 if why else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+                if int(failed.item()):
+                    if comm is not None:
+                        comm.close(); comm = None
+                    print("bench: RCCL communicator not available on every rank (%s): host collectives over torch.distributed instead" % (why,), file=sys.stderr)
+                    transport = "torch"
+            if comm is None:
+                comm = Comm.host(ctx, dist, rank, world, torch=torch)
     last = {}
 
     def step():
@@ -393,7 +408,7 @@ def main():
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence, %s), -c %d -k %d -m %d -s 80, learned ANI on%s"
                                % (n_total, args.mean_len / 1e6, CLADE, "listed clade by clade" if order == "clade" else "file order shuffled: clades span the GPUs", C, K, M,
-                                  "" if world == 1 else ", tiled across %d GPUs (%d genomes each) via RCCL" % (world, n_local)),
+                                  "" if world == 1 else ", tiled across %d GPUs (%d genomes each) via %s" % (world, n_local, "RCCL" if transport == "rccl" else "host collectives (gloo)")),
                    "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
                    "kept_pairs": kept, "order": order,
                    "parallelism": "single GPU" if world == 1 else

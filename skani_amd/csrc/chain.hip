@@ -267,7 +267,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         FinalizeScratch fs{ctx->arena.get<double>(NC + 1), ctx->arena.get<double>(NC + 1), ctx->arena.get<uint32_t>(NC + 1), ctx->arena.get<uint32_t>(NC + 1),
                            ctx->arena.get<uint64_t>(NC + 1)};
         uint32_t* n_est = ctx->arena.get<uint32_t>(np);
-#define SKH_FIN(CAP, MIN) SKH_LAUNCH((finalize_kernel<CAP, MIN>), (np + 3) / 4, 256, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
+#define SKH_FIN(CAP, MIN) SKH_LAUNCH((finalize_kernel<CAP, MIN>), np, FIN_THREADS, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
                    (const double*)chunk_est, (const uint32_t*)chunk_w, (const uint4*)chunk_sums, fs, n_est, d_out + p0); \
         check_launch("finalize")
         SKH_FIN(320, 0); SKH_FIN(1024, 321);

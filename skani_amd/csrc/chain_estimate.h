@@ -36,71 +36,82 @@ __device__ __forceinline__ uint64_t wyrand_mix(uint64_t s) {
 __device__ __forceinline__ uint64_t wyrand_state(uint64_t d) { return 7ull + (d + 1ull) * WYRAND_STEP; }   // state after d + 1 steps from seed 7
 __device__ __forceinline__ uint64_t wyrand_draw(uint64_t d) { return wyrand_mix(wyrand_state(d)); }
 
-// chain.rs:414-555 + regression.rs:30-64.  One wave per pair.  The per-pair work arrays (one entry per chunk) live in LDS;
-// the kernel is instantiated for FIN_LDS = 320 (genomes up to ~6 Mbp: 11 KB per wave, 3 waves per SIMD) and 1024 entries and
-// a pair runs in the smaller one that holds it; beyond 1024 chunks the arrays spill to global scratch.  The kernel is a chain
-// of dependent LDS reads, shuffles and f64 arithmetic -- other waves are what fills its issue slots.
+constexpr uint32_t FIN_WAVES = 2, FIN_THREADS = 64 * FIN_WAVES;   // measured on 9,500 pairs: 1 wave per pair 0.98 ms, 2: 0.67, 4: 0.70, 5: 0.97, 8: 1.04
+// chain.rs:414-555 + regression.rs:30-64.  One workgroup of FIN_WAVES waves per pair.  The per-pair work arrays (one entry per chunk) live in LDS;
+// the kernel is instantiated for FIN_LDS = 320 (genomes up to ~6 Mbp: 11 KB per pair) and 1024 entries and a pair runs in the smaller one that
+// holds it; beyond 1024 chunks the arrays spill to global scratch.  The work is a chain of dependent LDS reads, shuffles and f64 arithmetic:
+// with four pairs (one wave each) per workgroup the 45 KB of LDS held the kernel at 2.4 waves per SIMD for 1.0 ms; the rank sort and the 100 bootstrap resamples -- 9/10 of the
+// instructions -- are independent per element / per resample and are dealt to the waves, the short sequential steps run on wave 0 or
+// redundantly on every wave (same operations in the same order: the same bits).
 template <uint32_t FIN_LDS, uint32_t FIN_MIN>
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
                                                        const double* chunk_est, const uint32_t* chunk_w, const uint4* chunk_sums, FinalizeScratch fs,
                                                        uint32_t* n_est_out, skh_ani_result* out) {
-    __shared__ double lds_boot[4][128];
-    __shared__ double lds_u[4][FIN_LDS], lds_s[4][FIN_LDS];
-    __shared__ uint64_t lds_cum[4][FIN_LDS];
-    __shared__ uint32_t lds_uw[4][FIN_LDS], lds_sw[4][FIN_LDS];
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
+    __shared__ double lds_boot[128];
+    __shared__ double lds_u[FIN_LDS], lds_s[FIN_LDS];
+    __shared__ uint64_t lds_cum[FIN_LDS];
+    __shared__ uint32_t lds_uw[FIN_LDS], lds_sw[FIN_LDS];
+    __shared__ uint32_t lds_hdr[4];
+    __shared__ uint64_t lds_total;
+    const uint32_t wv = threadIdx.x >> 6, tid = threadIdx.x;
+    const uint32_t p = blockIdx.x;
     if (p >= fa.n_pairs) return;
     const uint32_t l = lane_id();
     const PairDesc pd = pairs[p];
     const uint32_t C0 = pc0[p], nc = n_chunks[p];
     if (nc < FIN_MIN || (FIN_LDS < 1024 && nc > FIN_LDS)) return;                   // the other instantiation's pair
     const bool in_lds = nc <= FIN_LDS;
-    double* U = in_lds ? lds_u[wv] : fs.u_est + C0; uint32_t* UW = in_lds ? lds_uw[wv] : fs.u_w + C0;
-    double* S = in_lds ? lds_s[wv] : fs.s_est + C0; uint32_t* SW = in_lds ? lds_sw[wv] : fs.s_w + C0;
-    uint64_t* CUM = in_lds ? lds_cum[wv] : fs.cum + C0;
-    // 1. valid (estimate, weight) pairs in chunk order
-    uint32_t n = 0, acl = 0, nchains = 0, tqb = 0;
-    for (uint32_t b = 0; b < nc; b += 64) {
-        const uint32_t s = C0 + b + l;
-        if (b + l < nc) { const uint4 cs = chunk_sums[s]; acl += cs.x; nchains += cs.y; tqb += cs.z; }
-        const bool v = b + l < nc && chunk_w[s] != NONE;
-        const unsigned long long m = __ballot(v);
-        if (v) { const uint32_t o = n + (uint32_t)__popcll(m & ((1ull << l) - 1ull)); U[o] = chunk_est[s]; UW[o] = chunk_w[s]; }
-        n += (uint32_t)__popcll(m);
+    double* U = in_lds ? lds_u : fs.u_est + C0; uint32_t* UW = in_lds ? lds_uw : fs.u_w + C0;
+    double* S = in_lds ? lds_s : fs.s_est + C0; uint32_t* SW = in_lds ? lds_sw : fs.s_w + C0;
+    uint64_t* CUM = in_lds ? lds_cum : fs.cum + C0;
+    // 1. valid (estimate, weight) pairs in chunk order (wave 0)
+    if (wv == 0) {
+        uint32_t n = 0, acl = 0, nchains = 0, tqb = 0;
+        for (uint32_t b = 0; b < nc; b += 64) {
+            const uint32_t s = C0 + b + l;
+            if (b + l < nc) { const uint4 cs = chunk_sums[s]; acl += cs.x; nchains += cs.y; tqb += cs.z; }
+            const bool v = b + l < nc && chunk_w[s] != NONE;
+            const unsigned long long m = __ballot(v);
+            if (v) { const uint32_t o = n + (uint32_t)__popcll(m & ((1ull << l) - 1ull)); U[o] = chunk_est[s]; UW[o] = chunk_w[s]; }
+            n += (uint32_t)__popcll(m);
+        }
+        acl = wave_sum(acl); nchains = wave_sum(nchains); tqb = wave_sum(tqb);
+        if (l == 0) { n_est_out[p] = n; lds_hdr[0] = n; lds_hdr[1] = acl; lds_hdr[2] = nchains; lds_hdr[3] = tqb; }
     }
-    if (l == 0) n_est_out[p] = n;
+    __syncthreads();
+    const uint32_t n = lds_hdr[0], acl = lds_hdr[1], nchains = lds_hdr[2], tqb = lds_hdr[3];
     skh_ani_result res;
     memset(&res, 0, sizeof res);
-    acl = wave_sum(acl); nchains = wave_sum(nchains); tqb = wave_sum(tqb);
     if (n == 0 || nchains == 0) {                                                   // chain.rs:416-420: AniEstResult::default() with ani = NaN
         res.ani = __builtin_nanf("");
-        if (l == 0) out[p] = res;
+        if (tid == 0) out[p] = res;
         return;
     }
-    wave_sync_mem();
-    // 2. ascending sort by (estimate, weight) by rank counting (chain.rs:414)
-    for (uint32_t i = l; i < n; i += 64) {
+    // 2. ascending sort by (estimate, weight) by rank counting (chain.rs:414): one element per thread
+    for (uint32_t i = tid; i < n; i += FIN_THREADS) {
         const double e = U[i]; const uint32_t w = UW[i];
         uint32_t rank = 0;
 #pragma unroll 4
         for (uint32_t j = 0; j < n; j++) { const double ej = U[j]; const uint32_t wj = UW[j]; rank += (ej < e || (ej == e && (wj < w || (wj == w && j < i)))) ? 1u : 0u; }
         S[rank] = e; SW[rank] = w;
     }
-    wave_sync_mem();
-    // 3. inclusive cumulative weights
-    uint64_t carry = 0;
-    for (uint32_t b = 0; b < n; b += 64) {
-        const uint32_t i = b + l;
-        uint64_t v = i < n ? SW[i] : 0;
+    __syncthreads();
+    // 3. inclusive cumulative weights (wave 0)
+    if (wv == 0) {
+        uint64_t carry = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + l;
+            uint64_t v = i < n ? SW[i] : 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v += t; }
-        if (i < n) CUM[i] = carry + v;
-        carry += __shfl(v, 63, 64);
+            for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v += t; }
+            if (i < n) CUM[i] = carry + v;
+            carry += __shfl(v, 63, 64);
+        }
+        if (l == 0) lds_total = carry;
     }
-    const uint64_t total_mult = carry;
-    wave_sync_mem();
-    // 4. quantile window (chain.rs:426-460)
+    __syncthreads();
+    const uint64_t total_mult = lds_total;
+    // 4. quantile window (chain.rs:426-460) -- steps 4 and 5 read only: every wave computes them for itself
     double lower = 0., upper = 1.;
     if (fa.median) { lower = 0.499; upper = 0.501; } else if (fa.robust) { lower = 0.10; upper = 0.90; }
     const uint64_t thr_lo = (uint64_t)((double)total_mult * lower), thr_hi = (uint64_t)((double)total_mult * upper);
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     for (uint32_t i = l; i < n; i += 64) { const double d = mean - S[i]; var += d * d; }
     var = wave_sum_f64(var);
     const double sd = sqrt(var / (double)n);
-    // 6. percentile bootstrap (chain.rs:57-86): 100 resamples of n draws from the multiplicity-expanded list
+    // 6. percentile bootstrap (chain.rs:57-86): 100 resamples of n draws from the multiplicity-expanded list, dealt to the waves in groups of four
     double ci_lo = 0., ci_hi = 1.;
     if (fa.compute_ci && n >= 10) {
         uint32_t nsteps = 0; while ((1u << nsteps) < n) nsteps++;                  // fixed-length branch-free binary search
@@ -141,18 +152,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
             uint32_t* C32 = UW; uint32_t* T = (uint32_t*)U;
             uint32_t sh = 0; while ((total_mult >> sh) >= 512) sh++;
             const uint32_t nb = (uint32_t)(total_mult >> sh) + 1;                      // x < total_mult  =>  x >> sh < nb <= 512
-            for (uint32_t i = l; i < n; i += 64) C32[i] = (uint32_t)CUM[i];
-            for (uint32_t b = l; b < nb; b += 64) T[b] = search64((uint64_t)b << sh) | (search64((uint64_t)(b + 1) << sh) << 16);   // past-the-end thresholds give n-1
-            wave_sync_mem();
+            for (uint32_t i = tid; i < n; i += FIN_THREADS) C32[i] = (uint32_t)CUM[i];
+            for (uint32_t b = tid; b < nb; b += FIN_THREADS) T[b] = search64((uint64_t)b << sh) | (search64((uint64_t)(b + 1) << sh) << 16);   // past-the-end thresholds give n-1
+            __syncthreads();
             const uint32_t tot32 = (uint32_t)total_mult;
-            // generator states of this lane's draws j = l + 64 u (+ 256 m) of resample `it`: advanced by n steps per resample instead of
-            // being recomputed from the draw number (a 64-bit multiply per draw)
-            uint64_t st[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) st[u] = wyrand_state((uint64_t)l + 64u * (uint32_t)u);
             const uint64_t step_it = (uint64_t)n * WYRAND_STEP, step_256 = 256ull * WYRAND_STEP;
-            // resamples in groups of four: the four wave reductions (six dependent shuffle steps each) then run interleaved
-            for (uint32_t it0 = 0; it0 < 100; it0 += 4) {
+            // resamples in groups of four: the four wave reductions (six dependent shuffle steps each) then run interleaved; group q -> wave q mod FIN_WAVES
+            for (uint32_t it0 = 4 * wv; it0 < 100; it0 += 4 * FIN_WAVES) {
+              // generator states of this lane's draws j = l + 64 u (+ 256 m) of resample `it0`: a pure function of the draw number it0 * n + j;
+              // advanced by n steps per resample instead of being recomputed (a 64-bit multiply per draw)
+              uint64_t st[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) st[u] = wyrand_state((uint64_t)it0 * n + (uint64_t)l + 64u * (uint32_t)u);
               double sg[4];
 #pragma unroll
               for (int g = 0; g < 4; g++) {
@@ -188,29 +199,30 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
               }
               if (l == 0) {
 #pragma unroll
-                  for (int g = 0; g < 4; g++) lds_boot[wv][it0 + g] = sg[g] / (double)n;
+                  for (int g = 0; g < 4; g++) lds_boot[it0 + g] = sg[g] / (double)n;
               }
             }
         } else {
-            for (uint32_t it = 0; it < 100; it++) {
+            for (uint32_t it = wv; it < 100; it += FIN_WAVES) {
                 double s = 0.;
                 for (uint32_t j0 = l; j0 < n; j0 += 64) {
                     const uint64_t r = wyrand_draw((uint64_t)it * n + j0);
                     s += S[search64(__umul64hi(r, total_mult))];
                 }
                 s = wave_sum_f64(s);
-                if (l == 0) lds_boot[wv][it] = s / (double)n;
+                if (l == 0) lds_boot[it] = s / (double)n;
             }
         }
-        wave_sync_mem();
-        for (uint32_t i = l; i < 100; i += 64) {
-            const double e = lds_boot[wv][i]; uint32_t rank = 0;
-            for (uint32_t j = 0; j < 100; j++) { const double ej = lds_boot[wv][j]; rank += (ej < e || (ej == e && j < i)) ? 1u : 0u; }
-            if (rank == 4) lds_boot[wv][100] = e;
-            if (rank == 94) lds_boot[wv][101] = e;
+        __syncthreads();
+        if (tid < 100) {
+            const uint32_t i = tid;
+            const double e = lds_boot[i]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < 100; j++) { const double ej = lds_boot[j]; rank += (ej < e || (ej == e && j < i)) ? 1u : 0u; }
+            if (rank == 4) lds_boot[100] = e;
+            if (rank == 94) lds_boot[101] = e;
         }
-        wave_sync_mem();
-        ci_lo = lds_boot[wv][100]; ci_hi = lds_boot[wv][101];
+        __syncthreads();
+        ci_lo = lds_boot[100]; ci_hi = lds_boot[101];
     }
     // 7. aligned fractions, cut-offs, output record (chain.rs:477-554) -- computed redundantly by every lane (wave-uniform)
     double cov_q = (double)tqb / (double)pd.query_total_len; if (!(cov_q < 1.)) cov_q = 1.;
@@ -225,14 +237,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
     res.avg_chain_int_len = acl / nchains;                                          // chain.rs:421
     res.total_bases_covered = tqb;
     // 8. learned ANI (regression.rs:30-64; gbdt 0.1.1 LAD predict = bias + sum shrinkage * leaf, f32, tree order).
-    //    The 195 tree walks are independent: lanes walk trees lane, lane+64, ...; the f32 sum stays sequential in tree order.
+    //    The 195 tree walks are independent: one tree per thread; the f32 sum stays sequential in tree order.
     if (fa.learned && res.ani > 0.9f && res.total_bases_covered > REGRESS_CUTOFF) { // wave-uniform condition
         float x[5];
         x[0] = res.ani * 100.f; x[1] = res.std; x[4] = (float)res.avg_chain_int_len;
         if (res.q50_r > res.q50_q) { x[2] = res.q90_r; x[3] = res.q90_q; } else { x[2] = res.q90_q; x[3] = res.q90_r; }
-        float* leaf = (float*)lds_boot[wv];                                         // 256 floats
-        wave_sync_mem();
-        for (uint32_t t = l; t < fa.n_trees && t < 256; t += 64) {
+        float* leaf = (float*)lds_boot;                                             // 256 floats
+        __syncthreads();                                                            // (every thread has read its interval bounds from lds_boot)
+        for (uint32_t t = tid; t < fa.n_trees && t < 256; t += FIN_THREADS) {
             const GbdtModel::Node* nd = fa.nodes + fa.tree_off[t]; int32_t i = 0;
             while (nd[i].feat >= 0) {
                 const int32_t ft = nd[i].feat;
@@ -241,8 +253,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
             }
             leaf[t] = nd[i].pred;
         }
-        wave_sync_mem();
-        if (l == 0) {
+        __syncthreads();
+        if (tid == 0) {
             float pred = fa.bias;
             for (uint32_t t = 0; t < fa.n_trees; t++) {
                 float lv;
@@ -257,5 +269,5 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs fa, const Pa
             }
         }
     }
-    if (l == 0) out[p] = res;
+    if (tid == 0) out[p] = res;
 }

@@ -28,7 +28,7 @@ class Comm:
         if rank == 0:
             ctx.check(ctx.L.skh_comm_unique_id(ident))
         if world > 1:
-            dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+            dev = device if (device is not None and "nccl" in str(dist.get_backend())) else torch.device("cpu")
             t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=0)
             ident = (C.c_uint8 * 128)(*[int(x) for x in t.cpu().tolist()])
