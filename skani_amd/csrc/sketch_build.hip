@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
 // ---- seed tables, built per genome in LDS
 // A genome's table is cut into slices of TAB_SLICE home slots (common.h); one workgroup builds one slice entirely in LDS and writes it out
 // densely, so the build needs no sort, no global scatter and no partial-line stores (round 1 sorted all records of the batch by (genome, hash)
-// with four device-wide radix passes and then emitted / placed the entries: 2.9 ms per 1000 genomes against ~0.4 ms now).
+// with four device-wide radix passes and then emitted / placed the entries: 2.9 ms per 1000 genomes against 0.2 + 1.6 ms now).
+//   first   slice_positions_kernel lists every slice's positions (index, hash); a slice's workgroup holds its positions in registers;
 //   pass A  every position whose seed's home slot falls into the slice is inserted by linear probing with 64-bit LDS compare-and-swap:
 //           slot = hash << 32 | multiplicity (the same seed again only bumps the count);
 //   pass B  slots are classified: single / listed (2 .. band occurrences: count + 1 words of the genome's list storage, handed out by a
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
 //           listed seeds append to their list, positions of repetitive seeds get their 'repetitive' bit (chain.rs:674-676);
 //   pass D  the short lists are put into ascending order (anchors must come out in (ref contig, ref pos) order for one query position);
 //   then the slice, its share of the bucket-occupancy bitmap and the number of distinct seeds are written out.
-// Clusters are not sorted by hash (insertion order is whatever the LDS atomics made it): a probe walks to its hash or to an empty slot.  The
-// outcome -- which positions a seed has, in which order -- does not depend on that order.
+// Between passes A and B every run of occupied slots is put into ascending hash order (see there); the outcome -- which positions a seed has, in
+// which order -- does not depend on the order the LDS atomics inserted in.
 constexpr uint32_t BUILD_THREADS = 1024;
 constexpr uint32_t SLOT_PENDING = 0xFFFFFFFEu;          // pass B -> pass C: single seed whose position is still to be filled in
 
@@ -73,7 +74,66 @@ __global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restr
     if (i < n) p_hash[i] = mix32(p_seed[i]);
 }
 
-__global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
+// The positions of a genome, dealt to the slices their seeds' home slots fall into: (position index, hash) slice by slice, in the genome's stretch
+// of p_slice (order within a slice: whatever the LDS atomics make it).  A slice's workgroup then reads its own ~2,000 positions instead of
+// testing all ~40,000 of the genome (that test was a third of build_tables_kernel's instructions).  One workgroup per genome, two passes over the
+// hashes: count per slice in LDS, scan, scatter.  Measured per 1000 genomes: 0.21 ms (0.26 ms with one load in flight per thread).  Variants that
+// were slower: one pass into fixed-capacity lists (0.24 ms), hashes kept in registers + the list assembled in LDS and written out in order
+// (0.27 ms: 80 KB of LDS leave one workgroup per CU) -- the kernel is bound by the latency of its phases, not by its scattered 8-byte writes.
+constexpr uint32_t SLICE_LDS_MAX = 8192;                // slices per genome handled here (16M positions); beyond: the slices re-scan the genome
+constexpr uint32_t SLICE_NO_LIST = 0xFFFFFFFFu;
+__global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_hash, const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
+                                                                      const uint32_t* __restrict__ slice_first, uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt,
+                                                                      uint2* __restrict__ p_slice) {
+    __shared__ uint32_t cnt[SLICE_LDS_MAX];
+    __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
+    const uint32_t n_sl = (NB + TAB_SLICE - 1) / TAB_SLICE, s0 = slice_first[g];
+    if (n_sl > SLICE_LDS_MAX) {
+        for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) { sl_start[s0 + s] = 0; sl_cnt[s0 + s] = SLICE_NO_LIST; }
+        return;
+    }
+    for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) cnt[s] = 0;
+    __syncthreads();
+    // (four independent loads in flight per thread: the loop is otherwise one memory round trip per position)
+    for (uint32_t i0 = tid; i0 < P; i0 += 4 * BUILD_THREADS) {
+        uint32_t hh[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (i0 + u * BUILD_THREADS < P) atomicAdd(&cnt[seed_bucket(hh[u], NB) >> TAB_SLICE_SHIFT], 1u);
+    }
+    __syncthreads();
+    constexpr uint32_t PER_MAX = SLICE_LDS_MAX / BUILD_THREADS;
+    const uint32_t per = (n_sl + BUILD_THREADS - 1) / BUILD_THREADS;                 // consecutive slices per thread
+    uint32_t loc[PER_MAX], sum = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER_MAX; u++) { const uint32_t s = tid * per + u; loc[u] = (u < per && s < n_sl) ? cnt[s] : 0u; sum += loc[u]; }
+    const uint32_t incl = wave_incl_scan(sum);
+    if (l == 63) lds_scan[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t q = 0; q < w; q++) run += lds_scan[q];
+#pragma unroll
+    for (uint32_t u = 0; u < PER_MAX; u++) {
+        const uint32_t s = tid * per + u;
+        if (u < per && s < n_sl) { sl_start[s0 + s] = run; sl_cnt[s0 + s] = loc[u]; cnt[s] = run; run += loc[u]; }   // cnt: the slice's write cursor now
+    }
+    __syncthreads();
+    for (uint32_t i0 = tid; i0 < P; i0 += 4 * BUILD_THREADS) {
+        uint32_t hh[4], oo[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) oo[u] = i0 + u * BUILD_THREADS < P ? atomicAdd(&cnt[seed_bucket(hh[u], NB) >> TAB_SLICE_SHIFT], 1u) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (i0 + u * BUILD_THREADS < P) p_slice[pos0 + oo[u]] = make_uint2(i0 + u * BUILD_THREADS, hh[u]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ sl_start,
+                                                            const uint32_t* __restrict__ sl_cnt, const uint2* __restrict__ p_slice, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
                                                             const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ tab_off,
                                                             const uint64_t* __restrict__ bmap_off, const uint64_t* __restrict__ ms_off, uint32_t band, uint32_t match_cap,
                                                             uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* ms, uint32_t* ms_used, uint32_t* n_distinct,
@@ -81,9 +141,9 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     SKH_DYN_SMEM(smem);
     unsigned long long* slots = (unsigned long long*)smem;                          // TAB_SLICE + TAB_SLACK
     uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // the slice's filter words (common.h): TAB_SLICE / TAB_FILTER_HOMES
-    uint32_t* mlist = lbm + TAB_SLICE / TAB_FILTER_HOMES;                                         // match_cap position indices (the positions whose seed lives in this slice)
+    uint32_t* mlist = lbm + TAB_SLICE / TAB_FILTER_HOMES;                                         // match_cap words: the slice's seed lists are assembled here
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
-    __shared__ uint32_t ms_base, distinct, n_match;
+    __shared__ uint32_t ms_base, distinct;
     const uint2 gs = blk[blockIdx.x];
     if (gs.x == 0xFFFFFFFFu) return;
     const uint32_t g = gs.x, sl = gs.y, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
@@ -92,39 +152,30 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     const uint64_t ms0 = ms_off[g]; const uint32_t ms_cap = (uint32_t)(ms_off[g + 1] - ms0);
     for (uint32_t a = tid; a < phys; a += BUILD_THREADS) slots[a] = TAB_EMPTY;
     for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += BUILD_THREADS) lbm[x] = 0;
-    if (tid == 0) { distinct = 0; n_match = 0; }
+    if (tid == 0) distinct = 0;
     __syncthreads();
-    // ---- scan: every slice reads all of the genome's hashes (coalesced, four loads in flight per thread, served by the XCD's L2 after the first
-    // slice) and lists the positions that belong to it -- the passes below then run densely over that list, one listed position per thread
-    for (uint32_t i0 = 0; i0 < P; i0 += BUILD_THREADS * 4) {
-        uint32_t hh[4]; bool m[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS + tid; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t i = i0 + u * BUILD_THREADS + tid;
-            m[u] = i < P && seed_bucket(hh[u], NB) - h0 < nh;                         // (unsigned: also home < h0)
-            const unsigned long long bal = __ballot(m[u]);
-            uint32_t base = 0;
-            if (l == 0 && bal) base = atomicAdd(&n_match, (uint32_t)__popcll(bal));
-            base = wave_bcast(base, 0);
-            if (m[u]) { const uint32_t o = base + (uint32_t)__popcll(bal & ((1ull << l) - 1ull)); if (o < match_cap) mlist[o] = i; }
-        }
-    }
-    __syncthreads();
-    // a slice with more positions than the list holds (sequence with very few distinct seeds): the passes re-scan all positions instead
+    // ---- the slice's positions: listed by slice_positions_kernel (one per thread and round, index and hash in registers); a slice with more positions
+    // than the passes hold that way (sequence with very few distinct seeds), or a genome of more slices than that kernel handles, re-scans all positions
+    const uint32_t bi = slice_first[g] + sl, n_match = sl_cnt[bi];
     const bool dense = n_match <= match_cap;
     const uint32_t NM = dense ? n_match : P;
     constexpr uint32_t MAX_OWN = 4;                                                  // listed positions per thread in dense mode (match_cap <= 4096)
-    uint32_t own[MAX_OWN];
+    uint32_t own[MAX_OWN], own_h[MAX_OWN];
+    {
+        const uint2* mine_list = p_slice + pos0 + sl_start[bi];
 #pragma unroll
-    for (uint32_t u = 0; u < MAX_OWN; u++) own[u] = (dense && tid + u * BUILD_THREADS < NM) ? mlist[tid + u * BUILD_THREADS] : 0xFFFFFFFFu;
+        for (uint32_t u = 0; u < MAX_OWN; u++) {
+            uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+            if (dense && tid + u * BUILD_THREADS < NM) e = mine_list[tid + u * BUILD_THREADS];
+            own[u] = e.x; own_h[u] = e.y;
+        }
+    }
     const uint32_t n_round = dense ? MAX_OWN : (P + BUILD_THREADS - 1) / BUILD_THREADS;
     // ---- pass A
     for (uint32_t u = 0; u < n_round; u++) {
         const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
         if (i >= P) continue;
-        const uint32_t h = p_hash[pos0 + i], home = seed_bucket(h, NB);
+        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], home = seed_bucket(h, NB);
         if (home - h0 >= nh) continue;
         uint32_t a = home - h0;
         for (;;) {
@@ -185,8 +236,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     uint32_t off = base + before + incl - need;
     const bool ms_ok = base + tot <= ms_cap && base + tot < TAB_OFF_MASK - 8;
     if (!ms_ok && tid == 0) atomicAdd(err, 1u);
-    // the lists of this slice are filled and ordered in LDS (the position list's space: every thread holds its positions in registers by now)
-    // and copied out whole; only a slice with more list words than that space fills them in memory
+    // the lists of this slice are filled and ordered in LDS and copied out whole; only a slice with more list words than that space fills them in memory
     uint32_t* stage = mlist;
     const bool staged = tot <= match_cap;
     for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
@@ -208,12 +258,12 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     for (uint32_t u = 0; u < n_round; u++) {
         const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
         if (i >= P) continue;
-        const uint32_t h = p_hash[pos0 + i], pg = p_g[pos0 + i];
+        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], pg = p_g[pos0 + i];
         uint32_t a = seed_bucket(h, NB) - h0;
         if (a >= nh) continue;
         unsigned long long v = slots[a];
         while ((uint32_t)(v >> 32) != h && a + 1 < phys) v = slots[++a];             // present by construction (unless the slice overflowed: err is set)
-        if ((uint32_t)(v >> 32) != h) continue;
+        if ((uint32_t)(v >> 32) != h || v == TAB_EMPTY) continue;                     // (an empty slot reads as hash 0xFFFFFFFF)
         const uint32_t x = (uint32_t)v;
         if (x == TAB_REPETITIVE) { const uint64_t gi = pos0 + i; atomicOr(&p_rep[gi >> 5], 1u << (gi & 31u)); }
         else if (x == SLOT_PENDING) {
@@ -310,6 +360,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     // table geometry from the position counts alone (two home slots per POSITION, at least as many as per distinct seed): nothing has to come back
     // from the device before the tables are allocated
     ss->dist_off.assign(ng + 1, 0); ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0); ss->ms_off.assign(ng + 1, 0);
+    std::vector<uint32_t> slice_first(ng + 1, 0);                                   // (genome, slice) -> index of the slice's position list
     std::vector<uint2> blocks[8];                                                   // (genome, slice), dealt to eight queues by genome: the slices of a genome
     for (uint32_t g = 0; g < ng; g++) {                                             // run on one XCD and share its seed arrays through that L2
         const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
@@ -317,6 +368,8 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
         const uint32_t n_sl = (nb + TAB_SLICE - 1) / TAB_SLICE;
         ss->n_buckets[g] = nb;
+        if ((uint64_t)slice_first[g] + n_sl >= 0xFFFFFFF0ull) throw Error("too many table slices in one build; split the batch");
+        slice_first[g + 1] = slice_first[g] + n_sl;
         ss->tab_off[g + 1] = ss->tab_off[g] + nb + (uint64_t)n_sl * TAB_SLACK;
         ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / TAB_FILTER_HOMES) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
         // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
@@ -344,13 +397,20 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
         const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TAB_SLICE, 4 * BUILD_THREADS);
+        uint32_t* d_sf = ctx->arena.get<uint32_t>(ng + 1); h2d(d_sf, slice_first.data(), (ng + 1) * 4, ctx->stream);
+        uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
+        uint2* d_ps = ctx->arena.get<uint2>(P + 1);
+        SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
+        check_launch("slice_positions");
         if (!blk.empty()) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)match_cap * 4;
 #ifndef SKANI_EMU
             static size_t attr_lds = 0;
             if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
 #endif
-            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), BUILD_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
+            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), BUILD_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
+                       (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
                        (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
                        BP_CHAIN_BAND / ss->params.c, match_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
             check_launch("build_tables");
