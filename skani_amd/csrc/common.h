@@ -85,7 +85,7 @@ struct SeedTile {
 //                                ascending; code = count - 1 for 2..4 occurrences (most lists: the join then needs no look at the list head), else 0
 //   x = TAB_REPETITIVE           more than band occurrences: the join drops the seed entirely (chain.rs:694-696)
 constexpr uint64_t TAB_EMPTY = ~0ull;
-constexpr uint32_t TAB_SLICE_SHIFT = 12, TAB_SLICE = 1u << TAB_SLICE_SHIFT, TAB_SLACK = 128;
+constexpr uint32_t TAB_SLICE_SHIFT = 11, TAB_SLICE = 1u << TAB_SLICE_SHIFT, TAB_SLACK = 128;
 constexpr uint32_t TAB_LISTED = 0x80000000u, TAB_REPETITIVE = 0xFFFFFFFDu, TAB_OFF_BITS = 29, TAB_OFF_MASK = (1u << TAB_OFF_BITS) - 1u;   // list offsets stay below TAB_OFF_MASK - 8: no payload equals
                                                                                                                           // TAB_REPETITIVE or all ones (hash 0xFFFFFFFF | all ones would read as an empty slot)
 __host__ __device__ __forceinline__ uint32_t tab_list_code(uint32_t x) { return (x >> TAB_OFF_BITS) & 3u; }   // 0: count at the list head, else count - 1

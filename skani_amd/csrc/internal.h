@@ -179,6 +179,7 @@ void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit);   // may redirect the pointers to the sorted arrays (arena)
 void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int begin_bit = 0);   // stable on bits [begin_bit, end_bit)
+void sort_segments_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, uint32_t n_seg, const uint64_t* d_off, const uint64_t* h_off, int end_bit);   // every segment [off[s], off[s+1]) on bits [0, end_bit)
 
 // ---- pack_seed.hip
 void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);

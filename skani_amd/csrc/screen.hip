@@ -21,15 +21,25 @@ __device__ __forceinline__ uint32_t seg_of64(const uint64_t* off, uint32_t n_seg
     return lo;
 }
 
-// key = marker << 22 | is_query << 21 | genome
+// key = (marker's low 10 bits << 22 | is_query << 21 | genome) << 32 | marker >> 10.  The incidence lists are sorted by the keys' LOW 32 bits only --
+// the marker's leading 16 bases: half the radix passes of a full sort; the incidences of one marker then sit somewhere inside their prefix group,
+// in no particular order, and the count kernels walk the group and compare whole markers.  Distinct markers that share a prefix are rare (tens
+// of millions of markers over 2^32 prefixes).  The sorted field sits in the low bits because rocPRIM 4.2's radix_sort_keys with begin_bit > 0
+// returns unsorted output for 1,200 .. 1,000,000 keys (tools/exp/rocprim_bits.hip; sorting bits [0, 32) is fine at every size).
+constexpr int SCREEN_SORT_BITS = 32;
+constexpr uint64_t SCREEN_MARKER_MASK = ~(((1ull << (ID_BITS + 1)) - 1ull) << 32);         // everything but is_query and genome
+__device__ __forceinline__ uint32_t skey_genome(uint64_t key) { return (uint32_t)(key >> 32) & (uint32_t)ID_MASK; }
+__device__ __forceinline__ uint32_t skey_prefix(uint64_t key) { return (uint32_t)key; }
+__device__ __forceinline__ bool skey_same_marker(uint64_t a, uint64_t b) { return ((a ^ b) & SCREEN_MARKER_MASK) == 0; }
 __global__ __launch_bounds__(256) void screen_keys_kernel(const uint64_t* markers, const uint64_t* mk_off, uint32_t ng, uint64_t n,
                                                           uint32_t is_query, uint64_t* keys) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = (markers[i] << (ID_BITS + 1)) | ((uint64_t)is_query << ID_BITS) | seg_of64(mk_off, ng, i);
+    const uint64_t m = markers[i];
+    keys[i] = ((((m & 0x3FFull) << (ID_BITS + 1)) | ((uint64_t)is_query << ID_BITS) | seg_of64(mk_off, ng, i)) << 32) | (m >> 10);
 }
 
-// triangle: incidence (m, a) pairs with every later incidence (m, b), b > a  ->  count[a - row0][b]
+// triangle: incidence (m, a) pairs with every later incidence (m, b) of its prefix group  ->  count[min(a, b) - row0][max(a, b)]
 // The counters are kept once per XCD (planes): a device-scope atomic leaves the XCD's L2 for the fabric (~20 M of them per step at 24 G/s),
 // while an atomic on memory that only this XCD touches during the kernel can stay in its L2 (workgroup scope = no sc1 write-through; the L2
 // itself is what makes it atomic among the XCD's CUs).  The plane is chosen by the hardware's XCC id, not by the block number.  The
@@ -61,33 +71,37 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
                                                                uint32_t* cnt, uint32_t n_planes, uint64_t plane) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const uint64_t key = keys[e], marker = key >> (ID_BITS + 1);
-    const uint32_t a = (uint32_t)(key & ID_MASK);
-    if (a < row0 || a >= row0 + rows) return;
-    uint32_t* row = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull) + (uint64_t)(a - row0) * ncols;
+    const uint64_t key = keys[e];
+    const uint32_t a = skey_genome(key), prefix = skey_prefix(key);
+    uint32_t* mine = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull);
     for (uint64_t f = e + 1; f < n; f++) {
         const uint64_t k2 = keys[f];
-        if ((k2 >> (ID_BITS + 1)) != marker) break;
-        if (n_planes > 1) count_local(&row[(uint32_t)(k2 & ID_MASK)]); else atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+        if (skey_prefix(k2) != prefix) break;
+        if (!skey_same_marker(k2, key)) continue;
+        const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
+        if (lo < row0 || lo >= row0 + rows) continue;
+        uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
+        if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
     }
 }
 
-// two sets, separately sorted key arrays: a query incidence (m, q) finds m's run in the refs' keys by binary search.  The refs'
+// two sets, separately sorted key arrays: a query incidence (m, q) finds m's prefix group in the refs' keys by binary search.  The refs'
 // sorted keys are cached in the sketch set (a database is screened many times; its index is built once).
 __global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* qkeys, uint64_t nq, const uint64_t* rkeys, uint64_t nr, uint32_t row0, uint32_t rows,
                                                                uint32_t ncols, uint32_t* cnt) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nq) return;
-    const uint64_t key = qkeys[e], marker = key >> (ID_BITS + 1);
-    const uint32_t q = (uint32_t)(key & ID_MASK);
+    const uint64_t key = qkeys[e];
+    const uint32_t q = skey_genome(key);
     if (q < row0 || q >= row0 + rows) return;
-    uint64_t lo = 0, hi = nr;                                                        // first ref key with marker >= m
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((rkeys[mid] >> (ID_BITS + 1)) < marker) lo = mid + 1; else hi = mid; }
+    const uint32_t prefix = skey_prefix(key);
+    uint64_t lo = 0, hi = nr;                                                        // first ref key of the prefix group
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (skey_prefix(rkeys[mid]) < prefix) lo = mid + 1; else hi = mid; }
     uint32_t* row = cnt + (uint64_t)(q - row0) * ncols;
     for (uint64_t f = lo; f < nr; f++) {
         const uint64_t k2 = rkeys[f];
-        if ((k2 >> (ID_BITS + 1)) != marker) break;
-        atomicAdd(&row[(uint32_t)(k2 & ID_MASK)], 1u);
+        if (skey_prefix(k2) != prefix) break;
+        if (skey_same_marker(k2, key)) atomicAdd(&row[skey_genome(k2)], 1u);
     }
 }
 
@@ -163,7 +177,7 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set) {
     if (MR) {
         SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, set->screen_keys.p);
         check_launch("screen_keys");
-        sort_keys_u64(ctx, set->screen_keys.p, MR, 64);
+        sort_keys_u64(ctx, set->screen_keys.p, MR, SCREEN_SORT_BITS);
     }
     dsync(ctx->stream);
 }
@@ -186,8 +200,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         SKH_LAUNCH(screen_keys_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, n_genomes, n,
                    is_query, out);
         check_launch("screen_keys");
-        sort_keys_u64(ctx, out, n, 64);     // all 64 bits: (marker, side, genome) are distinct keys, so the order does not lean on the sort being stable
-                                             // (rocPRIM's path for mid-sized inputs is not: sorting bits [22, 64) only scrambled equal markers at 28k keys)
+        sort_keys_u64(ctx, out, n, SCREEN_SORT_BITS);          // nothing leans on the order inside a prefix group
     };
     // the set's (marker, genome) incidences sorted by marker are cached in the set: built on first use, or ahead of time by prepare_screen_keys
     // (skh_sketch_genomes does that on its second stream while the seed tables are built, which takes the sort off the triangle's critical path)

@@ -132,17 +132,19 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
     }
 }
 
-__global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ sl_start,
+constexpr uint32_t TABLE_THREADS = 256;                 // workgroup of build_tables_kernel
+constexpr uint32_t TABLE_MATCH_MAX = 2048;              // positions of a slice its workgroup holds in registers (more: the slice re-scans the genome)
+__global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ sl_start,
                                                             const uint32_t* __restrict__ sl_cnt, const uint2* __restrict__ p_slice, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
                                                             const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ tab_off,
-                                                            const uint64_t* __restrict__ bmap_off, const uint64_t* __restrict__ ms_off, uint32_t band, uint32_t match_cap,
+                                                            const uint64_t* __restrict__ bmap_off, const uint64_t* __restrict__ ms_off, uint32_t band, uint32_t match_cap, uint32_t stage_cap,
                                                             uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* ms, uint32_t* ms_used, uint32_t* n_distinct,
                                                             uint32_t* p_rep, uint32_t* err) {
     SKH_DYN_SMEM(smem);
     unsigned long long* slots = (unsigned long long*)smem;                          // TAB_SLICE + TAB_SLACK
     uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // the slice's filter words (common.h): TAB_SLICE / TAB_FILTER_HOMES
-    uint32_t* mlist = lbm + TAB_SLICE / TAB_FILTER_HOMES;                                         // match_cap words: the slice's seed lists are assembled here
-    __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
+    uint32_t* mlist = lbm + TAB_SLICE / TAB_FILTER_HOMES;                                         // stage_cap words: the slice's seed lists are assembled here
+    __shared__ uint32_t lds_scan[TABLE_THREADS / 64];
     __shared__ uint32_t ms_base, distinct;
     const uint2 gs = blk[blockIdx.x];
     if (gs.x == 0xFFFFFFFFu) return;
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
     const uint32_t h0 = sl * TAB_SLICE, nh = (NB - h0 < TAB_SLICE ? NB - h0 : TAB_SLICE), phys = nh + TAB_SLACK;   // home slots / physical slots of this slice
     const uint64_t ms0 = ms_off[g]; const uint32_t ms_cap = (uint32_t)(ms_off[g + 1] - ms0);
-    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) slots[a] = TAB_EMPTY;
-    for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += BUILD_THREADS) lbm[x] = 0;
+    for (uint32_t a = tid; a < phys; a += TABLE_THREADS) slots[a] = TAB_EMPTY;
+    for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += TABLE_THREADS) lbm[x] = 0;
     if (tid == 0) distinct = 0;
     __syncthreads();
     // ---- the slice's positions: listed by slice_positions_kernel (one per thread and round, index and hash in registers); a slice with more positions
@@ -159,21 +161,21 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     const uint32_t bi = slice_first[g] + sl, n_match = sl_cnt[bi];
     const bool dense = n_match <= match_cap;
     const uint32_t NM = dense ? n_match : P;
-    constexpr uint32_t MAX_OWN = 4;                                                  // listed positions per thread in dense mode (match_cap <= 4096)
+    constexpr uint32_t MAX_OWN = TABLE_MATCH_MAX / TABLE_THREADS;                    // listed positions per thread in dense mode
     uint32_t own[MAX_OWN], own_h[MAX_OWN];
     {
         const uint2* mine_list = p_slice + pos0 + sl_start[bi];
 #pragma unroll
         for (uint32_t u = 0; u < MAX_OWN; u++) {
             uint2 e = make_uint2(0xFFFFFFFFu, 0u);
-            if (dense && tid + u * BUILD_THREADS < NM) e = mine_list[tid + u * BUILD_THREADS];
+            if (dense && tid + u * TABLE_THREADS < NM) e = mine_list[tid + u * TABLE_THREADS];
             own[u] = e.x; own_h[u] = e.y;
         }
     }
-    const uint32_t n_round = dense ? MAX_OWN : (P + BUILD_THREADS - 1) / BUILD_THREADS;
+    const uint32_t n_round = dense ? MAX_OWN : (P + TABLE_THREADS - 1) / TABLE_THREADS;
     // ---- pass A
     for (uint32_t u = 0; u < n_round; u++) {
-        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
+        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * TABLE_THREADS + tid;
         if (i >= P) continue;
         const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], home = seed_bucket(h, NB);
         if (home - h0 >= nh) continue;
@@ -195,11 +197,11 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     // cluster's first slot and counts the smaller entries of the cluster (reads only, clusters are short: two slots on average at load 0.5, the
     // longest of a slice around thirty), then all entries move at once.  (A thread per cluster sorting by insertion: +0.9 ms per 1000 genomes.)
     {
-        constexpr uint32_t MAX_SLOTS = (TAB_SLICE + TAB_SLACK + BUILD_THREADS - 1) / BUILD_THREADS;
+        constexpr uint32_t MAX_SLOTS = (TAB_SLICE + TAB_SLACK + TABLE_THREADS - 1) / TABLE_THREADS;
         unsigned long long mine[MAX_SLOTS]; uint32_t dest[MAX_SLOTS];
 #pragma unroll
         for (uint32_t u = 0; u < MAX_SLOTS; u++) {
-            const uint32_t a = tid + u * BUILD_THREADS;
+            const uint32_t a = tid + u * TABLE_THREADS;
             mine[u] = a < phys ? slots[a] : TAB_EMPTY; dest[u] = a;
             if (mine[u] == TAB_EMPTY) continue;
             uint32_t first = a, smaller = 0;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     __syncthreads();
     // ---- pass B: thread t owns slots t, t + 1024, ... ; list storage by a workgroup scan
     uint32_t need = 0, nd = 0;
-    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+    for (uint32_t a = tid; a < phys; a += TABLE_THREADS) {
         const unsigned long long v = slots[a];
         if (v == TAB_EMPTY) continue;
         const uint32_t c = (uint32_t)v; nd++;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     if (l == 0 && nd) atomicAdd(&distinct, nd);
     __syncthreads();
     uint32_t before = 0, tot = 0;
-    for (uint32_t q = 0; q < BUILD_THREADS / 64; q++) { const uint32_t t = lds_scan[q]; if (q < w) before += t; tot += t; }
+    for (uint32_t q = 0; q < TABLE_THREADS / 64; q++) { const uint32_t t = lds_scan[q]; if (q < w) before += t; tot += t; }
     if (tid == 0) {
         ms_base = tot ? atomicAdd(&ms_used[g], tot) : 0u;
         if (distinct) atomicAdd(&n_distinct[g], distinct);
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     if (!ms_ok && tid == 0) atomicAdd(err, 1u);
     // the lists of this slice are filled and ordered in LDS and copied out whole; only a slice with more list words than that space fills them in memory
     uint32_t* stage = mlist;
-    const bool staged = tot <= match_cap;
-    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+    const bool staged = tot <= stage_cap;
+    for (uint32_t a = tid; a < phys; a += TABLE_THREADS) {
         const unsigned long long v = slots[a];
         if (v == TAB_EMPTY) continue;
         const uint32_t c = (uint32_t)v; uint32_t x;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     __syncthreads();
     // ---- pass C
     for (uint32_t u = 0; u < n_round; u++) {
-        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * BUILD_THREADS + tid;
+        const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * TABLE_THREADS + tid;
         if (i >= P) continue;
         const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], pg = p_g[pos0 + i];
         uint32_t a = seed_bucket(h, NB) - h0;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
     block_fence();
     __syncthreads();
     // ---- pass D (lists into ascending order: anchors of one query position must come out by reference position) + write-out
-    for (uint32_t a = tid; a < phys; a += BUILD_THREADS) {
+    for (uint32_t a = tid; a < phys; a += TABLE_THREADS) {
         const unsigned long long v = slots[a];
         const uint32_t x = (uint32_t)v;
         if (v != TAB_EMPTY && (x & TAB_LISTED) && x != TAB_REPETITIVE && x != SLOT_PENDING) {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(const uint2* __restr
         tab[tab_off[g] + (uint64_t)sl * (TAB_SLICE + TAB_SLACK) + a] = v;
     }
     uint32_t* gbm = bmap + bmap_off[g] + sl * (TAB_SLICE / TAB_FILTER_HOMES);
-    for (uint32_t x = tid; x < (nh + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES; x += BUILD_THREADS) gbm[x] = lbm[x];
+    for (uint32_t x = tid; x < (nh + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES; x += TABLE_THREADS) gbm[x] = lbm[x];
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -396,7 +398,8 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
         // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
-        const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TAB_SLICE, 4 * BUILD_THREADS);
+        const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
+        const uint32_t stage_cap = ctx->tune.build_match_cap ? match_cap : 1024;       // list words of a slice assembled in LDS (~150 expected: 5 % of its ~2,000 positions are listed)
         uint32_t* d_sf = ctx->arena.get<uint32_t>(ng + 1); h2d(d_sf, slice_first.data(), (ng + 1) * 4, ctx->stream);
         uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
         uint2* d_ps = ctx->arena.get<uint2>(P + 1);
@@ -404,15 +407,15 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
                    (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
         check_launch("slice_positions");
         if (!blk.empty()) {
-            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)match_cap * 4;
+            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
 #ifndef SKANI_EMU
             static size_t attr_lds = 0;
             if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
 #endif
-            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), BUILD_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
+            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
                        (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
                        (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
-                       BP_CHAIN_BAND / ss->params.c, match_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
+                       BP_CHAIN_BAND / ss->params.c, match_cap, stage_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
             check_launch("build_tables");
         }
     }
@@ -462,7 +465,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         const unsigned nb = (unsigned)((M + 255) / 256);
         SKH_LAUNCH(marker_keys_kernel, nb, 256, 0, ctx->stream, raw.p, (const uint64_t*)d_ro, ng, M);
         check_launch("marker_keys");
-        sort_keys_u64(ctx, raw.p, M, 42 + bits_for(ng));
+        sort_segments_u64(ctx, raw.p, M, ng, (const uint64_t*)d_ro, raw_off.data(), 42);   // (genome, marker) order: the raw markers are already grouped by genome
         uint32_t* head = ctx->arena.get<uint32_t>(M); uint32_t* excl = ctx->arena.get<uint32_t>(M + 1);
         SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)raw.p, M, head);
         check_launch("head_flags");
