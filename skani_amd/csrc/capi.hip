@@ -66,8 +66,13 @@ int skh_ctx_create(int device, skh_ctx** out) {
         hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
         if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
         hip_check(hipSetDevice(device), "hipSetDevice");
-        hip_check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
-        hip_check(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking), "hipStreamCreate");
+        {   // the main stream carries the critical path; the second stream's kernels (marker sets, the screen's sort) run beside it and must not hold
+            // its small kernels and copies back: highest priority for the main stream, lowest for the second
+            int lo = 0, hi = 0;
+            hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
+            hip_check(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority");
+            hip_check(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority");
+        }
 #endif
         ctx->device = device;
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
@@ -77,6 +82,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.chain_super_tiles = (uint32_t)env("SKH_TUNE_CHAIN_SUPER_TILES", ctx->tune.chain_super_tiles);
         ctx->tune.chain_dp_lds_slots = (uint32_t)env("SKH_TUNE_CHAIN_DP_LDS_SLOTS", ctx->tune.chain_dp_lds_slots);
         ctx->tune.build_match_cap = (uint32_t)env("SKH_TUNE_BUILD_MATCH_CAP", ctx->tune.build_match_cap);
+        ctx->tune.marker_lds_max = (uint32_t)env("SKH_TUNE_MARKER_LDS_MAX", ctx->tune.marker_lds_max);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
     });
@@ -167,23 +173,49 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
         finalize_metadata(ss);
         SeedOutput so;
-        { Stopwatch sw(ctx, &ctx->timings.seed_ms); seed_genomes(ctx, gs, *sp, so); }
+        // Phase times from three events on the main stream, read when the call is over: nothing waits between the seeding's last kernel (the
+        // compaction, ~0.3 ms) and the table build, whose host-side tables are prepared while that kernel runs.
+#ifndef SKANI_EMU
+        hipEvent_t ev[3];
+        for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+        struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
+        hip_check(hipEventRecord(ev[0], ctx->stream), "hipEventRecord");
+        auto book = [&] {                                                             // (the caller has synchronised)
+            hip_check(hipEventRecord(ev[2], ctx->stream), "hipEventRecord"); hip_check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
+            float a = 0, b = 0;
+            hip_check(hipEventElapsedTime(&a, ev[0], ev[1]), "event time"); hip_check(hipEventElapsedTime(&b, ev[1], ev[2]), "event time");
+            ctx->timings.seed_ms += a; ctx->timings.sketch_build_ms += b;
+        };
+#else
+        auto book = [] {};
+#endif
+        seed_genomes(ctx, gs, *sp, so, true);
+#ifndef SKANI_EMU
+        hip_check(hipEventRecord(ev[1], ctx->stream), "hipEventRecord");
+#endif
+        // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)
+        struct TailGuard { bool armed = true; ~TailGuard() { if (armed) (void)hipDeviceSynchronizeCompat(); } } tail_guard;
         ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
-        Stopwatch sw(ctx, &ctx->timings.sketch_build_ms);
-        // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) are built on
-        // the second stream meanwhile: neither fills the GPU, together they take as long as the tables alone
+        // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) and the
+        // screen's sorted incidence list are built on the second stream meanwhile
         if (flags & SKH_SKETCH_DEFER_TABLES) {                                       // markers only; the tables are built where (and if) the sketches are chained
             ss->dist_off.assign(ss->n_genomes + 1, 0);
             upload_set_offsets(ctx, ss);
             build_markers(ctx, ss, so.markers_raw, so.mk_off);
+            dsync(ctx->stream);
+            book(); tail_guard.armed = false;
             return;
         }
         TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
+#ifndef SKANI_EMU
+        hip_check(hipStreamWaitEvent(ctx->stream2, ev[1], 0), "hipStreamWaitEvent");  // the raw markers come out of the compaction kernel
+#endif
         std::swap(ctx->stream, ctx->stream2);
         try { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
         catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         build_sketch_tables_finish(ctx, ss, tb);
+        book(); tail_guard.armed = false;
     });
     ctx->arena.reset();
     if (rc != SKH_OK) { delete ss; return rc; }

@@ -58,6 +58,7 @@ struct skh_tunables {
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
+    uint32_t marker_lds_max = 0;                        // raw markers per genome the in-LDS marker-set kernel takes (0 = 8192; tests use few to force the device-wide path)
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };
@@ -179,15 +180,17 @@ void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit);   // may redirect the pointers to the sorted arrays (arena)
 void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int begin_bit = 0);   // stable on bits [begin_bit, end_bit)
-void sort_segments_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, uint32_t n_seg, const uint64_t* d_off, const uint64_t* h_off, int end_bit);   // every segment [off[s], off[s+1]) on bits [0, end_bit)
+void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit);  // bits [0, end_bit); the result lands in `out`
+uint64_t* sort_segments_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, uint32_t n_seg, const uint64_t* d_off, const uint64_t* h_off, int end_bit);   // every segment [off[s], off[s+1]) on bits [0, end_bit); returns the sorted array
 
 // ---- pack_seed.hip
 void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
     DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> markers_raw; // hash = mix32(seed); g = padded coordinate << 1 | canonical (common.h CTG_PAD)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
+    bool tail_pending = false;               // the last kernel writing these arrays is still queued on the context's stream
 };
-void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out);
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail = false);
 
 // ---- sketch_build.hip
 // needs p_seed, pos_off, contig tables (finalize_metadata) filled, and either p_g (pos == cc == null) or pos / cc = device

@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src,
     if (i < n) out[i] = src[idx[i]];
 }
 
-void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out) {
+// async_tail: a set seeded in ONE launch returns with its compaction kernel still queued (no wait, the arena not rewound): the caller queues the table
+// build behind it and prepares that build's host tables meanwhile; out.tail_pending says so
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail) {
+    out.tail_pending = false;
     const uint64_t thr = ~0ull / (uint64_t)sp.c, thr_m = ~0ull / (uint64_t)sp.marker_c;   // seeding.rs:258-259
     const size_t n_tiles = gs->tiles.size();
     const uint32_t ng = gs->n_genomes;
@@ -433,6 +436,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         tr.mark("seed: overflow + alloc + compact");
         base_s += p.ns; base_m += p.nm;
         parts.push_back(std::move(p));
+        if (async_tail && parts.size() == 1 && t0 + nt >= n_tiles) { out.tail_pending = true; break; }
         dsync(ctx->stream);
         ctx->arena.reset();
     }

@@ -175,9 +175,10 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set) {
     if (set->screen_keys.n == MR && MR) return;
     set->screen_keys.alloc(MR ? MR : 1);
     if (MR) {
-        SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, set->screen_keys.p);
+        uint64_t* raw = ctx->arena.get<uint64_t>(MR);
+        SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
         check_launch("screen_keys");
-        sort_keys_u64(ctx, set->screen_keys.p, MR, SCREEN_SORT_BITS);
+        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS);
     }
     dsync(ctx->stream);
 }
@@ -197,10 +198,11 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     const uint64_t* rkeys = nullptr;     // two sets: the refs' sorted incidence list (cached in the set)
     auto make_keys = [&](const skh_sketch_set* set, uint32_t n_genomes, uint64_t n, uint32_t is_query, uint64_t* out) {
         if (!n) return;
+        uint64_t* raw = ctx->arena.get<uint64_t>(n);
         SKH_LAUNCH(screen_keys_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, n_genomes, n,
-                   is_query, out);
+                   is_query, raw);
         check_launch("screen_keys");
-        sort_keys_u64(ctx, out, n, SCREEN_SORT_BITS);          // nothing leans on the order inside a prefix group
+        sort_keys_u64_into(ctx, raw, out, n, SCREEN_SORT_BITS);   // nothing leans on the order inside a prefix group
     };
     // the set's (marker, genome) incidences sorted by marker are cached in the set: built on first use, or ahead of time by prepare_screen_keys
     // (skh_sketch_genomes does that on its second stream while the seed tables are built, which takes the sort off the triangle's critical path)

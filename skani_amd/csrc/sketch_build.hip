@@ -134,6 +134,16 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
 
 constexpr uint32_t TABLE_THREADS = 256;                 // workgroup of build_tables_kernel
 constexpr uint32_t TABLE_MATCH_MAX = 2048;              // positions of a slice its workgroup holds in registers (more: the slice re-scans the genome)
+// The build's workgroup list: (genome, slice) pairs dealt to eight queues by genome -- the slices of a genome run on one XCD and share its seed
+// arrays through that L2 -- written by the device from two small per-genome tables (as a host array it was a 320 KB upload read over PCIe: 0.15 ms
+// in front of the build).  Entry k * 8 + x = the k-th (genome, slice) of queue x; unused entries keep genome = 0xFFFFFFFF.
+__global__ __launch_bounds__(256) void table_blocks_kernel(uint32_t ng, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ queue_pos, uint2* __restrict__ blk) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const uint32_t n_sl = slice_first[g + 1] - slice_first[g], k0 = queue_pos[g], x = g & 7u;
+    for (uint32_t s = 0; s < n_sl; s++) blk[(size_t)(k0 + s) * 8 + x] = make_uint2(g, s);
+}
+
 __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ sl_start,
                                                             const uint32_t* __restrict__ sl_cnt, const uint2* __restrict__ p_slice, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
                                                             const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ tab_off,
@@ -343,28 +353,12 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
-    upload_set_offsets(ctx, ss);
-    ss->p_rep.alloc(P / 32 + 1); dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
-    if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
-    if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
-    if (P > 0 && pos && cc) {
-        SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
-        check_launch("pack_positions");
-    }
-    if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
-        ss->p_hash.alloc(P ? P : 1);
-    if (P) {
-        SKH_LAUNCH(hash_seeds_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, P, ss->p_hash.p);
-        check_launch("hash_seeds");
-    }
-    }
     // table geometry from the position counts alone (two home slots per POSITION, at least as many as per distinct seed): nothing has to come back
     // from the device before the tables are allocated
     ss->dist_off.assign(ng + 1, 0); ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0); ss->ms_off.assign(ng + 1, 0);
     std::vector<uint32_t> slice_first(ng + 1, 0);                                   // (genome, slice) -> index of the slice's position list
-    std::vector<uint2> blocks[8];                                                   // (genome, slice), dealt to eight queues by genome: the slices of a genome
-    for (uint32_t g = 0; g < ng; g++) {                                             // run on one XCD and share its seed arrays through that L2
+    std::vector<uint32_t> queue_pos(ng + 1, 0); uint32_t queue_len[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (genome, slice) pairs are dealt to eight queues by genome (table_blocks_kernel)
+    for (uint32_t g = 0; g < ng; g++) {
         const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
         if (pg >= (1ull << 30)) throw Error("a genome with >= 2^30 seed positions does not fit the seed table's 32-bit slot fields");
         const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
@@ -379,17 +373,37 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];
         ss->ms_off[g + 1] = ss->ms_off[g] + (span >= (1ull << 30) ? 2 * pg : pg + pg / 2) + 16;
         if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
-        for (uint32_t s = 0; s < n_sl; s++) blocks[g & 7u].push_back(make_uint2(g, s));
+        queue_pos[g] = queue_len[g & 7u]; queue_len[g & 7u] += n_sl;
     }
+    size_t n_blk = 0; for (uint32_t x = 0; x < 8; x++) n_blk = std::max<size_t>(n_blk, queue_len[x]);
+    n_blk *= 8;
+    if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
     ss->tab.alloc(ss->tab_off[ng] + 8);                                              // (slack behind the last table)
     ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
-    ss->d_n_buckets.alloc(ng ? ng : 1); h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
+    ss->d_n_buckets.alloc(ng ? ng : 1); ss->p_rep.alloc(P / 32 + 1);
+    // (everything above is host work on the position counts: when the seeding's compaction kernel is still running, this is where it is overlapped --
+    // the first copy below may wait for the stream)
+    upload_set_offsets(ctx, ss);
+    dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
+    if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
+    if (P > 0 && pos && cc) {
+        SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
+        check_launch("pack_positions");
+    }
+    if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
+        ss->p_hash.alloc(P ? P : 1);
+    if (P) {
+        SKH_LAUNCH(hash_seeds_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, P, ss->p_hash.p);
+        check_launch("hash_seeds");
+    }
+    }
+    h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
     TableBuild tb; tb.n = 2 * (size_t)ng + 1;                                        // err, distinct seeds per genome, list words used per genome
     if (ng) {
-        size_t mx = 0; for (auto& q : blocks) mx = std::max(mx, q.size());
-        std::vector<uint2> blk(mx * 8, make_uint2(0xFFFFFFFFu, 0));
-        for (uint32_t x = 0; x < 8; x++) for (size_t k = 0; k < blocks[x].size(); k++) blk[k * 8 + x] = blocks[x][k];
-        uint2* d_blk = ctx->arena.get<uint2>(blk.size() ? blk.size() : 1); h2d(d_blk, blk.data(), blk.size() * sizeof(uint2), ctx->stream);
+        uint32_t* d_sf = ctx->arena.get<uint32_t>(ng + 1); h2d(d_sf, slice_first.data(), (ng + 1) * 4, ctx->stream);
+        uint32_t* d_qp = ctx->arena.get<uint32_t>(ng + 1); h2d(d_qp, queue_pos.data(), (ng + 1) * 4, ctx->stream);
+        uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
         uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
         uint64_t* d_mo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_mo, ss->ms_off.data(), (ng + 1) * 8, ctx->stream);
@@ -400,19 +414,21 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
         const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
         const uint32_t stage_cap = ctx->tune.build_match_cap ? match_cap : 1024;       // list words of a slice assembled in LDS (~150 expected: 5 % of its ~2,000 positions are listed)
-        uint32_t* d_sf = ctx->arena.get<uint32_t>(ng + 1); h2d(d_sf, slice_first.data(), (ng + 1) * 4, ctx->stream);
         uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
         uint2* d_ps = ctx->arena.get<uint2>(P + 1);
+        // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
+        SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
+        check_launch("table_blocks");
         SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
                    (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
         check_launch("slice_positions");
-        if (!blk.empty()) {
+        if (n_blk) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
 #ifndef SKANI_EMU
             static size_t attr_lds = 0;
             if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
 #endif
-            SKH_LAUNCH(build_tables_kernel, (unsigned)blk.size(), TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
+            SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
                        (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
                        (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
                        BP_CHAIN_BAND / ss->params.c, match_cap, stage_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
@@ -453,6 +469,61 @@ __global__ __launch_bounds__(256) void marker_compact_kernel(const uint64_t* key
     out[excl[i]] = keys[i] & ((1ull << 42) - 1);
 }
 
+// A genome's marker set in one workgroup: its raw markers (~5,000 for 5 Mbp at m = 1000, duplicates included) are sorted in LDS by a bitonic network,
+// duplicates dropped, and the set written back to the front of the genome's stretch of `raw`; uniq[g] = its size.  Replaces genome-tagged keys +
+// a segmented radix sort + head flags + a scan over all markers of the batch (rocPRIM's segmented sort uses scratch memory: its launch held every
+// other queue's dispatches back for ~130 us, in front of the table build -- rocpd timeline of a bench step).
+constexpr uint32_t MARKER_LDS_MAX = 8192;              // raw markers of one genome the kernel sorts (more in any genome of the batch: the device-wide path)
+constexpr uint32_t MARKER_THREADS = 1024;
+__global__ __launch_bounds__(MARKER_THREADS) void marker_set_kernel(uint64_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, uint32_t* __restrict__ uniq) {
+    SKH_DYN_SMEM(smem);
+    unsigned long long* key = (unsigned long long*)smem;                            // N entries, N = the power of two >= the genome's raw markers
+    __shared__ uint32_t lds_scan[MARKER_THREADS / 64];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    const uint64_t r0 = raw_off[g]; const uint32_t n = (uint32_t)(raw_off[g + 1] - r0);
+    if (n == 0) { if (tid == 0) uniq[g] = 0; return; }
+    uint32_t N = 64; while (N < n) N <<= 1;
+    for (uint32_t i = tid; i < N; i += MARKER_THREADS) key[i] = i < n ? raw[r0 + i] : ~0ull;   // padding sorts last
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < N / 2; t += MARKER_THREADS) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;   // the t-th compare-exchange pair of this pass
+                const unsigned long long a = key[i], b = key[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { key[i] = b; key[x] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // distinct keys, in order: flags, workgroup scan, write-out
+    constexpr uint32_t PER = MARKER_LDS_MAX / MARKER_THREADS;
+    const uint32_t per = N / MARKER_THREADS ? N / MARKER_THREADS : 1;               // consecutive entries per thread (N >= 64: threads beyond N idle)
+    uint32_t cnt = 0; unsigned long long mine[PER]; bool head[PER];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; u++) {
+        const uint32_t i = tid * per + u;
+        head[u] = false; mine[u] = 0;
+        if (u < per && i < n) { mine[u] = key[i]; head[u] = i == 0 || key[i - 1] != mine[u]; cnt += head[u] ? 1u : 0u; }
+    }
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (l == 63) lds_scan[w] = incl;
+    __syncthreads();
+    uint32_t at = incl - cnt, tot = 0;
+    for (uint32_t q = 0; q < MARKER_THREADS / 64; q++) { const uint32_t t = lds_scan[q]; if (q < w) at += t; tot += t; }
+#pragma unroll
+    for (uint32_t u = 0; u < PER; u++) if (head[u]) raw[r0 + at++] = mine[u];
+    if (tid == 0) uniq[g] = tot;
+}
+// the sets, one behind the other: markers[mk_off[g] + x] = raw[raw_off[g] + x]
+__global__ __launch_bounds__(256) void marker_gather_kernel(const uint64_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint64_t* __restrict__ mk_off,
+                                                            uint32_t ng, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = seg_of(mk_off, ng, i);
+    out[i] = raw[raw_off[g] + (i - mk_off[g])];
+}
+
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
@@ -460,14 +531,41 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
     ss->mk_off.assign(ng + 1, 0);
     if (ng >= (1u << 22)) throw Error("more than 4M genomes in one sketch set");
     if (M >= 0xFFFFFFF0ull) throw Error("too many markers for one build; split the batch");
-    if (M > 0) {
+    uint64_t max_raw = 0; for (uint32_t g = 0; g < ng; g++) max_raw = std::max(max_raw, raw_off[g + 1] - raw_off[g]);
+    const uint32_t lds_max = ctx->tune.marker_lds_max ? std::min<uint32_t>(ctx->tune.marker_lds_max, MARKER_LDS_MAX) : MARKER_LDS_MAX;
+    if (M > 0 && max_raw <= lds_max) {                                               // one workgroup per genome, everything in LDS
+        uint64_t* d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
+        uint32_t* d_uq = ctx->arena.get<uint32_t>(ng);
+        uint32_t N = 64; while (N < max_raw) N <<= 1;
+        const size_t lds = (size_t)N * 8;
+#ifndef SKANI_EMU
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)marker_set_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
+#endif
+        SKH_LAUNCH(marker_set_kernel, ng, MARKER_THREADS, lds, ctx->stream, raw.p, (const uint64_t*)d_ro, d_uq);
+        check_launch("marker_set");
+        std::vector<uint32_t> h_uq(ng);
+        d2h(h_uq.data(), d_uq, (size_t)ng * 4, ctx->stream);
+        for (uint32_t g = 0; g < ng; g++) ss->mk_off[g + 1] = ss->mk_off[g] + h_uq[g];
+        const uint64_t MU = ss->mk_off[ng];
+        ss->markers.alloc(MU);
+        ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
+        if (MU) {
+            SKH_LAUNCH(marker_gather_kernel, (unsigned)((MU + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ng, MU, ss->markers.p);
+            check_launch("marker_gather");
+        }
+        dsync(ctx->stream);
+        tr.mark("build: markers");
+        return;
+    }
+    if (M > 0) {                                                                     // a genome with more raw markers than the LDS sort takes: device-wide passes
         uint64_t* d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
         const unsigned nb = (unsigned)((M + 255) / 256);
         SKH_LAUNCH(marker_keys_kernel, nb, 256, 0, ctx->stream, raw.p, (const uint64_t*)d_ro, ng, M);
         check_launch("marker_keys");
-        sort_segments_u64(ctx, raw.p, M, ng, (const uint64_t*)d_ro, raw_off.data(), 42);   // (genome, marker) order: the raw markers are already grouped by genome
+        const uint64_t* sorted = sort_segments_u64(ctx, raw.p, M, ng, (const uint64_t*)d_ro, raw_off.data(), 42);   // (genome, marker) order: the raw markers are already grouped by genome
         uint32_t* head = ctx->arena.get<uint32_t>(M); uint32_t* excl = ctx->arena.get<uint32_t>(M + 1);
-        SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)raw.p, M, head);
+        SKH_LAUNCH(head_flags_kernel, nb, 256, 0, ctx->stream, sorted, M, head);
         check_launch("head_flags");
         exclusive_scan_u32(ctx, head, M, excl);
         uint32_t* d_mo = ctx->arena.get<uint32_t>(ng + 1);
@@ -477,7 +575,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         d2h(h_mo.data(), d_mo, (ng + 1) * 4, ctx->stream);
         for (uint32_t g = 0; g <= ng; g++) ss->mk_off[g] = h_mo[g];
         ss->markers.alloc(ss->mk_off[ng]);
-        SKH_LAUNCH(marker_compact_kernel, nb, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint32_t*)head, (const uint32_t*)excl, M, ss->markers.p);
+        SKH_LAUNCH(marker_compact_kernel, nb, 256, 0, ctx->stream, sorted, (const uint32_t*)head, (const uint32_t*)excl, M, ss->markers.p);
         check_launch("marker_compact");
     } else ss->markers.alloc(0);
     ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);

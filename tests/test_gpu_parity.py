@@ -228,6 +228,7 @@ def test_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
     monkeypatch.setenv("SKH_TUNE_CHAIN_DP_LDS_SLOTS", "1")
     monkeypatch.setenv("SKH_TUNE_JOIN_BITMAP_WORDS", "8")                # genomes with more than 256 buckets probe without the staged bitmap
+    monkeypatch.setenv("SKH_TUNE_MARKER_LDS_MAX", "40")                 # genomes with more than 40 raw markers: marker sets by the device-wide passes
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
     c = sk.Context(0)
     try:
