@@ -32,19 +32,25 @@ namespace skh {
 // ------------------------------------------------------------------------------------------------ host driver
 namespace {
 
-// chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
-bool is_switched(const skh_sketch_set* R, uint32_t r, const skh_sketch_set* Q, uint32_t q) {
-    double q_proxy, r_proxy;
-    if (Q->total_len[q] > 100000 && R->total_len[r] > 100000) {
-        q_proxy = (double)(Q->mk_off[q + 1] - Q->mk_off[q]) * (double)Q->params.c;
-        r_proxy = (double)(R->mk_off[r + 1] - R->mk_off[r]) * (double)R->params.c;
-    } else { q_proxy = (double)Q->total_len[q]; r_proxy = (double)R->total_len[r]; }
-    const double sq = q_proxy * std::min(Q->mean_ctg[q], 300000.), sr = r_proxy * std::min(R->mean_ctg[r], 300000.);
-    if (sq == sr) {                                                                 // query_file_name > ref_file_name
-        if (!Q->names.empty() && !R->names.empty()) return Q->names[q] > R->names[r];
-        return Q->rank[q] > R->rank[r];
+// per-genome inputs of the pair descriptors, gathered once per set (after its tables exist: the pointers do not move afterwards)
+static void genome_halves(const skh_sketch_set* S) {
+    std::lock_guard<std::mutex> lk(S->cache_mu);
+    if (S->halves.size() == S->n_genomes && S->n_genomes) return;
+    S->halves.resize(S->n_genomes);
+    for (uint32_t g = 0; g < S->n_genomes; g++) {
+        skh_sketch_set::GenomeHalf& h = S->halves[g];
+        h.n_pos = (uint32_t)(S->pos_off[g + 1] - S->pos_off[g]); h.pos0 = (uint32_t)S->pos_off[g];
+        h.hash = S->p_hash.p + S->pos_off[g]; h.g = S->p_g.p + S->pos_off[g]; h.rep = S->p_rep.p;
+        h.ms = S->ms.p + S->ms_off[g]; h.tab = S->tab.p + S->tab_off[g]; h.nbk = S->n_buckets[g]; h.bmap = S->bmap.p + S->bmap_off[g];
+        h.goff = S->d_goff.p + S->ctg_off[g] + g; h.host_goff = S->goff.data() + S->ctg_off[g] + g;
+        h.nctg = (uint32_t)(S->ctg_off[g + 1] - S->ctg_off[g]);
+        h.total_len = S->total_len[g]; h.q10 = S->q10[g]; h.q50 = S->q50[g]; h.q90 = S->q90[g];
+        const double cap = std::min(S->mean_ctg[g], 300000.);
+        h.score_markers = ((double)(S->mk_off[g + 1] - S->mk_off[g]) * (double)S->params.c) * cap;
+        h.score_len = (double)S->total_len[g] * cap;
+        // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
+        h.chunk_bound = (uint32_t)(S->total_len[g] / CHUNK_SIZE + 2 * (uint64_t)h.nctg + 2);
     }
-    return sq > sr;
 }
 
 // same checksum as the oracle's ora_chain_stats.anchor_checksum: (query contig, query pos, ref contig, ref pos, reverse) per anchor
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void slot_tile_kernel(uint32_t p0, uint32_t p1
     for (uint32_t t = 0; t < ngr; t++) slot_tile[(size_t)(first + t) * 8 + x] = make_uint2(t0 + t * JOIN_GROUP, p);
 }
 // returns the device slot table for pairs [p0, p1) and its length
-static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::vector<PairDesc>& pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
+static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const PairDesc* pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
                         unsigned* n_slots) {
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> qp(p1 - p0);
@@ -102,7 +108,8 @@ static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const std::vecto
 namespace {
 
 struct ChainJob {                                        // what one run over a list of pairs needs (chain_pairs fills it)
-    std::vector<PairDesc> pds; std::vector<uint32_t> chunk_bound, pair_key;
+    PairDesc* pds = nullptr; uint32_t n_pairs = 0;       // in the context's pinned buffer: copied to the device as they are
+    std::vector<uint32_t> chunk_bound, pair_key;
     std::vector<const uint32_t*> host_go_a, host_go_b;   // only with stats
     uint32_t c = 0, k = 0, band = 0;
     const GbdtModel* model = nullptr;
@@ -113,8 +120,8 @@ struct ChainJob {                                        // what one run over a 
 void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats* stats) {
     // (A join that walks all tiles of a pair in one workgroup and writes the anchors in one pass -- no probe records, no pair counts on the host -- was
     //  built and measured in round 2: 4.7 ms against 3.4 ms for count + fill; long-lived workgroups hide the probe latency worse.  DESIGN.md section 5.)
-    std::vector<PairDesc>& pds = job.pds;
-    const uint32_t NP = (uint32_t)pds.size(), band = job.band, c = job.c, k = job.k;
+    PairDesc* pds = job.pds;
+    const uint32_t NP = job.n_pairs, band = job.band, c = job.c, k = job.k;
     const GbdtModel* model = job.model; const skh_map_params& mp = job.mp;
     StageTrace tr(ctx);
     uint64_t n_tiles_all = 0;
@@ -124,7 +131,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
     }
     const uint32_t NT = (uint32_t)n_tiles_all;
-    PairDesc* d_pairs_all = upload(ctx, pds);
+    PairDesc* d_pairs_all = ctx->arena.get<PairDesc>(NP ? NP : 1);
+    h2d(d_pairs_all, pds, (size_t)NP * sizeof(PairDesc), ctx->stream);
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
     uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_hits = ctx->arena.get<uint32_t>((size_t)NT + 1);
@@ -326,8 +334,11 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     }
     const uint32_t NP = (uint32_t)n_pairs_all;
     StageTrace tr(ctx);
-    // ---- pair descriptors
-    job.pds.resize(NP); job.chunk_bound.resize(NP); job.pair_key.resize(NP);
+    // ---- pair descriptors, from the sets' per-genome halves
+    for (uint32_t x = 0; x < n_rsets; x++) genome_halves(Rsets[x]);
+    for (uint32_t x = 0; x < n_qsets; x++) genome_halves(Qsets[x]);
+    job.pds = (PairDesc*)ctx->pin_pairs.need((size_t)NP * sizeof(PairDesc)); job.n_pairs = NP;
+    job.chunk_bound.resize(NP); job.pair_key.resize(NP);
     if (stats) { job.host_go_a.resize(NP); job.host_go_b.resize(NP); }
     for (uint32_t p = 0; p < NP; p++) {
         const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
@@ -335,26 +346,29 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         const skh_sketch_set* R = Rsets[rs]; const skh_sketch_set* Q = Qsets[qs];
         const uint32_t r = pair_ref[p], q = pair_query[p];
         if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
+        const skh_sketch_set::GenomeHalf& hr = R->halves[r]; const skh_sketch_set::GenomeHalf& hq = Q->halves[q];
         PairDesc& pd = job.pds[p];
-        const bool empty = R->ctg_off[r + 1] == R->ctg_off[r] || Q->ctg_off[q + 1] == Q->ctg_off[q];   // chain.rs:618-620
-        const bool sw = is_switched(R, r, Q, q);
-        const skh_sketch_set* A = sw ? R : Q; const uint32_t ga = sw ? r : q;       // enumerated side (chain.rs:652-660)
-        const skh_sketch_set* B = sw ? Q : R; const uint32_t gb = sw ? q : r;
-        pd.a_n = empty ? 0 : (uint32_t)(A->pos_off[ga + 1] - A->pos_off[ga]);
-        pd.a_hash = A->p_hash.p + A->pos_off[ga]; pd.a_g = A->p_g.p + A->pos_off[ga]; pd.a_rep = A->p_rep.p; pd.a_pos0 = (uint32_t)A->pos_off[ga];
-        pd.b_ms = B->ms.p + B->ms_off[gb]; pd.b_tab = B->tab.p + B->tab_off[gb]; pd.b_nbk = B->n_buckets[gb];
-        pd.b_bmap = B->bmap.p + B->bmap_off[gb];
+        const bool empty = hr.nctg == 0 || hq.nctg == 0;                              // chain.rs:618-620
+        // chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
+        const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
+        const double sq = both_long ? hq.score_markers : hq.score_len, sr = both_long ? hr.score_markers : hr.score_len;
+        bool sw;
+        if (sq == sr) sw = (!Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
+        else sw = sq > sr;
+        const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
+        const uint32_t gb = sw ? q : r;
+        pd.a_n = empty ? 0 : A.n_pos;
+        pd.a_hash = A.hash; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
+        pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap;
         pd.flags = sw ? 4u : 0u;
         pd.tile0 = 0;
-        pd.ref_total_len = R->total_len[r]; pd.query_total_len = Q->total_len[q];
-        pd.q10_q = Q->q10[q]; pd.q50_q = Q->q50[q]; pd.q90_q = Q->q90[q]; pd.q10_r = R->q10[r]; pd.q50_r = R->q50[r]; pd.q90_r = R->q90[r];
-        pd.nctg_q = (uint32_t)(Q->ctg_off[q + 1] - Q->ctg_off[q]); pd.nctg_r = (uint32_t)(R->ctg_off[r + 1] - R->ctg_off[r]);
-        pd.a_goff = A->d_goff.p + A->ctg_off[ga] + ga; pd.b_goff = B->d_goff.p + B->ctg_off[gb] + gb;
-        pd.a_nctg = (uint32_t)(A->ctg_off[ga + 1] - A->ctg_off[ga]); pd.b_nctg = (uint32_t)(B->ctg_off[gb + 1] - B->ctg_off[gb]);
-        if (stats) { job.host_go_a[p] = A->goff.data() + A->ctg_off[ga] + ga; job.host_go_b[p] = B->goff.data() + B->ctg_off[gb] + gb; }
+        pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;
+        pd.q10_q = hq.q10; pd.q50_q = hq.q50; pd.q90_q = hq.q90; pd.q10_r = hr.q10; pd.q50_r = hr.q50; pd.q90_r = hr.q90;
+        pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg;
+        pd.a_goff = A.goff; pd.b_goff = B.goff; pd.a_nctg = A.nctg; pd.b_nctg = B.nctg;
+        if (stats) { job.host_go_a[p] = A.host_goff; job.host_go_b[p] = B.host_goff; }
         job.pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                        // tiles probing the same sketch share an XCD
-        // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
-        job.chunk_bound[p] = (uint32_t)(A->total_len[ga] / CHUNK_SIZE + 2 * (A->ctg_off[ga + 1] - A->ctg_off[ga]) + 2);
+        job.chunk_bound[p] = A.chunk_bound;
     }
     tr.mark("host: pair descriptors");
     chain_run(ctx, job, out, stats);

@@ -39,6 +39,8 @@ inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(
 inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
 inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
 inline void dsync(devStream_t) {}
+inline void* pin_alloc(size_t n) { return malloc(n ? n : 1); }
+inline void pin_free(void* p) { free(p); }
 inline void check_launch(const char*) {}
 inline int hipDeviceSynchronizeCompat() { return 0; }
 #else
@@ -79,9 +81,18 @@ inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_c
 inline void dzero(void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, 0, n, s), "memset"); }
 inline void dfill(void* d, int byte, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, byte, n, s), "memset"); }
 inline void dsync(devStream_t s) { hip_check(hipStreamSynchronize(s), "stream sync"); }
+inline void* pin_alloc(size_t n) { void* p = nullptr; hip_check(hipHostMalloc(&p, n ? n : 1, hipHostMallocPortable), "hipHostMalloc"); return p; }
+inline void pin_free(void* p) { (void)hipHostFree(p); }
 inline void check_launch(const char* what) { hip_check(hipGetLastError(), what); }
 inline int hipDeviceSynchronizeCompat() { return (int)hipDeviceSynchronize(); }
 #endif
+
+// grow-only pinned host buffer (descriptor arrays that are built on the host and copied to the device as they are: no staging copy)
+struct PinBuf {
+    void* p = nullptr; size_t cap = 0;
+    ~PinBuf() { if (p) pin_free(p); }
+    void* need(size_t bytes) { if (bytes > cap) { if (p) pin_free(p); p = nullptr; cap = 0; p = pin_alloc(bytes + bytes / 2); cap = bytes + bytes / 2; } return p; }
+};
 
 // RAII device buffer
 template <class T> struct DBuf {

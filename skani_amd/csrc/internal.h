@@ -72,6 +72,7 @@ struct skh_ctx {
     skh::Arena arena;
     skh::GbdtModel model_c125, model_c200;
     skh_timings timings{};
+    skh::PinBuf pin_pairs;                               // the chaining's pair descriptors (host side)
     bool screen_planes_checked = false;                  // the per-XCD count planes of the triangle screen passed their self-test (screen.hip)
 };
 
@@ -110,6 +111,13 @@ struct skh_sketch_set {
     std::vector<uint64_t> total_len;
     std::vector<double> mean_ctg;
     std::vector<float> q10, q50, q90;
+    // everything the chaining's pair descriptors take from one genome, gathered once per set (chain.hip genome_halves)
+    struct GenomeHalf {
+        const uint32_t *hash, *g, *rep, *ms, *bmap, *goff; const uint64_t* tab; const uint32_t* host_goff;
+        uint32_t n_pos, pos0, nbk, nctg, chunk_bound; uint64_t total_len; float q10, q50, q90;
+        double score_markers, score_len;                  // switch_qr's two candidate scores (chain.rs:625-649)
+    };
+    mutable std::vector<GenomeHalf> halves;
     std::vector<uint32_t> rank;
     std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays
