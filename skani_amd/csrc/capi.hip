@@ -211,7 +211,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         hip_check(hipStreamWaitEvent(ctx->stream2, ev[1], 0), "hipStreamWaitEvent");  // the raw markers come out of the compaction kernel
 #endif
         std::swap(ctx->stream, ctx->stream2);
-        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
+        try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
         catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         build_sketch_tables_finish(ctx, ss, tb);

@@ -96,4 +96,12 @@ constexpr uint32_t TAB_FILTER_SHIFT = 4, TAB_FILTER_HOMES = 1u << TAB_FILTER_SHI
 __host__ __device__ __forceinline__ uint32_t tab_filter_bits(uint32_t hash) { return (1u << (hash & 31u)) | (1u << ((hash >> 5) & 31u)); }
 __host__ __device__ __forceinline__ uint32_t tab_slot(uint32_t home) { return home + (home >> TAB_SLICE_SHIFT) * TAB_SLACK; }   // physical slot of a home slot
 
+// Incidence key of the marker screen (screen.hip): (marker's low 10 bits << 22 | is_query << 21 | genome) << 32 | marker >> 10.  The lists are sorted by
+// the LOW 32 bits only -- the marker's leading 16 bases.
+constexpr int SCREEN_ID_BITS = 21;                      // genome id field inside the key (a marker is 42 bits)
+constexpr uint64_t SCREEN_ID_MASK = (1ull << SCREEN_ID_BITS) - 1;
+__host__ __device__ __forceinline__ uint64_t screen_key(uint64_t marker, uint32_t is_query, uint32_t genome) {
+    return ((((marker & 0x3FFull) << (SCREEN_ID_BITS + 1)) | ((uint64_t)is_query << SCREEN_ID_BITS) | genome) << 32) | (marker >> 10);
+}
+
 }  // namespace skh

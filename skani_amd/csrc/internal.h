@@ -211,11 +211,11 @@ void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, uint64_t** screen_keys_raw = nullptr);   // screen_keys_raw: also the screen's unsorted incidence keys (arena), when the fast path can make them
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set);
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr);
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)

@@ -12,8 +12,8 @@
 
 namespace skh {
 
-constexpr int ID_BITS = 21;                       // genome id field inside the sort key (marker is 42 bits)
-constexpr uint64_t ID_MASK = (1ull << ID_BITS) - 1;
+constexpr int ID_BITS = SCREEN_ID_BITS;            // genome id field inside the sort key (common.h screen_key; a marker is 42 bits)
+constexpr uint64_t ID_MASK = SCREEN_ID_MASK;
 
 __device__ __forceinline__ uint32_t seg_of64(const uint64_t* off, uint32_t n_seg, uint64_t i) {
     uint32_t lo = 0, hi = n_seg;
@@ -35,8 +35,7 @@ __global__ __launch_bounds__(256) void screen_keys_kernel(const uint64_t* marker
                                                           uint32_t is_query, uint64_t* keys) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t m = markers[i];
-    keys[i] = ((((m & 0x3FFull) << (ID_BITS + 1)) | ((uint64_t)is_query << ID_BITS) | seg_of64(mk_off, ng, i)) << 32) | (m >> 10);
+    keys[i] = screen_key(markers[i], is_query, seg_of64(mk_off, ng, i));
 }
 
 // triangle: incidence (m, a) pairs with every later incidence (m, b) of its prefix group  ->  count[min(a, b) - row0][max(a, b)]
@@ -167,7 +166,8 @@ static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __p
 }
 
 // fills the set's cache of sorted (marker, genome) incidences on the context's current stream (no-op when present)
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set) {
+// `premade`: the set's keys in (genome, marker) order, already written by the marker build (scratch: sorted from there into the cache)
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade) {
     const uint32_t ng = set->n_genomes;
     if (!ng || ng > ID_MASK) return;
     const uint64_t MR = set->mk_off[ng];
@@ -175,9 +175,12 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set) {
     if (set->screen_keys.n == MR && MR) return;
     set->screen_keys.alloc(MR ? MR : 1);
     if (MR) {
-        uint64_t* raw = ctx->arena.get<uint64_t>(MR);
-        SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
-        check_launch("screen_keys");
+        uint64_t* raw = premade;
+        if (!raw) {
+            raw = ctx->arena.get<uint64_t>(MR);
+            SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
+            check_launch("screen_keys");
+        }
         sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS);
     }
     dsync(ctx->stream);

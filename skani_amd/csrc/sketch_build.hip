@@ -515,16 +515,21 @@ __global__ __launch_bounds__(MARKER_THREADS) void marker_set_kernel(uint64_t* __
     for (uint32_t u = 0; u < PER; u++) if (head[u]) raw[r0 + at++] = mine[u];
     if (tid == 0) uniq[g] = tot;
 }
-// the sets, one behind the other: markers[mk_off[g] + x] = raw[raw_off[g] + x]
+// the sets, one behind the other: markers[mk_off[g] + x] = raw[raw_off[g] + x]; with `keys` also the screen's (marker, genome) incidence keys of the
+// same entries (screen.hip screen_key), still in (genome, marker) order.  One workgroup per genome: no search for the genome of an entry.
 __global__ __launch_bounds__(256) void marker_gather_kernel(const uint64_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint64_t* __restrict__ mk_off,
-                                                            uint32_t ng, uint64_t n, uint64_t* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t g = seg_of(mk_off, ng, i);
-    out[i] = raw[raw_off[g] + (i - mk_off[g])];
+                                                            uint64_t* __restrict__ out, uint64_t* __restrict__ keys) {
+    const uint32_t g = blockIdx.x;
+    const uint64_t r0 = raw_off[g], m0 = mk_off[g]; const uint32_t n = (uint32_t)(mk_off[g + 1] - m0);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t m = raw[r0 + i];
+        out[m0 + i] = m;
+        if (keys) keys[m0 + i] = screen_key(m, 0u, g);
+    }
 }
 
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, uint64_t** screen_keys_raw) {
+    if (screen_keys_raw) *screen_keys_raw = nullptr;
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
     StageTrace tr(ctx);
@@ -551,8 +556,10 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         ss->markers.alloc(MU);
         ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
         if (MU) {
-            SKH_LAUNCH(marker_gather_kernel, (unsigned)((MU + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ng, MU, ss->markers.p);
+            uint64_t* keys = (screen_keys_raw && ng <= SCREEN_ID_MASK) ? ctx->arena.get<uint64_t>(MU) : nullptr;   // the screen's incidence keys, made on the way
+            SKH_LAUNCH(marker_gather_kernel, ng, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ss->markers.p, keys);
             check_launch("marker_gather");
+            if (screen_keys_raw) *screen_keys_raw = keys;
         }
         dsync(ctx->stream);
         tr.mark("build: markers");
