@@ -66,13 +66,8 @@ int skh_ctx_create(int device, skh_ctx** out) {
         hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
         if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
         hip_check(hipSetDevice(device), "hipSetDevice");
-        {   // the main stream carries the critical path; the second stream's kernels (marker sets, the screen's sort) run beside it and must not hold
-            // its small kernels and copies back: highest priority for the main stream, lowest for the second
-            int lo = 0, hi = 0;
-            hip_check(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
-            hip_check(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority");
-            hip_check(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority");
-        }
+        hip_check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking), "hipStreamCreate");   // (stream priorities were measured: no effect on how the two share the GPU)
 #endif
         ctx->device = device;
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
