@@ -139,7 +139,6 @@ struct skh_sketch_set {
     bool tables_built = false;                     // seed tables / filter / list storage exist (skh_sketch_genomes_ex may defer them: a rank of a distributed
                                                    // triangle indexes only the sketches it ends up chaining; ensure_tables builds them on first use)
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off;
-    skh::DBuf<uint32_t> d_n_buckets;
 };
 
 namespace skh {

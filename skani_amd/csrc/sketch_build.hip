@@ -380,7 +380,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
     ss->tab.alloc(ss->tab_off[ng] + 8);                                              // (slack behind the last table)
     ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
-    ss->d_n_buckets.alloc(ng ? ng : 1); ss->p_rep.alloc(P / 32 + 1);
+    ss->p_rep.alloc(P / 32 + 1);
     // (everything above is host work on the position counts: when the seeding's compaction kernel is still running, this is where it is overlapped --
     // the first copy below may wait for the stream)
     upload_set_offsets(ctx, ss);
@@ -398,17 +398,21 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         check_launch("hash_seeds");
     }
     }
-    h2d(ss->d_n_buckets.p, ss->n_buckets.data(), ng * 4, ctx->stream);
     TableBuild tb; tb.n = 2 * (size_t)ng + 1;                                        // err, distinct seeds per genome, list words used per genome
     if (ng) {
-        uint32_t* d_sf = ctx->arena.get<uint32_t>(ng + 1); h2d(d_sf, slice_first.data(), (ng + 1) * 4, ctx->stream);
-        uint32_t* d_qp = ctx->arena.get<uint32_t>(ng + 1); h2d(d_qp, queue_pos.data(), (ng + 1) * 4, ctx->stream);
-        uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
-        uint64_t* d_to = ctx->arena.get<uint64_t>(ng + 1); h2d(d_to, ss->tab_off.data(), (ng + 1) * 8, ctx->stream);
-        uint64_t* d_bo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_bo, ss->bmap_off.data(), (ng + 1) * 8, ctx->stream);
-        uint64_t* d_mo = ctx->arena.get<uint64_t>(ng + 1); h2d(d_mo, ss->ms_off.data(), (ng + 1) * 8, ctx->stream);
-        uint32_t* d_back = ctx->arena.get<uint32_t>(tb.n); dzero(d_back, tb.n * 4, ctx->stream);
+        // the build's small tables in ONE upload (each copy in front of the first kernel is a 5 us blit plus its launch):
+        // tab_off, bmap_off, ms_off (u64 x ng+1) | slice_first, queue_pos (u32 x ng+1) | n_buckets (u32 x ng) | the zeroed counters read back at the end
+        const size_t n64 = 3 * ((size_t)ng + 1), n32 = 2 * ((size_t)ng + 1) + ng + tb.n;
+        std::vector<uint64_t> pack(n64 + (n32 + 1) / 2, 0);
+        uint64_t* h64 = pack.data(); uint32_t* h32 = (uint32_t*)(pack.data() + n64);
+        memcpy(h64, ss->tab_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + ng + 1, ss->bmap_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + 2 * ((size_t)ng + 1), ss->ms_off.data(), ((size_t)ng + 1) * 8);
+        memcpy(h32, slice_first.data(), ((size_t)ng + 1) * 4); memcpy(h32 + ng + 1, queue_pos.data(), ((size_t)ng + 1) * 4); memcpy(h32 + 2 * ((size_t)ng + 1), ss->n_buckets.data(), (size_t)ng * 4);
+        uint64_t* d_pack = ctx->arena.get<uint64_t>(pack.size()); h2d(d_pack, pack.data(), pack.size() * 8, ctx->stream);
+        uint64_t* d_to = d_pack; uint64_t* d_bo = d_pack + ng + 1; uint64_t* d_mo = d_pack + 2 * ((size_t)ng + 1);
+        uint32_t* d32 = (uint32_t*)(d_pack + n64);
+        uint32_t* d_sf = d32; uint32_t* d_qp = d32 + ng + 1; uint32_t* d_nb = d32 + 2 * ((size_t)ng + 1); uint32_t* d_back = d_nb + ng;
         tb.d_back = d_back;
+        uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
         dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
         // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
         // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
@@ -420,7 +424,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
         check_launch("table_blocks");
         SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint32_t*)ss->d_n_buckets.p, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
+                   (const uint32_t*)d_nb, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
         check_launch("slice_positions");
         if (n_blk) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
@@ -430,7 +434,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
 #endif
             SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
                        (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
-                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)ss->d_n_buckets.p, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
+                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
                        BP_CHAIN_BAND / ss->params.c, match_cap, stage_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
             check_launch("build_tables");
         }
