@@ -78,6 +78,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.chain_dp_lds_slots = (uint32_t)env("SKH_TUNE_CHAIN_DP_LDS_SLOTS", ctx->tune.chain_dp_lds_slots);
         ctx->tune.build_match_cap = (uint32_t)env("SKH_TUNE_BUILD_MATCH_CAP", ctx->tune.build_match_cap);
         ctx->tune.marker_lds_max = (uint32_t)env("SKH_TUNE_MARKER_LDS_MAX", ctx->tune.marker_lds_max);
+        ctx->tune.build_slice_max = (uint32_t)env("SKH_TUNE_BUILD_SLICE_MAX", ctx->tune.build_slice_max);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
     });

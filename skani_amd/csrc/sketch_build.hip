@@ -83,14 +83,14 @@ __global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restr
 constexpr uint32_t SLICE_LDS_MAX = 8192;                // slices per genome handled here (16M positions); beyond: the slices re-scan the genome
 constexpr uint32_t SLICE_NO_LIST = 0xFFFFFFFFu;
 __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_hash, const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
-                                                                      const uint32_t* __restrict__ slice_first, uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt,
-                                                                      uint2* __restrict__ p_slice) {
+                                                                      const uint32_t* __restrict__ slice_first, uint32_t max_slices, uint32_t* __restrict__ sl_start,
+                                                                      uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice) {
     __shared__ uint32_t cnt[SLICE_LDS_MAX];
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
     const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
     const uint32_t n_sl = (NB + TAB_SLICE - 1) / TAB_SLICE, s0 = slice_first[g];
-    if (n_sl > SLICE_LDS_MAX) {
+    if (n_sl > max_slices) {                                                         // (max_slices <= SLICE_LDS_MAX)
         for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) { sl_start[s0 + s] = 0; sl_cnt[s0 + s] = SLICE_NO_LIST; }
         return;
     }
@@ -424,7 +424,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
         check_launch("table_blocks");
         SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint32_t*)d_nb, (const uint32_t*)d_sf, d_ss, d_sc, d_ps);
+                   (const uint32_t*)d_nb, (const uint32_t*)d_sf, ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX, d_ss, d_sc, d_ps);
         check_launch("slice_positions");
         if (n_blk) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;

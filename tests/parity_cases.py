@@ -215,6 +215,50 @@ def case_screen_rules(ctx):
             assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri")
 
 
+def case_screen_marker_prefix_groups(ctx):
+    """The screen sorts its (marker, genome) incidences by the marker's leading 32 bits only: markers that differ in their low 10 bits share a prefix
+    group and must not be counted as shared.  Imported sketches with crafted marker sets: g0 and g1 share 600 markers exactly; g2 holds the same 600
+    prefixes with OTHER low bits (shares nothing); g3 shares 300 of g0's markers and has 300 same-prefix look-alikes."""
+    rng = np.random.default_rng(5)
+    pre = np.unique(rng.integers(0, 1 << 32, 600, dtype=np.uint64))[:600]
+    low = rng.integers(0, 512, len(pre), dtype=np.uint64)
+    m0 = (pre << np.uint64(10)) | low
+    sets = [m0, m0.copy(), (pre << np.uint64(10)) | (low + np.uint64(1)), np.concatenate([m0[:300], ((pre[300:] << np.uint64(10)) | (low[300:] ^ np.uint64(512)))])]
+    recs, osk = [], []
+    for g, mk in enumerate(sets):
+        n = 50
+        rec = dict(seed=rng.integers(0, 1 << 30, n, dtype=np.uint32), pos=np.arange(n, dtype=np.uint32) * 100, ctgcanon=np.zeros(n, np.uint32), markers=np.sort(mk),
+                   contig_lengths=np.array([600000], np.uint32), total_len=600000)
+        recs.append(rec)
+        osk.append(ora.Sketch.from_arrays(125, 15, 1000, "g%d" % g, rec["seed"], rec["pos"], rec["ctgcanon"], rec["markers"], rec["contig_lengths"], rec["total_len"]))
+    names = ["g%d" % g for g in range(len(sets))]
+    refs = ctx.import_sketches(sk.SketchParams(), recs, names=names)
+    for rescue in (True, False):
+        a, b = ctx.screen(refs, None, 0.8, 0, rescue)
+        exp = [(i, int(j)) for i in range(len(osk) - 1) for j in ora.screen_refs(osk, osk[i], 0.8, 0, rescue) if j > i]
+        assert list(zip(a.tolist(), b.tolist())) == sorted(exp), ("tri", rescue, list(zip(a.tolist(), b.tolist())), sorted(exp))
+        assert (0, 1) in exp and (0, 2) not in exp and (1, 2) not in exp
+        for rule in (0, 2):
+            a, b = ctx.screen(refs, refs, 0.8, rule, rescue)
+            exp = [(q, int(r)) for q in range(len(osk)) for r in ora.screen_refs(osk, osk[q], 0.8, rule, rescue)]
+            assert list(zip(a.tolist(), b.tolist())) == sorted(exp), ("qr", rule, rescue)
+    refs.close()
+
+
+def case_marker_set_sizes(ctx):
+    """Marker sets of a batch are made by one workgroup per genome in LDS (up to 8192 raw markers per genome), else by device-wide passes: genomes just
+    below the capacity, a batch with one genome above it, an empty one."""
+    sp = sk.SketchParams(c=30, marker_c=30)                              # every seed is a marker: ~len / 30 raw markers
+    for lens in ((100000, 243000, 700), (100000, 262000)):
+        genomes = [[("c", random_genome(n, 900 + i))] for i, n in enumerate(lens)]
+        names = ["m%d.fa" % i for i in range(len(genomes))]
+        ss = ctx.sketch_records(genomes, sp, names)
+        for g, rec in enumerate(genomes):
+            o = ora.sketch_records(rec, 30, 15, 30, names[g], 1)
+            assert np.array_equal(ss.export(g)["markers"], np.sort(o.markers())), (lens, g)
+        ss.close()
+
+
 def fragmented(root, seed, rate, lo=700, hi=9000, drop=0.1):
     """root cut into many contigs of lo..hi bases, a tenth dropped, the rest shuffled, every other one reverse-complemented."""
     rng = np.random.default_rng(seed)

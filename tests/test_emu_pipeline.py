@@ -25,6 +25,8 @@ def test_emu_viruses(ctx): pc.case_viruses_individual(ctx)
 def test_emu_triangle_synthetic(ctx): pc.case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 20)), length=120000)
 def test_emu_triangle_dense_sketches(ctx): pc.case_triangle_synthetic(ctx, params=((1, 8), (0, 3)), length=30000)   # c < 10: chain band beyond 256 anchors
 def test_emu_screen_rules(ctx): pc.case_screen_rules(ctx)
+def test_emu_screen_marker_prefix_groups(ctx): pc.case_screen_marker_prefix_groups(ctx)
+def test_emu_marker_set_sizes(ctx): pc.case_marker_set_sizes(ctx)
 def test_emu_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_emu_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
 def test_emu_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
@@ -42,6 +44,7 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_CHAIN_SUPER_TILES", "2")
     monkeypatch.setenv("SKH_TUNE_CHAIN_DP_LDS_SLOTS", "1")
     monkeypatch.setenv("SKH_TUNE_JOIN_BITMAP_WORDS", "8")                # genomes with more than 256 buckets probe without the staged bitmap
+    monkeypatch.setenv("SKH_TUNE_BUILD_SLICE_MAX", "1")                 # genomes with more than one table slice: no slice lists, the slices re-scan the genome
     monkeypatch.setenv("SKH_TUNE_MARKER_LDS_MAX", "40")                 # genomes with more than 40 raw markers: marker sets by the device-wide passes
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
     c = sk.Context(0, lib=emu_lib())
