@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     constexpr int R = 4;
     // B's occupancy filter (common.h: a word per 16 home slots, two bits per seed, ~20 KB) is staged in LDS with coalesced 16-byte loads: 85 % of
     // the probes of absent seeds end there and cost no memory request at all; the others read their home slot -- the entry
-    // itself, or the head of the short cluster it sits in (sketch_build.hip build_tables_kernel).  The kernel runs at the L2's
-    // request rate (measured: the TCC is busy 90 % of its cycles at 0.6 requests per clock and channel), so requests are what to save.
+    // itself, or the head of the short cluster it sits in (sketch_build.hip build_tables_kernel).  What the gathers cost is not L2 requests or
+    // latency but what the L1 can return (profiles/r02_join_count_ablation.md): fewer gathers is what pays.
     const uint32_t bm_words = ((pd.b_nbk + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES + 3) / 4 * 4;
     const bool use_bm = bm_words <= lds_words;
     if (use_bm) {
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
 }
 
 // Emits the anchors of the tiles at the offsets given by the tile scan, from the hit records of join_count_kernel (no second probe).  Same
-// shape: four tiles per workgroup, a wave per tile, 256 hits per round with the wave's own running offset -- no barrier at all.
+// shape: four tiles per workgroup, a wave per tile, 256 hits per round with the wave's own running offset -- no barrier at all.  The pass moves
+// 0.9 GB in and 2.4 GB out in 0.50 ms (6.6 TB/s): HBM-bound; two tiles per wave with the second tile's records prefetched changed nothing (0.52 ms).
 __global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, const uint2* slot_tile, uint32_t tile_base, const uint32_t* toff_a,
                                                         const uint32_t* tile_hits, const uint2* hits, uint32_t* anc_q, uint32_t* anc_r) {
     constexpr int R = 4;

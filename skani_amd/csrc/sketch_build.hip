@@ -414,8 +414,8 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         tb.d_back = d_back;
         uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
         dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
-        // LDS per workgroup: the slice (34 KB) + its bitmap + the list of the positions that belong to the slice -- TAB_SLICE / 2 on average (two home
-        // slots per position), the list takes twice that: 51 KB, three workgroups per CU.  Slices with more positions re-scan instead of listing.
+        // LDS per workgroup: the slice (17 KB) + its filter words + stage_cap words in which the slice's seed lists are assembled: 22 KB, seven workgroups
+        // of 256 threads per CU.  A slice takes up to match_cap positions from its list (registers); slices with more re-scan the genome.
         const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
         const uint32_t stage_cap = ctx->tune.build_match_cap ? match_cap : 1024;       // list words of a slice assembled in LDS (~150 expected: 5 % of its ~2,000 positions are listed)
         uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
