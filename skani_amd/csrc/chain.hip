@@ -176,6 +176,22 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         const uint32_t np = p1 - p0;
         const std::vector<size_t> arena_mark = ctx->arena.mark();
         if (na >= 0xFFFFFFF0ull) throw Error("a single genome pair produces more than 2^32 anchors");
+        // the fill pass needs the batch's anchor count and the tile scan only: it is queued first, and the per-pair prefix arrays of the later stages
+        // (a host loop over the pairs + four uploads, ~0.1 ms) are made while it runs
+        const uint32_t NA = (uint32_t)na;
+        const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
+        const PairDesc* d_pairs = d_pairs_all + p0;
+        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
+        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1);
+        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
+        tr.mark("tile scan");
+        if (nt) {
+            uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
+            if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
+            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
+                       t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q, anc_r);
+            check_launch("join_fill");
+        }
         // per-pair prefix arrays (batch-relative): anchors, chunks, candidate intervals, global sort scratch of the fallback selection kernel
         std::vector<uint32_t> pa0(np + 1, 0), pc0(np + 1, 0), pi0(np + 1, 0), ps0(np + 1, 0);
         for (uint32_t i = 0; i < np; i++) {
@@ -185,22 +201,9 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             const uint32_t icap = an / MIN_ANCHORS;
             pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
         }
-        const uint32_t NA = pa0[np], NC = pc0[np], NI = pi0[np], NS = ps0[np];
-        const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
-        const PairDesc* d_pairs = d_pairs_all + p0;
+        const uint32_t NC = pc0[np], NI = pi0[np], NS = ps0[np];
         uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pc0 = upload(ctx, pc0);
         uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
-        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
-        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1);
-        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
-        tr.mark("host prefix + uploads + scans");
-        if (nt) {
-            uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
-            if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
-            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
-                       t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q, anc_r);
-            check_launch("join_fill");
-        }
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
