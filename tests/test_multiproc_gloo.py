@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two and four processes, gloo backend, the sharded triangle of skani_amd.distributed.  Compute goes through
+"""N>1 path on CPU: two to eight processes, gloo backend, the sharded triangle of skani_amd.distributed.  Compute goes through
 the kernel simulator build (no GPU in this container); the point of the test is the sharding / exchange / gather logic:
 the union of the two ranks' work must equal the single-process triangle and the oracle."""
 import os
@@ -28,6 +28,9 @@ def _case(case):
         from tests.helpers import mutate, random_genome
         root = random_genome(40000, 71)
         return [[("c0", mutate(root, 0.004 + 0.003 * m, 7100 + m))] for m in range(12)], [4, 4, 4]
+    if case == "interleave8":          # eight ranks (the node size of BASELINE config 4) x two genomes; every clade is spread over four ranks
+        g = synthetic_clades(n_clades=4, members=4, length=40000, seed=81, tiny=False)
+        return [g[(k % 4) * 4 + k // 4] for k in range(16)], [2] * 8
     g = synthetic_clades(n_clades=3, members=4, length=60000, seed=51, tiny=False)
     g = [g[(k % 3) * 4 + k // 3] for k in range(12)]
     return g, {"interleave": [6, 6], "interleave4": [3, 3, 3, 3], "uneven": [5, 0, 4, 3]}[case]
@@ -49,14 +52,14 @@ def _worker(rank, world, port, q, case):
         params = sk.SketchParams()
         gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in mine], params.seeding_mode)      # file_io.rs:176
         # half of the cases sketch with deferred seed tables (what bench.py does on several GPUs): a rank then indexes only the sketches it chains
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks"))
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks", "interleave8"))
         i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, with_stats=True)
         q.put((rank, i, j, res, n, st))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense"])
+@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense", "interleave8"])
 def test_multi_rank_triangle_matches_single_process(case):
     import multiprocessing as mp
     import skani_amd as sk
@@ -94,7 +97,7 @@ def test_multi_rank_triangle_matches_single_process(case):
     assert all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))
     if case == "blocks":        # one cluster per rank: nothing travels
         assert all(s["bytes_received"] == 0 and s["n_genomes_received"] == 0 for s in stats)
-    if case in ("interleave", "interleave4", "uneven"):
+    if case in ("interleave", "interleave4", "uneven", "interleave8"):
         assert sum(s["n_genomes_received"] for s in stats) > 0 and sum(s["bytes_sent"] for s in stats) == sum(s["bytes_received"] for s in stats) > 0
     if case == "dense":         # one cluster of 66 pairs over three ranks: cut into tiles, shares within 10 % of the mean
         mean = n / world
