@@ -238,8 +238,8 @@ def file_sha(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genomes-per-gpu", type=int, default=0, help="default: 1000 on one GPU (BASELINE config 3), 1250 per GPU on several (config 4 = 10,000 on 8)")
     ap.add_argument("--mean-len", type=int, default=5_000_000)
     ap.add_argument("--order", default="", choices=["", "clade", "shuffled"], help="order of the collection: clade by clade, or shuffled like unrelated file names "
