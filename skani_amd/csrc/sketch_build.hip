@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
     }
 }
 
-constexpr uint32_t TABLE_THREADS = 256;                 // workgroup of build_tables_kernel
+constexpr uint32_t TABLE_THREADS = 256;                 // workgroup of build_tables_kernel (slice slots x threads, ms per 1000 genomes: 4096 x 1024 1.58, 4096 x 512 1.40, 2048 x 512 1.53, 2048 x 256 1.05, 1024 x 128 1.23)
 constexpr uint32_t TABLE_MATCH_MAX = 2048;              // positions of a slice its workgroup holds in registers (more: the slice re-scans the genome)
 // The build's workgroup list: (genome, slice) pairs dealt to eight queues by genome -- the slices of a genome run on one XCD and share its seed
 // arrays through that L2 -- written by the device from two small per-genome tables (as a host array it was a 320 KB upload read over PCIe: 0.15 ms
