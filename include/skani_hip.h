@@ -189,7 +189,10 @@ int skh_triangle(skh_ctx*, const skh_sketch_set*, double identity, int rescue_sm
  *   3. every rank receives, point-to-point, exactly the sketches its units need and it does not own (seed + position arrays, device memory),
  *      builds their seed tables, and chains its pairs; 4. the result rows are all-gathered, so every rank returns the whole triangle.
  * Global genome index = (number of genomes on lower ranks) + local index; ranks may hold different numbers of genomes (also none).
- * genome_rank of the local set must be the genome's rank in ONE ordering common to all ranks (switch_qr tie, chain.rs:20-22).
+ * genome_rank of the local set must be the genome's rank in ONE ordering common to all ranks, consistent with the file names' order where
+ * names were set: inside this call the switch_qr tie (chain.rs:20-22) always goes by genome_rank -- names are not exchanged, and which rank
+ * chains a pair must not decide its orientation.  A failure on one rank (out of memory, a table overflow, ...) is agreed on at the next
+ * exchange point: EVERY rank returns an error, none is left waiting in a collective.
  * A communicator either runs on RCCL (device buffers over xGMI; the library loads librccl.so.1 itself) or on host-memory collectives the
  * caller supplies (MPI, gloo, ...: the library stages device data through host buffers) -- the latter is what the CPU tests use. */
 typedef struct skh_comm skh_comm;

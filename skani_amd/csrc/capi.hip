@@ -10,8 +10,13 @@ using namespace skh;
 
 namespace {
 
+// Every entry point runs its body through here: the calling thread is bound to the context's device and its small uploads to the context's pinned
+// ring for the duration of the call; nothing unwinds across the boundary.
 template <class F> int guarded(skh_ctx* ctx, F&& f) {
-    try { f(); return SKH_OK; }
+    try {
+        if (ctx) { PinScope scope(ctx->device, &ctx->ring); f(); } else f();
+        return SKH_OK;
+    }
     catch (const std::bad_alloc&) { if (ctx) ctx->err = "out of host memory"; return SKH_ERR_NOMEM; }
     catch (const Error& e) { if (ctx) ctx->err = e.what(); return SKH_ERR_DEVICE; }
     catch (const std::invalid_argument& e) { if (ctx) ctx->err = e.what(); return SKH_ERR_INVALID; }
@@ -61,15 +66,8 @@ int skh_ctx_create(int device, skh_ctx** out) {
     skh_ctx* ctx = new (std::nothrow) skh_ctx();
     if (!ctx) return SKH_ERR_NOMEM;
     int rc = guarded(ctx, [&] {
-#ifndef SKANI_EMU
-        int n = 0;
-        hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
-        if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
-        hip_check(hipSetDevice(device), "hipSetDevice");
-        hip_check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
-        hip_check(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking), "hipStreamCreate");   // (stream priorities were measured: no effect on how the two share the GPU)
-#endif
-        ctx->device = device;
+        dev_open(device, &ctx->stream, &ctx->stream2);
+        ctx->device = device; ctx->ring.s0 = ctx->stream; ctx->ring.s1 = ctx->stream2;
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
         ctx->tune.seed_scratch_bytes = env("SKH_TUNE_SEED_SCRATCH_BYTES", ctx->tune.seed_scratch_bytes);
         ctx->tune.screen_cells = env("SKH_TUNE_SCREEN_CELLS", ctx->tune.screen_cells);
@@ -81,6 +79,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.build_slice_max = (uint32_t)env("SKH_TUNE_BUILD_SLICE_MAX", ctx->tune.build_slice_max);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
+        ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
     *out = ctx;
@@ -89,18 +88,11 @@ int skh_ctx_create(int device, skh_ctx** out) {
 
 void skh_ctx_destroy(skh_ctx* ctx) {
     if (!ctx) return;
-#ifndef SKANI_EMU
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream2);
-#endif
+    dev_drain(ctx->device, ctx->stream, ctx->stream2);
     ctx->arena.release_all();
     ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel();
     dcache_trim();                                   // hand the allocator's idle blocks back to the driver
-#ifndef SKANI_EMU
-    (void)hipStreamDestroy(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream2);
-#endif
+    dev_close(ctx->stream, ctx->stream2);
     delete ctx;
 }
 
@@ -171,26 +163,16 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         SeedOutput so;
         // Phase times from three events on the main stream, read when the call is over: nothing waits between the seeding's last kernel (the
         // compaction, ~0.3 ms) and the table build, whose host-side tables are prepared while that kernel runs.
-#ifndef SKANI_EMU
-        hipEvent_t ev[3];
-        for (auto& e : ev) hip_check(hipEventCreate(&e), "hipEventCreate");
-        struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
-        hip_check(hipEventRecord(ev[0], ctx->stream), "hipEventRecord");
+        DevEvent ev[3];
+        ev[0].record(ctx->stream);
         auto book = [&] {                                                             // (the caller has synchronised)
-            hip_check(hipEventRecord(ev[2], ctx->stream), "hipEventRecord"); hip_check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
-            float a = 0, b = 0;
-            hip_check(hipEventElapsedTime(&a, ev[0], ev[1]), "event time"); hip_check(hipEventElapsedTime(&b, ev[1], ev[2]), "event time");
-            ctx->timings.seed_ms += a; ctx->timings.sketch_build_ms += b;
+            ev[2].record(ctx->stream); ev[2].wait();
+            ctx->timings.seed_ms += DevEvent::ms(ev[0], ev[1]); ctx->timings.sketch_build_ms += DevEvent::ms(ev[1], ev[2]);
         };
-#else
-        auto book = [] {};
-#endif
         seed_genomes(ctx, gs, *sp, so, true);
-#ifndef SKANI_EMU
-        hip_check(hipEventRecord(ev[1], ctx->stream), "hipEventRecord");
-#endif
+        ev[1].record(ctx->stream);
         // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)
-        struct TailGuard { bool armed = true; ~TailGuard() { if (armed) (void)hipDeviceSynchronizeCompat(); } } tail_guard;
+        struct TailGuard { bool armed = true; ~TailGuard() { if (armed) device_sync_all(); } } tail_guard;
         ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
         // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) and the
         // screen's sorted incidence list are built on the second stream meanwhile
@@ -203,12 +185,10 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             return;
         }
         TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
-#ifndef SKANI_EMU
-        hip_check(hipStreamWaitEvent(ctx->stream2, ev[1], 0), "hipStreamWaitEvent");  // the raw markers come out of the compaction kernel
-#endif
+        ev[1].make_wait(ctx->stream2);                                                // the raw markers come out of the compaction kernel
         std::swap(ctx->stream, ctx->stream2);
         try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
-        catch (...) { std::swap(ctx->stream, ctx->stream2); (void)hipDeviceSynchronizeCompat(); throw; }
+        catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         build_sketch_tables_finish(ctx, ss, tb);
         book(); tail_guard.armed = false;

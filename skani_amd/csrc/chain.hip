@@ -317,7 +317,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
 
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats) {
+                 skh_chain_stats* stats, bool tie_by_rank) {
     if (n_pairs_all == 0) return;
     if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
     if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
@@ -356,7 +356,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
         const double sq = both_long ? hq.score_markers : hq.score_len, sr = both_long ? hr.score_markers : hr.score_len;
         bool sw;
-        if (sq == sr) sw = (!Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
+        if (sq == sr) sw = (!tie_by_rank && !Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
         else sw = sq > sr;
         const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
         const uint32_t gb = sw ? q : r;

@@ -1,8 +1,8 @@
 // dev.h -- device runtime glue for the skani-hip kernels (gfx950).
 //
-// Product builds compile this with hipcc for gfx950 only.  The single SKANI_EMU switch lets the test
-// suite compile the very same kernel sources against tests/emu/emu.h (a lockstep CPU simulator used to
-// debug kernels in a container without a GPU); it is never defined in libskani_hip.so.
+// Product builds compile this with hipcc for gfx950 only.  The one conditional below lets the test suite compile the very same kernel sources against
+// tests/emu/emu_dev.h, which gives every name of the HIP section a meaning on a lockstep CPU simulator (used to debug kernels in a container without
+// a GPU); that switch is never defined in libskani_hip.so.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -11,39 +11,22 @@
 #include <stdexcept>
 #include <string>
 
+namespace skh {
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+}
+
 #ifdef SKANI_EMU
-#include "emu.h"
-typedef int devStream_t;
-#define SKH_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    emu::launch_k(dim3(grid), dim3(block), (smem), kernel, __VA_ARGS__)
-#define SKH_DYN_SMEM(name) char* name = emu::g_blk->dyn_smem
+#include "emu_dev.h"
 #else
+// ================================================================================================ HIP (gfx950)
 #include <hip/hip_runtime.h>
 typedef hipStream_t devStream_t;
 #define SKH_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
 #define SKH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#endif
 
 namespace skh {
 
-struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
-
-#ifdef SKANI_EMU
-inline void* dmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); return p; }
-inline void dfree(void* p) { free(p); }
-inline void dcache_trim() {}
-inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
-inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
-inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }
-inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
-inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
-inline void dsync(devStream_t) {}
-inline void* pin_alloc(size_t n) { return malloc(n ? n : 1); }
-inline void pin_free(void* p) { free(p); }
-inline void check_launch(const char*) {}
-inline int hipDeviceSynchronizeCompat() { return 0; }
-#else
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -53,30 +36,41 @@ inline void hip_check(hipError_t e, const char* what) {
 void* dmalloc(size_t n);
 void dfree(void* p);
 void dcache_trim();                       // hand every cached block back to the driver
-// Small uploads (offset tables, descriptors) go through a pinned ring of the calling thread: a copy from pageable memory is staged by the runtime
-// and its first device read after the staging was measured at 130-150 us, in front of the kernels that wait for the table (rocpd timeline of a
-// bench step); from pinned memory the copy is an ordinary asynchronous DMA and the caller's buffer is free at once.  A slot is reused only after
-// the whole ring (8 MB of uploads) has gone by, with a device synchronisation at the wrap.
-struct PinRing { char* p = nullptr; size_t cap = 0, off = 0; bool tried = false; };
-inline PinRing& pin_ring() { static thread_local PinRing r; return r; }
+// Small uploads (offset tables, descriptors) go through a pinned ring that belongs to the CONTEXT the calling thread is working for (PinScope, set by
+// every entry point of the C ABI): a copy from pageable memory is staged by the runtime and its first device read after the staging was measured
+// at 130-150 us, in front of the kernels that wait for the table (rocpd timeline of a bench step); from pinned memory the copy is an ordinary
+// asynchronous DMA and the caller's buffer is free at once.  A slot is reused only after the whole ring (8 MB of uploads) has gone by, and the
+// wrap waits for the two streams of the ring's own context -- the only streams its slots are ever copied on.  The ring is freed with its context.
+struct PinRing {
+    char* p = nullptr; size_t cap = 0, off = 0; bool tried = false;
+    hipStream_t s0 = nullptr, s1 = nullptr;                                          // the owning context's streams
+    ~PinRing() { if (p) (void)hipHostFree(p); }
+};
+inline PinRing*& pin_ring_of_thread() { static thread_local PinRing* r = nullptr; return r; }
+struct PinScope {                                                                    // entry points: this thread's device is `device`, its small uploads use `ring`
+    PinRing* prev;
+    PinScope(int device, PinRing* ring) : prev(pin_ring_of_thread()) { (void)hipSetDevice(device); pin_ring_of_thread() = ring; }
+    ~PinScope() { pin_ring_of_thread() = prev; }
+};
 inline void h2d(void* d, const void* h, size_t n, devStream_t s) {
     if (!n) return;
     constexpr size_t PIN_RING = (size_t)8 << 20, PIN_MAX = (size_t)1 << 20;
-    if (n <= PIN_MAX) {
-        PinRing& r = pin_ring();
-        if (!r.tried) { r.tried = true; void* q = nullptr; if (hipHostMalloc(&q, PIN_RING, hipHostMallocPortable) == hipSuccess) { r.p = (char*)q; r.cap = PIN_RING; } else (void)hipGetLastError(); }
-        if (r.p) {
+    PinRing* r = pin_ring_of_thread();
+    if (r && n <= PIN_MAX && (s == r->s0 || s == r->s1)) {
+        if (!r->tried) { r->tried = true; void* q = nullptr; if (hipHostMalloc(&q, PIN_RING, hipHostMallocPortable) == hipSuccess) { r->p = (char*)q; r->cap = PIN_RING; } else (void)hipGetLastError(); }
+        if (r->p) {
             const size_t need = (n + 255) & ~(size_t)255;
-            if (r.off + need > r.cap) { hip_check(hipDeviceSynchronize(), "pinned ring wrap"); r.off = 0; }
-            memcpy(r.p + r.off, h, n);
-            hip_check(hipMemcpyAsync(d, r.p + r.off, n, hipMemcpyHostToDevice, s), "h2d");
-            r.off += need;
+            if (r->off + need > r->cap) { hip_check(hipStreamSynchronize(r->s0), "pinned ring wrap"); hip_check(hipStreamSynchronize(r->s1), "pinned ring wrap"); r->off = 0; }
+            memcpy(r->p + r->off, h, n);
+            hip_check(hipMemcpyAsync(d, r->p + r->off, n, hipMemcpyHostToDevice, s), "h2d");
+            r->off += need;
             return;
         }
     }
     hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d");
 }
 inline void d2h(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }
+inline void d2h_async(void* h, const void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); }   // h: pinned memory; the caller synchronises
 inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "d2d"); }
 inline void dzero(void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, 0, n, s), "memset"); }
 inline void dfill(void* d, int byte, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, byte, n, s), "memset"); }
@@ -84,8 +78,61 @@ inline void dsync(devStream_t s) { hip_check(hipStreamSynchronize(s), "stream sy
 inline void* pin_alloc(size_t n) { void* p = nullptr; hip_check(hipHostMalloc(&p, n ? n : 1, hipHostMallocPortable), "hipHostMalloc"); return p; }
 inline void pin_free(void* p) { (void)hipHostFree(p); }
 inline void check_launch(const char* what) { hip_check(hipGetLastError(), what); }
-inline int hipDeviceSynchronizeCompat() { return (int)hipDeviceSynchronize(); }
+inline void device_sync_all() noexcept { (void)hipDeviceSynchronize(); }              // error paths: nothing queued may outlive the buffers that go away
+
+// the device of a context and its two streams
+inline void dev_open(int device, devStream_t* s0, devStream_t* s1) {
+    int n = 0;
+    hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
+    if (device < 0 || device >= n) throw Error("no such HIP device (this library has no CPU path)");
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(s0, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(s1, hipStreamNonBlocking), "hipStreamCreate");   // (stream priorities were measured: no effect on how the two share the GPU)
+}
+inline void dev_drain(int device, devStream_t s0, devStream_t s1) noexcept { (void)hipSetDevice(device); (void)hipStreamSynchronize(s0); (void)hipStreamSynchronize(s1); }
+inline void dev_close(devStream_t s0, devStream_t s1) noexcept { (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1); }
+
+// stream events (phase timings, the hand-over between the two streams)
+struct DevEvent {
+    hipEvent_t e = nullptr;
+    DevEvent() { hip_check(hipEventCreate(&e), "hipEventCreate"); }
+    ~DevEvent() { if (e) (void)hipEventDestroy(e); }
+    DevEvent(const DevEvent&) = delete; DevEvent& operator=(const DevEvent&) = delete;
+    DevEvent(DevEvent&& o) noexcept : e(o.e) { o.e = nullptr; }
+    void record(devStream_t s) { hip_check(hipEventRecord(e, s), "hipEventRecord"); }
+    void wait() { hip_check(hipEventSynchronize(e), "hipEventSynchronize"); }
+    void make_wait(devStream_t s) { hip_check(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }   // `s` continues after this event
+    static float ms(const DevEvent& a, const DevEvent& b) { float t = 0; hip_check(hipEventElapsedTime(&t, a.e, b.e), "hipEventElapsedTime"); return t; }
+};
+
+// a kernel that asks for more than 64 KB of dynamic LDS has to be told so; the attribute belongs to the (device, function) pair, the call is cheap: made at every launch
+template <class K> inline void kernel_allow_lds(K kernel, size_t bytes) {
+    hip_check(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "LDS size attribute");
+}
+
+// ---- wave helpers (wave = 64 lanes on gfx950) ----
+// uniform-lane broadcast: lane index is the same for the whole wave -> v_readlane on gfx950
+__device__ __forceinline__ int wave_readlane(int v, int uniform_lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane)); }
+// Point where lanes of ONE wave exchange data through LDS/global memory: orders the memory operations and
+// keeps the compiler from moving accesses across it (the lanes themselves run in lockstep on hardware).
+__device__ __forceinline__ void wave_sync_mem() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// Orders this thread's memory operations for the other threads of its WORKGROUP (use with __syncthreads()).  Not __threadfence(): an agent-scope
+// fence on a multi-XCD part writes back / invalidates the XCD's L2 -- measured in round 2 at hundreds of microseconds per workgroup.
+__device__ __forceinline__ void block_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// |a - b| of two unsigned numbers in one instruction (v_sad_u32; hipcc expands __usad to min/max/sub)
+__device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) { uint32_t d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// value of the next / previous lane of the wave (lane 63 / lane 0 keep their own): one DPP move (wave_shl:1 / wave_shr:1) instead of a trip through the
+// LDS crossbar -- for dependent chains of neighbour exchanges
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+// the XCD (0..7 on MI355X) this wave runs on, and an increment performed in that XCD's L2 (workgroup scope): screen.hip's per-XCD count planes
+__device__ __forceinline__ uint32_t xcc_id() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xFu; }
+__device__ __forceinline__ void atomic_inc_xcd_local(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+}  // namespace skh
 #endif
+
+namespace skh {
 
 // grow-only pinned host buffer (descriptor arrays that are built on the host and copied to the device as they are: no staging copy)
 struct PinBuf {
@@ -108,64 +155,10 @@ template <class T> struct DBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
-// ---- wave helpers (wave = 64 lanes on gfx950) ----
+// ---- wave helpers built on the above ----
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
-
-template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane) {
-    return __shfl(v, src_lane, 64);
-}
-// uniform-lane broadcast: lane index is the same for the whole wave -> v_readlane on gfx950
-__device__ __forceinline__ int wave_readlane(int v, int uniform_lane) {
-#ifdef SKANI_EMU
-    return emu::shfl(v, uniform_lane);
-#else
-    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane));
-#endif
-}
+template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 __device__ __forceinline__ unsigned wave_readlane(unsigned v, int uniform_lane) { return (unsigned)wave_readlane((int)v, uniform_lane); }
-// Point where lanes of ONE wave exchange data through LDS/global memory: orders the memory operations and
-// keeps the compiler from moving accesses across it (the lanes themselves run in lockstep on hardware).
-__device__ __forceinline__ void wave_sync_mem() {
-#ifdef SKANI_EMU
-    emu::wave_sync();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-#endif
-}
-// Orders this thread's memory operations for the other threads of its WORKGROUP (use with __syncthreads()).  Not __threadfence(): an agent-scope
-// fence on a multi-XCD part writes back / invalidates the XCD's L2 -- measured in round 2 at hundreds of microseconds per workgroup.
-__device__ __forceinline__ void block_fence() {
-#ifdef SKANI_EMU
-    __threadfence_block();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
-}
-// |a - b| of two unsigned numbers in one instruction (v_sad_u32)
-__device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) {
-#ifdef SKANI_EMU
-    return a > b ? a - b : b - a;
-#else
-    uint32_t d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d;      // hipcc expands __usad to min/max/sub
-#endif
-}
-// value of the next / previous lane of the wave (lane 63 / lane 0 keep their own): one DPP move (wave_shl:1 / wave_shr:1) instead of a trip through the
-// LDS crossbar -- for dependent chains of neighbour exchanges (sketch_build.hip cluster sort)
-__device__ __forceinline__ uint32_t lane_next(uint32_t v) {
-#ifdef SKANI_EMU
-    const int l = (int)emu::lane(); return emu::shfl(v, l < 63 ? l + 1 : l);
-#else
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false);
-#endif
-}
-__device__ __forceinline__ uint32_t lane_prev(uint32_t v) {
-#ifdef SKANI_EMU
-    const int l = (int)emu::lane(); return emu::shfl(v, l > 0 ? l - 1 : l);
-#else
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
-#endif
-}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
     unsigned l = lane_id();

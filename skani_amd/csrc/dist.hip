@@ -159,7 +159,30 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::chrono::steady_clock::time_point ex_t0; double exch_ms = 0;
     auto ex_begin = [&] { dsync(ctx->stream); ex_t0 = std::chrono::steady_clock::now(); };
     auto ex_end = [&] { dsync(ctx->stream); exch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ex_t0).count(); };
-    // ---- 1. who holds what: per rank (genomes, seed positions, markers, contigs, c, k, marker_c), then per genome, then the contig lengths
+    // Failures that only ONE rank can see (out of memory, a table overflow, a failed launch) must not leave the others waiting in the next
+    // collective: every local phase runs under `local`, which keeps the first error; `agree` -- one small all-gather of status words, placed in
+    // front of the collective that follows the phase -- makes every rank throw together, naming the rank that failed.  (Errors every rank derives
+    // from the same all-gathered data, like the parameter check below, need no agreement.)
+    std::string local_err;
+    uint32_t local_phase = 0;                                                       // (SKH_TUNE_DIST_FAIL = n makes the n-th local phase of this rank fail: the tests' fault injection)
+    auto local = [&](auto&& body) {
+        local_phase++;
+        if (!local_err.empty()) return;
+        try { if (ctx->tune.dist_fail == local_phase) throw Error("injected failure (SKH_TUNE_DIST_FAIL)"); body(); }
+        catch (const std::exception& e) { local_err = e.what(); }
+        catch (...) { local_err = "unknown error"; }
+    };
+    auto agree = [&](const char* phase) {
+        uint64_t mine_ok = local_err.empty() ? 0 : 1; std::vector<uint64_t> all(W);
+        T.all_gather(ctx, &mine_ok, all.data(), 8, false);
+        for (int r = 0; r < W; r++)
+            if (all[r]) {
+                device_sync_all();                                                  // nothing queued may outlive the buffers the unwinding frees
+                if (r == me) throw Error(std::string("distributed triangle, ") + phase + ": " + local_err);
+                throw Error(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
+            }
+    };
+    // ---- 1. who holds what: per rank (genomes, seed positions, markers, contigs, c, k, marker_c, seeding mode), then per genome, then the contig lengths
     const uint32_t nL = L->n_genomes;
     uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, L->params.seeding_mode};
     std::vector<uint64_t> cnt((size_t)W * 8);
@@ -168,7 +191,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::vector<uint64_t> base(W + 1, 0);
     uint64_t max_n = 0, max_m = 0, max_c = 0;
     for (int r = 0; r < W; r++) {
-        if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6]) throw std::invalid_argument("the ranks sketched with different c / k / marker_c");
+        if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6] || cnt[r * 8 + 7] != mine[7])
+            throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
         base[r + 1] = base[r] + cnt[r * 8]; max_n = std::max(max_n, cnt[r * 8]); max_m = std::max(max_m, cnt[r * 8 + 2]); max_c = std::max(max_c, cnt[r * 8 + 3]);
     }
     const uint64_t N64 = base[W];
@@ -203,18 +227,24 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     skh_sketch_set S; S.ctx = ctx; S.params = L->params; S.n_genomes = N;
     S.mk_off.assign(N + 1, 0); for (uint32_t g = 0; g < N; g++) S.mk_off[g + 1] = S.mk_off[g] + g_nmk[g];
     const uint64_t MT = S.mk_off[N];
-    S.markers.alloc(MT ? MT : 1);
     {
         const uint64_t pad = std::max<uint64_t>(max_m, 1);
-        uint64_t* d_send = ctx->arena.get<uint64_t>(pad); uint64_t* d_recv = ctx->arena.get<uint64_t>(pad * W);
-        if (mine[2]) d2d(d_send, L->markers.p, mine[2] * 8, ctx->stream);
-        if (pad > mine[2]) dzero(d_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
-        dsync(ctx->stream);
+        uint64_t *d_send = nullptr, *d_recv = nullptr;
+        local([&] {
+            S.markers.alloc(MT ? MT : 1);
+            d_send = ctx->arena.get<uint64_t>(pad); d_recv = ctx->arena.get<uint64_t>(pad * W);
+            if (mine[2]) d2d(d_send, L->markers.p, mine[2] * 8, ctx->stream);
+            if (pad > mine[2]) dzero(d_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
+            dsync(ctx->stream);
+        });
+        agree("marker buffers");
         T.all_gather(ctx, d_send, d_recv, pad * 8, true);
-        for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
+        local([&] {
+            for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
+            S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
+            dsync(ctx->stream);
+        });
     }
-    S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
-    dsync(ctx->stream);
     ex_end();
     ctx->arena.reset();
     tr.mark("dist: tables + markers gathered");
@@ -231,14 +261,16 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.screen_row_begin = rb[me]; st.screen_row_end = rb[me + 1];
     std::vector<uint32_t> my_i, my_j;
-    if (rb[me + 1] > rb[me]) {
+    local([&] {                                                                     // (local phase 3)
+        if (rb[me + 1] <= rb[me]) return;
         Stopwatch sw(ctx, &ctx->timings.screen_ms);
         screen_pairs(ctx, &S, nullptr, identity, SKH_SCREEN_REFS, rescue_small, my_i, my_j, rb[me], rb[me + 1]);
-    }
+    });
     ctx->arena.reset();
     tr.mark("dist: screen rows");
     // ---- 4. the candidate list, everywhere (host memory; sorted by (i, j) because the row blocks ascend with the rank)
     ex_begin();
+    agree("screen");
     uint64_t my_np = my_i.size(); std::vector<uint64_t> np_all(W);
     T.all_gather(ctx, &my_np, np_all.data(), 8, false);
     uint64_t max_np = 1, NP64 = 0; for (int r = 0; r < W; r++) { max_np = std::max(max_np, np_all[r]); NP64 += np_all[r]; }
@@ -309,12 +341,17 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             r_off[r] = rw * 4; r_cnt[r] = r_words[r] * 2 * 4; rw += r_words[r] * 2;
         }
         st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
-        uint32_t* d_send = ctx->arena.get<uint32_t>(sw + 1); uint32_t* d_recv = ctx->arena.get<uint32_t>(rw + 1);
-        copy_segments(ctx, L->p_seed.p, d_send, seg_s);
-        copy_segments(ctx, L->p_g.p, d_send, seg_g);
-        dsync(ctx->stream);
+        uint32_t *d_send = nullptr, *d_recv = nullptr;
+        local([&] {
+            d_send = ctx->arena.get<uint32_t>(sw + 1); d_recv = ctx->arena.get<uint32_t>(rw + 1);
+            copy_segments(ctx, L->p_seed.p, d_send, seg_s);
+            copy_segments(ctx, L->p_g.p, d_send, seg_g);
+            dsync(ctx->stream);
+        });
+        agree("sketch exchange buffers");
         T.all_to_all_v(ctx, d_send, s_cnt.data(), s_off.data(), d_recv, r_cnt.data(), r_off.data(), true);
-        if (nR) {
+        local([&] {                                                                 // (local phase 5)
+            if (!nR) { for (uint32_t g : wk_ids) wk_index[g] = (uint32_t)(g - base[me]); return; }
             const uint32_t nW = (uint32_t)wk_ids.size();
             Wk.reset(new skh_sketch_set());
             Wk->ctx = ctx; Wk->params = L->params; Wk->n_genomes = nW;
@@ -341,17 +378,15 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             copy_segments(ctx, (const uint32_t*)S.markers.p, (uint32_t*)Wk->markers.p, mseg);
             Wk->d_mk_off.alloc(nW + 1); h2d(Wk->d_mk_off.p, Wk->mk_off.data(), (nW + 1) * 8, ctx->stream);
             dsync(ctx->stream);
-        } else for (uint32_t g : wk_ids) wk_index[g] = (uint32_t)(g - base[me]);
+        });
     }
     ex_end();
     ctx->arena.reset();
     tr.mark("dist: sketches exchanged");
     const skh_sketch_set* CS = Wk ? Wk.get() : L;                                   // the set that is chained
-    if (!wk_ids.empty()) {
-        { Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, CS); }
-        ctx->arena.reset();
-        tr.mark("dist: seed tables of the chained set");
-    }
+    local([&] { if (wk_ids.empty()) return; Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, CS); });   // (local phase 6)
+    ctx->arena.reset();
+    tr.mark("dist: seed tables of the chained set");
     // ---- 7. chain this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98)
     std::vector<uint32_t> c_i, c_j, c_r, c_q;
     for (size_t p = 0; p < NP; p++) {
@@ -360,16 +395,20 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.n_pairs_mine = c_i.size();
     std::vector<skh_ani_result> res(c_i.size());
-    if (c_i.size()) {
-        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &CS, 1, nullptr, &CS, 1, nullptr, c_r.data(), c_q.data(), c_i.size(), mp, res.data(), nullptr); }
-        ctx->arena.reset();
-    }
+    // ties of switch_qr go by genome_rank on every rank: the work set carries no file names, and which rank chains a pair must not decide its orientation
+    local([&] {                                                                     // (local phase 7)
+        if (c_i.empty()) return;
+        Stopwatch sw(ctx, &ctx->timings.chain_ms);
+        chain_pairs(ctx, &CS, 1, nullptr, &CS, 1, nullptr, c_r.data(), c_q.data(), c_i.size(), mp, res.data(), nullptr, true);
+    });
+    ctx->arena.reset();
     tr.mark("dist: chain");
     // ---- 8. results (ani > 0.1, triangle.rs:99) gathered on every rank, sorted by (i, j)
     struct Row { uint32_t i, j; skh_ani_result r; };
     std::vector<Row> rows;
     for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
     ex_begin();
+    agree("seed tables / chaining");
     uint64_t my_rows = rows.size(); std::vector<uint64_t> rows_all(W);
     T.all_gather(ctx, &my_rows, rows_all.data(), 8, false);
     uint64_t max_rows = 1, tot_rows = 0; for (int r = 0; r < W; r++) { max_rows = std::max(max_rows, rows_all[r]); tot_rows += rows_all[r]; }

@@ -61,6 +61,7 @@ struct skh_tunables {
     uint32_t build_slice_max = 0;                       // table slices per genome the slice-list kernel handles (0 = 8192; tests use 1: larger genomes' slices re-scan)
     uint32_t marker_lds_max = 0;                        // raw markers per genome the in-LDS marker-set kernel takes (0 = 8192; tests use few to force the device-wide path)
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
+    uint32_t dist_fail = 0;                             // tests: the n-th local phase of a distributed triangle fails on this rank (0 = never)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };
 
@@ -74,6 +75,7 @@ struct skh_ctx {
     skh::GbdtModel model_c125, model_c200;
     skh_timings timings{};
     skh::PinBuf pin_pairs;                               // the chaining's pair descriptors (host side)
+    skh::PinRing ring;                                   // pinned staging of this context's small uploads (dev.h h2d); entry points bind it to their thread
     bool screen_planes_checked = false;                  // the per-XCD count planes of the triangle screen passed their self-test (screen.hip)
 };
 
@@ -172,14 +174,9 @@ struct StageTrace {
 
 // adds the stream time between construction and destruction to *dst (HIP events on the context's stream; synchronises at the end)
 struct Stopwatch {   // wall-clock around stream-synchronous phases
-    skh_ctx* ctx; float* dst;
-#ifndef SKANI_EMU
-    hipEvent_t e0, e1;
-    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
-    ~Stopwatch() { (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *dst += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-#else
-    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) {}
-#endif
+    skh_ctx* ctx; float* dst; DevEvent e0, e1;
+    Stopwatch(skh_ctx* c, float* d) : ctx(c), dst(d) { e0.record(ctx->stream); }
+    ~Stopwatch() { try { e1.record(ctx->stream); e1.wait(); *dst += DevEvent::ms(e0, e1); } catch (...) {} }
 };
 
 // ---- scan.hip
@@ -230,6 +227,6 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* loca
 // chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats);
+                 skh_chain_stats* stats, bool tie_by_rank = false);   // tie_by_rank: switch_qr's tie (chain.rs:20-22) goes by genome_rank even when both sets carry file names
 
 }  // namespace skh

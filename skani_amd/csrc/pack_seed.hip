@@ -125,7 +125,7 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {   // reverse the order
 // integer instruction it can be built from -- v_mad_u64_u32, v_lshrrev_b64, v_lshl_add_u64, v_cmp_gt_u64, v_alignbit_b32 ... -- issues at the same
 // rate, so what counts is the NUMBER of instructions per window.  hipcc turns the multiplications of the Thomas Wang mix into pairs of
 // v_mad_u64_u32 glued with v_mov (registers pairs must be even-aligned) and the hit masks into cmp + cndmask + or: 45 instructions per window.
-// The helpers below pin the cheaper forms (25 per window).  SKANI_EMU (the CPU kernel simulator of the test suite) gets the plain C++ meaning.
+// The helpers below pin the cheaper forms (25 per window); the test suite's CPU kernel simulator gets the plain C++ meaning.
 #ifdef SKANI_EMU
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
 __device__ __forceinline__ uint64_t seed_hash(uint32_t seed) { return mm_hash64((uint64_t)seed); }
@@ -363,9 +363,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     std::vector<Part> parts;
     const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
     std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);   // running totals at genome starts
-#ifndef SKANI_EMU
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-#endif
+    std::vector<std::pair<DevEvent, DevEvent>> evs;                                   // around every launch of the seeding kernel: bench.py's roofline figure
     tr.mark("seed: host tile tables");
     uint64_t base_s = 0, base_m = 0;
     for (size_t t0 = 0; t0 < n_tiles; t0 += MAX_TILES) {
@@ -379,10 +377,8 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         uint32_t* n_ovf = ctx->arena.get<uint32_t>(1);
         dzero(n_ovf, 4, ctx->stream);
         const SeedTile* d_tiles = gs->d_tiles.p + t0;
-#ifndef SKANI_EMU
-        hipEvent_t e0, e1; hip_check(hipEventCreate(&e0), "event"); hip_check(hipEventCreate(&e1), "event");
-        hip_check(hipEventRecord(e0, ctx->stream), "event record");
-#endif
+        evs.emplace_back();
+        evs.back().first.record(ctx->stream);
         if (sp.k == 15) SKH_LAUNCH(seed_tiles_kernel<true>, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
                    t_seed, t_loc, t_marker, cnt_s, cnt_m);
@@ -390,9 +386,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
                    t_seed, t_loc, t_marker, cnt_s, cnt_m);
         check_launch("seed_tiles_kernel");
-#ifndef SKANI_EMU
-        hip_check(hipEventRecord(e1, ctx->stream), "event record"); evs.push_back({e0, e1});
-#endif
+        evs.back().second.record(ctx->stream);
         tr.mark("seed: tiles kernel");
         SKH_LAUNCH(seed_overflow_kernel, (nt + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf);
         check_launch("seed_overflow");
@@ -455,10 +449,8 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         }
         dsync(ctx->stream);
     }
-#ifndef SKANI_EMU
-    float ms = 0; for (auto& e : evs) { float t = 0; hip_check(hipEventElapsedTime(&t, e.first, e.second), "event time"); ms += t; (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    float ms = 0; for (auto& e : evs) ms += DevEvent::ms(e.first, e.second);           // (every launch was followed by a synchronising read-back)
     ctx->timings.seed_kernel_ms += ms; ctx->timings.seed_kernel_launches += (uint32_t)evs.size();
-#endif
 }
 
 }  // namespace skh

@@ -6,9 +6,17 @@
 // the all-gathers (marker sets, small tables) are RCCL's ring/tree collectives.  Host-memory buffers of the small table exchanges are staged
 // through device scratch: RCCL moves device memory only.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "internal.h"
+
+// The handful of RCCL declarations this file uses, restated from RCCL's public C API (rccl.h; the NCCL 2 ABI): the library is reached through
+// dlopen only, so neither its headers nor its import library are needed to build libskani_hip.so.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;                           // every other value is an error; its text comes from ncclGetErrorString
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;             // (bytes are all that travels here)
+}
 
 namespace skh {
 
@@ -109,7 +117,7 @@ int skh_comm_create_rccl(skh_ctx* ctx, const uint8_t id[SKH_COMM_ID_BYTES], int 
     *out = nullptr;
     try {
         if (world < 1 || rank < 0 || rank >= world) { ctx->err = "bad rank / world size"; return SKH_ERR_INVALID; }
-        hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+        PinScope scope(ctx->device, &ctx->ring);                                    // binds the thread to the context's device
         std::unique_ptr<RcclTransport> t(new RcclTransport());
         t->rank = rank; t->world = world;
         ncclUniqueId u; memcpy(&u, id, sizeof(u));

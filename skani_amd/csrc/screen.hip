@@ -43,20 +43,7 @@ __global__ __launch_bounds__(256) void screen_keys_kernel(const uint64_t* marker
 // while an atomic on memory that only this XCD touches during the kernel can stay in its L2 (workgroup scope = no sc1 write-through; the L2
 // itself is what makes it atomic among the XCD's CUs).  The plane is chosen by the hardware's XCC id, not by the block number.  The
 // threshold kernel adds the planes up.
-__device__ __forceinline__ uint32_t xcc_id() {
-#ifdef SKANI_EMU
-    return 0;
-#else
-    uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xFu;
-#endif
-}
-__device__ __forceinline__ void count_local(uint32_t* p) {
-#ifdef SKANI_EMU
-    atomicAdd(p, 1u);
-#else
-    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
+__device__ __forceinline__ void count_local(uint32_t* p) { atomic_inc_xcd_local(p); }   // (dev.h: xcc_id(), the XCD-local increment)
 // Self-test of the per-XCD planes, run once per context before they are used: 512 workgroups add into 64 counters of "their" plane with the same
 // XCD-local atomic; the planes must add up to exactly the number of increments.  The HIP memory model does not promise that workgroup-scope
 // atomics of different workgroups see each other -- on gfx950 they do, because an XCD performs them in its one L2 -- so the planes are only used

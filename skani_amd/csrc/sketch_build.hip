@@ -428,10 +428,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         check_launch("slice_positions");
         if (n_blk) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
-#ifndef SKANI_EMU
-            static size_t attr_lds = 0;
-            if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)build_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
-#endif
+            kernel_allow_lds(build_tables_kernel, lds);
             SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
                        (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
                        (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
@@ -547,10 +544,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         uint32_t* d_uq = ctx->arena.get<uint32_t>(ng);
         uint32_t N = 64; while (N < max_raw) N <<= 1;
         const size_t lds = (size_t)N * 8;
-#ifndef SKANI_EMU
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) { hip_check(hipFuncSetAttribute((const void*)marker_set_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size attribute"); attr_lds = lds; }
-#endif
+        kernel_allow_lds(marker_set_kernel, lds);
         SKH_LAUNCH(marker_set_kernel, ng, MARKER_THREADS, lds, ctx->stream, raw.p, (const uint64_t*)d_ro, d_uq);
         check_launch("marker_set");
         std::vector<uint32_t> h_uq(ng);

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "skani_amd", "csrc")
-SOURCES = ["scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "dist.hip", "capi.hip"]   # rccl_transport.hip (RCCL, GPU only) is not part of the simulator build
+SOURCES = ["scan.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "dist.hip", "capi.hip"]   # not part of the simulator build: rccl_transport.hip (RCCL, GPU only), sort.hip (rocPRIM; emu_sort.cpp stands in), alloc.hip
 LIB = os.path.join(HERE, "libskani_emu.so")
 FLAGS = ["-O2", "-g", "-ffp-contract=off", "-std=c++17", "-fPIC", "-DSKANI_EMU", "-I", HERE, "-I", CSRC, "-pthread", "-Wall", "-Wno-unknown-pragmas",
          "-Wno-attributes", "-fno-strict-aliasing"]
@@ -15,11 +15,12 @@ FLAGS = ["-O2", "-g", "-ffp-contract=off", "-std=c++17", "-fPIC", "-DSKANI_EMU",
 
 def build(force=False):
     objdir = os.path.join(HERE, "build"); os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "emu.h"),
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "emu.h"), os.path.join(HERE, "emu_dev.h"),
             os.path.join(ROOT, "include", "skani_hip.h")]
     jobs = []
     srcs = [(os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))) for s in SOURCES]
     srcs.append((os.path.join(HERE, "emu.cpp"), os.path.join(objdir, "emu.o")))
+    srcs.append((os.path.join(HERE, "emu_sort.cpp"), os.path.join(objdir, "emu_sort.o")))
     for src, obj in srcs:
         if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + deps):
             jobs.append(["g++"] + FLAGS + ["-x", "c++", "-c", src, "-o", obj])

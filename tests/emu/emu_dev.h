@@ -1,0 +1,55 @@
+/*
+ * emu_dev.h -- TEST-ONLY: what skani_amd/csrc/dev.h's HIP section means on the lockstep CPU simulator (emu.h).
+ *
+ * Included by dev.h in place of that section when the kernel sources are compiled with g++ -DSKANI_EMU into tests/emu/libskani_emu.so.  Every name the
+ * product sources use from the HIP section has a plain-C++ meaning here: device memory is host memory, streams and events do nothing, the wave helpers
+ * go through the simulator's fibers, the three inline-assembly helpers of the seeding loop (pack_seed.hip) keep their own conditional there.
+ * Not a product path; the skani_amd package never loads the simulator build.
+ */
+#pragma once
+#include "emu.h"
+
+typedef int devStream_t;
+#define SKH_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch_k(dim3(grid), dim3(block), (smem), kernel, __VA_ARGS__)
+#define SKH_DYN_SMEM(name) char* name = emu::g_blk->dyn_smem
+
+namespace skh {
+
+inline void* dmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); return p; }
+inline void dfree(void* p) { free(p); }
+inline void dcache_trim() {}
+struct PinRing { devStream_t s0 = 0, s1 = 0; };
+struct PinScope { PinScope(int, PinRing*) {} };
+inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
+inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
+inline void d2h_async(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
+inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }
+inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
+inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
+inline void dsync(devStream_t) {}
+inline void* pin_alloc(size_t n) { return malloc(n ? n : 1); }
+inline void pin_free(void* p) { free(p); }
+inline void check_launch(const char*) {}
+inline void device_sync_all() noexcept {}
+inline void dev_open(int, devStream_t* s0, devStream_t* s1) { *s0 = 0; *s1 = 0; }
+inline void dev_drain(int, devStream_t, devStream_t) noexcept {}
+inline void dev_close(devStream_t, devStream_t) noexcept {}
+struct DevEvent {
+    void record(devStream_t) {}
+    void wait() {}
+    void make_wait(devStream_t) {}
+    static float ms(const DevEvent&, const DevEvent&) { return 0.f; }
+};
+template <class K> inline void kernel_allow_lds(K, size_t) {}
+
+inline int wave_readlane(int v, int uniform_lane) { return emu::shfl(v, uniform_lane); }
+inline void wave_sync_mem() { emu::wave_sync(); }
+inline void block_fence() { __threadfence_block(); }
+inline uint32_t abs_diff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+inline uint32_t lane_next(uint32_t v) { const int l = (int)emu::lane(); return emu::shfl(v, l < 63 ? l + 1 : l); }
+inline uint32_t lane_prev(uint32_t v) { const int l = (int)emu::lane(); return emu::shfl(v, l > 0 ? l - 1 : l); }
+inline uint32_t xcc_id() { return 0; }
+inline void atomic_inc_xcd_local(uint32_t* p) { atomicAdd(p, 1u); }
+
+}  // namespace skh

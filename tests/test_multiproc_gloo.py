@@ -1,6 +1,8 @@
-"""N>1 path on CPU: two to eight processes, gloo backend, the sharded triangle of skani_amd.distributed.  Compute goes through
-the kernel simulator build (no GPU in this container); the point of the test is the sharding / exchange / gather logic:
-the union of the two ranks' work must equal the single-process triangle and the oracle."""
+"""N>1 path: two to eight processes over gloo through skh_triangle_distributed (csrc/dist.hip).  On the CPU the compute goes through the
+kernel simulator build (no GPU in this container) and the point is the protocol: screen rows, assignment, sketch exchange, result gather,
+and that a failure on one rank stops all of them; the union of the ranks' work must equal the single-process triangle and the oracle.
+The `-m gpu` tests at the end run the same protocol on an MI355X: BASELINE config 4's 10,000-genome collection as eight processes on one
+device, and the library's own RCCL transport with a world of one."""
 import os
 import socket
 import sys
@@ -104,6 +106,54 @@ def test_multi_rank_triangle_matches_single_process(case):
         assert n == 66 and all(abs(s["n_pairs_mine"] - mean) <= 0.1 * mean for s in stats), [s["n_pairs_mine"] for s in stats]
 
 
+def _failing_worker(rank, world, port, q, fail_rank, phase):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if rank == fail_rank:
+        os.environ["SKH_TUNE_DIST_FAIL"] = str(phase)
+    import torch.distributed as dist
+    import skani_amd as sk
+    from skani_amd.distributed import distributed_triangle
+    from tests.emu_lib import emu_lib
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = sk.Context(0, lib=emu_lib())
+        genomes, held = _case("interleave4")
+        base = sum(held[:rank])
+        params = sk.SketchParams()
+        gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in genomes[base:base + held[rank]]], params.seeding_mode)
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=True)
+        try:
+            distributed_triangle(ctx, ss_local, params, sk.MapParams(), dist, rank, world)
+            q.put((rank, "no error"))
+        except sk.SkaniHipError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("phase", [1, 3, 4, 7])
+def test_failure_on_one_rank_stops_every_rank(phase):
+    """One rank fails in a local phase (injected: marker buffers, screen, exchange buffers, chaining): at the next exchange point all ranks
+    agree on it and return an error -- nobody waits in a collective for a rank that has left (dist.hip `agree`)."""
+    import multiprocessing as mp
+    from tests.emu_lib import emu_lib
+    emu_lib()
+    world, fail_rank = 4, 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue(); port = _free_port()
+    procs = [ctxm.Process(target=_failing_worker, args=(r, world, port, q, fail_rank, phase)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    assert "injected failure" in got[fail_rank], got
+    for r in range(world):
+        if r != fail_rank:
+            assert "rank %d failed" % fail_rank in got[r], got
+
+
 def test_plan_balances_config4_shaped_collection():
     """BASELINE config 4's shape without the genomes: 10,000 genomes in clades of 20, file order shuffled (file_io.rs:250 sorts by NAME, not by
     clade), eight ranks of 1,250.  The plan keeps clusters whole, gives every rank the same number of pairs within 2 %, and moves every sketch
@@ -148,6 +198,14 @@ def test_plan_balances_config4_shaped_collection():
     assert np.array_equal(dense_owner, plan_pairs(L, n2, a.astype(np.uint32), b.astype(np.uint32), np.full(n2, 5000, np.uint64), world))
 
 
+def _two_rank_genomes(interleave):
+    """Two clades of six 1.2 Mbp genomes (1-6 contigs each).  interleave: the clades alternate, so every clade has members on both ranks and whole
+    sketches cross; otherwise one clade per rank and nothing moves."""
+    from tests.parity_cases import synthetic_clades
+    g = synthetic_clades(n_clades=2, members=6, length=1_200_000, seed=61, tiny=False)
+    return [g[(k % 2) * 6 + k // 2] for k in range(12)] if interleave else g
+
+
 def _gpu_worker(rank, world, port, q, interleave=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -157,39 +215,179 @@ def _gpu_worker(rank, world, port, q, interleave=False):
     from skani_amd.distributed import distributed_triangle
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device("cuda:0")
         ctx = sk.Context(0)
-        genomes, held = _case("interleave" if interleave else "blocks")
-        per = held[0]
+        genomes = _two_rank_genomes(interleave)
+        per = len(genomes) // world
         mine = genomes[rank * per:(rank + 1) * per]
         params = sk.SketchParams()
         gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in mine], params.seeding_mode)
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(rank * per, (rank + 1) * per)))
-        i, j, res, n = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, torch=torch, device=dev)
-        if rank == 0:
-            q.put((i, j, res, n))
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(rank * per, (rank + 1) * per)), defer_tables=interleave)
+        i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, torch=torch, with_stats=True)
+        q.put((rank, i, j, res, n, st))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("interleave", [False, True])
-def test_two_ranks_device_tensors_on_one_gpu(interleave):
-    """The device-memory path of the exchange (export into torch CUDA tensors -> all_gather -> import from the gathered tensor,
-    results gathered as CUDA byte tensors; interleave: pairs cross the rank blocks, so whole sketches travel as CUDA tensors through
-    all_to_all_single): two processes share the one GPU, collectives by gloo (RCCL needs one GPU per rank)."""
+def test_two_ranks_on_one_gpu(interleave):
+    """skh_triangle_distributed with two processes sharing the one GPU (host-collective transport over gloo; RCCL needs a GPU per rank): 12 genomes
+    of 1.2 Mbp.  interleave: every clade has members on both ranks, so whole sketches travel through the all-to-all and are indexed where they
+    arrive.  Checked against the oracle field by field and against the single-process triangle byte by byte."""
     import multiprocessing as mp
     import skani_amd as sk
+    from tests.helpers import MODEL_C125, ora
+    from tests.parity_cases import assert_result_close
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue(); port = _free_port()
     procs = [ctxm.Process(target=_gpu_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
     for p in procs:
         p.start()
-    i, j, res, n = q.get(timeout=600)
+    got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120); assert p.exitcode == 0
-    genomes, _ = _case("interleave" if interleave else "blocks")
+    _, i, j, res, n, st0 = got[0]
+    assert np.array_equal(got[1][1], i) and np.array_equal(got[1][2], j) and got[1][3].tobytes() == res.tobytes() and got[1][4] == n
+    genomes = _two_rank_genomes(interleave)
+    osk = [ora.sketch_records(g, file_name="g%03d" % k) for k, g in enumerate(genomes)]
+    oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+    assert n == onch == 30 and np.array_equal(i, oi) and np.array_equal(j, oj)
+    for x in range(len(res)):
+        assert_result_close(res[x], ores[x], (int(i[x]), int(j[x])))
     ctx = sk.Context(0)
     ss = ctx.sketch_records(genomes, sk.SketchParams(), None)
     si, sj, sres, sn = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
     assert sn == n and np.array_equal(si, i) and np.array_equal(sj, j) and sres.tobytes() == res.tobytes() and len(i) > 0
+    moved = sum(g[5]["n_genomes_received"] for g in got)
+    assert (moved > 0 and sum(g[5]["bytes_sent"] for g in got) == sum(g[5]["bytes_received"] for g in got) > 0) if interleave else moved == 0
+    ss.close(); ctx.close()
+
+
+def _config4_worker(rank, world, port, q, n_local):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import bench
+    import skani_amd as sk
+    from skani_amd.distributed import Comm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        ctx = sk.Context(0)
+        canon = bench.genome_order(n_local * world, "shuffled")
+        bases, coff, cgen, ng, _ = bench.make_genomes(torch, dev, canon[rank * n_local:(rank + 1) * n_local])
+        torch.cuda.synchronize()
+        gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+        del bases
+        torch.cuda.empty_cache()
+        ss = ctx.sketch_genomes(gs, sk.SketchParams(), genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32), defer_tables=True)
+        gs.close()
+        comm = Comm.host(ctx, dist, rank, world, torch=torch)
+        i, j, res, n, st = comm.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+        digest = hashlib.sha256(i.tobytes() + j.tobytes() + res.tobytes()).hexdigest()
+        q.put((rank, digest, n, st, (i, j, res) if rank == 0 else None))
+        comm.close(); ss.close(); ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config4_eight_ranks_one_device():
+    """BASELINE config 4 -- the triangle over 10,000 synthetic ~5 Mbp genomes tiled over eight ranks -- with the eight ranks as eight processes on
+    the ONE GPU of this box (host-collective transport; bench.py --gpus 8 runs the same call over RCCL, one GPU per rank).  Every rank generates and
+    sketches its 1,250 genomes of bench.py's shuffled collection (deferred seed tables) and calls skh_triangle_distributed.  Checked: 95,000
+    chained pairs, all inside clades; the same result bytes on every rank; shares within 2 %; what is sent is received, no sketch travels twice;
+    one clade field by field against the oracle; and the whole result byte by byte against ONE process running skh_triangle over the same 10,000
+    genomes on the same GPU (50 GB of ASCII, 12.5 GB packed, ~14 GB of sketches)."""
+    import multiprocessing as mp
+    import hashlib
+    import torch
+    import bench
+    import skani_amd as sk
+    from tests.helpers import MODEL_C125, ora
+    from tests.parity_cases import assert_result_close
+    world, n_local = 8, 1250
+    N = world * n_local
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue(); port = _free_port()
+    procs = [ctxm.Process(target=_config4_worker, args=(r, world, port, q, n_local)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=1500) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300); assert p.exitcode == 0
+    i, j, res = got[0][4]
+    canon = bench.genome_order(N, "shuffled")
+    clade_of = canon // 20                                         # clade of global genome g
+    assert all(g[2] == 95000 for g in got) and len(i) == 95000 and (i < j).all() and (clade_of[i] == clade_of[j]).all()
+    assert len({g[1] for g in got}) == 1                           # identical result bytes on every rank
+    stats = [g[3] for g in got]
+    shares = np.array([s["n_pairs_mine"] for s in stats])
+    assert shares.sum() == 95000 and np.abs(shares - shares.mean()).max() <= 0.02 * shares.mean(), shares
+    sent, recvd, moved = sum(s["bytes_sent"] for s in stats), sum(s["bytes_received"] for s in stats), sum(s["n_genomes_received"] for s in stats)
+    assert sent == recvd > 0 and 0 < moved <= N                    # every sketch is needed by one rank only: it travels at most once
+    assert stats[0]["screen_row_begin"] == 0 and stats[-1]["screen_row_end"] == N and all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))
+    # one clade against the oracle (host copies of the same bytes; names sort like the global indices)
+    dev = torch.device("cuda", 0)
+    members = np.nonzero(clade_of == 137)[0]
+    _, _, _, _, host = bench.make_genomes(torch, dev, canon[members], keep_host=True)
+    osk = [ora.sketch_records(g, file_name="s%05d.fa" % int(members[k])) for k, g in enumerate(host)]
+    oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+    sel = clade_of[i] == 137
+    assert onch == 190 and np.array_equal(i[sel], members[oi]) and np.array_equal(j[sel], members[oj])
+    for x, y in zip(res[sel], ores):
+        assert_result_close(x, y)
+    # the same collection in one process
+    ctx = sk.Context(0)
+    bases, coff, cgen, ng, _ = bench.make_genomes(torch, dev, canon)
+    torch.cuda.synchronize()
+    gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+    del bases
+    torch.cuda.empty_cache()
+    ss = ctx.sketch_genomes(gs, sk.SketchParams(), genome_rank=np.arange(N, dtype=np.uint32))
+    gs.close()
+    si, sj, sres, sn = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    assert sn == 95000 and hashlib.sha256(si.tobytes() + sj.tobytes() + sres.tobytes()).hexdigest() == got[0][1]
+    ss.close(); ctx.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_one():
+    """The library's own RCCL transport (csrc/rccl_transport.hip: librccl loaded with dlopen, communicator on the context's stream) with a world
+    of one -- all a one-GPU box can offer: skh_comm_unique_id, skh_comm_create_rccl, every all-gather and the (empty) send/recv group of
+    skh_triangle_distributed run through RCCL.  40 genomes of ~1 Mbp; the result equals skh_triangle byte by byte and the oracle field by field."""
+    import torch
+    import bench
+    import skani_amd as sk
+    from skani_amd.distributed import Comm
+    from tests.helpers import MODEL_C125, ora
+    from tests.parity_cases import assert_result_close
+    dev = torch.device("cuda", 0)
+    ctx = sk.Context(0)
+    try:
+        bases, coff, cgen, ng, host = bench.make_genomes(torch, dev, np.arange(40), mean_len=1_000_000, keep_host=True)
+        torch.cuda.synchronize()
+        gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+        del bases
+        ss = ctx.sketch_genomes(gs, sk.SketchParams(), genome_rank=np.arange(ng, dtype=np.uint32), defer_tables=True)
+        gs.close()
+        mp_ = sk.MapParams(learned_ani=True, compute_ci=True)
+        comm = Comm.rccl(ctx, None, 0, 1, torch=torch, device=dev)
+        i, j, res, n, st = comm.triangle(ss, mp_)
+        comm.close()
+        assert "librccl" in open("/proc/self/maps").read()
+        si, sj, sres, sn = ctx.triangle(ss, mp_)
+        assert n == sn == 380 and np.array_equal(i, si) and np.array_equal(j, sj) and res.tobytes() == sres.tobytes()
+        assert st["n_pairs_mine"] == 380 and st["n_genomes_received"] == 0 and st["screen_row_begin"] == 0 and st["screen_row_end"] == 40
+        osk = [ora.sketch_records(g, file_name="s%05d.fa" % k) for k, g in enumerate(host)]
+        oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
+        assert onch == 380 and np.array_equal(i, oi) and np.array_equal(j, oj)
+        for x in range(len(res)):
+            assert_result_close(res[x], ores[x], (int(i[x]), int(j[x])))
+        ss.close()
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
