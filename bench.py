@@ -14,7 +14,8 @@ exactly the sketches that are needed point-to-point and gathers the results.  va
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (seeding kernel, HBM bound per SURVEY 8d: 0.354 algorithmic
 bytes/base; plus the VALU issue fraction that actually binds it) and `cpu_baseline` (the C++ oracle = a port of the reference algorithms,
-run on this box's host cores on the same, full workload -- about 10 s; the Rust reference cannot be built here).
+run on this box's host cores on the same, full workload at several thread counts -- about 20 s in all; the best point is the value; the Rust
+reference cannot be built here).
 """
 import argparse
 import json
@@ -166,12 +167,33 @@ def run_search(args, torch, sk, ctx, device):
             (q, r, res, qclades))
 
 
-def cpu_baseline(host_genomes, threads, gpu_result=None, n_gpu_genomes=None):
-    """The oracle (a C++ restatement of the reference algorithms; kind = 'port', the Rust reference cannot be built here) timed on this box's
-    host cores on the genomes given -- by default the FULL workload the GPU ran -- phase by phase as BASELINE.md section 2 lists them: sketch,
-    marker index + screen of all pairs, chain of the passing pairs.  With the GPU triangle's result it also reports the metric's "ANI delta vs
-    ref" over every chained pair."""
-    from concurrent.futures import ThreadPoolExecutor
+def host_cores():
+    """(logical CPUs, physical cores, model name) of this box."""
+    logical = os.cpu_count() or 1
+    cores, model = set(), ""
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    physical = len(cores) if cores else max(1, logical // 2)
+    return logical, min(physical, logical), model
+
+
+def cpu_run(host_genomes, threads):
+    """One timed pass of the oracle (a C++ restatement of the reference algorithms) over the genomes given, phase by phase as BASELINE.md section 2
+    lists them: sketch (one C call, files in parallel like file_io.rs:147, AVX2 seeding like avx2_seeding.rs), marker index, screen of all pairs,
+    chain of the passing pairs (threads pulling pairs like triangle.rs:71-105)."""
     from oracle import oracle_py as ora
     names = ["s%05d.fa" % i for i in range(len(host_genomes))]
     # regression.rs:8-28: learned ANI only for c >= 70, table chosen by |c-125| < |c-200|
@@ -179,15 +201,39 @@ def cpu_baseline(host_genomes, threads, gpu_result=None, n_gpu_genomes=None):
     if C >= 70:
         model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin" if abs(C - 125) < abs(C - 200) else "gbdt_c200.bin"))
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:     # ctypes releases the GIL: genomes are sketched in parallel like file_io.rs:147
-        sks = list(ex.map(lambda a: ora.sketch_records(a[1], C, K, M, names[a[0]], 1), enumerate(host_genomes)))
+    sks = ora.sketch_batch(host_genomes, C, K, M, names, 1, 500, threads)
     t1 = time.perf_counter()
     oi, oj, res, n_chained, n_pass = ora.triangle(sks, model=model, threads=threads)
     t2 = time.perf_counter()
     index_s, screen_s, chain_s = ora.triangle_phases()
     n = len(host_genomes); pairs = n * (n - 1) // 2
     bases = sum(len(s) for g in host_genomes for _, s in g)
-    sketch_s = t1 - t0
+    return {"threads": threads, "genomes": n, "bases": bases, "pairs": pairs, "chained_pairs": int(n_chained), "value": pairs / (t2 - t0),
+            "seconds": {"sketch": t1 - t0, "marker_index": index_s, "screen": screen_s, "chain": chain_s, "total": t2 - t0},
+            "sketch_mbases_per_s": bases / 1e6 / (t1 - t0), "screen_pairs_per_s": pairs / max(index_s + screen_s, 1e-9),
+            "chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None}, (oi, oj, res)
+
+
+def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
+    """The CPU side of the metric: the oracle (kind = 'port': the Rust reference cannot be built here) on this box's host cores on the genomes given --
+    by default the FULL workload the GPU ran -- at several thread counts: 16, 64, the physical cores and all logical CPUs, each a complete run, plus
+    skani's default -t 3 (cli.rs:243) on five clades as the per-thread yardstick.  `value` is the BEST point of the sweep and `cores` the thread count
+    that gave it; every point carries its phase times and the parallel efficiency of the sketch and chain phases against the 3-thread per-thread rate.
+    With the GPU triangle's result it also reports the metric's "ANI delta vs ref" over every chained pair."""
+    logical, physical, model_name = host_cores()
+    n = len(host_genomes); pairs = n * (n - 1) // 2
+    cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)                      # (the first pass of a process pays the page faults of its heap: not the yardstick)
+    few, _ = cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)
+    per_thread = {"sketch": few["sketch_mbases_per_s"] / 3, "chain": (few["chained_pairs_per_s"] or 0) / 3}
+    counts = sorted({t for t in (16, 64, physical, logical) if t <= logical} or {logical})
+    sweep, result = [], None
+    for t in counts:
+        r, result = cpu_run(host_genomes, t)
+        r["efficiency"] = {"sketch": r["sketch_mbases_per_s"] / t / per_thread["sketch"] if per_thread["sketch"] else None,
+                           "chain": (r["chained_pairs_per_s"] or 0) / t / per_thread["chain"] if per_thread["chain"] else None}
+        sweep.append(r)
+    best = max(sweep, key=lambda r: r["value"])
+    oi, oj, res = result
     delta = None
     if gpu_result is not None:
         gi, gj, gres = gpu_result
@@ -201,13 +247,20 @@ def cpu_baseline(host_genomes, threads, gpu_result=None, n_gpu_genomes=None):
                 delta["max_abs_d_" + f] = float(np.max(np.abs(g[f].astype(np.float64) - res[f].astype(np.float64))))
             delta["int_fields_equal"] = bool(all(np.array_equal(g[f], res[f]) for f in ("avg_chain_int_len", "total_bases_covered", "num_contigs_q", "num_contigs_r")))
     full = n_gpu_genomes is None or n == n_gpu_genomes
-    return {"value": pairs / (t2 - t0), "unit": "genome-pairs/s", "cores": threads, "kind": "port", "delta_vs_oracle": delta,
+    sec = best["seconds"]
+    return {"value": best["value"], "unit": "genome-pairs/s", "cores": best["threads"], "kind": "port", "delta_vs_oracle": delta,
             "sample": ("the full workload, measured: " if full else "a sample, measured: ") +
                       "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + marker index %.2f s + screen of %d pairs %.2f s + chain of %d pairs %.2f s "
-                      "on %d threads; value = pairs / wall time of the four phases" % (n, n // CLADE, CLADE, bases / 1e6, sketch_s, index_s, pairs, screen_s, n_chained, chain_s, threads),
-            "seconds": {"sketch": sketch_s, "marker_index": index_s, "screen": screen_s, "chain": chain_s, "total": t2 - t0},
-            "sketch_mbases_per_s": bases / 1e6 / sketch_s, "screen_pairs_per_s": pairs / max(index_s + screen_s, 1e-9),
-            "chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None, "chained_pairs": int(n_chained)}
+                      "on %d threads (the best of %s threads; %d physical cores / %d logical CPUs, %s); value = pairs / wall time of the four phases"
+                      % (n, n // CLADE, CLADE, best["bases"] / 1e6, sec["sketch"], sec["marker_index"], pairs, sec["screen"], best["chained_pairs"], sec["chain"],
+                         best["threads"], "/".join(str(t) for t in counts), physical, logical, model_name),
+            "seconds": sec, "sketch_mbases_per_s": best["sketch_mbases_per_s"], "screen_pairs_per_s": best["screen_pairs_per_s"],
+            "chained_pairs_per_s": best["chained_pairs_per_s"], "chained_pairs": best["chained_pairs"],
+            "host": {"logical_cpus": logical, "physical_cores": physical, "model": model_name},
+            "sweep": [{k: r[k] for k in ("threads", "value", "seconds", "sketch_mbases_per_s", "chained_pairs_per_s", "efficiency")} for r in sweep],
+            "default_threads": {"cores": 3, "genomes": few["genomes"], "value": few["value"], "seconds": few["seconds"], "chained_pairs_per_s": few["chained_pairs_per_s"],
+                                "sketch_mbases_per_s": few["sketch_mbases_per_s"],
+                                "note": "skani's default -t 3 on %d genomes: the per-thread rates the sweep's efficiencies refer to (value = that sample's own pairs / time)" % few["genomes"]}}
 
 
 class stdout_to_stderr:
@@ -429,12 +482,7 @@ def main():
                                  "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes,
                                  "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in the latest profiles/r*_pmc_*.md"}
     if host_genomes:
-        threads = os.cpu_count() or 1
-        out["cpu_baseline"] = cpu_baseline(host_genomes, threads, last.get("result"), n_total)
-        # skani's default thread count (-t 3, cli.rs:243) on one clade of the same collection, for a like-for-like default
-        few = cpu_baseline(host_genomes[:CLADE], 3, None, n_total)
-        out["cpu_baseline"]["default_threads"] = {"cores": 3, "value": few["value"], "sample": few["sample"], "seconds": few["seconds"],
-                                                  "chained_pairs_per_s": few["chained_pairs_per_s"], "sketch_mbases_per_s": few["sketch_mbases_per_s"]}
+        out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

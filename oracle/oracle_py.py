@@ -53,6 +53,8 @@ def lib():
         L.ora_sketch_new.restype = vp; L.ora_sketch_new.argtypes = [u32, u32, u32, C.c_char_p]
         L.ora_sketch_free.argtypes = [vp]
         L.ora_sketch_add_contig.restype = i32; L.ora_sketch_add_contig.argtypes = [vp, vp, u64, i32, u64]
+        L.ora_sketch_batch.restype = None
+        L.ora_sketch_batch.argtypes = [u32, vp, vp, vp, u32, u32, u32, vp, i32, u64, i32, vp]
         L.ora_sketch_from_arrays.restype = vp
         L.ora_sketch_from_arrays.argtypes = [u32, u32, u32, C.c_char_p, vp, vp, vp, u64, vp, u64, vp, u32, u64]
         for n in ("n_positions", "n_distinct", "n_markers", "total_len"):
@@ -145,6 +147,20 @@ def sketch_records(records, c=125, k=15, marker_c=1000, file_name="", mode=1, mi
     for _, seq in records:
         sk.add_contig(seq, mode, min_len)
     return sk
+
+
+def sketch_batch(genomes, c=125, k=15, marker_c=1000, names=None, mode=1, min_len=500, threads=0):
+    """file_io.rs:141-252 for many files at once, sketched in parallel inside one C call (file_io.rs:147): genomes = list of lists of
+    (name, seq) records, seq = bytes or a uint8 numpy array."""
+    bufs = [np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, np.uint8) for g in genomes for _, s in g]
+    off = np.zeros(len(genomes) + 1, np.uint64); off[1:] = np.cumsum([len(g) for g in genomes])
+    ptrs = (C.c_void_p * max(len(bufs), 1))(*[b.ctypes.data for b in bufs])
+    lens = np.array([len(b) for b in bufs], np.uint64)
+    nm = [(names[i] if names else "").encode() for i in range(len(genomes))]
+    cn = (C.c_char_p * max(len(nm), 1))(*nm)
+    out = (C.c_void_p * max(len(genomes), 1))()
+    lib().ora_sketch_batch(len(genomes), _p(off), ptrs, _p(lens), c, k, marker_c, cn, mode, min_len, threads, out)
+    return [Sketch(c, k, marker_c, names[i] if names else "", handle=out[i]) for i in range(len(genomes))]
 
 
 def chain_seeds(ref, query, min_af=0.15, both_min_af=-0.01, robust=False, median=False, model=None, stats=False):

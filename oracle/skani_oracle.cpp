@@ -22,6 +22,10 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
+#include <malloc.h>
 
 namespace {
 
@@ -145,6 +149,12 @@ struct ora_sketch {
         if (*t & 1ull) { uint64_t packed = *t >> 1; tmp->pos = (uint32_t)(packed >> 31); tmp->cc = (uint32_t)(packed & 0x7FFFFFFFu); *out = tmp; return 1; }
         const auto& v = multi[(*t >> 1) - 1]; *out = v.data(); return v.size();
     }
+    // the same for the seed in slot h of the key table (an enumeration of the map needs no second hash look-up)
+    size_t get_at(size_t h, const SeedPos** out, SeedPos* tmp) const {
+        const uint64_t t = seeds.vals[h];
+        if (t & 1ull) { uint64_t packed = t >> 1; tmp->pos = (uint32_t)(packed >> 31); tmp->cc = (uint32_t)(packed & 0x7FFFFFFFu); *out = tmp; return 1; }
+        const auto& v = multi[(t >> 1) - 1]; *out = v.data(); return v.size();
+    }
 };
 
 struct ora_model {  // gbdt 0.1.1 GBDT restricted to what regression.rs uses
@@ -229,6 +239,66 @@ void fmh_seeds_avx2_semantics(const uint8_t* s, uint64_t slen, uint32_t c, uint3
     }
 }
 
+#ifdef __AVX2__
+// The same function with the reference's own instruction set (avx2_seeding.rs:33-272 IS AVX2 intrinsics code: four 64-bit lanes, one substring each).
+// Results are identical to fmh_seeds_avx2_semantics above, which stays as its checker (tests/test_oracle_golden.py) and is what non-AVX2 builds run;
+// this one is what sketching calls, so that the CPU baseline of bench.py is timed on vector code like the reference's.
+inline __m256i mm_hash64_x4(__m256i key) {   // types.rs:86-96, four keys
+    key = _mm256_xor_si256(_mm256_add_epi64(key, _mm256_slli_epi64(key, 21)), _mm256_set1_epi64x(-1));
+    key = _mm256_xor_si256(key, _mm256_srli_epi64(key, 24));
+    key = _mm256_add_epi64(_mm256_add_epi64(key, _mm256_slli_epi64(key, 3)), _mm256_slli_epi64(key, 8));
+    key = _mm256_xor_si256(key, _mm256_srli_epi64(key, 14));
+    key = _mm256_add_epi64(_mm256_add_epi64(key, _mm256_slli_epi64(key, 2)), _mm256_slli_epi64(key, 4));
+    key = _mm256_xor_si256(key, _mm256_srli_epi64(key, 28));
+    key = _mm256_add_epi64(key, _mm256_slli_epi64(key, 31));
+    return key;
+}
+void fmh_seeds_avx2(const uint8_t* s, uint64_t slen, uint32_t c, uint32_t k, uint32_t marker_c, uint32_t contig, ora_sketch& sk) {
+    const uint32_t marker_k = K_MARKER_DNA;
+    const uint64_t len = (slen - marker_k + 1) / 4;                    // :48
+    if (slen < 2 * marker_k) return;                                   // :56
+    const __m256i seed_mask = _mm256_set1_epi64x((long long)(~0ull >> (64 - 2 * k)));
+    const __m256i marker_mask = _mm256_set1_epi64x((long long)(~0ull >> (64 - 2 * marker_k)));
+    const __m256i rev_marker_mask = _mm256_set1_epi64x((long long)~(3ull << (2 * marker_k - 2)));
+    const uint64_t threshold = ~0ull / (uint64_t)c, threshold_marker = ~0ull / (uint64_t)marker_c;
+    const __m256i sign = _mm256_set1_epi64x((long long)0x8000000000000000ull);
+    const __m256i thr_s = _mm256_xor_si256(_mm256_set1_epi64x((long long)threshold), sign);     // unsigned compare through the signed one
+    const __m256i three = _mm256_set1_epi64x(3);
+    const uint8_t* str[4] = {s, s + len, s + 2 * len, s + 3 * len};    // :49-52
+    __m256i f = _mm256_setzero_si256(), r = _mm256_setzero_si256();
+    auto load = [&](uint64_t i) { return _mm256_set_epi64x(LUT.t[str[3][i]], LUT.t[str[2][i]], LUT.t[str[1][i]], LUT.t[str[0][i]]); };
+    for (uint32_t i = 0; i < marker_k - 1; i++) {                      // :63-81
+        const __m256i nf = load(i), nr = _mm256_sub_epi64(three, nf);
+        f = _mm256_or_si256(_mm256_slli_epi64(f, 2), nf); r = _mm256_or_si256(_mm256_srli_epi64(r, 2), _mm256_slli_epi64(nr, 40));
+    }
+    uint64_t resume[4] = {0, 0, 0, 0};
+    alignas(32) uint64_t fa[4], ra[4], sa[4], ha[4], ca[4];
+    for (uint64_t i = marker_k - 1; i < len + marker_k - 1; i++) {     // :108
+        for (int l = 0; l < 4; l++) if (str[l][i] == 78) resume[l] = i + marker_k;   // :115-126
+        const __m256i nf = load(i), nr = _mm256_sub_epi64(three, nf);
+        f = _mm256_and_si256(_mm256_or_si256(_mm256_slli_epi64(f, 2), nf), marker_mask);                                      // :137-139
+        r = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi64(r, 2), rev_marker_mask), _mm256_slli_epi64(nr, 40));           // :140-143
+        const __m256i fs = _mm256_and_si256(f, seed_mask), rs = _mm256_and_si256(r, seed_mask);
+        const __m256i canon = _mm256_cmpgt_epi64(rs, fs);                                                                     // :147 (values below 2^32)
+        const __m256i seed = _mm256_blendv_epi8(rs, fs, canon);                                                               // :149-150
+        const __m256i h = mm_hash64_x4(seed);
+        const int hit = _mm256_movemask_pd(_mm256_castsi256_pd(_mm256_cmpgt_epi64(thr_s, _mm256_xor_si256(h, sign))));        // h < threshold
+        if (!hit) continue;
+        _mm256_store_si256((__m256i*)fa, f); _mm256_store_si256((__m256i*)ra, r); _mm256_store_si256((__m256i*)sa, seed);
+        _mm256_store_si256((__m256i*)ha, h); _mm256_store_si256((__m256i*)ca, canon);
+        for (int l = 0; l < 4; l++) {                                  // lanes are emitted in order 0..3 (:181-270)
+            if (!((hit >> l) & 1) || resume[l] > i) continue;
+            sk.add_seed_position((uint32_t)sa[l], SeedPos{(uint32_t)(i + len * l), (contig << 1) | (ca[l] ? 1u : 0u)});
+            if (ha[l] < threshold_marker) sk.markers.insert(ra[l] > fa[l] ? fa[l] : ra[l]);  // :148,189-199
+        }
+    }
+}
+#else
+inline void fmh_seeds_avx2(const uint8_t* s, uint64_t slen, uint32_t c, uint32_t k, uint32_t marker_c, uint32_t contig, ora_sketch& sk) {
+    fmh_seeds_avx2_semantics(s, slen, c, k, marker_c, contig, sk);
+}
+#endif
+
 // ---------------------------------------------------------------- chaining data (types.rs:499-550)
 struct Anchor { uint32_t qctg, qpos, rctg, rpos; bool rev; };
 inline bool anchor_less(const Anchor& a, const Anchor& b) {  // derived Ord, types.rs:499-506
@@ -247,7 +317,26 @@ inline int ci_cmp(const ChainInterval& a, const ChainInterval& b) {  // derived 
 #undef CMPF
     return 0;
 }
-struct AnchorChunks { std::vector<std::vector<Anchor>> chunks; std::vector<std::vector<uint32_t>> seeds_in_chunk; };
+// Scratch of chain_seeds.  A thread keeps ONE across its calls (thread_local in chain_seeds) and every stage works on flat arrays in it: the reference
+// leans on its allocator (main.rs:10-18) for the per-pair vectors of chain.rs; with glibc's malloc each pair's half-megabyte anchor vector is an
+// mmap / munmap pair, and many threads then queue on the process's address-space lock instead of chaining (measured: ~5 % parallel efficiency at
+// 256 threads before this).  Storage only -- every stage below computes exactly what its reference lines compute, in the same order.
+struct Work {
+    std::vector<Anchor> anchors;                               // all anchors, sorted (chain.rs:721)
+    std::vector<std::vector<uint32_t>> qpos_all;               // query_positions_all per query contig (the first n_qctg entries are live)
+    std::vector<uint32_t> chunk_begin;                         // chunk i = anchors [chunk_begin[i], chunk_begin[i + 1])
+    std::vector<uint32_t> seeds, seeds_begin;                  // seeds_in_chunk, flattened the same way
+    std::vector<size_t> ptr, root, members, best;              // per anchor of the current chunk
+    std::vector<double> score, max_score;
+    std::vector<ChainInterval> ints;                           // candidate intervals of all chunks (get_chain_intervals)
+    std::vector<ChainInterval> good; std::vector<uint32_t> good_begin, good_fill;   // accepted intervals grouped by chunk, acceptance order inside a chunk
+    std::vector<uint32_t> accepted;                            // indices into ints, acceptance order
+    std::vector<std::vector<uint32_t>> acc_q, acc_r;           // accepted intervals per query / ref contig (the reference's interval trees)
+    std::vector<std::pair<double, size_t>> ests;
+    std::vector<std::pair<uint32_t, uint32_t>> uni;
+    std::vector<double> nomult, mult, boot; std::vector<size_t> rv;
+    size_t n_chunks() const { return chunk_begin.empty() ? 0 : chunk_begin.size() - 1; }
+};
 
 double mean_len(const std::vector<uint32_t>& v) { double s = 0; for (auto x : v) s += (double)x; return s / (double)v.size(); }
 
@@ -259,8 +348,9 @@ bool switch_qr(double mean_r, double mean_q, double q_sk_len, double r_sk_len, c
 }
 
 // chain.rs:608-836
-bool get_anchors(const ora_sketch& ref, const ora_sketch& query, size_t band, AnchorChunks& out, bool& have, ora_chain_stats* st) {
+bool get_anchors(const ora_sketch& ref, const ora_sketch& query, size_t band, Work& w, bool& have, ora_chain_stats* st) {
     have = false;
+    w.anchors.clear(); w.chunk_begin.clear(); w.seeds.clear(); w.seeds_begin.clear();
     if (ref.contig_lengths.empty() || query.contig_lengths.empty()) return true;  // :618-620
     double mean_q = mean_len(query.contig_lengths), mean_r = mean_len(ref.contig_lengths);
     double qproxy, rproxy;
@@ -270,12 +360,14 @@ bool get_anchors(const ora_sketch& ref, const ora_sketch& query, size_t band, An
     bool switched = switch_qr(mean_r, mean_q, qproxy, rproxy, query.file_name, ref.file_name);
     const ora_sketch& A = switched ? ref : query;   // enumerated ("kmer_seeds_query")
     const ora_sketch& B = switched ? query : ref;   // probed ("kmer_seeds_ref")
-    std::vector<std::vector<uint32_t>> qpos_all(A.contig_lengths.size());
-    std::vector<Anchor> anchors;
+    const size_t n_qctg = A.contig_lengths.size();
+    if (w.qpos_all.size() < n_qctg) w.qpos_all.resize(n_qctg);
+    for (size_t c = 0; c < n_qctg; c++) w.qpos_all[c].clear();
+    auto& qpos_all = w.qpos_all; auto& anchors = w.anchors;
     for (size_t h = 0; h < A.seeds.keys.size(); h++) {                              // :666
         uint32_t seed = A.seeds.keys[h];
         if (seed == SeedMap::EMPTY) continue;
-        const SeedPos* qp; SeedPos t1; size_t nq = A.get(seed, &qp, &t1);
+        const SeedPos* qp; SeedPos t1; size_t nq = A.get_at(h, &qp, &t1);
         if (nq > band) continue;                                                    // :674-676
         const SeedPos* rp; SeedPos t2; size_t nr = B.get(seed, &rp, &t2);
         if (nr == 0) { for (size_t i = 0; i < nq; i++) qpos_all[qp[i].cc >> 1].push_back(qp[i].pos); continue; }  // :682-685
@@ -286,33 +378,33 @@ bool get_anchors(const ora_sketch& ref, const ora_sketch& query, size_t band, An
     }
     if (anchors.empty()) return true;                                               // :714-720 (returns switched=true)
     std::sort(anchors.begin(), anchors.end(), anchor_less);                         // :721
-    for (auto& v : qpos_all) std::sort(v.begin(), v.end());                         // :722-724
+    for (size_t c = 0; c < n_qctg; c++) std::sort(qpos_all[c].begin(), qpos_all[c].end());   // :722-724
     if (st) {
-        st->n_anchors = anchors.size(); st->n_qpos = 0; for (auto& v : qpos_all) st->n_qpos += v.size();
+        st->n_anchors = anchors.size(); st->n_qpos = 0; for (size_t c = 0; c < n_qctg; c++) st->n_qpos += qpos_all[c].size();
         uint64_t hsh = 1469598103934665603ull;
         auto mix = [&](uint64_t x) { hsh ^= x; hsh *= 1099511628211ull; };
         for (auto& a : anchors) { mix(a.qctg); mix(a.qpos); mix(a.rctg); mix(a.rpos); mix(a.rev); }
         st->anchor_checksum = hsh;
     }
     const uint32_t FRAG = CHUNK_SIZE_DNA;
-    std::vector<Anchor> cur; uint32_t last = anchors[0].qctg; uint32_t end = anchors[0].qpos + FRAG; size_t rc = 0;  // :742-745
-    for (const Anchor& a : anchors) {
-        if (last != a.qctg || a.qpos > end) {                                       // :747
+    uint32_t last = anchors[0].qctg; uint32_t end = anchors[0].qpos + FRAG; size_t rc = 0;  // :742-745
+    w.chunk_begin.push_back(0); w.seeds_begin.push_back(0);
+    for (size_t ai = 0; ai < anchors.size(); ai++) {
+        const Anchor& a = anchors[ai];
+        if (last != a.qctg || a.qpos > end) {                                       // :747 -- the current chunk (never empty here) closes in front of anchor ai
             const auto& v = qpos_all[last];
-            std::vector<uint32_t> seeds;
-            while (rc < v.size() && v[rc] <= end) { seeds.push_back(v[rc]); rc++; } // :755-780
-            out.seeds_in_chunk.push_back(std::move(seeds));
+            while (rc < v.size() && v[rc] <= end) { w.seeds.push_back(v[rc]); rc++; }   // :755-780
+            w.seeds_begin.push_back((uint32_t)w.seeds.size());
             end += FRAG;                                                            // :782
-            out.chunks.push_back(std::move(cur)); cur.clear();
+            w.chunk_begin.push_back((uint32_t)ai);
             if (last != a.qctg) { end = a.qpos + FRAG; rc = 0; }                    // :786-789
         }
-        last = a.qctg; cur.push_back(a);
+        last = a.qctg;
     }
-    if (!cur.empty()) {                                                             // :794-824
+    {                                                                               // :794-824 (the open chunk holds at least the last anchor)
         const auto& v = qpos_all[last];
-        std::vector<uint32_t> seeds;
-        while (rc < v.size() && v[rc] <= cur.back().qpos) { seeds.push_back(v[rc]); rc++; }
-        out.chunks.push_back(std::move(cur)); out.seeds_in_chunk.push_back(std::move(seeds));
+        while (rc < v.size() && v[rc] <= anchors.back().qpos) { w.seeds.push_back(v[rc]); rc++; }
+        w.seeds_begin.push_back((uint32_t)w.seeds.size()); w.chunk_begin.push_back((uint32_t)anchors.size());
     }
     have = true;
     return switched;
@@ -332,79 +424,91 @@ inline bool score_anchors(const Anchor& cur, const Anchor& past, double& out) {
     return true;
 }
 
-struct ChainRes { std::vector<size_t> ptr; std::vector<double> score; };
-
-// chain.rs:838-896
-void chain_chunk(const std::vector<Anchor>& ch, size_t band, ChainRes& cr) {
+// chain.rs:838-896 on one chunk (n anchors at ch): fills w.score / w.ptr
+void chain_chunk(const Anchor* ch, size_t n, size_t band, Work& w) {
     const uint32_t past_len = (uint32_t)std::min<size_t>(CHUNK_SIZE_DNA / 2, BP_CHAIN_BAND);  // :842
-    size_t n = ch.size(); cr.ptr.assign(n, 0); cr.score.assign(n, 0.);
+    w.ptr.assign(n, 0); w.score.assign(n, 0.);
     for (size_t i = 0; i < n; i++) {
         double best = 0.; size_t bp = i;
         for (size_t j = i; j-- > 0;) {                                 // (0..i).rev()
             if (ch[i].rctg != ch[j].rctg) continue;                    // :856-858
             if (ch[i].qpos - ch[j].qpos > past_len || i - j > band) break;  // :859-863
             double s; if (!score_anchors(ch[i], ch[j], s)) continue;
-            double ns = s + cr.score[j];
+            double ns = s + w.score[j];
             if (ns > best) { best = ns; bp = j; }                      // :876-879
         }
-        cr.score[i] = best; cr.ptr[i] = bp;
+        w.score[i] = best; w.ptr[i] = bp;
     }
 }
 
 // chain.rs:939-1007.  Set membership = anchors sharing the pointer-forest root (chain.rs:883-885 unions
 // i with ptr[i] only).  Set iteration order per partitions 0.2.4: root first, then
-// members in descending index.
-void get_chain_intervals(std::vector<ChainInterval>& good, const ChainRes& cr, const std::vector<Anchor>& an, size_t chunk_id) {
-    size_t n = an.size();
-    std::vector<size_t> root(n);
-    for (size_t i = 0; i < n; i++) root[i] = cr.ptr[i] == i ? i : root[cr.ptr[i]];
-    std::vector<std::vector<size_t>> members(n);
-    for (size_t i = n; i-- > 0;) if (root[i] != i) members[root[i]].push_back(i);   // descending
+// members in descending index -- so the strict `>` of :952-964 keeps, among equal scores, the root, else the largest index.
+void get_chain_intervals(Work& w, const Anchor* an, size_t n, size_t chunk_id) {
+    w.root.resize(n); w.members.assign(n, 0); w.best.resize(n); w.max_score.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        w.root[i] = w.ptr[i] == i ? i : w.root[w.ptr[i]];
+        if (w.root[i] == i) { w.best[i] = i; w.max_score[i] = w.score[i]; }         // the root is visited first
+    }
+    for (size_t i = n; i-- > 0;) {                                                  // then the other members, descending
+        const size_t r = w.root[i];
+        if (r == i) continue;
+        w.members[r]++;
+        if (w.score[i] > w.max_score[r]) { w.max_score[r] = w.score[i]; w.best[r] = i; }
+    }
     const double min_score = (double)D_MIN_ANCHORS_ANI * D_ANCHOR_SCORE_ANI * 0.75;  // chain.rs:113
     for (size_t r = 0; r < n; r++) {
-        if (root[r] != r) continue;
-        if (members[r].size() + 1 < D_MIN_ANCHORS_ANI) continue;                    // :954-957
-        double max_score = -std::numeric_limits<double>::max(); size_t best = SIZE_MAX;
-        auto visit = [&](size_t idx) { if (cr.score[idx] > max_score) { max_score = cr.score[idx]; best = idx; } };
-        visit(r); for (size_t m : members[r]) visit(m);                             // :952-964
+        if (w.root[r] != r) continue;
+        if (w.members[r] + 1 < D_MIN_ANCHORS_ANI) continue;                         // :954-957
+        const double max_score = w.max_score[r]; const size_t best = w.best[r];     // :952-964
         size_t idx = best, na = 1;
-        while (cr.ptr[idx] != idx) { idx = cr.ptr[idx]; na++; }                     // :969-973
+        while (w.ptr[idx] != idx) { idx = w.ptr[idx]; na++; }                       // :969-973
         if (na < D_MIN_ANCHORS_ANI || max_score < min_score) continue;              // :974-977
         ChainInterval ci;
         ci.q0 = an[idx].qpos; ci.q1 = an[best].qpos;
         ci.r0 = std::min(an[idx].rpos, an[best].rpos); ci.r1 = std::max(an[idx].rpos, an[best].rpos);
         ci.rctg = an[idx].rctg; ci.qctg = an[idx].qctg; ci.score = max_score; ci.num_anchors = na;
         ci.chunk_id = chunk_id; ci.rev = an[idx].rev; ci.overlap = 0;
-        good.push_back(ci);
+        w.ints.push_back(ci);
     }
 }
 
-// chain.rs:1008-1099 (bio IntervalTree::find(a..b) = stored s..e with s<b && a<e; only sums are used)
-void get_nonoverlapping(std::vector<ChainInterval>& ints, size_t n_chunks, std::vector<std::vector<ChainInterval>>& good, ora_chain_stats* st) {
+// chain.rs:1008-1099 (bio IntervalTree::find(a..b) = stored s..e with s<b && a<e; only sums are used).  Output: w.good grouped by chunk.
+void get_nonoverlapping(Work& w, size_t n_chunks, size_t n_qctg, size_t n_rctg, ora_chain_stats* st) {
+    auto& ints = w.ints;
     std::stable_sort(ints.begin(), ints.end(), [](const ChainInterval& x, const ChainInterval& y) { return ci_cmp(y, x) < 0; });  // :1012
-    good.assign(n_chunks, {});
-    std::unordered_map<size_t, std::vector<size_t>> acc_q, acc_r;
+    if (w.acc_q.size() < n_qctg) w.acc_q.resize(n_qctg);
+    if (w.acc_r.size() < n_rctg) w.acc_r.resize(n_rctg);
+    for (const auto& in : ints) { w.acc_q[in.qctg].clear(); w.acc_r[in.rctg].clear(); }
+    w.accepted.clear();
     uint64_t hsh = 1469598103934665603ull; uint64_t nacc = 0;
     auto mix = [&](uint64_t x) { hsh ^= x; hsh *= 1099511628211ull; };
     for (size_t i = 0; i < ints.size(); i++) {
         const ChainInterval& in = ints[i];
-        auto& tr = acc_r[in.rctg]; auto& tq = acc_q[in.qctg];
+        auto& tr = w.acc_r[in.rctg]; auto& tq = w.acc_q[in.qctg];
         bool ok_ref, ok_q;
         {
             uint32_t sum = 0; size_t cnt = 0;
-            for (size_t o : tr) { const ChainInterval& ol = ints[o]; if (ol.r0 < in.r1 && in.r0 < ol.r1) { cnt++; sum += std::min(in.r1 - ol.r0, ol.r1 - in.r0); } }
+            for (uint32_t o : tr) { const ChainInterval& ol = ints[o]; if (ol.r0 < in.r1 && in.r0 < ol.r1) { cnt++; sum += std::min(in.r1 - ol.r0, ol.r1 - in.r0); } }
             ok_ref = cnt == 0 || (float)sum < (float)(in.r1 - in.r0) * OVERLAP_ORTHOLOGOUS_FRACTION;   // :1030-1056
         }
         {
             uint32_t sum = 0; size_t cnt = 0;
-            for (size_t o : tq) { const ChainInterval& ol = ints[o]; if (ol.q0 < in.q1 && in.q0 < ol.q1) { cnt++; sum += std::min(in.q1 - ol.q0, ol.q1 - in.q0); } }
+            for (uint32_t o : tq) { const ChainInterval& ol = ints[o]; if (ol.q0 < in.q1 && in.q0 < ol.q1) { cnt++; sum += std::min(in.q1 - ol.q0, ol.q1 - in.q0); } }
             ok_q = cnt == 0 || (float)sum < (float)(in.q1 - in.q0) * OVERLAP_ORTHOLOGOUS_FRACTION;     // :1058-1085
         }
         if (ok_ref && ok_q) {                                                        // :1086-1094 (stored overlap stays 0)
-            tq.push_back(i); tr.push_back(i); good[in.chunk_id].push_back(in); nacc++;
+            tq.push_back((uint32_t)i); tr.push_back((uint32_t)i); w.accepted.push_back((uint32_t)i); nacc++;
             mix((uint64_t)in.score); mix(in.num_anchors); mix(in.q0); mix(in.q1); mix(in.r0); mix(in.r1); mix(in.rctg); mix(in.qctg); mix(in.chunk_id); mix(in.rev);
         }
     }
+    // good_intervals[chunk_id].push(interval) in acceptance order (:1094): a stable bucketing by chunk
+    w.good_begin.assign(n_chunks + 1, 0);
+    for (uint32_t i : w.accepted) w.good_begin[ints[i].chunk_id + 1]++;
+    for (size_t c = 0; c < n_chunks; c++) w.good_begin[c + 1] += w.good_begin[c];
+    w.good_fill.assign(w.good_begin.begin(), w.good_begin.end() - 1);
+    w.good.resize(w.accepted.size());
+    for (uint32_t i : w.accepted) w.good[w.good_fill[ints[i].chunk_id]++] = ints[i];
     if (st) { st->n_accepted = nacc; st->interval_checksum = hsh; }
 }
 
@@ -426,15 +530,15 @@ double std_deviation(const std::vector<double>& d) {  // chain.rs:39-55
     return std::sqrt(v / (double)d.size());
 }
 
-void bootstrap_interval(const std::vector<std::pair<double, size_t>>& est, double& lo, double& hi, double& sd) {  // chain.rs:57-86
-    std::vector<double> nomult; for (auto& e : est) nomult.push_back(e.first);
+void bootstrap_interval(Work& w, const std::vector<std::pair<double, size_t>>& est, double& lo, double& hi, double& sd) {  // chain.rs:57-86
+    auto& nomult = w.nomult; nomult.clear(); for (auto& e : est) nomult.push_back(e.first);
     sd = std_deviation(nomult);
     size_t num_samp = est.size();
     if (num_samp < 10) { lo = 0.; hi = 1.; return; }
-    std::vector<double> mult; for (auto& e : est) for (size_t i = 0; i < e.second; i++) mult.push_back(e.first);
+    auto& mult = w.mult; mult.clear(); for (auto& e : est) for (size_t i = 0; i < e.second; i++) mult.push_back(e.first);
     WyRand rng{7};
-    const size_t iters = 100; std::vector<double> res;
-    std::vector<size_t> rv(num_samp);
+    const size_t iters = 100; auto& res = w.boot; res.clear();
+    auto& rv = w.rv; rv.resize(num_samp);
     for (size_t it = 0; it < iters; it++) {
         for (size_t j = 0; j < num_samp; j++) rv[j] = (size_t)rng.below(mult.size());
         double s = 0; for (size_t j = 0; j < num_samp; j++) s += mult[rv[j]];
@@ -447,18 +551,19 @@ void bootstrap_interval(const std::vector<std::pair<double, size_t>>& est, doubl
 float f32nan() { return std::numeric_limits<float>::quiet_NaN(); }
 
 // chain.rs:173-555
-void calculate_ani(const std::vector<std::vector<ChainInterval>>& int_chunks, const ora_sketch& ref, const ora_sketch& query,
-                   const AnchorChunks& ac, const ora_map_opts& mo, bool switched, ora_ani_result& out, ora_chain_stats* st) {
+void calculate_ani(Work& w, const ora_sketch& ref, const ora_sketch& query, const ora_map_opts& mo, bool switched, ora_ani_result& out, ora_chain_stats* st) {
     const uint32_t k = ref.k; const uint32_t c = ref.c;                // map_params.k = ref.k (chain.rs:115)
     const bool sensitive_af = c < 200;                                 // :184-190
-    std::vector<std::pair<double, size_t>> ests;
+    auto& ests = w.ests; ests.clear();
     uint32_t total_query_bases = 0, total_ref_range = 0, avg_chain_int_len = 0, num_chains = 0;
-    for (size_t i = 0; i < int_chunks.size(); i++) {
-        const auto& ints = int_chunks[i];
+    const size_t n_chunks = w.n_chunks();
+    for (size_t i = 0; i < n_chunks; i++) {
+        const ChainInterval* ints = w.good.data() + w.good_begin[i]; const size_t n_ints = w.good_begin[i + 1] - w.good_begin[i];
         size_t total_anchors = 0; uint32_t tbcq = 0;
         uint32_t rq0 = UINT32_MAX, rq1 = 0;
-        std::vector<std::pair<uint32_t, uint32_t>> uni;
-        for (const auto& in : ints) {
+        auto& uni = w.uni; uni.clear();
+        for (size_t x = 0; x < n_ints; x++) {
+            const ChainInterval& in = ints[x];
             total_anchors += in.num_anchors;
             if (in.q0 < rq0) rq0 = in.q0;
             if (in.q1 > rq1) rq1 = in.q1;
@@ -472,12 +577,14 @@ void calculate_ani(const std::vector<std::vector<ChainInterval>>& int_chunks, co
         if (rq1 - rq0 < MIN_LENGTH_COVER) continue;                                                      // :257
         if (!sensitive_af) { total_query_bases += rq1 - rq0 + 2 * c + k; total_ref_range += rq1 - rq0 + 2 * c + k; }
         size_t in_int = 0, upper_lower = 0;
-        for (uint32_t p : ac.seeds_in_chunk[i]) {
+        const uint32_t* sd0 = w.seeds.data() + w.seeds_begin[i]; const size_t n_seeds = w.seeds_begin[i + 1] - w.seeds_begin[i];
+        for (size_t x = 0; x < n_seeds; x++) {
+            const uint32_t p = sd0[x];
             bool hit = false; for (auto& u : uni) if (p >= u.first && p <= u.second) { hit = true; break; }
             if (hit) in_int++;
             if (p >= rq0 && p <= rq1) upper_lower++;                                                     // :326-332 (spacing = 0)
         }
-        size_t considered = ac.seeds_in_chunk[i].size();
+        size_t considered = n_seeds;
         double putative = std::pow((double)total_anchors / (double)in_int, 1. / (double)k);              // :335-339
         if (putative > 0.950 && tbcq > c * 4 && rq1 - rq0 < (uint32_t)(CHUNK_SIZE_DNA * 9 / 10) &&
             (double)considered > 1.05 * (double)upper_lower)
@@ -503,7 +610,7 @@ void calculate_ani(const std::vector<std::vector<ChainInterval>>& int_chunks, co
     size_t tm = 0; double wavg = 0.;
     for (size_t i = lower_i; i < upper_i; i++) { wavg += ests[i].first * (double)ests[i].second; tm += ests[i].second; }
     double final_ani = wavg / (double)tm;
-    double ci_lo, ci_hi, sd; bootstrap_interval(ests, ci_lo, ci_hi, sd);
+    double ci_lo, ci_hi, sd; bootstrap_interval(w, ests, ci_lo, ci_hi, sd);
     double cov_q = std::min(1., (double)total_query_bases / (double)query.total_len);
     double cov_r = std::min(1., (double)total_ref_range / (double)ref.total_len);
     double cutoff = mo.min_af < 0. ? 0.15 : mo.min_af;                                                   // chain.rs:100-107
@@ -547,18 +654,22 @@ void predict_from_ani_res(ora_ani_result& r, const ora_model& m) {
 
 void chain_seeds(const ora_sketch& ref, const ora_sketch& query, const ora_map_opts& mo, const ora_model* model,
                  ora_ani_result& out, ora_chain_stats* st) {
+    static thread_local Work w;                                         // this thread's scratch, kept across pairs
     if (st) memset(st, 0, sizeof *st);
     const size_t band = BP_CHAIN_BAND / ref.c;                          // chain.rs:112 index_chain_band
-    AnchorChunks ac; bool have;
-    bool switched = get_anchors(ref, query, band, ac, have, st);
-    if (st) { st->switched = switched; st->n_chunks = ac.chunks.size(); }
-    std::vector<ChainInterval> good;
-    ChainRes cr;
-    for (size_t i = 0; i < ac.chunks.size(); i++) { chain_chunk(ac.chunks[i], band, cr); get_chain_intervals(good, cr, ac.chunks[i], i); }
-    if (st) st->n_intervals = good.size();
-    std::vector<std::vector<ChainInterval>> good_chunks;
-    get_nonoverlapping(good, ac.chunks.size(), good_chunks, st);
-    calculate_ani(good_chunks, ref, query, ac, mo, switched, out, st);
+    bool have;
+    bool switched = get_anchors(ref, query, band, w, have, st);
+    const size_t n_chunks = w.n_chunks();
+    if (st) { st->switched = switched; st->n_chunks = n_chunks; }
+    w.ints.clear();
+    for (size_t i = 0; i < n_chunks; i++) {
+        const Anchor* ch = w.anchors.data() + w.chunk_begin[i]; const size_t n = w.chunk_begin[i + 1] - w.chunk_begin[i];
+        chain_chunk(ch, n, band, w); get_chain_intervals(w, ch, n, i);
+    }
+    if (st) st->n_intervals = w.ints.size();
+    const ora_sketch& A = switched ? ref : query; const ora_sketch& B = switched ? query : ref;   // interval contigs: query side = A, ref side = B
+    get_nonoverlapping(w, n_chunks, A.contig_lengths.size(), B.contig_lengths.size(), st);
+    calculate_ani(w, ref, query, mo, switched, out, st);
     if (model) predict_from_ani_res(out, *model);
 }
 
@@ -585,9 +696,36 @@ int ora_sketch_add_contig(ora_sketch* s, const uint8_t* seq, uint64_t len, int m
     if (len < min_len) return 0;                                        // file_io.rs:176
     uint32_t j = (uint32_t)s->contig_lengths.size();
     s->contig_lengths.push_back((uint32_t)len); s->total_len += len;   // file_io.rs:180-182
-    if (mode == 1 && len >= K_MARKER_DNA) fmh_seeds_avx2_semantics(seq, len, s->c, s->k, s->marker_c, j, *s);
-    else if (mode != 1) fmh_seeds_scalar(seq, len, s->c, s->k, s->marker_c, j, *s);
+    if (mode == 1 && len >= K_MARKER_DNA) fmh_seeds_avx2(seq, len, s->c, s->k, s->marker_c, j, *s);
+    else if (mode == 2 && len >= K_MARKER_DNA) fmh_seeds_avx2_semantics(seq, len, s->c, s->k, s->marker_c, j, *s);   // the plain-C++ statement of mode 1
+    else if (mode == 0) fmh_seeds_scalar(seq, len, s->c, s->k, s->marker_c, j, *s);
     return 1;
+}
+
+// glibc hands every vector beyond 128 KB to mmap and returns it with munmap: with many threads sketching / chaining at once those calls queue on the
+// process's address-space lock.  The reference links an allocator built for this (main.rs:10-18); here the thresholds are raised once so that the
+// arenas keep and reuse the memory.
+static void tune_malloc_once() {
+    static std::once_flag once;
+    std::call_once(once, [] { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 64 << 20); });
+}
+
+// file_io.rs:141-252 for a batch of files: genome g = contigs [genome_contig_off[g], genome_contig_off[g + 1]); files are sketched in parallel like the
+// reference's par_iter over files (file_io.rs:147), `threads` workers pulling genomes from a shared counter
+void ora_sketch_batch(uint32_t n_genomes, const uint64_t* genome_contig_off, const uint8_t* const* seq, const uint64_t* len, uint32_t c, uint32_t k,
+                      uint32_t marker_c, const char* const* names, int mode, uint64_t min_len, int threads, ora_sketch** out) {
+    tune_malloc_once();
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint32_t g = next.fetch_add(1); if (g >= n_genomes) break;
+            ora_sketch* s = ora_sketch_new(c, k, marker_c, names ? names[g] : "");
+            for (uint64_t x = genome_contig_off[g]; x < genome_contig_off[g + 1]; x++) ora_sketch_add_contig(s, seq[x], len[x], mode, min_len);
+            out[g] = s;
+        }
+    };
+    std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(worker); for (auto& t : th) t.join();
 }
 
 ora_sketch* ora_sketch_from_arrays(uint32_t c, uint32_t k, uint32_t marker_c, const char* file_name, const uint32_t* seed,
@@ -674,10 +812,29 @@ int ora_check_markers_quickly(const ora_sketch* ref, const ora_sketch* query, do
 namespace {
 struct InvIndex {  // screen.rs:190-210 (marker -> genome ids), built sort-based
     std::vector<uint64_t> key; std::vector<uint32_t> gid; std::vector<uint64_t> ukey; std::vector<uint32_t> ustart; size_t mask = 0; std::vector<uint32_t> table;
-    void build(const ora_sketch* const* sk, uint32_t n) {
+    // The reference builds this map serially (triangle.rs:55 -> screen.rs:190-210).  With threads > 1 the (marker, genome) incidences are dealt into
+    // ranges of the marker value, every range is sorted by one thread and the ranges are concatenated: the same sorted list, the same table.
+    void build(const ora_sketch* const* sk, uint32_t n, int threads = 1) {
         std::vector<std::pair<uint64_t, uint32_t>> v;
-        for (uint32_t g = 0; g < n; g++) sk[g]->markers.for_each([&](uint64_t m) { v.push_back({m, g}); });
-        std::sort(v.begin(), v.end());
+        if (threads <= 1 || n < 64) {
+            for (uint32_t g = 0; g < n; g++) sk[g]->markers.for_each([&](uint64_t m) { v.push_back({m, g}); });
+            std::sort(v.begin(), v.end());
+        } else {
+            const uint32_t NB = (uint32_t)threads * 4;                               // ranges of the 42-bit marker value
+            auto bucket = [&](uint64_t m) { return (uint32_t)(((m >> 10) * NB) >> 32); };
+            std::vector<std::vector<std::vector<std::pair<uint64_t, uint32_t>>>> part(threads, std::vector<std::vector<std::pair<uint64_t, uint32_t>>>(NB));
+            std::atomic<uint32_t> next{0};
+            auto deal = [&](int t) { for (;;) { const uint32_t g = next.fetch_add(1); if (g >= n) break; sk[g]->markers.for_each([&](uint64_t m) { part[t][bucket(m)].push_back({m, g}); }); } };
+            { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(deal, t); for (auto& t : th) t.join(); }
+            std::vector<size_t> off(NB + 1, 0);
+            for (uint32_t b = 0; b < NB; b++) { size_t c = 0; for (int t = 0; t < threads; t++) c += part[t][b].size(); off[b + 1] = off[b] + c; }
+            v.resize(off[NB]);
+            std::atomic<uint32_t> nb{0};
+            auto sort_range = [&]() { for (;;) { const uint32_t b = nb.fetch_add(1); if (b >= NB) break; size_t at = off[b];
+                for (int t = 0; t < threads; t++) { std::copy(part[t][b].begin(), part[t][b].end(), v.begin() + at); at += part[t][b].size(); }
+                std::sort(v.begin() + off[b], v.begin() + off[b + 1]); } };
+            { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(sort_range); for (auto& t : th) t.join(); }
+        }
         key.resize(v.size()); gid.resize(v.size());
         for (size_t i = 0; i < v.size(); i++) { key[i] = v[i].first; gid[i] = v[i].second; if (i == 0 || v[i].first != v[i - 1].first) { ukey.push_back(v[i].first); ustart.push_back((uint32_t)i); } }
         ustart.push_back((uint32_t)v.size());
@@ -731,8 +888,9 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
                       uint64_t* n_chained, uint64_t* n_screen_pass) {
     if (screen_val == 0.) screen_val = 0.80;                            // triangle.rs:33-42
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    tune_malloc_once();
     const auto t_start = std::chrono::steady_clock::now();
-    InvIndex ix; ix.build(sk, n);                                       // triangle.rs:55
+    InvIndex ix; ix.build(sk, n, threads);                              // triangle.rs:55
     const auto t_index = std::chrono::steady_clock::now();
     std::vector<std::vector<uint32_t>> pass(n);
     std::atomic<uint32_t> next{0};

@@ -50,6 +50,12 @@ void ora_sketch_free(ora_sketch*);
 /* file_io.rs:176-230: contigs shorter than min_len (500) are skipped entirely; returns 1 if kept.
  * mode 0 = seeding.rs:225-323 (scalar), 1 = avx2_seeding.rs:33-272 semantics. */
 int ora_sketch_add_contig(ora_sketch*, const uint8_t* seq, uint64_t len, int mode, uint64_t min_len);
+/* file_io.rs:141-252 for a batch of files, sketched by `threads` workers (file_io.rs:147 par_iter): genome g = contigs
+ * [genome_contig_off[g], genome_contig_off[g+1]) of seq[] / len[]; out[g] receives a new sketch named names[g].
+ * mode 2 = the plain-C++ statement of mode 1 (mode 1 itself runs AVX2 intrinsics like the reference where the build has them). */
+void ora_sketch_batch(uint32_t n_genomes, const uint64_t* genome_contig_off, const uint8_t* const* seq, const uint64_t* len,
+                      uint32_t c, uint32_t k, uint32_t marker_c, const char* const* names, int mode, uint64_t min_len, int threads,
+                      ora_sketch** out);
 /* build a sketch from explicit arrays (golden fixture) */
 ora_sketch* ora_sketch_from_arrays(uint32_t c, uint32_t k, uint32_t marker_c, const char* file_name,
                                    const uint32_t* seed, const uint32_t* pos, const uint32_t* ctgcanon,

@@ -298,7 +298,7 @@ def test_config4_eight_ranks_one_device():
     """BASELINE config 4 -- the triangle over 10,000 synthetic ~5 Mbp genomes tiled over eight ranks -- with the eight ranks as eight processes on
     the ONE GPU of this box (host-collective transport; bench.py --gpus 8 runs the same call over RCCL, one GPU per rank).  Every rank generates and
     sketches its 1,250 genomes of bench.py's shuffled collection (deferred seed tables) and calls skh_triangle_distributed.  Checked: 95,000
-    chained pairs, all inside clades; the same result bytes on every rank; shares within 2 %; what is sent is received, no sketch travels twice;
+    chained pairs, all inside clades; the same result bytes on every rank; cost shares within 1 % (pair counts within 3 %); what is sent is received, no sketch travels twice;
     one clade field by field against the oracle; and the whole result byte by byte against ONE process running skh_triangle over the same 10,000
     genomes on the same GPU (50 GB of ASCII, 12.5 GB packed, ~14 GB of sketches)."""
     import multiprocessing as mp
@@ -324,8 +324,10 @@ def test_config4_eight_ranks_one_device():
     assert all(g[2] == 95000 for g in got) and len(i) == 95000 and (i < j).all() and (clade_of[i] == clade_of[j]).all()
     assert len({g[1] for g in got}) == 1                           # identical result bytes on every rank
     stats = [g[3] for g in got]
-    shares = np.array([s["n_pairs_mine"] for s in stats])
-    assert shares.sum() == 95000 and np.abs(shares - shares.mean()).max() <= 0.02 * shares.mean(), shares
+    shares = np.array([s["n_pairs_mine"] for s in stats]); costs = np.array([s["cost_mine"] for s in stats], np.float64)
+    # whole clusters (190 pairs each) are dealt out by estimated cost (marker counts: the genomes are 4.5-5.5 Mbp): costs within 1 %, pair counts within 3 %
+    assert shares.sum() == 95000 and np.abs(shares - shares.mean()).max() <= 0.03 * shares.mean(), shares
+    assert np.abs(costs - costs.mean()).max() <= 0.01 * costs.mean() and all(s["cost_total"] == costs.sum() for s in stats), costs
     sent, recvd, moved = sum(s["bytes_sent"] for s in stats), sum(s["bytes_received"] for s in stats), sum(s["n_genomes_received"] for s in stats)
     assert sent == recvd > 0 and 0 < moved <= N                    # every sketch is needed by one rank only: it travels at most once
     assert stats[0]["screen_row_begin"] == 0 and stats[-1]["screen_row_end"] == N and all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))

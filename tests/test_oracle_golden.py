@@ -119,3 +119,31 @@ def test_screen_rules():
     assert ora.check_markers_quickly(w, o, 0.8, False)
     assert list(ora.screen_refs([w, o, p], o, 0.8, 0, True)) == [0, 1, 2]
     assert abs(ora.lib().ora_powi(0.8, 21) - 0.8**21) < 1e-15
+
+
+def test_avx2_intrinsics_equal_their_plain_statement():
+    """The oracle's mode 1 runs avx2_seeding.rs's algorithm with AVX2 intrinsics (what bench.py's CPU baseline times); mode 2 is the plain C++
+    statement of the same lines.  Same seeds, positions, strands and markers on the golden plasmid, E. coli W, the viruses (tail rule) and on random
+    contigs with N runs, lower-case bases and every length class mod 4; sketch_batch (threads) equals per-contig calls."""
+    from tests.helpers import random_genome
+    rng = np.random.default_rng(77)
+    sets = [golden_records("o157_plasmid.fasta"), golden_records("e.coli-W.fasta.gz"), golden_records("viruses.fna")]
+    rnd = []
+    for i in range(12):
+        s = bytearray(random_genome(int(rng.integers(600, 60000)) + i % 4, 500 + i, n_rate=0.0005 if i % 3 == 0 else 0.0))
+        if i % 2:
+            a = int(rng.integers(0, len(s) - 300)); s[a:a + 200] = bytes(s[a:a + 200]).lower()
+        if i % 5 == 0:
+            a = int(rng.integers(0, len(s) - 300)); s[a:a + 120] = b"N" * 120
+        rnd.append(("r%d" % i, bytes(s)))
+    sets.append(rnd)
+    for c in (125, 30):
+        fast = ora.sketch_batch(sets, c, 15, 1000, ["f%d" % i for i in range(len(sets))], 1, 500, 3)
+        for g, recs in enumerate(sets):
+            plain = ora.sketch_records(recs, c, 15, 1000, "f%d" % g, 2)
+            one = ora.sketch_records(recs, c, 15, 1000, "f%d" % g, 1)
+            for sk in (fast[g], one):
+                for u, v in zip(sk.seeds(True), plain.seeds(True)):
+                    assert np.array_equal(u, v)
+                assert np.array_equal(sk.markers(), plain.markers()) and list(sk.contig_lengths()) == list(plain.contig_lengths())
+            assert plain.n_positions > 0
