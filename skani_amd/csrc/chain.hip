@@ -124,6 +124,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     const uint32_t NP = job.n_pairs, band = job.band, c = job.c, k = job.k;
     const GbdtModel* model = job.model; const skh_map_params& mp = job.mp;
     StageTrace tr(ctx);
+    const bool join_trace = getenv("SKH_TRACE_JOIN") != nullptr;
     uint64_t n_tiles_all = 0;
     for (uint32_t p = 0; p < NP; p++) {
         pds[p].tile0 = (uint32_t)n_tiles_all;
@@ -154,15 +155,28 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         unsigned long long* inq_mask = ctx->arena.get<unsigned long long>((size_t)snt * (JOIN_TILE / 64) + 1);
         // kernels index tiles globally: shift the record arrays so that tile st0 maps to their start
         uint2* pis = hit_rec - (size_t)st0 * JOIN_TILE; unsigned long long* imk = inq_mask - (size_t)st0 * (JOIN_TILE / 64);
-        uint2* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         uint32_t bm_words = 0;                                                     // LDS for the largest bitmap of the batch, up to 32 KB
         for (uint32_t p = sp0; p < sp1; p++) bm_words = std::max(bm_words, ((pds[p].b_nbk + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES + 3) / 4 * 4);
         if (bm_words > ctx->tune.join_bitmap_words) bm_words = ctx->tune.join_bitmap_words;   // pairs with a larger bitmap probe the table directly
+        uint2* d_super_slots = nullptr; unsigned n_super_slots = 0;            // reused by the fill pass when the batch is the whole super-batch
         if (snt) {
-            uint2* d_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, job.pair_key, &n_super_slots);
-            d_super_slots = d_slots;
-            SKH_LAUNCH(join_count_kernel, n_super_slots, 256, (size_t)bm_words * 4, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
-                       band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words);
+            d_super_slots = xcd_slots(ctx, sp0, sp1, pds, d_pairs_all, job.pair_key, &n_super_slots);
+            const size_t lds = (size_t)bm_words * 4 + (size_t)JOIN_GROUP * JOIN_Q * 8;   // the filter + a probe queue per wave
+            if (lds > ((size_t)48 << 10)) kernel_allow_lds(join_count_kernel<false>, lds);
+            if (!join_trace)
+                SKH_LAUNCH(join_count_kernel<false>, n_super_slots, 256, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
+                           band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words, (unsigned long long*)nullptr);
+            else {                                                                     // SKH_TRACE_JOIN=1: where a wave of the count pass spends its cycles (slower: every phase waits for its loads)
+                unsigned long long* d_prof = ctx->arena.get<unsigned long long>(16); dzero(d_prof, 128, ctx->stream);
+                if (lds > ((size_t)48 << 10)) kernel_allow_lds(join_count_kernel<true>, lds);
+                SKH_LAUNCH(join_count_kernel<true>, n_super_slots, 256, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
+                           band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words, d_prof);
+                unsigned long long hp[16]; d2h(hp, d_prof, 128, ctx->stream);
+                const double nw = hp[8] ? (double)hp[8] : 1.;
+                fprintf(stderr, "[skh trace] join_count: %llu waves; cycles per wave: wait for the round's hashes %.0f, filter + prefix %.0f, queue %.0f, wait for the home slots %.0f, "
+                        "cluster walks %.0f (%.1f steps), results back %.0f, classify + list heads + stores %.0f\n", hp[8], hp[0] / nw, hp[1] / nw, hp[2] / nw, hp[3] / nw, hp[4] / nw,
+                        hp[7] / nw, hp[5] / nw, hp[6] / nw);
+            }
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");

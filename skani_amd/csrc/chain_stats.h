@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
     uint32_t cur[PF], nxt[PF];
     auto fetch = [&](const uint32_t* ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> uint32_t {
         if (s2 >= se_j) return 0u;
-        return (ag_j[s2] & ~1u) | (uint32_t)((mk_j[s2 >> 6] >> (s2 & 63u)) & 1ull);
+        return (ag_j[s2] & ~1u) | (uint32_t)((mk_j[((s2 >> 8) << 2) | (s2 & 3u)] >> ((s2 >> 2) & 63u)) & 1ull);   // join_count_kernel's layout: bit l of word r of a 256-position round = position 4 l + r
     };
     auto bcast_ptr = [&](const void* ptr, int src) -> const void* {
         const unsigned long long v = (unsigned long long)ptr;

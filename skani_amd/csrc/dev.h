@@ -125,6 +125,9 @@ __device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) { uint3
 // LDS crossbar -- for dependent chains of neighbour exchanges
 __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
 __device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+// in-kernel timing (SKH_TRACE_JOIN): the shader clock, and a point at which a loaded value must have arrived
+__device__ __forceinline__ unsigned long long wave_clock() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ void wait_for_value(uint32_t v) { asm volatile("" ::"v"(v)); }
 // the XCD (0..7 on MI355X) this wave runs on, and an increment performed in that XCD's L2 (workgroup scope): screen.hip's per-XCD count planes
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xFu; }
 __device__ __forceinline__ void atomic_inc_xcd_local(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
