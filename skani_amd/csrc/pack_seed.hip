@@ -27,28 +27,70 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {   // types.rs:40-49 
     return 0;
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(const uint8_t* bases, const uint64_t* src_off, const uint64_t* unit_off,
+// A thread packs 32 consecutive bases of one contig (a "unit": contigs start on unit boundaries).  Its 32 source bytes are fetched as nine
+// 4-byte-aligned words (two four-word loads and one more; neighbouring lanes read neighbouring 32-byte stretches: coalesced) and shifted into place;
+// base codes, the validity of every byte (types.rs:40-49: anything but ACGTU / acgtu / 0..3 is an A) and the N flags come out of byte-parallel
+// arithmetic on whole words, four bases at a time.  Round 2's kernel walked its 32 bytes one by one: 0.5 TB/s; this one is bound by HBM.
+struct __attribute__((packed, aligned(4))) PackWords4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {                       // 0x80 in every byte of v that is zero (exact, no borrow between bytes)
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t shift_bytes(uint32_t hi, uint32_t lo, uint32_t n_bytes) {   // bytes n .. n + 3 of the eight bytes hi:lo
+    return n_bytes ? (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8u * n_bytes)) : lo;
+}
+// four ASCII bases in a word (first base in the lowest byte) -> their codes in one byte, first base in the two highest bits
+__device__ __forceinline__ uint32_t codes_of_word(uint32_t w) {
+    const uint32_t x = (w >> 1) & 0x03030303u, letter = x ^ ((x >> 1) & 0x01010101u);   // A 0, C 1, G 2, T / U 3 from bits 1..2 of the letter, either case
+    const uint32_t lower = w | 0x20202020u;
+    const uint32_t is_letter = zero_bytes(lower ^ 0x61616161u) | zero_bytes(lower ^ 0x63636363u) | zero_bytes(lower ^ 0x67676767u) |
+                               zero_bytes(lower ^ 0x74747474u) | zero_bytes(lower ^ 0x75757575u);
+    const uint32_t is_small = zero_bytes(w & 0xFCFCFCFCu);                          // bytes 0..3 are their own code (the table's first row)
+    const uint32_t c = (letter & ((is_letter >> 7) * 3u)) | (w & ((is_small >> 7) * 3u));
+    return (c * 0x40100401u) >> 24;                                                 // byte 0 -> bits 7..6, byte 1 -> 5..4, byte 2 -> 3..2, byte 3 -> 1..0
+}
+__device__ __forceinline__ uint32_t n_flags_of_word(uint32_t w, int mode) {         // bit x = base x is an N for the selected seeding path
+    uint32_t f = zero_bytes(w ^ 0x4E4E4E4Eu);                                       // 'N': seeding.rs:272-275 and avx2_seeding.rs:115-126
+    if (mode == SKH_SEED_SCALAR) f |= zero_bytes(w ^ 0x6E6E6E6Eu);                  // 'n': the scalar path only
+    return ((f >> 7) * 0x10204080u) >> 28;
+}
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t* bases, uint64_t readable_bytes, const uint64_t* src_off, const uint64_t* unit_off,
                                                    ContigDesc* contigs, uint32_t n_contigs, uint64_t n_units, int mode,
                                                    uint32_t* packed, uint32_t* nmask) {
-    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_units) return;
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = u < n_units;
+    // the contig of the wave's first unit by binary search, the lanes' own by walking on from it (contigs have at least 16 units: a step or two)
+    const uint64_t u0 = __shfl(u, 0, 64);
     uint32_t lo = 0, hi = n_contigs;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= u) lo = mid; else hi = mid; }
-    const uint32_t ci = lo;
+    if (u0 < n_units) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= u0) lo = mid; else hi = mid; }
+    if (!live) return;
+    uint32_t ci = lo;
+    while (ci + 1 < n_contigs && unit_off[ci + 1] <= u) ci++;
     const uint64_t b0 = (u - unit_off[ci]) * 32;
     const uint32_t len = contigs[ci].len;
-    const uint8_t* src = bases + src_off[ci];
+    const uint64_t so = src_off[ci] + b0;                                           // first source byte of the unit
     uint32_t w0 = 0, w1 = 0, m = 0;
-    for (uint32_t x = 0; x < 32; x++) {
-        uint64_t p = b0 + x;
-        uint32_t byte = p < len ? src[p] : (uint32_t)'A';
-        uint32_t code = base_code(byte);
-        // seeding.rs:272-275 tests 'N'(78) and 'n'(110); avx2_seeding.rs:115-126 tests 'N' only
-        bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
-        if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
-        m |= (is_n ? 1u : 0u) << x;
+    const uint64_t addr = (uint64_t)(uintptr_t)bases + so; const uint32_t sh = (uint32_t)(addr & 3u);
+    if (b0 + 32 <= len && so - sh + 36 <= readable_bytes) {                         // a whole unit inside the contig, all nine words readable
+        const uint32_t* q = (const uint32_t*)(uintptr_t)(addr - sh);
+        const PackWords4 qa = *(const PackWords4*)q, qb = *(const PackWords4*)(q + 4); const uint32_t q8 = q[8];
+        const uint32_t d[8] = {shift_bytes(qa.y, qa.x, sh), shift_bytes(qa.z, qa.y, sh), shift_bytes(qa.w, qa.z, sh), shift_bytes(qb.x, qa.w, sh),
+                               shift_bytes(qb.y, qb.x, sh), shift_bytes(qb.z, qb.y, sh), shift_bytes(qb.w, qb.z, sh), shift_bytes(q8, qb.w, sh)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w0 |= codes_of_word(d[j]) << (24 - 8 * j); w1 |= codes_of_word(d[4 + j]) << (24 - 8 * j); }
+#pragma unroll
+        for (int j = 0; j < 8; j++) m |= n_flags_of_word(d[j], mode) << (4 * j);
+    } else {                                                                        // a contig's last unit(s), the end of the buffer: byte by byte
+        const uint8_t* src = bases + src_off[ci];
+        for (uint32_t x = 0; x < 32; x++) {
+            const uint64_t p = b0 + x;
+            const uint32_t byte = p < len ? src[p] : (uint32_t)'A';
+            const uint32_t code = base_code(byte);
+            const bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
+            if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
+            m |= (is_n ? 1u : 0u) << x;
+        }
     }
-    packed[2 * u] = w0; packed[2 * u + 1] = w1; nmask[u] = m;     // contig bases are laid out at 32*unit_off
+    *(uint2*)(packed + 2 * u) = make_uint2(w0, w1); nmask[u] = m;                   // contig bases are laid out at 32 * unit_off
     if (m) atomicOr(&contigs[ci].has_n, 1u);
 }
 
@@ -84,11 +126,14 @@ void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const 
     gs->d_contigs.alloc(nc ? nc : 1);
     h2d(gs->d_contigs.p, gs->contigs.data(), nc * sizeof(ContigDesc), ctx->stream);
     const uint8_t* d_bases = bases;
-    if (!on_device) { uint8_t* stage = ctx->arena.get<uint8_t>(total_src + 16); h2d(stage, bases, total_src, ctx->stream); d_bases = stage; }
+    // bytes the kernel may read from the source: the caller's buffer, rounded up to whole 4-byte words at both ends (an aligned word that holds a valid byte is readable)
+    uint64_t readable = total_src;
+    if (!on_device) { uint8_t* stage = ctx->arena.get<uint8_t>(total_src + 64); h2d(stage, bases, total_src, ctx->stream); d_bases = stage; readable = total_src + 64; }
+    else readable = (total_src + ((uint64_t)(uintptr_t)bases & 3u) + 3) / 4 * 4 - ((uint64_t)(uintptr_t)bases & 3u);
     uint64_t* d_src = ctx->arena.get<uint64_t>(nc + 1); uint64_t* d_unit = ctx->arena.get<uint64_t>(nc + 1);
     h2d(d_src, src_off.data(), nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), (nc + 1) * 8, ctx->stream);
     if (n_units) {
-        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, (const uint64_t*)d_src,
+        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
                    (const uint64_t*)d_unit, gs->d_contigs.p, nc, n_units, gs->seeding_mode, gs->packed.p, gs->nmask.p);
         check_launch("pack_kernel");
     }

@@ -74,6 +74,31 @@ def case_seeding_fixtures(ctx):
     assert ss.sizes(0)["n_pos"] == 0
 
 
+def case_pack_every_byte(ctx):
+    """The ingest kernel's byte handling (types.rs:40-49 BYTE_TO_SEQ, N detection of both seeding paths): contigs drawn from ACGT with lower case,
+    N / n runs, U / u, IUPAC letters, punctuation, the raw codes 0..3 and high bytes, with lengths that put the following contigs at every byte
+    alignment; dense sketches (c = 6) so that nearly every window is looked at; also through a device buffer at an odd address."""
+    rng = np.random.default_rng(31)
+    common = np.frombuffer(b"ACGT", np.uint8)
+    odd = np.frombuffer(b"acgtNnUuRYKMSWBDHVryx-*. \x00\x01\x02\x03\x7f\xff@[`{", np.uint8)
+    recs = []
+    for i in range(48):
+        L = int(rng.integers(520, 4000)) + i % 7
+        a = common[rng.integers(0, 4, L)]
+        where = rng.random(L) < (0.0 if i % 5 == 0 else 0.03)
+        a = np.where(where, odd[rng.integers(0, len(odd), L)], a).astype(np.uint8)
+        if i % 4 == 1:
+            st = int(rng.integers(0, L - 100)); a[st:st + 40] = ord("N")
+        if i % 4 == 2:
+            st = int(rng.integers(0, L - 100)); a[st:st + 33] = ord("n")
+        recs.append(("c%d" % i, a.tobytes()))
+    genomes = [recs[:20], recs[20:33], recs[33:]]
+    for mode in (sk.SEED_SCALAR, sk.SEED_AVX2):
+        ss = ctx.sketch_records(genomes, sk.SketchParams(6, 15, 24, mode), ["p%d" % g for g in range(3)])
+        for g, r in enumerate(genomes):
+            assert_sketch_equal(ss, g, ora.sketch_records(r, 6, 15, 24, "p%d" % g, mode))
+
+
 def case_seeding_ecoli_w(ctx):
     W = golden_records("e.coli-W.fasta.gz")
     ss = ctx.sketch_records([W], sk.SketchParams(), ["w"])

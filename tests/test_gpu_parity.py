@@ -31,6 +31,7 @@ def test_library_is_the_hip_build(ctx):
 def test_seeding_golden(ctx): pc.case_seeding_golden_plasmid(ctx)
 def test_seeding_fixtures(ctx): pc.case_seeding_fixtures(ctx)
 def test_seeding_ecoli_w(ctx): pc.case_seeding_ecoli_w(ctx)
+def test_pack_every_byte(ctx): pc.case_pack_every_byte(ctx)
 def test_seeding_low_complexity(ctx): pc.case_seeding_low_complexity(ctx)
 def test_pinned_triples(ctx): pc.case_pinned_triples(ctx)
 def test_w_vs_w(ctx): pc.case_w_vs_w(ctx)
@@ -43,6 +44,24 @@ def test_marker_set_sizes(ctx): pc.case_marker_set_sizes(ctx)
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
 def test_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
+
+
+def test_pack_device_buffer_at_odd_addresses(ctx):
+    """skh_genomes_pack with bases already in HBM (what bench.py does) at byte addresses 1, 2 and 3 past a word boundary and with the buffer ending
+    right behind the last base: the kernel's aligned four-word loads must neither shift the bases nor read past the buffer's last word."""
+    import torch
+    recs = [("a", random_genome(70001, 41, 0.0005)), ("b", random_genome(1203, 42)), ("c", random_genome(33333, 43).lower())]
+    flat = np.frombuffer(b"".join(s for _, s in recs), np.uint8)
+    off = np.zeros(len(recs) + 1, np.uint64); off[1:] = np.cumsum([len(s) for _, s in recs])
+    want = ora.sketch_records(recs, 30, 15, 200, "x", 1)
+    for shift in (0, 1, 2, 3):
+        t = torch.zeros(len(flat) + shift, dtype=torch.uint8, device="cuda:0")
+        t[shift:] = torch.from_numpy(flat.copy()).to("cuda:0")
+        torch.cuda.synchronize()
+        gs = ctx.pack_buffer(None, off, np.zeros(len(recs), np.uint32), 1, sk.SEED_AVX2, device_ptr=t.data_ptr() + shift)
+        ss = ctx.sketch_genomes(gs, sk.SketchParams(30, 15, 200, sk.SEED_AVX2))
+        pc.assert_sketch_equal(ss, 0, want)
+        ss.close(); gs.close()
 
 
 def test_w_derivatives_triangle(ctx):
