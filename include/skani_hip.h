@@ -85,6 +85,23 @@ int skh_load_models(skh_ctx*, const char* path_c125, const char* path_c200);
 int skh_genomes_pack(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off, const uint32_t* contig_genome,
                      uint32_t n_contigs, uint32_t n_genomes, int bases_on_device, int seeding_mode,
                      skh_genome_set** out);
+/* The same in batches, so that parsing, PCIe and packing overlap (file_io.rs:147 reads its files in parallel; here later files are parsed while
+ * earlier ones are copied and packed).  skh_genomes_begin sizes the set: n_genomes genomes and at most max_bases bases, counting every contig's
+ * length rounded up to a multiple of 64 (a parser that only knows its files' sizes announces 1.13 x their sum: contigs have at least 500 bases);
+ * max_contigs is an estimate, the contig table grows when it is exceeded.
+ * skh_genomes_append adds whole genomes: contig i of the batch = bases[contig_start[i] .. contig_start[i] + contig_len[i]) (gaps between contigs
+ * are fine: parser threads may write their files into stretches of one buffer), contig_genome[i] = the genome's number in the set -- its
+ * position in the caller's file order, whatever order the batches arrive in; a genome's contigs come together, in order, in ONE batch; a genome
+ * that never arrives has no contigs.  The call returns when the batch is queued; with `bases` in pinned memory (skh_host_alloc) the copy runs
+ * behind the caller's back and the buffer may be rewritten once skh_genomes_wait(ticket) has returned.  One thread at a time per context, like
+ * every call.  skh_genomes_finish completes the set (it then behaves like one from skh_genomes_pack). */
+void* skh_host_alloc(uint64_t bytes);   /* pinned host memory; NULL on failure */
+void skh_host_free(void*);
+int skh_genomes_begin(skh_ctx*, uint64_t max_bases, uint32_t max_contigs, uint32_t n_genomes, int seeding_mode, skh_genome_set** out);
+int skh_genomes_append(skh_genome_set*, const uint8_t* bases, const uint64_t* contig_start, const uint64_t* contig_len, const uint32_t* contig_genome,
+                       uint32_t n_contigs, int bases_on_device, uint64_t* ticket);
+int skh_genomes_wait(skh_genome_set*, uint64_t ticket);
+int skh_genomes_finish(skh_genome_set*);
 void skh_genomes_destroy(skh_genome_set*);
 uint64_t skh_genomes_total_bases(const skh_genome_set*);
 

@@ -44,6 +44,7 @@ class HostCollectives(C.Structure):
 
 
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
+           "skh_host_alloc", "skh_host_free", "skh_genomes_begin", "skh_genomes_append", "skh_genomes_wait", "skh_genomes_finish",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
            "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
            "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_triangle_distributed", "skh_plan_pairs"]
@@ -60,6 +61,12 @@ def load(path):
     L.skh_free.restype = None; L.skh_free.argtypes = [vp]
     L.skh_load_models.restype = i32; L.skh_load_models.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.skh_genomes_pack.restype = i32; L.skh_genomes_pack.argtypes = [vp, vp, vp, vp, u32, u32, i32, i32, pp]
+    L.skh_host_alloc.restype = vp; L.skh_host_alloc.argtypes = [u64]
+    L.skh_host_free.restype = None; L.skh_host_free.argtypes = [vp]
+    L.skh_genomes_begin.restype = i32; L.skh_genomes_begin.argtypes = [vp, u64, u32, u32, i32, pp]
+    L.skh_genomes_append.restype = i32; L.skh_genomes_append.argtypes = [vp, vp, vp, vp, vp, u32, i32, C.POINTER(u64)]
+    L.skh_genomes_wait.restype = i32; L.skh_genomes_wait.argtypes = [vp, u64]
+    L.skh_genomes_finish.restype = i32; L.skh_genomes_finish.argtypes = [vp]
     L.skh_genomes_destroy.restype = None; L.skh_genomes_destroy.argtypes = [vp]
     L.skh_genomes_total_bases.restype = u64; L.skh_genomes_total_bases.argtypes = [vp]
     L.skh_sketch_genomes.restype = i32; L.skh_sketch_genomes.argtypes = [vp, vp, C.POINTER(SketchParams), vp, pp]

@@ -108,6 +108,44 @@ class Context:
                                            1 if device_ptr is not None else 0, seeding_mode, C.byref(h)))
         return GenomeSet(self, h, seeding_mode, contig_off, contig_genome, n_genomes)
 
+    def pack_batches(self, batches, seeding_mode=SEED_AVX2, max_bases=None, max_contigs=None):
+        """skh_genomes_begin / _append / _finish: `batches` = list of batches, a batch = list of (genome number, [contig byte strings]); the genome
+        numbers of all batches together are 0 .. n-1 in any order.  Every batch goes through its own pinned buffer with a gap between the contigs
+        (what parser threads writing files into stretches of one buffer produce)."""
+        n_ctg = sum(len(c) for b in batches for _, c in b); n_bases = sum(len(s) for b in batches for _, c in b for s in c)
+        n_genomes = 1 + max([g for b in batches for g, _ in b], default=-1)
+        h = C.c_void_p()
+        self.check(self.L.skh_genomes_begin(self.h, max_bases if max_bases is not None else n_bases, max_contigs if max_contigs is not None else n_ctg, n_genomes,
+                                            seeding_mode, C.byref(h)))
+        pins = []
+        try:
+            for b in batches:
+                starts, lens, cg, at = [], [], [], 3
+                for g, ctgs in b:
+                    for s in ctgs:
+                        starts.append(at); lens.append(len(s)); cg.append(g); at += len(s) + 5      # five stray bytes between contigs
+                pin = self.L.skh_host_alloc(at + 8)
+                if not pin:
+                    raise SkaniHipError("skh_host_alloc failed")
+                pins.append(pin)
+                view = np.ctypeslib.as_array((C.c_uint8 * (at + 8)).from_address(pin)); view[:] = ord("#")
+                k = 0
+                for _, ctgs in b:
+                    for s in ctgs:
+                        view[starts[k]:starts[k] + lens[k]] = np.frombuffer(s, np.uint8); k += 1
+                st = np.array(starts, np.uint64); ln = np.array(lens, np.uint64); cgn = np.array(cg, np.uint32)
+                ticket = C.c_uint64()
+                self.check(self.L.skh_genomes_append(h, C.c_void_p(pin), _p(st), _p(ln), _p(cgn), len(starts), 0, C.byref(ticket)))
+                self.check(self.L.skh_genomes_wait(h, ticket.value))
+            self.check(self.L.skh_genomes_finish(h))
+        except Exception:
+            self.L.skh_genomes_destroy(h)
+            raise
+        finally:
+            for pin in pins:
+                self.L.skh_host_free(pin)
+        return GenomeSet(self, h, seeding_mode, None, None, n_genomes)
+
     # ---- sketch -------------------------------------------------------------------------------------------------
     def sketch_genomes(self, gs, params, genome_rank=None, names=None, defer_tables=False):
         """defer_tables: seeding + marker sets only; the seed tables are built on first use (a rank of a distributed triangle indexes only what it chains)."""

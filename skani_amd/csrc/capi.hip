@@ -112,25 +112,67 @@ int skh_genomes_pack(skh_ctx* ctx, const uint8_t* bases, const uint64_t* contig_
     int rc = guarded(ctx, [&] {
         if (seeding_mode != SKH_SEED_SCALAR && seeding_mode != SKH_SEED_AVX2) throw std::invalid_argument("bad seeding_mode");
         gs = new skh_genome_set();
-        gs->ctx = ctx; gs->seeding_mode = seeding_mode; gs->n_genomes = n_genomes; gs->n_contigs = n_contigs;
-        gs->contigs.resize(n_contigs); gs->genome_contig_off.assign(n_genomes + 1, 0);
-        uint32_t prev = 0, idx = 0;
+        gs->ctx = ctx; gs->seeding_mode = seeding_mode;
+        std::vector<uint64_t> len(n_contigs);
         for (uint32_t i = 0; i < n_contigs; i++) {
-            uint32_t g = contig_genome[i];
-            if (g >= n_genomes || g < prev) throw std::invalid_argument("contig_genome must be non-decreasing and < n_genomes");
-            if (g != prev) idx = 0;
-            gs->contigs[i].genome = g; gs->contigs[i].index = idx++;
-            gs->genome_contig_off[g + 1]++; prev = g;
+            if (contig_off[i + 1] < contig_off[i]) throw std::invalid_argument("contig_off must ascend");
+            if (contig_genome[i] >= n_genomes || (i && contig_genome[i] < contig_genome[i - 1])) throw std::invalid_argument("contig_genome must be non-decreasing and < n_genomes");
+            len[i] = contig_off[i + 1] - contig_off[i];
         }
-        for (uint32_t g = 0; g < n_genomes; g++) gs->genome_contig_off[g + 1] += gs->genome_contig_off[g];
-        static const uint64_t zero_off[1] = {0};
         Stopwatch sw(ctx, &ctx->timings.pack_ms);
-        genomes_pack(ctx, gs, bases, n_contigs ? contig_off : zero_off, on_device);
+        genomes_begin(ctx, gs, n_contigs ? contig_off[n_contigs] - contig_off[0] : 0, n_contigs, n_genomes);
+        genomes_append(ctx, gs, bases, contig_off, len.data(), contig_genome, n_contigs, on_device, nullptr);
+        genomes_finish(ctx, gs);
     });
     ctx->arena.reset();
+    if (rc != SKH_OK) { if (gs) device_sync_all(); delete gs; return rc; }
+    *out = gs;
+    return SKH_OK;
+}
+
+void* skh_host_alloc(uint64_t bytes) { try { return pin_alloc((size_t)bytes); } catch (...) { return nullptr; } }
+void skh_host_free(void* p) { if (p) pin_free(p); }
+
+int skh_genomes_begin(skh_ctx* ctx, uint64_t max_bases, uint32_t max_contigs, uint32_t n_genomes, int seeding_mode, skh_genome_set** out) {
+    if (!ctx || !out) return SKH_ERR_INVALID;
+    *out = nullptr;
+    skh_genome_set* gs = nullptr;
+    int rc = guarded(ctx, [&] {
+        if (seeding_mode != SKH_SEED_SCALAR && seeding_mode != SKH_SEED_AVX2) throw std::invalid_argument("bad seeding_mode");
+        gs = new skh_genome_set();
+        gs->ctx = ctx; gs->seeding_mode = seeding_mode;
+        genomes_begin(ctx, gs, max_bases, max_contigs, n_genomes);
+    });
     if (rc != SKH_OK) { delete gs; return rc; }
     *out = gs;
     return SKH_OK;
+}
+
+int skh_genomes_append(skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_start, const uint64_t* contig_len, const uint32_t* contig_genome,
+                       uint32_t n_contigs, int on_device, uint64_t* ticket) {
+    if (!gs || (n_contigs && (!bases || !contig_start || !contig_len || !contig_genome))) return SKH_ERR_INVALID;
+    skh_ctx* ctx = gs->ctx;
+    int rc = guarded(ctx, [&] {
+        gs->copied.emplace_back(new DevEvent());
+        genomes_append(ctx, gs, bases, contig_start, contig_len, contig_genome, n_contigs, on_device, gs->copied.back().get());
+        if (ticket) *ticket = gs->copied.size() - 1;
+    });
+    if (rc != SKH_OK) device_sync_all();
+    return rc;                                                                   // (the arena's small tables of this batch are recycled by skh_genomes_finish)
+}
+
+int skh_genomes_wait(skh_genome_set* gs, uint64_t ticket) {
+    if (!gs || ticket >= gs->copied.size()) return SKH_ERR_INVALID;
+    return guarded(gs->ctx, [&] { gs->copied[ticket]->wait(); });
+}
+
+int skh_genomes_finish(skh_genome_set* gs) {
+    if (!gs) return SKH_ERR_INVALID;
+    skh_ctx* ctx = gs->ctx;
+    int rc = guarded(ctx, [&] { Stopwatch sw(ctx, &ctx->timings.pack_ms); genomes_finish(ctx, gs); gs->copied.clear(); });
+    if (rc != SKH_OK) device_sync_all();
+    ctx->arena.reset();
+    return rc;
 }
 
 void skh_genomes_destroy(skh_genome_set* gs) { delete gs; }
@@ -154,6 +196,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
     skh_sketch_set* ss = nullptr;
     int rc = guarded(ctx, [&] {
         check_params(sp);
+        if (gs->open) throw std::invalid_argument("the genome set is still being filled: call skh_genomes_finish first");
         if ((int)sp->seeding_mode != gs->seeding_mode) throw std::invalid_argument("genome set was packed for the other seeding_mode");
         ss = new_sketch_set(ctx, *sp, gs->n_genomes, genome_rank);
         const uint32_t ng = gs->n_genomes;

@@ -69,6 +69,7 @@ inline void h2d(void* d, const void* h, size_t n, devStream_t s) {
     }
     hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d");
 }
+inline void h2d_big(void* d, const void* h, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d"); }   // large uploads: asynchronous when h is pinned
 inline void d2h(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }
 inline void d2h_async(void* h, const void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); }   // h: pinned memory; the caller synchronises
 inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "d2d"); }

@@ -96,6 +96,10 @@ struct skh_genome_set {
     std::vector<uint32_t> genome_first_tile;       // n_genomes + 1: index of each genome's first tile (genomes without tiles: their successor's)
     std::vector<uint32_t> tile_cached_for;         // {mode} the tile list was built for
     skh::DBuf<skh::SeedTile> d_tiles;
+    // filling state (pack_seed.hip genomes_begin / _append / _finish)
+    bool open = false; uint64_t cap_units = 0, n_units = 0; uint32_t cap_contigs = 0, n_batches = 0;
+    skh::DBuf<uint8_t> stage[2];                   // device staging of the batches' ASCII (host sources), alternating
+    std::vector<std::unique_ptr<skh::DevEvent>> copied;   // one per batch: recorded behind the copy of its bases (skh_genomes_wait)
 };
 
 // Device-resident Vec<Sketch>.  Index conventions: *_off are per-genome u64 offsets into the concatenated arrays.
@@ -189,7 +193,10 @@ void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n,
 uint64_t* sort_segments_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, uint32_t n_seg, const uint64_t* d_off, const uint64_t* h_off, int end_bit);   // every segment [off[s], off[s+1]) on bits [0, end_bit); returns the sorted array
 
 // ---- pack_seed.hip
-void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device);
+void genomes_begin(skh_ctx* ctx, skh_genome_set* gs, uint64_t max_bases, uint32_t max_contigs, uint32_t n_genomes);
+void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_start, const uint64_t* contig_len, const uint32_t* contig_genome,
+                    uint32_t n_contigs, int on_device, DevEvent* copied);
+void genomes_finish(skh_ctx* ctx, skh_genome_set* gs);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
     DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> markers_raw; // hash = mix32(seed); g = padded coordinate << 1 | canonical (common.h CTG_PAD)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1

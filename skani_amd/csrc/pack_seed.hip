@@ -100,44 +100,106 @@ static inline uint32_t windows_end(uint32_t len, int mode) {  // exclusive bound
     return len;                                                                    // seeding.rs:271
 }
 
-void genomes_pack(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_off, int on_device) {
-    const uint32_t nc = gs->n_contigs;
+// A genome set is filled in batches of whole genomes (skh_genomes_begin / _append / _finish; skh_genomes_pack is one batch): the packed arrays are
+// sized once for the announced capacity, every batch's ASCII goes to one of two device staging buffers (an asynchronous copy when the caller's
+// buffer is pinned) and is packed behind it on the context's stream, so the host parses the next files while the previous ones cross PCIe.
+void genomes_begin(skh_ctx* ctx, skh_genome_set* gs, uint64_t max_bases, uint32_t max_contigs, uint32_t n_genomes) {
+    const uint64_t cap_units = (max_bases + (uint64_t)max_contigs * (CONTIG_ALIGN - 1)) / 32 + 2 * (uint64_t)max_contigs + 2;
+    const uint64_t slack_words = 2 * (SEED_TILE / 16) + 64;    // a tile may read one tile + halo past its contig
+    gs->cap_units = cap_units; gs->cap_contigs = max_contigs; gs->n_units = 0; gs->open = true;
+    gs->packed.alloc(cap_units * 2 + slack_words); gs->nmask.alloc(cap_units + slack_words / 2 + 2);
+    gs->d_contigs.alloc(max_contigs ? max_contigs : 1);
+    gs->contigs.clear(); gs->genome_contig_off.assign((size_t)n_genomes + 1, 0); gs->n_genomes = n_genomes; gs->n_contigs = 0; gs->total_bases = 0;
+}
+
+// contig i of the batch = bases[contig_start[i] .. + contig_len[i]); contig_genome[i] = its genome's number in the set.  A genome's contigs arrive
+// together, in their order, in ONE batch; the genomes themselves may arrive in any order (parser threads finish as they finish).
+// Returns after queuing; `copied` (may be null) is recorded behind the copy of `bases`: the caller's buffer is free once it has passed.
+void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, const uint64_t* contig_start, const uint64_t* contig_len, const uint32_t* contig_genome,
+                    uint32_t nc, int on_device, DevEvent* copied) {
+    if (!gs->open) throw std::invalid_argument("the genome set is finished: no further batches");
+    if ((uint64_t)gs->n_contigs + nc > 0xFFFFFFF0ull) throw std::invalid_argument("too many contigs in one genome set");
+    if (gs->n_contigs + nc > gs->cap_contigs) {                                     // max_contigs was an estimate (a parser does not know it beforehand): grow
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)gs->cap_contigs * 2, (uint64_t)gs->n_contigs + nc));
+        dsync(ctx->stream);                                                         // queued pack kernels set has_n flags in the old array
+        DBuf<ContigDesc> bigger(cap);
+        d2d(bigger.p, gs->d_contigs.p, (size_t)gs->n_contigs * sizeof(ContigDesc), ctx->stream);
+        dsync(ctx->stream);
+        gs->d_contigs = std::move(bigger); gs->cap_contigs = cap;
+    }
+    const uint32_t c0 = gs->n_contigs, ng = gs->n_genomes;
     std::vector<uint64_t> unit_off(nc + 1, 0), src_off(nc);
-    uint64_t total_src = contig_off[nc];
-    uint64_t gat = 0;
+    uint64_t span_lo = ~0ull, span_hi = 0;                                        // the stretch of the caller's buffer the batch reads
     for (uint32_t i = 0; i < nc; i++) {
-        uint64_t len = contig_off[i + 1] - contig_off[i];
+        const uint32_t g = contig_genome[i];
+        if (g >= ng) throw std::invalid_argument("contig_genome must be < n_genomes");
+        if ((i == 0 || contig_genome[i - 1] != g) && gs->genome_contig_off[(size_t)g + 1]) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
+        gs->genome_contig_off[(size_t)g + 1]++;
+    }
+    gs->contigs.resize((size_t)c0 + nc);
+    uint32_t idx = 0; uint64_t gat = 0;
+    for (uint32_t i = 0; i < nc; i++) {
+        const uint32_t g = contig_genome[i];
+        if (i == 0 || contig_genome[i - 1] != g) idx = 0;
+        const uint64_t len = contig_len[i];
         if (len > 0xFFFFFFF0ull) throw Error("contig longer than 2^32 bases");
-        ContigDesc& cd = gs->contigs[i];
-        cd.len = (uint32_t)len; cd.base = unit_off[i] * 32; cd.has_n = 0;
+        ContigDesc& cd = gs->contigs[c0 + i];
+        cd.genome = g; cd.index = idx++;
+        cd.len = (uint32_t)len; cd.base = (gs->n_units + unit_off[i]) * 32; cd.has_n = 0;
         if (cd.index == 0) gat = CTG_PAD;
         cd.goff = (uint32_t)gat; cd.pad = 0; gat += len + CTG_PAD;                  // genomes beyond 2^31 are refused when a sketch set is made (finalize_metadata)
-        src_off[i] = contig_off[i];
-        uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
+        src_off[i] = contig_start[i];
+        if (len) { span_lo = std::min(span_lo, contig_start[i]); span_hi = std::max(span_hi, contig_start[i] + len); }
+        const uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
         unit_off[i + 1] = unit_off[i] + padded / 32;
         gs->total_bases += len;
     }
     const uint64_t n_units = unit_off[nc];
-    const uint64_t slack_words = 2 * (SEED_TILE / 16) + 64;    // a tile may read one tile + halo past its contig
-    gs->n_words = n_units * 2 + slack_words;
-    gs->packed.alloc(gs->n_words); gs->nmask.alloc(n_units + slack_words / 2 + 2);
-    dzero(gs->packed.p + n_units * 2, slack_words * 4, ctx->stream);
-    dzero(gs->nmask.p + n_units, (slack_words / 2 + 2) * 4, ctx->stream);
-    gs->d_contigs.alloc(nc ? nc : 1);
-    h2d(gs->d_contigs.p, gs->contigs.data(), nc * sizeof(ContigDesc), ctx->stream);
-    const uint8_t* d_bases = bases;
-    // bytes the kernel may read from the source: the caller's buffer, rounded up to whole 4-byte words at both ends (an aligned word that holds a valid byte is readable)
-    uint64_t readable = total_src;
-    if (!on_device) { uint8_t* stage = ctx->arena.get<uint8_t>(total_src + 64); h2d(stage, bases, total_src, ctx->stream); d_bases = stage; readable = total_src + 64; }
-    else readable = (total_src + ((uint64_t)(uintptr_t)bases & 3u) + 3) / 4 * 4 - ((uint64_t)(uintptr_t)bases & 3u);
+    if (gs->n_units + n_units > gs->cap_units) throw std::invalid_argument("more bases than skh_genomes_begin announced (every contig takes its length rounded up to 64 bases)");
+    if (span_lo > span_hi) { span_lo = 0; span_hi = 0; }
+    h2d(gs->d_contigs.p + c0, gs->contigs.data() + c0, (size_t)nc * sizeof(ContigDesc), ctx->stream);
+    // bytes the kernel may read from the source: rounded up to whole 4-byte words at both ends (an aligned word that holds a valid byte is readable)
+    const uint8_t* d_bases = bases; uint64_t readable;
+    if (!on_device) {
+        DBuf<uint8_t>& st = gs->stage[gs->n_batches & 1];                           // the batch before last has been packed: the stream is in order
+        const uint64_t need = span_hi - span_lo + 64;
+        if (st.n < need) { dsync(ctx->stream); st.alloc(need + need / 4); }
+        h2d_big(st.p, bases + span_lo, span_hi - span_lo, ctx->stream);
+        for (uint32_t i = 0; i < nc; i++) src_off[i] -= span_lo;
+        d_bases = st.p; readable = need;
+    } else {
+        const uint64_t mis = (uint64_t)(uintptr_t)bases & 3u;
+        readable = (span_hi + mis + 3) / 4 * 4 - mis;
+    }
+    if (copied) copied->record(ctx->stream);
     uint64_t* d_src = ctx->arena.get<uint64_t>(nc + 1); uint64_t* d_unit = ctx->arena.get<uint64_t>(nc + 1);
-    h2d(d_src, src_off.data(), nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), (nc + 1) * 8, ctx->stream);
+    h2d(d_src, src_off.data(), (size_t)nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), ((size_t)nc + 1) * 8, ctx->stream);
     if (n_units) {
         SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
-                   (const uint64_t*)d_unit, gs->d_contigs.p, nc, n_units, gs->seeding_mode, gs->packed.p, gs->nmask.p);
+                   (const uint64_t*)d_unit, gs->d_contigs.p + c0, nc, n_units, gs->seeding_mode, gs->packed.p + gs->n_units * 2, gs->nmask.p + gs->n_units);
         check_launch("pack_kernel");
     }
-    d2h(gs->contigs.data(), gs->d_contigs.p, nc * sizeof(ContigDesc), ctx->stream);   // picks up has_n (syncs)
+    gs->n_units += n_units; gs->n_contigs += nc; gs->n_batches++;
+}
+
+void genomes_finish(skh_ctx* ctx, skh_genome_set* gs) {
+    if (!gs->open) return;
+    gs->open = false;
+    const uint32_t nc = gs->n_contigs; const uint64_t n_units = gs->n_units;
+    for (size_t g = 0; g + 1 < gs->genome_contig_off.size(); g++) gs->genome_contig_off[g + 1] += gs->genome_contig_off[g];
+    const uint64_t slack_words = 2 * (SEED_TILE / 16) + 64;
+    gs->n_words = n_units * 2 + slack_words;
+    dzero(gs->packed.p + n_units * 2, slack_words * 4, ctx->stream);
+    dzero(gs->nmask.p + n_units, (slack_words / 2 + 2) * 4, ctx->stream);
+    d2h(gs->contigs.data(), gs->d_contigs.p, (size_t)nc * sizeof(ContigDesc), ctx->stream);   // picks up has_n (syncs)
+    gs->stage[0].release(); gs->stage[1].release();
+    // contigs in (genome, contig) order: batches may have brought the genomes in any order (within a genome the order is already right)
+    bool sorted = true;
+    for (uint32_t i = 1; i < nc && sorted; i++) sorted = gs->contigs[i - 1].genome <= gs->contigs[i].genome;
+    if (!sorted) {
+        std::stable_sort(gs->contigs.begin(), gs->contigs.end(), [](const ContigDesc& a, const ContigDesc& b) { return a.genome < b.genome; });
+        h2d_big(gs->d_contigs.p, gs->contigs.data(), (size_t)nc * sizeof(ContigDesc), ctx->stream);
+    }
     // tile list in (genome, contig, window) order
     gs->tiles.clear();
     for (uint32_t i = 0; i < nc; i++) {

@@ -1,8 +1,13 @@
 // fastx.cpp -- FASTA / FASTQ (.gz) ingest with the record semantics of needletail as used by file_io.rs:158-181.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <cstdio>
 #include <mutex>
 #include <stdexcept>
@@ -72,6 +77,49 @@ std::vector<Record> read_fasta(const std::string& path) {
         p = end;
     }
     return out;
+}
+
+bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t min_len, size_t* used, std::vector<std::string>& names, std::vector<uint64_t>& lens) {
+    *used = 0; names.clear(); lens.clear();
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
+    const size_t n = (size_t)sb.st_size;
+    if (n == 0) { close(fd); return true; }
+    void* map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, n};
+    (void)madvise(map, n, MADV_SEQUENTIAL);
+    const char* data = (const char*)map;
+    if (n >= 2 && (unsigned char)data[0] == 0x1f && (unsigned char)data[1] == 0x8b) return false;        // gzip
+    size_t p = 0;
+    while (p < n && (data[p] == '\n' || data[p] == '\r' || data[p] == ' ' || data[p] == '\t')) p++;
+    if (p == n) return true;
+    if (data[p] == '@') return false;                                                                     // FASTQ
+    if (data[p] != '>') throw std::runtime_error(path + " is not a valid fasta/fastq file");
+    if (cap < n) throw std::runtime_error("parse_fasta_plain: destination smaller than the file");
+    size_t at = 0;                                                                                        // bytes kept so far
+    while (p < n) {                                                                                       // data[p] == '>'
+        const char* eol = (const char*)memchr(data + p, '\n', n - p);
+        const size_t e = eol ? (size_t)(eol - data) : n;
+        std::string name(data + p + 1, e - p - 1);
+        while (!name.empty() && name.back() == '\r') name.pop_back();
+        p = e < n ? e + 1 : n;
+        const size_t start = at;
+        while (p < n && data[p] != '>') {                                                                 // sequence lines up to the next header line
+            const char* le = (const char*)memchr(data + p, '\n', n - p);
+            size_t l = le ? (size_t)(le - data) : n, len = l - p;
+            if (memchr(data + p, '\r', len)) { for (size_t i = p; i < l; i++) if (data[i] != '\r') dst[at++] = (uint8_t)data[i]; }
+            else { memcpy(dst + at, data + p, len); at += len; }
+            p = l < n ? l + 1 : n;
+        }
+        if (at - start >= min_len) { names.push_back(std::move(name)); lens.push_back(at - start); }
+        else at = start;                                                                                  // file_io.rs:176: the contig is skipped
+    }
+    *used = at;
+    return true;
 }
 
 LoadedGenomes load_genomes(const std::vector<std::string>& files_in, bool individual_contig, int threads) {

@@ -1,13 +1,19 @@
 // main.cpp -- `skani-hip {triangle,dist,sketch,search}`: the reference's drivers (triangle.rs:13-169, dist.rs:12-190,
 // sketch.rs:15-175, search.rs:16-282) over the C ABI.  Inputs may be FASTA (.gz) or skani sketch files / database folders.
 // Flag names follow cli.rs; only flags that reach the hot path or the writers are implemented.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -125,6 +131,103 @@ skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
     return ss;
 }
 
+// SKH_TIMING=1: wall-clock of the driver's phases on stderr, one JSON object (bench.py --workload e2e reads it)
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0; std::string json; bool on = getenv("SKH_TIMING") != nullptr;
+    void mark(const char* name) {
+        const auto n = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, "%s\"%s_s\": %.6f", json.empty() ? "" : ", ", name, std::chrono::duration<double>(n - last).count());
+        json += b; last = n;
+    }
+    void done() { if (on) fprintf(stderr, "{%s, \"total_s\": %.6f}\n", json.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+};
+PhaseClock g_clock;
+
+// fastx_to_sketches (file_io.rs:141-252) with parsing, PCIe and packing overlapped.  The reference parses its files in parallel (file_io.rs:147) and sketches
+// each on the thread that read it; here `threads` parser threads write the kept contigs of whole files into their own 64 MB buffers and hand a full
+// buffer to the GPU (skh_genomes_append: copy + pack kernel) while the other threads keep parsing.  Genome number = the file's position in the sorted
+// list (file_io.rs:250); files that end up without a kept contig are taken out of the numbering afterwards.  Only for plain FASTA files (mapped and
+// copied once); anything gzipped or FASTQ sends the whole run through load_genomes().
+struct Streamed { bool ok = false; skh_sketch_set* ss = nullptr; std::vector<GenomeInfo> info; std::vector<uint32_t> kept_index; };   // kept_index[set genome] = index into info, or ~0u
+Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Args& a) {
+    Streamed out;
+    std::vector<std::string> files = files_in;
+    std::stable_sort(files.begin(), files.end());
+    const uint32_t nf = (uint32_t)files.size();
+    uint64_t total = 0; std::vector<uint64_t> fsize(nf);
+    for (uint32_t i = 0; i < nf; i++) {
+        struct stat sb;
+        if (stat(files[i].c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return out;
+        FILE* f = fopen(files[i].c_str(), "rb"); if (!f) return out;
+        unsigned char m[2] = {0, 0}; const size_t got = fread(m, 1, 2, f); fclose(f);
+        if (got == 2 && m[0] == 0x1f && m[1] == 0x8b) return out;                  // gzip somewhere: the plain path is not for this run
+        fsize[i] = (uint64_t)sb.st_size; total += fsize[i];
+    }
+    skh_genome_set* gs = nullptr;
+    cx.check(skh_genomes_begin(cx.c, total + total / 7 + 4096, nf * 32 + 64, nf, a.seeding_mode, &gs), "skh_genomes_begin");
+    constexpr size_t CAP = (size_t)64 << 20;
+    std::vector<GenomeInfo> per(nf); std::vector<uint8_t> state(nf, 0);          // 1 = kept, 2 = no kept contig, 3 = unreadable, 4 = not plain FASTA
+    std::atomic<uint32_t> next{0}; std::atomic<bool> fallback{false}; std::mutex gpu; std::string gpu_err;
+    auto worker = [&]() {
+        std::unique_ptr<uint8_t[]> buf; size_t cap = 0, used = 0;
+        std::vector<uint64_t> starts, lens; std::vector<uint32_t> genome;
+        auto flush = [&]() {
+            if (starts.empty()) { used = 0; return; }
+            uint64_t ticket = 0; int rc;
+            { std::lock_guard<std::mutex> lk(gpu);
+              rc = skh_genomes_append(gs, buf.get(), starts.data(), lens.data(), genome.data(), (uint32_t)starts.size(), 0, &ticket);
+              if (rc == 0) rc = skh_genomes_wait(gs, ticket);                       // the buffer is rewritten next
+              if (rc != 0 && gpu_err.empty()) gpu_err = skh_last_error(cx.c); }
+            if (rc != 0) fallback = true;
+            starts.clear(); lens.clear(); genome.clear(); used = 0;
+        };
+        std::vector<std::string> names; std::vector<uint64_t> clen;
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= nf || fallback) break;
+            const size_t need = (size_t)fsize[i];
+            if (used + need > cap) {
+                flush();
+                if (need > cap) { cap = std::max(CAP, need); buf.reset(new uint8_t[cap]); }
+            }
+            size_t wrote = 0;
+            try {
+                if (!parse_fasta_plain(files[i], buf.get() + used, cap - used, 500, &wrote, names, clen)) { state[i] = 4; fallback = true; break; }
+            } catch (const std::exception& e) { state[i] = 3; fprintf(stderr, "WARN %s; skipping.\n", e.what()); continue; }
+            if (names.empty()) { state[i] = 2; continue; }
+            GenomeInfo& gi = per[i]; gi.file_name = files[i]; gi.contigs = std::move(names);
+            uint64_t at = used;
+            for (uint64_t l : clen) { gi.contig_lengths.push_back((uint32_t)l); starts.push_back(at); lens.push_back(l); genome.push_back(i); at += l; }
+            used += wrote; state[i] = 1;
+        }
+        flush();
+    };
+    {
+        const int nt = std::max(1, std::min<int>(a.threads, (int)nf));
+        std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(worker); for (auto& t : th) t.join();
+    }
+    if (fallback) {
+        skh_genomes_destroy(gs);
+        if (!gpu_err.empty()) die("skh_genomes_append: " + gpu_err);
+        return out;                                                                // a FASTQ / gzip file turned up: the caller reads everything the other way
+    }
+    cx.check(skh_genomes_finish(gs), "skh_genomes_finish");
+    g_clock.mark("parse_upload_pack");
+    out.kept_index.assign(nf, ~0u);
+    for (uint32_t i = 0; i < nf; i++) {
+        if (state[i] == 1) { out.kept_index[i] = (uint32_t)out.info.size(); out.info.push_back(std::move(per[i])); }
+        else if (state[i] == 2) fprintf(stderr, "WARN File %s consists of only contigs < 500 bp. Skipping this file.\n", files[i].c_str());
+    }
+    skh_sketch_params sp{a.c, a.k, a.m, (uint32_t)a.seeding_mode};
+    cx.check(skh_sketch_genomes(cx.c, gs, &sp, nullptr, &out.ss), "skh_sketch_genomes");   // genome_rank = number in the sorted file list
+    skh_genomes_destroy(gs);
+    std::vector<const char*> nm(nf); for (uint32_t i = 0; i < nf; i++) nm[i] = files[i].c_str();
+    cx.check(skh_sketch_set_names(out.ss, nm.data()), "skh_sketch_set_names");
+    g_clock.mark("sketch");
+    out.ok = true;
+    return out;
+}
+
 bool all_sketch_files(const std::vector<std::string>& files) {                     // parse.rs:264-281
     if (files.empty()) return false;
     for (auto& f : files) if (f.find(".sketch") == std::string::npos && f.find("markers.bin") == std::string::npos) return false;
@@ -210,7 +313,12 @@ int run_triangle(Args& a, Ctx& cx) {
     std::vector<std::string> files = a.files;
     if (!a.list.empty()) { auto l = read_list(a.list); files.insert(files.end(), l.begin(), l.end()); }
     if (files.empty()) die("No reference inputs found.");
-    Side sd = load_side(cx, files, a.individual, a);
+    Side sd; std::vector<uint32_t> kept_index;                                  // streamed ingest: set genome -> row of the output (files without a kept contig have none)
+    if (!a.individual && !all_sketch_files(files)) {
+        Streamed st = stream_side(cx, files, a);
+        if (st.ok) { sd.ss = st.ss; sd.info = std::move(st.info); kept_index = std::move(st.kept_index); }
+    }
+    if (!sd.ss) { sd = load_side(cx, files, a.individual, a); g_clock.mark("load_sketch"); }
     if (sd.info.empty()) die("No genomes/sketches found.");                     // triangle.rs:46-49
     skh_sketch_set* ss = sd.ss; struct { std::vector<GenomeInfo>& info; } lg{sd.info};
     const bool learned = !a.no_learned && a.c >= 70 && !a.individual && !a.median;   // regression.rs:8-10, parse.rs:885-889
@@ -218,14 +326,16 @@ int run_triangle(Args& a, Ctx& cx) {
     const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:798
     uint32_t *oi = nullptr, *oj = nullptr; skh_ani_result* res = nullptr; uint64_t kept = 0, chained = 0;
     cx.check(skh_triangle(cx.c, ss, a.s / 100., rescue_small, &mp, 0, 1, &oi, &oj, &res, &kept, &chained), "skh_triangle");
+    g_clock.mark("triangle");
     std::vector<PairResult> pr(kept);
-    for (uint64_t x = 0; x < kept; x++) pr[x] = PairResult{oi[x], oj[x], res[x]};    // ref = i, query = j (triangle.rs:98)
+    for (uint64_t x = 0; x < kept; x++) pr[x] = PairResult{kept_index.empty() ? oi[x] : kept_index[oi[x]], kept_index.empty() ? oj[x] : kept_index[oj[x]], res[x]};    // ref = i, query = j (triangle.rs:98)
     skh_free(oi); skh_free(oj); skh_free(res);
     if (a.sparse) emit(a.out, format_sparse(lg.info, pr, a.o));
     else {
         std::string ani, af; format_phylip(lg.info, pr, a.individual, a.o, ani, af);
         emit(a.out, ani); emit(a.out.empty() ? std::string("skani_matrix.af") : a.out + ".af", af);   // file_io.rs:428,467
     }
+    g_clock.mark("write");
     skh_sketch_set_destroy(ss);
     return 0;
 }
@@ -340,6 +450,7 @@ int main(int argc, char** argv) {
     if (skh_ctx_create(a.device, &cx.c) != 0) die("no usable MI355X device (skani-hip has no CPU path)");
     const std::string md = models_dir(a, argv[0]);
     cx.check(skh_load_models(cx.c, (md + "/gbdt_c125.bin").c_str(), (md + "/gbdt_c200.bin").c_str()), "skh_load_models");
+    g_clock.mark("startup");
     int rc;
     if (a.cmd == "triangle") rc = run_triangle(a, cx);
     else if (a.cmd == "dist") rc = run_dist(a, cx);
@@ -347,5 +458,6 @@ int main(int argc, char** argv) {
     else if (a.cmd == "search") rc = run_search(a, cx);
     else die("unknown subcommand " + a.cmd + " (supported: triangle, dist, sketch, search)");
     skh_ctx_destroy(cx.c);
+    g_clock.done();
     return rc;
 }

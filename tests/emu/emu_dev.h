@@ -22,6 +22,7 @@ inline void dcache_trim() {}
 struct PinRing { devStream_t s0 = 0, s1 = 0; };
 struct PinScope { PinScope(int, PinRing*) {} };
 inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
+inline void h2d_big(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
 inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
 inline void d2h_async(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
 inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }

@@ -3,6 +3,7 @@ kernel-simulator tests (tests/test_emu_pipeline.py, same kernel sources under te
 Every case compares the C-ABI path with the CPU oracle on identical inputs.  Integer outputs must be bit-exact;
 ANI/AF are compared with the north-star tolerance 1e-4 (they are in fact expected to be identical to f32 rounding)."""
 import numpy as np
+import pytest
 
 import skani_amd as sk
 from tests.helpers import (MODEL_C125, MODEL_C200, golden_records, mutate, o157_arrays, ora, oracle_o157, oracle_sketch_file,
@@ -97,6 +98,30 @@ def case_pack_every_byte(ctx):
         ss = ctx.sketch_records(genomes, sk.SketchParams(6, 15, 24, mode), ["p%d" % g for g in range(3)])
         for g, r in enumerate(genomes):
             assert_sketch_equal(ss, g, ora.sketch_records(r, 6, 15, 24, "p%d" % g, mode))
+
+
+def case_pack_in_batches(ctx):
+    """skh_genomes_begin / _append / _finish (the streaming ingest of `skani-hip triangle`): the same genomes packed in one call and in three batches from
+    pinned buffers with gaps between the contigs, the genomes arriving out of order -- one of them without contigs, one a tiny contig -- give the same
+    sketches; the capacity announced at the beginning and the one-batch-per-genome rule are enforced."""
+    genomes = synthetic_clades(n_clades=2, members=3, length=40000, seed=23, tiny=True)
+    kept = [[s for _, s in g if len(s) >= 500] for g in genomes] + [[]]
+    whole = ctx.pack_genomes(kept, sk.SEED_AVX2)
+    numbered = list(enumerate(kept))
+    parts = ctx.pack_batches([numbered[5:], numbered[:2], numbered[2:5][::-1]], sk.SEED_AVX2, max_bases=sum(len(s) for g in kept for s in g) + 1000, max_contigs=64)   # any order
+    assert whole.total_bases == parts.total_bases
+    a = ctx.sketch_genomes(whole, sk.SketchParams(c=30, marker_c=200)); b = ctx.sketch_genomes(parts, sk.SketchParams(c=30, marker_c=200))
+    assert len(a) == len(b) == len(kept)
+    for g in range(len(kept)):
+        ea, eb = a.export(g), b.export(g)
+        for key in ("seed", "pos", "ctgcanon", "markers", "contig_lengths"):
+            assert np.array_equal(ea[key], eb[key]), (g, key)
+    osk = ora.sketch_records(genomes[1], 30, 15, 200, "g1", 1)
+    assert_sketch_equal(b, 1, osk)
+    with pytest.raises(sk.SkaniHipError):
+        ctx.pack_batches([numbered[:2], numbered[2:]], sk.SEED_AVX2, max_bases=1000, max_contigs=64)
+    with pytest.raises(sk.SkaniHipError):                                       # a genome's contigs in two batches
+        ctx.pack_batches([[(0, kept[0][:1])], [(0, kept[0][1:] or kept[1])]], sk.SEED_AVX2)
 
 
 def case_seeding_ecoli_w(ctx):

@@ -18,6 +18,7 @@ def ctx():
 def test_emu_seeding_golden(ctx): pc.case_seeding_golden_plasmid(ctx)
 def test_emu_seeding_fixtures(ctx): pc.case_seeding_fixtures(ctx)
 def test_emu_pack_every_byte(ctx): pc.case_pack_every_byte(ctx)
+def test_emu_pack_in_batches(ctx): pc.case_pack_in_batches(ctx)
 def test_emu_seeding_ecoli_w(ctx): pc.case_seeding_ecoli_w(ctx)
 def test_emu_seeding_low_complexity(ctx): pc.case_seeding_low_complexity(ctx)
 def test_emu_pinned_triples(ctx): pc.case_pinned_triples(ctx)

@@ -20,7 +20,7 @@ def host():
     build_hip()
     lib, _ = build_host()
     L = C.CDLL(lib)
-    for f in ("skhost_fasta_summary", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
+    for f in ("skhost_fasta_summary", "skhost_fasta_plain", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
         getattr(L, f).restype = C.c_void_p
     return L
 
@@ -64,6 +64,34 @@ def _res(**kw):
 
 def _arr(strs):
     a = (C.c_char_p * len(strs))(*[s.encode() for s in strs]); return a
+
+
+def test_mapped_fasta_parser_equals_the_record_reader(host, tmp_path):
+    """parse_fasta_plain (the streaming ingest's parser: the file is mapped, kept contigs are written once, straight to the upload buffer) keeps exactly
+    what read_fasta + the >= 500 bp filter keep: wrapped lines, CRLF, blank lines, '>' inside a sequence line, a last line without newline; gzip and
+    FASTQ are left to the record reader."""
+    import gzip
+    rng = np.random.default_rng(8)
+    def seq(n):
+        return "".join("ACGTNacgt"[int(x)] for x in rng.integers(0, 9, n))
+    a, b, c, d = seq(1300), seq(499), seq(777), seq(600)
+    wrap = lambda s, w: "\n".join(s[i:i + w] for i in range(0, len(s), w))
+    text = "\n\n>a first\r\n" + wrap(a, 60).replace("\n", "\r\n") + "\r\n>b short\n" + wrap(b, 80) + "\n\n>c x>y\n" + c[:300] + ">" + c[300:] + "\n>d\n" + wrap(d, 70)
+    p = tmp_path / "m.fa"; p.write_bytes(text.encode())
+    got = _take(host, host.skhost_fasta_plain(str(p).encode(), 500))
+    want_recs = [("a first", a), ("c x>y", c[:300] + ">" + c[300:]), ("d", d)]
+    assert got == "".join("%s\t%d\n" % (n, len(s)) for n, s in want_recs) + "=" + "".join(s for _, s in want_recs)
+    assert got.split("=")[0] == _take(host, host.skhost_fasta_summary(str(p).encode(), 500))
+    for name in ("viruses.fna", "o157_plasmid.fasta"):
+        q = os.path.join(GOLDEN, name)
+        head, bases = _take(host, host.skhost_fasta_plain(q.encode(), 500)).split("=", 1)
+        assert head == _take(host, host.skhost_fasta_summary(q.encode(), 500)) and bases.encode() == b"".join(s for _, s in golden_records(name) if len(s) >= 500)
+    gz = tmp_path / "m.fa.gz"; gz.write_bytes(gzip.compress(text.encode()))
+    assert _take(host, host.skhost_fasta_plain(str(gz).encode(), 500)) == "NOT PLAIN"
+    fq = tmp_path / "r.fq"; fq.write_text("@r1\nACGT\n+\nIIII\n")
+    assert _take(host, host.skhost_fasta_plain(str(fq).encode(), 0)) == "NOT PLAIN"
+    e = tmp_path / "e.fa"; e.write_text("")
+    assert _take(host, host.skhost_fasta_plain(str(e).encode(), 0)) == "="
 
 
 def test_triangle_matrix_format(host):
@@ -146,6 +174,41 @@ def test_cli_triangle_and_dist_end_to_end(tmp_path):
     dl = d.stdout.splitlines()
     assert dl[0].startswith("Ref_file\tQuery_file\tANI") and len(dl) == 3
     assert all(l.split("\t")[1] == files[0] for l in dl[1:]) and float(dl[1].split("\t")[2]) >= float(dl[2].split("\t")[2])
+
+
+@pytest.mark.gpu
+def test_cli_triangle_streaming_ingest(tmp_path):
+    """`skani-hip triangle` on plain FASTA files takes the streaming ingest (parser threads -> skh_genomes_append -> pack while the next files are
+    parsed): same matrix as the one-shot path of the Python API, with a file of short contigs only dropped from the middle of the name order
+    (file_io.rs:176,230: its row disappears), multi-contig files, CRLF line ends and one or several parser threads."""
+    from tests.parity_cases import synthetic_clades
+    _, exe = build_host()
+    genomes = synthetic_clades(n_clades=2, members=3, length=90000, seed=5, tiny=False)
+    files = []
+    for g, recs in enumerate(genomes):
+        p = tmp_path / ("s%02d.fa" % (g if g < 3 else g + 1))
+        eol = b"\r\n" if g == 1 else b"\n"
+        p.write_bytes(b"".join(b">" + n.encode() + eol + eol.join(s[k:k + 70] for k in range(0, len(s), 70)) + eol for n, s in recs))
+        files.append(str(p))
+    short = tmp_path / "s03.fa"; short.write_bytes(b">tiny1\n" + b"ACGT" * 100 + b"\n>tiny2\n" + b"GGCA" * 90 + b"\n")
+    files.insert(3, str(short))
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"), SKH_TIMING="1")
+    ctx = sk.Context(0)
+    kept = [f for f in files if f != str(short)]
+    ss = sk.fastx_to_sketches(ctx, kept, sk.SketchParams())
+    i, j, res, _ = ctx.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+    want = {(int(a), int(b)): "%.2f" % (float(np.float32(r["ani"]) * np.float32(100))) for a, b, r in zip(i, j, res)}
+    outs = []
+    for t in ("1", "4"):
+        out = subprocess.run([exe, "triangle", "-t", t] + files[::-1], capture_output=True, text=True, cwd=tmp_path, env=env)
+        assert out.returncode == 0, out.stderr
+        assert "consists of only contigs < 500 bp" in out.stderr and '"parse_upload_pack_s"' in out.stderr      # the streaming path ran
+        lines = out.stdout.splitlines()
+        assert lines[0] == "6" and [l.split("\t")[0] for l in lines[1:]] == kept
+        for row in range(1, 6):
+            assert lines[1 + row].split("\t")[1:] == [want.get((c, row), "0.00") for c in range(row)]
+        outs.append(out.stdout)
+    assert outs[0] == outs[1] and len(want) >= 6
 
 
 @pytest.mark.gpu
