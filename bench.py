@@ -263,6 +263,72 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
                                 "note": "skani's default -t 3 on %d genomes: the per-thread rates the sweep's efficiencies refer to (value = that sample's own pairs / time)" % few["genomes"]}}
 
 
+def write_fasta(path, recs, width=80):
+    """recs = [(name, uint8 array)]: a FASTA file with `width` bases per line."""
+    with open(path, "wb") as f:
+        for name, a in recs:
+            f.write(b">" + name.encode() + b"\n")
+            n = len(a); rows = n // width
+            if rows:
+                body = np.empty((rows, width + 1), np.uint8); body[:, :width] = a[:rows * width].reshape(rows, width); body[:, width] = 10
+                f.write(body.tobytes())
+            if n > rows * width:
+                f.write(a[rows * width:].tobytes() + b"\n")
+
+
+def e2e_leg(host_genomes, threads):
+    """End to end: the collection as FASTA files on a RAM disk -> `skani-hip triangle` (parse on `threads` threads, copy + pack while
+    the next files are parsed, sketch, screen, chain, matrix writer) -> the ANI matrix file; wall clock of the whole process (HIP start-up and model load
+    included) and the driver's own phase clock.  Beside it the oracle on the same files: read + sketch on the same number of threads, marker index,
+    screen, chain (no writer)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_py as ora
+    exe = os.path.join(ROOT, "skani_amd", "bin", "skani-hip")
+    if not os.path.exists(exe):
+        return {"error": "skani_amd/bin/skani-hip is not built"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="skani_e2e_", dir=base)
+    try:
+        names = [os.path.join(d, "s%05d.fa" % i) for i in range(len(host_genomes))]
+        with ThreadPoolExecutor(max_workers=min(32, threads)) as ex:
+            list(ex.map(lambda a: write_fasta(names[a[0]], a[1]), enumerate(host_genomes)))
+        lst = os.path.join(d, "files.txt"); open(lst, "w").write("\n".join(names) + "\n")
+        nbytes = sum(os.path.getsize(f) for f in names)
+        env = dict(os.environ, SKH_TIMING="1", SKANI_HIP_DATA=os.path.join(ROOT, "skani_amd", "data"))
+        runs = []
+        for _ in range(2):                                            # the second run is the one reported (the first pages the binary and the files in)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "triangle", "-t", str(threads), "-l", lst, "-o", os.path.join(d, "matrix.txt")], capture_output=True, text=True, env=env)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "skani-hip triangle failed: " + r.stderr[-400:]}
+            phases = None
+            for line in r.stderr.splitlines():
+                if line.startswith("{") and "total_s" in line:
+                    phases = json.loads(line)
+            runs.append((wall, phases))
+        wall, phases = runs[-1]
+        n = len(host_genomes); pairs = n * (n - 1) // 2
+        rows = open(os.path.join(d, "matrix.txt")).read().count("\n")
+        out = {"genomes": n, "fasta_bytes": nbytes, "threads": threads, "wall_s": wall, "first_run_wall_s": runs[0][0], "pairs_per_s": pairs / wall,
+               "phases_s": phases, "matrix_rows": rows - 1, "command": "skani-hip triangle -t %d -l files.txt -o matrix.txt (FASTA on %s)" % (threads, base or "the temp dir")}
+        model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin" if abs(C - 125) < abs(C - 200) else "gbdt_c200.bin")) if C >= 70 else None
+        t0 = time.perf_counter()
+        sks = ora.sketch_files(names, C, K, M, 1, 500, threads)
+        t1 = time.perf_counter()
+        ora.triangle(sks, model=model, threads=threads)
+        t2 = time.perf_counter()
+        ix, sc, ch = ora.triangle_phases()
+        out["oracle"] = {"wall_s": t2 - t0, "threads": threads, "pairs_per_s": pairs / (t2 - t0),
+                         "phases_s": {"read_sketch": t1 - t0, "marker_index": ix, "screen": sc, "chain": ch}, "note": "no matrix writer, no process start-up"}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner through C stdio on stdout when its first communicator is made; the contract is ONE JSON line on stdout.  While this is
     active, file descriptor 1 points at stderr; on exit C's buffers are flushed there and stdout is restored."""
@@ -299,6 +365,7 @@ def main():
                     "(default on several GPUs: members of a clade sit on different ranks and their sketches have to travel)")
     ap.add_argument("--cpu-clades", type=int, default=-1, help="clades (x20 genomes) the CPU baseline runs on; default -1 = the full workload, 0 disables")
     ap.add_argument("--no-ci", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (FASTA files on a RAM disk through the skani-hip binary, ~20 s)")
     ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
     ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
     ap.add_argument("--workload", default="triangle", choices=["triangle", "search"], help="triangle = the headline metric; search = BASELINE config 5 (optional)")
@@ -483,6 +550,11 @@ def main():
                                  "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in the latest profiles/r*_pmc_*.md"}
     if host_genomes:
         out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total)
+        if not args.no_e2e:
+            try:
+                out["e2e"] = e2e_leg(host_genomes, min(host_cores()[1], 64))
+            except Exception as e:                                   # the headline line must not depend on a RAM disk
+                out["e2e"] = {"error": repr(e)}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -55,6 +55,7 @@ def lib():
         L.ora_sketch_add_contig.restype = i32; L.ora_sketch_add_contig.argtypes = [vp, vp, u64, i32, u64]
         L.ora_sketch_batch.restype = None
         L.ora_sketch_batch.argtypes = [u32, vp, vp, vp, u32, u32, u32, vp, i32, u64, i32, vp]
+        L.ora_sketch_files.restype = None; L.ora_sketch_files.argtypes = [u32, vp, u32, u32, u32, i32, u64, i32, vp]
         L.ora_sketch_from_arrays.restype = vp
         L.ora_sketch_from_arrays.argtypes = [u32, u32, u32, C.c_char_p, vp, vp, vp, u64, vp, u64, vp, u32, u64]
         for n in ("n_positions", "n_distinct", "n_markers", "total_len"):
@@ -161,6 +162,14 @@ def sketch_batch(genomes, c=125, k=15, marker_c=1000, names=None, mode=1, min_le
     out = (C.c_void_p * max(len(genomes), 1))()
     lib().ora_sketch_batch(len(genomes), _p(off), ptrs, _p(lens), c, k, marker_c, cn, mode, min_len, threads, out)
     return [Sketch(c, k, marker_c, names[i] if names else "", handle=out[i]) for i in range(len(genomes))]
+
+
+def sketch_files(paths, c=125, k=15, marker_c=1000, mode=1, min_len=500, threads=0):
+    """fastx_to_sketches (file_io.rs:141-252) on plain FASTA files: the sketches of the files that have a kept contig, in the order given."""
+    arr = (C.c_char_p * max(len(paths), 1))(*[p.encode() for p in paths])
+    out = (C.c_void_p * max(len(paths), 1))()
+    lib().ora_sketch_files(len(paths), arr, c, k, marker_c, mode, min_len, threads, out)
+    return [Sketch(c, k, marker_c, paths[i], handle=out[i]) for i in range(len(paths)) if out[i]]
 
 
 def chain_seeds(ref, query, min_af=0.15, both_min_af=-0.01, robust=False, median=False, model=None, stats=False):

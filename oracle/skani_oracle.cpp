@@ -728,6 +728,45 @@ void ora_sketch_batch(uint32_t n_genomes, const uint64_t* genome_contig_off, con
     std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(worker); for (auto& t : th) t.join();
 }
 
+// fastx_to_sketches (file_io.rs:141-252) from files on disk: every file is read by the thread that sketches it (file_io.rs:147 par_iter), records are
+// split the way needletail does for FASTA (header line without '>', sequence = the following lines without their line ends, up to the next line that
+// starts with '>'), contigs shorter than min_len are skipped (:176).  Plain FASTA only -- what bench.py's end-to-end leg writes.  out[i] = the sketch of
+// paths[i], or NULL when the file cannot be read or holds no kept contig (:230: such files are dropped).
+void ora_sketch_files(uint32_t n_files, const char* const* paths, uint32_t c, uint32_t k, uint32_t marker_c, int mode, uint64_t min_len, int threads, ora_sketch** out) {
+    tune_malloc_once();
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        std::vector<char> data; std::vector<uint8_t> seq;
+        for (;;) {
+            const uint32_t f = next.fetch_add(1); if (f >= n_files) break;
+            out[f] = nullptr;
+            FILE* fp = fopen(paths[f], "rb"); if (!fp) continue;
+            fseek(fp, 0, SEEK_END); const long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+            data.resize((size_t)(sz > 0 ? sz : 0));
+            const size_t n = sz > 0 ? fread(data.data(), 1, (size_t)sz, fp) : 0;
+            fclose(fp);
+            ora_sketch* s = ora_sketch_new(c, k, marker_c, paths[f]);
+            size_t p = 0; int kept = 0;
+            while (p < n && data[p] != '>') p++;
+            while (p < n) {
+                const char* eol = (const char*)memchr(data.data() + p, '\n', n - p);
+                p = eol ? (size_t)(eol - data.data()) + 1 : n;
+                seq.clear();
+                while (p < n && data[p] != '>') {
+                    const char* le = (const char*)memchr(data.data() + p, '\n', n - p);
+                    const size_t l = le ? (size_t)(le - data.data()) : n;
+                    for (size_t i = p; i < l; i++) if (data[i] != '\r') seq.push_back((uint8_t)data[i]);
+                    p = l < n ? l + 1 : n;
+                }
+                kept += ora_sketch_add_contig(s, seq.data(), seq.size(), mode, min_len);
+            }
+            if (kept) out[f] = s; else ora_sketch_free(s);
+        }
+    };
+    std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(worker); for (auto& t : th) t.join();
+}
+
 ora_sketch* ora_sketch_from_arrays(uint32_t c, uint32_t k, uint32_t marker_c, const char* file_name, const uint32_t* seed,
                                    const uint32_t* pos, const uint32_t* ctgcanon, uint64_t n_pos, const uint64_t* markers,
                                    uint64_t n_markers, const uint32_t* contig_lengths, uint32_t n_contigs, uint64_t total_len) {

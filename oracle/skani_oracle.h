@@ -56,6 +56,9 @@ int ora_sketch_add_contig(ora_sketch*, const uint8_t* seq, uint64_t len, int mod
 void ora_sketch_batch(uint32_t n_genomes, const uint64_t* genome_contig_off, const uint8_t* const* seq, const uint64_t* len,
                       uint32_t c, uint32_t k, uint32_t marker_c, const char* const* names, int mode, uint64_t min_len, int threads,
                       ora_sketch** out);
+/* the same from plain FASTA files on disk, every file read by the worker that sketches it; out[i] = NULL for unreadable files and files without a kept contig */
+void ora_sketch_files(uint32_t n_files, const char* const* paths, uint32_t c, uint32_t k, uint32_t marker_c, int mode, uint64_t min_len, int threads,
+                      ora_sketch** out);
 /* build a sketch from explicit arrays (golden fixture) */
 ora_sketch* ora_sketch_from_arrays(uint32_t c, uint32_t k, uint32_t marker_c, const char* file_name,
                                    const uint32_t* seed, const uint32_t* pos, const uint32_t* ctgcanon,
