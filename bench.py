@@ -167,9 +167,27 @@ def run_search(args, torch, sk, ctx, device):
             (q, r, res, qclades))
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), or None when unlimited: a box can show 256 CPUs and grant 16."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
     """(logical CPUs, physical cores, model name) of this box."""
     logical = os.cpu_count() or 1
+    try:
+        logical = min(logical, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     cores, model = set(), ""
     try:
         phys = core = None
@@ -225,7 +243,11 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
     cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)                      # (the first pass of a process pays the page faults of its heap: not the yardstick)
     few, _ = cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)
     per_thread = {"sketch": few["sketch_mbases_per_s"] / 3, "chain": (few["chained_pairs_per_s"] or 0) / 3}
-    counts = sorted({t for t in (16, 64, physical, logical) if t <= logical} or {logical})
+    quota = cpu_quota()
+    counts = {t for t in (16, 64, physical, logical) if t <= logical} or {logical}
+    if quota:                                                          # the thread count the container's CPU quota pays for
+        counts.add(max(1, min(logical, int(round(quota)))))
+    counts = sorted(counts)
     sweep, result = [], None
     for t in counts:
         r, result = cpu_run(host_genomes, t)
@@ -251,12 +273,12 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
     return {"value": best["value"], "unit": "genome-pairs/s", "cores": best["threads"], "kind": "port", "delta_vs_oracle": delta,
             "sample": ("the full workload, measured: " if full else "a sample, measured: ") +
                       "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + marker index %.2f s + screen of %d pairs %.2f s + chain of %d pairs %.2f s "
-                      "on %d threads (the best of %s threads; %d physical cores / %d logical CPUs, %s); value = pairs / wall time of the four phases"
+                      "on %d threads (the best of %s threads; %d physical cores / %d logical CPUs%s, %s); value = pairs / wall time of the four phases"
                       % (n, n // CLADE, CLADE, best["bases"] / 1e6, sec["sketch"], sec["marker_index"], pairs, sec["screen"], best["chained_pairs"], sec["chain"],
-                         best["threads"], "/".join(str(t) for t in counts), physical, logical, model_name),
+                         best["threads"], "/".join(str(t) for t in counts), physical, logical, ", cgroup CPU quota %.1f" % quota if quota else "", model_name),
             "seconds": sec, "sketch_mbases_per_s": best["sketch_mbases_per_s"], "screen_pairs_per_s": best["screen_pairs_per_s"],
             "chained_pairs_per_s": best["chained_pairs_per_s"], "chained_pairs": best["chained_pairs"],
-            "host": {"logical_cpus": logical, "physical_cores": physical, "model": model_name},
+            "host": {"logical_cpus": logical, "physical_cores": physical, "model": model_name, "cgroup_cpu_quota": quota},
             "sweep": [{k: r[k] for k in ("threads", "value", "seconds", "sketch_mbases_per_s", "chained_pairs_per_s", "efficiency")} for r in sweep],
             "default_threads": {"cores": 3, "genomes": few["genomes"], "value": few["value"], "seconds": few["seconds"], "chained_pairs_per_s": few["chained_pairs_per_s"],
                                 "sketch_mbases_per_s": few["sketch_mbases_per_s"],
@@ -552,7 +574,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total)
         if not args.no_e2e:
             try:
-                out["e2e"] = e2e_leg(host_genomes, min(host_cores()[1], 64))
+                q = cpu_quota()
+                out["e2e"] = e2e_leg(host_genomes, max(4, min(host_cores()[1], 64, int(round(q)) * 2 if q else 64)))
             except Exception as e:                                   # the headline line must not depend on a RAM disk
                 out["e2e"] = {"error": repr(e)}
     else:

@@ -153,23 +153,27 @@ int skh_genomes_append(skh_genome_set* gs, const uint8_t* bases, const uint64_t*
     if (!gs || (n_contigs && (!bases || !contig_start || !contig_len || !contig_genome))) return SKH_ERR_INVALID;
     skh_ctx* ctx = gs->ctx;
     int rc = guarded(ctx, [&] {
-        gs->copied.emplace_back(new DevEvent());
-        genomes_append(ctx, gs, bases, contig_start, contig_len, contig_genome, n_contigs, on_device, gs->copied.back().get());
-        if (ticket) *ticket = gs->copied.size() - 1;
+        DevEvent* ev = nullptr; size_t id = 0;
+        { std::lock_guard<std::mutex> lk(gs->copied_mu); gs->copied.emplace_back(new DevEvent()); ev = gs->copied.back().get(); id = gs->copied.size() - 1; }
+        genomes_append(ctx, gs, bases, contig_start, contig_len, contig_genome, n_contigs, on_device, ev);
+        if (ticket) *ticket = id;
     });
     if (rc != SKH_OK) device_sync_all();
     return rc;                                                                   // (the arena's small tables of this batch are recycled by skh_genomes_finish)
 }
 
-int skh_genomes_wait(skh_genome_set* gs, uint64_t ticket) {
-    if (!gs || ticket >= gs->copied.size()) return SKH_ERR_INVALID;
-    return guarded(gs->ctx, [&] { gs->copied[ticket]->wait(); });
+int skh_genomes_wait(skh_genome_set* gs, uint64_t ticket) {                      // any thread, also while another thread appends: touches nothing but the batch's event
+    if (!gs) return SKH_ERR_INVALID;
+    DevEvent* ev = nullptr;
+    { std::lock_guard<std::mutex> lk(gs->copied_mu); if (ticket < gs->copied.size()) ev = gs->copied[ticket].get(); }
+    if (!ev) return SKH_ERR_INVALID;
+    try { ev->wait(); return SKH_OK; } catch (...) { return SKH_ERR_DEVICE; }
 }
 
 int skh_genomes_finish(skh_genome_set* gs) {
     if (!gs) return SKH_ERR_INVALID;
     skh_ctx* ctx = gs->ctx;
-    int rc = guarded(ctx, [&] { Stopwatch sw(ctx, &ctx->timings.pack_ms); genomes_finish(ctx, gs); gs->copied.clear(); });
+    int rc = guarded(ctx, [&] { Stopwatch sw(ctx, &ctx->timings.pack_ms); genomes_finish(ctx, gs); std::lock_guard<std::mutex> lk(gs->copied_mu); gs->copied.clear(); });
     if (rc != SKH_OK) device_sync_all();
     ctx->arena.reset();
     return rc;
@@ -227,8 +231,10 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             book(); tail_guard.armed = false;
             return;
         }
-        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
-        ev[1].make_wait(ctx->stream2);                                                // the raw markers come out of the compaction kernel
+        DevEvent tables_queued;
+        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr, &tables_queued);
+        if (ss->n_genomes) tables_queued.make_wait(ctx->stream2);                     // (behind the compaction kernel, whose raw markers the second stream sorts)
+        else ev[1].make_wait(ctx->stream2);
         std::swap(ctx->stream, ctx->stream2);
         try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }

@@ -180,6 +180,10 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             check_launch("join_count");
         }
         tr.mark("join_count (+slots)");
+        // the tile scan of the whole super-batch is queued before the pair counts are waited for: it is what the fill pass needs when the anchors of all
+        // these pairs fit one batch (the usual case), and it runs while the host waits
+        uint32_t* toff_super = ctx->arena.get<uint32_t>(snt + 1);
+        exclusive_scan_u32(ctx, tile_anch + st0, snt, toff_super);
         d2h(pair_anch.data() + sp0, d_pair_anch + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
         if (stats) d2h(pair_inq.data() + sp0, d_pair_inq + sp0, (size_t)(sp1 - sp0) * 4, ctx->stream);
         tr.mark("d2h pair counts");
@@ -196,8 +200,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
         const PairDesc* d_pairs = d_pairs_all + p0;
         uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
-        uint32_t* toff_a = ctx->arena.get<uint32_t>(nt + 1);
-        exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a);
+        uint32_t* toff_a = toff_super;
+        if (t0 != st0 || t1 != st1) { toff_a = ctx->arena.get<uint32_t>(nt + 1); exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); }
         tr.mark("tile scan");
         if (nt) {
             uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
@@ -216,8 +220,11 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
         }
         const uint32_t NC = pc0[np], NI = pi0[np], NS = ps0[np];
-        uint32_t* d_pa0 = upload(ctx, pa0); uint32_t* d_pc0 = upload(ctx, pc0);
-        uint32_t* d_pi0 = upload(ctx, pi0); uint32_t* d_ps0 = upload(ctx, ps0);
+        // one upload for the four arrays (each copy behind the fill pass is a launch of its own)
+        std::vector<uint32_t> pfx(4 * ((size_t)np + 1));
+        memcpy(pfx.data(), pa0.data(), ((size_t)np + 1) * 4); memcpy(pfx.data() + (np + 1), pc0.data(), ((size_t)np + 1) * 4);
+        memcpy(pfx.data() + 2 * ((size_t)np + 1), pi0.data(), ((size_t)np + 1) * 4); memcpy(pfx.data() + 3 * ((size_t)np + 1), ps0.data(), ((size_t)np + 1) * 4);
+        uint32_t* d_pa0 = upload(ctx, pfx); uint32_t* d_pc0 = d_pa0 + (np + 1); uint32_t* d_pi0 = d_pc0 + (np + 1); uint32_t* d_ps0 = d_pi0 + (np + 1);
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
@@ -238,10 +245,11 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 const size_t n_spill = band + 1 > ls ? (size_t)(band + 1 - ls) * gt * T : 1;   // written only by chunks with more live chains than LDS slots
                 unsigned long long* spill_best = ctx->arena.get<unsigned long long>(n_spill); uint32_t* spill_rr = ctx->arena.get<uint32_t>(n_spill);
                 uint4* emit_q = ctx->arena.get<uint4>((size_t)DP_EMIT_Q * gt * T);
-                uint32_t* okeys = ctx->arena.get<uint32_t>(NC); uint32_t* order = ctx->arena.get<uint32_t>(NC);
-                SKH_LAUNCH(dp_order_keys_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, okeys, order);
-                check_launch("dp_order_keys");
-                sort_pairs_u32_u32(ctx, okeys, order, NC, 10);                      // redirects `order` to the sorted array
+                uint32_t* order = ctx->arena.get<uint32_t>(NC); uint32_t* ohist = ctx->arena.get<uint32_t>(2 * DP_ORDER_KEYS);   // histogram | scatter cursors
+                dzero(ohist, 2 * DP_ORDER_KEYS * 4, ctx->stream);
+                SKH_LAUNCH(dp_order_hist_kernel, (NC + 1023) / 1024, 256, 0, ctx->stream, NC, (const Chunk*)chunks, ohist);
+                SKH_LAUNCH(dp_order_scatter_kernel, (NC + 1023) / 1024, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)ohist, ohist + DP_ORDER_KEYS, order);
+                check_launch("dp_order");
 #define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
 #define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)
                 // the presets' bands (2500 / c for c = 200, 125, 70, 30) get kernels with exactly that many ring slots

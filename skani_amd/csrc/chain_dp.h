@@ -136,13 +136,39 @@ __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t
 }
 
 // The 64 lanes of a wave step through their chunks in lockstep, so a wave takes as long as its longest chunk: chunks are
-// handed out in order of decreasing anchor count (dp_order_keys_kernel + a 10-bit radix sort), which puts chunks of nearly equal
-// length side by side (in slot order a wave's lanes are busy only ~1/3 of the time: mean 131 anchors, longest of 64 ~350).
-__global__ __launch_bounds__(256) void dp_order_keys_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t* keys, uint32_t* vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
-    const uint32_t len = chunks[i].a_end - chunks[i].a_begin;
-    keys[i] = 1023u - (len >= 1023u ? 1023u : len); vals[i] = i;
+// handed out in order of decreasing anchor count, which puts chunks of nearly equal length side by side (in slot order a wave's lanes are busy only
+// ~1/3 of the time: mean 131 anchors, longest of 64 ~350).  The order is a counting sort on the 1024 length classes in two small kernels (a histogram
+// and a scatter; which of two equally long chunks comes first is left to the atomics -- it only decides which lane works on which).  Round 2 used
+// rocPRIM's radix sort for this: eight launches, 130 us in front of the DP.
+constexpr uint32_t DP_ORDER_KEYS = 1024;
+__device__ __forceinline__ uint32_t dp_order_key(const Chunk& c) { const uint32_t len = c.a_end - c.a_begin; return (DP_ORDER_KEYS - 1u) - (len >= DP_ORDER_KEYS - 1u ? DP_ORDER_KEYS - 1u : len); }
+__global__ __launch_bounds__(256) void dp_order_hist_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t* hist) {
+    __shared__ uint32_t lh[DP_ORDER_KEYS];
+    for (uint32_t x = threadIdx.x; x < DP_ORDER_KEYS; x += 256) lh[x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = (blockIdx.x + 1u) * 1024u < n_slots ? (blockIdx.x + 1u) * 1024u : n_slots; i < e; i += 256) atomicAdd(&lh[dp_order_key(chunks[i])], 1u);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < DP_ORDER_KEYS; x += 256) if (lh[x]) atomicAdd(&hist[x], lh[x]);
+}
+__global__ __launch_bounds__(256) void dp_order_scatter_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* hist, uint32_t* cursor, uint32_t* order) {
+    __shared__ uint32_t base[DP_ORDER_KEYS]; __shared__ uint32_t wsum[4];
+    // exclusive prefix of the histogram, redone by every workgroup (1024 values): thread t owns classes 4t .. 4t + 3
+    const uint32_t t = threadIdx.x;
+    uint32_t h[4], s = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) { h[x] = hist[4 * t + x]; s += h[x]; }
+    const uint32_t incl = wave_incl_scan(s);
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t off = incl - s;
+    for (uint32_t w = 0; w < (t >> 6); w++) off += wsum[w];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { base[4 * t + x] = off; off += h[x]; }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024u + t, e = (blockIdx.x + 1u) * 1024u < n_slots ? (blockIdx.x + 1u) * 1024u : n_slots; i < e; i += 256) {
+        const uint32_t k = dp_order_key(chunks[i]);
+        order[base[k] + atomicAdd(&cursor[k], 1u)] = i;
+    }
 }
 
 #ifndef DP_EMIT_Q

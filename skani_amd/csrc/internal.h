@@ -100,6 +100,7 @@ struct skh_genome_set {
     bool open = false; uint64_t cap_units = 0, n_units = 0; uint32_t cap_contigs = 0, n_batches = 0;
     skh::DBuf<uint8_t> stage[2];                   // device staging of the batches' ASCII (host sources), alternating
     std::vector<std::unique_ptr<skh::DevEvent>> copied;   // one per batch: recorded behind the copy of its bases (skh_genomes_wait)
+    std::mutex copied_mu;
 };
 
 // Device-resident Vec<Sketch>.  Index conventions: *_off are per-genome u64 offsets into the concatenated arrays.
@@ -209,7 +210,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 // arrays of (position in contig, contig << 1 | canonical) in position order, which are converted into p_g
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
 struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                    // a table build that is queued but not yet waited for
-TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc, DevEvent* before_kernels = nullptr);
 void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);
 void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
         tab[tab_off[g] + (uint64_t)sl * (TAB_SLICE + TAB_SLACK) + a] = v;
     }
     uint32_t* gbm = bmap + bmap_off[g] + sl * (TAB_SLICE / TAB_FILTER_HOMES);
-    for (uint32_t x = tid; x < (nh + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES; x += TABLE_THREADS) gbm[x] = lbm[x];
+    for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += TABLE_THREADS) gbm[x] = lbm[x];   // the whole slice's words (zero beyond its home slots): the filter needs no clearing beforehand
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
@@ -349,7 +349,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
 }
 
 // queues the whole table build on the context's stream and returns without waiting; _finish reads the counts back
-TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc, DevEvent* before_kernels) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
@@ -413,7 +413,6 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         uint32_t* d_sf = d32; uint32_t* d_qp = d32 + ng + 1; uint32_t* d_nb = d32 + 2 * ((size_t)ng + 1); uint32_t* d_back = d_nb + ng;
         tb.d_back = d_back;
         uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
-        dzero(ss->bmap.p, ss->bmap_off[ng] * 4, ctx->stream);                         // the padding words of partly filled slices
         // LDS per workgroup: the slice (17 KB) + its filter words + stage_cap words in which the slice's seed lists are assembled: 22 KB, seven workgroups
         // of 256 threads per CU.  A slice takes up to match_cap positions from its list (registers); slices with more re-scan the genome.
         const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
@@ -423,6 +422,9 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
         SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
         check_launch("table_blocks");
+        // the build's big kernels follow: a second stream that waits for this point (the marker sets) starts beside them instead of beside the small
+        // copies and fills above, which a kernel that fills the GPU held back by ~150 us (rocpd timeline of a bench step)
+        if (before_kernels) before_kernels->record(ctx->stream);
         SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
                    (const uint32_t*)d_nb, (const uint32_t*)d_sf, ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX, d_ss, d_sc, d_ps);
         check_launch("slice_positions");

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,74 +145,100 @@ struct PhaseClock {
 PhaseClock g_clock;
 
 // fastx_to_sketches (file_io.rs:141-252) with parsing, PCIe and packing overlapped.  The reference parses its files in parallel (file_io.rs:147) and sketches
-// each on the thread that read it; here `threads` parser threads write the kept contigs of whole files into their own 64 MB buffers and hand a full
-// buffer to the GPU (skh_genomes_append: copy + pack kernel) while the other threads keep parsing.  Genome number = the file's position in the sorted
-// list (file_io.rs:250); files that end up without a kept contig are taken out of the numbering afterwards.  Only for plain FASTA files (mapped and
-// copied once); anything gzipped or FASTQ sends the whole run through load_genomes().
+// each on the thread that read it; here `threads` parser threads write the kept contigs of the files (mapped, copied once) into a few pinned buffers and
+// the thread that completes a buffer hands it to the GPU (skh_genomes_append: asynchronous copy + pack kernel) while the others keep parsing.  The
+// files are laid out beforehand: consecutive files of the sorted list share a buffer, every file gets a stretch of its own size, the buffers rotate
+// through SLOTS pinned allocations.  Genome number = the file's position in the sorted list (file_io.rs:250); files that end up without a kept
+// contig are taken out of the numbering afterwards.  Only for plain FASTA files; anything gzipped or FASTQ sends the whole run through load_genomes().
 struct Streamed { bool ok = false; skh_sketch_set* ss = nullptr; std::vector<GenomeInfo> info; std::vector<uint32_t> kept_index; };   // kept_index[set genome] = index into info, or ~0u
 Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Args& a) {
     Streamed out;
     std::vector<std::string> files = files_in;
     std::stable_sort(files.begin(), files.end());
     const uint32_t nf = (uint32_t)files.size();
-    uint64_t total = 0; std::vector<uint64_t> fsize(nf);
+    uint64_t total = 0, largest = 0; std::vector<uint64_t> fsize(nf);
     for (uint32_t i = 0; i < nf; i++) {
         struct stat sb;
         if (stat(files[i].c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return out;
         FILE* f = fopen(files[i].c_str(), "rb"); if (!f) return out;
         unsigned char m[2] = {0, 0}; const size_t got = fread(m, 1, 2, f); fclose(f);
         if (got == 2 && m[0] == 0x1f && m[1] == 0x8b) return out;                  // gzip somewhere: the plain path is not for this run
-        fsize[i] = (uint64_t)sb.st_size; total += fsize[i];
+        fsize[i] = (uint64_t)sb.st_size; total += fsize[i]; largest = std::max(largest, fsize[i]);
     }
+    // buffers: consecutive files up to SLOT bytes; buffer b lives in pinned slot b % SLOTS
+    const uint64_t SLOT = std::max<uint64_t>((uint64_t)64 << 20, largest + 64);
+    const uint32_t SLOTS = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(6, ((uint64_t)3 << 29) / SLOT));
+    struct Buf { uint32_t f0 = 0, f1 = 0; std::atomic<uint32_t> remaining{0}; };
+    std::vector<uint32_t> buf_of(nf); std::vector<uint64_t> off_in(nf);
+    std::vector<std::unique_ptr<Buf>> bufs;
+    {
+        uint64_t at = SLOT + 1;
+        for (uint32_t i = 0; i < nf; i++) {
+            if (at + fsize[i] + 16 > SLOT) { bufs.emplace_back(new Buf()); bufs.back()->f0 = i; at = 0; }
+            buf_of[i] = (uint32_t)bufs.size() - 1; off_in[i] = at; at += (fsize[i] + 15) / 16 * 16;
+            bufs.back()->f1 = i + 1; bufs.back()->remaining++;
+        }
+    }
+    std::vector<uint8_t*> slot(SLOTS, nullptr);
+    for (uint32_t x = 0; x < std::min<uint32_t>(SLOTS, (uint32_t)bufs.size()); x++) if (!(slot[x] = (uint8_t*)skh_host_alloc(SLOT))) die("cannot pin host memory for the ingest buffers");
+    std::vector<uint64_t> slot_gen(SLOTS, 0);                                       // buffers of slot x up to generation slot_gen[x] have been copied: the next may be written
+    std::mutex slot_mu; std::condition_variable slot_cv;
     skh_genome_set* gs = nullptr;
     cx.check(skh_genomes_begin(cx.c, total + total / 7 + 4096, nf * 32 + 64, nf, a.seeding_mode, &gs), "skh_genomes_begin");
-    constexpr size_t CAP = (size_t)64 << 20;
-    std::vector<GenomeInfo> per(nf); std::vector<uint8_t> state(nf, 0);          // 1 = kept, 2 = no kept contig, 3 = unreadable, 4 = not plain FASTA
+    std::vector<GenomeInfo> per(nf); std::vector<uint8_t> state(nf, 0);          // 1 = kept, 2 = no kept contig, 3 = unreadable
+    std::vector<std::vector<uint64_t>> clens(nf);
     std::atomic<uint32_t> next{0}; std::atomic<bool> fallback{false}; std::mutex gpu; std::string gpu_err;
     auto worker = [&]() {
-        std::unique_ptr<uint8_t[]> buf; size_t cap = 0, used = 0;
-        std::vector<uint64_t> starts, lens; std::vector<uint32_t> genome;
-        auto flush = [&]() {
-            if (starts.empty()) { used = 0; return; }
-            uint64_t ticket = 0; int rc;
-            { std::lock_guard<std::mutex> lk(gpu);
-              rc = skh_genomes_append(gs, buf.get(), starts.data(), lens.data(), genome.data(), (uint32_t)starts.size(), 0, &ticket);
-              if (rc == 0) rc = skh_genomes_wait(gs, ticket);                       // the buffer is rewritten next
-              if (rc != 0 && gpu_err.empty()) gpu_err = skh_last_error(cx.c); }
-            if (rc != 0) fallback = true;
-            starts.clear(); lens.clear(); genome.clear(); used = 0;
-        };
-        std::vector<std::string> names; std::vector<uint64_t> clen;
+        std::vector<std::string> names;
         for (;;) {
             const uint32_t i = next.fetch_add(1);
-            if (i >= nf || fallback) break;
-            const size_t need = (size_t)fsize[i];
-            if (used + need > cap) {
-                flush();
-                if (need > cap) { cap = std::max(CAP, need); buf.reset(new uint8_t[cap]); }
+            if (i >= nf) break;
+            Buf& B = *bufs[buf_of[i]];
+            const uint32_t x = buf_of[i] % SLOTS; const uint64_t gen = buf_of[i] / SLOTS;
+            { std::unique_lock<std::mutex> lk(slot_mu); slot_cv.wait(lk, [&] { return slot_gen[x] >= gen || fallback; }); }
+            if (!fallback) {
+                size_t wrote = 0;
+                try {
+                    if (!parse_fasta_plain(files[i], slot[x] + off_in[i], (size_t)fsize[i] + 16, 500, &wrote, names, clens[i])) { fallback = true; slot_cv.notify_all(); }
+                    else if (names.empty()) state[i] = 2;
+                    else { state[i] = 1; GenomeInfo& gi = per[i]; gi.file_name = files[i]; gi.contigs = std::move(names); for (uint64_t l : clens[i]) gi.contig_lengths.push_back((uint32_t)l); }
+                } catch (const std::exception& e) { state[i] = 3; fprintf(stderr, "WARN %s; skipping.\n", e.what()); }
             }
-            size_t wrote = 0;
-            try {
-                if (!parse_fasta_plain(files[i], buf.get() + used, cap - used, 500, &wrote, names, clen)) { state[i] = 4; fallback = true; break; }
-            } catch (const std::exception& e) { state[i] = 3; fprintf(stderr, "WARN %s; skipping.\n", e.what()); continue; }
-            if (names.empty()) { state[i] = 2; continue; }
-            GenomeInfo& gi = per[i]; gi.file_name = files[i]; gi.contigs = std::move(names);
-            uint64_t at = used;
-            for (uint64_t l : clen) { gi.contig_lengths.push_back((uint32_t)l); starts.push_back(at); lens.push_back(l); genome.push_back(i); at += l; }
-            used += wrote; state[i] = 1;
+            if (B.remaining.fetch_sub(1) != 1) continue;
+            // this thread completed the buffer: hand it over, wait for its copy, free the slot for the buffer after next
+            if (!fallback) {
+                std::vector<uint64_t> starts, lens; std::vector<uint32_t> genome;
+                for (uint32_t f = B.f0; f < B.f1; f++) {
+                    if (state[f] != 1) continue;
+                    uint64_t at = off_in[f];
+                    for (uint64_t l : clens[f]) { starts.push_back(at); lens.push_back(l); genome.push_back(f); at += l; }
+                }
+                if (!starts.empty()) {
+                    uint64_t ticket = 0; int rc;
+                    { std::lock_guard<std::mutex> lk(gpu);
+                      rc = skh_genomes_append(gs, slot[x], starts.data(), lens.data(), genome.data(), (uint32_t)starts.size(), 0, &ticket);
+                      if (rc != 0 && gpu_err.empty()) gpu_err = skh_last_error(cx.c); }
+                    if (rc == 0) rc = skh_genomes_wait(gs, ticket);                 // (thread-safe: other threads keep appending)
+                    if (rc != 0) fallback = true;
+                }
+            }
+            { std::lock_guard<std::mutex> lk(slot_mu); slot_gen[x] = gen + 1; }
+            slot_cv.notify_all();
         }
-        flush();
     };
     {
         const int nt = std::max(1, std::min<int>(a.threads, (int)nf));
         std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(worker); for (auto& t : th) t.join();
     }
     if (fallback) {
+        (void)skh_genomes_finish(gs);                                              // drains the queued copies before the buffers go away
         skh_genomes_destroy(gs);
+        for (uint8_t* p : slot) skh_host_free(p);
         if (!gpu_err.empty()) die("skh_genomes_append: " + gpu_err);
         return out;                                                                // a FASTQ / gzip file turned up: the caller reads everything the other way
     }
     cx.check(skh_genomes_finish(gs), "skh_genomes_finish");
+    for (uint8_t* p : slot) skh_host_free(p);
     g_clock.mark("parse_upload_pack");
     out.kept_index.assign(nf, ~0u);
     for (uint32_t i = 0; i < nf; i++) {
