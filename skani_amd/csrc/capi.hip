@@ -231,10 +231,11 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             book(); tail_guard.armed = false;
             return;
         }
-        DevEvent tables_queued;
-        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr, &tables_queued);
-        if (ss->n_genomes) tables_queued.make_wait(ctx->stream2);                     // (behind the compaction kernel, whose raw markers the second stream sorts)
-        else ev[1].make_wait(ctx->stream2);
+        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
+        ev[1].make_wait(ctx->stream2);                                                // the raw markers come out of the compaction kernel
+        // (letting the second stream start only beside the table build's big kernels -- instead of beside the small copies and fills in front of them,
+        //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
+        //  and the sketch phase grows from 1.60 to 1.81 ms)
         std::swap(ctx->stream, ctx->stream2);
         try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }

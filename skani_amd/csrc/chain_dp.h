@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256) void dp_order_hist_kernel(uint32_t n_slots, co
     for (uint32_t x = threadIdx.x; x < DP_ORDER_KEYS; x += 256) if (lh[x]) atomicAdd(&hist[x], lh[x]);
 }
 __global__ __launch_bounds__(256) void dp_order_scatter_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* hist, uint32_t* cursor, uint32_t* order) {
-    __shared__ uint32_t base[DP_ORDER_KEYS]; __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base[DP_ORDER_KEYS], mine[DP_ORDER_KEYS]; __shared__ uint32_t wsum[4];
     // exclusive prefix of the histogram, redone by every workgroup (1024 values): thread t owns classes 4t .. 4t + 3
     const uint32_t t = threadIdx.x;
     uint32_t h[4], s = 0;
 #pragma unroll
-    for (int x = 0; x < 4; x++) { h[x] = hist[4 * t + x]; s += h[x]; }
+    for (int x = 0; x < 4; x++) { h[x] = hist[4 * t + x]; s += h[x]; mine[4 * t + x] = 0; }
     const uint32_t incl = wave_incl_scan(s);
     if ((t & 63u) == 63u) wsum[t >> 6] = incl;
     __syncthreads();
@@ -165,10 +165,18 @@ __global__ __launch_bounds__(256) void dp_order_scatter_kernel(uint32_t n_slots,
 #pragma unroll
     for (int x = 0; x < 4; x++) { base[4 * t + x] = off; off += h[x]; }
     __syncthreads();
-    for (uint32_t i = blockIdx.x * 1024u + t, e = (blockIdx.x + 1u) * 1024u < n_slots ? (blockIdx.x + 1u) * 1024u : n_slots; i < e; i += 256) {
-        const uint32_t k = dp_order_key(chunks[i]);
-        order[base[k] + atomicAdd(&cursor[k], 1u)] = i;
-    }
+    // the workgroup's 1024 chunks: rank within the workgroup by an LDS counter per class, then ONE global reservation per class the workgroup holds
+    // (the unused chunk slots of all pairs share the last class: a global atomic per chunk queued a quarter of a million of them on one address)
+    const uint32_t i0 = blockIdx.x * 1024u + t;
+    uint32_t k[4], r[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { const uint32_t i = i0 + 256u * x; k[x] = DP_ORDER_KEYS; if (i < n_slots) { k[x] = dp_order_key(chunks[i]); r[x] = atomicAdd(&mine[k[x]], 1u); } }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < 4; x++) { const uint32_t c = 4 * t + x, n = mine[c]; if (n) base[c] += atomicAdd(&cursor[c], n); }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < 4; x++) if (k[x] < DP_ORDER_KEYS) order[base[k[x]] + r[x]] = i0 + 256u * x;
 }
 
 #ifndef DP_EMIT_Q

@@ -27,11 +27,11 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {   // types.rs:40-49 
     return 0;
 }
 
-// A thread packs 16 consecutive bases of one contig (half a "unit" of 32: contigs start on unit boundaries).  Its 16 source bytes are fetched as four
-// 4-byte-aligned words in one load (neighbouring lanes read neighbouring 16-byte stretches: a wave's load is one contiguous kilobyte) plus one more word
-// when the contig does not start on a word boundary, and shifted into place;
+// A thread packs 32 consecutive bases of one contig (a "unit": contigs start on unit boundaries).  Its 32 source bytes are fetched as nine
+// 4-byte-aligned words (two four-word loads and one more; neighbouring lanes read neighbouring 32-byte stretches: coalesced) and shifted into place;
 // base codes, the validity of every byte (types.rs:40-49: anything but ACGTU / acgtu / 0..3 is an A) and the N flags come out of byte-parallel
-// arithmetic on whole words, four bases at a time.  (Round 2's kernel walked 32 bytes per thread one by one: 9.6 ms per 4.9 Gbases.)
+// arithmetic on whole words, four bases at a time: 3.9 ms per 4.9 Gbases (round 2's kernel walked its 32 bytes one by one: 9.6 ms; a variant with
+// 16 bases per thread, whose loads cover one contiguous kilobyte per wave, took 5.9 ms -- twice the threads, twice the per-thread contig look-up).
 struct __attribute__((packed, aligned(4))) PackWords4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {                       // 0x80 in every byte of v that is zero (exact, no borrow between bytes)
     return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
@@ -57,41 +57,42 @@ __device__ __forceinline__ uint32_t n_flags_of_word(uint32_t w, int mode) {     
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* bases, uint64_t readable_bytes, const uint64_t* src_off, const uint64_t* unit_off,
                                                    ContigDesc* contigs, uint32_t n_contigs, uint64_t n_units, int mode,
                                                    uint32_t* packed, uint32_t* nmask) {
-    // a thread packs SIXTEEN bases (one output word, half a unit): the wave's four-word loads then cover one contiguous kilobyte of the source
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, u = t >> 1;
-    const uint32_t half = (uint32_t)t & 1u;
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = u < n_units;
     // the contig of the wave's first unit by binary search, the lanes' own by walking on from it (contigs have at least 16 units: a step or two)
     const uint64_t u0 = __shfl(u, 0, 64);
     uint32_t lo = 0, hi = n_contigs;
     if (u0 < n_units) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= u0) lo = mid; else hi = mid; }
-    uint32_t w = 0, m = 0, ci = lo;
-    if (live) {
-        while (ci + 1 < n_contigs && unit_off[ci + 1] <= u) ci++;
-        const uint64_t b0 = (u - unit_off[ci]) * 32 + 16u * half;
-        const uint32_t len = contigs[ci].len;
-        const uint64_t so = src_off[ci] + b0;                                       // first source byte of the sixteen
-        const uint64_t addr = (uint64_t)(uintptr_t)bases + so; const uint32_t sh = (uint32_t)(addr & 3u);
-        if (b0 + 16 <= len && so - sh + 20 <= readable_bytes) {                     // sixteen bases inside the contig, all five words readable
-            const uint32_t* q = (const uint32_t*)(uintptr_t)(addr - sh);
-            const PackWords4 qa = *(const PackWords4*)q; const uint32_t q4 = sh ? q[4] : 0u;
-            const uint32_t d[4] = {shift_bytes(qa.y, qa.x, sh), shift_bytes(qa.z, qa.y, sh), shift_bytes(qa.w, qa.z, sh), shift_bytes(q4, qa.w, sh)};
+    if (!live) return;
+    uint32_t ci = lo;
+    while (ci + 1 < n_contigs && unit_off[ci + 1] <= u) ci++;
+    const uint64_t b0 = (u - unit_off[ci]) * 32;
+    const uint32_t len = contigs[ci].len;
+    const uint64_t so = src_off[ci] + b0;                                           // first source byte of the unit
+    uint32_t w0 = 0, w1 = 0, m = 0;
+    const uint64_t addr = (uint64_t)(uintptr_t)bases + so; const uint32_t sh = (uint32_t)(addr & 3u);
+    if (b0 + 32 <= len && so - sh + 36 <= readable_bytes) {                         // a whole unit inside the contig, all nine words readable
+        const uint32_t* q = (const uint32_t*)(uintptr_t)(addr - sh);
+        const PackWords4 qa = *(const PackWords4*)q, qb = *(const PackWords4*)(q + 4); const uint32_t q8 = q[8];
+        const uint32_t d[8] = {shift_bytes(qa.y, qa.x, sh), shift_bytes(qa.z, qa.y, sh), shift_bytes(qa.w, qa.z, sh), shift_bytes(qb.x, qa.w, sh),
+                               shift_bytes(qb.y, qb.x, sh), shift_bytes(qb.z, qb.y, sh), shift_bytes(qb.w, qb.z, sh), shift_bytes(q8, qb.w, sh)};
 #pragma unroll
-            for (int j = 0; j < 4; j++) { w |= codes_of_word(d[j]) << (24 - 8 * j); m |= n_flags_of_word(d[j], mode) << (4 * j); }
-        } else {                                                                    // a contig's last bases, the end of the buffer: byte by byte
-            const uint8_t* src = bases + src_off[ci];
-            for (uint32_t x = 0; x < 16; x++) {
-                const uint64_t p = b0 + x;
-                const uint32_t byte = p < len ? src[p] : (uint32_t)'A';
-                const bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
-                w |= base_code(byte) << (30 - 2 * x); m |= (is_n ? 1u : 0u) << x;
-            }
+        for (int j = 0; j < 4; j++) { w0 |= codes_of_word(d[j]) << (24 - 8 * j); w1 |= codes_of_word(d[4 + j]) << (24 - 8 * j); }
+#pragma unroll
+        for (int j = 0; j < 8; j++) m |= n_flags_of_word(d[j], mode) << (4 * j);
+    } else {                                                                        // a contig's last unit(s), the end of the buffer: byte by byte
+        const uint8_t* src = bases + src_off[ci];
+        for (uint32_t x = 0; x < 32; x++) {
+            const uint64_t p = b0 + x;
+            const uint32_t byte = p < len ? src[p] : (uint32_t)'A';
+            const uint32_t code = base_code(byte);
+            const bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
+            if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
+            m |= (is_n ? 1u : 0u) << x;
         }
     }
-    const uint32_t m_hi = __shfl_down(m, 1, 64);                                    // the odd lane's sixteen N flags join the even lane's
-    if (!live) return;
-    packed[t] = w;                                                                  // contig bases are laid out at 32 * unit_off
-    if (!half) { const uint32_t mm = m | (m_hi << 16); nmask[u] = mm; if (mm) atomicOr(&contigs[ci].has_n, 1u); }
+    *(uint2*)(packed + 2 * u) = make_uint2(w0, w1); nmask[u] = m;                   // contig bases are laid out at 32 * unit_off
+    if (m) atomicOr(&contigs[ci].has_n, 1u);
 }
 
 static inline uint32_t windows_end(uint32_t len, int mode) {  // exclusive bound on the window's last-base index i
@@ -175,7 +176,7 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
     uint64_t* d_src = ctx->arena.get<uint64_t>(nc + 1); uint64_t* d_unit = ctx->arena.get<uint64_t>(nc + 1);
     h2d(d_src, src_off.data(), (size_t)nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), ((size_t)nc + 1) * 8, ctx->stream);
     if (n_units) {
-        SKH_LAUNCH(pack_kernel, (unsigned)((2 * n_units + 255) / 256), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
+        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
                    (const uint64_t*)d_unit, gs->d_contigs.p + c0, nc, n_units, gs->seeding_mode, gs->packed.p + gs->n_units * 2, gs->nmask.p + gs->n_units);
         check_launch("pack_kernel");
     }

@@ -349,7 +349,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
 }
 
 // queues the whole table build on the context's stream and returns without waiting; _finish reads the counts back
-TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc, DevEvent* before_kernels) {
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
@@ -422,9 +422,6 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
         SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
         check_launch("table_blocks");
-        // the build's big kernels follow: a second stream that waits for this point (the marker sets) starts beside them instead of beside the small
-        // copies and fills above, which a kernel that fills the GPU held back by ~150 us (rocpd timeline of a bench step)
-        if (before_kernels) before_kernels->record(ctx->stream);
         SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
                    (const uint32_t*)d_nb, (const uint32_t*)d_sf, ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX, d_ss, d_sc, d_ps);
         check_launch("slice_positions");
