@@ -245,10 +245,11 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 const size_t n_spill = band + 1 > ls ? (size_t)(band + 1 - ls) * gt * T : 1;   // written only by chunks with more live chains than LDS slots
                 unsigned long long* spill_best = ctx->arena.get<unsigned long long>(n_spill); uint32_t* spill_rr = ctx->arena.get<uint32_t>(n_spill);
                 uint4* emit_q = ctx->arena.get<uint4>((size_t)DP_EMIT_Q * gt * T);
+                const unsigned ob = (NC + DP_ORDER_BLOCK - 1) / DP_ORDER_BLOCK;
                 uint32_t* order = ctx->arena.get<uint32_t>(NC); uint32_t* ohist = ctx->arena.get<uint32_t>(2 * DP_ORDER_KEYS);   // histogram | scatter cursors
                 dzero(ohist, 2 * DP_ORDER_KEYS * 4, ctx->stream);
-                SKH_LAUNCH(dp_order_hist_kernel, (NC + 1023) / 1024, 256, 0, ctx->stream, NC, (const Chunk*)chunks, ohist);
-                SKH_LAUNCH(dp_order_scatter_kernel, (NC + 1023) / 1024, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)ohist, ohist + DP_ORDER_KEYS, order);
+                SKH_LAUNCH(dp_order_hist_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, ohist);
+                SKH_LAUNCH(dp_order_scatter_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)ohist, ohist + DP_ORDER_KEYS, order);
                 check_launch("dp_order");
 #define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
 #define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)

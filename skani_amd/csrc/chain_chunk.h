@@ -35,6 +35,52 @@ __device__ __forceinline__ void narrow_by_samples(const uint32_t* samp, uint32_t
     if (a < t1) { const uint32_t t = org + a * CHUNK_SAMPLE; hi = t < hi ? t : hi; }               // sample a holds: the answer is at or before it
 }
 
+// N binary searches of a lane advanced TOGETHER, four ways per step: every step probes the three quarter points of each open range at once (independent
+// loads), the last step reads the remaining (up to eight) entries at once -- a range of 128 closes in three dependent round trips to memory instead of
+// seven.  The kernel is a chain of such round trips (a wave per pair, 64 searches wide): their number is what it costs.
+// arr[x][i] >> sh[x] is the key of entry i; the answer for search x is the first index in [lo, hi) whose key is > v[x] (upper[x]) or >= v[x], else hi.
+template <int N>
+__device__ __forceinline__ void search_together(const uint32_t* const (&arr)[N], const uint32_t (&sh)[N], uint32_t (&lo)[N], uint32_t (&hi)[N], const uint32_t (&v)[N],
+                                                const bool (&upper)[N]) {
+    auto holds = [&](int x, uint32_t key) { return upper[x] ? key > v[x] : key >= v[x]; };
+    for (;;) {
+        bool open = false;
+#pragma unroll
+        for (int x = 0; x < N; x++) open = open || lo[x] < hi[x];
+        if (__ballot(open) == 0ull) break;
+        uint32_t k[N][8];
+#pragma unroll
+        for (int x = 0; x < N; x++) {
+            const uint32_t n = hi[x] - lo[x];
+            if (lo[x] >= hi[x]) continue;
+            if (n <= 8u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) k[x][j] = j < n ? arr[x][lo[x] + j] >> sh[x] : 0u;
+            } else {
+                const uint32_t q = n >> 2;
+#pragma unroll
+                for (uint32_t j = 1; j < 4; j++) k[x][j] = arr[x][lo[x] + j * q] >> sh[x];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < N; x++) {
+            const uint32_t n = hi[x] - lo[x];
+            if (lo[x] >= hi[x]) continue;
+            if (n <= 8u) {
+                uint32_t ans = hi[x];
+                for (uint32_t j = n; j-- > 0;) if (holds(x, k[x][j])) ans = lo[x] + j;
+                lo[x] = hi[x] = ans;                                                 // closed: lo == hi == the answer
+            } else {
+                const uint32_t q = n >> 2, p1 = lo[x] + q, p2 = lo[x] + 2 * q, p3 = lo[x] + 3 * q;
+                if (holds(x, k[x][1])) hi[x] = p1;
+                else if (holds(x, k[x][2])) { lo[x] = p1 + 1; hi[x] = p2; }
+                else if (holds(x, k[x][3])) { lo[x] = p2 + 1; hi[x] = p3; }
+                else lo[x] = p3 + 1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0, const uint32_t* pan,
                                                     const uint32_t* pc0, const uint32_t* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
@@ -74,12 +120,11 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 narrow_by_samples<false>(sa, ns_a, A0, cstart, lo_a, hi_a); narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e);
                 narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
             }
-            while (__ballot(lo_a < hi_a || lo_e < hi_e || lo_r < hi_r) != 0ull) {  // the three searches advance together: their round trips overlap
-                const uint32_t ma = (lo_a + hi_a) >> 1, me = (lo_e + hi_e) >> 1, mr = (lo_r + hi_r) >> 1;
-                const uint32_t va = lo_a < hi_a ? anc_q[ma] : 0u, ve = lo_e < hi_e ? anc_q[me] : 0u, vr = lo_r < hi_r ? ag[mr] >> 1 : 0u;
-                if (lo_a < hi_a) { if (va < cstart) lo_a = ma + 1; else hi_a = ma; }
-                if (lo_e < hi_e) { if (ve < cnext) lo_e = me + 1; else hi_e = me; }
-                if (lo_r < hi_r) { if (vr < cstart) lo_r = mr + 1; else hi_r = mr; }
+            {                                                                       // the three searches advance together: their round trips overlap
+                const uint32_t* const arr[3] = {anc_q, anc_q, ag}; const uint32_t sh[3] = {0, 0, 1}; const uint32_t vv[3] = {cstart, cnext, cstart}; const bool up[3] = {false, false, false};
+                uint32_t lo3[3] = {lo_a, lo_e, lo_r}, hi3[3] = {hi_a, hi_e, hi_r};
+                search_together<3>(arr, sh, lo3, hi3, vv, up);
+                lo_a = lo3[0]; lo_e = lo3[1]; lo_r = lo3[2];
             }
             const uint32_t ca = lo_a, ce = lo_e, rc0 = lo_r;                        // running_counter = 0 within the contig starts at rc0 (chain.rs:742-744)
             const bool has = cv && ce > ca;
@@ -101,11 +146,11 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
                 uint32_t lo_b = a_c, hi_b = iv ? A1 : a_c, lo_s = 0, hi_s = iv ? Q1 : 0;
                 if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
-                while (__ballot(lo_b < hi_b || lo_s < hi_s) != 0ull) {
-                    const uint32_t mb = (lo_b + hi_b) >> 1, ms = (lo_s + hi_s) >> 1;
-                    const uint32_t vb = lo_b < hi_b ? anc_q[mb] : 0u, vs = lo_s < hi_s ? ag[ms] >> 1 : 0u;
-                    if (lo_b < hi_b) { if (vb > lim) hi_b = mb; else lo_b = mb + 1; }
-                    if (lo_s < hi_s) { if (vs > lim) hi_s = ms; else lo_s = ms + 1; }
+                {
+                    const uint32_t* const arr[2] = {anc_q, ag}; const uint32_t sh[2] = {0, 1}; const uint32_t vv[2] = {lim, lim}; const bool up[2] = {true, true};
+                    uint32_t lo2[2] = {lo_b, lo_s}, hi2[2] = {hi_b, hi_s};
+                    search_together<2>(arr, sh, lo2, hi2, vv, up);
+                    lo_b = lo2[0]; lo_s = lo2[1];
                 }
                 const uint32_t bnd = lo_b, sb = lo_s;
                 const uint32_t cid = iv ? c0 + (uint32_t)src : 0xFFFFFF00u + l;    // lanes without an item: segments of their own
