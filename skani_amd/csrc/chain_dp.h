@@ -137,44 +137,48 @@ __device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t
 
 // The 64 lanes of a wave step through their chunks in lockstep, so a wave takes as long as its longest chunk: chunks are
 // handed out in order of decreasing anchor count, which puts chunks of nearly equal length side by side (in slot order a wave's lanes are busy only
-// ~1/3 of the time: mean 131 anchors, longest of 64 ~350).  The order is a counting sort on 128 length classes in two small kernels (a histogram
+// ~1/3 of the time: mean 131 anchors, longest of 64 ~350).  The order is a counting sort on the 1024 chunk lengths in two small kernels (a histogram
 // and a scatter; which of two equally long chunks comes first is left to the atomics -- it only decides which lane works on which).  Round 2 used
 // rocPRIM's radix sort for this: eight launches, 130 us in front of the DP.
-constexpr uint32_t DP_ORDER_KEYS = 128, DP_ORDER_BLOCK = 4096;                       // length classes of 8 anchors (the last one: 1016 and more); chunks per workgroup
-__device__ __forceinline__ uint32_t dp_order_key(const Chunk& c) { const uint32_t len = (c.a_end - c.a_begin) >> 3; return (DP_ORDER_KEYS - 1u) - (len >= DP_ORDER_KEYS - 1u ? DP_ORDER_KEYS - 1u : len); }
+constexpr uint32_t DP_ORDER_KEYS = 1024, DP_ORDER_BLOCK = 8192;                      // one class per chunk length (the last one: 1023 and more); chunks per workgroup
+__device__ __forceinline__ uint32_t dp_order_key(const Chunk& c) { const uint32_t len = c.a_end - c.a_begin; return (DP_ORDER_KEYS - 1u) - (len >= DP_ORDER_KEYS - 1u ? DP_ORDER_KEYS - 1u : len); }
 __global__ __launch_bounds__(256) void dp_order_hist_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t* hist) {
     __shared__ uint32_t lh[DP_ORDER_KEYS];
-    if (threadIdx.x < DP_ORDER_KEYS) lh[threadIdx.x] = 0;
+    for (uint32_t x = threadIdx.x; x < DP_ORDER_KEYS; x += 256) lh[x] = 0;
     __syncthreads();
     const uint32_t e = (blockIdx.x + 1u) * DP_ORDER_BLOCK < n_slots ? (blockIdx.x + 1u) * DP_ORDER_BLOCK : n_slots;
     for (uint32_t i = blockIdx.x * DP_ORDER_BLOCK + threadIdx.x; i < e; i += 256) atomicAdd(&lh[dp_order_key(chunks[i])], 1u);
     __syncthreads();
-    if (threadIdx.x < DP_ORDER_KEYS && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    for (uint32_t x = threadIdx.x; x < DP_ORDER_KEYS; x += 256) if (lh[x]) atomicAdd(&hist[x], lh[x]);
 }
 __global__ __launch_bounds__(256) void dp_order_scatter_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* hist, uint32_t* cursor, uint32_t* order) {
-    __shared__ uint32_t base[DP_ORDER_KEYS], mine[DP_ORDER_KEYS], first_half;
+    __shared__ uint32_t base[DP_ORDER_KEYS], mine[DP_ORDER_KEYS]; __shared__ uint32_t wsum[4];
+    // exclusive prefix of the histogram, redone by every workgroup (1024 values): thread t owns classes 4t .. 4t + 3
     const uint32_t t = threadIdx.x;
-    // exclusive prefix of the histogram, redone by every workgroup: two waves hold the 128 classes
-    if (t < DP_ORDER_KEYS) {
-        const uint32_t h = hist[t], incl = wave_incl_scan(h);
-        mine[t] = 0; base[t] = incl - h;
-        if (t == 63) first_half = incl;
-    }
+    uint32_t h[4], s = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) { h[x] = hist[4 * t + x]; s += h[x]; mine[4 * t + x] = 0; }
+    const uint32_t incl = wave_incl_scan(s);
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
     __syncthreads();
-    if (t >= 64 && t < DP_ORDER_KEYS) base[t] += first_half;
+    uint32_t off = incl - s;
+    for (uint32_t w = 0; w < (t >> 6); w++) off += wsum[w];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { base[4 * t + x] = off; off += h[x]; }
     __syncthreads();
     // the workgroup's chunks: rank within the workgroup by an LDS counter per class, then ONE global reservation per class the workgroup holds
     // (the unused chunk slots of all pairs share the last class: a global atomic per chunk queued a quarter of a million of them on one address: 3.8 ms)
     constexpr int PER = DP_ORDER_BLOCK / 256;
     const uint32_t i0 = blockIdx.x * DP_ORDER_BLOCK + t;
-    uint8_t k[PER]; uint16_t r[PER];
+    uint16_t k[PER], r[PER];
 #pragma unroll
-    for (int x = 0; x < PER; x++) { const uint32_t i = i0 + 256u * x; k[x] = 0xFF; if (i < n_slots) { k[x] = (uint8_t)dp_order_key(chunks[i]); r[x] = (uint16_t)atomicAdd(&mine[k[x]], 1u); } }
-    __syncthreads();
-    if (t < DP_ORDER_KEYS && mine[t]) base[t] += atomicAdd(&cursor[t], mine[t]);
+    for (int x = 0; x < PER; x++) { const uint32_t i = i0 + 256u * x; k[x] = 0xFFFF; if (i < n_slots) { k[x] = (uint16_t)dp_order_key(chunks[i]); r[x] = (uint16_t)atomicAdd(&mine[k[x]], 1u); } }
     __syncthreads();
 #pragma unroll
-    for (int x = 0; x < PER; x++) if (k[x] != 0xFF) order[base[k[x]] + r[x]] = i0 + 256u * x;
+    for (int x = 0; x < 4; x++) { const uint32_t c = 4 * t + x, n = mine[c]; if (n) base[c] += atomicAdd(&cursor[c], n); }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < PER; x++) if (k[x] != 0xFFFF) order[base[k[x]] + r[x]] = i0 + 256u * x;
 }
 
 #ifndef DP_EMIT_Q
