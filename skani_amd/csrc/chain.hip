@@ -228,7 +228,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         tr.mark("join_fill (+slots)");
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, np, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)(d_pair_anch + p0),
+        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)(d_pair_anch + p0),
                    (const uint32_t*)d_pc0, (const uint32_t*)anc_q, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         tr.mark("chunk");

@@ -14,12 +14,6 @@
 // positions up to its last anchor instead (chain.rs:794-824).  query_positions_all is not materialised: it is the enumerated
 // sketch's own position array (coordinates ascend) filtered by the join's one-bit-per-position mask, so a chunk records a range
 // of POSITION indices and chunk_stats_kernel applies the mask.
-// first index in [lo, hi) of a sketch's position array (entries are coordinate << 1 | canonical) whose coordinate is > v, else hi
-__device__ __forceinline__ uint32_t pos_first_above(const uint32_t* g1, uint32_t lo, uint32_t hi, uint32_t v) {
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((g1[mid] >> 1) > v) hi = mid; else lo = mid + 1; }
-    return lo;
-}
-
 // Two-level search: every CHUNK_SAMPLE-th key of the pair's anchor / position arrays is copied to LDS once; a search first narrows its
 // range [lo, hi) to one sample interval there (LDS round trips) and only the last log2(CHUNK_SAMPLE) probes go to memory.
 // UPPER: first index whose key is > v; otherwise first index whose key is >= v.  samp[t] = key(array[org + t * CHUNK_SAMPLE]), t < ns.
@@ -81,24 +75,19 @@ __device__ __forceinline__ void search_together(const uint32_t* const (&arr)[N],
     }
 }
 
-// A WORKGROUP (four waves) per pair.  What costs here is not arithmetic but the chain of dependent round trips to memory a pair needs -- the key samples, the
-// contig boundaries, then a search per chunk boundary -- times the few pairs there are to hide them behind (9,500 waves at a wave per pair: 1.8 resident
-// per SIMD).  So the searches, which do not depend on one another, are spread over the workgroup's 256 threads (256 chunk boundaries per round instead of
-// 64), and only the running maximum that ties the boundaries of a contig together, and the chunk records it yields, are left to one wave.
-struct ChunkCtg { uint32_t P, kmax, ca, ce, rc0, q_first, cnext, cstart; };        // per query contig of the current round of 64: LDS
+// (A workgroup of four waves per pair -- 256 boundary searches per round, the running maximum left to one wave -- was measured in round 3: 0.54 instead of
+//  0.45 ms.  Three of a pair's four waves then sit at barriers most of the time and take the residency of three other pairs.)
 __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0, const uint32_t* pan,
                                                     const uint32_t* pc0, const uint32_t* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
-    __shared__ uint32_t lds_samp[2][CHUNK_SAMPLES];
-    __shared__ ChunkCtg lds_ctg[64];
-    __shared__ uint32_t lds_bnd[256], lds_sb[256], lds_m;
-    const uint32_t p = blockIdx.x;
+    __shared__ uint32_t lds_samp[4][2][CHUNK_SAMPLES];
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
-    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    const uint32_t l = lane_id();
     // the pair's anchors: pan[p] of them from pa0[p] on (its stretch of the batch arrays may be longer; a pair that overflowed its stretch is
     // re-run by the host, here it is merely kept inside it)
     const uint32_t A0 = pa0[p], A1 = A0 + (pan[p] < pa0[p + 1] - A0 ? pan[p] : pa0[p + 1] - A0), C0 = pc0[p], C1 = pc0[p + 1];
-    uint32_t nc = 0;                                                                // chunks written so far (wave 0 counts)
+    uint32_t nc = 0;
     if (A1 > A0) {
         const uint32_t* go = pairs[p].a_goff;
         const uint32_t nctg = pairs[p].a_nctg;
@@ -106,116 +95,96 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         const uint32_t q_pair_last = anc_q[A1 - 1];
         const uint32_t ns_a = (A1 - A0 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE, ns_s = (Q1 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE;
         const bool sampled = ns_a <= CHUNK_SAMPLES && ns_s <= CHUNK_SAMPLES;
-        uint32_t* sa = lds_samp[0]; uint32_t* ss = lds_samp[1];
+        uint32_t* sa = lds_samp[threadIdx.x >> 6][0]; uint32_t* ss = lds_samp[threadIdx.x >> 6][1];
         if (sampled) {
-            for (uint32_t t = tid; t < ns_a; t += 256) sa[t] = anc_q[A0 + t * CHUNK_SAMPLE];
-            for (uint32_t t = tid; t < ns_s; t += 256) ss[t] = ag[t * CHUNK_SAMPLE] >> 1;
+            for (uint32_t t = l; t < ns_a; t += 64) sa[t] = anc_q[A0 + t * CHUNK_SAMPLE];
+            for (uint32_t t = l; t < ns_s; t += 64) ss[t] = ag[t * CHUNK_SAMPLE] >> 1;
+            wave_sync_mem();
         }
-        __syncthreads();
         uint32_t sf_lo = 0, sf_hi = Q1;
         if (sampled) narrow_by_samples<true>(ss, ns_s, 0, q_pair_last, sf_lo, sf_hi);
-        const uint32_t s_final = pos_first_above(ag, sf_lo, sf_hi, q_pair_last);    // the pair's final chunk ends its seed range here (chain.rs:794-824)
-        // 64 query contigs per round, one per lane of wave 0: the contig's anchor range [ca, ce), its first position rc0 and its number of end points;
-        // then the (contig, k) items of the round are worked off 256 at a time -- a genome in a thousand contigs costs rounds of searches by the
+        uint32_t s_final;                                                           // the pair's final chunk ends its seed range here (chain.rs:794-824)
+        {
+            const uint32_t* const arr[1] = {ag}; const uint32_t sh[1] = {1}; const uint32_t vv[1] = {q_pair_last}; const bool up[1] = {true};
+            uint32_t lo1[1] = {sf_lo}, hi1[1] = {sf_hi};
+            search_together<1>(arr, sh, lo1, hi1, vv, up);
+            s_final = lo1[0];
+        }
+        // 64 query contigs per round, one per lane: the contig's anchor range [ca, ce), its first position rc0 and its number of end points;
+        // then the (contig, k) items of the round are worked off 64 at a time -- a genome in a thousand contigs costs rounds of searches by the
         // sixty-fourth of its contigs, not by the contig
-        uint32_t carry_cid = NONE, carry_t = 0, carry_s = 0; int32_t carry_uu = 0;   // (wave 0)
+        uint32_t carry_cid = NONE, carry_t = 0, carry_s = 0; int32_t carry_uu = 0;
         for (uint32_t c0 = 0; c0 < nctg; c0 += 64) {
-            if (w == 0) {
-                const uint32_t cl = c0 + l; const bool cv = cl < nctg;
-                const uint32_t cstart = cv ? go[cl] : 0xFFFFFFFFu, cnext = cv ? go[cl + 1] : 0xFFFFFFFFu;
-                uint32_t lo_a = A0, hi_a = cv ? A1 : A0, lo_e = A0, hi_e = cv ? A1 : A0, lo_r = 0, hi_r = cv ? Q1 : 0;
-                if (sampled) {
-                    narrow_by_samples<false>(sa, ns_a, A0, cstart, lo_a, hi_a); narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e);
-                    narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
-                }
-                {                                                                   // the three searches advance together: their round trips overlap
-                    const uint32_t* const arr[3] = {anc_q, anc_q, ag}; const uint32_t sh[3] = {0, 0, 1}; const uint32_t vv[3] = {cstart, cnext, cstart}; const bool up[3] = {false, false, false};
-                    uint32_t lo3[3] = {lo_a, lo_e, lo_r}, hi3[3] = {hi_a, hi_e, hi_r};
-                    search_together<3>(arr, sh, lo3, hi3, vv, up);
-                    lo_a = lo3[0]; lo_e = lo3[1]; lo_r = lo3[2];
-                }
-                const uint32_t ca = lo_a, ce = lo_e, rc0 = lo_r;                    // running_counter = 0 within the contig starts at rc0 (chain.rs:742-744)
-                const bool has = cv && ce > ca;
-                const uint32_t q_first = has ? anc_q[ca] : 0u, q_last = has ? anc_q[ce - 1] : 0u;
-                const uint32_t kmax = has ? (q_last - q_first) / CHUNK_SIZE + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
-                const uint32_t P = wave_incl_scan(kmax);
-                lds_ctg[l] = ChunkCtg{P, kmax, ca, ce, rc0, q_first, cnext, cstart};
-                if (l == 63) lds_m = P;
+            const uint32_t cl = c0 + l; const bool cv = cl < nctg;
+            const uint32_t cstart = cv ? go[cl] : 0xFFFFFFFFu, cnext = cv ? go[cl + 1] : 0xFFFFFFFFu;
+            uint32_t lo_a = A0, hi_a = cv ? A1 : A0, lo_e = A0, hi_e = cv ? A1 : A0, lo_r = 0, hi_r = cv ? Q1 : 0;
+            if (sampled) {
+                narrow_by_samples<false>(sa, ns_a, A0, cstart, lo_a, hi_a); narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e);
+                narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
             }
-            __syncthreads();
-            const uint32_t M = lds_m;
-            for (uint32_t J0 = 0; J0 < M; J0 += 256) {
-                // ---- every thread: one (contig, k) item -- its owner contig (first with P > j), the limit, the two searches
+            {                                                                       // the three searches advance together: their round trips overlap
+                const uint32_t* const arr[3] = {anc_q, anc_q, ag}; const uint32_t sh[3] = {0, 0, 1}; const uint32_t vv[3] = {cstart, cnext, cstart}; const bool up[3] = {false, false, false};
+                uint32_t lo3[3] = {lo_a, lo_e, lo_r}, hi3[3] = {hi_a, hi_e, hi_r};
+                search_together<3>(arr, sh, lo3, hi3, vv, up);
+                lo_a = lo3[0]; lo_e = lo3[1]; lo_r = lo3[2];
+            }
+            const uint32_t ca = lo_a, ce = lo_e, rc0 = lo_r;                        // running_counter = 0 within the contig starts at rc0 (chain.rs:742-744)
+            const bool has = cv && ce > ca;
+            const uint32_t q_first = has ? anc_q[ca] : 0u, q_last = has ? anc_q[ce - 1] : 0u;
+            const uint32_t kmax = has ? (q_last - q_first) / CHUNK_SIZE + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
+            const uint32_t P = wave_incl_scan(kmax), M = __shfl(P, 63, 64);
+            for (uint32_t j0 = 0; j0 < M; j0 += 64) {
+                const uint32_t j = j0 + l; const bool iv = j < M;
+                uint32_t slo = 0, shi = 63;                                        // the lane (contig) that owns item j: first with P > j
+#pragma unroll
+                for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; const uint32_t pm = __shfl(P, (int)mid, 64); if (pm > j) shi = mid; else slo = mid + 1; }
+                const int src = (int)(iv ? slo : 63u);
+                const uint32_t o_kmax = __shfl(kmax, src, 64), o_P = __shfl(P, src, 64), a_c = __shfl(ca, src, 64), e_c = __shfl(ce, src, 64), r_c = __shfl(rc0, src, 64);
+                const uint32_t qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64), cs = __shfl(cstart, src, 64);
+                const uint32_t k = j - (o_P - o_kmax) + 1u;
+                const uint64_t end64 = (uint64_t)qf + (uint64_t)k * CHUNK_SIZE;
+                const uint32_t lim = end64 < (uint64_t)(cn - 1) ? (uint32_t)end64 : cn - 1;   // beyond it: another contig, or past the window
+                //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
+                //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
+                uint32_t lo_b = a_c, hi_b = iv ? A1 : a_c, lo_s = 0, hi_s = iv ? Q1 : 0;
+                if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
                 {
-                    const uint32_t j = J0 + tid; const bool iv = j < M;
-                    uint32_t slo = 0, shi = 63;
-#pragma unroll
-                    for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; if (lds_ctg[mid].P > j) shi = mid; else slo = mid + 1; }
-                    const ChunkCtg o = lds_ctg[iv ? slo : 63u];
-                    const uint32_t k = j - (o.P - o.kmax) + 1u;
-                    const uint64_t end64 = (uint64_t)o.q_first + (uint64_t)k * CHUNK_SIZE;
-                    const uint32_t lim = end64 < (uint64_t)(o.cnext - 1) ? (uint32_t)end64 : o.cnext - 1;   // beyond it: another contig, or past the window
-                    //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
-                    //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
-                    uint32_t lo_b = o.ca, hi_b = iv ? A1 : o.ca, lo_s = 0, hi_s = iv ? Q1 : 0;
-                    if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
-                    {
-                        const uint32_t* const arr[2] = {anc_q, ag}; const uint32_t sh[2] = {0, 1}; const uint32_t vv[2] = {lim, lim}; const bool up[2] = {true, true};
-                        uint32_t lo2[2] = {lo_b, lo_s}, hi2[2] = {hi_b, hi_s};
-                        search_together<2>(arr, sh, lo2, hi2, vv, up);
-                        lo_b = lo2[0]; lo_s = lo2[1];
-                    }
-                    lds_bnd[tid] = lo_b; lds_sb[tid] = lo_s;
+                    const uint32_t* const arr[2] = {anc_q, ag}; const uint32_t sh[2] = {0, 1}; const uint32_t vv[2] = {lim, lim}; const bool up[2] = {true, true};
+                    uint32_t lo2[2] = {lo_b, lo_s}, hi2[2] = {hi_b, hi_s};
+                    search_together<2>(arr, sh, lo2, hi2, vv, up);
+                    lo_b = lo2[0]; lo_s = lo2[1];
                 }
-                __syncthreads();
-                // ---- wave 0: the running maximum within each contig and the chunk records, 64 items at a time
-                if (w == 0) {
-                    for (uint32_t j0 = J0; j0 < M && j0 < J0 + 256; j0 += 64) {
-                        const uint32_t j = j0 + l; const bool iv = j < M;
-                        uint32_t slo = 0, shi = 63;
+                const uint32_t bnd = lo_b, sb = lo_s;
+                const uint32_t cid = iv ? c0 + (uint32_t)src : 0xFFFFFF00u + l;    // lanes without an item: segments of their own
+                int32_t v = (int32_t)bnd - (int32_t)k;                              // u_k
+                if (k == 1) v = v > (int32_t)a_c ? v : (int32_t)a_c;                // u_0 = t_0 = the contig's first anchor
+                if (l == 0 && cid == carry_cid) v = v > carry_uu ? v : carry_uu;    // the contig continues from the previous batch
 #pragma unroll
-                        for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; if (lds_ctg[mid].P > j) shi = mid; else slo = mid + 1; }
-                        const uint32_t src = iv ? slo : 63u;
-                        const ChunkCtg o = lds_ctg[src];
-                        const uint32_t a_c = o.ca, e_c = o.ce, r_c = o.rc0, cs = o.cstart;
-                        const uint32_t k = j - (o.P - o.kmax) + 1u;
-                        const uint32_t bnd = lds_bnd[j - J0 < 256u ? j - J0 : 0u], sb = lds_sb[j - J0 < 256u ? j - J0 : 0u];
-                        const uint32_t cid = iv ? c0 + src : 0xFFFFFF00u + l;       // lanes without an item: segments of their own
-                        int32_t v = (int32_t)bnd - (int32_t)k;                      // u_k
-                        if (k == 1) v = v > (int32_t)a_c ? v : (int32_t)a_c;        // u_0 = t_0 = the contig's first anchor
-                        if (l == 0 && cid == carry_cid) v = v > carry_uu ? v : carry_uu;   // the contig continues from the previous batch
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {                          // running maximum within the contig
-                            const int32_t tv = __shfl_up(v, d, 64); const uint32_t tc = __shfl_up(cid, d, 64);
-                            if (l >= (uint32_t)d && tc == cid) v = tv > v ? tv : v;
-                        }
-                        const uint32_t t = (uint32_t)(v + (int32_t)k);              // t_k (may run past e: the chunk is then cut at e)
-                        uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
-                        if (l == 0) { t_prev = carry_t; s_prev = carry_s; }
-                        if (k == 1) { t_prev = a_c; s_prev = r_c; }
-                        const bool valid = iv && t_prev < e_c;                      // chunk k exists
-                        Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cs; ck.qctg = c0 + src;
-                        if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
-                        const unsigned long long vm = __ballot(valid);
-                        const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
-                        if (valid) {
-                            if (slot < C1) { chunks[slot] = ck; chunk_pair[slot] = p; }
-                            else atomicAdd(err, 1u);
-                        }
-                        nc += (uint32_t)__popcll(vm);
-                        carry_cid = __shfl(cid, 63, 64); carry_uu = __shfl(v, 63, 64); carry_t = __shfl(t, 63, 64); carry_s = __shfl(sb, 63, 64);
-                    }
+                for (int d = 1; d < 64; d <<= 1) {                                  // running maximum within the contig
+                    const int32_t tv = __shfl_up(v, d, 64); const uint32_t tc = __shfl_up(cid, d, 64);
+                    if (l >= (uint32_t)d && tc == cid) v = tv > v ? tv : v;
                 }
-                __syncthreads();                                                    // the item arrays are rewritten by the next round
+                const uint32_t t = (uint32_t)(v + (int32_t)k);                      // t_k (may run past e: the chunk is then cut at e)
+                uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
+                if (l == 0) { t_prev = carry_t; s_prev = carry_s; }
+                if (k == 1) { t_prev = a_c; s_prev = r_c; }
+                const bool valid = iv && t_prev < e_c;                              // chunk k exists
+                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cs; ck.qctg = c0 + (uint32_t)src;
+                if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
+                const unsigned long long vm = __ballot(valid);
+                const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
+                if (valid) {
+                    if (slot < C1) { chunks[slot] = ck; chunk_pair[slot] = p; }
+                    else atomicAdd(err, 1u);
+                }
+                nc += (uint32_t)__popcll(vm);
+                carry_cid = __shfl(cid, 63, 64); carry_uu = __shfl(v, 63, 64); carry_t = __shfl(t, 63, 64); carry_s = __shfl(sb, 63, 64);
             }
-            __syncthreads();                                                        // (M has been read by every wave before the next round's table is written)
         }
     }
-    if (w == 0) {
-        const uint32_t used = nc < C1 - C0 ? nc : C1 - C0;
-        for (uint32_t s = C0 + used + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0, 0, 0}; chunk_pair[s] = p; }
-        if (l == 0) n_chunks[p] = used;
-    }
+    const uint32_t used = nc < C1 - C0 ? nc : C1 - C0;
+    for (uint32_t s = C0 + used + l; s < C1; s += 64) { chunks[s] = Chunk{0, 0, 0, 0, 0, 0}; chunk_pair[s] = p; }
+    if (l == 0) n_chunks[p] = used;
 }
 
 // Per-component argmax record kept at the component's ROOT anchor: score (24 bits) | index of the best anchor inside its

@@ -98,7 +98,6 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
     Interval c_next = iv[ci_next];
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t s = base + l;
-        const bool have = s < n;
         const uint32_t ci = ci_next;
         const Interval c = c_next;
         if (base + 64 < n) { ci_next = s + 64 < n ? idx[s + 64] : 0; c_next = iv[ci_next]; }

@@ -325,7 +325,6 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
     for (uint32_t x = tid; x < TAB_SLICE / TAB_FILTER_HOMES; x += TABLE_THREADS) gbm[x] = lbm[x];   // the whole slice's words (zero beyond its home slots): the filter needs no clearing beforehand
 }
 
-static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) b++; return b; }
 
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc) {
     if (!n || (!pos && !cc)) return;
