@@ -568,8 +568,24 @@ def main():
     if chain_s > 0 and chained:
         chain_bytes = 12.0 * 2.0 * (total_bases_local / max(n_local, 1) / C) * (chained / world)
         out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
-                                 "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes,
-                                 "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in the latest profiles/r*_pmc_*.md"}
+                                 "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes, "traffic": None,
+                                 "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in profiles/r03_pmc.md"}
+        # measured HBM bytes of the stage per step (separate rocprofv3 --pmc passes, tools/make_chain_traffic.py), quoted while the chaining sources are unchanged
+        cpath = os.path.join(ROOT, "profiles", "chain_traffic.json")
+        if os.path.exists(cpath) and world == 1 and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
+            try:
+                import hashlib
+                cj = json.load(open(cpath))
+                srcs = sorted(f for f in os.listdir(os.path.join(ROOT, "skani_amd", "csrc")) if f.startswith("chain"))
+                sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "skani_amd", "csrc", f), "rb").read() for f in srcs)).hexdigest()[:16]
+                if cj.get("chain_sources_sha256_16") == sha:
+                    out["roofline_chain"]["traffic"] = cj["hbm_bytes_per_step"]
+                    out["roofline_chain"]["traffic_over_algorithmic"] = cj["hbm_bytes_per_step"] / chain_bytes
+                    out["roofline_chain"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s, %s" % (cj.get("commit"), cj.get("rule"))
+                else:
+                    out["roofline_chain"]["traffic_source"] = "profiles/chain_traffic.json was measured on other chaining sources: not quoted"
+            except Exception as e:
+                out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
     if host_genomes:
         out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total)
         if not args.no_e2e:

@@ -273,8 +273,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 check_launch("interval_emit");
             }
         }
-#define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, (np + 1) / 2, 128, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
-                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
+#define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, np, 64, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
+                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, ctx->tune.greedy_len_limit, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
         tr.mark("dp (+order sort)");
         uint32_t* g_keys = ctx->arena.get<uint32_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
         SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);

@@ -11,24 +11,30 @@ __device__ __forceinline__ int ivl_cmp(const Interval& a, const Interval& b) {  
 }
 
 constexpr uint32_t GREEDY_LDS = 2048;   // sorted-index slots per wave kept in LDS by the fallback kernel
-constexpr uint32_t GREEDY_FAST = 1024;  // pairs with at most this many candidate intervals take the all-LDS kernel
+constexpr uint32_t GREEDY_FAST = 1023;  // pairs with at most this many candidate intervals take the all-LDS kernel (its 10-bit links keep 1023 for "none")
+constexpr uint32_t GREEDY_REDO = 0xFFFFFFFFu;   // n_accepted value by which the all-LDS kernel hands a pair over to greedy_kernel
 
-// Fast path (n <= GREEDY_FAST candidates): one wave per pair, two waves per workgroup, everything staged in LDS.
+// Fast path (n <= GREEDY_FAST candidates): ONE WAVE PER PAIR AND WORKGROUP, everything staged in LDS.
 //   1. bitonic sort of (key, index) with key = score(24) | anchors(20) | top 20 bits of q0; key ties (rare) fall back to
 //      the full tuple comparison -> the reference's descending order (chain.rs:1012);
 //   2. greedy acceptance 64 candidates at a time: every lane owns one candidate and sums its overlaps against the
 //      accepted list (uniform LDS broadcasts, no reductions); the 64 decisions are then resolved in order, an accepted
 //      candidate's interval being broadcast (v_readlane) to the later lanes of the same batch (chain.rs:1017-1095).
-//   LDS per wave is 36 B x CAP; the kernel is instantiated for CAP = 256 / 512 / 1024 and a pair runs in the smallest one that
-//   holds it, so that typical pairs (a few hundred candidates) leave room for 2-3 waves per SIMD: the greedy loop is a chain
-//   of dependent instructions, and other waves are the only thing that can fill its issue slots.
+//   The greedy loop is a chain of dependent instructions, and other waves are the only thing that can fill its issue slots: what the kernel costs is
+//   set by how many pairs are resident, i.e. by LDS per pair.  Round 3: an accepted interval takes 24 bytes (was 32: lengths instead of end points in
+//   16 bits each, the chunk instead of the query contig -- intervals of different chunks never overlap on the query axis --, three 10-bit links and the
+//   candidate's number in one word each), the sorted order 2 bytes per candidate (was 4), one wave per workgroup: 14 KB for the 512 class instead of
+//   19 KB per wave -> 2.75 instead of 2 waves per SIMD.  A pair with an interval that does not fit the 16-bit fields (a chain spanning 64 kb of the
+//   reference, a 65,536th chunk) is handed to greedy_kernel (GREEDY_REDO).
+//   The kernel is instantiated for CAP = 256 / 512 / 1024 and a pair runs in the smallest one that holds it.
 //   Pairs are handed out by decreasing candidate count (greedy_order_keys_kernel + a 16-bit radix sort): the kernel ends when its
 //   slowest wave does, so the long ones start first.
-// Accepted interval, 32 B (two 16-byte LDS reads), threaded on up to three lists: the accepted intervals of its chunk (query axis) and
+// Accepted interval, 24 B, threaded on up to three lists: the accepted intervals of its chunk (query axis) and
 // those of the one or two GREEDY_BIN-sized bins of the reference axis it touches (intervals spanning more go on a separate short list)
-struct AccIvl { uint32_t rctg, r0, r1, qctg, q0, q1; uint16_t qnext, rnext0, rnext1, cand; };   // cand = the interval's index among the pair's candidates
+struct AccIvl { uint32_t rctg, r0, q0, lens /* r1 - r0 | (q1 - q0) << 16 */, cc /* chunk | candidate << 16 */, links /* qnext | rnext0 << 10 | rnext1 << 20 */; };
+constexpr uint32_t GREEDY_NIL = 0x3FFu;         // "no entry" in the 10-bit links and in the list heads
 constexpr uint32_t GREEDY_BIN_SHIFT = 15;       // 32 kb reference bins: a chain interval of a 20 kb chunk touches one or two
-constexpr uint32_t GREEDY_BUCKETS = 256;        // list heads per axis (hashed chunk id / hashed (contig, bin)); 1 KB per wave keeps four workgroups of the 512 class on a CU
+constexpr uint32_t GREEDY_BUCKETS = 256;        // list heads per axis (hashed chunk id / hashed (contig, bin))
 constexpr uint32_t GREEDY_LONG = 64;            // accepted intervals spanning more than two bins (beyond that: every candidate scans the whole list)
 __device__ __forceinline__ uint32_t greedy_rhash(uint32_t rctg, uint32_t bin) { return (rctg * 37u + bin) & (GREEDY_BUCKETS - 1u); }
 // heads[bucket] <- value, returns the previous head; the 16-bit heads are exchanged through a compare-and-swap on their 32-bit word
@@ -46,28 +52,32 @@ __global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs
     keys[p] = 0xFFFFu - (n > 0xFFFFu ? 0xFFFFu : n); vals[p] = p;
 }
 template <uint32_t CAP>
-__global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
-                                                          const Interval* ivls, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
-    __shared__ uint32_t lds_idx[2][CAP];
-    __shared__ __attribute__((aligned(16))) AccIvl lds_acc[2][CAP];   // accepted intervals; the sort keys (8 B each) borrow this space first
-    __shared__ __attribute__((aligned(4))) uint16_t lds_qh[2][GREEDY_BUCKETS], lds_rh[2][GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
-    __shared__ uint16_t lds_long[2][GREEDY_LONG];
-    const uint32_t wv = threadIdx.x >> 6;
-    if (blockIdx.x * 2 + wv >= n_pairs) return;
-    const uint32_t p = order[blockIdx.x * 2 + wv];
+__global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                         const Interval* ivls, uint32_t len_limit, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    __shared__ __attribute__((aligned(16))) AccIvl acc[CAP];          // accepted intervals; the sort keys (8 B each) borrow this space first
+    __shared__ uint16_t idx[CAP];                                     // the candidates in sorted order
+    __shared__ __attribute__((aligned(4))) uint16_t qh[GREEDY_BUCKETS], rh[GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
+    __shared__ uint16_t lng[GREEDY_LONG];
+    if (blockIdx.x >= n_pairs) return;
+    const uint32_t p = order[blockIdx.x];
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
-    if (n > CAP || (CAP > 256 && n <= CAP / 2)) return;                              // another instantiation's (or greedy_kernel's) pair
+    if (n > GREEDY_FAST || n > CAP || (CAP > 256 && n <= CAP / 2)) return;          // another instantiation's (or greedy_kernel's) pair
     if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
     uint32_t N = 1; while (N < n) N <<= 1;
-    unsigned long long* key = (unsigned long long*)lds_acc[wv]; uint32_t* idx = lds_idx[wv];
+    unsigned long long* key = (unsigned long long*)acc;
     const Interval* iv = ivls + I0;
+    bool wide_field = false;                                                        // an interval that does not fit the packed record
     for (uint32_t i = l; i < N; i += 64) {
-        unsigned long long kx = 0; uint32_t ix = NONE;
-        if (i < n) { const Interval e = iv[i]; kx = ((unsigned long long)e.score << 40) | ((unsigned long long)(e.na & 0xFFFFFu) << 20) | (e.q0 >> 12); ix = i; }
-        key[i] = kx; idx[i] = ix;
+        unsigned long long kx = 0; uint32_t ix = 0xFFFFu;
+        if (i < n) {
+            const Interval e = iv[i]; kx = ((unsigned long long)e.score << 40) | ((unsigned long long)(e.na & 0xFFFFFu) << 20) | (e.q0 >> 12); ix = i;
+            wide_field = wide_field || e.r1 - e.r0 >= len_limit || e.q1 - e.q0 >= len_limit || e.chunk >= 0x10000u;
+        }
+        key[i] = kx; idx[i] = (uint16_t)ix;
     }
+    if (__any(wide_field)) { if (l == 0) n_accepted[p] = GREEDY_REDO; return; }
     wave_sync_mem();
     for (uint32_t k = 2; k <= N; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -80,16 +90,14 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                 const uint32_t f = up ? b : a, s2 = up ? a : b;
                 const unsigned long long kf = up ? kb : ka, ks = up ? ka : kb;
                 bool sw;
-                if (f == NONE) sw = false; else if (s2 == NONE) sw = true;
+                if (f == 0xFFFFu) sw = false; else if (s2 == 0xFFFFu) sw = true;
                 else if (kf != ks) sw = kf > ks; else sw = ivl_cmp(iv[f], iv[s2]) > 0;
-                if (sw) { idx[i] = b; idx[x] = a; key[i] = kb; key[x] = ka; }
+                if (sw) { idx[i] = (uint16_t)b; idx[x] = (uint16_t)a; key[i] = kb; key[x] = ka; }
             }
             wave_sync_mem();
         }
     }
-    AccIvl* acc = lds_acc[wv];
-    uint16_t* qh = lds_qh[wv]; uint16_t* rh = lds_rh[wv]; uint16_t* lng = lds_long[wv];
-    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = 0xFFFFu; rh[i] = 0xFFFFu; }
+    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = (uint16_t)GREEDY_NIL; rh[i] = (uint16_t)GREEDY_NIL; }
     wave_sync_mem();
     uint32_t nacc = 0, nlong = 0;
     bool long_overflow = false;                                                     // more than GREEDY_LONG wide intervals: fall back to scanning everything
@@ -103,13 +111,15 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
         if (base + 64 < n) { ci_next = s + 64 < n ? idx[s + 64] : 0; c_next = iv[ci_next]; }
         uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
         auto add_r = [&](const AccIvl& a) {                                        // chain.rs:1030-1045
-            const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a.r1;
-            const uint32_t xr = c.r1 - a.r0, yr = a.r1 - c.r0;
+            const uint32_t a_r1 = a.r0 + (a.lens & 0xFFFFu);
+            const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a_r1;
+            const uint32_t xr = c.r1 - a.r0, yr = a_r1 - c.r0;
             cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
         };
-        auto add_q = [&](const AccIvl& a) {                                        // chain.rs:1059-1073
-            const bool hq = a.qctg == c.qctg && a.q0 < c.q1 && c.q0 < a.q1;
-            const uint32_t xq = c.q1 - a.q0, yq = a.q1 - c.q0;
+        auto add_q = [&](const AccIvl& a) {                                        // chain.rs:1059-1073; same chunk <=> the only accepted intervals that can overlap on this axis
+            const uint32_t a_q1 = a.q0 + (a.lens >> 16);
+            const bool hq = (a.cc & 0xFFFFu) == c.chunk && a.q0 < c.q1 && c.q0 < a_q1;
+            const uint32_t xq = c.q1 - a.q0, yq = a_q1 - c.q0;
             cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
         };
         if (long_overflow) {
@@ -118,17 +128,17 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
             // Accepted intervals that can overlap this candidate: on the query axis those of its own chunk (chunks are disjoint ranges of one
             // contig), on the reference axis those sharing a bin with it.  An interval listed in two bins is counted in the bin that holds
             // max(candidate start, interval start), a point of the overlap if there is one.
-            for (uint32_t a = qh[c.chunk & (GREEDY_BUCKETS - 1u)]; a != 0xFFFFu;) { const AccIvl e = acc[a]; add_q(e); a = e.qnext; }
+            for (uint32_t a = qh[c.chunk & (GREEDY_BUCKETS - 1u)]; a != GREEDY_NIL;) { const AccIvl e = acc[a]; add_q(e); a = e.links & GREEDY_NIL; }
             const uint32_t c0 = c.r0 >> GREEDY_BIN_SHIFT, c1 = greedy_last_bin(c.r0, c.r1);
             for (uint32_t x = c0; x <= c1; x++) {
                 const uint32_t h = greedy_rhash(c.rctg, x);
-                for (uint32_t a = rh[h]; a != 0xFFFFu;) {
+                for (uint32_t a = rh[h]; a != GREEDY_NIL;) {
                     const AccIvl e = acc[a];
                     const uint32_t e0 = e.r0 >> GREEDY_BIN_SHIFT;
                     const bool first = greedy_rhash(e.rctg, e0) == h;               // which of the interval's (at most two, consecutive) bins hangs on this head
                     const uint32_t eb = first ? e0 : e0 + 1u;
                     if (e.rctg == c.rctg && eb == x && x == (c0 > e0 ? c0 : e0)) add_r(e);
-                    a = first ? e.rnext0 : e.rnext1;
+                    a = (first ? e.links >> 10 : e.links >> 20) & GREEDY_NIL;
                 }
             }
             for (uint32_t t = 0; t < nlong; t++) add_r(acc[lng[t]]);
@@ -152,8 +162,7 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
                 const uint32_t b0 = ar0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(ar0, ar1);
                 const bool wide = b1 - b0 >= 2u;                                   // wave-uniform, like everything about the accepted interval
                 if (l == 0) {                                                      // stores only: nothing in this loop waits for LDS
-                    acc[nacc] = AccIvl{actg, ar0, ar1, aqc, aq0, aq1, (uint16_t)(bchunk & (GREEDY_BUCKETS - 1u)) /* its query-axis list, until it is linked */,
-                                       0xFFFFu, 0xFFFFu, (uint16_t)bci};
+                    acc[nacc] = AccIvl{actg, ar0, aq0, (ar1 - ar0) | ((aq1 - aq0) << 16), bchunk | (bci << 16), GREEDY_NIL | (GREEDY_NIL << 10) | (GREEDY_NIL << 20)};
                     if (wide && nlong < GREEDY_LONG) lng[nlong] = (uint16_t)nacc;
                 }
                 if (wide) { if (nlong < GREEDY_LONG) nlong++; else long_overflow = true; }
@@ -164,12 +173,14 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
         // link this batch's accepted intervals into the lists, one per lane (the lists' order is free)
         if (nacc0 + l < nacc) {
             AccIvl* e = &acc[nacc0 + l];
-            e->qnext = (uint16_t)greedy_push(qh, e->qnext, nacc0 + l);
-            const uint32_t b0 = e->r0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(e->r0, e->r1);
+            const uint32_t r1 = e->r0 + (e->lens & 0xFFFFu);
+            uint32_t links = greedy_push(qh, e->cc & (GREEDY_BUCKETS - 1u), nacc0 + l) | (GREEDY_NIL << 10) | (GREEDY_NIL << 20);
+            const uint32_t b0 = e->r0 >> GREEDY_BIN_SHIFT, b1 = greedy_last_bin(e->r0, r1);
             if (b1 - b0 < 2u) {
-                e->rnext0 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b0), nacc0 + l);
-                if (b1 > b0) e->rnext1 = (uint16_t)greedy_push(rh, greedy_rhash(e->rctg, b1), nacc0 + l);
+                links = (links & ~(GREEDY_NIL << 10)) | (greedy_push(rh, greedy_rhash(e->rctg, b0), nacc0 + l) << 10);
+                if (b1 > b0) links = (links & ~(GREEDY_NIL << 20)) | (greedy_push(rh, greedy_rhash(e->rctg, b1), nacc0 + l) << 20);
             }
+            e->links = links;
         }
         wave_sync_mem();
     }
@@ -177,14 +188,14 @@ __global__ __launch_bounds__(128) void greedy_fast_kernel(uint32_t n_pairs, cons
     // summed over (chunk_stats_kernel), so their order is free -- and a push from inside the loop above would put a global-memory round trip
     // (read the chunk's head) into every one of the ~400 sequential steps of a pair
     for (uint32_t a = l; a < nacc; a += 64) {
-        const uint32_t bci = acc[a].cand;
-        const uint32_t slot = pc0[p] + iv[bci].chunk;
+        const uint32_t cc = acc[a].cc, bci = cc >> 16;
+        const uint32_t slot = pc0[p] + (cc & 0xFFFFu);
         ivl_next[I0 + bci] = atomicExch(&chunk_head[slot], I0 + bci);
     }
     if (l == 0) n_accepted[p] = nacc;
 }
 
-// Fallback for pairs with more than GREEDY_FAST candidate intervals: one wave per pair: bitonic-sort the pair's candidate
+// Fallback for pairs with more than GREEDY_FAST candidate intervals, and for those the fast kernel handed over: one wave per pair: bitonic-sort the pair's candidate
 // interval indices into DESCENDING tuple order (chain.rs:1012), then accept greedily (chain.rs:1017-1095).  An accepted
 // interval is flagged in bit 31 of its sorted slot and pushed on its chunk's list.
 __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
-    if (n <= GREEDY_FAST) return;                                                   // handled by greedy_fast_kernel
+    if (n <= GREEDY_FAST && n_accepted[p] != GREEDY_REDO) return;                   // done by greedy_fast_kernel (which writes n_accepted for every pair it is given)
     uint32_t N = 1; while (N < n) N <<= 1;                                          // ps0 reserves pow2(cap) >= N slots per pair
     uint32_t* idx = N <= GREEDY_LDS ? lds_idx[wv] : sorted_glob + ps0[p];
     const Interval* iv = ivls + I0;

@@ -61,6 +61,7 @@ struct skh_tunables {
     uint32_t build_slice_max = 0;                       // table slices per genome the slice-list kernel handles (0 = 8192; tests use 1: larger genomes' slices re-scan)
     uint32_t marker_lds_max = 0;                        // raw markers per genome the in-LDS marker-set kernel takes (0 = 8192; tests use few to force the device-wide path)
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
+    uint32_t greedy_len_limit = 0x10000;               // chain intervals at least this long on either axis send their pair to the general selection kernel (tests use a small value to drive that hand-over)
     uint32_t dist_fail = 0;                             // tests: the n-th local phase of a distributed triangle fails on this rank (0 = never)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
 };

@@ -49,6 +49,7 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_BUILD_SLICE_MAX", "1")                 # genomes with more than one table slice: no slice lists, the slices re-scan the genome
     monkeypatch.setenv("SKH_TUNE_MARKER_LDS_MAX", "40")                 # genomes with more than 40 raw markers: marker sets by the device-wide passes
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
+    monkeypatch.setenv("SKH_TUNE_GREEDY_LEN_LIMIT", "3000")             # pairs with a chain interval of 3 kb or more are handed from the all-LDS selection kernel to the general one
     c = sk.Context(0, lib=emu_lib())
     try:
         pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
