@@ -172,6 +172,19 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         catch (const std::exception& e) { local_err = e.what(); }
         catch (...) { local_err = "unknown error"; }
     };
+    auto stop_together = [&](const char* phase, int r) {                           // rank r reported a failure: every rank throws
+        device_sync_all();                                                          // nothing queued may outlive the buffers the unwinding frees
+        if (r == me) throw Error(std::string("distributed triangle, ") + phase + ": " + local_err);
+        throw Error(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
+    };
+    // a count every rank contributes anyway + its status in ONE small all-gather (where a phase is followed by such a gather the agreement is free)
+    auto gather_count_and_status = [&](uint64_t my_count, std::vector<uint64_t>& counts, const char* phase) {
+        uint64_t mine2[2] = {my_count, local_err.empty() ? 0ull : 1ull}; std::vector<uint64_t> all((size_t)W * 2);
+        T.all_gather(ctx, mine2, all.data(), sizeof(mine2), false);
+        counts.resize(W);
+        for (int r = 0; r < W; r++) counts[r] = all[(size_t)r * 2];
+        for (int r = 0; r < W; r++) if (all[(size_t)r * 2 + 1]) stop_together(phase, r);
+    };
     auto agree = [&](const char* phase) {
         uint64_t mine_ok = local_err.empty() ? 0 : 1; std::vector<uint64_t> all(W);
         T.all_gather(ctx, &mine_ok, all.data(), 8, false);
@@ -200,12 +213,24 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     const uint32_t N = (uint32_t)N64;
     st.n_genomes_total = N;
     constexpr uint32_t GF = 5;                                                      // per genome: seed positions, markers, contigs, total length, rank
-    std::vector<uint64_t> gm_mine((size_t)std::max<uint64_t>(max_n, 1) * GF, 0), gm_all((size_t)W * gm_mine.size());
+    // (one more word behind the per-genome fields: this rank's status after preparing its marker buffers below -- the agreement rides on this gather)
+    std::vector<uint64_t> gm_mine((size_t)std::max<uint64_t>(max_n, 1) * GF + 1, 0), gm_all((size_t)W * gm_mine.size());
     for (uint32_t g = 0; g < nL; g++) {
         gm_mine[g * GF + 0] = L->pos_off[g + 1] - L->pos_off[g]; gm_mine[g * GF + 1] = L->mk_off[g + 1] - L->mk_off[g];
         gm_mine[g * GF + 2] = L->ctg_off[g + 1] - L->ctg_off[g]; gm_mine[g * GF + 3] = L->total_len[g]; gm_mine[g * GF + 4] = L->rank[g];
     }
+    // this rank's marker set, padded, in the staging buffers of the marker all-gather further down; how that went travels with the table
+    const uint64_t pad = std::max<uint64_t>(max_m, 1);
+    uint64_t *d_send = nullptr, *d_recv = nullptr;
+    local([&] {                                                                     // (local phase 1)
+        d_send = ctx->arena.get<uint64_t>(pad); d_recv = ctx->arena.get<uint64_t>(pad * W);
+        if (mine[2]) d2d(d_send, L->markers.p, mine[2] * 8, ctx->stream);
+        if (pad > mine[2]) dzero(d_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
+        dsync(ctx->stream);
+    });
+    gm_mine.back() = local_err.empty() ? 0 : 1;
     T.all_gather(ctx, gm_mine.data(), gm_all.data(), gm_mine.size() * 8, false);
+    for (int r = 0; r < W; r++) if (gm_all[(size_t)(r + 1) * gm_mine.size() - 1]) stop_together("marker buffers", r);
     std::vector<uint32_t> cl_mine(std::max<uint64_t>(max_c, 1), 0), cl_all((size_t)W * cl_mine.size());
     std::copy(L->ctg_len.begin(), L->ctg_len.end(), cl_mine.begin());
     T.all_gather(ctx, cl_mine.data(), cl_all.data(), cl_mine.size() * 4, false);
@@ -228,18 +253,9 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     S.mk_off.assign(N + 1, 0); for (uint32_t g = 0; g < N; g++) S.mk_off[g + 1] = S.mk_off[g] + g_nmk[g];
     const uint64_t MT = S.mk_off[N];
     {
-        const uint64_t pad = std::max<uint64_t>(max_m, 1);
-        uint64_t *d_send = nullptr, *d_recv = nullptr;
-        local([&] {
-            S.markers.alloc(MT ? MT : 1);
-            d_send = ctx->arena.get<uint64_t>(pad); d_recv = ctx->arena.get<uint64_t>(pad * W);
-            if (mine[2]) d2d(d_send, L->markers.p, mine[2] * 8, ctx->stream);
-            if (pad > mine[2]) dzero(d_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
-            dsync(ctx->stream);
-        });
-        agree("marker buffers");
         T.all_gather(ctx, d_send, d_recv, pad * 8, true);
-        local([&] {
+        local([&] {                                                                 // (local phase 2; agreed on with the candidate counts)
+            S.markers.alloc(MT ? MT : 1);
             for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
             S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
             dsync(ctx->stream);
@@ -270,9 +286,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     tr.mark("dist: screen rows");
     // ---- 4. the candidate list, everywhere (host memory; sorted by (i, j) because the row blocks ascend with the rank)
     ex_begin();
-    agree("screen");
     uint64_t my_np = my_i.size(); std::vector<uint64_t> np_all(W);
-    T.all_gather(ctx, &my_np, np_all.data(), 8, false);
+    gather_count_and_status(my_np, np_all, "marker sets / screen");
     uint64_t max_np = 1, NP64 = 0; for (int r = 0; r < W; r++) { max_np = std::max(max_np, np_all[r]); NP64 += np_all[r]; }
     std::vector<uint32_t> pi, pj;
     {
@@ -408,9 +423,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::vector<Row> rows;
     for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
     ex_begin();
-    agree("seed tables / chaining");
     uint64_t my_rows = rows.size(); std::vector<uint64_t> rows_all(W);
-    T.all_gather(ctx, &my_rows, rows_all.data(), 8, false);
+    gather_count_and_status(my_rows, rows_all, "seed tables / chaining");
     uint64_t max_rows = 1, tot_rows = 0; for (int r = 0; r < W; r++) { max_rows = std::max(max_rows, rows_all[r]); tot_rows += rows_all[r]; }
     std::vector<Row> sendr(max_rows), recvr((size_t)W * max_rows);
     memset((void*)sendr.data(), 0, sendr.size() * sizeof(Row));
