@@ -130,6 +130,11 @@ int skh_sketch_set_names(skh_sketch_set*, const char* const* names);
 
 /* sizes */
 uint32_t skh_sketch_n_genomes(const skh_sketch_set*);
+/* 1 when the set holds a genome of 2^31 - 8192 or more padded bases (total length + 8192 per contig; a human genome, say): the set then keeps 64-bit
+ * coordinates beside its 32-bit position records, and every chaining run it takes part in -- with itself or with ordinary sets -- works on 64-bit
+ * coordinates (chain.hip "Wide").  Same results, same entry points; contigs stay below 2^32 bases and genomes below 2^30 seed positions, as in the
+ * reference's u32 fields (types.rs:131-138).  Not exchanged between ranks: skh_triangle_distributed refuses such a set on every rank. */
+int skh_sketch_is_wide(const skh_sketch_set*);
 int skh_sketch_sizes(const skh_sketch_set*, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers,
                      uint32_t* n_contigs, uint64_t* total_len);
 /* flat export for serialisation / exchange between GPUs / parity checks.  Arrays are caller-allocated from

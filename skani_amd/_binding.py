@@ -46,7 +46,7 @@ class HostCollectives(C.Structure):
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
            "skh_host_alloc", "skh_host_free", "skh_genomes_begin", "skh_genomes_append", "skh_genomes_wait", "skh_genomes_finish",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
-           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
+           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_is_wide", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
            "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_triangle_distributed", "skh_plan_pairs"]
 RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
 
@@ -76,6 +76,7 @@ def load(path):
     L.skh_sketch_set_destroy.restype = None; L.skh_sketch_set_destroy.argtypes = [vp]
     L.skh_sketch_set_names.restype = i32; L.skh_sketch_set_names.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.skh_sketch_n_genomes.restype = u32; L.skh_sketch_n_genomes.argtypes = [vp]
+    L.skh_sketch_is_wide.restype = C.c_int; L.skh_sketch_is_wide.argtypes = [vp]
     L.skh_sketch_sizes.restype = i32
     L.skh_sketch_sizes.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]
     L.skh_sketch_export.restype = i32; L.skh_sketch_export.argtypes = [vp, u32, vp, vp, vp, vp, vp]

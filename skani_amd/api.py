@@ -298,6 +298,11 @@ class SketchSet:
     def __len__(self):
         return self.ctx.L.skh_sketch_n_genomes(self.h)
 
+    @property
+    def wide(self):
+        """The set holds a genome beyond 31-bit padded coordinates and keeps 64-bit ones (include/skani_hip.h skh_sketch_is_wide)."""
+        return bool(self.ctx.L.skh_sketch_is_wide(self.h))
+
     def sizes(self, g):
         a, b, c_, d, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
         self.ctx.check(self.ctx.L.skh_sketch_sizes(self.h, g, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(e)))

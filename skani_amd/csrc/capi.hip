@@ -80,6 +80,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
+        ctx->tune.wide_span = std::min<uint64_t>(ctx->tune.wide_span, env("SKH_TUNE_WIDE_SPAN", ctx->tune.wide_span));
         ctx->tune.greedy_len_limit = (uint32_t)std::min<uint64_t>(0x10000, env("SKH_TUNE_GREEDY_LEN_LIMIT", 0x10000));
     });
     if (rc != SKH_OK) { delete ctx; return rc; }
@@ -217,11 +218,11 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             ev[2].record(ctx->stream); ev[2].wait();
             ctx->timings.seed_ms += DevEvent::ms(ev[0], ev[1]); ctx->timings.sketch_build_ms += DevEvent::ms(ev[1], ev[2]);
         };
-        seed_genomes(ctx, gs, *sp, so, true);
+        seed_genomes(ctx, gs, *sp, so, true, ss->wide);
         ev[1].record(ctx->stream);
         // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)
         struct TailGuard { bool armed = true; ~TailGuard() { if (armed) device_sync_all(); } } tail_guard;
-        ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->pos_off = so.pos_off;
+        ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->p_g64 = std::move(so.g64); ss->pos_off = so.pos_off;
         // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) and the
         // screen's sorted incidence list are built on the second stream meanwhile
         if (flags & SKH_SKETCH_DEFER_TABLES) {                                       // markers only; the tables are built where (and if) the sketches are chained
@@ -268,6 +269,7 @@ int skh_sketch_set_names(skh_sketch_set* ss, const char* const* names) {
     return guarded(ss->ctx, [&] { ss->names.resize(ss->n_genomes); for (uint32_t g = 0; g < ss->n_genomes; g++) ss->names[g] = names[g] ? names[g] : ""; });
 }
 uint32_t skh_sketch_n_genomes(const skh_sketch_set* ss) { return ss ? ss->n_genomes : 0; }
+int skh_sketch_is_wide(const skh_sketch_set* ss) { return ss && ss->wide ? 1 : 0; }
 
 int skh_sketch_sizes(const skh_sketch_set* ss, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers, uint32_t* n_contigs, uint64_t* total_len) {
     if (!ss || g >= ss->n_genomes) return SKH_ERR_INVALID;

@@ -43,6 +43,8 @@ static void genome_halves(const skh_sketch_set* S) {
         h.hash = S->p_hash.p + S->pos_off[g]; h.g = S->p_g.p + S->pos_off[g]; h.rep = S->p_rep.p;
         h.ms = S->ms.p + S->ms_off[g]; h.tab = S->tab.p + S->tab_off[g]; h.nbk = S->n_buckets[g]; h.bmap = S->bmap.p + S->bmap_off[g];
         h.goff = S->d_goff.p + S->ctg_off[g] + g; h.host_goff = S->goff.data() + S->ctg_off[g] + g;
+        h.g64 = nullptr; h.goff64 = nullptr; h.host_goff64 = nullptr;
+        if (S->wide) { h.g64 = S->p_g64.p + S->pos_off[g]; h.goff64 = S->d_goff64.p + S->ctg_off[g] + g; h.host_goff64 = S->goff64.data() + S->ctg_off[g] + g; h.goff = nullptr; h.host_goff = nullptr; }
         h.nctg = (uint32_t)(S->ctg_off[g + 1] - S->ctg_off[g]);
         h.total_len = S->total_len[g]; h.q10 = S->q10[g]; h.q50 = S->q50[g]; h.q90 = S->q90[g];
         const double cap = std::min(S->mean_ctg[g], 300000.);
@@ -54,13 +56,14 @@ static void genome_halves(const skh_sketch_set* S) {
 }
 
 // same checksum as the oracle's ora_chain_stats.anchor_checksum: (query contig, query pos, ref contig, ref pos, reverse) per anchor
-uint64_t fnv_anchors(const std::vector<uint32_t>& anc, const std::vector<uint32_t>& anc_r, size_t a0, size_t a1, const uint32_t* a_go, uint32_t a_n, const uint32_t* b_go, uint32_t b_n) {
+template <class Co, class Arr>
+uint64_t fnv_anchors(const std::vector<Co>& anc, const std::vector<Co>& anc_r, size_t a0, size_t a1, const Arr& a_go, uint32_t a_n, const Arr& b_go, uint32_t b_n) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t x) { h ^= x; h *= 1099511628211ull; };
     for (size_t i = a0; i < a1; i++) {
-        const uint32_t gq = anc[i], gr = anc_r[i] >> 1, rev = anc_r[i] & 1u;
+        const Co gq = anc[i], gr = anc_r[i] >> 1; const uint32_t rev = (uint32_t)(anc_r[i] & 1u);
         const uint32_t qc = ctg_of(a_go, a_n, gq), rc = ctg_of(b_go, b_n, gr);
-        mix(qc); mix(gq - a_go[qc]); mix(rc); mix(gr - b_go[rc]); mix(rev);
+        mix(qc); mix((uint32_t)(gq - a_go[qc])); mix(rc); mix((uint32_t)(gr - b_go[rc])); mix(rev);
     }
     return h;
 }
@@ -105,10 +108,26 @@ static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const PairDesc* 
     return d_slots;
 }
 
+// Wide runs: the join's anchors (32-bit records: a coordinate, or -- on the side of a wide set -- a position index) -> 64-bit coordinates.
+// One thread per anchor; its pair by a search in the batch's anchor prefix.
+__global__ __launch_bounds__(256) void widen_anchors_kernel(uint32_t n_anchors, uint32_t n_pairs, const uint32_t* pa0, const WidePair* wide, const uint32_t* anc_q32, const uint32_t* anc_r32,
+                                                            uint64_t* anc_q, uint64_t* anc_r) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_anchors) return;
+    uint32_t lo = 0, hi = n_pairs;                                                  // largest p with pa0[p] <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pa0[mid] <= i) lo = mid; else hi = mid; }
+    const WidePair wp = wide[lo];
+    const uint32_t q = anc_q32[i], r = anc_r32[i];
+    anc_q[i] = wp.a_is_index ? wp.a_g[q] >> 1 : (uint64_t)q;
+    anc_r[i] = wp.b_g64 ? (wp.b_g64[r >> 1] & ~1ull) | (r & 1u) : (uint64_t)r;
+}
+
 namespace {
 
 struct ChainJob {                                        // what one run over a list of pairs needs (chain_pairs fills it)
     PairDesc* pds = nullptr; uint32_t n_pairs = 0;       // in the context's pinned buffer: copied to the device as they are
+    std::vector<WidePair> wps;                           // a run with a wide sketch set: one per pair
+    std::vector<CoArr> host_go_a64, host_go_b64;         //   (host tables for the stats' checksum)
     std::vector<uint32_t> chunk_bound, pair_key;
     std::vector<const uint32_t*> host_go_a, host_go_b;   // only with stats
     uint32_t c = 0, k = 0, band = 0;
@@ -116,8 +135,10 @@ struct ChainJob {                                        // what one run over a 
     skh_map_params mp{};
 };
 
-// Runs the chaining pipeline over all pairs of the job.
+// Runs the chaining pipeline over all pairs of the job.  W: the run's coordinate width (chain_types.h).
+template <class W>
 void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats* stats) {
+    using Co = typename W::Co;
     // (A join that walks all tiles of a pair in one workgroup and writes the anchors in one pass -- no probe records, no pair counts on the host -- was
     //  built and measured in round 2: 4.7 ms against 3.4 ms for count + fill; long-lived workgroups hide the probe latency worse.  DESIGN.md section 5.)
     PairDesc* pds = job.pds;
@@ -134,6 +155,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = ctx->arena.get<PairDesc>(NP ? NP : 1);
     h2d(d_pairs_all, pds, (size_t)NP * sizeof(PairDesc), ctx->stream);
+    const WidePair* d_wide_all = nullptr;
+    if (W::wide) d_wide_all = upload(ctx, job.wps);
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
     uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
     uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_hits = ctx->arena.get<uint32_t>((size_t)NT + 1);
@@ -198,8 +221,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         // (a host loop over the pairs + four uploads, ~0.1 ms) are made while it runs
         const uint32_t NA = (uint32_t)na;
         const uint32_t t0 = pds[p0].tile0, t1 = p1 < NP ? pds[p1].tile0 : NT, nt = t1 - t0;
-        const PairDesc* d_pairs = d_pairs_all + p0;
-        uint32_t* anc_q = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r = ctx->arena.get<uint32_t>((size_t)NA + 16);
+        const PairDesc* d_pairs = d_pairs_all + p0; const WidePair* d_wide = W::wide ? d_wide_all + p0 : nullptr;
+        uint32_t* anc_q32 = ctx->arena.get<uint32_t>((size_t)NA + 16); uint32_t* anc_r32 = ctx->arena.get<uint32_t>((size_t)NA + 16);   // what the join writes
         uint32_t* toff_a = toff_super;
         if (t0 != st0 || t1 != st1) { toff_a = ctx->arena.get<uint32_t>(nt + 1); exclusive_scan_u32(ctx, tile_anch + t0, nt, toff_a); }
         tr.mark("tile scan");
@@ -207,7 +230,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
             if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
             SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
-                       t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q, anc_r);
+                       t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q32, anc_r32);
             check_launch("join_fill");
         }
         // per-pair prefix arrays (batch-relative): anchors, chunks, candidate intervals, global sort scratch of the fallback selection kernel
@@ -226,19 +249,29 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         memcpy(pfx.data() + 2 * ((size_t)np + 1), pi0.data(), ((size_t)np + 1) * 4); memcpy(pfx.data() + 3 * ((size_t)np + 1), ps0.data(), ((size_t)np + 1) * 4);
         uint32_t* d_pa0 = upload(ctx, pfx); uint32_t* d_pc0 = d_pa0 + (np + 1); uint32_t* d_pi0 = d_pc0 + (np + 1); uint32_t* d_ps0 = d_pi0 + (np + 1);
         tr.mark("join_fill (+slots)");
+        Co *anc_q, *anc_r;
+        if constexpr (W::wide) {
+            anc_q = ctx->arena.get<uint64_t>((size_t)NA + 16); anc_r = ctx->arena.get<uint64_t>((size_t)NA + 16);
+            if (NA) {
+                SKH_LAUNCH(widen_anchors_kernel, (NA + 255) / 256, 256, 0, ctx->stream, NA, np, (const uint32_t*)d_pa0, d_wide, (const uint32_t*)anc_q32, (const uint32_t*)anc_r32, anc_q, anc_r);
+                check_launch("widen_anchors");
+            }
+        } else { anc_q = anc_q32; anc_r = anc_r32; }
         Chunk* chunks = ctx->arena.get<Chunk>(NC + 1); uint32_t* chunk_pair = ctx->arena.get<uint32_t>(NC + 1);
         uint32_t* n_chunks = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(chunk_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, (const uint32_t*)d_pa0, (const uint32_t*)(d_pair_anch + p0),
-                   (const uint32_t*)d_pc0, (const uint32_t*)anc_q, chunks, chunk_pair, n_chunks, d_err);
+        SKH_LAUNCH(chunk_kernel<W>, (np + 3) / 4, 256, 0, ctx->stream, np, d_pairs, d_wide, (const uint32_t*)d_pa0, (const uint32_t*)(d_pair_anch + p0),
+                   (const uint32_t*)d_pc0, (const Co*)anc_q, chunks, chunk_pair, n_chunks, d_err);
         check_launch("chunk");
         tr.mark("chunk");
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
-        const EmitCtx ec{anc_q, anc_r, d_pairs, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
+        const EmitCtxT<W> ec{anc_q, anc_r, d_pairs, d_wide, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
-            if (band <= 84) {   // fused thread-per-chunk chaining + interval emission
+            bool chained = false;
+            if constexpr (!W::wide) if (band <= 84) {   // fused thread-per-chunk chaining + interval emission (32-bit coordinates only)
+                chained = true;
                 constexpr int T = 64;
                 const unsigned gt = (NC + T - 1) / T;
                 const uint32_t ls = ctx->tune.chain_dp_lds_slots <= 1 ? 1u : 8u;  // 1: tests push every second live chain through the spill table (4 / 6 slots measured: 1.65 / 1.55 vs 1.53 ms)
@@ -259,16 +292,17 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
 #undef SKH_DPT
 #undef SKH_DPT2
                 check_launch("chain_dp_thread");
-            } else {            // wave-per-chunk sweep + per-anchor argmax records + emit
+            }
+            if (!chained) {     // wave-per-chunk sweep + per-anchor argmax records + emit
                 unsigned long long* best = ctx->arena.get<unsigned long long>((size_t)NA + 64);
                 dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
                 const unsigned gb = (NC + 3) / 4;
                 uint32_t* dp_state = band > 256 ? ctx->arena.get<uint32_t>(3 * (size_t)NA + 4) : nullptr;   // c < 10: earlier anchors' state goes through memory
-#define SKH_DP(PB) SKH_LAUNCH(chain_dp_kernel<PB>, gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const uint32_t*)anc_q, (const uint32_t*)anc_r, best, dp_state)
+#define SKH_DP(PB) SKH_LAUNCH((chain_dp_kernel<PB, W>), gb, 256, 0, ctx->stream, NC, (const Chunk*)chunks, band, (const Co*)anc_q, (const Co*)anc_r, best, dp_state)
                 if (band <= 64) SKH_DP(1); else if (band <= 128) SKH_DP(2); else if (band <= 192) SKH_DP(3); else if (band <= 256) SKH_DP(4); else SKH_DP(0);
 #undef SKH_DP
                 check_launch("chain_dp");
-                SKH_LAUNCH(interval_emit_kernel, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const unsigned long long*)best,
+                SKH_LAUNCH(interval_emit_kernel<W>, (NC + 3) / 4, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const unsigned long long*)best,
                            (const uint32_t*)chunk_pair, ec);
                 check_launch("interval_emit");
             }
@@ -289,8 +323,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         double* chunk_est = ctx->arena.get<double>(NC + 1); uint32_t* chunk_w = ctx->arena.get<uint32_t>(NC + 1);
         uint4* chunk_sums = ctx->arena.get<uint4>(NC + 1);
         if (NC) {
-            SKH_LAUNCH(chunk_stats_kernel, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
-                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, (const unsigned long long*)imk, c, k, chunk_est, chunk_w, chunk_sums);
+            SKH_LAUNCH(chunk_stats_kernel<W>, (NC + 255) / 256, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)chunk_head,
+                       (const uint32_t*)ivl_next, (const Interval*)ivls, d_pairs, d_wide, (const unsigned long long*)imk, c, k, chunk_est, chunk_w, chunk_sums);
             check_launch("chunk_stats");
         }
         tr.mark("chunk_stats");
@@ -311,14 +345,15 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             std::vector<uint32_t> h_nc(np), h_ni(np), h_nacc(np), h_ne(np);
             d2h(h_nc.data(), n_chunks, np * 4, ctx->stream); d2h(h_ni.data(), ivl_cnt, np * 4, ctx->stream);
             d2h(h_nacc.data(), n_acc, np * 4, ctx->stream); d2h(h_ne.data(), n_est, np * 4, ctx->stream);
-            std::vector<uint32_t> hanc((size_t)NA), hanr((size_t)NA);
-            d2h(hanc.data(), anc_q, (uint64_t)NA * 4, ctx->stream); d2h(hanr.data(), anc_r, (uint64_t)NA * 4, ctx->stream);
+            std::vector<Co> hanc((size_t)NA), hanr((size_t)NA);
+            d2h(hanc.data(), anc_q, (uint64_t)NA * sizeof(Co), ctx->stream); d2h(hanr.data(), anc_r, (uint64_t)NA * sizeof(Co), ctx->stream);
             for (uint32_t i = 0; i < np; i++) {
                 skh_chain_stats& st = stats[p0 + i];
                 const uint32_t an = std::min(pair_anch[p0 + i], pa0[i + 1] - pa0[i]);
                 st.switched = (pds[p0 + i].flags >> 2) & 1u; st.n_chunks = h_nc[i]; st.n_intervals = h_ni[i]; st.n_accepted = h_nacc[i]; st.n_estimates = h_ne[i];
                 st.reserved = 0; st.n_anchors = pair_anch[p0 + i]; st.n_qpos = pair_inq[p0 + i];
-                st.anchor_checksum = an ? fnv_anchors(hanc, hanr, pa0[i], pa0[i] + an, job.host_go_a[p0 + i], pds[p0 + i].a_nctg, job.host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
+                if constexpr (W::wide) st.anchor_checksum = an ? fnv_anchors(hanc, hanr, pa0[i], pa0[i] + an, job.host_go_a64[p0 + i], pds[p0 + i].a_nctg, job.host_go_b64[p0 + i], pds[p0 + i].b_nctg) : 0;
+                else st.anchor_checksum = an ? fnv_anchors(hanc, hanr, pa0[i], pa0[i] + an, job.host_go_a[p0 + i], pds[p0 + i].a_nctg, job.host_go_b[p0 + i], pds[p0 + i].b_nctg) : 0;
                 if (pair_anch[p0 + i] == 0) { st.switched = 1; st.n_qpos = 0; }   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
@@ -365,7 +400,12 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     for (uint32_t x = 0; x < n_qsets; x++) genome_halves(Qsets[x]);
     job.pds = (PairDesc*)ctx->pin_pairs.need((size_t)NP * sizeof(PairDesc)); job.n_pairs = NP;
     job.chunk_bound.resize(NP); job.pair_key.resize(NP);
-    if (stats) { job.host_go_a.resize(NP); job.host_go_b.resize(NP); }
+    // a run that involves a wide set (a genome beyond 31-bit coordinates) works on 64-bit coordinates from the chunking on
+    bool wide_run = false;
+    for (uint32_t x = 0; x < n_rsets; x++) wide_run = wide_run || Rsets[x]->wide;
+    for (uint32_t x = 0; x < n_qsets; x++) wide_run = wide_run || Qsets[x]->wide;
+    if (wide_run) job.wps.resize(NP);
+    if (stats) { job.host_go_a.resize(NP); job.host_go_b.resize(NP); if (wide_run) { job.host_go_a64.resize(NP); job.host_go_b64.resize(NP); } }
     for (uint32_t p = 0; p < NP; p++) {
         const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
         if (rs >= n_rsets || qs >= n_qsets) throw std::invalid_argument("pair names a sketch set that was not passed");
@@ -393,11 +433,22 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg;
         pd.a_goff = A.goff; pd.b_goff = B.goff; pd.a_nctg = A.nctg; pd.b_nctg = B.nctg;
         if (stats) { job.host_go_a[p] = A.host_goff; job.host_go_b[p] = B.host_goff; }
+        if (wide_run) {
+            const bool aw = A.g64 != nullptr, bw = B.g64 != nullptr;
+            WidePair& wp = job.wps[p];
+            wp.a_g = aw ? CoArr{A.g64, 1u} : CoArr{A.g, 0u};
+            wp.a_goff = aw ? CoArr{A.goff64, 1u} : CoArr{A.goff, 0u}; wp.b_goff = bw ? CoArr{B.goff64, 1u} : CoArr{B.goff, 0u};
+            wp.b_g64 = B.g64; wp.a_is_index = aw ? 1u : 0u; wp.pad = 0;
+            if (stats) {
+                job.host_go_a64[p] = aw ? CoArr{A.host_goff64, 1u} : CoArr{A.host_goff, 0u};
+                job.host_go_b64[p] = bw ? CoArr{B.host_goff64, 1u} : CoArr{B.host_goff, 0u};
+            }
+        }
         job.pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                        // tiles probing the same sketch share an XCD
         job.chunk_bound[p] = A.chunk_bound;
     }
     tr.mark("host: pair descriptors");
-    chain_run(ctx, job, out, stats);
+    if (wide_run) chain_run<Wide>(ctx, job, out, stats); else chain_run<Narrow>(ctx, job, out, stats);
 }
 
 }  // namespace skh

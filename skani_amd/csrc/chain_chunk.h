@@ -18,13 +18,13 @@
 // range [lo, hi) to one sample interval there (LDS round trips) and only the last log2(CHUNK_SAMPLE) probes go to memory.
 // UPPER: first index whose key is > v; otherwise first index whose key is >= v.  samp[t] = key(array[org + t * CHUNK_SAMPLE]), t < ns.
 constexpr uint32_t CHUNK_SAMPLE = 128, CHUNK_SAMPLES = 512;     // 2 x 2 KB of LDS per wave; arrays beyond 65,536 entries are searched directly
-template <bool UPPER>
-__device__ __forceinline__ void narrow_by_samples(const uint32_t* samp, uint32_t ns, uint32_t org, uint32_t v, uint32_t& lo, uint32_t& hi) {
+template <bool UPPER, class Co>
+__device__ __forceinline__ void narrow_by_samples(const Co* samp, uint32_t ns, uint32_t org, Co v, uint32_t& lo, uint32_t& hi) {
     if (lo >= hi) return;
     const uint32_t t0 = (lo - org + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE;
     uint32_t t1 = (hi - org + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE; if (t1 > ns) t1 = ns;
     uint32_t a = t0, b = t1;                                                        // first sample in [t0, t1) for which the predicate holds
-    while (a < b) { const uint32_t m = (a + b) >> 1; const uint32_t x = samp[m]; if (UPPER ? x > v : x >= v) b = m; else a = m + 1; }
+    while (a < b) { const uint32_t m = (a + b) >> 1; const Co x = samp[m]; if (UPPER ? x > v : x >= v) b = m; else a = m + 1; }
     if (a > t0) { const uint32_t f = org + (a - 1) * CHUNK_SAMPLE + 1; lo = f > lo ? f : lo; }     // sample a-1 fails: the answer lies beyond it
     if (a < t1) { const uint32_t t = org + a * CHUNK_SAMPLE; hi = t < hi ? t : hi; }               // sample a holds: the answer is at or before it
 }
@@ -33,27 +33,28 @@ __device__ __forceinline__ void narrow_by_samples(const uint32_t* samp, uint32_t
 // loads), the last step reads the remaining (up to eight) entries at once -- a range of 128 closes in three dependent round trips to memory instead of
 // seven.  The kernel is a chain of such round trips (a wave per pair, 64 searches wide): their number is what it costs.
 // arr[x][i] >> sh[x] is the key of entry i; the answer for search x is the first index in [lo, hi) whose key is > v[x] (upper[x]) or >= v[x], else hi.
-template <int N>
-__device__ __forceinline__ void search_together(const uint32_t* const (&arr)[N], const uint32_t (&sh)[N], uint32_t (&lo)[N], uint32_t (&hi)[N], const uint32_t (&v)[N],
+// (Arr: const uint32_t*, or CoArr in a Wide run -- chain_types.h; Co: the key type)
+template <int N, class Arr, class Co>
+__device__ __forceinline__ void search_together(const Arr (&arr)[N], const uint32_t (&sh)[N], uint32_t (&lo)[N], uint32_t (&hi)[N], const Co (&v)[N],
                                                 const bool (&upper)[N]) {
-    auto holds = [&](int x, uint32_t key) { return upper[x] ? key > v[x] : key >= v[x]; };
+    auto holds = [&](int x, Co key) { return upper[x] ? key > v[x] : key >= v[x]; };
     for (;;) {
         bool open = false;
 #pragma unroll
         for (int x = 0; x < N; x++) open = open || lo[x] < hi[x];
         if (__ballot(open) == 0ull) break;
-        uint32_t k[N][8];
+        Co k[N][8];
 #pragma unroll
         for (int x = 0; x < N; x++) {
             const uint32_t n = hi[x] - lo[x];
             if (lo[x] >= hi[x]) continue;
             if (n <= 8u) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) k[x][j] = j < n ? arr[x][lo[x] + j] >> sh[x] : 0u;
+                for (uint32_t j = 0; j < 8; j++) k[x][j] = j < n ? (Co)(arr[x][lo[x] + j] >> sh[x]) : (Co)0;
             } else {
                 const uint32_t q = n >> 2;
 #pragma unroll
-                for (uint32_t j = 1; j < 4; j++) k[x][j] = arr[x][lo[x] + j * q] >> sh[x];
+                for (uint32_t j = 1; j < 4; j++) k[x][j] = (Co)(arr[x][lo[x] + j * q] >> sh[x]);
             }
         }
 #pragma unroll
@@ -77,10 +78,15 @@ __device__ __forceinline__ void search_together(const uint32_t* const (&arr)[N],
 
 // (A workgroup of four waves per pair -- 256 boundary searches per round, the running maximum left to one wave -- was measured in round 3: 0.54 instead of
 //  0.45 ms.  Three of a pair's four waves then sit at barriers most of the time and take the residency of three other pairs.)
-__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const uint32_t* pa0, const uint32_t* pan,
-                                                    const uint32_t* pc0, const uint32_t* anc_q,
+template <class W>
+__global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const PairDesc* pairs, const WidePair* wide, const uint32_t* pa0, const uint32_t* pan,
+                                                    const uint32_t* pc0, const typename W::Co* anc_q,
                                                     Chunk* chunks, uint32_t* chunk_pair, uint32_t* n_chunks, uint32_t* err) {
-    __shared__ uint32_t lds_samp[4][2][CHUNK_SAMPLES];
+    using Co = typename W::Co; using Arr = typename W::Arr;
+    constexpr Co CO_MAX = ~(Co)0;
+    __shared__ Co lds_samp[4][2][CHUNK_SAMPLES];
+    Arr anc_arr;                                                                    // the anchors' query coordinates as one of the searched arrays
+    if constexpr (W::wide) anc_arr = CoArr{anc_q, 1u}; else anc_arr = anc_q;
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();
@@ -89,25 +95,25 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
     const uint32_t A0 = pa0[p], A1 = A0 + (pan[p] < pa0[p + 1] - A0 ? pan[p] : pa0[p + 1] - A0), C0 = pc0[p], C1 = pc0[p + 1];
     uint32_t nc = 0;
     if (A1 > A0) {
-        const uint32_t* go = pairs[p].a_goff;
+        const Arr go = W::a_goff(pairs[p], wide, p);
         const uint32_t nctg = pairs[p].a_nctg;
-        const uint32_t* ag = pairs[p].a_g; const uint32_t Q1 = pairs[p].a_n;         // the enumerated sketch's positions
-        const uint32_t q_pair_last = anc_q[A1 - 1];
+        const Arr ag = W::a_g(pairs[p], wide, p); const uint32_t Q1 = pairs[p].a_n;   // the enumerated sketch's positions
+        const Co q_pair_last = anc_q[A1 - 1];
         const uint32_t ns_a = (A1 - A0 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE, ns_s = (Q1 + CHUNK_SAMPLE - 1) / CHUNK_SAMPLE;
         const bool sampled = ns_a <= CHUNK_SAMPLES && ns_s <= CHUNK_SAMPLES;
-        uint32_t* sa = lds_samp[threadIdx.x >> 6][0]; uint32_t* ss = lds_samp[threadIdx.x >> 6][1];
+        Co* sa = lds_samp[threadIdx.x >> 6][0]; Co* ss = lds_samp[threadIdx.x >> 6][1];
         if (sampled) {
             for (uint32_t t = l; t < ns_a; t += 64) sa[t] = anc_q[A0 + t * CHUNK_SAMPLE];
-            for (uint32_t t = l; t < ns_s; t += 64) ss[t] = ag[t * CHUNK_SAMPLE] >> 1;
+            for (uint32_t t = l; t < ns_s; t += 64) ss[t] = (Co)(ag[t * CHUNK_SAMPLE] >> 1);
             wave_sync_mem();
         }
         uint32_t sf_lo = 0, sf_hi = Q1;
         if (sampled) narrow_by_samples<true>(ss, ns_s, 0, q_pair_last, sf_lo, sf_hi);
         uint32_t s_final;                                                           // the pair's final chunk ends its seed range here (chain.rs:794-824)
         {
-            const uint32_t* const arr[1] = {ag}; const uint32_t sh[1] = {1}; const uint32_t vv[1] = {q_pair_last}; const bool up[1] = {true};
+            const Arr arr[1] = {ag}; const uint32_t sh[1] = {1}; const Co vv[1] = {q_pair_last}; const bool up[1] = {true};
             uint32_t lo1[1] = {sf_lo}, hi1[1] = {sf_hi};
-            search_together<1>(arr, sh, lo1, hi1, vv, up);
+            search_together<1, Arr, Co>(arr, sh, lo1, hi1, vv, up);
             s_final = lo1[0];
         }
         // 64 query contigs per round, one per lane: the contig's anchor range [ca, ce), its first position rc0 and its number of end points;
@@ -116,22 +122,22 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         uint32_t carry_cid = NONE, carry_t = 0, carry_s = 0; int32_t carry_uu = 0;
         for (uint32_t c0 = 0; c0 < nctg; c0 += 64) {
             const uint32_t cl = c0 + l; const bool cv = cl < nctg;
-            const uint32_t cstart = cv ? go[cl] : 0xFFFFFFFFu, cnext = cv ? go[cl + 1] : 0xFFFFFFFFu;
+            const Co cstart = cv ? (Co)go[cl] : CO_MAX, cnext = cv ? (Co)go[cl + 1] : CO_MAX;
             uint32_t lo_a = A0, hi_a = cv ? A1 : A0, lo_e = A0, hi_e = cv ? A1 : A0, lo_r = 0, hi_r = cv ? Q1 : 0;
             if (sampled) {
                 narrow_by_samples<false>(sa, ns_a, A0, cstart, lo_a, hi_a); narrow_by_samples<false>(sa, ns_a, A0, cnext, lo_e, hi_e);
                 narrow_by_samples<false>(ss, ns_s, 0, cstart, lo_r, hi_r);
             }
             {                                                                       // the three searches advance together: their round trips overlap
-                const uint32_t* const arr[3] = {anc_q, anc_q, ag}; const uint32_t sh[3] = {0, 0, 1}; const uint32_t vv[3] = {cstart, cnext, cstart}; const bool up[3] = {false, false, false};
+                const Arr arr[3] = {anc_arr, anc_arr, ag}; const uint32_t sh[3] = {0, 0, 1}; const Co vv[3] = {cstart, cnext, cstart}; const bool up[3] = {false, false, false};
                 uint32_t lo3[3] = {lo_a, lo_e, lo_r}, hi3[3] = {hi_a, hi_e, hi_r};
-                search_together<3>(arr, sh, lo3, hi3, vv, up);
+                search_together<3, Arr, Co>(arr, sh, lo3, hi3, vv, up);
                 lo_a = lo3[0]; lo_e = lo3[1]; lo_r = lo3[2];
             }
             const uint32_t ca = lo_a, ce = lo_e, rc0 = lo_r;                        // running_counter = 0 within the contig starts at rc0 (chain.rs:742-744)
             const bool has = cv && ce > ca;
-            const uint32_t q_first = has ? anc_q[ca] : 0u, q_last = has ? anc_q[ce - 1] : 0u;
-            const uint32_t kmax = has ? (q_last - q_first) / CHUNK_SIZE + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
+            const Co q_first = has ? anc_q[ca] : (Co)0, q_last = has ? anc_q[ce - 1] : (Co)0;
+            const uint32_t kmax = has ? (uint32_t)((q_last - q_first) / CHUNK_SIZE) + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
             const uint32_t P = wave_incl_scan(kmax), M = __shfl(P, 63, 64);
             for (uint32_t j0 = 0; j0 < M; j0 += 64) {
                 const uint32_t j = j0 + l; const bool iv = j < M;
@@ -140,18 +146,18 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; const uint32_t pm = __shfl(P, (int)mid, 64); if (pm > j) shi = mid; else slo = mid + 1; }
                 const int src = (int)(iv ? slo : 63u);
                 const uint32_t o_kmax = __shfl(kmax, src, 64), o_P = __shfl(P, src, 64), a_c = __shfl(ca, src, 64), e_c = __shfl(ce, src, 64), r_c = __shfl(rc0, src, 64);
-                const uint32_t qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64), cs = __shfl(cstart, src, 64);
+                const Co qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64), cs = __shfl(cstart, src, 64);
                 const uint32_t k = j - (o_P - o_kmax) + 1u;
                 const uint64_t end64 = (uint64_t)qf + (uint64_t)k * CHUNK_SIZE;
-                const uint32_t lim = end64 < (uint64_t)(cn - 1) ? (uint32_t)end64 : cn - 1;   // beyond it: another contig, or past the window
+                const Co lim = end64 < (uint64_t)(cn - 1) ? (Co)end64 : cn - 1;   // beyond it: another contig, or past the window
                 //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
                 //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
                 uint32_t lo_b = a_c, hi_b = iv ? A1 : a_c, lo_s = 0, hi_s = iv ? Q1 : 0;
                 if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
                 {
-                    const uint32_t* const arr[2] = {anc_q, ag}; const uint32_t sh[2] = {0, 1}; const uint32_t vv[2] = {lim, lim}; const bool up[2] = {true, true};
+                    const Arr arr[2] = {anc_arr, ag}; const uint32_t sh[2] = {0, 1}; const Co vv[2] = {lim, lim}; const bool up[2] = {true, true};
                     uint32_t lo2[2] = {lo_b, lo_s}, hi2[2] = {hi_b, hi_s};
-                    search_together<2>(arr, sh, lo2, hi2, vv, up);
+                    search_together<2, Arr, Co>(arr, sh, lo2, hi2, vv, up);
                     lo_b = lo2[0]; lo_s = lo2[1];
                 }
                 const uint32_t bnd = lo_b, sb = lo_s;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
                 if (l == 0) { t_prev = carry_t; s_prev = carry_s; }
                 if (k == 1) { t_prev = a_c; s_prev = r_c; }
                 const bool valid = iv && t_prev < e_c;                              // chunk k exists
-                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = cs; ck.qctg = c0 + (uint32_t)src;
+                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = (uint32_t)cs; ck.qctg = c0 + (uint32_t)src;
                 if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
                 const unsigned long long vm = __ballot(valid);
                 const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));

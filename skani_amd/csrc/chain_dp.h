@@ -6,13 +6,15 @@
 // chain.rs:838-896 + score_anchors :558-603.  One wave per chunk.  Lanes own anchors base..base+63; sources j are
 // swept in increasing order; a source's score is final when the sweep reaches it, so it is broadcast with v_readlane.
 // All values are integers (positions, 20, gap) => int32 is exact where the reference uses f64.
-struct Blk { uint32_t q, r, cr; int32_t score; uint32_t root, depth; };
+template <class Co> struct Blk { Co q, r; uint32_t cr; int32_t score; uint32_t root, depth; };
 
 // PB = number of earlier 64-anchor blocks kept in registers (band <= 64 PB).  PB = 0: any band (c < 10: up to 2500 anchors) -- the state of earlier
 // anchors (score, root, depth) goes through a per-anchor record array in memory instead; read past the L1, the same wave wrote it a block ago.
-template <int PB>
-__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const uint32_t* anc_q, const uint32_t* anc_r, unsigned long long* best,
+// W (chain_types.h): 32- or 64-bit coordinates; a Wide run chains with this kernel whatever its band.
+template <int PB, class W>
+__global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const Chunk* chunks, uint32_t band, const typename W::Co* anc_q, const typename W::Co* anc_r, unsigned long long* best,
                                                        uint32_t* st /* PB == 0: 3 words per anchor */) {
+    using Co = typename W::Co; using Blk = skh::Blk<Co>;
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];
@@ -25,21 +27,21 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
         const uint32_t t = base + (uint32_t)l;
         const bool valid = t < ck.a_end;
         Blk cur;
-        uint2 av = make_uint2(0, 0);
-        if (valid) av = make_uint2(anc_q[t], anc_r[t]);
-        cur.q = av.x; cur.r = av.y >> 1; cur.cr = av.y & 1u;                         // cr: strand only -- different contigs are > MAX_LIN apart
+        Co av_q = 0, av_r = 0;
+        if (valid) { av_q = anc_q[t]; av_r = anc_r[t]; }
+        cur.q = av_q; cur.r = av_r >> 1; cur.cr = (uint32_t)(av_r & 1u);               // cr: strand only -- different contigs are > MAX_LIN apart
         cur.score = 0; cur.root = t; cur.depth = 1;
         uint32_t ptr = t;
         uint32_t jlo = base - ck.a_begin > band ? base - band : ck.a_begin;
         const uint32_t jhi = ck.a_end < base + 64 ? ck.a_end : base + 64;
         {   // anchors ascend in q: sources more than BP_CHAIN_BAND below this block's first target cannot link to any of its targets
-            const uint32_t q_base = anc_q[base];
+            const Co q_base = anc_q[base];
             uint32_t lo = jlo, hi = base;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (anc_q[mid] + BP_CHAIN_BAND < q_base) lo = mid + 1; else hi = mid; }
             jlo = lo;
         }
         for (uint32_t j = jlo; j < jhi; j++) {
-            uint32_t qj, rj, crj; int32_t sj;
+            Co qj, rj; uint32_t crj; int32_t sj;
             if (j >= base) {
                 const int ln = (int)(j - base);
                 // finalise lane ln: its score/ptr can no longer change (all its predecessors were swept)
@@ -59,10 +61,10 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
                 if (l == ln) { cur.root = rootj; cur.depth = depthj; }
                 qj = wave_readlane(cur.q, ln); rj = wave_readlane(cur.r, ln); crj = wave_readlane(cur.cr, ln); sj = wave_readlane(cur.score, ln);
             } else if (PB == 0) {
-                const uint32_t rr = anc_r[j];
-                qj = anc_q[j]; rj = rr >> 1; crj = rr & 1u; sj = (int32_t)__atomic_load_n(&st[3 * (size_t)j], __ATOMIC_RELAXED);
+                const Co rr = anc_r[j];
+                qj = anc_q[j]; rj = rr >> 1; crj = (uint32_t)(rr & 1u); sj = (int32_t)__atomic_load_n(&st[3 * (size_t)j], __ATOMIC_RELAXED);
             } else {
-                qj = rj = crj = 0; sj = 0;
+                qj = rj = 0; crj = 0; sj = 0;
 #pragma unroll
                 for (int b = 0; b < PB; b++) {
                     const uint32_t bb = base - 64u * (uint32_t)(b + 1);
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
             // link j -> t (score_anchors).  Candidates: same ref contig and strand, i-j <= band, 0 < dq <= 2500,
             // 0 < dr <= 5000, |dr-dq| <= 300 (chain.rs:856-863, 564-597)
             if (valid && t > j && t - j <= band && cur.cr == crj) {
-                const uint32_t dq = cur.q - qj;
+                const Co dq = cur.q - qj;
                 const bool rev = (crj & 1u) != 0;
                 const bool fwd_ok = rev ? (rj > cur.r) : (cur.r > rj);
-                const uint32_t dr = rev ? rj - cur.r : cur.r - rj;
-                if (dq != 0 && dq <= BP_CHAIN_BAND && fwd_ok && dr <= (uint32_t)MAX_LIN) {
+                const Co dr = rev ? rj - cur.r : cur.r - rj;
+                if (dq != 0 && dq <= BP_CHAIN_BAND && fwd_ok && dr <= (Co)MAX_LIN) {
                     const int32_t gap = (int32_t)dr > (int32_t)dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
                     const int32_t s = ANCHOR_SCORE - gap + sj;
                     // reference scans j downwards and replaces only on strictly greater => among equal maxima the largest j wins
@@ -111,27 +113,33 @@ __global__ __launch_bounds__(256) void chain_dp_kernel(uint32_t n_slots, const C
 // ring the component is final and, if it reaches 3 anchors / score 45 (chain.rs:954-977), its interval is emitted straight
 // away: the kernel writes nothing per anchor.
 // the interval record of a finished chain (root anchor .. best anchor), back in contig-local coordinates (types.rs:508-519)
-struct EmitCtx { const uint32_t *anc_q, *anc_r; const PairDesc* pairs; const uint32_t *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
+template <class W> struct EmitCtxT { const typename W::Co *anc_q, *anc_r; const PairDesc* pairs; const WidePair* wide; const uint32_t *pc0, *pi0; uint32_t* ivl_cnt; Interval* ivls; uint32_t* err; };
+using EmitCtx = EmitCtxT<Narrow>;
 __device__ __forceinline__ bool dp_keep(unsigned long long b) {                  // chain.rs:954-957, 974-977
     const uint32_t sc = (uint32_t)(b >> 40), na = (uint32_t)(b & 0xFFFFFu);
     return na >= MIN_ANCHORS && (int32_t)sc >= MIN_SCORE;
 }
 // writes the record of a kept chain as the pair's k-th candidate interval
-__device__ __forceinline__ void dp_write(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec, uint32_t k) {
+template <class W>
+__device__ __forceinline__ void dp_write(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtxT<W>& ec, uint32_t k) {
+    using Co = typename W::Co;
     const uint32_t sc = (uint32_t)(b >> 40), bi = (uint32_t)((b >> 20) & 0xFFFFFu), na = (uint32_t)(b & 0xFFFFFu);
     if (ec.pi0[p] + k >= ec.pi0[p + 1]) { atomicAdd(ec.err, 1u); return; }
-    const uint2 ar = make_uint2(ec.anc_q[ck.a_begin + root], ec.anc_r[ck.a_begin + root]), ab = make_uint2(ec.anc_q[ck.a_begin + bi], ec.anc_r[ck.a_begin + bi]);
+    const Co ar_q = ec.anc_q[ck.a_begin + root], ar_r = ec.anc_r[ck.a_begin + root], ab_q = ec.anc_q[ck.a_begin + bi], ab_r = ec.anc_r[ck.a_begin + bi];
     const PairDesc& pd = ec.pairs[p];
-    const uint32_t* bo = pd.b_goff;
-    const uint32_t ra = ar.y >> 1, rb = ab.y >> 1;
-    const uint32_t rctg = ctg_of(bo, pd.b_nctg, ra), roff = bo[rctg];
+    const typename W::Arr bo = W::b_goff(pd, ec.wide, p);
+    const Co ra = ar_r >> 1, rb = ab_r >> 1;
+    const uint32_t rctg = ctg_of(bo, pd.b_nctg, ra); const Co roff = bo[rctg];
+    Co qoff = ck.qoff;                                                               // (a Wide run's chunks do not carry their contig's start)
+    if constexpr (W::wide) qoff = W::a_goff(pd, ec.wide, p)[ck.qctg];
     Interval iv;
-    iv.score = sc; iv.na = na; iv.q0 = ar.x - ck.qoff; iv.q1 = ab.x - ck.qoff;
-    iv.r0 = (ra < rb ? ra : rb) - roff; iv.r1 = (ra < rb ? rb : ra) - roff;
-    iv.rctg = rctg; iv.qctg = ck.qctg; iv.chunk = slot - ec.pc0[p]; iv.rev = ar.y & 1u;
+    iv.score = sc; iv.na = na; iv.q0 = (uint32_t)(ar_q - qoff); iv.q1 = (uint32_t)(ab_q - qoff);
+    iv.r0 = (uint32_t)((ra < rb ? ra : rb) - roff); iv.r1 = (uint32_t)((ra < rb ? rb : ra) - roff);
+    iv.rctg = rctg; iv.qctg = ck.qctg; iv.chunk = slot - ec.pc0[p]; iv.rev = (uint32_t)(ar_r & 1u);
     ec.ivls[ec.pi0[p] + k] = iv;
 }
-__device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtx& ec) {
+template <class W>
+__device__ __forceinline__ void dp_emit(const Chunk& ck, uint32_t slot, uint32_t p, uint32_t root, unsigned long long b, const EmitCtxT<W>& ec) {
     if (dp_keep(b)) dp_write(ck, slot, p, root, b, ec, atomicAdd(&ec.ivl_cnt[p], 1u));
 }
 
@@ -337,7 +345,8 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
 
 // chain.rs:939-1007: one candidate interval per pointer-forest component that reaches 3 anchors / score 45
 // One wave per chunk: roots are the anchors whose argmax record is non-zero.
-__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const unsigned long long* best, const uint32_t* chunk_pair, EmitCtx ec) {
+template <class W>
+__global__ __launch_bounds__(256) void interval_emit_kernel(uint32_t n_slots, const Chunk* chunks, const unsigned long long* best, const uint32_t* chunk_pair, EmitCtxT<W> ec) {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= n_slots) return;
     const Chunk ck = chunks[slot];

@@ -11,26 +11,30 @@
 // list 4-5 times over.)
 constexpr int STATS_REG = 4;   // intervals of one chunk kept in registers (more -> slow path re-walks the list per position)
 
+template <class W>
 __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* chunk_head,
-                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const unsigned long long* inq_mask,
+                                                          const uint32_t* ivl_next, const Interval* ivls, const PairDesc* pairs, const WidePair* wide, const unsigned long long* inq_mask,
                                                           uint32_t c, uint32_t k, double* chunk_est, uint32_t* chunk_w, uint4* chunk_sums) {
+    using Co = typename W::Co; using Arr = typename W::Arr;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t l = lane_id();
     const bool valid = slot < n_slots;
     const uint32_t head = valid ? chunk_head[slot] : NONE;
     if (valid) chunk_w[slot] = NONE;                                                // NONE = no estimate from this chunk
-    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0, s_begin = 0, s_end = 0, qoff = 0;
+    uint32_t total_anchors = 0, rq0 = 0xFFFFFFFFu, rq1 = 0, tbcq = 0, sum_len = 0, n_int = 0, s_begin = 0, s_end = 0; Co qoff = 0;
     uint32_t lo[STATS_REG], hi[STATS_REG];
 #pragma unroll
     for (int i = 0; i < STATS_REG; i++) { lo[i] = 1; hi[i] = 0; }                   // empty
     bool active = false;
-    const uint32_t* ag = nullptr; const unsigned long long* mk = nullptr;           // the chunk's pair: position array and "listed" bits
+    const void* ag = nullptr; uint32_t ag64 = 0; const unsigned long long* mk = nullptr;   // the chunk's pair: position array (32- or 64-bit records) and "listed" bits
     if (head != NONE) {                                                             // else total_anchors == 0 (chain.rs:253)
         const Chunk ck = chunks[slot];
         const uint32_t p = chunk_pair[slot];
         const bool switched = (pairs[p].flags & 4u) != 0;
-        ag = pairs[p].a_g; mk = inq_mask + (uint64_t)pairs[p].tile0 * (JOIN_TILE / 64);
-        s_begin = ck.s_begin; s_end = ck.s_end; qoff = ck.qoff;
+        mk = inq_mask + (uint64_t)pairs[p].tile0 * (JOIN_TILE / 64);
+        s_begin = ck.s_begin; s_end = ck.s_end;
+        if constexpr (W::wide) { const CoArr a = wide[p].a_g; ag = a.p; ag64 = a.is64; qoff = wide[p].a_goff[ck.qctg]; }
+        else { ag = pairs[p].a_g; qoff = ck.qoff; }
         for (uint32_t e = head; e != NONE; e = ivl_next[e]) {
             const Interval iv = ivls[e];
             total_anchors += iv.na;
@@ -57,10 +61,16 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
     // coordinate << 1 | listed.  (Assembling the 64 "listed" bits of a block from two wave-uniform loads instead of one load
     // per lane is slower: 1.27 vs 0.79 ms -- the scalar loads sit in the dependent chain.)
     constexpr int PF = 4;
-    uint32_t cur[PF], nxt[PF];
-    auto fetch = [&](const uint32_t* ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> uint32_t {
-        if (s2 >= se_j) return 0u;
-        return (ag_j[s2] & ~1u) | (uint32_t)((mk_j[((s2 >> 8) << 2) | (s2 & 3u)] >> ((s2 >> 2) & 63u)) & 1ull);   // join_count_kernel's layout: bit l of word r of a 256-position round = position 4 l + r
+    Co cur[PF], nxt[PF];
+    auto fetch = [&](const Arr& ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> Co {
+        if (s2 >= se_j) return (Co)0;
+        return ((Co)ag_j[s2] & ~(Co)1) | (Co)((mk_j[((s2 >> 8) << 2) | (s2 & 3u)] >> ((s2 >> 2) & 63u)) & 1ull);   // join_count_kernel's layout: bit l of word r of a 256-position round = position 4 l + r
+    };
+    auto bcast_arr = [&](int src) -> Arr {                                           // lane src's position array, to all lanes
+        const unsigned long long v = (unsigned long long)ag;
+        const uint32_t lo32 = wave_readlane((uint32_t)v, src), hi32 = wave_readlane((uint32_t)(v >> 32), src);
+        const void* ptr = (const void*)(((unsigned long long)hi32 << 32) | lo32);
+        if constexpr (W::wide) return CoArr{ptr, wave_readlane(ag64, src)}; else return (const uint32_t*)ptr;
     };
     auto bcast_ptr = [&](const void* ptr, int src) -> const void* {
         const unsigned long long v = (unsigned long long)ptr;
@@ -68,33 +78,33 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         return (const void*)(((unsigned long long)hi32 << 32) | lo32);
     };
     int j = -1; uint32_t sb = 0, se = 0;
-    const uint32_t* agj = nullptr; const unsigned long long* mkj = nullptr;
+    Arr agj{}; const unsigned long long* mkj = nullptr;
     if (todo) {
         j = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
         sb = wave_readlane(s_begin, j); se = wave_readlane(s_end, j);
-        agj = (const uint32_t*)bcast_ptr(ag, j); mkj = (const unsigned long long*)bcast_ptr(mk, j);
+        agj = bcast_arr(j); mkj = (const unsigned long long*)bcast_ptr(mk, j);
 #pragma unroll
         for (int u = 0; u < PF; u++) cur[u] = fetch(agj, mkj, sb + 64u * (uint32_t)u + l, se);
     }
     while (j >= 0) {                                                                // wave-uniform
         int jn = -1; uint32_t sbn = 0, sen = 0;
-        const uint32_t* agn = nullptr; const unsigned long long* mkn = nullptr;
+        Arr agn{}; const unsigned long long* mkn = nullptr;
         if (todo) {
             jn = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
             sbn = wave_readlane(s_begin, jn); sen = wave_readlane(s_end, jn);
-            agn = (const uint32_t*)bcast_ptr(ag, jn); mkn = (const unsigned long long*)bcast_ptr(mk, jn);
+            agn = bcast_arr(jn); mkn = (const unsigned long long*)bcast_ptr(mk, jn);
 #pragma unroll
             for (int u = 0; u < PF; u++) nxt[u] = fetch(agn, mkn, sbn + 64u * (uint32_t)u + l, sen);
         }
         const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
-        const uint32_t qoffj = wave_readlane(qoff, j);                              // positions are padded coordinates; intervals are contig-local
+        const Co qoffj = wave_readlane(qoff, j);                                    // positions are padded coordinates; intervals are contig-local
         uint32_t lj[STATS_REG], hj[STATS_REG];
 #pragma unroll
         for (int i = 0; i < STATS_REG; i++) { lj[i] = wave_readlane(lo[i], j); hj[i] = wave_readlane(hi[i], j); }
         uint32_t cu = 0, cr = 0, cl = 0;
-        auto count = [&](uint32_t v) {
+        auto count = [&](Co v) {
             const bool on = (v & 1u) != 0;                                          // listed in query_positions_all (0 beyond the chunk)
-            const uint32_t pos = (v >> 1) - qoffj;
+            const uint32_t pos = (uint32_t)((v >> 1) - qoffj);
             bool hit = false;
             if (nj <= (uint32_t)STATS_REG) {
 #pragma unroll

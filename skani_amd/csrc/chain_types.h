@@ -23,6 +23,35 @@ struct PairDesc {
     float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
 };
 
+// ------------------------------------------------------------------------------------------------ coordinate width
+// A run over pairs of ordinary sketch sets keeps every coordinate in 32 bits (Narrow).  A run that involves a WIDE set (internal.h: a genome beyond
+// 2^31 padded bases) works on 64-bit coordinates from the chunking on (Wide): the join is the same -- a wide set's position records and table
+// payloads are position indices --, widen_anchors_kernel then turns the anchors into 64-bit coordinates, and the kernels behind it are instantiated
+// a second time.  The sides of a pair may differ (a 3 Gbp genome against a bacterial one): CoArr reads either record width.
+struct CoArr {
+    const void* p; uint32_t is64;
+    __host__ __device__ __forceinline__ uint64_t operator[](uint64_t i) const { return is64 ? ((const uint64_t*)p)[i] : (uint64_t)((const uint32_t*)p)[i]; }
+};
+struct WidePair {                // per pair of a Wide run, beside its PairDesc
+    CoArr a_g;                   // A's positions as coordinate << 1 | canonical (PairDesc::a_g holds indices when A's set is wide)
+    CoArr a_goff, b_goff;        // padded contig starts
+    const uint64_t* b_g64;       // B's coordinate records when B's set is wide (its anchors carry indices), else null
+    uint32_t a_is_index;         // A's set is wide: anc_q from the join is a position index
+    uint32_t pad;
+};
+struct Narrow {
+    using Co = uint32_t; using Arr = const uint32_t*; static constexpr bool wide = false;
+    static __device__ __forceinline__ Arr a_g(const PairDesc& pd, const WidePair*, uint32_t) { return pd.a_g; }
+    static __device__ __forceinline__ Arr a_goff(const PairDesc& pd, const WidePair*, uint32_t) { return pd.a_goff; }
+    static __device__ __forceinline__ Arr b_goff(const PairDesc& pd, const WidePair*, uint32_t) { return pd.b_goff; }
+};
+struct Wide {
+    using Co = uint64_t; using Arr = CoArr; static constexpr bool wide = true;
+    static __device__ __forceinline__ Arr a_g(const PairDesc&, const WidePair* wp, uint32_t p) { return wp[p].a_g; }
+    static __device__ __forceinline__ Arr a_goff(const PairDesc&, const WidePair* wp, uint32_t p) { return wp[p].a_goff; }
+    static __device__ __forceinline__ Arr b_goff(const PairDesc&, const WidePair* wp, uint32_t p) { return wp[p].b_goff; }
+};
+
 constexpr uint32_t JOIN_TILE = 1024;    // positions per join tile (one wave: 4 rounds x 4 probes per lane)
 constexpr uint32_t JOIN_GROUP = 4;      // tiles per join workgroup (one wave each)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -30,5 +59,5 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // An anchor is 8 bytes in two arrays: anc_q = padded query coordinate, anc_r = padded ref coordinate << 1 | reverse_match
 // (chunking only needs the first).  Contigs are recovered from the padded contig-start tables where a stage needs them
 // (chunk boundaries, interval records).
-struct Chunk { uint32_t a_begin, a_end, s_begin, s_end, qoff, qctg; };   // batch-relative anchor / seed-list ranges; the chunk's query contig and its padded start
+struct Chunk { uint32_t a_begin, a_end, s_begin, s_end, qoff, qctg; };   // batch-relative anchor / seed-list ranges; the chunk's query contig and its padded start (Wide runs: qoff is not used, the start is a_goff[qctg])
 struct Interval { uint32_t score, na, q0, q1, r0, r1, rctg, qctg, chunk, rev; };   // types.rs:508-519 field order = sort order

@@ -45,13 +45,15 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
 }
 
 // Padded genome coordinates: a seed at (contig c, pos) lives at goff[c] + pos, where the first contig starts at CTG_PAD and
-// consecutive contigs are CTG_PAD apart; a genome's padded span must stay below 2^31 - CTG_PAD.
+// consecutive contigs are CTG_PAD apart.  A genome whose padded span stays below 2^31 - CTG_PAD keeps them in 32-bit records; a sketch set with a
+// longer genome is "wide" (internal.h skh_sketch_set::wide): 64-bit coordinates beside position indices.
 // CTG_PAD exceeds every distance the chaining DP can bridge (D_MAX_LIN_LENGTH, BP_CHAIN_BAND), so "same contig" is implied
 // by "close enough" and an anchor needs no contig field; the margins at both ends of the coordinate range let the DP fold
 // the strand test into the same comparison (chain.hip).  A position is stored as gpos << 1 | canonical-strand bit.
 constexpr uint32_t CTG_PAD = 8192;
 static_assert(CTG_PAD > (uint32_t)MAX_LIN && CTG_PAD > BP_CHAIN_BAND, "contig padding must exceed the chaining reach");
-__host__ __device__ __forceinline__ uint32_t ctg_of(const uint32_t* goff, uint32_t n_ctg, uint32_t gpos) {   // largest c with goff[c] <= gpos
+template <class Arr, class Co>
+__host__ __device__ __forceinline__ uint32_t ctg_of(const Arr& goff, uint32_t n_ctg, Co gpos) {   // largest c with goff[c] <= gpos
     uint32_t lo = 0, hi = n_ctg;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (goff[mid] <= gpos) lo = mid; else hi = mid; }
     return lo;
@@ -67,8 +69,8 @@ struct ContigDesc {
     uint32_t genome;    // genome id within the set
     uint32_t index;     // contig index within its genome (types.rs:124 contig_index)
     uint32_t has_n;     // set by the pack kernel when the contig contains a masked byte
-    uint32_t goff;      // padded-coordinate start of the contig within its genome (CTG_PAD)
-    uint32_t pad;
+    uint32_t goff;      // padded-coordinate start of the contig within its genome (CTG_PAD): low word,
+    uint32_t goff_hi;   // high word (non-zero only in genomes beyond 2^31 padded bases: "wide" sketch sets, internal.h)
 };
 
 // one seeding workgroup's work: SEED_TILE consecutive windows of one contig

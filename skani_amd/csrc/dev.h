@@ -163,6 +163,9 @@ template <class T> struct DBuf {
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 __device__ __forceinline__ unsigned wave_readlane(unsigned v, int uniform_lane) { return (unsigned)wave_readlane((int)v, uniform_lane); }
+__device__ __forceinline__ uint64_t wave_readlane(uint64_t v, int uniform_lane) {
+    return ((uint64_t)wave_readlane((unsigned)(v >> 32), uniform_lane) << 32) | wave_readlane((unsigned)v, uniform_lane);
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
     unsigned l = lane_id();

@@ -197,15 +197,17 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     };
     // ---- 1. who holds what: per rank (genomes, seed positions, markers, contigs, c, k, marker_c, seeding mode), then per genome, then the contig lengths
     const uint32_t nL = L->n_genomes;
-    uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, L->params.seeding_mode};
+    uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, (uint64_t)L->params.seeding_mode | (L->wide ? 256u : 0u)};
     std::vector<uint64_t> cnt((size_t)W * 8);
     ex_begin();
     T.all_gather(ctx, mine, cnt.data(), sizeof(mine), false);
     std::vector<uint64_t> base(W + 1, 0);
     uint64_t max_n = 0, max_m = 0, max_c = 0;
     for (int r = 0; r < W; r++) {
-        if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6] || cnt[r * 8 + 7] != mine[7])
+        if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6] || (cnt[r * 8 + 7] & 255u) != (mine[7] & 255u))
             throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
+        // (every rank sees the same table, so all of them stop here together)
+        if (cnt[r * 8 + 7] & 256u) throw std::invalid_argument("a rank holds a genome beyond 2^31 padded bases: wide sketch sets are not exchanged between ranks; chain such genomes on one device");
         base[r + 1] = base[r] + cnt[r * 8]; max_n = std::max(max_n, cnt[r * 8]); max_m = std::max(max_m, cnt[r * 8 + 2]); max_c = std::max(max_c, cnt[r * 8 + 3]);
     }
     const uint64_t N64 = base[W];

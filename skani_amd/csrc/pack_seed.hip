@@ -148,7 +148,7 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
         cd.genome = g; cd.index = idx++;
         cd.len = (uint32_t)len; cd.base = (gs->n_units + unit_off[i]) * 32; cd.has_n = 0;
         if (cd.index == 0) gat = CTG_PAD;
-        cd.goff = (uint32_t)gat; cd.pad = 0; gat += len + CTG_PAD;                  // genomes beyond 2^31 are refused when a sketch set is made (finalize_metadata)
+        cd.goff = (uint32_t)gat; cd.goff_hi = (uint32_t)(gat >> 32); gat += len + CTG_PAD;   // (a genome beyond 2^31 makes its sketch set wide: finalize_metadata)
         src_off[i] = contig_start[i];
         if (len) { span_lo = std::min(span_lo, contig_start[i]); span_hi = std::max(span_hi, contig_start[i] + len); }
         const uint64_t padded = (len + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256) void seed_overflow_kernel(const uint32_t* cnt_
     ovf_idx[t] = idx;
 }
 
-// one wave per tile: copy the tile's records to their final (contig,pos)-ordered place
+// one wave per tile: copy the tile's records to their final (contig,pos)-ordered place.  WIDE (a set with a genome beyond 31-bit coordinates): the
+// coordinates go out as 64-bit records (o_g64); the table build derives the set's 32-bit position records from them (sketch_build.hip)
+template <bool WIDE>
 __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __restrict__ tiles, const ContigDesc* __restrict__ contigs,
                                                            uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m, const uint32_t* __restrict__ ovf_idx,
                                                            const uint32_t* __restrict__ t_seed, const uint16_t* __restrict__ t_loc,
@@ -418,12 +420,13 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                                                            const uint16_t* __restrict__ o_loc2, const uint64_t* __restrict__ o_marker2,
                                                            const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
                                                            uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_hash, uint32_t* __restrict__ o_g,
-                                                           uint64_t* __restrict__ o_marker) {
+                                                           uint64_t* __restrict__ o_g64, uint64_t* __restrict__ o_marker) {
     const uint32_t lt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
     const uint32_t ln = threadIdx.x & 63;
     const SeedTile tile = tiles[lt];
     const uint32_t goff = contigs[tile.contig].goff;
+    const uint64_t goff64 = ((uint64_t)contigs[tile.contig].goff_hi << 32) | goff;
     const uint32_t s0 = off_s[lt], ns = off_s[lt + 1] - s0, m0 = off_m[lt], nm = off_m[lt + 1] - m0;
     const uint32_t ov = ovf_idx[lt];
     const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
             if (x < ns) {
                 o_seed[s0 + x] = sd[u]; o_hash[s0 + x] = mix32(sd[u]);              // the table hash the sketch build and the join work with
                 const uint32_t pos = pos0 + (loc[u] & 0x1FFFu);                         // pos = index of the window's last base
-                o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                     // SeedPosition (types.rs:131-138) in padded coordinates
+                if (WIDE) o_g64[s0 + x] = ((goff64 + pos) << 1) | (loc[u] >> 15);
+                else o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                // SeedPosition (types.rs:131-138) in padded coordinates
             }
         }
     }
@@ -455,8 +459,8 @@ __global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src,
 
 // async_tail: a set seeded in ONE launch returns with its compaction kernel still queued (no wait, the arena not rewound): the caller queues the table
 // build behind it and prepares that build's host tables meanwhile; out.tail_pending says so
-void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail) {
-    out.tail_pending = false;
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail, bool wide) {
+    out.tail_pending = false; out.wide = wide;
     const uint64_t thr = ~0ull / (uint64_t)sp.c, thr_m = ~0ull / (uint64_t)sp.marker_c;   // seeding.rs:258-259
     const size_t n_tiles = gs->tiles.size();
     const uint32_t ng = gs->n_genomes;
@@ -467,7 +471,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
     const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
-    struct Part { DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> mk; uint64_t ns = 0, nm = 0; };
+    struct Part { DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
     std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);   // running totals at genome starts
@@ -530,10 +534,13 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
                        o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
         }
-        p.seed.alloc(p.ns); p.hash.alloc(p.ns); p.g.alloc(p.ns); p.mk.alloc(p.nm);
-        SKH_LAUNCH(seed_compact_kernel, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m,
-                   (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2,
-                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.hash.p, p.g.p, p.mk.p);
+        p.seed.alloc(p.ns); p.hash.alloc(p.ns); p.mk.alloc(p.nm);
+        if (wide) p.g64.alloc(p.ns); else p.g.alloc(p.ns);
+#define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
+                   (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2, \
+                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.hash.p, p.g.p, p.g64.p, p.mk.p)
+        if (wide) SKH_COMPACT(true); else SKH_COMPACT(false);
+#undef SKH_COMPACT
         check_launch("seed_compact_kernel");
         tr.mark("seed: overflow + alloc + compact");
         base_s += p.ns; base_m += p.nm;
@@ -546,12 +553,14 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
     const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
     if (parts.size() == 1) {
-        out.seed = std::move(parts[0].seed); out.hash = std::move(parts[0].hash); out.g = std::move(parts[0].g); out.markers_raw = std::move(parts[0].mk);
+        out.seed = std::move(parts[0].seed); out.hash = std::move(parts[0].hash); out.g = std::move(parts[0].g); out.g64 = std::move(parts[0].g64); out.markers_raw = std::move(parts[0].mk);
     } else {
-        out.seed.alloc(NS); out.hash.alloc(NS); out.g.alloc(NS); out.markers_raw.alloc(NM);
+        out.seed.alloc(NS); out.hash.alloc(NS); out.markers_raw.alloc(NM);
+        if (wide) out.g64.alloc(NS); else out.g.alloc(NS);
         uint64_t so = 0, mo = 0;
         for (auto& p : parts) {
-            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.hash.p + so, p.hash.p, p.ns * 4, ctx->stream); d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream);
+            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.hash.p + so, p.hash.p, p.ns * 4, ctx->stream);
+            if (wide) d2d(out.g64.p + so, p.g64.p, p.ns * 8, ctx->stream); else d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream);
             d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
             so += p.ns; mo += p.nm;
         }

@@ -21,23 +21,32 @@ __device__ __forceinline__ uint32_t seg_of(const uint64_t* off, uint32_t n_seg, 
     return lo;
 }
 
-// (pos, contig << 1 | canonical) -> padded coordinate << 1 | canonical
+// (pos, contig << 1 | canonical) -> padded coordinate << 1 | canonical; Co = uint32_t, or uint64_t for a wide set (internal.h)
+template <class Co>
 __global__ __launch_bounds__(256) void pack_positions_kernel(const uint32_t* pos, const uint32_t* cc, const uint64_t* pos_off, const uint64_t* ctg_off, uint32_t ng,
-                                                             uint64_t n, const uint32_t* goff, uint32_t* p_g) {
+                                                             uint64_t n, const Co* goff, Co* p_g) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = seg_of(pos_off, ng, i), c = cc[i];
     p_g[i] = ((goff[ctg_off[g] + g + (c >> 1)] + pos[i]) << 1) | (c & 1u);
 }
-__global__ __launch_bounds__(256) void unpack_positions_kernel(const uint32_t* p_g, const uint64_t* pos_off, const uint64_t* ctg_off, uint32_t ng, uint64_t p0,
-                                                               uint64_t n, const uint32_t* goff, uint32_t* pos, uint32_t* cc) {
+template <class Co>
+__global__ __launch_bounds__(256) void unpack_positions_kernel(const Co* p_g, const uint64_t* pos_off, const uint64_t* ctg_off, uint32_t ng, uint64_t p0,
+                                                               uint64_t n, const Co* goff, uint32_t* pos, uint32_t* cc) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t g = seg_of(pos_off, ng, p0 + i), v = p_g[p0 + i];
-    const uint32_t* go = goff + ctg_off[g] + g;
-    const uint32_t c = ctg_of(go, (uint32_t)(ctg_off[g + 1] - ctg_off[g]), v >> 1);
-    if (pos) pos[i] = (v >> 1) - go[c];
-    if (cc) cc[i] = (c << 1) | (v & 1u);
+    const uint32_t g = seg_of(pos_off, ng, p0 + i); const Co v = p_g[p0 + i];
+    const Co* go = goff + ctg_off[g] + g;
+    const uint32_t c = ctg_of(go, (uint32_t)(ctg_off[g + 1] - ctg_off[g]), (Co)(v >> 1));
+    if (pos) pos[i] = (uint32_t)((v >> 1) - go[c]);
+    if (cc) cc[i] = (c << 1) | (uint32_t)(v & 1u);
+}
+// a wide set's 32-bit position records: index within the genome << 1 | canonical (what its seed tables store and the join hands on)
+__global__ __launch_bounds__(256) void index_positions_kernel(const uint64_t* p_g64, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t* p_g) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = seg_of(pos_off, ng, i);
+    p_g[i] = ((uint32_t)(i - pos_off[g]) << 1) | (uint32_t)(p_g64[i] & 1u);
 }
 
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, uint64_t n, uint32_t* head) {
@@ -328,7 +337,9 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
 
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc) {
     if (!n || (!pos && !cc)) return;
-    SKH_LAUNCH(unpack_positions_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_g.p, (const uint64_t*)ss->d_pos_off.p,
+    if (ss->wide) SKH_LAUNCH(unpack_positions_kernel<uint64_t>, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->p_g64.p, (const uint64_t*)ss->d_pos_off.p,
+               (const uint64_t*)ss->d_ctg_off.p, ss->n_genomes, p0, n, (const uint64_t*)ss->d_goff64.p, pos, cc);
+    else SKH_LAUNCH(unpack_positions_kernel<uint32_t>, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_g.p, (const uint64_t*)ss->d_pos_off.p,
                (const uint64_t*)ss->d_ctg_off.p, ss->n_genomes, p0, n, (const uint32_t*)ss->d_goff.p, pos, cc);
     check_launch("unpack_positions");
 }
@@ -339,6 +350,7 @@ void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss) {
     if (ss->d_pos_off.n == ng + 1 && ss->d_ctg_off.n == ng + 1) return;
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
+    if (ss->wide) { ss->d_goff64.alloc(ss->goff64.size() ? ss->goff64.size() : 1); h2d(ss->d_goff64.p, ss->goff64.data(), ss->goff64.size() * 8, ctx->stream); }
     ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
 }
 
@@ -369,7 +381,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / TAB_FILTER_HOMES) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
         // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
         // coordinates pass 2^30 may need two words for a single position
-        const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];
+        const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];   // (a wide set's records are indices below 2^30)
         ss->ms_off[g + 1] = ss->ms_off[g] + (span >= (1ull << 30) ? 2 * pg : pg + pg / 2) + 16;
         if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
         queue_pos[g] = queue_len[g & 7u]; queue_len[g & 7u] += n_sl;
@@ -384,11 +396,19 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     // the first copy below may wait for the stream)
     upload_set_offsets(ctx, ss);
     dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
-    if (pos || cc || ss->p_g.n != P) ss->p_g.alloc(P);
+    const bool fresh_g = pos || cc || ss->p_g.n != P;                                // (a set whose tables were deferred arrives with its records made)
+    if (fresh_g) ss->p_g.alloc(P);
+    if (ss->wide && (pos || cc || ss->p_g64.n != P)) ss->p_g64.alloc(P);
     if (P > 0 && pos && cc) {
-        SKH_LAUNCH(pack_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
+        if (ss->wide) SKH_LAUNCH(pack_positions_kernel<uint64_t>, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint64_t*)ss->d_goff64.p, ss->p_g64.p);
+        else SKH_LAUNCH(pack_positions_kernel<uint32_t>, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
                    (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
         check_launch("pack_positions");
+    }
+    if (ss->wide && P > 0 && fresh_g) {
+        SKH_LAUNCH(index_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->p_g64.p, (const uint64_t*)ss->d_pos_off.p, ng, P, ss->p_g.p);
+        check_launch("index_positions");
     }
     if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
         ss->p_hash.alloc(P ? P : 1);
@@ -590,13 +610,18 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
 // (chain.rs:519-526): sorted contig lengths at indices n*10/100, n*50/100, n*90/100; and the padded contig starts.
 void finalize_metadata(skh_sketch_set* ss) {
     const uint32_t ng = ss->n_genomes;
-    ss->goff.assign(ss->ctg_len.size() + ng, 0);
+    // padded contig starts; a genome of wide_span padded bases or more (total length + 8192 per contig) makes the set wide
+    const uint64_t lim = ss->ctx ? ss->ctx->tune.wide_span : (1ull << 31) - CTG_PAD;
+    ss->goff64.assign(ss->ctg_len.size() + ng, 0);
+    ss->wide = false;
     for (uint32_t g = 0; g < ng; g++) {
-        uint64_t at = CTG_PAD; const uint64_t base = ss->ctg_off[g] + g, lim = (1ull << 31) - CTG_PAD;
-        for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff[base + (c - ss->ctg_off[g])] = (uint32_t)at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; if (at >= lim) break; }
-        if (at >= lim) throw Error("a genome spans >= 2^31 padded bases (total length + 8192 per contig); it does not fit the 32-bit position records");
-        ss->goff[base + (ss->ctg_off[g + 1] - ss->ctg_off[g])] = (uint32_t)at;
+        uint64_t at = CTG_PAD; const uint64_t base = ss->ctg_off[g] + g;
+        for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff64[base + (c - ss->ctg_off[g])] = at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; }
+        ss->goff64[base + (ss->ctg_off[g + 1] - ss->ctg_off[g])] = at;
+        if (at >= lim) ss->wide = true;
     }
+    ss->goff.clear();
+    if (!ss->wide) { ss->goff.assign(ss->goff64.begin(), ss->goff64.end()); ss->goff64.clear(); }
     ss->mean_ctg.assign(ng, 0.); ss->q10.assign(ng, 0.f); ss->q50.assign(ng, 0.f); ss->q90.assign(ng, 0.f);
     for (uint32_t g = 0; g < ng; g++) {
         std::vector<uint32_t> v(ss->ctg_len.begin() + ss->ctg_off[g], ss->ctg_len.begin() + ss->ctg_off[g + 1]);

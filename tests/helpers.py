@@ -55,6 +55,28 @@ def random_genome(length, seed, n_rate=0.0):
     return s.tobytes()
 
 
+def big_random_genome(length, seed, piece=1 << 26):
+    """random_genome for lengths in the Gbp range: made piece by piece from one-byte draws (random_genome's int64 draws take 8 bytes per base)"""
+    rng = np.random.default_rng(seed); acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = np.empty(length, np.uint8)
+    for at in range(0, length, piece):
+        n = min(piece, length - at)
+        out[at:at + n] = acgt[rng.integers(0, 4, n, dtype=np.uint8)]
+    return out
+
+
+def big_mutate(a, rate, seed, piece=1 << 26):
+    """substitutions at `rate` in a uint8 array of bases, piece by piece; returns a new array"""
+    rng = np.random.default_rng(seed); acgt = np.frombuffer(b"ACGT", np.uint8)
+    lut = np.zeros(256, np.uint8); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+    out = a.copy()
+    for at in range(0, len(a), piece):
+        v = out[at:at + piece]
+        idx = np.nonzero(rng.random(len(v), dtype=np.float32) < rate)[0]
+        v[idx] = acgt[(lut[v[idx]] + rng.integers(1, 4, len(idx), dtype=np.uint8)) % 4]
+    return out
+
+
 def mutate(seq, rate, seed):
     rng = np.random.default_rng(seed)
     a = np.frombuffer(seq, np.uint8).copy()

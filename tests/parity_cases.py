@@ -487,14 +487,22 @@ def case_edge_cases_and_errors(ctx):
         ctx.chain_pairs_multi([ss, one], one, [2], [0], [0], sk.MapParams())
     r = ctx.chain_pairs_multi([ss, one], one, [1, 0], [0, 0], [0, 0], sk.MapParams())
     assert r["ani"][0] >= 1.0 and r["ani"][1] >= 1.0
-    # a genome whose padded span (length + 8192 per contig) does not fit 31 bits is refused when the set is made
+    # a genome whose padded span (length + 8192 per contig) does not fit 31 bits makes its set WIDE (64-bit coordinates): the same sketch comes back
+    # out of it, and chained against itself or against the ordinary set it gives the anchors and the ANI of the ordinary pair
     e = one.export(0)
+    r0, s0 = ctx.chain_pairs(one, None, [0], [0], sk.MapParams(), stats=True)
     big = dict(e); big["contig_lengths"] = np.array([0x7FFFF000], np.uint32); big["total_len"] = 0x7FFFF000
-    with pytest.raises(sk.SkaniHipError, match="padded"):
-        ctx.import_sketches(sk.SketchParams(), [big])
-    many = dict(e); many["contig_lengths"] = np.full(300000, 1000, np.uint32); many["total_len"] = 300000 * 1000
-    with pytest.raises(sk.SkaniHipError, match="padded"):
-        ctx.import_sketches(sk.SketchParams(), [many])
+    many = dict(e); many["contig_lengths"] = np.concatenate([e["contig_lengths"], np.full(300000, 1000, np.uint32)]); many["total_len"] = int(many["contig_lengths"].sum())
+    for variant in (big, many):
+        wide = ctx.import_sketches(sk.SketchParams(), [variant])
+        back = wide.export(0)
+        for key in ("seed", "pos", "ctgcanon", "markers", "contig_lengths"):
+            assert np.array_equal(back[key], variant[key]), key
+        for refs, queries in ((wide, None), (wide, one), (one, wide)):
+            r, st = ctx.chain_pairs(refs, queries, [0], [0], sk.MapParams(), stats=True)
+            assert r["ani"][0] in (r0["ani"][0], -1.0)                               # (-1: the aligned fraction of a 2 Gbp "genome" is below min_af)
+            assert st["n_anchors"][0] == s0["n_anchors"][0] and st["anchor_checksum"][0] == s0["anchor_checksum"][0]
+            assert st["n_chunks"][0] == s0["n_chunks"][0] and st["n_accepted"][0] == s0["n_accepted"][0]
 
 
 def case_database_formats(ctx, tmp):

@@ -8,9 +8,19 @@ from tests import parity_cases as pc
 from tests.emu_lib import emu_lib
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = sk.Context(0, lib=emu_lib())
+@pytest.fixture(scope="module", params=["narrow", "wide"])
+def ctx(request):
+    """Every case runs twice: with ordinary sketch sets, and with SKH_TUNE_WIDE_SPAN=0, which makes every sketch set a wide one (64-bit coordinates:
+    the path of genomes beyond 2^31 padded bases, include/skani_hip.h skh_sketch_is_wide).  Tunables are read when the context is made."""
+    import os
+    if request.param == "wide": os.environ["SKH_TUNE_WIDE_SPAN"] = "0"
+    try:
+        c = sk.Context(0, lib=emu_lib())
+    finally:
+        os.environ.pop("SKH_TUNE_WIDE_SPAN", None)
+    probe = c.sketch_records([[("a", pc.random_genome(3000, 1))]], sk.SketchParams(), ["a.fa"])
+    assert probe.wide == (request.param == "wide")
+    probe.close()
     yield c
     c.close()
 

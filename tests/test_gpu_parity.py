@@ -282,6 +282,110 @@ def test_long_genome_pair(ctx):
     assert int(st[0]["n_chunks"]) > 1024 and 0.96 < res[0]["ani"] < 0.98
 
 
+def _wide_context(monkeypatch, span):
+    monkeypatch.setenv("SKH_TUNE_WIDE_SPAN", str(span))
+    return sk.Context(0)
+
+
+def test_wide_sets_forced(monkeypatch):
+    """SKH_TUNE_WIDE_SPAN=0 makes every sketch set a wide one -- the 64-bit coordinate path of genomes beyond 2^31 padded bases (include/skani_hip.h
+    skh_sketch_is_wide): position indices in the tables and the join, widen_anchors_kernel, the 64-bit instantiations of the chunking, the sweep DP,
+    the interval emission and the chunk statistics.  The parity cases must not notice."""
+    import importlib.util, os
+    c = _wide_context(monkeypatch, 0)
+    try:
+        probe = c.sketch_records([[("a", pc.random_genome(3000, 1))]], sk.SketchParams(), ["a.fa"])
+        assert probe.wide
+        pc.case_triangle_synthetic(c, params=((1, 125), (0, 30), (1, 8)), length=120000)
+        pc.case_pinned_triples(c)
+        pc.case_w_vs_w(c)
+        pc.case_fragmented_genomes(c)
+        pc.case_degenerate_pairs(c)
+        pc.case_large_pair(c)
+        pc.case_search_resident_db(c)
+        pc.case_edge_cases_and_errors(c)
+        spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+        fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+        rng = np.random.default_rng(77)
+        assert sum(fz.one_round(c, rng, r) for r in range(15)) > 100
+    finally:
+        c.close()
+
+
+def test_wide_set_meets_ordinary_sets(monkeypatch):
+    """A threshold between the genome sizes: the set of the long genomes is wide, the set of the short ones is not, and pairs across the two sets
+    (either one as the reference) take the mixed path -- one side's anchors carry position indices, the other's coordinates."""
+    from tests.helpers import random_genome, mutate, ora
+    c = _wide_context(monkeypatch, 300000)
+    try:
+        root = random_genome(400000, 5)
+        longs = [[("l%d" % i, mutate(root, 0.02 + 0.01 * i, 40 + i))] for i in range(3)]
+        shorts = [[("s%d" % i, mutate(root[50000 * i:50000 * i + 150000], 0.03, 50 + i)), ("t%d" % i, mutate(root[300000:340000], 0.01, 60 + i))] for i in range(3)]
+        ln, sn = ["long%d.fa" % i for i in range(3)], ["short%d.fa" % i for i in range(3)]
+        L = c.sketch_records(longs, sk.SketchParams(), ln); S = c.sketch_records(shorts, sk.SketchParams(), sn)
+        assert L.wide and not S.wide
+        ol = [ora.sketch_records(x, file_name=ln[i]) for i, x in enumerate(longs)]; os_ = [ora.sketch_records(x, file_name=sn[i]) for i, x in enumerate(shorts)]
+        pr, pq = np.repeat(np.arange(3), 3), np.tile(np.arange(3), 3)
+        for refs, queries, o_r, o_q in ((L, S, ol, os_), (S, L, os_, ol), (L, None, ol, ol)):
+            res, st = c.chain_pairs(refs, queries, pr, pq, sk.MapParams(compute_ci=True), stats=True)
+            for x in range(9):
+                o, so = ora.chain_seeds(o_r[pr[x]], o_q[pq[x]], stats=True)
+                pc.assert_result_close(res[x], o, (int(pr[x]), int(pq[x])))
+                assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["anchor_checksum"])) == \
+                    (so.n_intervals, so.n_accepted, so.n_chunks, so.anchor_checksum)
+    finally:
+        c.close()
+
+
+def test_fragmented_genomes_beyond_31_bits(ctx):
+    """No tunable here: two assemblies of 270,000 contigs of 600 bases are 162 Mbp of sequence but 2.37 G padded bases (8192 per contig), past the 31 bits
+    of an ordinary set's coordinates.  Round 2 refused them; now the set is wide and the pair chains like any other."""
+    from tests.helpers import big_random_genome, big_mutate, ora
+    n_ctg, ln = 270000, 600
+    a = big_random_genome(n_ctg * ln, 31); b = big_mutate(a, 0.02, 32)
+    g = [[("c%d" % i, x[i * ln:(i + 1) * ln].tobytes()) for i in range(n_ctg)] for x in (a, b)]
+    names = ["frag0.fa", "frag1.fa"]
+    ss = ctx.sketch_records(g, sk.SketchParams(), names)
+    assert ss.wide
+    osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]
+    pc.assert_sketch_equal(ss, 1, osk[1])
+    res, st = ctx.chain_pairs(ss, None, [0, 1], [1, 0], sk.MapParams(compute_ci=True), stats=True)
+    for x, (i, j) in enumerate(((0, 1), (1, 0))):
+        o, so = ora.chain_seeds(osk[i], osk[j], stats=True)
+        pc.assert_result_close(res[x], o, (i, j))
+        assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["n_estimates"]), int(st[x]["anchor_checksum"])) == \
+            (so.n_intervals, so.n_accepted, so.n_chunks, so.n_estimates, so.anchor_checksum)
+
+
+def test_genome_pair_beyond_2_gbp(ctx):
+    """A 2.3 Gbp genome in three contigs against its copy at 1 % divergence, and against a 3 Mbp piece of itself kept in an ordinary set: coordinates
+    beyond 2^31 in the seeding, the tables, the join, the chaining and the statistics; 115,000 chunks in one pair."""
+    from tests.helpers import big_random_genome, big_mutate, ora
+    total = 2_300_000_000
+    a = big_random_genome(total, 71); b = big_mutate(a, 0.01, 72)
+    cuts = [0, 900_000_000, 1_700_000_000, total]
+    g = [[("chr%d" % i, x[cuts[i]:cuts[i + 1]].tobytes()) for i in range(3)] for x in (a, b)]
+    piece = [[("p", a[2_200_000_000:2_203_000_000].tobytes())]]
+    del a, b
+    names = ["giant0.fa", "giant1.fa"]
+    ss = ctx.sketch_records(g, sk.SketchParams(), names); small = ctx.sketch_records(piece, sk.SketchParams(), ["piece.fa"])
+    assert ss.wide and not small.wide
+    osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]; op = ora.sketch_records(piece[0], file_name="piece.fa")
+    del g
+    pc.assert_sketch_equal(ss, 1, osk[1])
+    res, st = ctx.chain_pairs(ss, None, [0], [1], sk.MapParams(compute_ci=True), stats=True)
+    o, so = ora.chain_seeds(osk[0], osk[1], stats=True)
+    pc.assert_result_close(res[0], o, (0, 1))
+    assert (int(st[0]["n_intervals"]), int(st[0]["n_accepted"]), int(st[0]["n_chunks"]), int(st[0]["n_estimates"]), int(st[0]["anchor_checksum"])) == \
+        (so.n_intervals, so.n_accepted, so.n_chunks, so.n_estimates, so.anchor_checksum)
+    assert int(st[0]["n_chunks"]) > 100000 and 0.985 < res[0]["ani"] < 0.995
+    for refs, queries, o_r, o_q in ((ss, small, osk[1], op), (small, ss, op, osk[1])):
+        res, st = ctx.chain_pairs(refs, queries, [1 if refs is ss else 0], [0 if refs is ss else 1], sk.MapParams(), stats=True)
+        o, so = ora.chain_seeds(o_r, o_q, stats=True)
+        pc.assert_result_close(res[0], o, (0, 0))
+        assert (int(st[0]["n_accepted"]), int(st[0]["n_chunks"]), int(st[0]["anchor_checksum"])) == (so.n_accepted, so.n_chunks, so.anchor_checksum)
+
+
 def test_randomised_differential(ctx):
     """tools/fuzz_parity.py: random genomes with duplications, inversions, N runs, many contigs; random c / k / m / seeding mode /
     estimator options; sketches, screens and every chaining stage against the oracle (600 rounds = 11,106 pairs were run clean
