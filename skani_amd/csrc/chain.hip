@@ -165,7 +165,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
 
     const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~30 B of scratch each)
     const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (up to 8 KiB of hit records each)
-    auto pow2_at_least = [](uint32_t x) { uint32_t n = 1; while (n < x) n <<= 1; return n; };
+    const uint32_t big_min = std::max<uint32_t>(2, std::min<uint32_t>(ctx->tune.greedy_big_min, GREEDY_LDS + 1));   // candidate intervals from which a pair takes greedy_big_kernel
     std::vector<uint32_t> pair_anch(NP), pair_inq(NP);
     uint32_t sp0 = 0;
     while (sp0 < NP) {
@@ -240,7 +240,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             pa0[i + 1] = pa0[i] + an;
             pc0[i + 1] = pc0[i] + (an ? std::min(job.chunk_bound[p0 + i], an) : 0);
             const uint32_t icap = an / MIN_ANCHORS;
-            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap > GREEDY_LDS ? pow2_at_least(icap) : 0);
+            pi0[i + 1] = pi0[i] + icap; ps0[i + 1] = ps0[i] + (icap >= big_min ? icap : 0);   // candidate slots of greedy_big_kernel's scratch
+            if (ps0[i + 1] < ps0[i]) throw Error("too many candidate intervals in one chain batch");
         }
         const uint32_t NC = pc0[np], NI = pi0[np], NS = ps0[np];
         // one upload for the four arrays (each copy behind the fill pass is a launch of its own)
@@ -264,7 +265,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         check_launch("chunk");
         tr.mark("chunk");
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
-        uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* sorted_glob = ctx->arena.get<uint32_t>(NS + 1);
+        uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* greedy_scratch = ctx->arena.get<uint32_t>((size_t)NS * GREEDY_BIG_WORDS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
         dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
         const EmitCtxT<W> ec{anc_q, anc_r, d_pairs, d_wide, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
@@ -308,7 +309,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             }
         }
 #define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, np, 64, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
-                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, ctx->tune.greedy_len_limit, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
+                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, ctx->tune.greedy_len_limit, big_min, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
         tr.mark("dp (+order sort)");
         uint32_t* g_keys = ctx->arena.get<uint32_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
         SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);
@@ -316,9 +317,14 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         sort_pairs_u32_u32(ctx, g_keys, g_order, np, 16);
         SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
 #undef SKH_GREEDY
-        SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
-                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, sorted_glob, ivl_next, chunk_head, n_acc);
+        SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0,
+                   (const uint32_t*)ivl_cnt, (const Interval*)ivls, big_min, ivl_next, chunk_head, n_acc);
         check_launch("greedy");
+        if (NS) {                                                                     // the batch has a pair that may reach big_min candidates
+            SKH_LAUNCH(greedy_big_kernel, np, 1024, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_ps0, (const uint32_t*)d_pc0,
+                       (const uint32_t*)ivl_cnt, (const Interval*)ivls, big_min, greedy_scratch, ivl_next, chunk_head, n_acc);
+            check_launch("greedy_big");
+        }
         tr.mark("greedy");
         double* chunk_est = ctx->arena.get<double>(NC + 1); uint32_t* chunk_w = ctx->arena.get<uint32_t>(NC + 1);
         uint4* chunk_sums = ctx->arena.get<uint4>(NC + 1);
@@ -335,10 +341,13 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         FinalizeScratch fs{ctx->arena.get<double>(NC + 1), ctx->arena.get<double>(NC + 1), ctx->arena.get<uint32_t>(NC + 1), ctx->arena.get<uint32_t>(NC + 1),
                            ctx->arena.get<uint64_t>(NC + 1)};
         uint32_t* n_est = ctx->arena.get<uint32_t>(np);
-#define SKH_FIN(CAP, MIN) SKH_LAUNCH((finalize_kernel<CAP, MIN>), np, FIN_THREADS, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
+#define SKH_FIN(CAP, MIN, MAX, THR) SKH_LAUNCH((finalize_kernel<CAP, MIN, MAX, THR>), np, THR, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
                    (const double*)chunk_est, (const uint32_t*)chunk_w, (const uint4*)chunk_sums, fs, n_est, d_out + p0); \
         check_launch("finalize")
-        SKH_FIN(320, 0); SKH_FIN(1024, 321);
+        SKH_FIN(320, 0, 320, FIN_THREADS); SKH_FIN(1024, 321, 1024, FIN_THREADS);
+        bool any_long = false;                                                        // a pair that may have more than 1024 chunks: the global-memory instantiation
+        for (uint32_t i = 0; i < np && !any_long; i++) any_long = pc0[i + 1] - pc0[i] > 1024;
+        if (any_long) { SKH_FIN(1, 1025, 0xFFFFFFFFu, 1024); }
 #undef SKH_FIN
         tr.mark("finalize");
         if (stats) {   // parity/debug path: pull the stage sizes (and the anchors, for the checksum) back to the host

@@ -43,8 +43,8 @@ constexpr uint32_t FIN_WAVES = 2, FIN_THREADS = 64 * FIN_WAVES;   // measured on
 // with four pairs (one wave each) per workgroup the 45 KB of LDS held the kernel at 2.4 waves per SIMD for 1.0 ms; the rank sort and the 100 bootstrap resamples -- 9/10 of the
 // instructions -- are independent per element / per resample and are dealt to the waves, the short sequential steps run on wave 0 or
 // redundantly on every wave (same operations in the same order: the same bits).
-template <uint32_t FIN_LDS, uint32_t FIN_MIN>
-__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
+template <uint32_t FIN_LDS, uint32_t FIN_MIN, uint32_t FIN_MAX, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void finalize_kernel(FinalizeArgs fa, const PairDesc* pairs, const uint32_t* pc0, const uint32_t* n_chunks,
                                                        const double* chunk_est, const uint32_t* chunk_w, const uint4* chunk_sums, FinalizeScratch fs,
                                                        uint32_t* n_est_out, skh_ani_result* out) {
     __shared__ double lds_boot[128];
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, 
     const uint32_t l = lane_id();
     const PairDesc pd = pairs[p];
     const uint32_t C0 = pc0[p], nc = n_chunks[p];
-    if (nc < FIN_MIN || (FIN_LDS < 1024 && nc > FIN_LDS)) return;                   // the other instantiation's pair
+    if (nc < FIN_MIN || nc > FIN_MAX) return;                                       // another instantiation's pair
+    constexpr uint32_t WAVES = THREADS / 64;
     const bool in_lds = nc <= FIN_LDS;
     double* U = in_lds ? lds_u : fs.u_est + C0; uint32_t* UW = in_lds ? lds_uw : fs.u_w + C0;
     double* S = in_lds ? lds_s : fs.s_est + C0; uint32_t* SW = in_lds ? lds_sw : fs.s_w + C0;
@@ -87,8 +88,34 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, 
         if (tid == 0) out[p] = res;
         return;
     }
-    // 2. ascending sort by (estimate, weight) by rank counting (chain.rs:414): one element per thread
-    for (uint32_t i = tid; i < n; i += FIN_THREADS) {
+    // 2. ascending sort by (estimate, weight) (chain.rs:414).  In LDS by rank counting, one element per thread.  The instantiation for pairs beyond
+    //    the LDS arrays (a 2.3 Gbp pair has 115,000 chunks: counting ranks took 11 s) sorts in global memory with a bitonic network whose comparators
+    //    all point the same way -- any n, no padding; elements equal in both fields are interchangeable, so no index is carried.
+    if (!in_lds) {
+        unsigned long long* SB = (unsigned long long*)S;                            // (estimates are non-negative: their bit patterns order like the values)
+        for (uint32_t i = tid; i < n; i += THREADS) { const double d = U[i]; unsigned long long bits; memcpy(&bits, &d, 8); __atomic_store_n(&SB[i], bits, __ATOMIC_RELAXED); __atomic_store_n(&SW[i], UW[i], __ATOMIC_RELAXED); }
+        block_fence(); __syncthreads();
+        uint32_t N = 1; while (N < n) N <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t x) {                                // i < x: the smaller element to i
+            if (x >= n) return;
+            const unsigned long long ea = __atomic_load_n(&SB[i], __ATOMIC_RELAXED), eb = __atomic_load_n(&SB[x], __ATOMIC_RELAXED);
+            if (eb > ea) return;
+            const uint32_t wa = __atomic_load_n(&SW[i], __ATOMIC_RELAXED), wb = __atomic_load_n(&SW[x], __ATOMIC_RELAXED);
+            if (eb == ea && wb >= wa) return;
+            __atomic_store_n(&SB[i], eb, __ATOMIC_RELAXED); __atomic_store_n(&SW[i], wb, __ATOMIC_RELAXED);
+            __atomic_store_n(&SB[x], ea, __ATOMIC_RELAXED); __atomic_store_n(&SW[x], wa, __ATOMIC_RELAXED);
+        };
+        for (uint32_t kk = 2; kk <= N; kk <<= 1) {
+            const uint32_t hk = kk >> 1;
+            for (uint32_t t = tid; t < N / 2; t += THREADS) { const uint32_t blk = t / hk, off = t % hk; exchange(blk * kk + off, blk * kk + (kk - 1u - off)); }
+            block_fence(); __syncthreads();
+            for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < N / 2; t += THREADS) { const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)); exchange(i, i | j); }
+                block_fence(); __syncthreads();
+            }
+        }
+    } else
+    for (uint32_t i = tid; i < n; i += THREADS) {
         const double e = U[i]; const uint32_t w = UW[i];
         uint32_t rank = 0;
 #pragma unroll 4
@@ -152,13 +179,13 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, 
             uint32_t* C32 = UW; uint32_t* T = (uint32_t*)U;
             uint32_t sh = 0; while ((total_mult >> sh) >= 512) sh++;
             const uint32_t nb = (uint32_t)(total_mult >> sh) + 1;                      // x < total_mult  =>  x >> sh < nb <= 512
-            for (uint32_t i = tid; i < n; i += FIN_THREADS) C32[i] = (uint32_t)CUM[i];
-            for (uint32_t b = tid; b < nb; b += FIN_THREADS) T[b] = search64((uint64_t)b << sh) | (search64((uint64_t)(b + 1) << sh) << 16);   // past-the-end thresholds give n-1
+            for (uint32_t i = tid; i < n; i += THREADS) C32[i] = (uint32_t)CUM[i];
+            for (uint32_t b = tid; b < nb; b += THREADS) T[b] = search64((uint64_t)b << sh) | (search64((uint64_t)(b + 1) << sh) << 16);   // past-the-end thresholds give n-1
             __syncthreads();
             const uint32_t tot32 = (uint32_t)total_mult;
             const uint64_t step_it = (uint64_t)n * WYRAND_STEP, step_256 = 256ull * WYRAND_STEP;
-            // resamples in groups of four: the four wave reductions (six dependent shuffle steps each) then run interleaved; group q -> wave q mod FIN_WAVES
-            for (uint32_t it0 = 4 * wv; it0 < 100; it0 += 4 * FIN_WAVES) {
+            // resamples in groups of four: the four wave reductions (six dependent shuffle steps each) then run interleaved; group q -> wave q mod WAVES
+            for (uint32_t it0 = 4 * wv; it0 < 100; it0 += 4 * WAVES) {
               // generator states of this lane's draws j = l + 64 u (+ 256 m) of resample `it0`: a pure function of the draw number it0 * n + j;
               // advanced by n steps per resample instead of being recomputed (a 64-bit multiply per draw)
               uint64_t st[4];
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, 
               }
             }
         } else {
-            for (uint32_t it = wv; it < 100; it += FIN_WAVES) {
+            for (uint32_t it = wv; it < 100; it += WAVES) {
                 double s = 0.;
                 for (uint32_t j0 = l; j0 < n; j0 += 64) {
                     const uint64_t r = wyrand_draw((uint64_t)it * n + j0);
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinalizeArgs fa, 
         if (res.q50_r > res.q50_q) { x[2] = res.q90_r; x[3] = res.q90_q; } else { x[2] = res.q90_q; x[3] = res.q90_r; }
         float* leaf = (float*)lds_boot;                                             // 256 floats
         __syncthreads();                                                            // (every thread has read its interval bounds from lds_boot)
-        for (uint32_t t = tid; t < fa.n_trees && t < 256; t += FIN_THREADS) {
+        for (uint32_t t = tid; t < fa.n_trees && t < 256; t += THREADS) {
             const GbdtModel::Node* nd = fa.nodes + fa.tree_off[t]; int32_t i = 0;
             while (nd[i].feat >= 0) {
                 const int32_t ft = nd[i].feat;

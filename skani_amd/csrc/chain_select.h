@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs
 }
 template <uint32_t CAP>
 __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
-                                                         const Interval* ivls, uint32_t len_limit, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+                                                         const Interval* ivls, uint32_t len_limit, uint32_t big_min, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ __attribute__((aligned(16))) AccIvl acc[CAP];          // accepted intervals; the sort keys (8 B each) borrow this space first
     __shared__ uint16_t idx[CAP];                                     // the candidates in sorted order
     __shared__ __attribute__((aligned(4))) uint16_t qh[GREEDY_BUCKETS], rh[GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
-    if (n > GREEDY_FAST || n > CAP || (CAP > 256 && n <= CAP / 2)) return;          // another instantiation's (or greedy_kernel's) pair
+    if (n > GREEDY_FAST || n > CAP || (CAP > 256 && n <= CAP / 2) || n >= big_min) return;   // another instantiation's (or greedy_kernel's / greedy_big_kernel's) pair
     if (n == 0) { if (l == 0) n_accepted[p] = 0; return; }
     uint32_t N = 1; while (N < n) N <<= 1;
     unsigned long long* key = (unsigned long long*)acc;
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const
     if (l == 0) n_accepted[p] = nacc;
 }
 
-// Fallback for pairs with more than GREEDY_FAST candidate intervals, and for those the fast kernel handed over: one wave per pair: bitonic-sort the pair's candidate
-// interval indices into DESCENDING tuple order (chain.rs:1012), then accept greedily (chain.rs:1017-1095).  An accepted
-// interval is flagged in bit 31 of its sorted slot and pushed on its chunk's list.
-__global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
-                                                     const Interval* ivls, uint32_t* sorted_glob, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+// Fallback for pairs with GREEDY_FAST < n <= GREEDY_LDS candidate intervals, and for those the fast kernel handed over: one wave per pair: bitonic-sort the pair's candidate
+// interval indices into DESCENDING tuple order (chain.rs:1012), then accept greedily (chain.rs:1017-1095), every candidate against all accepted
+// ones.  An accepted interval is flagged in bit 31 of its sorted slot and pushed on its chunk's list.  (Pairs beyond GREEDY_LDS: greedy_big_kernel.)
+__global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                     const Interval* ivls, uint32_t big_min, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
     __shared__ uint32_t lds_idx[4][GREEDY_LDS];
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
     const uint32_t l = lane_id();
     const uint32_t I0 = pi0[p];
     uint32_t n = ivl_cnt[p]; const uint32_t cap = pi0[p + 1] - I0; if (n > cap) n = cap;
+    if (n >= big_min) return;                                                       // greedy_big_kernel's pair
     if (n <= GREEDY_FAST && n_accepted[p] != GREEDY_REDO) return;                   // done by greedy_fast_kernel (which writes n_accepted for every pair it is given)
-    uint32_t N = 1; while (N < n) N <<= 1;                                          // ps0 reserves pow2(cap) >= N slots per pair
-    uint32_t* idx = N <= GREEDY_LDS ? lds_idx[wv] : sorted_glob + ps0[p];
+    uint32_t N = 1; while (N < n) N <<= 1;                                          // n < big_min <= GREEDY_LDS + 1
+    uint32_t* idx = lds_idx[wv];
     const Interval* iv = ivls + I0;
     for (uint32_t i = l; i < N; i += 64) idx[i] = i < n ? i : NONE;
     wave_sync_mem();
@@ -253,6 +254,129 @@ __global__ __launch_bounds__(256) void greedy_kernel(uint32_t n_pairs, const uin
             }
             nacc++;
         }
+        wave_sync_mem();
+    }
+    if (l == 0) n_accepted[p] = nacc;
+}
+
+// Pairs with GREEDY_LDS or more candidate intervals (a 2.3 Gbp genome against its relative: 130,000): one workgroup per pair, everything in a global
+// scratch area of GREEDY_BIG_WORDS words per candidate.  (greedy_kernel's every-candidate-against-every-accepted-one walk took 105 s for that pair.)
+//   1. all 1024 threads sort (key, candidate) records into the reference's order (chain.rs:1012) with a bitonic network whose comparators all point
+//      the same way, so that any n works without padding; key = the leading fields of the tuple, inverted; equal keys compare the whole tuple;
+//   2. wave 0 accepts greedily (chain.rs:1017-1095) 64 candidates at a time like greedy_fast_kernel.  The accepted intervals a candidate can overlap
+//      are found through lists: on the query axis its chunk's list -- the output list itself (chunk_head / ivl_next) --, on the reference axis the
+//      lists of the GREEDY_BIN-sized bins it touches (heads hashed by (contig, bin), one head per candidate slot), plus a list of the accepted
+//      intervals spanning more than two bins.  Lists are written with atomics and read past the L1.
+constexpr uint32_t GREEDY_BIG_WORDS = 8;        // per candidate slot: record (key, candidate: 4 words) | bin-list links (2) | a bin-list head | a long-list entry
+__device__ __forceinline__ uint32_t greedy_big_bucket(uint32_t rctg, uint32_t bin, uint32_t H) { return (uint32_t)(((uint64_t)(rctg * 0x9E3779B1u) + bin) % H); }   // consecutive bins -> different buckets
+__global__ __launch_bounds__(1024) void greedy_big_kernel(uint32_t n_pairs, const uint32_t* pi0, const uint32_t* ps0, const uint32_t* pc0, const uint32_t* ivl_cnt,
+                                                          const Interval* ivls, uint32_t big_min, uint32_t* scratch, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {
+    const uint32_t p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t I0 = pi0[p], cap = pi0[p + 1] - I0;
+    uint32_t n = ivl_cnt[p]; if (n > cap) n = cap;
+    if (n < big_min) return;
+    const uint32_t tid = threadIdx.x, l = tid & 63u, NT = blockDim.x;
+    const Interval* iv = ivls + I0;
+    uint32_t* area = scratch + (size_t)ps0[p] * GREEDY_BIG_WORDS;
+    unsigned long long* rec = (unsigned long long*)area;                             // 2 per slot: inverted key, candidate
+    uint32_t* rn0 = area + 4 * (size_t)cap; uint32_t* rn1 = rn0 + cap; uint32_t* rhd = rn1 + cap; uint32_t* lng = rhd + cap;
+    const uint32_t H = cap;
+    auto ld32 = [](const uint32_t* q) { return __atomic_load_n(q, __ATOMIC_RELAXED); };
+    auto ld64 = [](const unsigned long long* q) { return __atomic_load_n(q, __ATOMIC_RELAXED); };
+    for (uint32_t i = tid; i < n; i += NT) {
+        const Interval e = iv[i];
+        const unsigned long long k = ((unsigned long long)e.score << 40) | ((unsigned long long)(e.na & 0xFFFFFu) << 20) | (e.q0 >> 12);
+        __atomic_store_n(&rec[2 * (size_t)i], ~k, __ATOMIC_RELAXED); __atomic_store_n(&rec[2 * (size_t)i + 1], (unsigned long long)i, __ATOMIC_RELAXED);
+    }
+    for (uint32_t i = tid; i < H; i += NT) __atomic_store_n(&rhd[i], NONE, __ATOMIC_RELAXED);
+    block_fence();
+    __syncthreads();
+    // ---- 1. sort
+    uint32_t N = 1; while (N < n) N <<= 1;
+    auto exchange = [&](uint32_t i, uint32_t x) {                                    // i < x: the smaller record to i
+        if (x >= n) return;
+        const unsigned long long ka = ld64(&rec[2 * (size_t)i]), kb = ld64(&rec[2 * (size_t)x]);
+        if (kb > ka) return;
+        const unsigned long long a = ld64(&rec[2 * (size_t)i + 1]), b = ld64(&rec[2 * (size_t)x + 1]);
+        if (kb == ka && ivl_cmp(iv[b], iv[a]) <= 0) return;                          // descending tuples: b goes first only when it is the greater one
+        __atomic_store_n(&rec[2 * (size_t)i], kb, __ATOMIC_RELAXED); __atomic_store_n(&rec[2 * (size_t)i + 1], b, __ATOMIC_RELAXED);
+        __atomic_store_n(&rec[2 * (size_t)x], ka, __ATOMIC_RELAXED); __atomic_store_n(&rec[2 * (size_t)x + 1], a, __ATOMIC_RELAXED);
+    };
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = tid; t < N / 2; t += NT) { const uint32_t blk = t / hk, off = t % hk; exchange(blk * k + off, blk * k + (k - 1u - off)); }   // the mirrored step
+        block_fence(); __syncthreads();
+        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < N / 2; t += NT) { const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)); exchange(i, i | j); }
+            block_fence(); __syncthreads();
+        }
+    }
+    if (tid >= 64) return;
+    // ---- 2. greedy acceptance (wave 0)
+    uint32_t nacc = 0, nlong = 0;
+    const uint32_t C0 = pc0[p];
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t s = base + l; const bool have = s < n;
+        const uint32_t ci = have ? (uint32_t)ld64(&rec[2 * (size_t)s + 1]) : 0u;
+        const Interval c = iv[ci];
+        uint32_t sum_r = 0, sum_q = 0, cnt_r = 0, cnt_q = 0;
+        auto add_r = [&](const Interval& a) {                                      // chain.rs:1030-1045
+            const bool hr = a.rctg == c.rctg && a.r0 < c.r1 && c.r0 < a.r1;
+            const uint32_t xr = c.r1 - a.r0, yr = a.r1 - c.r0;
+            cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+        };
+        auto add_q = [&](const Interval& a) {                                      // chain.rs:1059-1073 (the chunk's list: same query contig)
+            const bool hq = a.q0 < c.q1 && c.q0 < a.q1;
+            const uint32_t xq = c.q1 - a.q0, yq = a.q1 - c.q0;
+            cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+        };
+        const uint32_t c0 = c.r0 >> GREEDY_BIN_SHIFT, c1 = greedy_last_bin(c.r0, c.r1);
+        if (have) {
+            for (uint32_t e = ld32(&chunk_head[C0 + c.chunk]); e != NONE; e = ld32(&ivl_next[e])) add_q(ivls[e]);
+            for (uint32_t x = c0; x <= c1; x++) {
+                const uint32_t h = greedy_big_bucket(c.rctg, x, H);
+                for (uint32_t a = ld32(&rhd[h]); a != NONE;) {
+                    const Interval e = iv[a];
+                    const uint32_t e0 = e.r0 >> GREEDY_BIN_SHIFT;
+                    const bool first = greedy_big_bucket(e.rctg, e0, H) == h;       // which of the interval's (at most two, consecutive) bins hangs on this head
+                    const uint32_t eb = first ? e0 : e0 + 1u;
+                    if (e.rctg == c.rctg && eb == x && x == (c0 > e0 ? c0 : e0)) add_r(e);   // counted in the bin of max(candidate start, interval start)
+                    a = ld32(first ? &rn0[a] : &rn1[a]);
+                }
+            }
+            for (uint32_t t = 0; t < nlong; t++) add_r(iv[ld32(&lng[t])]);
+        }
+        const uint32_t nb = n - base < 64 ? n - base : 64;
+        bool mine = false;
+        for (uint32_t b = 0; b < nb; b++) {
+            const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+            const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
+            const int okb = wave_readlane((int)((ok_r && ok_q) ? 1 : 0), (int)b);
+            if (!okb) continue;                                                     // wave-uniform
+            if (l == b) mine = true;
+            const uint32_t actg = wave_readlane(c.rctg, (int)b), ar0 = wave_readlane(c.r0, (int)b), ar1 = wave_readlane(c.r1, (int)b);
+            const uint32_t achunk = wave_readlane(c.chunk, (int)b), aq0 = wave_readlane(c.q0, (int)b), aq1 = wave_readlane(c.q1, (int)b);
+            if (l > b) {                                                            // later candidates of this batch see the new accepted interval
+                const bool hr = actg == c.rctg && ar0 < c.r1 && c.r0 < ar1;
+                const bool hq = achunk == c.chunk && aq0 < c.q1 && c.q0 < aq1;
+                const uint32_t xr = c.r1 - ar0, yr = ar1 - c.r0, xq = c.q1 - aq0, yq = aq1 - c.q0;
+                cnt_r += hr ? 1u : 0u; sum_r += hr ? (xr < yr ? xr : yr) : 0u;
+                cnt_q += hq ? 1u : 0u; sum_q += hq ? (xq < yq ? xq : yq) : 0u;
+            }
+        }
+        // the batch's accepted intervals onto their lists, one per lane (the lists' order is free)
+        const bool is_long = mine && c1 - c0 >= 2u;
+        const unsigned long long ml = __ballot(is_long);
+        if (mine) {
+            __atomic_store_n(&ivl_next[I0 + ci], atomicExch(&chunk_head[C0 + c.chunk], I0 + ci), __ATOMIC_RELAXED);   // good_non_overlap_intervals[chunk_id].push (chain.rs:1086-1094)
+            if (is_long) __atomic_store_n(&lng[nlong + (uint32_t)__popcll(ml & ((1ull << l) - 1ull))], ci, __ATOMIC_RELAXED);
+            else {
+                __atomic_store_n(&rn0[ci], atomicExch(&rhd[greedy_big_bucket(c.rctg, c0, H)], ci), __ATOMIC_RELAXED);
+                if (c1 > c0) __atomic_store_n(&rn1[ci], atomicExch(&rhd[greedy_big_bucket(c.rctg, c1, H)], ci), __ATOMIC_RELAXED);
+            }
+        }
+        nlong += (uint32_t)__popcll(ml); nacc += (uint32_t)__popcll(__ballot(mine));
         wave_sync_mem();
     }
     if (l == 0) n_accepted[p] = nacc;

@@ -62,6 +62,7 @@ struct skh_tunables {
     uint32_t marker_lds_max = 0;                        // raw markers per genome the in-LDS marker-set kernel takes (0 = 8192; tests use few to force the device-wide path)
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
     uint32_t greedy_len_limit = 0x10000;               // chain intervals at least this long on either axis send their pair to the general selection kernel (tests use a small value to drive that hand-over)
+    uint32_t greedy_big_min = 2049;                    // candidate intervals from which a pair's selection runs in global memory (greedy_big_kernel); tests use small values
     uint32_t dist_fail = 0;                             // tests: the n-th local phase of a distributed triangle fails on this rank (0 = never)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
     uint64_t wide_span = (1ull << 31) - 8192;           // a genome of at least this many padded bases makes its sketch set "wide" (tests use small values to run everything through the 64-bit path)

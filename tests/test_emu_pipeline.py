@@ -60,11 +60,30 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_MARKER_LDS_MAX", "40")                 # genomes with more than 40 raw markers: marker sets by the device-wide passes
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
     monkeypatch.setenv("SKH_TUNE_GREEDY_LEN_LIMIT", "3000")             # pairs with a chain interval of 3 kb or more are handed from the all-LDS selection kernel to the general one
+    monkeypatch.setenv("SKH_TUNE_GREEDY_BIG_MIN", "4")                  # pairs with four or more candidate intervals select in global memory (greedy_big_kernel)
     c = sk.Context(0, lib=emu_lib())
     try:
         pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
         pc.case_screen_rules(c)
         pc.case_seeding_fixtures(c)
+    finally:
+        c.close()
+
+
+def test_emu_selection_in_global_memory(monkeypatch):
+    """SKH_TUNE_GREEDY_BIG_MIN=2: every pair with two or more candidate intervals selects its chains with greedy_big_kernel (the kernel of pairs with
+    thousands of candidates: its sort, its bin lists and its long-interval list in global memory)."""
+    import importlib.util, os
+    monkeypatch.setenv("SKH_TUNE_GREEDY_BIG_MIN", "2")
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        pc.case_large_pair(c)
+        pc.case_fragmented_genomes(c)
+        pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=150000)
+        spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+        fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+        rng = np.random.default_rng(99)
+        assert sum(fz.one_round(c, rng, r) for r in range(6)) > 30
     finally:
         c.close()
 

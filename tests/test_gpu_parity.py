@@ -254,12 +254,32 @@ def test_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_MARKER_LDS_MAX", "40")                 # genomes with more than 40 raw markers: marker sets by the device-wide passes
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
     monkeypatch.setenv("SKH_TUNE_GREEDY_LEN_LIMIT", "3000")             # pairs with a chain interval of 3 kb or more are handed from the all-LDS selection kernel to the general one
+    monkeypatch.setenv("SKH_TUNE_GREEDY_BIG_MIN", "4")                  # pairs with four or more candidate intervals select in global memory (greedy_big_kernel)
     c = sk.Context(0)
     try:
         pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
         pc.case_screen_rules(c)
         pc.case_seeding_fixtures(c)
         pc.case_w_vs_w(c)
+    finally:
+        c.close()
+
+
+def test_selection_in_global_memory(monkeypatch):
+    """SKH_TUNE_GREEDY_BIG_MIN=2: every pair with two or more candidate intervals selects its chains with greedy_big_kernel (the kernel of pairs with
+    thousands of candidates: its sort, its bin lists and its long-interval list in global memory)."""
+    import importlib.util, os
+    monkeypatch.setenv("SKH_TUNE_GREEDY_BIG_MIN", "2")
+    c = sk.Context(0)
+    try:
+        pc.case_large_pair(c)
+        pc.case_fragmented_genomes(c)
+        pc.case_w_vs_w(c)
+        pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=150000)
+        spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+        fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+        rng = np.random.default_rng(99)
+        assert sum(fz.one_round(c, rng, r) for r in range(20)) > 100
     finally:
         c.close()
 
@@ -368,19 +388,29 @@ def test_genome_pair_beyond_2_gbp(ctx):
     piece = [[("p", a[2_200_000_000:2_203_000_000].tobytes())]]
     del a, b
     names = ["giant0.fa", "giant1.fa"]
-    ss = ctx.sketch_records(g, sk.SketchParams(), names); small = ctx.sketch_records(piece, sk.SketchParams(), ["piece.fa"])
+    import time
+    t0 = time.time()
+    ss = ctx.sketch_records(g, sk.SketchParams(), names)
+    t_sketch = time.time() - t0
+    small = ctx.sketch_records(piece, sk.SketchParams(), ["piece.fa"])
     assert ss.wide and not small.wide
     osk = [ora.sketch_records(x, file_name=names[i]) for i, x in enumerate(g)]; op = ora.sketch_records(piece[0], file_name="piece.fa")
     del g
     pc.assert_sketch_equal(ss, 1, osk[1])
+    ctx.chain_pairs(ss, None, [0], [1], sk.MapParams(compute_ci=True))
+    t0 = time.time()
+    res = ctx.chain_pairs(ss, None, [0], [1], sk.MapParams(compute_ci=True))
+    t_chain = time.time() - t0
     res, st = ctx.chain_pairs(ss, None, [0], [1], sk.MapParams(compute_ci=True), stats=True)
+    t0 = time.time()
     o, so = ora.chain_seeds(osk[0], osk[1], stats=True)
+    print("2.3 Gbp pair: pack + sketch (host buffers) %.2f s, chain %.3f s on the device; oracle chain_seeds %.2f s on one core" % (t_sketch, t_chain, time.time() - t0))
     pc.assert_result_close(res[0], o, (0, 1))
     assert (int(st[0]["n_intervals"]), int(st[0]["n_accepted"]), int(st[0]["n_chunks"]), int(st[0]["n_estimates"]), int(st[0]["anchor_checksum"])) == \
         (so.n_intervals, so.n_accepted, so.n_chunks, so.n_estimates, so.anchor_checksum)
     assert int(st[0]["n_chunks"]) > 100000 and 0.985 < res[0]["ani"] < 0.995
     for refs, queries, o_r, o_q in ((ss, small, osk[1], op), (small, ss, op, osk[1])):
-        res, st = ctx.chain_pairs(refs, queries, [1 if refs is ss else 0], [0 if refs is ss else 1], sk.MapParams(), stats=True)
+        res, st = ctx.chain_pairs(refs, queries, [1 if refs is ss else 0], [0 if refs is ss else 1], sk.MapParams(compute_ci=True), stats=True)
         o, so = ora.chain_seeds(o_r, o_q, stats=True)
         pc.assert_result_close(res[0], o, (0, 0))
         assert (int(st[0]["n_accepted"]), int(st[0]["n_chunks"]), int(st[0]["anchor_checksum"])) == (so.n_accepted, so.n_chunks, so.anchor_checksum)
