@@ -89,18 +89,24 @@ __global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restr
 // hashes: count per slice in LDS, scan, scatter.  Measured per 1000 genomes: 0.21 ms (0.26 ms with one load in flight per thread).  Variants that
 // were slower: one pass into fixed-capacity lists (0.24 ms), hashes kept in registers + the list assembled in LDS and written out in order
 // (0.27 ms: 80 KB of LDS leave one workgroup per CU) -- the kernel is bound by the latency of its phases, not by its scattered 8-byte writes.
-constexpr uint32_t SLICE_LDS_MAX = 8192;                // slices per genome handled here (16M positions); beyond: the slices re-scan the genome
+// Instantiated for SLICE_LDS_MAX = 8192 slices per genome (8M positions: 32 KB of LDS counters) and, for sets with a larger genome, for SLICE_LDS_BIG = 32768
+// (33M positions, a 4 Gbp genome at c = 125; 128 KB of LDS): launch `SLICES` takes the genomes with min_slices < slices <= max_slices; beyond the last launch's
+// max_slices a genome's slices re-scan all its positions (mark_beyond; 3.9 s for a 2.3 Gbp pair before the second instantiation existed).
+constexpr uint32_t SLICE_LDS_MAX = 8192, SLICE_LDS_BIG = 32768;
 constexpr uint32_t SLICE_NO_LIST = 0xFFFFFFFFu;
+template <uint32_t SLICES>
 __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_hash, const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
-                                                                      const uint32_t* __restrict__ slice_first, uint32_t max_slices, uint32_t* __restrict__ sl_start,
-                                                                      uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice) {
-    __shared__ uint32_t cnt[SLICE_LDS_MAX];
+                                                                      const uint32_t* __restrict__ slice_first, uint32_t min_slices, uint32_t max_slices, uint32_t mark_beyond,
+                                                                      uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice) {
+    SKH_DYN_SMEM(smem);
+    uint32_t* cnt = (uint32_t*)smem;                                                 // SLICES counters
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
     const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
     const uint32_t n_sl = (NB + TAB_SLICE - 1) / TAB_SLICE, s0 = slice_first[g];
-    if (n_sl > max_slices) {                                                         // (max_slices <= SLICE_LDS_MAX)
-        for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) { sl_start[s0 + s] = 0; sl_cnt[s0 + s] = SLICE_NO_LIST; }
+    if (n_sl <= min_slices) return;                                                  // an earlier launch's genome
+    if (n_sl > max_slices) {                                                         // (max_slices <= SLICES)
+        if (mark_beyond) for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) { sl_start[s0 + s] = 0; sl_cnt[s0 + s] = SLICE_NO_LIST; }
         return;
     }
     for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) cnt[s] = 0;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
         for (uint32_t u = 0; u < 4; u++) if (i0 + u * BUILD_THREADS < P) atomicAdd(&cnt[seed_bucket(hh[u], NB) >> TAB_SLICE_SHIFT], 1u);
     }
     __syncthreads();
-    constexpr uint32_t PER_MAX = SLICE_LDS_MAX / BUILD_THREADS;
+    constexpr uint32_t PER_MAX = SLICES / BUILD_THREADS;
     const uint32_t per = (n_sl + BUILD_THREADS - 1) / BUILD_THREADS;                 // consecutive slices per thread
     uint32_t loc[PER_MAX], sum = 0;
 #pragma unroll
@@ -441,8 +447,18 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
         SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
         check_launch("table_blocks");
-        SKH_LAUNCH(slice_positions_kernel, ng, BUILD_THREADS, 0, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
-                   (const uint32_t*)d_nb, (const uint32_t*)d_sf, ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX, d_ss, d_sc, d_ps);
+        {
+            const uint32_t max_a = ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX;
+            uint32_t most = 0; for (uint32_t g = 0; g < ng; g++) most = std::max(most, slice_first[g + 1] - slice_first[g]);
+            const bool second = !ctx->tune.build_slice_max && most > SLICE_LDS_MAX;   // a genome beyond 8M positions: the instantiation with 128 KB of counters takes it
+            SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_MAX>, ng, BUILD_THREADS, SLICE_LDS_MAX * 4, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
+                       (const uint32_t*)d_nb, (const uint32_t*)d_sf, 0u, max_a, second ? 0u : 1u, d_ss, d_sc, d_ps);
+            if (second) {
+                kernel_allow_lds(slice_positions_kernel<SLICE_LDS_BIG>, SLICE_LDS_BIG * 4);
+                SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_BIG>, ng, BUILD_THREADS, SLICE_LDS_BIG * 4, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
+                           (const uint32_t*)d_nb, (const uint32_t*)d_sf, SLICE_LDS_MAX, SLICE_LDS_BIG, 1u, d_ss, d_sc, d_ps);
+            }
+        }
         check_launch("slice_positions");
         if (n_blk) {
             const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
