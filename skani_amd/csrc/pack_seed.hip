@@ -30,8 +30,8 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {   // types.rs:40-49 
 // A thread packs 32 consecutive bases of one contig (a "unit": contigs start on unit boundaries).  Its 32 source bytes are fetched as nine
 // 4-byte-aligned words (two four-word loads and one more; neighbouring lanes read neighbouring 32-byte stretches: coalesced) and shifted into place;
 // base codes, the validity of every byte (types.rs:40-49: anything but ACGTU / acgtu / 0..3 is an A) and the N flags come out of byte-parallel
-// arithmetic on whole words, four bases at a time: 3.9 ms per 4.9 Gbases (round 2's kernel walked its 32 bytes one by one: 9.6 ms; a variant with
-// 16 bases per thread, whose loads cover one contiguous kilobyte per wave, took 5.9 ms -- twice the threads, twice the per-thread contig look-up).
+// arithmetic on whole words, four bases at a time (round 2's kernel walked its 32 bytes one by one: 9.6 ms per 4.9 Gbases; a variant with
+// 16 bases per thread, whose loads cover one contiguous kilobyte per wave, took 5.9 ms against 3.9 -- twice the threads, twice the contig look-ups).
 struct __attribute__((packed, aligned(4))) PackWords4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {                       // 0x80 in every byte of v that is zero (exact, no borrow between bytes)
     return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
@@ -49,50 +49,99 @@ __device__ __forceinline__ uint32_t codes_of_word(uint32_t w) {
     const uint32_t c = (letter & ((is_letter >> 7) * 3u)) | (w & ((is_small >> 7) * 3u));
     return (c * 0x40100401u) >> 24;                                                 // byte 0 -> bits 7..6, byte 1 -> 5..4, byte 2 -> 3..2, byte 3 -> 1..0
 }
+// The same for a word of nothing but A C G T U in either case -- the usual word -- in a third of the instructions: the codes from bits 1..3 of the
+// letters, then the letter each code stands for is rebuilt (0x41 + {0, 2, 6, 19}) and compared with the upper-cased byte; `bad` collects the
+// differences (U differs from the rebuilt T in bit 0, which is let through for code 3 only).  bad != 0 afterwards: some byte of the unit is
+// something else (an N, a digit, a byte 0..3 ...) and the unit is redone with codes_of_word / n_flags_of_word.
+__device__ __forceinline__ uint32_t codes_of_acgtu_word(uint32_t w, uint32_t& bad) {
+    const uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+    const uint32_t b0 = c & 0x01010101u, b1 = (c >> 1) & 0x01010101u, b01 = b0 & b1;
+    const uint32_t letter = 0x41414141u + 2u * b0 + 6u * b1 + 11u * b01;
+    bad |= ((w & 0xDFDFDFDFu) ^ letter) & ~b01;
+    return (c * 0x40100401u) >> 24;
+}
 __device__ __forceinline__ uint32_t n_flags_of_word(uint32_t w, int mode) {         // bit x = base x is an N for the selected seeding path
     uint32_t f = zero_bytes(w ^ 0x4E4E4E4Eu);                                       // 'N': seeding.rs:272-275 and avx2_seeding.rs:115-126
     if (mode == SKH_SEED_SCALAR) f |= zero_bytes(w ^ 0x6E6E6E6Eu);                  // 'n': the scalar path only
     return ((f >> 7) * 0x10204080u) >> 28;
 }
+// A wave packs PACK_ROUNDS x 64 consecutive units, 64 per round.  The contig of its first unit comes from one binary search; from there every lane
+// walks on (contigs have at least 16 units: a step now and then) and keeps its contig's record in registers, so a round is the nine source words, the
+// arithmetic and two stores.  One round per wave -- a search and three dependent look-ups in front of every 2 KB of source -- ran at the latency of those
+// look-ups: 3.9 ms per 4.9 Gbases (1.27 TB/s of ASCII); eight rounds: 2.27 ms, and the kernel then ran at the rate of its ~560 vector instructions per
+// unit (the exact byte table in byte-parallel arithmetic: 55 per word, + 9 for the N flags) -- hence codes_of_acgtu_word for the words that are all letters.
+#ifndef PACK_ROUNDS_N
+#define PACK_ROUNDS_N 8
+#endif
+constexpr uint32_t PACK_ROUNDS = PACK_ROUNDS_N;
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* bases, uint64_t readable_bytes, const uint64_t* src_off, const uint64_t* unit_off,
                                                    ContigDesc* contigs, uint32_t n_contigs, uint64_t n_units, int mode,
                                                    uint32_t* packed, uint32_t* nmask) {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = u < n_units;
-    // the contig of the wave's first unit by binary search, the lanes' own by walking on from it (contigs have at least 16 units: a step or two)
-    const uint64_t u0 = __shfl(u, 0, 64);
+    const uint32_t l = threadIdx.x & 63u;
+    const uint64_t first = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64u * PACK_ROUNDS);   // the wave's first unit
+    if (first >= n_units) return;
     uint32_t lo = 0, hi = n_contigs;
-    if (u0 < n_units) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= u0) lo = mid; else hi = mid; }
-    if (!live) return;
-    uint32_t ci = lo;
-    while (ci + 1 < n_contigs && unit_off[ci + 1] <= u) ci++;
-    const uint64_t b0 = (u - unit_off[ci]) * 32;
-    const uint32_t len = contigs[ci].len;
-    const uint64_t so = src_off[ci] + b0;                                           // first source byte of the unit
-    uint32_t w0 = 0, w1 = 0, m = 0;
-    const uint64_t addr = (uint64_t)(uintptr_t)bases + so; const uint32_t sh = (uint32_t)(addr & 3u);
-    if (b0 + 32 <= len && so - sh + 36 <= readable_bytes) {                         // a whole unit inside the contig, all nine words readable
-        const uint32_t* q = (const uint32_t*)(uintptr_t)(addr - sh);
-        const PackWords4 qa = *(const PackWords4*)q, qb = *(const PackWords4*)(q + 4); const uint32_t q8 = q[8];
-        const uint32_t d[8] = {shift_bytes(qa.y, qa.x, sh), shift_bytes(qa.z, qa.y, sh), shift_bytes(qa.w, qa.z, sh), shift_bytes(qb.x, qa.w, sh),
-                               shift_bytes(qb.y, qb.x, sh), shift_bytes(qb.z, qb.y, sh), shift_bytes(qb.w, qb.z, sh), shift_bytes(q8, qb.w, sh)};
-#pragma unroll
-        for (int j = 0; j < 4; j++) { w0 |= codes_of_word(d[j]) << (24 - 8 * j); w1 |= codes_of_word(d[4 + j]) << (24 - 8 * j); }
-#pragma unroll
-        for (int j = 0; j < 8; j++) m |= n_flags_of_word(d[j], mode) << (4 * j);
-    } else {                                                                        // a contig's last unit(s), the end of the buffer: byte by byte
-        const uint8_t* src = bases + src_off[ci];
-        for (uint32_t x = 0; x < 32; x++) {
-            const uint64_t p = b0 + x;
-            const uint32_t byte = p < len ? src[p] : (uint32_t)'A';
-            const uint32_t code = base_code(byte);
-            const bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
-            if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
-            m |= (is_n ? 1u : 0u) << x;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unit_off[mid] <= first) lo = mid; else hi = mid; }
+    uint32_t ci = lo, cached = 0xFFFFFFFFu, len = 0;
+    uint64_t c_unit = 0, c_next = 0, c_src = 0;                                    // the cached contig: first unit, first unit of its successor, first source byte
+    // a round's source words are fetched while the round before is computed
+    struct Fetched { PackWords4 qa, qb; uint32_t q8, sh, ci, len; uint64_t b0, src; bool live, whole; };
+    auto fetch = [&](uint32_t r) {
+        Fetched f; f.qa = PackWords4{0, 0, 0, 0}; f.qb = f.qa; f.q8 = 0; f.sh = 0; f.whole = false;
+        const uint64_t u = first + (uint64_t)r * 64u + l;
+        f.live = r < PACK_ROUNDS && u < n_units;
+        if (!f.live) { f.ci = cached; f.len = 0; f.b0 = 0; f.src = 0; return f; }
+        if (cached != ci || u >= c_next) {
+            while (ci + 1 < n_contigs && unit_off[ci + 1] <= u) ci++;
+            cached = ci; c_unit = unit_off[ci]; c_next = ci + 1 < n_contigs ? unit_off[ci + 1] : ~0ull; c_src = src_off[ci]; len = contigs[ci].len;
         }
+        f.ci = ci; f.len = len; f.b0 = (u - c_unit) * 32; f.src = c_src;
+        const uint64_t so = c_src + f.b0;                                           // first source byte of the unit
+        const uint64_t addr = (uint64_t)(uintptr_t)bases + so; f.sh = (uint32_t)(addr & 3u);
+        f.whole = f.b0 + 32 <= len && so - f.sh + 36 <= readable_bytes;             // a whole unit inside the contig, all nine words readable
+        if (f.whole) { const uint32_t* q = (const uint32_t*)(uintptr_t)(addr - f.sh); f.qa = *(const PackWords4*)q; f.qb = *(const PackWords4*)(q + 4); f.q8 = q[8]; }
+        return f;
+    };
+    uint32_t n_ci = 0xFFFFFFFFu, seen_n = 0;                                         // N flags seen in contig n_ci
+    Fetched cur = fetch(0);
+    for (uint32_t r = 0; r < PACK_ROUNDS; r++) {
+        const Fetched nxt = fetch(r + 1);
+        if (!cur.live) break;
+        const uint64_t u = first + (uint64_t)r * 64u + l;
+        uint32_t w0 = 0, w1 = 0, m = 0;
+        if (cur.whole) {
+            const PackWords4 qa = cur.qa, qb = cur.qb; const uint32_t q8 = cur.q8, sh = cur.sh;
+            const uint32_t d[8] = {shift_bytes(qa.y, qa.x, sh), shift_bytes(qa.z, qa.y, sh), shift_bytes(qa.w, qa.z, sh), shift_bytes(qb.x, qa.w, sh),
+                                   shift_bytes(qb.y, qb.x, sh), shift_bytes(qb.z, qb.y, sh), shift_bytes(qb.w, qb.z, sh), shift_bytes(q8, qb.w, sh)};
+            uint32_t bad = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { w0 |= codes_of_acgtu_word(d[j], bad) << (24 - 8 * j); w1 |= codes_of_acgtu_word(d[4 + j], bad) << (24 - 8 * j); }
+            if (bad) {                                                              // a byte that is not a base letter: the exact table, and the N flags
+                w0 = 0; w1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { w0 |= codes_of_word(d[j]) << (24 - 8 * j); w1 |= codes_of_word(d[4 + j]) << (24 - 8 * j); }
+#pragma unroll
+                for (int j = 0; j < 8; j++) m |= n_flags_of_word(d[j], mode) << (4 * j);
+            }
+        } else {                                                                    // a contig's last unit(s), the end of the buffer: byte by byte
+            const uint8_t* src = bases + cur.src;
+            for (uint32_t x = 0; x < 32; x++) {
+                const uint64_t p = cur.b0 + x;
+                const uint32_t byte = p < cur.len ? src[p] : (uint32_t)'A';
+                const uint32_t code = base_code(byte);
+                const bool is_n = byte == 78u || (mode == SKH_SEED_SCALAR && byte == 110u);
+                if (x < 16) w0 |= code << (30 - 2 * x); else w1 |= code << (30 - 2 * (x - 16));
+                m |= (is_n ? 1u : 0u) << x;
+            }
+        }
+        *(uint2*)(packed + 2 * u) = make_uint2(w0, w1); nmask[u] = m;               // contig bases are laid out at 32 * unit_off
+        if (m) {
+            if (n_ci != cur.ci && seen_n) atomicOr(&contigs[n_ci].has_n, 1u);
+            n_ci = cur.ci; seen_n = 1;
+        }
+        cur = nxt;
     }
-    *(uint2*)(packed + 2 * u) = make_uint2(w0, w1); nmask[u] = m;                   // contig bases are laid out at 32 * unit_off
-    if (m) atomicOr(&contigs[ci].has_n, 1u);
+    if (seen_n) atomicOr(&contigs[n_ci].has_n, 1u);
 }
 
 static inline uint32_t windows_end(uint32_t len, int mode) {  // exclusive bound on the window's last-base index i
@@ -176,7 +225,7 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
     uint64_t* d_src = ctx->arena.get<uint64_t>(nc + 1); uint64_t* d_unit = ctx->arena.get<uint64_t>(nc + 1);
     h2d(d_src, src_off.data(), (size_t)nc * 8, ctx->stream); h2d(d_unit, unit_off.data(), ((size_t)nc + 1) * 8, ctx->stream);
     if (n_units) {
-        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 255) / 256), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
+        SKH_LAUNCH(pack_kernel, (unsigned)((n_units + 256 * PACK_ROUNDS - 1) / (256 * PACK_ROUNDS)), 256, 0, ctx->stream, d_bases, readable, (const uint64_t*)d_src,
                    (const uint64_t*)d_unit, gs->d_contigs.p + c0, nc, n_units, gs->seeding_mode, gs->packed.p + gs->n_units * 2, gs->nmask.p + gs->n_units);
         check_launch("pack_kernel");
     }
