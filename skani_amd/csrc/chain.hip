@@ -44,7 +44,9 @@ static void genome_halves(const skh_sketch_set* S) {
         h.ms = S->ms.p + S->ms_off[g]; h.tab = S->tab.p + S->tab_off[g]; h.nbk = S->n_buckets[g]; h.bmap = S->bmap.p + S->bmap_off[g];
         h.goff = S->d_goff.p + S->ctg_off[g] + g; h.host_goff = S->goff.data() + S->ctg_off[g] + g;
         h.g64 = nullptr; h.goff64 = nullptr; h.host_goff64 = nullptr;
-        if (S->wide) { h.g64 = S->p_g64.p + S->pos_off[g]; h.goff64 = S->d_goff64.p + S->ctg_off[g] + g; h.host_goff64 = S->goff64.data() + S->ctg_off[g] + g; h.goff = nullptr; h.host_goff = nullptr; }
+        if (S->wide && S->wide_g[g]) {                                                // a genome beyond 31-bit coordinates: p_g holds its position indices
+            h.g64 = S->p_g64.p + S->pos_off[g]; h.goff64 = S->d_goff64.p + S->ctg_off[g] + g; h.host_goff64 = S->goff64.data() + S->ctg_off[g] + g; h.goff = nullptr; h.host_goff = nullptr;
+        }
         h.nctg = (uint32_t)(S->ctg_off[g + 1] - S->ctg_off[g]);
         h.total_len = S->total_len[g]; h.q10 = S->q10[g]; h.q50 = S->q50[g]; h.q90 = S->q90[g];
         const double cap = std::min(S->mean_ctg[g], 300000.);
@@ -407,57 +409,82 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     // ---- pair descriptors, from the sets' per-genome halves
     for (uint32_t x = 0; x < n_rsets; x++) genome_halves(Rsets[x]);
     for (uint32_t x = 0; x < n_qsets; x++) genome_halves(Qsets[x]);
-    job.pds = (PairDesc*)ctx->pin_pairs.need((size_t)NP * sizeof(PairDesc)); job.n_pairs = NP;
-    job.chunk_bound.resize(NP); job.pair_key.resize(NP);
-    // a run that involves a wide set (a genome beyond 31-bit coordinates) works on 64-bit coordinates from the chunking on
-    bool wide_run = false;
-    for (uint32_t x = 0; x < n_rsets; x++) wide_run = wide_run || Rsets[x]->wide;
-    for (uint32_t x = 0; x < n_qsets; x++) wide_run = wide_run || Qsets[x]->wide;
-    if (wide_run) job.wps.resize(NP);
-    if (stats) { job.host_go_a.resize(NP); job.host_go_b.resize(NP); if (wide_run) { job.host_go_a64.resize(NP); job.host_go_b64.resize(NP); } }
-    for (uint32_t p = 0; p < NP; p++) {
-        const uint32_t rs = pair_rset ? pair_rset[p] : 0u, qs = pair_qset ? pair_qset[p] : 0u;
+    auto halves_of = [&](uint32_t p, const skh_sketch_set*& R, const skh_sketch_set*& Q, uint32_t& rs, uint32_t& qs) {
+        rs = pair_rset ? pair_rset[p] : 0u; qs = pair_qset ? pair_qset[p] : 0u;
         if (rs >= n_rsets || qs >= n_qsets) throw std::invalid_argument("pair names a sketch set that was not passed");
-        const skh_sketch_set* R = Rsets[rs]; const skh_sketch_set* Q = Qsets[qs];
-        const uint32_t r = pair_ref[p], q = pair_query[p];
-        if (r >= R->n_genomes || q >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
-        const skh_sketch_set::GenomeHalf& hr = R->halves[r]; const skh_sketch_set::GenomeHalf& hq = Q->halves[q];
-        PairDesc& pd = job.pds[p];
-        const bool empty = hr.nctg == 0 || hq.nctg == 0;                              // chain.rs:618-620
-        // chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
-        const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
-        const double sq = both_long ? hq.score_markers : hq.score_len, sr = both_long ? hr.score_markers : hr.score_len;
-        bool sw;
-        if (sq == sr) sw = (!tie_by_rank && !Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
-        else sw = sq > sr;
-        const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
-        const uint32_t gb = sw ? q : r;
-        pd.a_n = empty ? 0 : A.n_pos;
-        pd.a_hash = A.hash; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
-        pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap;
-        pd.flags = sw ? 4u : 0u;
-        pd.tile0 = 0;
-        pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;
-        pd.q10_q = hq.q10; pd.q50_q = hq.q50; pd.q90_q = hq.q90; pd.q10_r = hr.q10; pd.q50_r = hr.q50; pd.q90_r = hr.q90;
-        pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg;
-        pd.a_goff = A.goff; pd.b_goff = B.goff; pd.a_nctg = A.nctg; pd.b_nctg = B.nctg;
-        if (stats) { job.host_go_a[p] = A.host_goff; job.host_go_b[p] = B.host_goff; }
-        if (wide_run) {
-            const bool aw = A.g64 != nullptr, bw = B.g64 != nullptr;
-            WidePair& wp = job.wps[p];
-            wp.a_g = aw ? CoArr{A.g64, 1u} : CoArr{A.g, 0u};
-            wp.a_goff = aw ? CoArr{A.goff64, 1u} : CoArr{A.goff, 0u}; wp.b_goff = bw ? CoArr{B.goff64, 1u} : CoArr{B.goff, 0u};
-            wp.b_g64 = B.g64; wp.a_is_index = aw ? 1u : 0u; wp.pad = 0;
-            if (stats) {
-                job.host_go_a64[p] = aw ? CoArr{A.host_goff64, 1u} : CoArr{A.host_goff, 0u};
-                job.host_go_b64[p] = bw ? CoArr{B.host_goff64, 1u} : CoArr{B.host_goff, 0u};
-            }
+        R = Rsets[rs]; Q = Qsets[qs];
+        if (pair_ref[p] >= R->n_genomes || pair_query[p] >= Q->n_genomes) throw std::invalid_argument("pair index out of range");
+    };
+    // A pair with a genome beyond 31-bit coordinates (internal.h: wide sets) is chained on 64-bit coordinates from the chunking on; the other pairs of
+    // the call -- all of them, unless a set is wide -- take the ordinary run.  Two runs then, each over its own list of the call's pairs.
+    bool any_wide_set = false;
+    for (uint32_t x = 0; x < n_rsets; x++) any_wide_set = any_wide_set || Rsets[x]->wide;
+    for (uint32_t x = 0; x < n_qsets; x++) any_wide_set = any_wide_set || Qsets[x]->wide;
+    std::vector<uint32_t> sel[2];                                                     // [0] ordinary pairs, [1] pairs with a wide genome (only filled when there are any)
+    if (any_wide_set) {
+        for (uint32_t p = 0; p < NP; p++) {
+            const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
+            sel[(R->halves[pair_ref[p]].g64 || Q->halves[pair_query[p]].g64) ? 1 : 0].push_back(p);
         }
-        job.pair_key[p] = gb + 3u * (sw ? n_rsets + qs : rs);                        // tiles probing the same sketch share an XCD
-        job.chunk_bound[p] = A.chunk_bound;
+        if (sel[1].empty()) sel[0].clear();                                            // nothing wide after all: one run over the call's pairs as they are
     }
-    tr.mark("host: pair descriptors");
-    if (wide_run) chain_run<Wide>(ctx, job, out, stats); else chain_run<Narrow>(ctx, job, out, stats);
+    const bool split = !sel[1].empty();
+    for (int run = 0; run < (split ? 2 : 1); run++) {
+        const bool wide_run = split && run == 1;
+        const uint32_t* idx = split ? sel[run].data() : nullptr;
+        const uint32_t n = split ? (uint32_t)sel[run].size() : NP;
+        if (n == 0) continue;
+        job.pds = (PairDesc*)ctx->pin_pairs.need((size_t)n * sizeof(PairDesc)); job.n_pairs = n;
+        job.chunk_bound.assign(n, 0); job.pair_key.assign(n, 0);
+        job.wps.clear(); job.host_go_a.clear(); job.host_go_b.clear(); job.host_go_a64.clear(); job.host_go_b64.clear();
+        if (wide_run) job.wps.resize(n);
+        if (stats) { job.host_go_a.resize(n); job.host_go_b.resize(n); if (wide_run) { job.host_go_a64.resize(n); job.host_go_b64.resize(n); } }
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t p = idx ? idx[i] : i;
+            const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
+            const uint32_t r = pair_ref[p], q = pair_query[p];
+            const skh_sketch_set::GenomeHalf& hr = R->halves[r]; const skh_sketch_set::GenomeHalf& hq = Q->halves[q];
+            PairDesc& pd = job.pds[i];
+            const bool empty = hr.nctg == 0 || hq.nctg == 0;                          // chain.rs:618-620
+            // chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
+            const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
+            const double sq = both_long ? hq.score_markers : hq.score_len, sr = both_long ? hr.score_markers : hr.score_len;
+            bool sw;
+            if (sq == sr) sw = (!tie_by_rank && !Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
+            else sw = sq > sr;
+            const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
+            const uint32_t gb = sw ? q : r;
+            pd.a_n = empty ? 0 : A.n_pos;
+            pd.a_hash = A.hash; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
+            pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap;
+            pd.flags = sw ? 4u : 0u;
+            pd.tile0 = 0;
+            pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;
+            pd.q10_q = hq.q10; pd.q50_q = hq.q50; pd.q90_q = hq.q90; pd.q10_r = hr.q10; pd.q50_r = hr.q50; pd.q90_r = hr.q90;
+            pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg;
+            pd.a_goff = A.goff; pd.b_goff = B.goff; pd.a_nctg = A.nctg; pd.b_nctg = B.nctg;
+            if (stats) { job.host_go_a[i] = A.host_goff; job.host_go_b[i] = B.host_goff; }
+            if (wide_run) {
+                const bool aw = A.g64 != nullptr, bw = B.g64 != nullptr;
+                WidePair& wp = job.wps[i];
+                wp.a_g = aw ? CoArr{A.g64, 1u} : CoArr{A.g, 0u};
+                wp.a_goff = aw ? CoArr{A.goff64, 1u} : CoArr{A.goff, 0u}; wp.b_goff = bw ? CoArr{B.goff64, 1u} : CoArr{B.goff, 0u};
+                wp.b_g64 = B.g64; wp.a_is_index = aw ? 1u : 0u; wp.pad = 0;
+                if (stats) {
+                    job.host_go_a64[i] = aw ? CoArr{A.host_goff64, 1u} : CoArr{A.host_goff, 0u};
+                    job.host_go_b64[i] = bw ? CoArr{B.host_goff64, 1u} : CoArr{B.host_goff, 0u};
+                }
+            }
+            job.pair_key[i] = gb + 3u * (sw ? n_rsets + qs : rs);                    // tiles probing the same sketch share an XCD
+            job.chunk_bound[i] = A.chunk_bound;
+        }
+        tr.mark("host: pair descriptors");
+        if (!split) { chain_run<Narrow>(ctx, job, out, stats); break; }
+        std::vector<skh_ani_result> part(n); std::vector<skh_chain_stats> part_st(stats ? n : 0);
+        if (wide_run) chain_run<Wide>(ctx, job, part.data(), stats ? part_st.data() : nullptr);
+        else chain_run<Narrow>(ctx, job, part.data(), stats ? part_st.data() : nullptr);
+        for (uint32_t i = 0; i < n; i++) { out[idx[i]] = part[i]; if (stats) stats[idx[i]] = part_st[i]; }
+    }
 }
 
 }  // namespace skh

@@ -119,10 +119,12 @@ struct skh_sketch_set {
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
     std::vector<uint32_t> goff;                    // padded-coordinate start of every contig, n_contigs(g)+1 entries per genome at
                                                    // index ctg_off[g] + g (the last one = the genome's padded span)
-    // A set with a genome of wide_span padded bases or more is WIDE: coordinates do not fit 31 bits.  Then goff64 / p_g64 hold the padded coordinates
-    // (goff is empty), and p_g holds the position's INDEX within its genome << 1 | canonical instead: the seed tables and the join work on p_g exactly as
-    // they do otherwise (ascending index = ascending coordinate), and the anchors are translated to 64-bit coordinates before the chaining (chain.hip).
-    bool wide = false;
+    // A set with a genome of wide_span padded bases or more is WIDE: that genome's coordinates do not fit 31 bits.  The set then also keeps goff64 /
+    // p_g64, the padded coordinates in 64 bits (of all its genomes), and for its wide genomes (wide_g) p_g holds the position's INDEX within the
+    // genome << 1 | canonical instead: the seed tables and the join work on p_g exactly as they do otherwise (ascending index = ascending coordinate),
+    // and the anchors of a pair with such a genome are translated to 64-bit coordinates before the chaining (chain.hip).  goff: exact for the others.
+    bool wide = false, indexed = false;            // indexed: the wide genomes' p_g records have been made (sketch_build.hip)
+    std::vector<uint8_t> wide_g;                   // per genome (wide sets only)
     std::vector<uint64_t> goff64;
     std::vector<uint64_t> total_len;
     std::vector<double> mean_ctg;
@@ -130,7 +132,7 @@ struct skh_sketch_set {
     // everything the chaining's pair descriptors take from one genome, gathered once per set (chain.hip genome_halves)
     struct GenomeHalf {
         const uint32_t *hash, *g, *rep, *ms, *bmap, *goff; const uint64_t* tab; const uint32_t* host_goff;
-        const uint64_t *g64, *goff64, *host_goff64;       // wide sets (else null)
+        const uint64_t *g64, *goff64, *host_goff64;       // a wide genome (else null)
         uint32_t n_pos, pos0, nbk, nctg, chunk_bound; uint64_t total_len; float q10, q50, q90;
         double score_markers, score_len;                  // switch_qr's two candidate scores (chain.rs:625-649)
     };
@@ -138,8 +140,8 @@ struct skh_sketch_set {
     std::vector<uint32_t> rank;
     std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays
-    skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical (wide sets: index in the genome << 1 | canonical)
-    skh::DBuf<uint64_t> p_g64;                     // wide sets: padded coordinate << 1 | canonical
+    skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical (wide genomes: index in the genome << 1 | canonical)
+    skh::DBuf<uint64_t> p_g64;                     // wide sets: padded coordinate << 1 | canonical, all genomes
     skh::DBuf<uint32_t> p_rep;                     // 1 bit per position (set-wide position index): its seed occurs more than 2500 / c times in its genome (chain.rs:674-676)
     skh::DBuf<uint32_t> p_hash;                    // mix32(p_seed): what the join enumerates and probes with
     // seed table (probe side), common.h: per genome n_buckets home slots in slices of TAB_SLICE, each followed by TAB_SLACK overflow slots;
@@ -150,6 +152,7 @@ struct skh_sketch_set {
     skh::DBuf<uint64_t> markers;                   // sorted unique per genome
     skh::DBuf<uint32_t> d_goff;
     skh::DBuf<uint64_t> d_goff64;
+    skh::DBuf<uint32_t> d_wide_g;
     // lazily built by the first two-set screen that uses this set as the reference side: its (marker, genome) incidences
     // sorted by marker (screen.hip).  The set is otherwise immutable; the mutex makes the one-time build safe when several
     // contexts share the set.
@@ -211,7 +214,7 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
 void genomes_finish(skh_ctx* ctx, skh_genome_set* gs);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
     DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> markers_raw; // hash = mix32(seed); g = padded coordinate << 1 | canonical (common.h CTG_PAD)
-    DBuf<uint64_t> g64; bool wide = false;                    // a set with a genome beyond 31-bit coordinates: g64 = the coordinates, g = index in the genome << 1 | canonical
+    DBuf<uint64_t> g64; bool wide = false;                    // a set with a genome beyond 31-bit coordinates: also g64 = the coordinates in 64 bits (g: their low words)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
     bool tail_pending = false;               // the last kernel writing these arrays is still queued on the context's stream
 };

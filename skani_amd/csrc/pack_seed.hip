@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void seed_overflow_kernel(const uint32_t* cnt_
 }
 
 // one wave per tile: copy the tile's records to their final (contig,pos)-ordered place.  WIDE (a set with a genome beyond 31-bit coordinates): the
-// coordinates go out as 64-bit records (o_g64); the table build derives the set's 32-bit position records from them (sketch_build.hip)
+// coordinates also go out as 64-bit records (o_g64); the table build replaces the 32-bit records of the wide genomes by position indices (sketch_build.hip)
 template <bool WIDE>
 __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __restrict__ tiles, const ContigDesc* __restrict__ contigs,
                                                            uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m, const uint32_t* __restrict__ ovf_idx,
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                 o_seed[s0 + x] = sd[u]; o_hash[s0 + x] = mix32(sd[u]);              // the table hash the sketch build and the join work with
                 const uint32_t pos = pos0 + (loc[u] & 0x1FFFu);                         // pos = index of the window's last base
                 if (WIDE) o_g64[s0 + x] = ((goff64 + pos) << 1) | (loc[u] >> 15);
-                else o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                // SeedPosition (types.rs:131-138) in padded coordinates
+                o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                     // SeedPosition (types.rs:131-138) in padded coordinates (a wide genome's records are replaced by indices later)
             }
         }
     }
@@ -584,7 +584,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
             check_launch("seed_tiles_kernel(overflow)");
         }
         p.seed.alloc(p.ns); p.hash.alloc(p.ns); p.mk.alloc(p.nm);
-        if (wide) p.g64.alloc(p.ns); else p.g.alloc(p.ns);
+        p.g.alloc(p.ns); if (wide) p.g64.alloc(p.ns);
 #define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2, \
                    (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.hash.p, p.g.p, p.g64.p, p.mk.p)
@@ -605,11 +605,11 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         out.seed = std::move(parts[0].seed); out.hash = std::move(parts[0].hash); out.g = std::move(parts[0].g); out.g64 = std::move(parts[0].g64); out.markers_raw = std::move(parts[0].mk);
     } else {
         out.seed.alloc(NS); out.hash.alloc(NS); out.markers_raw.alloc(NM);
-        if (wide) out.g64.alloc(NS); else out.g.alloc(NS);
+        out.g.alloc(NS); if (wide) out.g64.alloc(NS);
         uint64_t so = 0, mo = 0;
         for (auto& p : parts) {
             d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.hash.p + so, p.hash.p, p.ns * 4, ctx->stream);
-            if (wide) d2d(out.g64.p + so, p.g64.p, p.ns * 8, ctx->stream); else d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream);
+            d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream); if (wide) d2d(out.g64.p + so, p.g64.p, p.ns * 8, ctx->stream);
             d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
             so += p.ns; mo += p.nm;
         }

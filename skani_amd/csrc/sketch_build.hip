@@ -41,12 +41,12 @@ __global__ __launch_bounds__(256) void unpack_positions_kernel(const Co* p_g, co
     if (pos) pos[i] = (uint32_t)((v >> 1) - go[c]);
     if (cc) cc[i] = (c << 1) | (uint32_t)(v & 1u);
 }
-// a wide set's 32-bit position records: index within the genome << 1 | canonical (what its seed tables store and the join hands on)
-__global__ __launch_bounds__(256) void index_positions_kernel(const uint64_t* p_g64, const uint64_t* pos_off, uint32_t ng, uint64_t n, uint32_t* p_g) {
+// the 32-bit position records of a wide set's wide genomes: index within the genome << 1 | canonical (what their seed tables store and the join hands on)
+__global__ __launch_bounds__(256) void index_positions_kernel(const uint64_t* p_g64, const uint64_t* pos_off, const uint32_t* wide_g, uint32_t ng, uint64_t n, uint32_t* p_g) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = seg_of(pos_off, ng, i);
-    p_g[i] = ((uint32_t)(i - pos_off[g]) << 1) | (uint32_t)(p_g64[i] & 1u);
+    if (wide_g[g]) p_g[i] = ((uint32_t)(i - pos_off[g]) << 1) | (uint32_t)(p_g64[i] & 1u);
 }
 
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t* keys, uint64_t n, uint32_t* head) {
@@ -356,7 +356,11 @@ void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss) {
     if (ss->d_pos_off.n == ng + 1 && ss->d_ctg_off.n == ng + 1) return;
     ss->d_pos_off.alloc(ng + 1); h2d(ss->d_pos_off.p, ss->pos_off.data(), (ng + 1) * 8, ctx->stream);
     ss->d_goff.alloc(ss->goff.size() ? ss->goff.size() : 1); h2d(ss->d_goff.p, ss->goff.data(), ss->goff.size() * 4, ctx->stream);
-    if (ss->wide) { ss->d_goff64.alloc(ss->goff64.size() ? ss->goff64.size() : 1); h2d(ss->d_goff64.p, ss->goff64.data(), ss->goff64.size() * 8, ctx->stream); }
+    if (ss->wide) {
+        ss->d_goff64.alloc(ss->goff64.size() ? ss->goff64.size() : 1); h2d(ss->d_goff64.p, ss->goff64.data(), ss->goff64.size() * 8, ctx->stream);
+        std::vector<uint32_t> flags(ss->wide_g.begin(), ss->wide_g.end());
+        ss->d_wide_g.alloc(ng ? ng : 1); h2d(ss->d_wide_g.p, flags.data(), (size_t)ng * 4, ctx->stream);
+    }
     ss->d_ctg_off.alloc(ng + 1); h2d(ss->d_ctg_off.p, ss->ctg_off.data(), (ng + 1) * 8, ctx->stream);
 }
 
@@ -387,7 +391,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / TAB_FILTER_HOMES) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
         // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
         // coordinates pass 2^30 may need two words for a single position
-        const uint64_t span = ss->goff.empty() ? 0 : ss->goff[ss->ctg_off[g + 1] + g];   // (a wide set's records are indices below 2^30)
+        const uint64_t span = (ss->wide && ss->wide_g[g]) ? 0 : ss->goff[ss->ctg_off[g + 1] + g];   // (a wide genome's records are indices below 2^30)
         ss->ms_off[g + 1] = ss->ms_off[g] + (span >= (1ull << 30) ? 2 * pg : pg + pg / 2) + 16;
         if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
         queue_pos[g] = queue_len[g & 7u]; queue_len[g & 7u] += n_sl;
@@ -402,20 +406,21 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     // the first copy below may wait for the stream)
     upload_set_offsets(ctx, ss);
     dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
-    const bool fresh_g = pos || cc || ss->p_g.n != P;                                // (a set whose tables were deferred arrives with its records made)
-    if (fresh_g) ss->p_g.alloc(P);
+    if (pos || cc || ss->p_g.n != P) { ss->p_g.alloc(P); ss->indexed = false; }
     if (ss->wide && (pos || cc || ss->p_g64.n != P)) ss->p_g64.alloc(P);
     if (P > 0 && pos && cc) {
         if (ss->wide) SKH_LAUNCH(pack_positions_kernel<uint64_t>, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
                    (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint64_t*)ss->d_goff64.p, ss->p_g64.p);
-        else SKH_LAUNCH(pack_positions_kernel<uint32_t>, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
+        SKH_LAUNCH(pack_positions_kernel<uint32_t>, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, pos, cc, (const uint64_t*)ss->d_pos_off.p,
                    (const uint64_t*)ss->d_ctg_off.p, ng, P, (const uint32_t*)ss->d_goff.p, ss->p_g.p);
         check_launch("pack_positions");
     }
-    if (ss->wide && P > 0 && fresh_g) {
-        SKH_LAUNCH(index_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->p_g64.p, (const uint64_t*)ss->d_pos_off.p, ng, P, ss->p_g.p);
+    if (ss->wide && P > 0 && !ss->indexed) {
+        SKH_LAUNCH(index_positions_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)ss->p_g64.p, (const uint64_t*)ss->d_pos_off.p,
+                   (const uint32_t*)ss->d_wide_g.p, ng, P, ss->p_g.p);
         check_launch("index_positions");
     }
+    ss->indexed = true;
     if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
         ss->p_hash.alloc(P ? P : 1);
     if (P) {
@@ -629,15 +634,16 @@ void finalize_metadata(skh_sketch_set* ss) {
     // padded contig starts; a genome of wide_span padded bases or more (total length + 8192 per contig) makes the set wide
     const uint64_t lim = ss->ctx ? ss->ctx->tune.wide_span : (1ull << 31) - CTG_PAD;
     ss->goff64.assign(ss->ctg_len.size() + ng, 0);
-    ss->wide = false;
+    ss->wide = false; ss->wide_g.assign(ng, 0);
     for (uint32_t g = 0; g < ng; g++) {
         uint64_t at = CTG_PAD; const uint64_t base = ss->ctg_off[g] + g;
         for (uint64_t c = ss->ctg_off[g]; c < ss->ctg_off[g + 1]; c++) { ss->goff64[base + (c - ss->ctg_off[g])] = at; at += (uint64_t)ss->ctg_len[c] + CTG_PAD; }
         ss->goff64[base + (ss->ctg_off[g + 1] - ss->ctg_off[g])] = at;
-        if (at >= lim) ss->wide = true;
+        if (at >= lim) { ss->wide = true; ss->wide_g[g] = 1; }
     }
-    ss->goff.clear();
-    if (!ss->wide) { ss->goff.assign(ss->goff64.begin(), ss->goff64.end()); ss->goff64.clear(); }
+    ss->goff.assign(ss->goff64.size(), 0);                                            // (low words: exact for every genome that is not wide)
+    for (size_t x = 0; x < ss->goff64.size(); x++) ss->goff[x] = (uint32_t)ss->goff64[x];
+    if (!ss->wide) { ss->goff64.clear(); ss->wide_g.clear(); }
     ss->mean_ctg.assign(ng, 0.); ss->q10.assign(ng, 0.f); ss->q50.assign(ng, 0.f); ss->q90.assign(ng, 0.f);
     for (uint32_t g = 0; g < ng; g++) {
         std::vector<uint32_t> v(ss->ctg_len.begin() + ss->ctg_off[g], ss->ctg_len.begin() + ss->ctg_off[g + 1]);

@@ -353,6 +353,20 @@ def test_wide_set_meets_ordinary_sets(monkeypatch):
                 pc.assert_result_close(res[x], o, (int(pr[x]), int(pq[x])))
                 assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["anchor_checksum"])) == \
                     (so.n_intervals, so.n_accepted, so.n_chunks, so.anchor_checksum)
+        # one set holding both kinds: the set is wide, its short genomes keep ordinary records, and a call over all its pairs splits into an
+        # ordinary run (short against short) and a wide run (every pair with a long genome)
+        M = c.sketch_records(longs + shorts, sk.SketchParams(), ln + sn); oall = ol + os_
+        assert M.wide
+        for g in range(6): pc.assert_sketch_equal(M, g, oall[g])
+        pr = [i for i in range(6) for j in range(6)]; pq = [j for i in range(6) for j in range(6)]
+        res, st = c.chain_pairs(M, None, pr, pq, sk.MapParams(compute_ci=True), stats=True)
+        for x in range(36):
+            o, so = ora.chain_seeds(oall[pr[x]], oall[pq[x]], stats=True)
+            pc.assert_result_close(res[x], o, (pr[x], pq[x]))
+            assert (int(st[x]["n_intervals"]), int(st[x]["n_accepted"]), int(st[x]["n_chunks"]), int(st[x]["anchor_checksum"])) == \
+                (so.n_intervals, so.n_accepted, so.n_chunks, so.anchor_checksum)
+        i, j, r, n = c.triangle(M, sk.MapParams())
+        assert len(i) == 15
     finally:
         c.close()
 
