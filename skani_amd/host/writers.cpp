@@ -54,30 +54,40 @@ static bool usable(const skh_ani_result& r) { return !(r.ani == -1.f || std::isn
 void format_phylip(const std::vector<GenomeInfo>& g, const std::vector<PairResult>& res, bool use_contig_names, const OutOpts& o,
                    std::string& ani_txt, std::string& af_txt) {
     const size_t n = g.size();
-    std::map<std::pair<uint32_t, uint32_t>, const skh_ani_result*> m;          // anis[x][y], x < y
-    for (auto& p : res) m[{std::min(p.ref, p.query), std::max(p.ref, p.query)}] = &p.r;
+    // anis[x][y], x < y (a later result for the same pair replaces an earlier one, as inserting into the reference's map does); per genome the
+    // results it takes part in, so that a row is laid out from a table of n cells instead of n look-ups (the two matrices of 1,000 genomes are
+    // 1.5 million cells, nearly all of them the "nothing" value: their text is made once)
+    std::vector<std::vector<std::pair<uint32_t, const skh_ani_result*>>> of(n);
+    for (auto& p : res) { if (p.ref == p.query) continue; of[p.ref].push_back({p.query, &p.r}); of[p.query].push_back({p.ref, &p.r}); }
     const float perfect = o.distance ? 0.f : 100.f, none = 100.f - perfect;   // file_io.rs:374-375
+    const std::string t_perfect = "\t" + f2(perfect), t_none = "\t" + f2(none), t_100 = "\t" + f2(100.f), t_0 = "\t" + f2(0.f);
     std::string a = std::to_string(n) + "\n", f = std::to_string(n) + "\n";
+    a.reserve(n * 64 + res.size() * 8 + n * n * 3); f.reserve(n * 64 + n * n * 6);
+    std::vector<const skh_ani_result*> cell(n, nullptr);
+    char buf[64];
+    auto put = [&](std::string& out, float v) { const int len = snprintf(buf, sizeof buf, "\t%.2f", (double)v); out.append(buf, (size_t)len); };
     for (size_t i = 0; i < n; i++) {
+        for (auto& e : of[i]) cell[e.first] = usable(*e.second) ? e.second : nullptr;
         const std::string& name = use_contig_names ? g[i].contigs[0] : g[i].file_name;
         a += name; f += name;
         const size_t end = o.full_matrix ? n : (o.diagonal ? i + 1 : i);
         for (size_t j = 0; j < end; j++) {
-            if (j == i) { a += "\t" + f2(perfect); continue; }
-            auto it = m.find({(uint32_t)std::min(i, j), (uint32_t)std::max(i, j)});
-            if (it == m.end() || !usable(*it->second)) a += "\t" + f2(none);
-            else { const float val = it->second->ani * 100.f; a += "\t" + f2(o.distance ? 100.f - val : val); }
+            if (j == i) { a += t_perfect; continue; }
+            const skh_ani_result* r = cell[j];
+            if (!r) a += t_none;
+            else { const float val = r->ani * 100.f; put(a, o.distance ? 100.f - val : val); }
         }
         a += "\n";
         for (size_t j = 0; j < n; j++) {                                       // the AF matrix is always full (file_io.rs:428-461)
-            if (i == j) { f += "\t" + f2(100.f); continue; }
-            auto it = m.find({(uint32_t)std::min(i, j), (uint32_t)std::max(i, j)});
-            if (it == m.end() || !usable(*it->second)) f += "\t" + f2(0.f);
-            else f += "\t" + f2((j > i ? it->second->af_ref : it->second->af_query) * 100.f);
+            if (i == j) { f += t_100; continue; }
+            const skh_ani_result* r = cell[j];
+            if (!r) f += t_0;
+            else put(f, (j > i ? r->af_ref : r->af_query) * 100.f);
         }
         f += "\n";
+        for (auto& e : of[i]) cell[e.first] = nullptr;
     }
-    ani_txt = a; af_txt = f;
+    ani_txt = std::move(a); af_txt = std::move(f);
 }
 
 std::string format_sparse(const std::vector<GenomeInfo>& g, const std::vector<PairResult>& res, const OutOpts& o) {
