@@ -130,10 +130,12 @@ int skh_sketch_set_names(skh_sketch_set*, const char* const* names);
 
 /* sizes */
 uint32_t skh_sketch_n_genomes(const skh_sketch_set*);
-/* 1 when the set holds a genome of 2^31 - 8192 or more padded bases (total length + 8192 per contig; a human genome, say): the set then keeps 64-bit
- * coordinates beside its 32-bit position records, and every chaining run it takes part in -- with itself or with ordinary sets -- works on 64-bit
- * coordinates (chain.hip "Wide").  Same results, same entry points; contigs stay below 2^32 bases and genomes below 2^30 seed positions, as in the
- * reference's u32 fields (types.rs:131-138).  Not exchanged between ranks: skh_triangle_distributed refuses such a set on every rank. */
+/* 1 when the set holds a genome of 2^31 - 8192 or more padded bases (total length + 8192 per contig: a human genome, or an assembly of 250,000
+ * short contigs).  Such a set is "wide": it keeps the coordinates of its positions in 64 bits as well, and the 32-bit position records of its
+ * wide genomes hold position indices.  Every entry point takes it like any other set and returns the same results; a chaining call runs the pairs
+ * that involve a wide genome on 64-bit coordinates and the others as always (chain.hip).  What remains are the reference's own u32 fields
+ * (types.rs:131-138): contigs below 2^32 bases, genomes below 2^30 seed positions.  Wide sets are not exchanged between ranks:
+ * skh_triangle_distributed refuses them, on every rank alike. */
 int skh_sketch_is_wide(const skh_sketch_set*);
 int skh_sketch_sizes(const skh_sketch_set*, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers,
                      uint32_t* n_contigs, uint64_t* total_len);
