@@ -134,8 +134,9 @@ uint32_t skh_sketch_n_genomes(const skh_sketch_set*);
  * short contigs).  Such a set is "wide": it keeps the coordinates of its positions in 64 bits as well, and the 32-bit position records of its
  * wide genomes hold position indices.  Every entry point takes it like any other set and returns the same results; a chaining call runs the pairs
  * that involve a wide genome on 64-bit coordinates and the others as always (chain.hip).  What remains are the reference's own u32 fields
- * (types.rs:131-138): contigs below 2^32 bases, genomes below 2^30 seed positions.  Wide sets are not exchanged between ranks:
- * skh_triangle_distributed refuses them, on every rank alike. */
+ * (types.rs:131-138): contigs below 2^32 bases, genomes below 2^30 seed positions.  skh_triangle_distributed: when any rank holds a wide set, the
+ * ranks exchange positions in this header's (position in contig, contig << 1 | canonical) form -- 8 bytes per position instead of 4 -- and every
+ * rank makes the set it chains through the import path. */
 int skh_sketch_is_wide(const skh_sketch_set*);
 int skh_sketch_sizes(const skh_sketch_set*, uint32_t g, uint64_t* n_pos, uint64_t* n_distinct, uint64_t* n_markers,
                      uint32_t* n_contigs, uint64_t* total_len);

@@ -98,23 +98,27 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         }
         const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
         const Co qoffj = wave_readlane(qoff, j);                                    // positions are padded coordinates; intervals are contig-local
-        uint32_t lj[STATS_REG], hj[STATS_REG];
+        // the chunk's intervals as (start, width): wave-uniform values, "inside" is one unsigned compare; a chunk has one interval as a rule (mean 1.2),
+        // the tests of the others are skipped by scalar branches on their number
+        uint32_t lj[STATS_REG], wj[STATS_REG];
 #pragma unroll
-        for (int i = 0; i < STATS_REG; i++) { lj[i] = wave_readlane(lo[i], j); hj[i] = wave_readlane(hi[i], j); }
+        for (int i = 0; i < STATS_REG; i++) { lj[i] = 0; wj[i] = 0; if (i == 0 || (uint32_t)i < nj) { lj[i] = wave_readlane(lo[i], j); wj[i] = wave_readlane(hi[i], j) - lj[i]; } }
+        const uint32_t qwj = q1j - q0j;
         uint32_t cu = 0, cr = 0, cl = 0;
         auto count = [&](Co v) {
             const bool on = (v & 1u) != 0;                                          // listed in query_positions_all (0 beyond the chunk)
             const uint32_t pos = (uint32_t)((v >> 1) - qoffj);
-            bool hit = false;
+            bool hit;
             if (nj <= (uint32_t)STATS_REG) {
-#pragma unroll
-                for (int i = 0; i < STATS_REG; i++) hit = hit || (pos >= lj[i] && pos <= hj[i]);
+                hit = pos - lj[0] <= wj[0];                                         // (an active chunk has at least one interval)
+                if (nj > 1) { hit = hit || pos - lj[1] <= wj[1]; if (nj > 2) { hit = hit || pos - lj[2] <= wj[2]; if (nj > 3) hit = hit || pos - lj[3] <= wj[3]; } }
             } else {
+                hit = false;
                 for (uint32_t e = headj; e != NONE; e = ivl_next[e]) { const Interval iv = ivls[e]; const uint32_t l0 = iv.q0 > c ? iv.q0 - c : 0; hit = hit || (pos >= l0 && pos <= iv.q1 + c); }
             }
             cl += (uint32_t)__popcll(__ballot(on));                                 // chain.rs:755-780: seeds of the chunk
             cu += (uint32_t)__popcll(__ballot(on && hit));                          // chain.rs:268-272
-            cr += (uint32_t)__popcll(__ballot(on && pos >= q0j && pos <= q1j));     // chain.rs:326-332 (spacing estimates are 0)
+            cr += (uint32_t)__popcll(__ballot(on && pos - q0j <= qwj));             // chain.rs:326-332 (spacing estimates are 0)
         };
 #pragma unroll
         for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(cur[u]);

@@ -203,11 +203,14 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     T.all_gather(ctx, mine, cnt.data(), sizeof(mine), false);
     std::vector<uint64_t> base(W + 1, 0);
     uint64_t max_n = 0, max_m = 0, max_c = 0;
+    // A rank with a wide set (a genome beyond 31-bit padded coordinates, internal.h): position records are not portable then (a wide genome's are
+    // indices beside 64-bit coordinates), so ALL ranks exchange (position in contig, contig << 1 | canonical) -- the C ABI's form, 8 bytes instead
+    // of 4 -- and the chained set is made through the import path, which decides per genome from the contig lengths, the same on every rank.
+    bool wide_any = false;
     for (int r = 0; r < W; r++) {
         if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6] || (cnt[r * 8 + 7] & 255u) != (mine[7] & 255u))
             throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
-        // (every rank sees the same table, so all of them stop here together)
-        if (cnt[r * 8 + 7] & 256u) throw std::invalid_argument("a rank holds a genome beyond 2^31 padded bases: wide sketch sets are not exchanged between ranks; chain such genomes on one device");
+        if (cnt[r * 8 + 7] & 256u) wide_any = true;                                 // (every rank sees the same table)
         base[r + 1] = base[r] + cnt[r * 8]; max_n = std::max(max_n, cnt[r * 8]); max_m = std::max(max_m, cnt[r * 8 + 2]); max_c = std::max(max_c, cnt[r * 8 + 3]);
     }
     const uint64_t N64 = base[W];
@@ -337,32 +340,40 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::vector<uint32_t> wk_index(N, 0xFFFFFFFFu);                                 // global genome -> index in the chained set
     ex_begin();
     {
-        // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words)
-        std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g;
+        // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words; with a wide set somewhere:
+        // [seeds][positions in contig][contig << 1 | canonical])
+        const uint64_t NF = wide_any ? 3 : 2;                                       // 32-bit fields per seed position
+        std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g, seg_c;
         uint64_t sw = 0;
         for (int r = 0; r < W; r++) {
             uint64_t words = 0; for (uint32_t g : send_to[r]) words += g_npos[g];
-            s_off[r] = sw * 4; s_cnt[r] = words * 2 * 4;
+            s_off[r] = sw * 4; s_cnt[r] = words * NF * 4;
             uint64_t at = sw;
             for (uint32_t g : send_to[r]) {
                 const uint64_t lp = L->pos_off[g - base[me]];
-                seg_s.insert(seg_s.end(), {lp, at, g_npos[g]}); seg_g.insert(seg_g.end(), {lp, at + words, g_npos[g]});   // the position halves follow the seed halves
+                seg_s.insert(seg_s.end(), {lp, at, g_npos[g]}); seg_g.insert(seg_g.end(), {lp, at + words, g_npos[g]});   // the position parts follow the seed parts
+                if (wide_any) seg_c.insert(seg_c.end(), {lp, at + 2 * words, g_npos[g]});
                 at += g_npos[g];
             }
-            sw += words * 2;
+            sw += words * NF;
         }
         uint64_t rw = 0; std::vector<uint64_t> r_words(W, 0);
         std::vector<uint64_t> recv_at(N, 0);                                        // word offset of a received genome's seeds inside its source's block
         for (int r = 0; r < W; r++) {
             for (uint32_t g : recv_from[r]) { recv_at[g] = r_words[r]; r_words[r] += g_npos[g]; }
-            r_off[r] = rw * 4; r_cnt[r] = r_words[r] * 2 * 4; rw += r_words[r] * 2;
+            r_off[r] = rw * 4; r_cnt[r] = r_words[r] * NF * 4; rw += r_words[r] * NF;
         }
         st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
-        uint32_t *d_send = nullptr, *d_recv = nullptr;
+        uint32_t *d_send = nullptr, *d_recv = nullptr, *l_pos = nullptr, *l_cc = nullptr;   // l_pos / l_cc: the local set's positions in the C ABI's form (wide_any)
         local([&] {
             d_send = ctx->arena.get<uint32_t>(sw + 1); d_recv = ctx->arena.get<uint32_t>(rw + 1);
             copy_segments(ctx, L->p_seed.p, d_send, seg_s);
-            copy_segments(ctx, L->p_g.p, d_send, seg_g);
+            if (wide_any) {
+                const uint64_t PL = L->pos_off[nL];
+                l_pos = ctx->arena.get<uint32_t>(PL + 1); l_cc = ctx->arena.get<uint32_t>(PL + 1);
+                unpack_positions(ctx, L, 0, PL, l_pos, l_cc);
+                copy_segments(ctx, l_pos, d_send, seg_g); copy_segments(ctx, l_cc, d_send, seg_c);
+            } else copy_segments(ctx, L->p_g.p, d_send, seg_g);
             dsync(ctx->stream);
         });
         agree("sketch exchange buffers");
@@ -382,18 +393,28 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             }
             finalize_metadata(Wk.get());
             const uint64_t PW = Wk->pos_off[nW], MW = Wk->mk_off[nW];
-            Wk->p_seed.alloc(PW ? PW : 1); Wk->p_g.alloc(PW); Wk->markers.alloc(MW ? MW : 1);
-            std::vector<uint64_t> ls, lg, rs, rg, mseg;                             // local / received seed and position segments; markers: already here (step 2), 64-bit = two words
+            Wk->p_seed.alloc(PW ? PW : 1); Wk->markers.alloc(MW ? MW : 1);
+            uint32_t *w_pos = nullptr, *w_cc = nullptr;                             // wide_any: the chained set's positions in the C ABI's form, for the import path
+            if (wide_any) { w_pos = ctx->arena.get<uint32_t>(PW + 1); w_cc = ctx->arena.get<uint32_t>(PW + 1); } else Wk->p_g.alloc(PW);
+            std::vector<uint64_t> ls, lg, rs, rg, rc, mseg;                         // local / received seed and position segments; markers: already here (step 2), 64-bit = two words
             for (uint32_t x = 0; x < nW; x++) {
                 const uint32_t g = wk_ids[x]; const uint64_t n = g_npos[g], dst = Wk->pos_off[x];
                 if (rank_of[g] == me) { const uint64_t lp = L->pos_off[g - base[me]]; ls.insert(ls.end(), {lp, dst, n}); lg.insert(lg.end(), {lp, dst, n}); }
-                else { const uint64_t b0 = r_off[rank_of[g]] / 4; rs.insert(rs.end(), {b0 + recv_at[g], dst, n}); rg.insert(rg.end(), {b0 + r_words[rank_of[g]] + recv_at[g], dst, n}); }
+                else {
+                    const uint64_t b0 = r_off[rank_of[g]] / 4, rwd = r_words[rank_of[g]];
+                    rs.insert(rs.end(), {b0 + recv_at[g], dst, n}); rg.insert(rg.end(), {b0 + rwd + recv_at[g], dst, n});
+                    if (wide_any) rc.insert(rc.end(), {b0 + 2 * rwd + recv_at[g], dst, n});
+                }
                 mseg.insert(mseg.end(), {S.mk_off[g] * 2, Wk->mk_off[x] * 2, g_nmk[g] * 2});
             }
-            copy_segments(ctx, L->p_seed.p, Wk->p_seed.p, ls); copy_segments(ctx, L->p_g.p, Wk->p_g.p, lg);
-            copy_segments(ctx, d_recv, Wk->p_seed.p, rs); copy_segments(ctx, d_recv, Wk->p_g.p, rg);
+            copy_segments(ctx, L->p_seed.p, Wk->p_seed.p, ls); copy_segments(ctx, d_recv, Wk->p_seed.p, rs);
+            if (wide_any) {
+                copy_segments(ctx, l_pos, w_pos, lg); copy_segments(ctx, l_cc, w_cc, lg);
+                copy_segments(ctx, d_recv, w_pos, rg); copy_segments(ctx, d_recv, w_cc, rc);
+            } else { copy_segments(ctx, L->p_g.p, Wk->p_g.p, lg); copy_segments(ctx, d_recv, Wk->p_g.p, rg); }
             copy_segments(ctx, (const uint32_t*)S.markers.p, (uint32_t*)Wk->markers.p, mseg);
             Wk->d_mk_off.alloc(nW + 1); h2d(Wk->d_mk_off.p, Wk->mk_off.data(), (nW + 1) * 8, ctx->stream);
+            if (wide_any) { Stopwatch sw2(ctx, &ctx->timings.sketch_build_ms); build_sketch_tables(ctx, Wk.get(), w_pos, w_cc); }   // (the position arrays live in the arena: the tables are made here)
             dsync(ctx->stream);
         });
     }

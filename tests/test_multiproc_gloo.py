@@ -22,7 +22,10 @@ def _case(case):
     """interleave / interleave4: 3 clades x 4 members dealt out so that most candidate pairs cross the rank blocks (sketches travel);
     blocks: 2 clades x 6, one per rank -- nothing has to move;
     uneven: 3 clades x 4 spread over four ranks holding 5, 0, 4 and 3 genomes (clades span the rank boundaries; one rank holds nothing);
-    dense: ONE clade of 12 genomes on three ranks -- all 66 pairs are chained and have to be split evenly although they form one cluster."""
+    dense: ONE clade of 12 genomes on three ranks -- all 66 pairs are chained and have to be split evenly although they form one cluster;
+    wide_one_rank: "interleave" with SKH_TUNE_WIDE_SPAN=0 on rank 0 only -- its sketch set is a wide one (64-bit coordinates, the form of genomes beyond
+        2^31 padded bases), the other rank's is not: the ranks then exchange positions in the C ABI's form and every rank makes the set it chains its own way;
+    wide_mixed: every other genome carries an extra contig that takes it past SKH_TUNE_WIDE_SPAN=90000 on all ranks: wide and ordinary genomes in every set."""
     from tests.parity_cases import synthetic_clades
     if case == "blocks":
         return synthetic_clades(n_clades=2, members=6, length=60000, seed=61, tiny=False), [6, 6]
@@ -35,7 +38,14 @@ def _case(case):
         return [g[(k % 4) * 4 + k // 4] for k in range(16)], [2] * 8
     g = synthetic_clades(n_clades=3, members=4, length=60000, seed=51, tiny=False)
     g = [g[(k % 3) * 4 + k // 3] for k in range(12)]
-    return g, {"interleave": [6, 6], "interleave4": [3, 3, 3, 3], "uneven": [5, 0, 4, 3]}[case]
+    if case == "wide_mixed":
+        from tests.helpers import random_genome
+        g = [x + [("extra%d" % k, random_genome(30000, 900 + k))] if k % 2 == 0 else x for k, x in enumerate(g)]
+    return g, {"interleave": [6, 6], "interleave4": [3, 3, 3, 3], "uneven": [5, 0, 4, 3], "wide_one_rank": [6, 6], "wide_mixed": [4, 4, 4]}[case]
+
+
+def _wide_span_of(case, rank):
+    return {"wide_one_rank": "0" if rank == 0 else None, "wide_mixed": "90000"}.get(case)
 
 
 def _worker(rank, world, port, q, case):
@@ -47,6 +57,7 @@ def _worker(rank, world, port, q, case):
     from tests.emu_lib import emu_lib
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if _wide_span_of(case, rank) is not None: os.environ["SKH_TUNE_WIDE_SPAN"] = _wide_span_of(case, rank)
         ctx = sk.Context(0, lib=emu_lib())
         genomes, held = _case(case)
         base = sum(held[:rank])
@@ -54,14 +65,15 @@ def _worker(rank, world, port, q, case):
         params = sk.SketchParams()
         gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in mine], params.seeding_mode)      # file_io.rs:176
         # half of the cases sketch with deferred seed tables (what bench.py does on several GPUs): a rank then indexes only the sketches it chains
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks", "interleave8"))
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks", "interleave8", "wide_mixed"))
+        if case.startswith("wide"): assert ss_local.wide == (case == "wide_mixed" or rank == 0)
         i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, with_stats=True)
         q.put((rank, i, j, res, n, st))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense", "interleave8"])
+@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense", "interleave8", "wide_one_rank", "wide_mixed"])
 def test_multi_rank_triangle_matches_single_process(case):
     import multiprocessing as mp
     import skani_amd as sk
@@ -99,7 +111,7 @@ def test_multi_rank_triangle_matches_single_process(case):
     assert all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))
     if case == "blocks":        # one cluster per rank: nothing travels
         assert all(s["bytes_received"] == 0 and s["n_genomes_received"] == 0 for s in stats)
-    if case in ("interleave", "interleave4", "uneven", "interleave8"):
+    if case in ("interleave", "interleave4", "uneven", "interleave8", "wide_one_rank", "wide_mixed"):
         assert sum(s["n_genomes_received"] for s in stats) > 0 and sum(s["bytes_sent"] for s in stats) == sum(s["bytes_received"] for s in stats) > 0
     if case == "dense":         # one cluster of 66 pairs over three ranks: cut into tiles, shares within 10 % of the mean
         mean = n / world
