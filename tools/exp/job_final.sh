@@ -2,10 +2,11 @@
 # usage (GPU box): tools/exp/job_final.sh <tag>: everything the round's profiles/ are made from
 tag=$1
 timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/gpu_tests_$tag.log 2>&1; tail -14 gpurun_out/gpu_tests_$tag.log
-timeout 600 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || tail -5 gpurun_out/bench_$tag.err
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")"
+timeout 900 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || tail -5 gpurun_out/bench_$tag.err
 python -c "
 import json; d=json.load(open('gpurun_out/bench_$tag.json')); print(round(d['ms_per_step'],3), {k: round(v,2) for k,v in d['phase_ms_per_step'].items()}, round(d['roofline']['ms_per_launch'],3), d['cpu_baseline']['delta_vs_oracle'], round(d['cpu_baseline']['value']), d['cpu_baseline']['cores'], d['e2e']['wall_s'] if 'wall_s' in d.get('e2e', {}) else d.get('e2e'))"
-tools/prof.sh $tag > /dev/null 2>&1; head -30 gpurun_out/trace_$tag.txt | cut -c1-66,98-125
+tools/prof.sh $tag --no-e2e > /dev/null 2>&1; head -30 gpurun_out/trace_$tag.txt | cut -c1-66,98-125
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_gaps.py $db gpurun_out/gaps_$tag.txt | head -3
 python tools/rocpd_timeline.py $db gpurun_out/timeline_$tag.txt
