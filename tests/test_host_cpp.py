@@ -212,6 +212,41 @@ def test_cli_triangle_streaming_ingest(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_triangle_with_genomes_beyond_31_bits(tmp_path):
+    """Two assemblies of 270,000 contigs of 600 bases (2.37 G padded bases each: a wide sketch set) and an ordinary genome through `skani-hip triangle`:
+    the streaming ingest with a thousand times more contigs than it announced, the wide run for the two assemblies and the ordinary path in one call;
+    the matrix against the oracle."""
+    from tests.helpers import big_random_genome, big_mutate, random_genome, ora
+    _, exe = build_host()
+    n_ctg, ln = 270000, 600
+    a = big_random_genome(n_ctg * ln, 31); b = big_mutate(a, 0.02, 32)
+    small = a[:3_000_000].tobytes()
+    recs = []
+    for x in (a, b):
+        rows = x.reshape(n_ctg, ln)
+        recs.append([("c%d" % i, rows[i].tobytes()) for i in range(n_ctg)])
+    recs.append([("s0", small)])
+    names = ["w0.fa", "w1.fa", "w2.fa"]
+    for nm, rs in zip(names, recs):
+        with open(tmp_path / nm, "wb") as f:
+            f.write(b"".join(b">" + n.encode() + b"\n" + s + b"\n" for n, s in rs))
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"), SKH_TIMING="1")
+    out = subprocess.run([exe, "triangle", "-t", "8"] + names, capture_output=True, text=True, cwd=tmp_path, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert '"parse_upload_pack_s"' in out.stderr                                      # the streaming path ran
+    lines = out.stdout.splitlines()
+    assert lines[0] == "3" and [l.split("\t")[0] for l in lines[1:]] == names
+    osk = [ora.sketch_records(rs, file_name=nm) for nm, rs in zip(names, recs)]
+    model = ora.Model(os.path.join(os.path.dirname(sk.library_path()), "data", "gbdt_c125.bin"))
+    oi, oj, ores, _, _ = ora.triangle(osk, screen_val=0.8, model=model)
+    want = {(int(i), int(j)): "%.2f" % (float(np.float32(r["ani"]) * np.float32(100))) for i, j, r in zip(oi, oj, ores)}
+    assert (0, 1) in want
+    for row in range(1, 3):
+        assert lines[1 + row].split("\t")[1:] == [want.get((col, row), "0.00") for col in range(row)]
+    assert float(lines[2].split("\t")[1]) > 95.0                                     # the two assemblies are 2 % apart
+
+
+@pytest.mark.gpu
 def test_cli_sketch_then_search_reproduces_the_reference_golden_rows(tmp_path):
     """tests/integration_test.rs:59-68 + test_results_versions/0.3.0:130-135: `search --median` of the o157 sketch against
     a database of the plasmid and W must print 100.00/99.84/1.68 and 98.39/85.46/75.97.  Both database flavours, a
