@@ -189,12 +189,12 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
             const size_t lds = (size_t)bm_words * 4 + (size_t)JOIN_GROUP * JOIN_Q * 8;   // the filter + a probe queue per wave
             if (lds > ((size_t)48 << 10)) kernel_allow_lds(join_count_kernel<false>, lds);
             if (!join_trace)
-                SKH_LAUNCH(join_count_kernel<false>, n_super_slots, 256, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
+                SKH_LAUNCH(join_count_kernel<false>, n_super_slots, JOIN_THREADS, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
                            band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words, (unsigned long long*)nullptr);
             else {                                                                     // SKH_TRACE_JOIN=1: where a wave of the count pass spends its cycles (slower: every phase waits for its loads)
                 unsigned long long* d_prof = ctx->arena.get<unsigned long long>(16); dzero(d_prof, 128, ctx->stream);
                 if (lds > ((size_t)48 << 10)) kernel_allow_lds(join_count_kernel<true>, lds);
-                SKH_LAUNCH(join_count_kernel<true>, n_super_slots, 256, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
+                SKH_LAUNCH(join_count_kernel<true>, n_super_slots, JOIN_THREADS, lds, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_super_slots,
                            band, tile_anch, tile_hits, d_pair_anch, d_pair_inq, pis, imk, bm_words, d_prof);
                 unsigned long long hp[16]; d2h(hp, d_prof, 128, ctx->stream);
                 const double nw = hp[8] ? (double)hp[8] : 1.;
@@ -231,7 +231,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         if (nt) {
             uint2* d_slots = d_super_slots; unsigned n_slots = n_super_slots;
             if (t0 != st0 || t1 != st1) d_slots = xcd_slots(ctx, p0, p1, pds, d_pairs_all, job.pair_key, &n_slots);
-            SKH_LAUNCH(join_fill_kernel, n_slots, 256, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
+            SKH_LAUNCH(join_fill_kernel, n_slots, JOIN_THREADS, 0, ctx->stream, (const PairDesc*)d_pairs_all, (const uint2*)d_slots,
                        t0, (const uint32_t*)toff_a, (const uint32_t*)tile_hits, (const uint2*)pis, anc_q32, anc_r32);
             check_launch("join_fill");
         }

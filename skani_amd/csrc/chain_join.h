@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t wave_excl_small(uint32_t c, uint32_t l, uint
     return (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
 }
 template <bool PROF>
-__global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, const uint2* slot_tile,
+__global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc* pairs, const uint2* slot_tile,
                                                          uint32_t band, uint32_t* tile_anch, uint32_t* tile_hits, uint32_t* pair_anch, uint32_t* pair_inq,
                                                          uint2* hits, unsigned long long* inq_mask, uint32_t lds_words, unsigned long long* prof = nullptr) {
     SKH_DYN_SMEM(smem);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
     const bool use_bm = bm_words <= lds_words;
     if (use_bm) {                                                                    // B's occupancy filter, staged once for the workgroup's tiles (the only barrier)
         const uint4* src = (const uint4*)pd.b_bmap;
-        for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += 256) ((uint4*)bm)[w4] = src[w4];
+        for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += JOIN_THREADS) ((uint4*)bm)[w4] = src[w4];
         __syncthreads();
     }
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const PairDesc* pairs, 
 // Emits the anchors of the tiles at the offsets given by the tile scan, from the hit records of join_count_kernel (no second probe).  Same
 // shape: four tiles per workgroup, a wave per tile, 256 hits per round with the wave's own running offset -- no barrier at all.  The pass moves
 // 0.9 GB in and 2.4 GB out in 0.50 ms (6.6 TB/s): HBM-bound; two tiles per wave with the second tile's records prefetched changed nothing (0.52 ms).
-__global__ __launch_bounds__(256) void join_fill_kernel(const PairDesc* pairs, const uint2* slot_tile, uint32_t tile_base, const uint32_t* toff_a,
+__global__ __launch_bounds__(JOIN_THREADS) void join_fill_kernel(const PairDesc* pairs, const uint2* slot_tile, uint32_t tile_base, const uint32_t* toff_a,
                                                         const uint32_t* tile_hits, const uint2* hits, uint32_t* anc_q, uint32_t* anc_r) {
     constexpr int R = 4;
     const uint2 st = slot_tile[blockIdx.x];

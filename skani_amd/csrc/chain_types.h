@@ -53,7 +53,8 @@ struct Wide {
 };
 
 constexpr uint32_t JOIN_TILE = 1024;    // positions per join tile (one wave: 4 rounds x 4 probes per lane)
-constexpr uint32_t JOIN_GROUP = 4;      // tiles per join workgroup (one wave each)
+constexpr uint32_t JOIN_GROUP = 4;      // tiles per join workgroup (one wave each); count pass with 2 / 4 / 8 / 16: 2.92 / 2.16 / 2.42 / 2.60 ms
+constexpr uint32_t JOIN_THREADS = 64 * JOIN_GROUP;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // An anchor is 8 bytes in two arrays: anc_q = padded query coordinate, anc_r = padded ref coordinate << 1 | reverse_match
