@@ -463,24 +463,33 @@ def main():
                 comm = Comm.host(ctx, dist, rank, world, torch=torch)
     last = {}
 
+    host_t = [0.0, 0.0, 0.0]                      # BENCH_STEP_TIMES=1: wall time of a step's three calls as the host sees them (stderr)
+
     def step():
         # genome_rank = global index: the collection's names sort like its indices
         # several GPUs: seed tables deferred -- every rank indexes only the sketches it ends up chaining (its own that stay + the ones it receives)
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32), defer_tables=comm is not None)
+        t0 = time.perf_counter()
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=genome_rank, defer_tables=comm is not None)
+        t1 = time.perf_counter()
         if comm is None:
             i, j, res, n_chained = ctx.triangle(ss_local, mp)
         else:
             i, j, res, n_chained, last["stats"] = comm.triangle(ss_local, mp)
+        t2 = time.perf_counter()
         ss_local.close()
+        t3 = time.perf_counter()
+        host_t[0] += t1 - t0; host_t[1] += t2 - t1; host_t[2] += t3 - t2
         last["result"] = (i, j, res)
         return len(i), n_chained
 
+    genome_rank = np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32)
     with stdout_to_stderr():                      # (the first collective may still print)
         for _ in range(args.warmup):
             step()
         if comm is not None and args.warmup == 0:
             dist.barrier()
     ctx.timings()
+    host_t[:] = [0.0, 0.0, 0.0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -493,6 +502,9 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
+    if os.environ.get("BENCH_STEP_TIMES"):
+        print("host view of a step (ms): sketch_genomes %.3f, triangle %.3f, sketch set close %.3f; library timers: %s" %
+              tuple([1e3 * x / args.steps for x in host_t] + [{k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms")}]), file=sys.stderr)
     per_rank = None
     if comm is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
