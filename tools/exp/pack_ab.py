@@ -1,4 +1,4 @@
-"""pack_kernel variants (tools/exp/build_pack_variants.py) on device-resident ASCII: ms per 4.9 Gbases from the context's pack timer."""
+"""pack_kernel variants (tools/exp/build_variants.py pack_seed.hip PACK_ROUNDS_N 4 8 16) on device-resident ASCII: ms per 4.9 Gbases from the context's pack timer."""
 import sys, glob, os
 import numpy as np
 sys.path.insert(0, '.')
@@ -14,7 +14,7 @@ for at in range(0, codes.numel(), 1 << 28): bases[at:at + (1 << 28)] = lut[codes
 del codes
 contig_off = np.arange(n_genomes + 1, dtype=np.uint64) * L
 contig_genome = np.arange(n_genomes, dtype=np.uint32)
-for path in sorted(glob.glob("tools/exp/variants/libskani_hip_r*.so")):
+for path in sorted(glob.glob("tools/exp/variants/libskani_hip_*.so")):
     lib = B.load(path)
     ctx = sk.Context(0, lib=lib)
     res = []
