@@ -21,3 +21,6 @@ timeout 300 python bench.py --genomes-per-gpu 5000 --cpu-clades 0 --steps 2 2>/d
 timeout 300 python bench.py --clade 1000 --cpu-clades 0 --steps 1 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dense', round(d['ms_per_step'],1), d['config']['chained_pairs'])"
 timeout 400 python tools/fuzz_parity.py 1500 $RANDOM | tail -1
 timeout 200 python tools/fuzz_parity.py 100 $RANDOM big | tail -1
+SKH_TUNE_WIDE_SPAN=0 timeout 300 python tools/fuzz_parity.py 600 $RANDOM | tail -1
+SKH_TUNE_WIDE_SPAN=120000 timeout 300 python tools/fuzz_parity.py 600 $RANDOM | tail -1
+SKH_TUNE_GREEDY_BIG_MIN=2 timeout 300 python tools/fuzz_parity.py 400 $RANDOM | tail -1
