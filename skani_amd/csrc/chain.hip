@@ -368,7 +368,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 if (pair_anch[p0 + i] == 0) { st.switched = 1; st.n_qpos = 0; }   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
-        dsync(ctx->stream);
+        d2h(out + p0, d_out + p0, (size_t)np * sizeof(skh_ani_result), ctx->stream);   // the batch's results; this is also the batch's synchronisation
         ctx->arena.rewind(arena_mark);
         p0 = p1;
         }
@@ -377,7 +377,6 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     }
     uint32_t h_err = 0;
     d2h(&h_err, d_err, 4, ctx->stream);
-    d2h(out, d_out, (uint64_t)NP * sizeof(skh_ani_result), ctx->stream);
     tr.mark("results d2h");
     if (h_err) throw Error("internal capacity bound violated in chain pipeline (" + std::to_string(h_err) + " events)");
 }
