@@ -134,13 +134,19 @@ skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
 
 // SKH_TIMING=1: wall-clock of the driver's phases on stderr, one JSON object (bench.py --workload e2e reads it)
 struct PhaseClock {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0; std::string json; bool on = getenv("SKH_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0; bool on = getenv("SKH_TIMING") != nullptr;
+    std::vector<std::pair<std::string, double>> phases;                              // a phase that is marked twice (the two sides of `dist`) adds up
     void mark(const char* name) {
-        const auto n = std::chrono::steady_clock::now();
-        char b[96]; snprintf(b, sizeof b, "%s\"%s_s\": %.6f", json.empty() ? "" : ", ", name, std::chrono::duration<double>(n - last).count());
-        json += b; last = n;
+        const auto n = std::chrono::steady_clock::now(); const double dt = std::chrono::duration<double>(n - last).count(); last = n;
+        for (auto& p : phases) if (p.first == name) { p.second += dt; return; }
+        phases.emplace_back(name, dt);
     }
-    void done() { if (on) fprintf(stderr, "{%s, \"total_s\": %.6f}\n", json.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    void done() {
+        if (!on) return;
+        std::string json;
+        for (auto& p : phases) { char b[96]; snprintf(b, sizeof b, "\"%s_s\": %.6f, ", p.first.c_str(), p.second); json += b; }
+        fprintf(stderr, "{%s\"total_s\": %.6f}\n", json.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
 };
 PhaseClock g_clock;
 
@@ -380,8 +386,17 @@ int run_dist(Args& a, Ctx& cx) {
     const uint32_t rc = a.c, rk = a.k, rm = a.m;
     if (q_sk) lq = load_side(cx, q, a.qi, a);
     if (r_sk && q_sk && (rc != a.c || rk != a.k || rm != a.m)) die("Query sketch parameters were not equal to reference sketch parameters. Exiting.");
-    if (!r_sk) lr = load_side(cx, r, a.ri, a);
-    if (!q_sk) lq = load_side(cx, q, a.qi, a);
+    // FASTA sides: the streaming ingest of `triangle` (parser threads -> pinned buffers -> asynchronous copy + pack) when the files allow it.  A set made
+    // that way numbers its genomes by the sorted file list, files without a kept contig included: *_row maps a genome to its entry in `info`.
+    std::vector<uint32_t> r_row, q_row;
+    auto fasta_side = [&](const std::vector<std::string>& files, bool individual, std::vector<uint32_t>& row) {
+        Side sd;
+        if (!individual) { Streamed st = stream_side(cx, files, a); if (st.ok) { sd.ss = st.ss; sd.info = std::move(st.info); row = std::move(st.kept_index); return sd; } }
+        sd = load_side(cx, files, individual, a); g_clock.mark("load_sketch");
+        return sd;
+    };
+    if (!r_sk) lr = fasta_side(r, a.ri, r_row);
+    if (!q_sk) lq = fasta_side(q, a.qi, q_row);
     if (lq.info.empty() || lr.info.empty()) die("No reference sketches/genomes or query sketches/genomes found.");
     skh_sketch_set* sq = lq.ss; skh_sketch_set* sr = lr.ss;
     const bool learned = !a.no_learned && a.c >= 70 && !a.qi && !a.ri && !a.median;   // parse.rs:752-756
@@ -393,9 +408,11 @@ int run_dist(Args& a, Ctx& cx) {
     std::vector<skh_ani_result> res(np);
     cx.check(skh_chain_pairs(cx.c, sr, sq, prf, pq, np, &mp, res.data(), nullptr), "skh_chain_pairs");   // chain_seeds(ref, query): dist.rs:114
     std::vector<PairResult> pr;
-    for (uint64_t x = 0; x < np; x++) if (res[x].ani > 0.1f) pr.push_back(PairResult{prf[x], pq[x], res[x]});   // dist.rs:115
+    for (uint64_t x = 0; x < np; x++) if (res[x].ani > 0.1f) pr.push_back(PairResult{r_row.empty() ? prf[x] : r_row[prf[x]], q_row.empty() ? pq[x] : q_row[pq[x]], res[x]});   // dist.rs:115
     skh_free(pq); skh_free(prf);
+    g_clock.mark("screen_chain");
     emit(a.out, format_query_ref_list(lr.info, lq.info, pr, a.n, a.o));
+    g_clock.mark("write");
     skh_sketch_set_destroy(sq); skh_sketch_set_destroy(sr);
     return 0;
 }
