@@ -27,12 +27,15 @@ char* skhost_fasta_summary(const char* path, uint64_t min_len) {
     } catch (const std::exception& e) { return dup(std::string("ERROR ") + e.what()); }
 }
 // the mapped-file parser of the streaming ingest: "name\tlen\n" per kept contig, then "=" and the kept bases as they were written; "NOT PLAIN" for gzip / FASTQ
-char* skhost_fasta_plain(const char* path, uint64_t min_len) {
+char* skhost_fasta_plain_threads(const char* path, uint64_t min_len, int threads);
+char* skhost_fasta_plain(const char* path, uint64_t min_len) { return skhost_fasta_plain_threads(path, min_len, 1); }
+// threads > 1: the several-thread parse whatever the file's size
+char* skhost_fasta_plain_threads(const char* path, uint64_t min_len, int threads) {
     try {
         FILE* f = fopen(path, "rb"); if (!f) return dup("ERROR cannot open");
         fseek(f, 0, SEEK_END); const long n = ftell(f); fclose(f);
         std::vector<uint8_t> dst((size_t)n + 16); size_t used = 0; std::vector<std::string> names; std::vector<uint64_t> lens;
-        if (!parse_fasta_plain(path, dst.data(), dst.size(), (size_t)min_len, &used, names, lens)) return dup("NOT PLAIN");
+        if (!parse_fasta_plain(path, dst.data(), dst.size(), (size_t)min_len, &used, names, lens, threads, 0)) return dup("NOT PLAIN");
         std::string s;
         for (size_t i = 0; i < names.size(); i++) s += names[i] + "\t" + std::to_string(lens[i]) + "\n";
         return dup(s + "=" + std::string((const char*)dst.data(), used));

@@ -79,7 +79,43 @@ std::vector<Record> read_fasta(const std::string& path) {
     return out;
 }
 
-bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t min_len, size_t* used, std::vector<std::string>& names, std::vector<uint64_t>& lens) {
+// A file of `par_min` bytes or more (a eukaryote's chromosomes in one file) is parsed by `threads` threads: the file is cut at byte offsets, every thread
+// takes the lines that START in its stretch -- header lines ('>' at a line start) and sequence lines --, first to count the bases between the
+// headers, then, once the contigs' lengths and places are known, to copy them.  One thread, line by line, managed 1.9 GB/s: 2.4 s of the 3.0 s a
+// human-sized pair took end to end.
+namespace {
+struct Stretch {                                     // what one thread found in its part of the file
+    struct Header { size_t pos, end; uint64_t bases; };   // the header line [pos, end) and the bases behind it up to the next header of this stretch / its end
+    uint64_t before = 0;                             // bases in front of the stretch's first header: they belong to the contig an earlier stretch opened
+    std::vector<Header> headers;
+};
+// calls on_header(pos, end) / on_seq(pos, end) for every line that starts in [lo, hi); `end` excludes the line feed
+template <class H, class S>
+void walk_lines(const char* data, size_t n, size_t lo, size_t hi, bool lo_starts_a_line, H on_header, S on_seq) {
+    size_t p = lo;
+    if (!lo_starts_a_line && p > 0 && data[p - 1] != '\n') { const char* nl = (const char*)memchr(data + p, '\n', n - p); p = nl ? (size_t)(nl - data) + 1 : n; }   // the line in progress belongs to the stretch before
+    while (p < hi && p < n) {
+        const char* le = (const char*)memchr(data + p, '\n', n - p);
+        const size_t l = le ? (size_t)(le - data) : n;
+        if (data[p] == '>') on_header(p, l); else on_seq(p, l);
+        p = l < n ? l + 1 : n;
+    }
+}
+inline size_t copy_line(const char* data, size_t p, size_t l, uint8_t* dst) {          // the line's bytes without carriage returns; returns their number
+    const size_t len = l - p;
+    if (!memchr(data + p, '\r', len)) { memcpy(dst, data + p, len); return len; }
+    size_t k = 0; for (size_t i = p; i < l; i++) if (data[i] != '\r') dst[k++] = (uint8_t)data[i];
+    return k;
+}
+inline size_t count_line(const char* data, size_t p, size_t l) {
+    size_t k = l - p; const char* q = data + p; size_t left = l - p;
+    while (const char* r = (const char*)memchr(q, '\r', left)) { k--; left -= (size_t)(r - q) + 1; q = r + 1; }
+    return k;
+}
+}  // namespace
+
+bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t min_len, size_t* used, std::vector<std::string>& names, std::vector<uint64_t>& lens,
+                       int threads, size_t par_min) {
     *used = 0; names.clear(); lens.clear();
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + path);
@@ -100,6 +136,52 @@ bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t
     if (data[p] == '@') return false;                                                                     // FASTQ
     if (data[p] != '>') throw std::runtime_error(path + " is not a valid fasta/fastq file");
     if (cap < n) throw std::runtime_error("parse_fasta_plain: destination smaller than the file");
+    if (threads > 1 && n >= par_min) {
+        // ---- several threads.  The first header is at p (a line start: only line ends and blanks precede it); the stretches begin there.
+        const size_t T = (size_t)threads, first = p;
+        std::vector<size_t> cut(T + 1); for (size_t t = 0; t <= T; t++) cut[t] = first + (n - first) / T * t; cut[T] = n;
+        std::vector<Stretch> st(T);
+        auto each = [&](auto fn) { std::vector<std::thread> th; for (size_t t = 1; t < T; t++) th.emplace_back(fn, t); fn((size_t)0); for (auto& x : th) x.join(); };
+        each([&](size_t t) {
+            Stretch& S = st[t];
+            walk_lines(data, n, cut[t], cut[t + 1], t == 0,
+                       [&](size_t a, size_t e) { S.headers.push_back({a, e, 0}); },
+                       [&](size_t a, size_t e) { const size_t k = count_line(data, a, e); if (S.headers.empty()) S.before += k; else S.headers.back().bases += k; });
+        });
+        // contigs in file order: a header's bases run on through the header-less fronts of the stretches behind it
+        struct Contig { size_t t, h; uint64_t len, at; bool kept; };
+        std::vector<Contig> ctg;
+        for (size_t t = 0; t < T; t++) {
+            if (!ctg.empty()) ctg.back().len += st[t].before;
+            for (size_t h = 0; h < st[t].headers.size(); h++) ctg.push_back({t, h, st[t].headers[h].bases, 0, false});
+        }
+        uint64_t at = 0;
+        for (auto& c : ctg) { c.kept = c.len >= min_len; c.at = at; if (c.kept) at += c.len; }             // file_io.rs:176: shorter contigs are skipped
+        // where every stretch writes: its front continues the last contig opened before it, then its own contigs
+        std::vector<uint64_t> front_at(T, 0); std::vector<char> front_kept(T, 0);
+        {
+            size_t ci = 0; uint64_t run = 0; bool open = false, kept = false;                               // `run`: bases of the open contig written by earlier stretches
+            for (size_t t = 0; t < T; t++) {
+                if (open) { front_at[t] = ctg[ci - 1].at + run; front_kept[t] = kept; run += st[t].before; }
+                for (size_t h = 0; h < st[t].headers.size(); h++) { open = true; kept = ctg[ci].kept; run = st[t].headers[h].bases; ci++; }
+            }
+        }
+        each([&](size_t t) {
+            size_t ci = 0; for (size_t u = 0; u < t; u++) ci += st[u].headers.size();                         // index of this stretch's first own contig
+            uint8_t* w = front_kept[t] ? dst + front_at[t] : nullptr;
+            walk_lines(data, n, cut[t], cut[t + 1], t == 0,
+                       [&](size_t, size_t) { w = ctg[ci].kept ? dst + ctg[ci].at : nullptr; ci++; },
+                       [&](size_t a, size_t e) { if (w) w += copy_line(data, a, e, w); });
+        });
+        for (auto& c : ctg) if (c.kept) {
+            const Stretch::Header& H = st[c.t].headers[c.h];
+            std::string name(data + H.pos + 1, H.end - H.pos - 1);
+            while (!name.empty() && name.back() == '\r') name.pop_back();
+            names.push_back(std::move(name)); lens.push_back(c.len);
+        }
+        *used = at;
+        return true;
+    }
     size_t at = 0;                                                                                        // bytes kept so far
     while (p < n) {                                                                                       // data[p] == '>'
         const char* eol = (const char*)memchr(data + p, '\n', n - p);
@@ -110,9 +192,8 @@ bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t
         const size_t start = at;
         while (p < n && data[p] != '>') {                                                                 // sequence lines up to the next header line
             const char* le = (const char*)memchr(data + p, '\n', n - p);
-            size_t l = le ? (size_t)(le - data) : n, len = l - p;
-            if (memchr(data + p, '\r', len)) { for (size_t i = p; i < l; i++) if (data[i] != '\r') dst[at++] = (uint8_t)data[i]; }
-            else { memcpy(dst + at, data + p, len); at += len; }
+            const size_t l = le ? (size_t)(le - data) : n;
+            at += copy_line(data, p, l, dst + at);
             p = l < n ? l + 1 : n;
         }
         if (at - start >= min_len) { names.push_back(std::move(name)); lens.push_back(at - start); }

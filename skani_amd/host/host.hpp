@@ -19,7 +19,8 @@ std::vector<Record> read_fasta(const std::string& path);
 // The same for a plain (uncompressed) FASTA file, without the intermediate strings: the file is mapped and the sequence bytes of every contig of at least
 // min_len bases are written one after the other to dst (which must hold the file's size); names / lens describe the kept contigs in file order.
 // Returns false -- nothing written -- when the file is gzipped or FASTQ: the caller takes read_fasta.  Throws like read_fasta.
-bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t min_len, size_t* used, std::vector<std::string>& names, std::vector<uint64_t>& lens);
+bool parse_fasta_plain(const std::string& path, uint8_t* dst, size_t cap, size_t min_len, size_t* used, std::vector<std::string>& names, std::vector<uint64_t>& lens,
+                       int threads = 1, size_t par_min = (size_t)256 << 20);   // files of par_min bytes or more are parsed by `threads` threads
 
 // One entry per Sketch (types.rs:252-277): what the host keeps next to the device-resident sketch set.
 struct GenomeInfo {

@@ -156,6 +156,20 @@ PhaseClock g_clock;
 // files are laid out beforehand: consecutive files of the sorted list share a buffer, every file gets a stretch of its own size, the buffers rotate
 // through SLOTS pinned allocations.  Genome number = the file's position in the sorted list (file_io.rs:250); files that end up without a kept
 // contig are taken out of the numbering afterwards.  Only for plain FASTA files; anything gzipped or FASTQ sends the whole run through load_genomes().
+// The pinned buffers of the streaming ingest outlive a call: `dist` runs it once per side, and page-locking a buffer the size of a chromosome file takes
+// longer than parsing the file (0.45 s for 2.3 GB).  Handed back by main() at the end.
+struct PinnedPool {
+    std::vector<std::pair<uint8_t*, uint64_t>> have;
+    uint8_t* take(uint64_t bytes) {
+        for (auto& b : have) if (b.first && b.second >= bytes) { uint8_t* p = b.first; b.first = nullptr; return p; }
+        for (auto& b : have) if (b.first) { skh_host_free(b.first); b.first = nullptr; }                  // too small: make room before asking for more
+        return (uint8_t*)skh_host_alloc(bytes);
+    }
+    void give(uint8_t* p, uint64_t bytes) { if (!p) return; for (auto& b : have) if (!b.first) { b = {p, bytes}; return; } have.emplace_back(p, bytes); }
+    void release() { for (auto& b : have) if (b.first) { skh_host_free(b.first); b.first = nullptr; } }   // (called by main before the runtime goes away)
+};
+PinnedPool g_pinned;
+
 struct Streamed { bool ok = false; skh_sketch_set* ss = nullptr; std::vector<GenomeInfo> info; std::vector<uint32_t> kept_index; };   // kept_index[set genome] = index into info, or ~0u
 Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Args& a) {
     Streamed out;
@@ -186,7 +200,7 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
         }
     }
     std::vector<uint8_t*> slot(SLOTS, nullptr);
-    for (uint32_t x = 0; x < std::min<uint32_t>(SLOTS, (uint32_t)bufs.size()); x++) if (!(slot[x] = (uint8_t*)skh_host_alloc(SLOT))) die("cannot pin host memory for the ingest buffers");
+    for (uint32_t x = 0; x < std::min<uint32_t>(SLOTS, (uint32_t)bufs.size()); x++) if (!(slot[x] = g_pinned.take(SLOT))) die("cannot pin host memory for the ingest buffers");
     std::vector<uint64_t> slot_gen(SLOTS, 0);                                       // buffers of slot x up to generation slot_gen[x] have been copied: the next may be written
     std::mutex slot_mu; std::condition_variable slot_cv;
     skh_genome_set* gs = nullptr;
@@ -194,6 +208,7 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
     std::vector<GenomeInfo> per(nf); std::vector<uint8_t> state(nf, 0);          // 1 = kept, 2 = no kept contig, 3 = unreadable
     std::vector<std::vector<uint64_t>> clens(nf);
     std::atomic<uint32_t> next{0}; std::atomic<bool> fallback{false}; std::mutex gpu; std::string gpu_err;
+    const int per_file = std::max(1, a.threads / (int)std::max<uint32_t>(1, nf));      // few files, many threads: the threads of a large file's parse (fastx.cpp)
     auto worker = [&]() {
         std::vector<std::string> names;
         for (;;) {
@@ -205,7 +220,7 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
             if (!fallback) {
                 size_t wrote = 0;
                 try {
-                    if (!parse_fasta_plain(files[i], slot[x] + off_in[i], (size_t)fsize[i] + 16, 500, &wrote, names, clens[i])) { fallback = true; slot_cv.notify_all(); }
+                    if (!parse_fasta_plain(files[i], slot[x] + off_in[i], (size_t)fsize[i] + 16, 500, &wrote, names, clens[i], per_file)) { fallback = true; slot_cv.notify_all(); }
                     else if (names.empty()) state[i] = 2;
                     else { state[i] = 1; GenomeInfo& gi = per[i]; gi.file_name = files[i]; gi.contigs = std::move(names); for (uint64_t l : clens[i]) gi.contig_lengths.push_back((uint32_t)l); }
                 } catch (const std::exception& e) { state[i] = 3; fprintf(stderr, "WARN %s; skipping.\n", e.what()); }
@@ -239,12 +254,12 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
     if (fallback) {
         (void)skh_genomes_finish(gs);                                              // drains the queued copies before the buffers go away
         skh_genomes_destroy(gs);
-        for (uint8_t* p : slot) skh_host_free(p);
+        for (uint8_t* p : slot) g_pinned.give(p, SLOT);
         if (!gpu_err.empty()) die("skh_genomes_append: " + gpu_err);
         return out;                                                                // a FASTQ / gzip file turned up: the caller reads everything the other way
     }
     cx.check(skh_genomes_finish(gs), "skh_genomes_finish");
-    for (uint8_t* p : slot) skh_host_free(p);
+    for (uint8_t* p : slot) g_pinned.give(p, SLOT);
     g_clock.mark("parse_upload_pack");
     out.kept_index.assign(nf, ~0u);
     for (uint32_t i = 0; i < nf; i++) {
@@ -501,6 +516,7 @@ int main(int argc, char** argv) {
     else if (a.cmd == "sketch") rc = run_sketch(a, cx);
     else if (a.cmd == "search") rc = run_search(a, cx);
     else die("unknown subcommand " + a.cmd + " (supported: triangle, dist, sketch, search)");
+    g_pinned.release();
     skh_ctx_destroy(cx.c);
     g_clock.done();
     return rc;

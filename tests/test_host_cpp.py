@@ -20,7 +20,7 @@ def host():
     build_hip()
     lib, _ = build_host()
     L = C.CDLL(lib)
-    for f in ("skhost_fasta_summary", "skhost_fasta_plain", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
+    for f in ("skhost_fasta_summary", "skhost_fasta_plain", "skhost_fasta_plain_threads", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
         getattr(L, f).restype = C.c_void_p
     return L
 
@@ -92,6 +92,20 @@ def test_mapped_fasta_parser_equals_the_record_reader(host, tmp_path):
     assert _take(host, host.skhost_fasta_plain(str(fq).encode(), 0)) == "NOT PLAIN"
     e = tmp_path / "e.fa"; e.write_text("")
     assert _take(host, host.skhost_fasta_plain(str(e).encode(), 0)) == "="
+    # the several-thread parse of large files (a chromosome-sized contig is cut between threads): the same output for any number of threads, wherever
+    # the cuts fall -- inside header lines, inside CRLF pairs, in blank lines, in contigs that are dropped, with more threads than lines
+    texts = [text, ">only\n" + seq(5000), ">x\n\n\n" + wrap(seq(2000), 7) + "\n>y tail\r\n" + seq(30) + "\r\n>z\n" + seq(501), "  \n>lead\n" + wrap(seq(900), 50) + "\n", " \t>after blanks\n" + wrap(seq(1200), 33)]
+    for k, tx in enumerate(texts):
+        q = tmp_path / ("t%d.fa" % k); q.write_bytes(tx.encode())
+        one = _take(host, host.skhost_fasta_plain_threads(str(q).encode(), 500, 1))
+        assert one.split("=")[0] == _take(host, host.skhost_fasta_summary(str(q).encode(), 500))
+        for t in (2, 3, 4, 7, 16, 61):
+            assert _take(host, host.skhost_fasta_plain_threads(str(q).encode(), 500, t)) == one, (k, t)
+    for name in ("viruses.fna", "o157_plasmid.fasta"):
+        q = os.path.join(GOLDEN, name)
+        one = _take(host, host.skhost_fasta_plain_threads(q.encode(), 500, 1))
+        for t in (2, 5, 13):
+            assert _take(host, host.skhost_fasta_plain_threads(q.encode(), 500, t)) == one
 
 
 def test_triangle_matrix_format(host):
