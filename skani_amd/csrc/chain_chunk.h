@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
     constexpr Co CO_MAX = ~(Co)0;
     __shared__ Co lds_samp[4][2][CHUNK_SAMPLES];
     Arr anc_arr;                                                                    // the anchors' query coordinates as one of the searched arrays
-    if constexpr (W::wide) anc_arr = CoArr{anc_q, 1u}; else anc_arr = anc_q;
+    if constexpr (W::wide) anc_arr = CoArr{anc_q, 1u}; else anc_arr = global_of(anc_q);
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pairs) return;
     const uint32_t l = lane_id();

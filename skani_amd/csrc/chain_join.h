@@ -42,8 +42,12 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
     constexpr uint32_t RW = 64u * R;                                                 // positions per round
     const uint32_t bm_words = ((pd.b_nbk + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES + 3) / 4 * 4;
     const bool use_bm = bm_words <= lds_words;
+    // The sketches' arrays are reached through pointers that were loaded from the pair record: generic pointers to the compiler, whose loads (flat_load)
+    // count on the LDS wait counter as well -- every wait for the filter or the probe queue then also waits for the hashes requested a round ahead.
+    // global_of() (dev.h) names the address space; the loads become global_load and the waits exact.
+    const GlobalPtr<uint32_t> a_hash = global_of(pd.a_hash), a_g = global_of(pd.a_g), a_rep = global_of(pd.a_rep), b_ms = global_of(pd.b_ms);
     if (use_bm) {                                                                    // B's occupancy filter, staged once for the workgroup's tiles (the only barrier)
-        const uint4* src = (const uint4*)pd.b_bmap;
+        const GlobalPtr<uint4> src = (GlobalPtr<uint4>)global_of(pd.b_bmap);
         for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += JOIN_THREADS) ((uint4*)bm)[w4] = src[w4];
         __syncthreads();
     }
@@ -52,23 +56,23 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
     const uint32_t tile = st.x + w;                                                  // this wave's tile
     const uint32_t start = (tile - pd.tile0) * JOIN_TILE;
     if (start >= pd.a_n) return;
-    const uint64_t* tab = pd.b_tab;
+    const GlobalPtr<uint64_t> tab = global_of(pd.b_tab);
     // position start + round * 256 + 4 l + r sits in slot r of lane l.  A genome's arrays start at any element of the set's arrays: the four-word loads
     // are only 4-byte aligned (Words4), which global_load_dwordx4 takes.
     uint32_t nh[R], ng[R], nrep;
     auto fetch = [&](uint32_t round) {
         const uint32_t i0 = start + round * RW + 4u * l;
         if (i0 + 4u <= pd.a_n) {
-            const Words4 a = *(const Words4*)(pd.a_hash + i0), b = *(const Words4*)(pd.a_g + i0);
+            const Words4 a = *(GlobalPtr<Words4>)(a_hash + i0), b = *(GlobalPtr<Words4>)(a_g + i0);
             nh[0] = a.x; nh[1] = a.y; nh[2] = a.z; nh[3] = a.w; ng[0] = b.x; ng[1] = b.y; ng[2] = b.z; ng[3] = b.w;
         } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) { const bool in = i0 + (uint32_t)r < pd.a_n; nh[r] = in ? pd.a_hash[i0 + r] : 0u; ng[r] = in ? pd.a_g[i0 + r] : 0u; }
+            for (int r = 0; r < R; r++) { const bool in = i0 + (uint32_t)r < pd.a_n; nh[r] = in ? a_hash[i0 + r] : 0u; ng[r] = in ? a_g[i0 + r] : 0u; }
         }
         // 'repetitive' bits (chain.rs:674-676: more than `band` positions in A) of the round's 256 positions: bits [x0, x0 + 256) of the words from rw0 on
         const uint32_t gi0 = pd.a_pos0 + start + round * RW, rw0 = gi0 >> 5, x = (gi0 & 31u) + 4u * l;
         const uint32_t last_w = (pd.a_pos0 + pd.a_n - 1u) >> 5;
-        const uint32_t word = (l < 9u && rw0 + l <= last_w) ? pd.a_rep[rw0 + l] : 0u;
+        const uint32_t word = (l < 9u && rw0 + l <= last_w) ? a_rep[rw0 + l] : 0u;
         const uint32_t lo = __shfl(word, (int)(x >> 5), 64), hi = __shfl(word, (int)((x >> 5) + 1u), 64);
         nrep = (uint32_t)(((((unsigned long long)hi << 32) | lo) >> (x & 31u)) & 0xFull);
 #pragma unroll
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
             // round trips, as many as the longest walk of the round has steps -- pairs of slots halve them: 2.25 -> 2.15 ms (four slots per request:
             // no further gain, 2.13-2.15 ms).  Behind a slice's last slot, which is empty and ends every walk, lies the next slice or the table's
             // slack: readable, never used.
-            auto ld = [&](uint32_t ps) { return *(const Slots2*)(tab + ps); };
+            auto ld = [&](uint32_t ps) { return *(GlobalPtr<Slots2>)(tab + ps); };
             const Slots2 none{TAB_EMPTY, TAB_EMPTY};
             Slots2 s0 = v0 ? ld(ps0) : none, s1 = v1 ? ld(ps1) : none;
             auto settle = [](const Slots2& s, uint32_t ph, unsigned long long& e) {       // the first slot whose hash is not below the probe's, if it is here
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
             if (!(xl & TAB_LISTED)) n_anch[r] = 1u; else if (code) n_anch[r] = code + 1u; else head[r] = 1;
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) if (head[r]) n_anch[r] = pd.b_ms[rec[r] & TAB_OFF_MASK];   // long lists (more than four positions): the count heads the list
+        for (int r = 0; r < R; r++) if (head[r]) n_anch[r] = b_ms[rec[r] & TAB_OFF_MASK];   // long lists (more than four positions): the count heads the list
         // "listed in query_positions_all" (chain.rs:682-700): four words per round, bit l of word r = position 4 l + r of the round
         unsigned long long mine = 0;
 #pragma unroll
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_fill_kernel(const PairDesc*
         for (int r = 0; r < R; r++) {
             const bool listed = rec[r] != TAB_REPETITIVE && (rec[r] & TAB_LISTED);
             const uint32_t code = tab_list_code(rec[r]);
-            const uint32_t* bs = pd.b_ms + (rec[r] & TAB_OFF_MASK);
+            const GlobalPtr<uint32_t> bs = global_of(pd.b_ms) + (rec[r] & TAB_OFF_MASK);
             n_anch[r] = rec[r] == TAB_REPETITIVE ? 0u : (!listed ? 1u : (code ? code + 1u : bs[0]));
             f0[r] = listed ? bs[1] : rec[r]; f1[r] = listed ? bs[2] : 0u;             // (behind a list of one -- a single beyond 2^31 -- follows another list or the storage's slack)
         }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_fill_kernel(const PairDesc*
             const uint32_t tot = wave_readlane(incl, 63);
             if (n_anch[r]) {
                 uint32_t oa = run + incl - n_anch[r];
-                const uint32_t* bs = pd.b_ms + (rec[r] & TAB_OFF_MASK) + 1;
+                const GlobalPtr<uint32_t> bs = global_of(pd.b_ms) + (rec[r] & TAB_OFF_MASK) + 1;
                 for (uint32_t k = 0; k < n_anch[r]; k++, oa++) {                     // chain.rs:703-711, already in sorted order
                     const uint32_t rg = k == 0 ? f0[r] : (k == 1 ? f1[r] : bs[k]);
                     anc_q[oa] = qg[r] >> 1; anc_r[oa] = (rg & ~1u) | ((rg ^ qg[r]) & 1u);

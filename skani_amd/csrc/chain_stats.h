@@ -60,17 +60,25 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
     // current chunk is counted: the loop is otherwise a chain of dependent round trips to memory.  A fetched value is
     // coordinate << 1 | listed.  (Assembling the 64 "listed" bits of a block from two wave-uniform loads instead of one load
     // per lane is slower: 1.27 vs 0.79 ms -- the scalar loads sit in the dependent chain.)
+    // What is fetched stays RAW -- the position record and the 64-bit word its "listed" bit sits in -- and is put together where it is counted: put
+    // together at once (round 2 and 3's first half) every one of the four fetches waited for its own loads, four round trips in a row per chunk
+    // instead of none.  Loads are unconditional (an index beyond the chunk reads its last position and counts as nothing): no branch around them.
     constexpr int PF = 4;
-    Co cur[PF], nxt[PF];
-    auto fetch = [&](const Arr& ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> Co {
-        if (s2 >= se_j) return (Co)0;
-        return ((Co)ag_j[s2] & ~(Co)1) | (Co)((mk_j[((s2 >> 8) << 2) | (s2 & 3u)] >> ((s2 >> 2) & 63u)) & 1ull);   // join_count_kernel's layout: bit l of word r of a 256-position round = position 4 l + r
+    struct Raw { Co v; unsigned long long m; };
+    Raw cur[PF] = {}, nxt[PF] = {};
+    auto fetch = [&](const Arr& ag_j, const unsigned long long* mk_j, uint32_t s2, uint32_t se_j) -> Raw {
+        const uint32_t s = s2 < se_j ? s2 : (se_j ? se_j - 1u : 0u);
+        const unsigned long long m = global_of(mk_j)[((s >> 8) << 2) | (s & 3u)];   // join_count_kernel's layout: bit l of word r of a 256-position round = position 4 l + r
+        return Raw{(Co)ag_j[s], m};
+    };
+    auto value = [](const Raw& r, uint32_t s2, uint32_t se_j) -> Co {                // coordinate << 1 | listed; 0 beyond the chunk
+        return s2 < se_j ? (r.v & ~(Co)1) | (Co)((r.m >> ((s2 >> 2) & 63u)) & 1ull) : (Co)0;
     };
     auto bcast_arr = [&](int src) -> Arr {                                           // lane src's position array, to all lanes
         const unsigned long long v = (unsigned long long)ag;
         const uint32_t lo32 = wave_readlane((uint32_t)v, src), hi32 = wave_readlane((uint32_t)(v >> 32), src);
         const void* ptr = (const void*)(((unsigned long long)hi32 << 32) | lo32);
-        if constexpr (W::wide) return CoArr{ptr, wave_readlane(ag64, src)}; else return (const uint32_t*)ptr;
+        if constexpr (W::wide) return CoArr{ptr, wave_readlane(ag64, src)}; else return global_of((const uint32_t*)ptr);
     };
     auto bcast_ptr = [&](const void* ptr, int src) -> const void* {
         const unsigned long long v = (unsigned long long)ptr;
@@ -87,15 +95,15 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
         for (int u = 0; u < PF; u++) cur[u] = fetch(agj, mkj, sb + 64u * (uint32_t)u + l, se);
     }
     while (j >= 0) {                                                                // wave-uniform
-        int jn = -1; uint32_t sbn = 0, sen = 0;
-        Arr agn{}; const unsigned long long* mkn = nullptr;
-        if (todo) {
-            jn = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
-            sbn = wave_readlane(s_begin, jn); sen = wave_readlane(s_end, jn);
-            agn = bcast_arr(jn); mkn = (const unsigned long long*)bcast_ptr(mk, jn);
+        // the next chunk's first 256 positions are requested now, without a branch around the loads (after the last chunk: the current one once more), so that
+        // the wait in front of the counting below is for the CURRENT chunk's words only -- the compiler counts exactly what is in flight behind them
+        const bool more = todo != 0;
+        const int jn = more ? __ffsll((long long)todo) - 1 : j;
+        todo &= todo - 1ull;                                                        // (0 stays 0)
+        const uint32_t sbn = wave_readlane(s_begin, jn), sen = wave_readlane(s_end, jn);
+        const Arr agn = bcast_arr(jn); const unsigned long long* mkn = (const unsigned long long*)bcast_ptr(mk, jn);
 #pragma unroll
-            for (int u = 0; u < PF; u++) nxt[u] = fetch(agn, mkn, sbn + 64u * (uint32_t)u + l, sen);
-        }
+        for (int u = 0; u < PF; u++) nxt[u] = fetch(agn, mkn, sbn + 64u * (uint32_t)u + l, sen);
         const uint32_t nj = wave_readlane(n_int, j), q0j = wave_readlane(rq0, j), q1j = wave_readlane(rq1, j), headj = wave_readlane(head, j);
         const Co qoffj = wave_readlane(qoff, j);                                    // positions are padded coordinates; intervals are contig-local
         // the chunk's intervals as (start, width): wave-uniform values, "inside" is one unsigned compare; a chunk has one interval as a rule (mean 1.2),
@@ -121,10 +129,10 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(uint32_t n_slots, cons
             cr += (uint32_t)__popcll(__ballot(on && pos - q0j <= qwj));             // chain.rs:326-332 (spacing estimates are 0)
         };
 #pragma unroll
-        for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(cur[u]);
-        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) count(fetch(agj, mkj, b2 + l, se));
+        for (int u = 0; u < PF; u++) if (sb + 64u * (uint32_t)u < se) count(value(cur[u], sb + 64u * (uint32_t)u + l, se));
+        for (uint32_t b2 = sb + 64u * PF; b2 < se; b2 += 64) count(value(fetch(agj, mkj, b2 + l, se), b2 + l, se));
         if ((int)l == j) { in_u = cu; in_range = cr; in_list = cl; }
-        j = jn; sb = sbn; se = sen; agj = agn; mkj = mkn;
+        j = more ? jn : -1; sb = sbn; se = sen; agj = agn; mkj = mkn;
 #pragma unroll
         for (int u = 0; u < PF; u++) cur[u] = nxt[u];
     }

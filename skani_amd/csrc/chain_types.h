@@ -39,11 +39,11 @@ struct WidePair {                // per pair of a Wide run, beside its PairDesc
     uint32_t a_is_index;         // A's set is wide: anc_q from the join is a position index
     uint32_t pad;
 };
-struct Narrow {
-    using Co = uint32_t; using Arr = const uint32_t*; static constexpr bool wide = false;
-    static __device__ __forceinline__ Arr a_g(const PairDesc& pd, const WidePair*, uint32_t) { return pd.a_g; }
-    static __device__ __forceinline__ Arr a_goff(const PairDesc& pd, const WidePair*, uint32_t) { return pd.a_goff; }
-    static __device__ __forceinline__ Arr b_goff(const PairDesc& pd, const WidePair*, uint32_t) { return pd.b_goff; }
+struct Narrow {   // (Arr: pointers out of the pair record are named as what they are, global memory -- dev.h global_of)
+    using Co = uint32_t; using Arr = GlobalPtr<uint32_t>; static constexpr bool wide = false;
+    static __device__ __forceinline__ Arr a_g(const PairDesc& pd, const WidePair*, uint32_t) { return global_of(pd.a_g); }
+    static __device__ __forceinline__ Arr a_goff(const PairDesc& pd, const WidePair*, uint32_t) { return global_of(pd.a_goff); }
+    static __device__ __forceinline__ Arr b_goff(const PairDesc& pd, const WidePair*, uint32_t) { return global_of(pd.b_goff); }
 };
 struct Wide {
     using Co = uint64_t; using Arr = CoArr; static constexpr bool wide = true;

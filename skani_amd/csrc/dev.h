@@ -111,6 +111,16 @@ template <class K> inline void kernel_allow_lds(K kernel, size_t bytes) {
     hip_check(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "LDS size attribute");
 }
 
+// A pointer that was put together from integers (broadcast through v_readlane, say) is a generic one to the compiler: its loads are flat_load, which count on two
+// wait counters at once and make the compiler wait for everything in flight.  global_of() says what it is: global memory.
+// (The host pass of the compiler only checks kernel bodies: it sees plain pointers.)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> using GlobalPtr = const T __attribute__((address_space(1)))*;
+#else
+template <class T> using GlobalPtr = const T*;
+#endif
+template <class T> __device__ __forceinline__ GlobalPtr<T> global_of(const T* p) { return (GlobalPtr<T>)p; }
+
 // ---- wave helpers (wave = 64 lanes on gfx950) ----
 // uniform-lane broadcast: lane index is the same for the whole wave -> v_readlane on gfx950
 __device__ __forceinline__ int wave_readlane(int v, int uniform_lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane)); }

@@ -44,6 +44,8 @@ struct DevEvent {
 };
 template <class K> inline void kernel_allow_lds(K, size_t) {}
 
+template <class T> using GlobalPtr = const T*;
+template <class T> inline GlobalPtr<T> global_of(const T* p) { return p; }
 inline int wave_readlane(int v, int uniform_lane) { return emu::shfl(v, uniform_lane); }
 inline void wave_sync_mem() { emu::wave_sync(); }
 inline void block_fence() { __threadfence_block(); }
