@@ -54,7 +54,7 @@ struct GbdtModel {  // flat table from tools/extract_gbdt_model.py (regression.r
 struct skh_tunables {
     uint64_t seed_scratch_bytes = (uint64_t)6 << 30;    // capped tile scratch per seeding launch
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
-    uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~44 B of scratch each)
+    uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
