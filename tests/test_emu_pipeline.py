@@ -88,6 +88,21 @@ def test_emu_selection_in_global_memory(monkeypatch):
         c.close()
 
 
+def test_emu_sets_of_both_kinds_of_genomes(monkeypatch):
+    """SKH_TUNE_WIDE_SPAN between the sizes of the fuzzer's genomes: sets with wide and ordinary genomes side by side, chaining calls that split into an
+    ordinary and a 64-bit run."""
+    import importlib.util, os
+    monkeypatch.setenv("SKH_TUNE_WIDE_SPAN", "120000")
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+        fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+        rng = np.random.default_rng(123)
+        assert sum(fz.one_round(c, rng, r) for r in range(8)) > 40
+    finally:
+        c.close()
+
+
 def test_emu_randomised_differential(ctx):
     """a few rounds of tools/fuzz_parity.py through the simulator"""
     import importlib.util, os
