@@ -6,9 +6,12 @@ One "step" = one full pass of the hot path over the resident batch: FracMinHash 
 2-bit packed bases already in HBM, sketch-table construction, marker screen of all N(N-1)/2 pairs, chaining +
 ANI/AF (+ learned ANI) of every pair that passes the screen.  Default -c 125 -k 15 -m 1000 -s 80.
 
-Workload: N = 1: 1000 genomes in clades of 20 (BASELINE config 3).  N > 1 (weak scaling): 1250 genomes per GPU -- 10,000 on 8 GPUs is
-BASELINE config 4 -- in SHUFFLED order (files sort by name, not by clade: file_io.rs:250), so the members of a clade sit on different
-GPUs.  Every rank sketches its own genomes; skh_triangle_distributed (csrc/dist.hip, RCCL below the C ABI) all-gathers the marker sets,
+Workload: N = 1: 1000 genomes in clades of 20 (BASELINE config 3).  N > 1 (weak scaling, the default): 1250 genomes per GPU -- 10,000 on
+8 GPUs is BASELINE config 4 -- in SHUFFLED order (files sort by name, not by clade: file_io.rs:250), so the members of a clade sit on different
+GPUs.  `--collection 10000` is the STRONG-scaling mode: config 4's 10,000 shuffled genomes at every N (10000 / N per rank; N = 1 fits one GPU).
+The pair count grows with the square of the collection while the work (bases seeded, pairs chained) grows linearly, so the line also carries
+`bases_per_s_per_gpu` and `chained_pairs_per_s_per_gpu`: the rates that compare across N and across the two modes.
+`--one-device` puts all ranks on cuda:0 (host collectives over gloo): the whole multi-rank branch of this file on a one-GPU box.  Every rank sketches its own genomes; skh_triangle_distributed (csrc/dist.hip, RCCL below the C ABI) all-gathers the marker sets,
 screens a share of the rows on every rank, assigns the candidate pairs to ranks cluster by cluster (balanced, order-independent), moves
 exactly the sketches that are needed point-to-point and gathers the results.  value = N_total (N_total - 1) / 2 / step time.
 
@@ -46,7 +49,8 @@ def make_genomes(torch, device, wanted, members=CLADE, mean_len=5_000_000, keep_
     with substitution rate U(0.005,0.08), 0-5 deletions of 10-50 kb, split into 1-20 contigs (>= 10 kb).  `wanted` lists canonical ids
     (clade * members + member) in the order the caller wants them; a genome is a pure function of its id (the clade's random streams are
     replayed up to the member), so any rank can generate any subset.  Returns (ascii uint8 device tensor, contig_off, contig_genome,
-    n_genomes, host copies [list of (name, uint8 array) per genome] when keep_host)."""
+    n_genomes, host copies [list of (name, uint8 array) per genome] when keep_host: True = of every genome, a boolean mask over `wanted` = of those)."""
+    on_host = None if keep_host is False or keep_host is None else (np.ones(len(wanted), bool) if keep_host is True else np.asarray(keep_host, bool))
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     wanted = [int(x) for x in wanted]
     by_clade = {}
@@ -94,7 +98,7 @@ def make_genomes(torch, device, wanted, members=CLADE, mean_len=5_000_000, keep_
             pos = want[m]
             pieces[pos] = asc
             bounds_of[pos] = [0] + [int(c) for c in cuts] + [n]
-            if keep_host:
+            if on_host is not None and on_host[pos]:
                 h = asc.cpu().numpy()
                 host_of[pos] = [("c%d" % i, h[a_:b_]) for i, (a_, b_) in enumerate(zip(bounds_of[pos][:-1], bounds_of[pos][1:]))]
     contig_off, contig_genome = [0], []
@@ -102,7 +106,7 @@ def make_genomes(torch, device, wanted, members=CLADE, mean_len=5_000_000, keep_
         for a_, b_ in zip(bnd[:-1], bnd[1:]):
             contig_off.append(contig_off[-1] + (b_ - a_)); contig_genome.append(g)
     bases = torch.cat(pieces) if pieces else torch.zeros(1, dtype=torch.uint8, device=device)
-    return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), len(wanted), (host_of if keep_host else [])
+    return bases, np.array(contig_off, np.uint64), np.array(contig_genome, np.uint32), len(wanted), (host_of if on_host is not None else [])
 
 
 def make_queries(torch, device, clades, mean_len=5_000_000, first=0):
@@ -208,12 +212,12 @@ def host_cores():
     return logical, min(physical, logical), model
 
 
-def cpu_run(host_genomes, threads):
+def cpu_run(host_genomes, threads, ids=None):
     """One timed pass of the oracle (a C++ restatement of the reference algorithms) over the genomes given, phase by phase as BASELINE.md section 2
     lists them: sketch (one C call, files in parallel like file_io.rs:147, AVX2 seeding like avx2_seeding.rs), marker index, screen of all pairs,
     chain of the passing pairs (threads pulling pairs like triangle.rs:71-105)."""
     from oracle import oracle_py as ora
-    names = ["s%05d.fa" % i for i in range(len(host_genomes))]
+    names = ["s%05d.fa" % (i if ids is None else int(ids[i])) for i in range(len(host_genomes))]     # (names sort like the collection's global indices: the switch_qr tie)
     # regression.rs:8-28: learned ANI only for c >= 70, table chosen by |c-125| < |c-200|
     model = None
     if C >= 70:
@@ -232,16 +236,20 @@ def cpu_run(host_genomes, threads):
             "chained_pairs_per_s": n_chained / chain_s if chain_s > 0 else None}, (oi, oj, res)
 
 
-def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
+def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None, ids=None):
     """The CPU side of the metric: the oracle (kind = 'port': the Rust reference cannot be built here) on this box's host cores on the genomes given --
     by default the FULL workload the GPU ran -- at several thread counts: 16, 64, the physical cores and all logical CPUs, each a complete run, plus
     skani's default -t 3 (cli.rs:243) on five clades as the per-thread yardstick.  `value` is the BEST point of the sweep and `cores` the thread count
     that gave it; every point carries its phase times and the parallel efficiency of the sketch and chain phases against the 3-thread per-thread rate.
-    With the GPU triangle's result it also reports the metric's "ANI delta vs ref" over every chained pair."""
+    With the GPU triangle's result it also reports the metric's "ANI delta vs ref" over every chained pair.
+    ids: the global index of each genome given (a sample of whole clades out of a larger, shuffled collection: --collection); the sample's phase rates are
+    then scaled to the collection -- sketching and chaining linearly, the screen with the pair count -- and `value` is the collection's pairs over that time."""
     logical, physical, model_name = host_cores()
     n = len(host_genomes); pairs = n * (n - 1) // 2
-    cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)                      # (the first pass of a process pays the page faults of its heap: not the yardstick)
-    few, _ = cpu_run(host_genomes[:min(n, 5 * CLADE)], 3)
+    if ids is None:
+        ids = np.arange(n, dtype=np.int64)
+    cpu_run(host_genomes[:min(n, 5 * CLADE)], 3, ids)                 # (the first pass of a process pays the page faults of its heap: not the yardstick)
+    few, _ = cpu_run(host_genomes[:min(n, 5 * CLADE)], 3, ids)
     per_thread = {"sketch": few["sketch_mbases_per_s"] / 3, "chain": (few["chained_pairs_per_s"] or 0) / 3}
     quota = cpu_quota()
     counts = {t for t in (16, 64, physical, logical) if t <= logical} or {logical}
@@ -250,7 +258,7 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
     counts = sorted(counts)
     sweep, result = [], None
     for t in counts:
-        r, result = cpu_run(host_genomes, t)
+        r, result = cpu_run(host_genomes, t, ids)
         r["efficiency"] = {"sketch": r["sketch_mbases_per_s"] / t / per_thread["sketch"] if per_thread["sketch"] else None,
                            "chain": (r["chained_pairs_per_s"] or 0) / t / per_thread["chain"] if per_thread["chain"] else None}
         sweep.append(r)
@@ -259,8 +267,9 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
     delta = None
     if gpu_result is not None:
         gi, gj, gres = gpu_result
-        sel = (gi < n) & (gj < n)
-        gkeys = gi[sel].astype(np.int64) * n + gj[sel]; okeys = oi.astype(np.int64) * n + oj
+        big = int(n_gpu_genomes or n)
+        sel = np.isin(gi, ids) & np.isin(gj, ids)                      # the GPU's pairs inside the genomes the oracle ran on (global indices)
+        gkeys = gi[sel].astype(np.int64) * big + gj[sel]; okeys = ids[oi].astype(np.int64) * big + ids[oj]
         same = len(gkeys) == len(okeys) and bool(np.array_equal(gkeys, okeys))
         delta = {"pairs_compared": int(len(okeys)), "same_pair_set": same}
         if same and len(okeys):
@@ -270,12 +279,24 @@ def cpu_baseline(host_genomes, gpu_result=None, n_gpu_genomes=None):
             delta["int_fields_equal"] = bool(all(np.array_equal(g[f], res[f]) for f in ("avg_chain_int_len", "total_bases_covered", "num_contigs_q", "num_contigs_r")))
     full = n_gpu_genomes is None or n == n_gpu_genomes
     sec = best["seconds"]
-    return {"value": best["value"], "unit": "genome-pairs/s", "cores": best["threads"], "kind": "port", "delta_vs_oracle": delta,
-            "sample": ("the full workload, measured: " if full else "a sample, measured: ") +
+    value, scaled = best["value"], None
+    if not full:                                                       # scale the sample's phases to the collection the GPU ran
+        f = n_gpu_genomes / n; big_pairs = n_gpu_genomes * (n_gpu_genomes - 1) // 2
+        scaled = {"sketch": sec["sketch"] * f, "marker_index": sec["marker_index"] * f, "screen": sec["screen"] * big_pairs / max(pairs, 1), "chain": sec["chain"] * f}
+        scaled["total"] = sum(scaled.values())
+        value = big_pairs / scaled["total"]
+    return {"value": value, "unit": "genome-pairs/s", "cores": best["threads"], "threads": best["threads"],
+            "cpus_granted": quota if quota else logical, "kind": "port", "delta_vs_oracle": delta,
+            "sample": ("the full workload, measured: " if full else "a sample of whole clades out of the %d-genome collection, measured: " % n_gpu_genomes) +
                       "%d synthetic genomes (%d clades of %d, %.0f Mbp): oracle sketch %.2f s + marker index %.2f s + screen of %d pairs %.2f s + chain of %d pairs %.2f s "
-                      "on %d threads (the best of %s threads; %d physical cores / %d logical CPUs%s, %s); value = pairs / wall time of the four phases"
+                      "on %d threads (the best of %s threads; %d physical cores / %d logical CPUs%s, %s); %s"
                       % (n, n // CLADE, CLADE, best["bases"] / 1e6, sec["sketch"], sec["marker_index"], pairs, sec["screen"], best["chained_pairs"], sec["chain"],
-                         best["threads"], "/".join(str(t) for t in counts), physical, logical, ", cgroup CPU quota %.1f" % quota if quota else "", model_name),
+                         best["threads"], "/".join(str(t) for t in counts), physical, logical, ", cgroup CPU quota %.1f: `cores` is a THREAD count, the container is granted "
+                         "%.0f CPUs' worth of time" % (quota, quota) if quota else "", model_name,
+                         "value = pairs / wall time of the four phases" if full else
+                         "value = the collection's pairs / the sample's phase times scaled to the collection (sketch, index, chain x %.1f; screen x the pair ratio): %.1f s"
+                         % (n_gpu_genomes / n, scaled["total"])),
+            "seconds_scaled_to_collection": scaled,
             "seconds": sec, "sketch_mbases_per_s": best["sketch_mbases_per_s"], "screen_pairs_per_s": best["screen_pairs_per_s"],
             "chained_pairs_per_s": best["chained_pairs_per_s"], "chained_pairs": best["chained_pairs"],
             "host": {"logical_cpus": logical, "physical_cores": physical, "model": model_name, "cgroup_cpu_quota": quota},
@@ -346,6 +367,15 @@ def e2e_leg(host_genomes, threads):
         ix, sc, ch = ora.triangle_phases()
         out["oracle"] = {"wall_s": t2 - t0, "threads": threads, "pairs_per_s": pairs / (t2 - t0),
                          "phases_s": {"read_sketch": t1 - t0, "marker_index": ix, "screen": sc, "chain": ch}, "note": "no matrix writer, no process start-up"}
+        # if the box happens to have the reference itself (a `skani` binary on PATH -- it cannot be built in this image), time it on the same files
+        ref = shutil.which("skani")
+        if ref:
+            t0 = time.perf_counter()
+            r = subprocess.run([ref, "triangle", "-t", str(threads), "-l", lst, "-o", os.path.join(d, "ref_matrix.txt")], capture_output=True, text=True)
+            out["reference_binary"] = {"path": ref, "returncode": r.returncode, "wall_s": time.perf_counter() - t0, "threads": threads,
+                                       "pairs_per_s": pairs / max(time.perf_counter() - t0, 1e-9) if r.returncode == 0 else None}
+        else:
+            out["reference_binary"] = None                               # looked for on PATH, not there
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -395,6 +425,11 @@ def main():
     ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0, host collectives over gloo (RCCL refuses two ranks on one GPU): runs this file's whole "
+                    "multi-rank branch on a one-GPU box (tests/test_bench_multirank.py); the number it prints is not a multi-GPU measurement")
+    ap.add_argument("--collection", type=int, default=0, help="strong scaling: a fixed collection of this many genomes (10000 = BASELINE config 4) in shuffled order at every "
+                    "--gpus N, collection / N genomes per rank")
+    ap.add_argument("--cpu-sample-clades", type=int, default=50, help="--collection on one GPU: whole clades (taken evenly from the collection) the oracle chains beside the GPU for delta_vs_oracle")
     args = ap.parse_args()
 
     import torch
@@ -406,13 +441,18 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    if args.one_device:
+        local = 0; args.transport = "torch"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")             # one node: the ranks meet on the loopback interface whatever the host name resolves to
         with stdout_to_stderr():
-            # RCCL for device tensors; gloo beside it so that the host-collective transport stays available if the library's own communicator cannot be made
-            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=device, rank=rank, world_size=world)
+            # torch.distributed is the CONTROL plane only (the RCCL unique id, agreement on the transport, the timing reduction, barriers): gloo on host
+            # tensors, the same with one GPU per rank and with --one-device.  The data plane is the library's own RCCL communicator (csrc/rccl_transport.hip),
+            # or -- if that cannot be made, or on request -- host collectives over this same gloo group.
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = sk.Context(local)
     if args.workload == "search":
         if world > 1:
@@ -422,17 +462,31 @@ def main():
         print(json.dumps(run_search(args, torch, sk, ctx, device)[0]))
         return
 
-    n_local = args.genomes_per_gpu or (1000 if world == 1 else 1250)
+    strong = args.collection > 0
+    if strong:
+        if args.collection % world or args.genomes_per_gpu:
+            raise SystemExit("--collection must be a multiple of --gpus (and excludes --genomes-per-gpu)")
+        n_local = args.collection // world
+    else:
+        n_local = args.genomes_per_gpu or (1000 if world == 1 else 1250)
     n_total = n_local * world
     assert n_total % CLADE == 0, "the collection must consist of whole clades"
-    order = args.order or ("clade" if world == 1 else "shuffled")
+    order = args.order or ("clade" if world == 1 and not strong else "shuffled")
     canon = genome_order(n_total, order)                               # global genome index -> canonical id
     mine = canon[rank * n_local:(rank + 1) * n_local]
-    n_cpu = 0
+    # genomes the oracle runs on beside the GPU (rank 0 of a one-GPU run): the full workload by default; with --collection whole clades taken evenly from
+    # the collection (their members are spread over the shuffled order).  cpu_ids = their global indices, ascending.
+    cpu_ids = np.zeros(0, np.int64)
     if rank == 0 and world == 1 and args.cpu_clades != 0:
-        n_cpu = n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE)
-    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=n_cpu > 0)
-    host_genomes = host_genomes[:n_cpu]
+        if strong:
+            n_cl = n_total // CLADE; take = max(1, min(n_cl, args.cpu_sample_clades if args.cpu_clades < 0 else args.cpu_clades))
+            cl = set((np.arange(take, dtype=np.int64) * n_cl // take).tolist())
+            cpu_ids = np.nonzero(np.isin(canon // CLADE, list(cl)))[0]
+        else:
+            cpu_ids = np.arange(n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE), dtype=np.int64)
+    keep = np.zeros(n_local, bool); keep[cpu_ids] = True
+    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=keep if len(cpu_ids) else False)
+    host_genomes = [host_genomes[int(x)] for x in cpu_ids]
     torch.cuda.synchronize()
     gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
     total_bases_local = int(contig_off[-1])
@@ -450,9 +504,11 @@ def main():
             if transport == "rccl":
                 try:
                     comm = Comm.rccl(ctx, dist, rank, world, torch=torch, device=device)
+                    comm.selftest()                  # one small all-gather and one all-to-all through the communicator, checked: a transport that does not
+                                                     # move bytes correctly is found here, where every rank can still fall back together
                 except Exception as e:               # e.g. no librccl for dlopen: every rank must take the same way out
                     why = repr(e)
-                failed = torch.tensor([1 if why else 0], dtype=torch.int32, device=device)
+                failed = torch.tensor([1 if why else 0], dtype=torch.int32)
                 dist.all_reduce(failed, op=dist.ReduceOp.MAX)
                 if int(failed.item()):
                     if comm is not None:
@@ -507,13 +563,14 @@ def main():
               tuple([1e3 * x / args.steps for x in host_t] + [{k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms")}]), file=sys.stderr)
     per_rank = None
     if comm is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         st = last["stats"]
         mine_t = torch.tensor([st["n_pairs_mine"], st["n_genomes_received"], st["bytes_received"], int(tm["chain_ms"] * 1000), int(tm["exchange_ms"] * 1000),
-                               int(tm["seed_ms"] * 1000), int(tm["sketch_build_ms"] * 1000), int(tm["screen_ms"] * 1000)], dtype=torch.int64, device=device)
+                               int(tm["seed_ms"] * 1000), int(tm["sketch_build_ms"] * 1000), int(tm["screen_ms"] * 1000), total_bases_local,
+                               int(tm.get("exchange_wait_ms", 0.0) * 1000)], dtype=torch.int64)
         allt = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
-        per_rank = [[int(x) for x in a.cpu()] for a in allt]
+        per_rank = [[int(x) for x in a] for a in allt]
     if rank != 0:
         if comm is not None:
             comm.close()
@@ -558,21 +615,30 @@ def main():
         roof["valu"] = valu
     out = {
         "metric": "genome-pairs/sec (triangle, ~5 Mbp genomes)", "value": value, "unit": "genome-pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence, %s), -c %d -k %d -m %d -s 80, learned ANI on%s"
                                % (n_total, args.mean_len / 1e6, CLADE, "listed clade by clade" if order == "clade" else "file order shuffled: clades span the GPUs", C, K, M,
-                                  "" if world == 1 else ", tiled across %d GPUs (%d genomes each) via %s" % (world, n_local, "RCCL" if transport == "rccl" else "host collectives (gloo)")),
+                                  "" if world == 1 else ", tiled across %d %s (%d genomes each) via %s" % (world, "processes on ONE GPU" if args.one_device else "GPUs", n_local,
+                                                                                                   "RCCL" if transport == "rccl" else "host collectives (gloo)")),
                    "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
-                   "kept_pairs": kept, "order": order,
+                   "kept_pairs": kept, "order": order, "mode": ("strong scaling: a fixed collection of %d genomes at every N" % n_total) if strong else
+                   ("weak scaling: %d genomes per GPU" % n_local if world > 1 else "one GPU"), "one_device": bool(args.one_device),
+                   "transport": transport,
                    "parallelism": "single GPU" if world == 1 else
                                   "one process per GPU; every rank sketches its genomes; markers all-gathered, screen sharded by rows, candidate pairs assigned "
                                   "to ranks cluster by cluster (balanced, order-independent), only the needed sketches travel point-to-point, results all-gathered"},
         "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "exchange_ms")},
         "roofline": roof,
     }
+    # what compares across N and across the weak / strong modes: the pair count grows with the square of the collection, the work with its size
+    step_s = dt / args.steps
+    total_bases = sum(r[8] for r in per_rank) if per_rank else total_bases_local
+    out["bases_per_s_per_gpu"] = total_bases / step_s / world
+    out["chained_pairs_per_s_per_gpu"] = chained / step_s / world
+    out["genomes_per_s_per_gpu"] = n_total / step_s / world
     if per_rank:
-        names = ("chained_pairs", "sketches_received", "bytes_received", "chain_us", "exchange_us", "seed_us", "sketch_build_us", "screen_us")
+        names = ("chained_pairs", "sketches_received", "bytes_received", "chain_us", "exchange_us", "seed_us", "sketch_build_us", "screen_us", "bases", "exchange_wait_us")
         out["per_rank"] = {nm: [r[x] // (args.steps if nm.endswith("_us") else 1) for r in per_rank] for x, nm in enumerate(names)}
     # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
     # (~0.96 MB per pair of 5 Mbp genomes at c=125)
@@ -599,8 +665,8 @@ def main():
             except Exception as e:
                 out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
     if host_genomes:
-        out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total)
-        if not args.no_e2e:
+        out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total, ids=cpu_ids)
+        if not args.no_e2e and not strong:
             try:
                 q = cpu_quota()
                 out["e2e"] = e2e_leg(host_genomes, max(4, min(host_cores()[1], 64, int(round(q)) * 2 if q else 64)))

@@ -236,6 +236,9 @@ typedef struct {
 } skh_host_collectives;
 int skh_comm_create_host(skh_ctx*, const skh_host_collectives*, int rank, int world, skh_comm** out);
 void skh_comm_destroy(skh_comm*);
+/* Collective: a small all-gather of host memory, one of device memory and a sketch-exchange-shaped all-to-all (blocking and asynchronous) through the
+ * communicator, every byte checked.  Meant to be called once after creation, where all ranks can still agree on another transport. */
+int skh_comm_selftest(skh_ctx*, skh_comm*);
 /* what this rank did in the last distributed triangle (balance / traffic, for tests and bench.py) */
 typedef struct {
     uint64_t n_genomes_total, n_candidate_pairs_total;   /* the whole collection */
@@ -243,6 +246,8 @@ typedef struct {
     uint64_t cost_mine, cost_total;                      /* estimated chaining cost (sum of both genomes' marker counts per pair) */
     uint64_t n_genomes_received, bytes_received, bytes_sent;   /* sketches that crossed ranks */
     uint64_t screen_row_begin, screen_row_end;           /* this rank's rows of the screen */
+    uint64_t n_pairs_home;                               /* pairs of this rank with both sketches its own: chained while the other sketches travel */
+    uint64_t exchange_async_us, exchange_wait_us;        /* the sketch exchange from start to last byte, and the part of it the chaining had to wait for */
 } skh_dist_stats;
 /* Collective: every rank of the communicator calls it with its own local set.  Results (global indices, sorted by (i, j), ani > 0.1 as
  * triangle.rs:99) are returned on EVERY rank; n_chained = candidate pairs chained over all ranks.  stats may be NULL. */

@@ -31,7 +31,8 @@ STATS_DTYPE = np.dtype([(n, np.uint32) for n in ("switched", "n_chunks", "n_inte
 class DistStats(C.Structure):
     """skh_dist_stats"""
     _fields_ = [(n, C.c_uint64) for n in ("n_genomes_total", "n_candidate_pairs_total", "n_pairs_mine", "n_units_mine", "n_units_total", "cost_mine", "cost_total",
-                                          "n_genomes_received", "bytes_received", "bytes_sent", "screen_row_begin", "screen_row_end")]
+                                          "n_genomes_received", "bytes_received", "bytes_sent", "screen_row_begin", "screen_row_end",
+                                          "n_pairs_home", "exchange_async_us", "exchange_wait_us")]
 
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -47,7 +48,7 @@ EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "s
            "skh_host_alloc", "skh_host_free", "skh_genomes_begin", "skh_genomes_append", "skh_genomes_wait", "skh_genomes_finish",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
            "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_is_wide", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
-           "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_triangle_distributed", "skh_plan_pairs"]
+           "skh_triangle", "skh_get_timings", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_comm_selftest", "skh_triangle_distributed", "skh_plan_pairs"]
 RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
 
 
@@ -95,6 +96,7 @@ def load(path):
     L.skh_get_timings.restype = i32; L.skh_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.skh_comm_create_host.restype = i32; L.skh_comm_create_host.argtypes = [vp, C.POINTER(HostCollectives), i32, i32, pp]
     L.skh_comm_destroy.restype = None; L.skh_comm_destroy.argtypes = [vp]
+    L.skh_comm_selftest.restype = i32; L.skh_comm_selftest.argtypes = [vp, vp]
     L.skh_triangle_distributed.restype = i32
     L.skh_triangle_distributed.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(MapParams), pp, pp, pp, C.POINTER(u64), C.POINTER(u64), C.POINTER(DistStats)]
     L.skh_plan_pairs.restype = i32; L.skh_plan_pairs.argtypes = [u32, vp, vp, u64, vp, vp, i32, vp]

@@ -477,6 +477,13 @@ int skh_comm_create_host(skh_ctx* ctx, const skh_host_collectives* hc, int rank,
 
 void skh_comm_destroy(skh_comm* c) { delete c; }
 
+int skh_comm_selftest(skh_ctx* ctx, skh_comm* c) {
+    if (!ctx || !c || !c->t) return SKH_ERR_INVALID;
+    int rc = guarded(ctx, [&] { comm_selftest(ctx, *c->t); });
+    ctx->arena.reset();
+    return rc;
+}
+
 int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs, const uint64_t* weight, const uint32_t* holder, int world,
                    uint8_t* owner) {
     if ((n_pairs && (!pair_i || !pair_j || !owner)) || !weight || world < 1 || world > 255) return SKH_ERR_INVALID;

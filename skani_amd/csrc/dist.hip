@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 #include "internal.h"
@@ -43,6 +44,36 @@ struct HostTransport : Transport {
         d2h(hs.data(), send, sb, ctx->stream); dsync(ctx->stream);
         if (hc.all_to_all_v(hc.user, hs.data(), send_cnt, send_off, hr.data(), recv_cnt, recv_off)) throw Error("host all_to_all_v failed");
         h2d(recv, hr.data(), rb, ctx->stream); dsync(ctx->stream);
+    }
+    // asynchronous form: the send buffer comes to the host at once, the caller's collective runs on a thread of its own (the calling thread is inside the
+    // library, not inside the caller's runtime, and makes no other collective until _end), the received bytes go up in _end
+    std::thread worker; std::vector<char> a_send, a_recv; int a_rc = 0; void* a_dst = nullptr; uint64_t a_rb = 0;
+    std::chrono::steady_clock::time_point a_t0, a_t1; uint64_t a_wait_us = 0;
+    ~HostTransport() override { if (worker.joinable()) worker.join(); }
+    void exchange_begin(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                        const uint64_t* recv_off) override {
+        if (worker.joinable()) throw Error("exchange_begin: an exchange is already open");
+        uint64_t sb = 0, rb = 0;
+        for (int r = 0; r < world; r++) { sb = std::max(sb, send_off[r] + send_cnt[r]); rb = std::max(rb, recv_off[r] + recv_cnt[r]); }
+        a_send.assign(sb + 1, 0); a_recv.assign(rb + 1, 0); a_dst = recv; a_rb = rb; a_rc = 0; a_wait_us = 0;
+        d2h(a_send.data(), send, sb, ctx->stream); dsync(ctx->stream);
+        a_t0 = a_t1 = std::chrono::steady_clock::now();
+        worker = std::thread([this, send_cnt, send_off, recv_cnt, recv_off] {
+            a_rc = hc.all_to_all_v(hc.user, a_send.data(), send_cnt, send_off, a_recv.data(), recv_cnt, recv_off);
+            a_t1 = std::chrono::steady_clock::now();
+        });
+    }
+    void exchange_end(skh_ctx* ctx) override {
+        if (!worker.joinable()) return;
+        const auto w0 = std::chrono::steady_clock::now();
+        worker.join();
+        a_wait_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        if (a_rc) throw Error("host all_to_all_v failed");
+        h2d_big(a_dst, a_recv.data(), a_rb, ctx->stream); dsync(ctx->stream);
+    }
+    void exchange_times(uint64_t* total_us, uint64_t* wait_us) override {
+        if (total_us) *total_us = (uint64_t)std::chrono::duration<double, std::micro>(a_t1 - a_t0).count();
+        if (wait_us) *wait_us = a_wait_us;
     }
 };
 
@@ -147,6 +178,39 @@ void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std
     for (size_t p = 0; p < NP; p++) owner[p] = unit_rank[unit_of[p]];
 }
 
+// One all-gather instead of "counts, then payload": every rank sends a 16-byte head (records, status) and its records in a block sized by the capacity the
+// communicator remembers from its previous call (Transport::cap_*).  A collection is usually run again with the same sizes (bench.py: every step), so the
+// first round fits; when some rank has more records than the capacity -- every rank reads that from the same gathered heads -- all ranks raise the
+// capacity to the largest count and go round once more.  Returns the records of all ranks back to back (rank order) and the per-rank counts; a rank whose
+// status word is set stops every rank (on_failed).
+template <class Rec, class Failed>
+static void gather_records(skh_ctx* ctx, Transport& T, const std::vector<Rec>& mine, bool my_status, uint64_t& cap, std::vector<Rec>& all, std::vector<uint64_t>& counts, Failed&& on_failed) {
+    static_assert(sizeof(Rec) % 8 == 0, "records keep the block 8-byte aligned");
+    const int W = T.world;
+    counts.assign(W, 0);
+    for (int round = 0;; round++) {
+        const size_t block = 16 + (size_t)cap * sizeof(Rec);
+        std::vector<char> send(block, 0), recv((size_t)W * block);
+        uint64_t head[2] = {mine.size(), my_status ? 1ull : 0ull};
+        memcpy(send.data(), head, 16);
+        if (mine.size() <= cap && !mine.empty()) memcpy(send.data() + 16, mine.data(), mine.size() * sizeof(Rec));
+        T.all_gather(ctx, send.data(), recv.data(), block, false);
+        uint64_t mx = 0, tot = 0;
+        for (int r = 0; r < W; r++) {
+            uint64_t h[2]; memcpy(h, recv.data() + (size_t)r * block, 16);
+            counts[r] = h[0]; mx = std::max(mx, h[0]); tot += h[0];
+            if (h[1]) on_failed(r);
+        }
+        if (mx <= cap) {
+            all.clear(); all.reserve(tot);
+            for (int r = 0; r < W; r++) { const Rec* b = (const Rec*)(recv.data() + (size_t)r * block + 16); all.insert(all.end(), b, b + counts[r]); }
+            return;
+        }
+        if (round) throw Error("gather_records: the second round did not fit (ranks disagree on the sizes)");
+        cap = mx;
+    }
+}
+
 void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, double identity, int rescue_small, const skh_map_params& mp,
                           std::vector<uint32_t>& out_i, std::vector<uint32_t>& out_j, std::vector<skh_ani_result>& out_res, uint64_t* n_chained, skh_dist_stats* stats) {
     const int W = T.world, me = T.rank;
@@ -155,13 +219,14 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     out_i.clear(); out_j.clear(); out_res.clear();
     skh_dist_stats st{};
     StageTrace tr(ctx);
-    // exchange steps are timed on the host clock: the collectives may run on the transport's own stream
+    // the blocking exchange steps are timed on the host clock (the collectives may run on the transport's own stream); the sketch exchange is asynchronous
+    // and adds only what the chaining had to wait for (exchange_end)
     std::chrono::steady_clock::time_point ex_t0; double exch_ms = 0;
     auto ex_begin = [&] { dsync(ctx->stream); ex_t0 = std::chrono::steady_clock::now(); };
     auto ex_end = [&] { dsync(ctx->stream); exch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ex_t0).count(); };
     // Failures that only ONE rank can see (out of memory, a table overflow, a failed launch) must not leave the others waiting in the next
-    // collective: every local phase runs under `local`, which keeps the first error; `agree` -- one small all-gather of status words, placed in
-    // front of the collective that follows the phase -- makes every rank throw together, naming the rank that failed.  (Errors every rank derives
+    // collective: every local phase runs under `local`, which keeps the first error; the status word travels with the next gather (or `agree`, an
+    // 8-byte all-gather, where no gather follows) and makes every rank throw together, naming the rank that failed.  (Errors every rank derives
     // from the same all-gathered data, like the parameter check below, need no agreement.)
     std::string local_err;
     uint32_t local_phase = 0;                                                       // (SKH_TUNE_DIST_FAIL = n makes the n-th local phase of this rank fail: the tests' fault injection)
@@ -172,84 +237,99 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         catch (const std::exception& e) { local_err = e.what(); }
         catch (...) { local_err = "unknown error"; }
     };
+    struct ExchangeGuard {                                                          // the asynchronous sketch exchange is never left open, whatever unwinds
+        Transport& T; skh_ctx* ctx; bool open = false;
+        void close() { if (open) { open = false; T.exchange_end(ctx); } }
+        ~ExchangeGuard() { try { close(); } catch (...) {} }
+    } xg{T, ctx};
     auto stop_together = [&](const char* phase, int r) {                           // rank r reported a failure: every rank throws
+        try { xg.close(); } catch (...) {}
         device_sync_all();                                                          // nothing queued may outlive the buffers the unwinding frees
         if (r == me) throw Error(std::string("distributed triangle, ") + phase + ": " + local_err);
         throw Error(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
     };
-    // a count every rank contributes anyway + its status in ONE small all-gather (where a phase is followed by such a gather the agreement is free)
-    auto gather_count_and_status = [&](uint64_t my_count, std::vector<uint64_t>& counts, const char* phase) {
-        uint64_t mine2[2] = {my_count, local_err.empty() ? 0ull : 1ull}; std::vector<uint64_t> all((size_t)W * 2);
-        T.all_gather(ctx, mine2, all.data(), sizeof(mine2), false);
-        counts.resize(W);
-        for (int r = 0; r < W; r++) counts[r] = all[(size_t)r * 2];
-        for (int r = 0; r < W; r++) if (all[(size_t)r * 2 + 1]) stop_together(phase, r);
-    };
     auto agree = [&](const char* phase) {
         uint64_t mine_ok = local_err.empty() ? 0 : 1; std::vector<uint64_t> all(W);
         T.all_gather(ctx, &mine_ok, all.data(), 8, false);
-        for (int r = 0; r < W; r++)
-            if (all[r]) {
-                device_sync_all();                                                  // nothing queued may outlive the buffers the unwinding frees
-                if (r == me) throw Error(std::string("distributed triangle, ") + phase + ": " + local_err);
-                throw Error(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
-            }
+        for (int r = 0; r < W; r++) if (all[r]) stop_together(phase, r);
     };
-    // ---- 1. who holds what: per rank (genomes, seed positions, markers, contigs, c, k, marker_c, seeding mode), then per genome, then the contig lengths
+    // ---- 1. who holds what, in ONE all-gather: per rank a head (genomes, seed positions, markers, contigs, c, k, marker_c, seeding mode, status), its per-genome
+    // table and its contig lengths, in a block laid out by the capacities of the communicator's previous call (as gather_records does)
     const uint32_t nL = L->n_genomes;
-    uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, (uint64_t)L->params.seeding_mode | (L->wide ? 256u : 0u)};
-    std::vector<uint64_t> cnt((size_t)W * 8);
+    constexpr uint32_t GF = 5, HDR = 10;                                            // per genome: seed positions, markers, contigs, total length, rank
+    const uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, (uint64_t)L->params.seeding_mode | (L->wide ? 256u : 0u)};
+    // this rank's marker set, padded, in the staging buffers of the marker all-gather further down: sized by the remembered capacity, so that how that went
+    // can travel with the table
+    uint64_t pad = 0; uint64_t *d_mk_send = nullptr, *d_mk_recv = nullptr;
+    auto prepare_markers = [&](uint64_t p) {
+        pad = std::max<uint64_t>(p, 1);
+        local([&] {                                                                 // (local phase 1)
+            d_mk_send = ctx->arena.get<uint64_t>(pad); d_mk_recv = ctx->arena.get<uint64_t>(pad * W);
+            if (mine[2]) d2d(d_mk_send, L->markers.p, mine[2] * 8, ctx->stream);
+            if (pad > mine[2]) dzero(d_mk_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
+            dsync(ctx->stream);
+        });
+    };
     ex_begin();
-    T.all_gather(ctx, mine, cnt.data(), sizeof(mine), false);
-    std::vector<uint64_t> base(W + 1, 0);
+    const bool markers_early = T.cap_m >= mine[2] && T.cap_m > 0;
+    if (markers_early) prepare_markers(T.cap_m);
+    std::vector<uint64_t> cnt((size_t)W * 8), tab_all; size_t tab_words = 0;        // tab_all: the gathered blocks, tab_words each
     uint64_t max_n = 0, max_m = 0, max_c = 0;
+    for (int round = 0;; round++) {
+        const uint64_t cn = T.cap_n, cc = T.cap_c;
+        tab_words = HDR + cn * GF + (cc + 1) / 2;
+        std::vector<uint64_t> send(tab_words, 0); tab_all.assign((size_t)W * tab_words, 0);
+        memcpy(send.data(), mine, sizeof(mine));
+        send[8] = (markers_early && !local_err.empty()) ? 1 : 0;
+        if (nL <= cn && mine[3] <= cc) {
+            for (uint32_t g = 0; g < nL; g++) {
+                uint64_t* f = send.data() + HDR + (size_t)g * GF;
+                f[0] = L->pos_off[g + 1] - L->pos_off[g]; f[1] = L->mk_off[g + 1] - L->mk_off[g]; f[2] = L->ctg_off[g + 1] - L->ctg_off[g]; f[3] = L->total_len[g]; f[4] = L->rank[g];
+            }
+            if (!L->ctg_len.empty()) memcpy(send.data() + HDR + cn * GF, L->ctg_len.data(), L->ctg_len.size() * 4);
+        }
+        T.all_gather(ctx, send.data(), tab_all.data(), tab_words * 8, false);
+        max_n = max_m = max_c = 0;
+        for (int r = 0; r < W; r++) {
+            const uint64_t* h = tab_all.data() + (size_t)r * tab_words;
+            memcpy(cnt.data() + (size_t)r * 8, h, 64);
+            if (h[4] != mine[4] || h[5] != mine[5] || h[6] != mine[6] || (h[7] & 255u) != (mine[7] & 255u))
+                throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
+            max_n = std::max(max_n, h[0]); max_m = std::max(max_m, h[2]); max_c = std::max(max_c, h[3]);
+        }
+        for (int r = 0; r < W; r++) if (tab_all[(size_t)r * tab_words + 8]) stop_together("marker buffers", r);
+        if (max_n <= cn && max_c <= cc) break;
+        if (round) throw Error("distributed triangle: the second table round did not fit (ranks disagree on the sizes)");
+        T.cap_n = max_n; T.cap_c = max_c;
+    }
+    std::vector<uint64_t> base(W + 1, 0);
     // A rank with a wide set (a genome beyond 31-bit padded coordinates, internal.h): position records are not portable then (a wide genome's are
     // indices beside 64-bit coordinates), so ALL ranks exchange (position in contig, contig << 1 | canonical) -- the C ABI's form, 8 bytes instead
-    // of 4 -- and the chained set is made through the import path, which decides per genome from the contig lengths, the same on every rank.
+    // of 4 -- and the received genomes are indexed through the import path, which decides per genome from the contig lengths.
     bool wide_any = false;
-    for (int r = 0; r < W; r++) {
-        if (cnt[r * 8 + 4] != mine[4] || cnt[r * 8 + 5] != mine[5] || cnt[r * 8 + 6] != mine[6] || (cnt[r * 8 + 7] & 255u) != (mine[7] & 255u))
-            throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
-        if (cnt[r * 8 + 7] & 256u) wide_any = true;                                 // (every rank sees the same table)
-        base[r + 1] = base[r] + cnt[r * 8]; max_n = std::max(max_n, cnt[r * 8]); max_m = std::max(max_m, cnt[r * 8 + 2]); max_c = std::max(max_c, cnt[r * 8 + 3]);
-    }
+    for (int r = 0; r < W; r++) { if (cnt[r * 8 + 7] & 256u) wide_any = true; base[r + 1] = base[r] + cnt[r * 8]; }   // (every rank sees the same table)
     const uint64_t N64 = base[W];
     if (N64 >= (1ull << 21)) throw std::invalid_argument("more than 2M genomes in one distributed triangle");
     const uint32_t N = (uint32_t)N64;
     st.n_genomes_total = N;
-    constexpr uint32_t GF = 5;                                                      // per genome: seed positions, markers, contigs, total length, rank
-    // (one more word behind the per-genome fields: this rank's status after preparing its marker buffers below -- the agreement rides on this gather)
-    std::vector<uint64_t> gm_mine((size_t)std::max<uint64_t>(max_n, 1) * GF + 1, 0), gm_all((size_t)W * gm_mine.size());
-    for (uint32_t g = 0; g < nL; g++) {
-        gm_mine[g * GF + 0] = L->pos_off[g + 1] - L->pos_off[g]; gm_mine[g * GF + 1] = L->mk_off[g + 1] - L->mk_off[g];
-        gm_mine[g * GF + 2] = L->ctg_off[g + 1] - L->ctg_off[g]; gm_mine[g * GF + 3] = L->total_len[g]; gm_mine[g * GF + 4] = L->rank[g];
+    if (T.cap_m == 0 || max_m > T.cap_m) {                                          // first call of the communicator, or a larger marker set than it has seen (the same test on every rank): buffers now, agreement of its own
+        prepare_markers(max_m);
+        agree("marker buffers");
     }
-    // this rank's marker set, padded, in the staging buffers of the marker all-gather further down; how that went travels with the table
-    const uint64_t pad = std::max<uint64_t>(max_m, 1);
-    uint64_t *d_send = nullptr, *d_recv = nullptr;
-    local([&] {                                                                     // (local phase 1)
-        d_send = ctx->arena.get<uint64_t>(pad); d_recv = ctx->arena.get<uint64_t>(pad * W);
-        if (mine[2]) d2d(d_send, L->markers.p, mine[2] * 8, ctx->stream);
-        if (pad > mine[2]) dzero(d_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
-        dsync(ctx->stream);
-    });
-    gm_mine.back() = local_err.empty() ? 0 : 1;
-    T.all_gather(ctx, gm_mine.data(), gm_all.data(), gm_mine.size() * 8, false);
-    for (int r = 0; r < W; r++) if (gm_all[(size_t)(r + 1) * gm_mine.size() - 1]) stop_together("marker buffers", r);
-    std::vector<uint32_t> cl_mine(std::max<uint64_t>(max_c, 1), 0), cl_all((size_t)W * cl_mine.size());
-    std::copy(L->ctg_len.begin(), L->ctg_len.end(), cl_mine.begin());
-    T.all_gather(ctx, cl_mine.data(), cl_all.data(), cl_mine.size() * 4, false);
-    auto G = [&](uint32_t g, uint32_t f) {                                          // field f of global genome g
-        const int r = (int)(std::upper_bound(base.begin(), base.end(), (uint64_t)g) - base.begin()) - 1;
-        return gm_all[(size_t)r * gm_mine.size() + (size_t)(g - base[r]) * GF + f];
-    };
-    std::vector<int> rank_of(N); std::vector<uint64_t> g_npos(N), g_nmk(N), g_nctg(N), g_len(N), g_rank(N), g_ctg0(N);   // g_ctg0: first contig in cl_all
+    T.cap_m = std::max(T.cap_m, max_m);
+    std::vector<int> rank_of(N); std::vector<uint64_t> g_npos(N), g_nmk(N), g_nctg(N), g_len(N), g_rank(N);
+    std::vector<uint32_t> cl_all; std::vector<uint64_t> g_ctg0(N);                  // contig lengths of all genomes, global genome order; g_ctg0: a genome's first
     {
         uint32_t g = 0;
         for (int r = 0; r < W; r++) {
-            uint64_t c0 = (uint64_t)r * cl_mine.size();
+            const uint64_t* blk = tab_all.data() + (size_t)r * tab_words;
+            const uint32_t* cl = (const uint32_t*)(blk + HDR + T.cap_n * GF);
+            uint64_t c0 = 0;
             for (uint64_t x = 0; x < cnt[r * 8]; x++, g++) {
-                rank_of[g] = r; g_npos[g] = G(g, 0); g_nmk[g] = G(g, 1); g_nctg[g] = G(g, 2); g_len[g] = G(g, 3); g_rank[g] = G(g, 4); g_ctg0[g] = c0; c0 += g_nctg[g];
+                const uint64_t* f = blk + HDR + x * GF;
+                rank_of[g] = r; g_npos[g] = f[0]; g_nmk[g] = f[1]; g_nctg[g] = f[2]; g_len[g] = f[3]; g_rank[g] = f[4]; g_ctg0[g] = cl_all.size();
+                if (c0 + f[2] > cnt[r * 8 + 3]) throw Error("distributed triangle: a rank's contig table is inconsistent");
+                cl_all.insert(cl_all.end(), cl + c0, cl + c0 + f[2]); c0 += f[2];
             }
         }
     }
@@ -258,10 +338,10 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     S.mk_off.assign(N + 1, 0); for (uint32_t g = 0; g < N; g++) S.mk_off[g + 1] = S.mk_off[g] + g_nmk[g];
     const uint64_t MT = S.mk_off[N];
     {
-        T.all_gather(ctx, d_send, d_recv, pad * 8, true);
+        T.all_gather(ctx, d_mk_send, d_mk_recv, pad * 8, true);
         local([&] {                                                                 // (local phase 2; agreed on with the candidate counts)
             S.markers.alloc(MT ? MT : 1);
-            for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
+            for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_mk_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
             S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
             dsync(ctx->stream);
         });
@@ -289,21 +369,16 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     });
     ctx->arena.reset();
     tr.mark("dist: screen rows");
-    // ---- 4. the candidate list, everywhere (host memory; sorted by (i, j) because the row blocks ascend with the rank)
-    ex_begin();
-    uint64_t my_np = my_i.size(); std::vector<uint64_t> np_all(W);
-    gather_count_and_status(my_np, np_all, "marker sets / screen");
-    uint64_t max_np = 1, NP64 = 0; for (int r = 0; r < W; r++) { max_np = std::max(max_np, np_all[r]); NP64 += np_all[r]; }
+    // ---- 4. the candidate list, everywhere (host memory; sorted by (i, j) because the row blocks ascend with the rank), with the status of the phases above
+    struct Cand { uint32_t i, j; };
     std::vector<uint32_t> pi, pj;
+    ex_begin();
     {
-        std::vector<uint32_t> sendp(max_np * 2, 0), recvp((size_t)W * max_np * 2);
-        std::copy(my_i.begin(), my_i.end(), sendp.begin()); std::copy(my_j.begin(), my_j.end(), sendp.begin() + max_np);
-        T.all_gather(ctx, sendp.data(), recvp.data(), sendp.size() * 4, false);
-        pi.reserve(NP64); pj.reserve(NP64);
-        for (int r = 0; r < W; r++) {
-            const uint32_t* b = recvp.data() + (size_t)r * max_np * 2;
-            pi.insert(pi.end(), b, b + np_all[r]); pj.insert(pj.end(), b + max_np, b + max_np + np_all[r]);
-        }
+        std::vector<Cand> mine_c(my_i.size()), all_c; std::vector<uint64_t> np_all;
+        for (size_t x = 0; x < my_i.size(); x++) mine_c[x] = Cand{my_i[x], my_j[x]};
+        gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, np_all, [&](int r) { stop_together("marker sets / screen", r); });
+        pi.resize(all_c.size()); pj.resize(all_c.size());
+        for (size_t x = 0; x < all_c.size(); x++) { pi[x] = all_c[x].i; pj[x] = all_c[x].j; }
     }
     ex_end();
     const size_t NP = pi.size();
@@ -317,12 +392,12 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     tr.mark("dist: pairs gathered + assigned");
     // ---- 6. which sketches move: mark[g][r] = rank r chains a pair with genome g
     std::vector<std::vector<uint32_t>> send_to(W), recv_from(W);                   // global ids, ascending
-    std::vector<uint32_t> wk_ids;                                                   // the genomes THIS rank chains (its own that stay + the ones it receives), ascending
+    std::vector<uint32_t> home_ids, away_ids;                                       // the genomes THIS rank chains: its own that stay / the ones it receives, ascending
     {
         std::vector<uint8_t> mark((size_t)N * W, 0);
         for (size_t p = 0; p < NP; p++) { mark[(size_t)pi[p] * W + owner[p]] = 1; mark[(size_t)pj[p] * W + owner[p]] = 1; }
         for (uint32_t g = 0; g < N; g++) {
-            if (mark[(size_t)g * W + me]) wk_ids.push_back(g);
+            if (mark[(size_t)g * W + me]) (rank_of[g] == me ? home_ids : away_ids).push_back(g);
             for (int r = 0; r < W; r++)
                 if (mark[(size_t)g * W + r] && rank_of[g] != r) {
                     if (rank_of[g] == me) send_to[r].push_back(g);
@@ -330,138 +405,202 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
                 }
         }
     }
-    uint32_t nR = 0; for (int r = 0; r < W; r++) nR += (uint32_t)recv_from[r].size();
+    const uint32_t nR = (uint32_t)away_ids.size();
     st.n_genomes_received = nR;
-    // The work set: when sketches arrive, ONE set is made of the genomes this rank chains -- the local ones copied, the received ones from the
-    // exchange buffer, in ascending global index -- and its seed tables are built once.  A local sketch whose clusters went to other ranks is never
-    // indexed here (with deferred tables: skh_sketch_genomes_ex), a sketch that travels is indexed only where it arrives.  Nothing received: the local
-    // set itself is chained.
-    std::unique_ptr<skh_sketch_set> Wk;
-    std::vector<uint32_t> wk_index(N, 0xFFFFFFFFu);                                 // global genome -> index in the chained set
-    ex_begin();
-    {
-        // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words; with a wide set somewhere:
-        // [seeds][positions in contig][contig << 1 | canonical])
-        const uint64_t NF = wide_any ? 3 : 2;                                       // 32-bit fields per seed position
-        std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g, seg_c;
-        uint64_t sw = 0;
-        for (int r = 0; r < W; r++) {
-            uint64_t words = 0; for (uint32_t g : send_to[r]) words += g_npos[g];
-            s_off[r] = sw * 4; s_cnt[r] = words * NF * 4;
-            uint64_t at = sw;
-            for (uint32_t g : send_to[r]) {
-                const uint64_t lp = L->pos_off[g - base[me]];
-                seg_s.insert(seg_s.end(), {lp, at, g_npos[g]}); seg_g.insert(seg_g.end(), {lp, at + words, g_npos[g]});   // the position parts follow the seed parts
-                if (wide_any) seg_c.insert(seg_c.end(), {lp, at + 2 * words, g_npos[g]});
-                at += g_npos[g];
-            }
-            sw += words * NF;
+    // ---- 7. the sketches that move travel ASYNCHRONOUSLY (RCCL: on the context's second stream; host collectives: on a thread), and meanwhile this rank
+    // indexes the genomes of its own that it chains and chains its HOME pairs (both sketches its own).  The sets:
+    //   H   the home side: the local set itself when its tables exist already, when nothing arrives, or with a wide set somewhere; otherwise a compact copy
+    //       of the local genomes that stay (with deferred tables -- skh_sketch_genomes_ex -- a local sketch whose clusters went elsewhere is never indexed);
+    //   Wr  the received genomes, in ascending global index, indexed when they have arrived; the AWAY pairs (a received sketch on either side) are
+    //       chained over the two sets.
+    std::unique_ptr<skh_sketch_set> Wh, Wr;
+    std::vector<uint32_t> wk_set(N, 0), wk_index(N, 0xFFFFFFFFu);                   // global genome -> (0 = H, 1 = Wr, index in that set)
+    const uint64_t NF = wide_any ? 3 : 2;                                           // 32-bit fields per seed position on the wire
+    std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g, seg_c, r_words(W, 0), recv_at(N, 0);
+    uint64_t sw = 0, rw = 0;
+    // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words; with a wide set somewhere:
+    // [seeds][positions in contig][contig << 1 | canonical])
+    for (int r = 0; r < W; r++) {
+        uint64_t words = 0; for (uint32_t g : send_to[r]) words += g_npos[g];
+        s_off[r] = sw * 4; s_cnt[r] = words * NF * 4;
+        uint64_t at = sw;
+        for (uint32_t g : send_to[r]) {
+            const uint64_t lp = L->pos_off[g - base[me]];
+            seg_s.insert(seg_s.end(), {lp, at, g_npos[g]}); seg_g.insert(seg_g.end(), {lp, at + words, g_npos[g]});   // the position parts follow the seed parts
+            if (wide_any) seg_c.insert(seg_c.end(), {lp, at + 2 * words, g_npos[g]});
+            at += g_npos[g];
         }
-        uint64_t rw = 0; std::vector<uint64_t> r_words(W, 0);
-        std::vector<uint64_t> recv_at(N, 0);                                        // word offset of a received genome's seeds inside its source's block
-        for (int r = 0; r < W; r++) {
-            for (uint32_t g : recv_from[r]) { recv_at[g] = r_words[r]; r_words[r] += g_npos[g]; }
-            r_off[r] = rw * 4; r_cnt[r] = r_words[r] * NF * 4; rw += r_words[r] * NF;
-        }
-        st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
-        uint32_t *d_send = nullptr, *d_recv = nullptr, *l_pos = nullptr, *l_cc = nullptr;   // l_pos / l_cc: the local set's positions in the C ABI's form (wide_any)
-        local([&] {
-            d_send = ctx->arena.get<uint32_t>(sw + 1); d_recv = ctx->arena.get<uint32_t>(rw + 1);
-            copy_segments(ctx, L->p_seed.p, d_send, seg_s);
-            if (wide_any) {
-                const uint64_t PL = L->pos_off[nL];
-                l_pos = ctx->arena.get<uint32_t>(PL + 1); l_cc = ctx->arena.get<uint32_t>(PL + 1);
-                unpack_positions(ctx, L, 0, PL, l_pos, l_cc);
-                copy_segments(ctx, l_pos, d_send, seg_g); copy_segments(ctx, l_cc, d_send, seg_c);
-            } else copy_segments(ctx, L->p_g.p, d_send, seg_g);
-            dsync(ctx->stream);
-        });
-        agree("sketch exchange buffers");
-        T.all_to_all_v(ctx, d_send, s_cnt.data(), s_off.data(), d_recv, r_cnt.data(), r_off.data(), true);
-        local([&] {                                                                 // (local phase 5)
-            if (!nR) { for (uint32_t g : wk_ids) wk_index[g] = (uint32_t)(g - base[me]); return; }
-            const uint32_t nW = (uint32_t)wk_ids.size();
-            Wk.reset(new skh_sketch_set());
-            Wk->ctx = ctx; Wk->params = L->params; Wk->n_genomes = nW;
-            Wk->rank.resize(nW); Wk->pos_off.assign(nW + 1, 0); Wk->mk_off.assign(nW + 1, 0); Wk->ctg_off.assign(nW + 1, 0); Wk->total_len.resize(nW);
-            for (uint32_t x = 0; x < nW; x++) {
-                const uint32_t g = wk_ids[x];
-                wk_index[g] = x;
-                Wk->rank[x] = (uint32_t)g_rank[g]; Wk->total_len[x] = g_len[g];
-                Wk->pos_off[x + 1] = Wk->pos_off[x] + g_npos[g]; Wk->mk_off[x + 1] = Wk->mk_off[x] + g_nmk[g]; Wk->ctg_off[x + 1] = Wk->ctg_off[x] + g_nctg[g];
-                for (uint64_t c = 0; c < g_nctg[g]; c++) Wk->ctg_len.push_back(cl_all[g_ctg0[g] + c]);
-            }
-            finalize_metadata(Wk.get());
-            const uint64_t PW = Wk->pos_off[nW], MW = Wk->mk_off[nW];
-            Wk->p_seed.alloc(PW ? PW : 1); Wk->markers.alloc(MW ? MW : 1);
-            uint32_t *w_pos = nullptr, *w_cc = nullptr;                             // wide_any: the chained set's positions in the C ABI's form, for the import path
-            if (wide_any) { w_pos = ctx->arena.get<uint32_t>(PW + 1); w_cc = ctx->arena.get<uint32_t>(PW + 1); } else Wk->p_g.alloc(PW);
-            std::vector<uint64_t> ls, lg, rs, rg, rc, mseg;                         // local / received seed and position segments; markers: already here (step 2), 64-bit = two words
-            for (uint32_t x = 0; x < nW; x++) {
-                const uint32_t g = wk_ids[x]; const uint64_t n = g_npos[g], dst = Wk->pos_off[x];
-                if (rank_of[g] == me) { const uint64_t lp = L->pos_off[g - base[me]]; ls.insert(ls.end(), {lp, dst, n}); lg.insert(lg.end(), {lp, dst, n}); }
-                else {
-                    const uint64_t b0 = r_off[rank_of[g]] / 4, rwd = r_words[rank_of[g]];
-                    rs.insert(rs.end(), {b0 + recv_at[g], dst, n}); rg.insert(rg.end(), {b0 + rwd + recv_at[g], dst, n});
-                    if (wide_any) rc.insert(rc.end(), {b0 + 2 * rwd + recv_at[g], dst, n});
-                }
-                mseg.insert(mseg.end(), {S.mk_off[g] * 2, Wk->mk_off[x] * 2, g_nmk[g] * 2});
-            }
-            copy_segments(ctx, L->p_seed.p, Wk->p_seed.p, ls); copy_segments(ctx, d_recv, Wk->p_seed.p, rs);
-            if (wide_any) {
-                copy_segments(ctx, l_pos, w_pos, lg); copy_segments(ctx, l_cc, w_cc, lg);
-                copy_segments(ctx, d_recv, w_pos, rg); copy_segments(ctx, d_recv, w_cc, rc);
-            } else { copy_segments(ctx, L->p_g.p, Wk->p_g.p, lg); copy_segments(ctx, d_recv, Wk->p_g.p, rg); }
-            copy_segments(ctx, (const uint32_t*)S.markers.p, (uint32_t*)Wk->markers.p, mseg);
-            Wk->d_mk_off.alloc(nW + 1); h2d(Wk->d_mk_off.p, Wk->mk_off.data(), (nW + 1) * 8, ctx->stream);
-            if (wide_any) { Stopwatch sw2(ctx, &ctx->timings.sketch_build_ms); build_sketch_tables(ctx, Wk.get(), w_pos, w_cc); }   // (the position arrays live in the arena: the tables are made here)
-            dsync(ctx->stream);
-        });
+        sw += words * NF;
     }
+    for (int r = 0; r < W; r++) {                                                   // recv_at: word offset of a received genome's seeds inside its source's block
+        for (uint32_t g : recv_from[r]) { recv_at[g] = r_words[r]; r_words[r] += g_npos[g]; }
+        r_off[r] = rw * 4; r_cnt[r] = r_words[r] * NF * 4; rw += r_words[r] * NF;
+    }
+    st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
+    uint32_t *d_send = nullptr, *d_recv = nullptr;
+    // the exchange buffers live outside the arena: the chaining of the home pairs resets it while they are in flight
+    DBuf<uint32_t> send_buf, recv_buf;
+    local([&] {                                                                     // (local phase 4)
+        send_buf.alloc(sw + 1); recv_buf.alloc(rw + 1); d_send = send_buf.p; d_recv = recv_buf.p;
+        copy_segments(ctx, L->p_seed.p, d_send, seg_s);
+        if (wide_any) {
+            const uint64_t PL = L->pos_off[nL];
+            uint32_t* l_pos = ctx->arena.get<uint32_t>(PL + 1); uint32_t* l_cc = ctx->arena.get<uint32_t>(PL + 1);   // the local set's positions in the C ABI's form
+            unpack_positions(ctx, L, 0, PL, l_pos, l_cc);
+            copy_segments(ctx, l_pos, d_send, seg_g); copy_segments(ctx, l_cc, d_send, seg_c);
+        } else copy_segments(ctx, L->p_g.p, d_send, seg_g);
+        dsync(ctx->stream);
+    });
+    ctx->arena.reset();
+    ex_begin();
+    agree("sketch exchange buffers");
     ex_end();
+    T.exchange_begin(ctx, d_send, s_cnt.data(), s_off.data(), d_recv, r_cnt.data(), r_off.data());
+    xg.open = true;
+    // -- the home side, while the sketches travel
+    const bool compact_home = nR > 0 && !L->tables_built && !wide_any && !home_ids.empty();
+    const skh_sketch_set* H = L;
+    auto describe = [&](skh_sketch_set* X, const std::vector<uint32_t>& ids, uint32_t set_no) {   // host metadata of a set made of the listed global genomes
+        const uint32_t n = (uint32_t)ids.size();
+        X->ctx = ctx; X->params = L->params; X->n_genomes = n;
+        X->rank.resize(n); X->pos_off.assign(n + 1, 0); X->mk_off.assign(n + 1, 0); X->ctg_off.assign(n + 1, 0); X->total_len.resize(n);
+        for (uint32_t x = 0; x < n; x++) {
+            const uint32_t g = ids[x];
+            wk_set[g] = set_no; wk_index[g] = x;
+            X->rank[x] = (uint32_t)g_rank[g]; X->total_len[x] = g_len[g];
+            X->pos_off[x + 1] = X->pos_off[x] + g_npos[g]; X->mk_off[x + 1] = X->mk_off[x] + g_nmk[g]; X->ctg_off[x + 1] = X->ctg_off[x] + g_nctg[g];
+            for (uint64_t c = 0; c < g_nctg[g]; c++) X->ctg_len.push_back(cl_all[g_ctg0[g] + c]);
+        }
+        finalize_metadata(X);
+        X->markers.alloc(1);                                                        // (the chaining takes the marker COUNTS, chain.rs:625-649; the sets themselves stay in S)
+    };
+    local([&] {                                                                     // (local phase 5)
+        if (!compact_home) { for (uint32_t g : home_ids) { wk_set[g] = 0; wk_index[g] = (uint32_t)(g - base[me]); } return; }
+        Wh.reset(new skh_sketch_set());
+        describe(Wh.get(), home_ids, 0);
+        const uint64_t PW = Wh->pos_off[Wh->n_genomes];
+        Wh->p_seed.alloc(PW ? PW : 1); Wh->p_g.alloc(PW);
+        std::vector<uint64_t> seg;
+        for (uint32_t x = 0; x < Wh->n_genomes; x++) { const uint32_t g = home_ids[x]; seg.insert(seg.end(), {L->pos_off[g - base[me]], Wh->pos_off[x], g_npos[g]}); }
+        copy_segments(ctx, L->p_seed.p, Wh->p_seed.p, seg); copy_segments(ctx, L->p_g.p, Wh->p_g.p, seg);
+        H = Wh.get();
+    });
+    local([&] { if (home_ids.empty()) return; Stopwatch swb(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, H); });   // (local phase 6)
     ctx->arena.reset();
-    tr.mark("dist: sketches exchanged");
-    const skh_sketch_set* CS = Wk ? Wk.get() : L;                                   // the set that is chained
-    local([&] { if (wk_ids.empty()) return; Stopwatch sw(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, CS); });   // (local phase 6)
-    ctx->arena.reset();
-    tr.mark("dist: seed tables of the chained set");
-    // ---- 7. chain this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98)
-    std::vector<uint32_t> c_i, c_j, c_r, c_q;
+    tr.mark("dist: home set indexed");
+    // this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98); home pairs first
+    std::vector<uint32_t> c_i, c_j; std::vector<uint8_t> c_away;
     for (size_t p = 0; p < NP; p++) {
         if (owner[p] != me) continue;
-        c_i.push_back(pi[p]); c_j.push_back(pj[p]); c_r.push_back(wk_index[pi[p]]); c_q.push_back(wk_index[pj[p]]);
+        c_i.push_back(pi[p]); c_j.push_back(pj[p]); c_away.push_back(rank_of[pi[p]] != me || rank_of[pj[p]] != me);
     }
     st.n_pairs_mine = c_i.size();
     std::vector<skh_ani_result> res(c_i.size());
-    // ties of switch_qr go by genome_rank on every rank: the work set carries no file names, and which rank chains a pair must not decide its orientation
-    local([&] {                                                                     // (local phase 7)
-        if (c_i.empty()) return;
-        Stopwatch sw(ctx, &ctx->timings.chain_ms);
-        chain_pairs(ctx, &CS, 1, nullptr, &CS, 1, nullptr, c_r.data(), c_q.data(), c_i.size(), mp, res.data(), nullptr, true);
+    std::vector<uint32_t> sel_home, sel_away;
+    for (uint32_t x = 0; x < c_i.size(); x++) (c_away[x] ? sel_away : sel_home).push_back(x);
+    st.n_pairs_home = sel_home.size();
+    // ties of switch_qr go by genome_rank on every rank: the sets made here carry no file names, and which rank chains a pair must not decide its orientation
+    auto chain_selected = [&](const std::vector<uint32_t>& sel) {
+        if (sel.empty()) return;
+        const skh_sketch_set* sets[2] = {H, Wr ? Wr.get() : H};
+        std::vector<uint32_t> rs(sel.size()), qs(sel.size()), rr(sel.size()), qq(sel.size());
+        for (size_t x = 0; x < sel.size(); x++) {
+            const uint32_t gi = c_i[sel[x]], gj = c_j[sel[x]];
+            rs[x] = wk_set[gi]; rr[x] = wk_index[gi]; qs[x] = wk_set[gj]; qq[x] = wk_index[gj];
+        }
+        std::vector<skh_ani_result> part(sel.size());
+        Stopwatch swc(ctx, &ctx->timings.chain_ms);
+        chain_pairs(ctx, sets, Wr ? 2u : 1u, rs.data(), sets, Wr ? 2u : 1u, qs.data(), rr.data(), qq.data(), sel.size(), mp, part.data(), nullptr, true);
+        for (size_t x = 0; x < sel.size(); x++) res[sel[x]] = part[x];
+    };
+    local([&] { chain_selected(sel_home); });                                       // (local phase 7)
+    ctx->arena.reset();
+    tr.mark("dist: home pairs chained");
+    // -- the sketches have arrived (whatever happened above, the exchange is waited for: nobody may be left inside it)
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        try { xg.close(); } catch (const std::exception& e) { if (local_err.empty()) local_err = e.what(); }
+        dsync(ctx->stream);
+        exch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
+    local([&] {                                                                     // (local phase 8)
+        if (!nR) return;
+        Wr.reset(new skh_sketch_set());
+        describe(Wr.get(), away_ids, 1);
+        const uint32_t nW = Wr->n_genomes; const uint64_t PW = Wr->pos_off[nW];
+        Wr->p_seed.alloc(PW ? PW : 1);
+        uint32_t *w_pos = nullptr, *w_cc = nullptr;                                 // wide_any: the positions in the C ABI's form, for the import path
+        if (wide_any) { w_pos = ctx->arena.get<uint32_t>(PW + 1); w_cc = ctx->arena.get<uint32_t>(PW + 1); } else Wr->p_g.alloc(PW);
+        std::vector<uint64_t> rs, rg, rc;
+        for (uint32_t x = 0; x < nW; x++) {
+            const uint32_t g = away_ids[x]; const uint64_t n = g_npos[g], dst = Wr->pos_off[x];
+            const uint64_t b0 = r_off[rank_of[g]] / 4, rwd = r_words[rank_of[g]];
+            rs.insert(rs.end(), {b0 + recv_at[g], dst, n}); rg.insert(rg.end(), {b0 + rwd + recv_at[g], dst, n});
+            if (wide_any) rc.insert(rc.end(), {b0 + 2 * rwd + recv_at[g], dst, n});
+        }
+        copy_segments(ctx, d_recv, Wr->p_seed.p, rs);
+        if (wide_any) { copy_segments(ctx, d_recv, w_pos, rg); copy_segments(ctx, d_recv, w_cc, rc); } else copy_segments(ctx, d_recv, Wr->p_g.p, rg);
+        Stopwatch swb(ctx, &ctx->timings.sketch_build_ms);
+        if (wide_any) build_sketch_tables(ctx, Wr.get(), w_pos, w_cc);             // (the position arrays live in the arena: the tables are made here)
+        else ensure_tables(ctx, Wr.get());
     });
     ctx->arena.reset();
-    tr.mark("dist: chain");
+    tr.mark("dist: received sketches indexed");
+    local([&] { chain_selected(sel_away); });                                       // (local phase 9)
+    ctx->arena.reset();
+    tr.mark("dist: away pairs chained");
+    T.exchange_times(&st.exchange_async_us, &st.exchange_wait_us);
     // ---- 8. results (ani > 0.1, triangle.rs:99) gathered on every rank, sorted by (i, j)
     struct Row { uint32_t i, j; skh_ani_result r; };
-    std::vector<Row> rows;
-    for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
+    std::vector<Row> rows, all;
+    for (size_t p = 0; p < res.size(); p++) if (local_err.empty() && res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
     ex_begin();
-    uint64_t my_rows = rows.size(); std::vector<uint64_t> rows_all(W);
-    gather_count_and_status(my_rows, rows_all, "seed tables / chaining");
-    uint64_t max_rows = 1, tot_rows = 0; for (int r = 0; r < W; r++) { max_rows = std::max(max_rows, rows_all[r]); tot_rows += rows_all[r]; }
-    std::vector<Row> sendr(max_rows), recvr((size_t)W * max_rows);
-    memset((void*)sendr.data(), 0, sendr.size() * sizeof(Row));
-    std::copy(rows.begin(), rows.end(), sendr.begin());
-    T.all_gather(ctx, sendr.data(), recvr.data(), max_rows * sizeof(Row), false);
+    std::vector<uint64_t> rows_all;
+    gather_records(ctx, T, rows, !local_err.empty(), T.cap_rows, all, rows_all, [&](int r) { stop_together("seed tables / chaining", r); });
     ex_end();
-    std::vector<Row> all; all.reserve(tot_rows);
-    for (int r = 0; r < W; r++) all.insert(all.end(), recvr.begin() + (size_t)r * max_rows, recvr.begin() + (size_t)r * max_rows + rows_all[r]);
     std::sort(all.begin(), all.end(), [](const Row& a, const Row& b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
     out_i.resize(all.size()); out_j.resize(all.size()); out_res.resize(all.size());
     for (size_t x = 0; x < all.size(); x++) { out_i[x] = all[x].i; out_j[x] = all[x].j; out_res[x] = all[x].r; }
     ctx->timings.exchange_ms += (float)exch_ms;
     if (stats) *stats = st;
     tr.mark("dist: results gathered");
+}
+
+// One small all-gather of host memory, one of device memory and one sketch-exchange-shaped all-to-all through the communicator, every byte checked: run
+// once after a communicator is made, where every rank can still choose another transport together (bench.py).
+void comm_selftest(skh_ctx* ctx, Transport& T) {
+    const int W = T.world, me = T.rank;
+    const char* bad = nullptr;                                                      // (every collective is made before anything is thrown: no rank is left inside one)
+    {   // host all-gather
+        uint64_t mine[4]; std::vector<uint64_t> all((size_t)W * 4);
+        for (int x = 0; x < 4; x++) mine[x] = (uint64_t)me * 1000 + x;
+        T.all_gather(ctx, mine, all.data(), sizeof(mine), false);
+        for (int r = 0; r < W; r++) for (int x = 0; x < 4; x++) if (all[(size_t)r * 4 + x] != (uint64_t)r * 1000 + x) bad = "communicator self-test: host all-gather returned wrong data";
+    }
+    {   // device all-gather
+        const size_t n = 1024; std::vector<uint32_t> h(n), back(n * W);
+        for (size_t x = 0; x < n; x++) h[x] = (uint32_t)(me * 100003u + x);
+        DBuf<uint32_t> ds(n), dr(n * W);
+        h2d(ds.p, h.data(), n * 4, ctx->stream); dsync(ctx->stream);
+        T.all_gather(ctx, ds.p, dr.p, n * 4, true);
+        d2h(back.data(), dr.p, n * W * 4, ctx->stream);
+        for (int r = 0; r < W; r++) for (size_t x = 0; x < n; x++) if (back[(size_t)r * n + x] != (uint32_t)(r * 100003u + x)) bad = "communicator self-test: device all-gather returned wrong data";
+    }
+    for (int async = 0; async < 2; async++) {   // all-to-all with uneven shares (rank r sends 256 (1 + (r + q) % 3) words to rank q; nothing to itself when W > 1), blocking and asynchronous
+        std::vector<uint64_t> sc(W), so(W), rc(W), ro(W); uint64_t sw = 0, rw = 0;
+        auto words = [&](int r, int q) { return (uint64_t)((r == q && W > 1) ? 0 : 256 * (1 + (r + q) % 3)); };
+        for (int q = 0; q < W; q++) { so[q] = sw * 4; sc[q] = words(me, q) * 4; sw += words(me, q); ro[q] = rw * 4; rc[q] = words(q, me) * 4; rw += words(q, me); }
+        std::vector<uint32_t> h(sw + 1), back(rw + 1);
+        for (int q = 0; q < W; q++) for (uint64_t x = 0; x < words(me, q); x++) h[so[q] / 4 + x] = (uint32_t)((me << 24) ^ (q << 16) ^ x);
+        DBuf<uint32_t> ds(sw + 1), dr(rw + 1);
+        h2d_big(ds.p, h.data(), sw * 4, ctx->stream); dsync(ctx->stream);
+        if (async) { T.exchange_begin(ctx, ds.p, sc.data(), so.data(), dr.p, rc.data(), ro.data()); T.exchange_end(ctx); }
+        else T.all_to_all_v(ctx, ds.p, sc.data(), so.data(), dr.p, rc.data(), ro.data(), true);
+        d2h(back.data(), dr.p, rw * 4, ctx->stream);
+        for (int q = 0; q < W; q++) for (uint64_t x = 0; x < words(q, me); x++)
+            if (back[ro[q] / 4 + x] != (uint32_t)((q << 24) ^ (me << 16) ^ x)) bad = async ? "communicator self-test: asynchronous all-to-all returned wrong data" : "communicator self-test: all-to-all returned wrong data";
+    }
+    if (bad) throw Error(bad);
 }
 
 Transport* make_host_transport(const skh_host_collectives* hc, int rank, int world) {

@@ -169,12 +169,24 @@ namespace skh {
 // host-memory collectives (device data staged through host buffers).  Every call returns when the data has arrived.
 struct Transport {
     int rank = 0, world = 1;
+    // Sizes of the communicator's previous distributed triangle (largest per-rank genome / contig / marker / candidate-pair / result-row counts): the next
+    // call lays its gathers out by them and needs one collective where counts-then-payload would need two (dist.hip gather_records).
+    uint64_t cap_n = 0, cap_c = 0, cap_m = 0, cap_pairs = 0, cap_rows = 0;
     virtual ~Transport() {}
     // every rank contributes `bytes` bytes; recv gets world * bytes in rank order.  device: both buffers are device memory.
     virtual void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) = 0;
     // send_cnt[r] bytes at send + send_off[r] go to rank r; recv_cnt[r] bytes from rank r land at recv + recv_off[r]
     virtual void all_to_all_v(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
                               const uint64_t* recv_off, bool device) = 0;
+    // The same exchange on DEVICE buffers, asynchronously: _begin returns once the send buffer (complete on the context's stream at the call) has been handed
+    // over; _end makes the received data visible to whatever is queued on the context's stream afterwards.  The count / offset arrays and both buffers stay
+    // untouched in between.  One exchange at a time; no other collective of this communicator between the two calls.
+    virtual void exchange_begin(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                                const uint64_t* recv_off) = 0;
+    virtual void exchange_end(skh_ctx* ctx) = 0;
+    // microseconds the last exchange took from _begin to the arrival of the last byte, and how much of that the context's stream (or the calling thread)
+    // spent waiting in _end; call when the context's stream is idle
+    virtual void exchange_times(uint64_t* total_us, uint64_t* wait_us) = 0;
 };
 Transport* make_host_transport(const skh_host_collectives* hc, int rank, int world);    // dist.hip (the RCCL transport and its two entry points: rccl_transport.hip)
 
@@ -245,6 +257,7 @@ void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std
                   int world, std::vector<uint8_t>& owner, std::vector<uint64_t>& units_of, std::vector<uint64_t>& load);
 void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params& mp,
                           std::vector<uint32_t>& out_i, std::vector<uint32_t>& out_j, std::vector<skh_ani_result>& out_res, uint64_t* n_chained, skh_dist_stats* stats);
+void comm_selftest(skh_ctx* ctx, Transport& T);
 
 // ---- chain.hip
 // chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)

@@ -91,6 +91,45 @@ struct RcclTransport : Transport {
         if (!device) d2h(recv, dr.p, rb, ctx->stream);
         else dsync(ctx->stream);
     }
+    // asynchronous form: the grouped send/recv runs on the context's SECOND stream behind an event of the first (the send buffer is complete there); _end
+    // makes the first stream wait for it on the device -- the host never blocks, and what is queued on the first stream in between (the home pairs'
+    // table build and chaining, dist.hip) runs beside the transfers
+    std::unique_ptr<DevEvent> ev_ready, ev_t0, ev_t1, ev_w0, ev_w1; bool open = false, timed = false;
+    void exchange_begin(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
+                        const uint64_t* recv_off) override {
+        if (open) throw Error("exchange_begin: an exchange is already open");
+        if (!ev_ready) { ev_ready.reset(new DevEvent()); ev_t0.reset(new DevEvent()); ev_t1.reset(new DevEvent()); ev_w0.reset(new DevEvent()); ev_w1.reset(new DevEvent()); }
+        const char* s = (const char*)send; char* rv = (char*)recv;
+        ev_ready->record(ctx->stream); ev_ready->make_wait(ctx->stream2);
+        ev_t0->record(ctx->stream2);
+        if (send_cnt[rank]) {                                                       // own share: a device copy, not a message
+            if (send_cnt[rank] != recv_cnt[rank]) throw Error("exchange: own send and receive sizes differ");
+            d2d(rv + recv_off[rank], s + send_off[rank], send_cnt[rank], ctx->stream2);
+        }
+        rccl_check(api().GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < world; r++) {
+            if (r == rank) continue;
+            if (send_cnt[r]) rccl_check(api().Send(s + send_off[r], send_cnt[r], ncclUint8, r, comm, ctx->stream2), "ncclSend");
+            if (recv_cnt[r]) rccl_check(api().Recv(rv + recv_off[r], recv_cnt[r], ncclUint8, r, comm, ctx->stream2), "ncclRecv");
+        }
+        rccl_check(api().GroupEnd(), "ncclGroupEnd");
+        ev_t1->record(ctx->stream2);
+        open = true; timed = false;
+    }
+    void exchange_end(skh_ctx* ctx) override {
+        if (!open) return;
+        open = false;
+        ev_w0->record(ctx->stream); ev_t1->make_wait(ctx->stream); ev_w1->record(ctx->stream);
+        timed = true;
+    }
+    void exchange_times(uint64_t* total_us, uint64_t* wait_us) override {
+        if (total_us) *total_us = 0;
+        if (wait_us) *wait_us = 0;
+        if (!timed) return;
+        ev_w1->wait();
+        if (total_us) *total_us = (uint64_t)(DevEvent::ms(*ev_t0, *ev_t1) * 1000.f);
+        if (wait_us) *wait_us = (uint64_t)(DevEvent::ms(*ev_w0, *ev_w1) * 1000.f);
+    }
 };
 
 }  // namespace

@@ -98,6 +98,10 @@ class Comm:
             L.skh_free(oi); L.skh_free(oj); L.skh_free(orr)
         return i, j, res, nch.value, {nm: getattr(st, nm) for nm, _ in st._fields_}
 
+    def selftest(self):
+        """Collective: small gathers and exchanges through the communicator, every byte checked (skh_comm_selftest)."""
+        self.ctx.check(self.ctx.L.skh_comm_selftest(self.ctx.h, self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.L.skh_comm_destroy(self.h); self.h = None

@@ -144,10 +144,11 @@ def _failing_worker(rank, world, port, q, fail_rank, phase):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("phase", [1, 3, 4, 7])
+@pytest.mark.parametrize("phase", [1, 3, 4, 6, 7, 8, 9])
 def test_failure_on_one_rank_stops_every_rank(phase):
-    """One rank fails in a local phase (injected: marker buffers, screen, exchange buffers, chaining): at the next exchange point all ranks
-    agree on it and return an error -- nobody waits in a collective for a rank that has left (dist.hip `agree`)."""
+    """One rank fails in a local phase (injected: marker buffers, screen, exchange buffers, home tables, home pairs -- while the sketch exchange is in
+    flight --, received sketches, away pairs): at the next exchange point all ranks agree on it and return an error -- nobody waits in a collective
+    for a rank that has left, and the asynchronous exchange is closed on every path (dist.hip `agree`, ExchangeGuard)."""
     import multiprocessing as mp
     from tests.emu_lib import emu_lib
     emu_lib()
@@ -164,6 +165,69 @@ def test_failure_on_one_rank_stops_every_rank(phase):
     for r in range(world):
         if r != fail_rank:
             assert "rank %d failed" % fail_rank in got[r], got
+
+
+def _reuse_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import skani_amd as sk
+    from skani_amd.distributed import Comm
+    from tests.emu_lib import emu_lib
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = sk.Context(0, lib=emu_lib())
+        genomes, held = _case("interleave4")
+        base = sum(held[:rank])
+        params = sk.SketchParams()
+        comm = Comm.host(ctx, dist, rank, world)
+        comm.selftest()
+        out = []
+        # call 1: every rank holds ONE genome (small tables); calls 2 and 3: the whole collection -- the communicator's remembered capacities are too small
+        # in call 2 (every gather takes its second round) and exact in call 3 (one round each)
+        for n_mine in (1, held[rank], held[rank]):
+            mine = genomes[base:base + n_mine]
+            gs = ctx.pack_genomes([[s for _, s in g if len(s) >= 500] for g in mine], params.seeding_mode)
+            ss = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + n_mine)), defer_tables=True)
+            i, j, res, n, st = comm.triangle(ss, sk.MapParams(learned_ani=True, compute_ci=True))
+            out.append((i, j, res, n, st))
+            ss.close(); gs.close()
+        comm.close()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_communicator_reused_with_growing_and_equal_sizes():
+    """The gathers of skh_triangle_distributed are laid out by the sizes of the communicator's previous call (one collective instead of counts + payload):
+    a first call with one genome per rank, a second with the whole collection (every gather has to go round twice), a third with the same sizes (one
+    round).  Calls 2 and 3 return the single-process triangle byte by byte; call 1 the triangle of its four genomes.  The communicator's self-test
+    (host and device all-gather, blocking and asynchronous all-to-all) runs first."""
+    import multiprocessing as mp
+    import skani_amd as sk
+    from tests.emu_lib import emu_lib
+    emu_lib()
+    genomes, held = _case("interleave4"); world = len(held)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue(); port = _free_port()
+    procs = [ctxm.Process(target=_reuse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    ctx = sk.Context(0, lib=emu_lib())
+    mp_ = sk.MapParams(learned_ani=True, compute_ci=True)
+    firsts = [genomes[sum(held[:r])] for r in range(world)]
+    for call, gset in ((0, firsts), (1, genomes), (2, genomes)):
+        ss = ctx.sketch_records(gset, sk.SketchParams(), None)
+        si, sj, sres, sn = ctx.triangle(ss, mp_)
+        for r in range(world):
+            i, j, res, n, st = got[r][call]
+            assert n == sn and np.array_equal(i, si) and np.array_equal(j, sj) and res.tobytes() == sres.tobytes(), (call, r)
+        ss.close()
+    assert sum(got[r][2][4]["n_pairs_home"] for r in range(world)) < got[0][2][3]          # interleaved clades: most pairs need a received sketch
+    ctx.close()
 
 
 def test_plan_balances_config4_shaped_collection():
