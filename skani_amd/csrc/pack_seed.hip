@@ -283,11 +283,31 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {   // reverse the order
 // rate, so what counts is the NUMBER of instructions per window.  hipcc turns the multiplications of the Thomas Wang mix into pairs of
 // v_mad_u64_u32 glued with v_mov (registers pairs must be even-aligned) and the hit masks into cmp + cndmask + or: 45 instructions per window.
 // The helpers below pin the cheaper forms (25 per window); the test suite's CPU kernel simulator gets the plain C++ meaning.
+// Round 4: the hot loop no longer decides "hash < threshold" exactly.  It computes seed_probe(), a 32-bit quantity from which a SUPERSET of the hits
+// follows with one 32-bit compare (probe_is_candidate): the last step of the mix, key + (key << 31), is only carried out on the high word, without the
+// carry of the low words -- the true high word is that value or one more -- and a window is a candidate when the larger of the two could be below the
+// threshold's high word.  One candidate in ~2^31 is not a hit; the dense pass behind the loop hashes every candidate's seed once more anyway (for the
+// marker test) and drops those (seed_tiles_kernel).  Against the exact form this saves the 64-bit add, the 64-bit compare and the add-with-carry that
+// collected the per-lane hit bits: the candidates of window j are a wave-wide mask in scalar registers, and a lane's bits are put together from the
+// masks' few set bits (1/c of the windows) by scalar code.
 #ifdef SKANI_EMU
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
 __device__ __forceinline__ uint64_t seed_hash(uint32_t seed) { return mm_hash64((uint64_t)seed); }
-__device__ __forceinline__ void push_less(uint32_t& bits, uint64_t h, uint64_t thr) { bits = (bits << 1) | (h < thr ? 1u : 0u); }
+// (the simulator's superset is deliberately loose -- the hash's leading 16 bits -- so that the drop path runs in every test genome: ~0.1 % of its candidates are not hits)
+__device__ __forceinline__ uint32_t seed_probe(uint32_t seed) { return ~((uint32_t)(mm_hash64((uint64_t)seed) >> 32) & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __ballot(a >= b); }
+extern "C" { unsigned long long skh_emu_seed_drops = 0; }              // candidates the dense pass dropped (the tests assert that the path runs)
+#define SKH_SEED_DROP_NOTE() __atomic_fetch_add(&skh_emu_seed_drops, 1ull, __ATOMIC_RELAXED)
 #else
+#define SKH_SEED_DROP_NOTE() ((void)0)
+// lanes with a >= b as a wave mask: ONE compare writing a scalar register pair (__ballot() goes through a select and a second compare)
+#ifdef SKH_SEED_CMP_VCC   // (experiment: the compare in its short encoding writes vcc, a scalar move keeps the mask)
+__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) {
+    unsigned long long m; asm volatile("v_cmp_le_u32_e32 vcc, %2, %1\n\ts_mov_b64 %0, vcc" : "=s"(m) : "v"(a), "s"(b) : "vcc"); return m;
+}
+#else
+__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35 /* ICMP_UGE */); }
+#endif
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 template <int SH> __device__ __forceinline__ uint64_t shl_add_u64(uint64_t a, uint64_t b) {          // (a << SH) + b, SH <= 4, one instruction
     uint64_t d; asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH)); return d;
@@ -308,11 +328,29 @@ __device__ __forceinline__ uint64_t seed_hash(uint32_t seed) {
     key ^= key >> 28;
     return shl_add_u64<0>(key << 31, key);
 }
-// bits = bits << 1 | (h < thr): compare into vcc, add-with-carry shifts it in
-__device__ __forceinline__ void push_less(uint32_t& bits, uint64_t h, uint64_t thr) {
-    asm("v_cmp_gt_u64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(h), "s"(thr) : "vcc");
+// the same mix up to its last step; returns n = ~hi + ((~hi:~lo) >> 1) of the key before that step, which is ~(hi + ((hi:lo) >> 1) + 1): the complement of
+// "high word of key + (key << 31), carry of the low words taken as one".  ~x comes free: the step before is an XOR, taken as XNOR.
+__device__ __forceinline__ uint32_t seed_probe(uint32_t seed) {
+    const uint64_t p = (uint64_t)seed * 0x200001ull;
+    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
+    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
+    const uint64_t q = (uint64_t)lo2 * 265u;
+    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
+    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
+    key ^= key >> 14;
+    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
+    uint64_t sh; asm("v_lshrrev_b64 %0, 28, %1" : "=v"(sh) : "v"(key));   // (one instruction for both words; hipcc splits the shift into two)
+    uint32_t nlo, nhi;
+    asm("v_xnor_b32 %0, %1, %2" : "=v"(nlo) : "v"((uint32_t)key), "v"((uint32_t)sh));
+    asm("v_xnor_b32 %0, %1, %2" : "=v"(nhi) : "v"((uint32_t)(key >> 32)), "v"((uint32_t)(sh >> 32)));
+    return nhi + __builtin_amdgcn_alignbit(nhi, nlo, 1);
 }
 #endif
+// Candidate test on seed_probe's n (both builds).  With t = high word without the carry, the true high word is t or t + 1 (mod 2^32), and h < thr needs
+// it <= thr_hi: every hit has (t + 1 mod 2^32) <= thr_hi + 1, i.e. ~n <= thr_hi + 1 with n = ~(t + 1), i.e. n >= ~(thr_hi + 1).  (t = 0xFFFFFFFF with a carry
+// wraps to a true high word of 0: t + 1 = 0 passes.)
+__device__ __forceinline__ uint32_t probe_limit(uint64_t thr) { const uint32_t th = (uint32_t)(thr >> 32); return th == 0xFFFFFFFFu ? 0u : ~(th + 1u); }   // (c = 1: every window)
 
 // Slow path, taken only by contigs that contain an N: bit j set = window j of this thread is suppressed.
 // scalar (seeding.rs:272-275,300): an N/n at p (p >= 20) suppresses windows i in [p, p+k).
@@ -352,6 +390,7 @@ __device__ __forceinline__ HitRecord derive_hit(uint32_t a0, uint32_t a1, uint32
     return hr;
 }
 
+constexpr uint32_t SEED_DROP_MAX = 16;   // candidates-that-are-not-hits a tile notes per listing round (more: further rounds)
 template <bool K15>   // k = 15 (every preset): one instruction less per window
 __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                                                          const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
@@ -362,7 +401,8 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ cnt_m) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[SEED_TILE / 16 + 8];
     __shared__ uint32_t lds_scan[16];
-    __shared__ uint32_t lds_nm;
+    __shared__ uint32_t lds_nm, lds_ndrop, lds_again;
+    __shared__ uint16_t lds_drop[SEED_DROP_MAX];
     SKH_DYN_SMEM(dyn_smem);
     uint16_t* lds_hit = (uint16_t*)dyn_smem;                 // cap_s entries
     const uint32_t tid = threadIdx.x;
@@ -382,7 +422,8 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     //   r & mask(2k) = complement of the k OLDEST bases, oldest lowest = bits [2(x-20), ..) of the complemented, group-reversed string w2:w1:w0.
     // One funnel shift + one AND each, with compile-time shifts (the loop is fully unrolled).
     const uint32_t w0 = rev2_32(~a0), w1 = rev2_32(~a1), w2 = rev2_32(~a2);
-    uint32_t hits = 0;
+    const uint32_t lim = probe_limit(thr);
+    unsigned long long cand[SEED_RUN];                                            // candidates of window j over the wave (scalar registers)
 #pragma unroll
     for (uint32_t j = 0; j < SEED_RUN; j++) {
         const uint32_t s = 86u - 2u * j;                                           // 126 - 2*(20 + j)
@@ -400,50 +441,72 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
             const uint32_t fs = fw & smask, rs = rw & smask;                       // seeding.rs:288-289
             seed = fs < rs ? fs : rs;                                              // seeding.rs:290-296
         }
-        const uint64_t h = seed_hash(seed);
-        push_less(hits, h, thr);                                                   // seeding.rs:300
+        cand[j] = wave_mask_ge(seed_probe(seed), lim);                               // seeding.rs:300, as a superset (see seed_probe)
     }
-    hits = __brev(hits);                                                           // push_less shifts in from the right: window 0 ended up at bit 31
+    // a lane's candidate bits, from the set bits of the 32 masks: 1/c of the windows, ~16 per wave
+    uint32_t hits = 0;
+    {
+        const uint32_t ln_ = tid & 63u;
+#pragma unroll
+        for (uint32_t j = 0; j < SEED_RUN; j++) {
+            unsigned long long m = cand[j];
+            while (m) { const uint32_t l1 = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1ull; if (ln_ == l1) hits |= 1u << j; }
+        }
+    }
     const uint32_t i0 = (K_MARKER - 1) + tile.first * SEED_TILE + SEED_RUN * tid;   // i of this thread's window 0
     uint32_t nvalid = iend > i0 ? iend - i0 : 0;
     const uint32_t vmask = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
     hits &= vmask;
     if (cd.has_n) hits &= ~n_suppress_mask(nmask, cd, i0, iend, k, mode);
-    // workgroup prefix sum of the hit counts
-    const uint32_t c = (uint32_t)__popc(hits);
-    uint32_t incl = wave_incl_scan(c);
+    // Candidates that are not hits (hash >= thr: one in ~2^31) are found by the dense pass below, which hashes every listed seed anyway; it notes them in
+    // lds_drop, their owners clear the bits, and the listing is done again (a handful of tiles per 5 billion windows).
     const uint32_t wv = tid >> 6, ln = tid & 63;
-    if (ln == 63) lds_scan[wv] = incl;
-    if (tid == 0) lds_nm = 0;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (uint32_t q = 0; q < SEED_THREADS / 64; q++) { uint32_t t = lds_scan[q]; if (q < wv) base += t; tot += t; }
-    // Hits are 1/c of the windows, scattered over the lanes: deriving their records lane by lane would keep a whole wave busy for as many
-    // rounds as its unluckiest lane has hits.  Instead every thread appends (thread << 5 | window) for its hits to a list in LDS (window order,
-    // from the prefix sum) and the list is worked off densely, one hit per thread: seed, strand and -- by hashing the seed once more, which is
-    // cheaper than a second compare in the hot loop -- whether the window is a marker (seeding.rs:311-319).  Marker slots are handed out by an
-    // LDS counter; their order is irrelevant (marker_seeds is a set, built by sorting: sketch_build.hip).
-    // The tile scratch holds cap_s seeds / cap_m markers; a tile that needs more (low-complexity sequence) is re-run by the host with full
-    // capacity -- the two counts are exact either way.
     const uint64_t obase = (uint64_t)blockIdx.x * cap_s, mbase = (uint64_t)blockIdx.x * cap_m;
-    if (tot <= cap_s) {
-        uint32_t so = base + incl - c, hm = hits;
-        while (hm) { const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; lds_hit[so++] = (uint16_t)((tid << 5) | j); }
+    uint32_t tot = 0;
+    for (;;) {
+        // workgroup prefix sum of the hit counts
+        const uint32_t c = (uint32_t)__popc(hits);
+        uint32_t incl = wave_incl_scan(c);
+        if (ln == 63) lds_scan[wv] = incl;
+        if (tid == 0) { lds_nm = 0; lds_ndrop = 0; lds_again = 0; }
         __syncthreads();
-        for (uint32_t x = tid; x < tot; x += SEED_THREADS) {
-            const uint32_t code = lds_hit[x], src = code >> 5;
-            const HitRecord hr = derive_hit(lds_w[2 * src], lds_w[2 * src + 1], lds_w[2 * src + 2], lds_w[2 * src + 3], code & 31u, smask);
-            t_seed[obase + x] = hr.seed;
-            t_loc[obase + x] = (uint16_t)(code | (hr.canonical ? 0x8000u : 0u));        // code = SEED_RUN * thread + window
-            if (seed_hash(hr.seed) < thr_m) { const uint32_t mo = atomicAdd(&lds_nm, 1u); if (mo < cap_m) t_marker[mbase + mo] = hr.kmer; }
+        uint32_t base = 0; tot = 0;
+        for (uint32_t q = 0; q < SEED_THREADS / 64; q++) { uint32_t t = lds_scan[q]; if (q < wv) base += t; tot += t; }
+        // Hits are 1/c of the windows, scattered over the lanes: deriving their records lane by lane would keep a whole wave busy for as many
+        // rounds as its unluckiest lane has hits.  Instead every thread appends (thread << 5 | window) for its hits to a list in LDS (window order,
+        // from the prefix sum) and the list is worked off densely, one hit per thread: seed, strand and -- from one more hash of the seed -- whether
+        // the candidate is a hit at all (seeding.rs:300, exactly) and whether the window is a marker (seeding.rs:311-319).  Marker slots are handed out by an
+        // LDS counter; their order is irrelevant (marker_seeds is a set, built by sorting: sketch_build.hip).
+        // The tile scratch holds cap_s seeds / cap_m markers; a tile that needs more (low-complexity sequence) is re-run by the host with full
+        // capacity -- the two counts are exact either way.
+        if (tot <= cap_s) {
+            uint32_t so = base + incl - c, hm = hits;
+            while (hm) { const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; lds_hit[so++] = (uint16_t)((tid << 5) | j); }
+            __syncthreads();
+            for (uint32_t x = tid; x < tot; x += SEED_THREADS) {
+                const uint32_t code = lds_hit[x], src = code >> 5;
+                const HitRecord hr = derive_hit(lds_w[2 * src], lds_w[2 * src + 1], lds_w[2 * src + 2], lds_w[2 * src + 3], code & 31u, smask);
+                const uint64_t h = seed_hash(hr.seed);
+                if (h >= thr) { SKH_SEED_DROP_NOTE(); const uint32_t d = atomicAdd(&lds_ndrop, 1u); if (d < SEED_DROP_MAX) lds_drop[d] = (uint16_t)code; continue; }
+                t_seed[obase + x] = hr.seed;
+                t_loc[obase + x] = (uint16_t)(code | (hr.canonical ? 0x8000u : 0u));        // code = SEED_RUN * thread + window
+                if (h < thr_m) { const uint32_t mo = atomicAdd(&lds_nm, 1u); if (mo < cap_m) t_marker[mbase + mo] = hr.kmer; }
+            }
+        } else {                                                                               // only the counts matter
+            uint32_t hm = hits, nm = 0;
+            while (hm) {
+                const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
+                const uint64_t h = seed_hash(derive_hit(a0, a1, a2, a3, j, smask).seed);
+                if (h >= thr) { SKH_SEED_DROP_NOTE(); hits &= ~(1u << j); lds_again = 1; }                              // (dropped by its owner at once; the counts are taken again)
+                else if (h < thr_m) nm++;
+            }
+            if (nm) atomicAdd(&lds_nm, nm);
         }
-    } else {                                                                               // only the counts matter
-        uint32_t hm = hits, nm = 0;
-        while (hm) {
-            const uint32_t j = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u;
-            if (seed_hash(derive_hit(a0, a1, a2, a3, j, smask).seed) < thr_m) nm++;
-        }
-        if (nm) atomicAdd(&lds_nm, nm);
+        __syncthreads();
+        const uint32_t nd = lds_ndrop;
+        if (!nd && !lds_again) break;
+        for (uint32_t d = 0; d < nd && d < SEED_DROP_MAX; d++) { const uint32_t code = lds_drop[d]; if ((code >> 5) == tid) hits &= ~(1u << (code & 31u)); }
+        __syncthreads();                                                                       // (lds_ndrop / lds_drop are rewritten by the next round)
     }
     __syncthreads();
     if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; }
@@ -516,7 +579,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     StageTrace tr(ctx);
     out.pos_off.assign(ng + 1, 0); out.mk_off.assign(ng + 1, 0);
     // capped tile scratch: 4x the expected hits per tile; tiles that exceed it are re-run with full capacity
-    const uint32_t cap_s = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
+    const uint32_t cap_s = ctx->tune.seed_tile_cap ? std::min<uint32_t>(SEED_TILE, ctx->tune.seed_tile_cap) : std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
     const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch

@@ -110,3 +110,37 @@ def test_emu_randomised_differential(ctx):
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     rng = np.random.default_rng(7)
     assert sum(fz.one_round(ctx, rng, r) for r in range(4)) > 20
+
+
+def test_emu_seeding_drops_candidates_that_are_not_hits():
+    """The seeding loop lists a SUPERSET of the hits (32-bit compare on the hash's leading word, pack_seed.hip seed_probe) and its dense pass drops the
+    rest.  The simulator's superset is deliberately loose, so the drop path -- one candidate in ~2^31 on the GPU -- runs here on ordinary sequence,
+    in both forms (a tile that lists its hits, and a low-complexity tile that only counts because it overflows the capped scratch), and the sketches
+    still equal the oracle's."""
+    import ctypes
+    from tests.helpers import ora
+    import os
+    L = emu_lib()
+    drops = ctypes.c_ulonglong.in_dll(L, "skh_emu_seed_drops")
+    g = pc.random_genome(600000, 99)
+    low = np.frombuffer((b"ACGTTGCA" * 3000), np.uint8).copy()                # few distinct seeds: a tile beyond the capped scratch
+    for tile_cap in (None, "8"):                                               # SKH_TUNE_SEED_TILE_CAP=8: every tile overflows the capped scratch, counts only, and is listed by the re-run
+        if tile_cap: os.environ["SKH_TUNE_SEED_TILE_CAP"] = tile_cap
+        try:
+            c = sk.Context(0, lib=L)
+        finally:
+            os.environ.pop("SKH_TUNE_SEED_TILE_CAP", None)
+        try:
+            before = drops.value
+            for mode in (sk.SEED_SCALAR, sk.SEED_AVX2):
+                for cc in (125, 2):
+                    recs = [[("a", g[:200000 if cc == 2 else len(g)])], [("l", low)]]
+                    ss = c.sketch_records(recs, sk.SketchParams(cc, 15, 1000, mode), ["a.fa", "l.fa"])
+                    for k, r in enumerate(recs):
+                        o = ora.sketch_records(r, c=cc, k=15, marker_c=1000, mode=mode, file_name="x.fa")
+                        e = ss.export(k); s, p, q = o.seeds(pos_order=True)
+                        assert np.array_equal(e["seed"], s) and np.array_equal(e["pos"], p) and np.array_equal(e["ctgcanon"], q) and np.array_equal(e["markers"], o.markers())
+                    ss.close()
+            assert drops.value - before > (40 if tile_cap else 20), (tile_cap, drops.value - before)   # (with the small cap every drop happens twice: counting, then listing)
+        finally:
+            c.close()
