@@ -94,7 +94,10 @@ int skh_genomes_pack(skh_ctx*, const uint8_t* bases, const uint64_t* contig_off,
  * position in the caller's file order, whatever order the batches arrive in; a genome's contigs come together, in order, in ONE batch; a genome
  * that never arrives has no contigs.  The call returns when the batch is queued; with `bases` in pinned memory (skh_host_alloc) the copy runs
  * behind the caller's back and the buffer may be rewritten once skh_genomes_wait(ticket) has returned.  One thread at a time per context, like
- * every call -- except skh_genomes_wait, which any thread may call while another one appends.  skh_genomes_finish completes the set (it then behaves like one from skh_genomes_pack). */
+ * every call -- except skh_genomes_wait, which any thread may call while another one appends or finishes (a wait holds its own reference to the batch's
+ * event); every wait must have returned before skh_genomes_destroy.  A refused skh_genomes_append (a bad genome number, a genome in two batches, more
+ * bases than announced) leaves the set as it was.  skh_genomes_finish completes the set (it then behaves like one from skh_genomes_pack).
+ * Every skh_* call binds the calling thread to its context's device for its duration and puts the thread's previous current device back when it returns. */
 void* skh_host_alloc(uint64_t bytes);   /* pinned host memory; NULL on failure */
 void skh_host_free(void*);
 int skh_genomes_begin(skh_ctx*, uint64_t max_bases, uint32_t max_contigs, uint32_t n_genomes, int seeding_mode, skh_genome_set** out);

@@ -58,7 +58,7 @@ HOST_BIN = os.path.join(HERE, "bin", "skani-hip")
 def build_host(force=False):
     """C++ host side (FASTA ingest, writers, triangle/dist drivers): g++ only, links the C ABI library."""
     srcs = [os.path.join(HOST, f) for f in ("fastx.cpp", "writers.cpp", "formats.cpp")]
-    deps = srcs + [os.path.join(HOST, "host.hpp"), os.path.join(HOST, "capi_test.cpp"), os.path.join(HOST, "capi_db.cpp"), os.path.join(HOST, "main.cpp"), LIB]
+    deps = srcs + [os.path.join(HOST, "host.hpp"), os.path.join(HOST, "capi_db.cpp"), os.path.join(HOST, "main.cpp"), LIB]
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -66,7 +66,7 @@ def build_host(force=False):
             raise RuntimeError("g++ failed: %s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
     common = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"]
     if force or _stale(HOST_LIB, deps):
-        run(common + ["-shared", "-o", HOST_LIB] + srcs + [os.path.join(HOST, "capi_test.cpp"), os.path.join(HOST, "capi_db.cpp"), "-lz", "-pthread"])
+        run(common + ["-shared", "-o", HOST_LIB] + srcs + [os.path.join(HOST, "capi_db.cpp"), "-lz", "-pthread"])   # (capi_db.cpp: what skani_amd/formats.py binds)
     if force or _stale(HOST_BIN, deps):
         run(common + ["-o", HOST_BIN, os.path.join(HOST, "main.cpp")] + srcs + ["-L", HERE, "-lskani_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/.."])
     return HOST_LIB, HOST_BIN

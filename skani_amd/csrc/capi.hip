@@ -168,8 +168,8 @@ int skh_genomes_append(skh_genome_set* gs, const uint8_t* bases, const uint64_t*
 
 int skh_genomes_wait(skh_genome_set* gs, uint64_t ticket) {                      // any thread, also while another thread appends: touches nothing but the batch's event
     if (!gs) return SKH_ERR_INVALID;
-    DevEvent* ev = nullptr;
-    { std::lock_guard<std::mutex> lk(gs->copied_mu); if (ticket < gs->copied.size()) ev = gs->copied[ticket].get(); }
+    std::shared_ptr<DevEvent> ev;
+    { std::lock_guard<std::mutex> lk(gs->copied_mu); if (ticket < gs->copied.size()) ev = gs->copied[ticket]; }
     if (!ev) return SKH_ERR_INVALID;
     try { ev->wait(); return SKH_OK; } catch (...) { return SKH_ERR_DEVICE; }
 }

@@ -48,9 +48,14 @@ struct PinRing {
 };
 inline PinRing*& pin_ring_of_thread() { static thread_local PinRing* r = nullptr; return r; }
 struct PinScope {                                                                    // entry points: this thread's device is `device`, its small uploads use `ring`
-    PinRing* prev;
-    PinScope(int device, PinRing* ring) : prev(pin_ring_of_thread()) { (void)hipSetDevice(device); pin_ring_of_thread() = ring; }
-    ~PinScope() { pin_ring_of_thread() = prev; }
+    PinRing* prev; int prev_dev = -1;                                                // (the caller's current device is put back on the way out: a host application may share the thread)
+    PinScope(int device, PinRing* ring) : prev(pin_ring_of_thread()) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        if (cur != device) { (void)hipSetDevice(device); prev_dev = cur; }
+        pin_ring_of_thread() = ring;
+    }
+    ~PinScope() { pin_ring_of_thread() = prev; if (prev_dev >= 0) (void)hipSetDevice(prev_dev); }
 };
 inline void h2d(void* d, const void* h, size_t n, devStream_t s) {
     if (!n) return;
@@ -136,6 +141,21 @@ __device__ __forceinline__ uint32_t abs_diff_u32(uint32_t a, uint32_t b) { uint3
 // LDS crossbar -- for dependent chains of neighbour exchanges
 __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
 __device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+// inclusive prefix sum across the wave: four row shifts inside the rows of 16 lanes, then the two row broadcasts (lane 15 of a row to the next row, lane 31
+// to the upper half) -- six DPP additions.  (Through __shfl_up it was six LDS-crossbar round trips plus a compare, a select and an address per step:
+// ~40 vector instructions and six waits.)  (Every parity test runs through it: the seeding's hit lists and the join's anchor offsets are its sums.)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    // v += v of the lane 1 / 2 / 4 / 8 below in the row (a lane without such a source keeps v: the instruction is off there), then rows 1, 3 += lane 15 of
+    // the row before and rows 2, 3 += lane 31.  One instruction per step (through __builtin_amdgcn_update_dpp hipcc makes three); a DPP operand written by
+    // the instruction before needs two idle states.
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+}
 // in-kernel timing (SKH_TRACE_JOIN): the shader clock, and a point at which a loaded value must have arrived
 __device__ __forceinline__ unsigned long long wave_clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void wait_for_value(uint32_t v) { asm volatile("" ::"v"(v)); }
@@ -175,13 +195,6 @@ template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane) { 
 __device__ __forceinline__ unsigned wave_readlane(unsigned v, int uniform_lane) { return (unsigned)wave_readlane((int)v, uniform_lane); }
 __device__ __forceinline__ uint64_t wave_readlane(uint64_t v, int uniform_lane) {
     return ((uint64_t)wave_readlane((unsigned)(v >> 32), uniform_lane) << 32) | wave_readlane((unsigned)v, uniform_lane);
-}
-// inclusive prefix sum across the wave
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
-    unsigned l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(v, d, 64); if (l >= (unsigned)d) v += t; }
-    return v;
 }
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 #pragma unroll

@@ -103,7 +103,7 @@ struct skh_genome_set {
     // filling state (pack_seed.hip genomes_begin / _append / _finish)
     bool open = false; uint64_t cap_units = 0, n_units = 0; uint32_t cap_contigs = 0, n_batches = 0;
     skh::DBuf<uint8_t> stage[2];                   // device staging of the batches' ASCII (host sources), alternating
-    std::vector<std::unique_ptr<skh::DevEvent>> copied;   // one per batch: recorded behind the copy of its bases (skh_genomes_wait)
+    std::vector<std::shared_ptr<skh::DevEvent>> copied;   // one per batch: recorded behind the copy of its bases (skh_genomes_wait holds its own reference while it waits: _finish may clear the list meanwhile)
     std::mutex copied_mu;
 };
 

@@ -180,19 +180,28 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
     const uint32_t c0 = gs->n_contigs, ng = gs->n_genomes;
     std::vector<uint64_t> unit_off(nc + 1, 0), src_off(nc);
     uint64_t span_lo = ~0ull, span_hi = 0;                                        // the stretch of the caller's buffer the batch reads
-    for (uint32_t i = 0; i < nc; i++) {
-        const uint32_t g = contig_genome[i];
-        if (g >= ng) throw std::invalid_argument("contig_genome must be < n_genomes");
-        if ((i == 0 || contig_genome[i - 1] != g) && gs->genome_contig_off[(size_t)g + 1]) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
-        gs->genome_contig_off[(size_t)g + 1]++;
+    // everything that can refuse the batch is checked before the set is touched: a refused append leaves the set as it was
+    {
+        uint64_t units = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            const uint32_t g = contig_genome[i];
+            if (g >= ng) throw std::invalid_argument("contig_genome must be < n_genomes");
+            if (i == 0 || contig_genome[i - 1] != g) {
+                if (gs->genome_contig_off[(size_t)g + 1]) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
+                for (uint32_t y = 0; y < i; y++) if (contig_genome[y] == g) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
+            }
+            if (contig_len[i] > 0xFFFFFFF0ull) throw std::invalid_argument("contig longer than 2^32 bases");
+            units += (contig_len[i] + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN / 32;
+        }
+        if (gs->n_units + units > gs->cap_units) throw std::invalid_argument("more bases than skh_genomes_begin announced (every contig takes its length rounded up to 64 bases)");
     }
+    for (uint32_t i = 0; i < nc; i++) gs->genome_contig_off[(size_t)contig_genome[i] + 1]++;
     gs->contigs.resize((size_t)c0 + nc);
     uint32_t idx = 0; uint64_t gat = 0;
     for (uint32_t i = 0; i < nc; i++) {
         const uint32_t g = contig_genome[i];
         if (i == 0 || contig_genome[i - 1] != g) idx = 0;
         const uint64_t len = contig_len[i];
-        if (len > 0xFFFFFFF0ull) throw Error("contig longer than 2^32 bases");
         ContigDesc& cd = gs->contigs[c0 + i];
         cd.genome = g; cd.index = idx++;
         cd.len = (uint32_t)len; cd.base = (gs->n_units + unit_off[i]) * 32; cd.has_n = 0;
@@ -205,7 +214,6 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
         gs->total_bases += len;
     }
     const uint64_t n_units = unit_off[nc];
-    if (gs->n_units + n_units > gs->cap_units) throw std::invalid_argument("more bases than skh_genomes_begin announced (every contig takes its length rounded up to 64 bases)");
     if (span_lo > span_hi) { span_lo = 0; span_hi = 0; }
     h2d(gs->d_contigs.p + c0, gs->contigs.data() + c0, (size_t)nc * sizeof(ContigDesc), ctx->stream);
     // bytes the kernel may read from the source: rounded up to whole 4-byte words at both ends (an aligned word that holds a valid byte is readable)
@@ -296,6 +304,7 @@ __device__ __forceinline__ uint64_t seed_hash(uint32_t seed) { return mm_hash64(
 // (the simulator's superset is deliberately loose -- the hash's leading 16 bits -- so that the drop path runs in every test genome: ~0.1 % of its candidates are not hits)
 __device__ __forceinline__ uint32_t seed_probe(uint32_t seed) { return ~((uint32_t)(mm_hash64((uint64_t)seed) >> 32) & 0xFFFF0000u); }
 __device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __ballot(a >= b); }
+__device__ __forceinline__ void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) { if ((lanes >> (threadIdx.x & 63u)) & 1ull) v |= bits; }
 extern "C" { unsigned long long skh_emu_seed_drops = 0; }              // candidates the dense pass dropped (the tests assert that the path runs)
 #define SKH_SEED_DROP_NOTE() __atomic_fetch_add(&skh_emu_seed_drops, 1ull, __ATOMIC_RELAXED)
 #else
@@ -308,6 +317,11 @@ __device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t 
 #else
 __device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35 /* ICMP_UGE */); }
 #endif
+// v |= bits in the lanes of the (wave-uniform, non-empty) mask: ONE vector instruction under a narrowed exec mask (as an `if` it is compare + select + or)
+__device__ __forceinline__ void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(v), "=&s"(save) : "s"(lanes), "s"(bits));
+}
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 template <int SH> __device__ __forceinline__ uint64_t shl_add_u64(uint64_t a, uint64_t b) {          // (a << SH) + b, SH <= 4, one instruction
     uint64_t d; asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH)); return d;
@@ -446,11 +460,9 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     // a lane's candidate bits, from the set bits of the 32 masks: 1/c of the windows, ~16 per wave
     uint32_t hits = 0;
     {
-        const uint32_t ln_ = tid & 63u;
 #pragma unroll
         for (uint32_t j = 0; j < SEED_RUN; j++) {
-            unsigned long long m = cand[j];
-            while (m) { const uint32_t l1 = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1ull; if (ln_ == l1) hits |= 1u << j; }
+            if (cand[j]) or_in_lanes(hits, cand[j], 1u << j);                      // (all its lanes at once: the mask IS the set of lanes)
         }
     }
     const uint32_t i0 = (K_MARKER - 1) + tile.first * SEED_TILE + SEED_RUN * tid;   // i of this thread's window 0

@@ -30,6 +30,8 @@ void finish(FlatDb* db) {
 
 extern "C" {
 
+void skhost_free(char* p) { free(p); }
+
 // kind 0: folder written by `skani sketch` / `skani-hip sketch` (or its markers.bin); kind 1: '\n'-separated .sketch files.
 // Returns NULL and sets *out, or an error string (skhost_free it).
 char* skhost_db_open(const char* path, int kind, void** out) {

@@ -52,6 +52,11 @@ inline void block_fence() { __threadfence_block(); }
 inline uint32_t abs_diff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 inline uint32_t lane_next(uint32_t v) { const int l = (int)emu::lane(); return emu::shfl(v, l < 63 ? l + 1 : l); }
 inline uint32_t lane_prev(uint32_t v) { const int l = (int)emu::lane(); return emu::shfl(v, l > 0 ? l - 1 : l); }
+inline unsigned wave_incl_scan(unsigned v) {
+    const unsigned l = emu::lane();
+    for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(v, (unsigned)d, 64); if (l >= (unsigned)d) v += t; }
+    return v;
+}
 inline unsigned long long wave_clock() { return 0; }
 inline void wait_for_value(uint32_t) {}
 inline uint32_t xcc_id() { return 0; }

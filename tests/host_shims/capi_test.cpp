@@ -1,8 +1,9 @@
-// capi_test.cpp -- extern "C" hooks so the CPU test-suite can exercise the host code (FASTA reader, writers) via ctypes.
+// capi_test.cpp -- TEST-ONLY: extern "C" hooks so the CPU test-suite can exercise the C++ host code (FASTA reader, writers, formats) via ctypes.
+// Built by tests/host_shims/build_shims.py into tests/host_shims/libskani_host_test.so together with the host sources; not part of the product libraries.
 #include <cstdlib>
 #include <cstring>
 
-#include "host.hpp"
+#include "../../skani_amd/host/host.hpp"
 
 using namespace skhost;
 
@@ -16,7 +17,7 @@ static std::vector<GenomeInfo> infos(uint32_t n, const char** files, const char*
 static OutOpts opts(uint32_t flags) { OutOpts o; o.ci = flags & 1; o.detailed = flags & 2; o.short_header = flags & 4; o.diagonal = flags & 8; o.full_matrix = flags & 16; o.distance = flags & 32; return o; }
 
 extern "C" {
-void skhost_free(char* p) { free(p); }
+void skhost_test_free(char* p) { free(p); }
 
 // returns "name\tlen\n" per kept record (>= min_len) -- checks reader semantics
 char* skhost_fasta_summary(const char* path, uint64_t min_len) {

@@ -16,9 +16,8 @@ from tests.helpers import GOLDEN
 
 @pytest.fixture(scope="module")
 def host():
-    build_hip()
-    lib, _ = build_host()
-    L = C.CDLL(lib)
+    from tests.host_shims.build_shims import build as build_shims
+    L = C.CDLL(build_shims())                                         # the host sources behind test-only extern "C" hooks (tests/host_shims)
     for f in ("skhost_sketch_read", "skhost_sketch_write", "skhost_db_write", "skhost_db_summary", "skhost_sketch_summary"):
         getattr(L, f).restype = C.c_void_p
     return L
@@ -27,7 +26,7 @@ def host():
 def _take(L, p):
     if not p:
         return None
-    s = C.string_at(p).decode(); L.skhost_free(C.c_void_p(p)); return s
+    s = C.string_at(p).decode(); L.skhost_test_free(C.c_void_p(p)); return s
 
 
 def read_sketch(L, path):
@@ -40,8 +39,8 @@ def read_sketch(L, path):
         raise RuntimeError(err)
     def arr(p, n, dt):
         a = np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt).copy() if n else np.zeros(0, dt)
-        L.skhost_free(C.cast(p, C.c_void_p)); return a
-    nm = C.string_at(names).decode().split("\n"); L.skhost_free(names)
+        L.skhost_test_free(C.cast(p, C.c_void_p)); return a
+    nm = C.string_at(names).decode().split("\n"); L.skhost_test_free(names)
     return dict(c=ckm[0], k=ckm[1], m=ckm[2], format=fmt.value, seed=arr(seed, n_rec.value, np.uint32), pos=arr(pos, n_rec.value, np.uint32),
                 ctgcanon=arr(cc, n_rec.value, np.uint32), markers=arr(mk, n_mk.value, np.uint64), contig_lengths=arr(clen, n_ctg.value, np.uint32),
                 total_len=scal[0], sk_marker_c=scal[1], sk_c=scal[2], sk_k=scal[3], contig_order=scal[4], repetitive=scal[5], file_name=nm[0], contigs=nm[1:])

@@ -17,16 +17,15 @@ from tests.helpers import GOLDEN, golden_records, mutate
 
 @pytest.fixture(scope="module")
 def host():
-    build_hip()
-    lib, _ = build_host()
-    L = C.CDLL(lib)
+    from tests.host_shims.build_shims import build as build_shims
+    L = C.CDLL(build_shims())                                         # the host sources behind test-only extern "C" hooks (tests/host_shims)
     for f in ("skhost_fasta_summary", "skhost_fasta_plain", "skhost_fasta_plain_threads", "skhost_fasta_seq", "skhost_phylip", "skhost_sparse", "skhost_query_ref_list"):
         getattr(L, f).restype = C.c_void_p
     return L
 
 
 def _take(L, p):
-    s = C.string_at(p).decode(); L.skhost_free(C.c_void_p(p)); return s
+    s = C.string_at(p).decode(); L.skhost_test_free(C.c_void_p(p)); return s
 
 
 def test_fasta_reader_matches_needletail_semantics(host, tmp_path):
