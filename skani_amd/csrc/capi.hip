@@ -224,7 +224,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         ev[1].record(ctx->stream);
         // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)
         struct TailGuard { bool armed = true; ~TailGuard() { if (armed) device_sync_all(); } } tail_guard;
-        ss->p_seed = std::move(so.seed); ss->p_hash = std::move(so.hash); ss->p_g = std::move(so.g); ss->p_g64 = std::move(so.g64); ss->pos_off = so.pos_off;
+        ss->p_seed = std::move(so.seed); ss->p_g = std::move(so.g); ss->p_g64 = std::move(so.g64); ss->pos_off = so.pos_off;
         // the seed tables are queued on the main stream; the marker sets (a sort and a few small kernels, with a read-back of their own) and the
         // screen's sorted incidence list are built on the second stream meanwhile
         if (flags & SKH_SKETCH_DEFER_TABLES) {                                       // markers only; the tables are built where (and if) the sketches are chained

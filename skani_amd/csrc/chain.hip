@@ -40,7 +40,7 @@ static void genome_halves(const skh_sketch_set* S) {
     for (uint32_t g = 0; g < S->n_genomes; g++) {
         skh_sketch_set::GenomeHalf& h = S->halves[g];
         h.n_pos = (uint32_t)(S->pos_off[g + 1] - S->pos_off[g]); h.pos0 = (uint32_t)S->pos_off[g];
-        h.hash = S->p_hash.p + S->pos_off[g]; h.g = S->p_g.p + S->pos_off[g]; h.rep = S->p_rep.p;
+        h.seed = S->p_seed.p + S->pos_off[g]; h.g = S->p_g.p + S->pos_off[g]; h.rep = S->p_rep.p; h.salt = S->salt[g];
         h.ms = S->ms.p + S->ms_off[g]; h.tab = S->tab.p + S->tab_off[g]; h.nbk = S->n_buckets[g]; h.bmap = S->bmap.p + S->bmap_off[g];
         h.goff = S->d_goff.p + S->ctg_off[g] + g; h.host_goff = S->goff.data() + S->ctg_off[g] + g;
         h.g64 = nullptr; h.goff64 = nullptr; h.host_goff64 = nullptr;
@@ -454,8 +454,8 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
             const uint32_t gb = sw ? q : r;
             pd.a_n = empty ? 0 : A.n_pos;
-            pd.a_hash = A.hash; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
-            pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap;
+            pd.a_seed = A.seed; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
+            pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap; pd.b_salt = B.salt;
             pd.flags = sw ? 4u : 0u;
             pd.tile0 = 0;
             pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
     // The sketches' arrays are reached through pointers that were loaded from the pair record: generic pointers to the compiler, whose loads (flat_load)
     // count on the LDS wait counter as well -- every wait for the filter or the probe queue then also waits for the hashes requested a round ahead.
     // global_of() (dev.h) names the address space; the loads become global_load and the waits exact.
-    const GlobalPtr<uint32_t> a_hash = global_of(pd.a_hash), a_g = global_of(pd.a_g), a_rep = global_of(pd.a_rep), b_ms = global_of(pd.b_ms);
+    const GlobalPtr<uint32_t> a_seed = global_of(pd.a_seed), a_g = global_of(pd.a_g), a_rep = global_of(pd.a_rep), b_ms = global_of(pd.b_ms);
     if (use_bm) {                                                                    // B's occupancy filter, staged once for the workgroup's tiles (the only barrier)
         const GlobalPtr<uint4> src = (GlobalPtr<uint4>)global_of(pd.b_bmap);
         for (uint32_t w4 = threadIdx.x; w4 < bm_words / 4; w4 += JOIN_THREADS) ((uint4*)bm)[w4] = src[w4];
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
     auto fetch = [&](uint32_t round) {
         const uint32_t i0 = start + round * RW + 4u * l;
         if (i0 + 4u <= pd.a_n) {
-            const Words4 a = *(GlobalPtr<Words4>)(a_hash + i0), b = *(GlobalPtr<Words4>)(a_g + i0);
+            const Words4 a = *(GlobalPtr<Words4>)(a_seed + i0), b = *(GlobalPtr<Words4>)(a_g + i0);
             nh[0] = a.x; nh[1] = a.y; nh[2] = a.z; nh[3] = a.w; ng[0] = b.x; ng[1] = b.y; ng[2] = b.z; ng[3] = b.w;
         } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) { const bool in = i0 + (uint32_t)r < pd.a_n; nh[r] = in ? a_hash[i0 + r] : 0u; ng[r] = in ? a_g[i0 + r] : 0u; }
+            for (int r = 0; r < R; r++) { const bool in = i0 + (uint32_t)r < pd.a_n; nh[r] = in ? a_seed[i0 + r] : 0u; ng[r] = in ? a_g[i0 + r] : 0u; }
         }
         // 'repetitive' bits (chain.rs:674-676: more than `band` positions in A) of the round's 256 positions: bits [x0, x0 + 256) of the words from rw0 on
         const uint32_t gi0 = pd.a_pos0 + start + round * RW, rw0 = gi0 >> 5, x = (gi0 & 31u) + 4u * l;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc
         uint32_t h[R], qg[R], sl[R]; bool live[R], pass[R];
         const uint32_t rep = nrep;
 #pragma unroll
-        for (int r = 0; r < R; r++) { h[r] = nh[r]; qg[r] = ng[r]; live[r] = !((rep >> r) & 1u); }
+        for (int r = 0; r < R; r++) { h[r] = table_hash(nh[r], pd.b_salt); qg[r] = ng[r]; live[r] = !((rep >> r) & 1u); }   // (the seeds are stored, not their hashes: 4 bytes less per position, and B decides the salt)
         if (PROF) { wait_for_value(h[0]); wait_for_value(qg[3]); tick(0); }                 // 0: the round's hashes / positions have arrived
         if (round + 1 < JOIN_TILE / RW) fetch(round + 1);
         // the occupancy filter (common.h): 85 % of the probes of absent seeds end here

@@ -7,13 +7,14 @@
 // element), so the pairs of one call may draw their sketches from any number of resident sketch sets (a sharded database).
 struct PairDesc {
     // A = enumerated sketch (position order); p_g = padded coordinate << 1 | canonical
-    const uint32_t *a_hash, *a_g; const uint32_t* a_rep;   // a_hash = mix32(seed); a_rep: the set's "repetitive seed" bits; bit a_pos0 + i belongs to position i
+    const uint32_t *a_seed, *a_g; const uint32_t* a_rep;   // a_rep: the set's "repetitive seed" bits; bit a_pos0 + i belongs to position i
     // B = probed sketch: seed table (common.h: position or list reference in the slot), list storage, bucket-occupancy bitmap
     const uint32_t* b_ms; const uint64_t* b_tab; const uint32_t* b_bmap;
     const uint32_t *a_goff, *b_goff;   // padded contig starts (common.h CTG_PAD), a_nctg + 1 / b_nctg + 1 entries
     uint32_t a_n;       // positions in A
     uint32_t a_pos0;    // A's first position in its set's position numbering
     uint32_t b_nbk;     // B: buckets (home slots) of its seed table
+    uint32_t b_salt;    // B's table works on table_hash(seed, b_salt) (common.h): the join hashes A's seeds with it
     uint32_t flags;     // bit2: switched (chain.rs:649)
     uint32_t tile0;     // first join tile of this pair (global over the call)
     uint32_t a_nctg, b_nctg;

@@ -59,6 +59,11 @@ __host__ __device__ __forceinline__ uint32_t ctg_of(const Arr& goff, uint32_t n_
     return lo;
 }
 
+// A genome's seed table works on table_hash(seed, salt): the salt is 0 unless the genome's seeds crowded one stretch of the hash range under it (a table
+// slice's overflow slots ran out, sketch_build.hip) -- such a genome is indexed under the next salt, and the join hashes the enumerated seeds with the
+// probed genome's salt.  A bijection of the seed for every salt: equal hash <=> equal seed.
+__host__ __device__ __forceinline__ uint32_t table_hash(uint32_t seed, uint32_t salt) { return mix32(seed ^ salt); }
+
 // home slot (bucket) of a hashed seed in a genome's seed table: monotone in the hash, any bucket count
 __host__ __device__ __forceinline__ uint32_t seed_bucket(uint32_t hash, uint32_t n_buckets) { return (uint32_t)(((uint64_t)hash * n_buckets) >> 32); }
 

@@ -115,6 +115,7 @@ struct skh_sketch_set {
     // host metadata (one entry per genome unless noted)
     std::vector<uint64_t> pos_off, dist_off, mk_off, ctg_off, tab_off;   // n_genomes+1
     std::vector<uint32_t> n_buckets;               // home slots (buckets) of each genome's seed table
+    std::vector<uint32_t> salt;                    // per genome: its table works on mix32(seed ^ salt) (common.h table_hash); 0 unless the seeds crowded the hash range
     std::vector<uint64_t> bmap_off;                // n_genomes+1: first 32-bit word of each genome's bucket-occupancy bitmap
     std::vector<uint64_t> ms_off;                  // n_genomes+1: first word of each genome's seed-list storage
     std::vector<uint32_t> ctg_len;                 // concatenated contig lengths
@@ -132,7 +133,7 @@ struct skh_sketch_set {
     std::vector<float> q10, q50, q90;
     // everything the chaining's pair descriptors take from one genome, gathered once per set (chain.hip genome_halves)
     struct GenomeHalf {
-        const uint32_t *hash, *g, *rep, *ms, *bmap, *goff; const uint64_t* tab; const uint32_t* host_goff;
+        const uint32_t *seed, *g, *rep, *ms, *bmap, *goff; const uint64_t* tab; const uint32_t* host_goff; uint32_t salt;
         const uint64_t *g64, *goff64, *host_goff64;       // a wide genome (else null)
         uint32_t n_pos, pos0, nbk, nctg, chunk_bound; uint64_t total_len; float q10, q50, q90;
         double score_markers, score_len;                  // switch_qr's two candidate scores (chain.rs:625-649)
@@ -144,7 +145,6 @@ struct skh_sketch_set {
     skh::DBuf<uint32_t> p_seed, p_g;               // position order (contig, pos); p_g = padded coordinate << 1 | canonical (wide genomes: index in the genome << 1 | canonical)
     skh::DBuf<uint64_t> p_g64;                     // wide sets: padded coordinate << 1 | canonical, all genomes
     skh::DBuf<uint32_t> p_rep;                     // 1 bit per position (set-wide position index): its seed occurs more than 2500 / c times in its genome (chain.rs:674-676)
-    skh::DBuf<uint32_t> p_hash;                    // mix32(p_seed): what the join enumerates and probes with
     // seed table (probe side), common.h: per genome n_buckets home slots in slices of TAB_SLICE, each followed by TAB_SLACK overflow slots;
     // slot = mix32(seed) << 32 | position (single seeds) / list reference / "repetitive"; TAB_EMPTY = free
     skh::DBuf<uint64_t> tab;                       // tab_off[g] .. (sketch_build.hip build_tables_kernel)
@@ -226,7 +226,7 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
                     uint32_t n_contigs, int on_device, DevEvent* copied);
 void genomes_finish(skh_ctx* ctx, skh_genome_set* gs);
 struct SeedOutput {   // position-ordered raw seeding output for a whole genome set
-    DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> markers_raw; // hash = mix32(seed); g = padded coordinate << 1 | canonical (common.h CTG_PAD)
+    DBuf<uint32_t> seed, g; DBuf<uint64_t> markers_raw;       // g = padded coordinate << 1 | canonical (common.h CTG_PAD)
     DBuf<uint64_t> g64; bool wide = false;                    // a set with a genome beyond 31-bit coordinates: also g64 = the coordinates in 64 bits (g: their low words)
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
     bool tail_pending = false;               // the last kernel writing these arrays is still queued on the context's stream

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                                                            const uint64_t* __restrict__ t_marker, const uint32_t* __restrict__ o_seed2,
                                                            const uint16_t* __restrict__ o_loc2, const uint64_t* __restrict__ o_marker2,
                                                            const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
-                                                           uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_hash, uint32_t* __restrict__ o_g,
+                                                           uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_g,
                                                            uint64_t* __restrict__ o_g64, uint64_t* __restrict__ o_marker) {
     const uint32_t lt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
         for (int u = 0; u < 4; u++) {
             const uint32_t x = x0 + 64u * (uint32_t)u + ln;
             if (x < ns) {
-                o_seed[s0 + x] = sd[u]; o_hash[s0 + x] = mix32(sd[u]);              // the table hash the sketch build and the join work with
+                o_seed[s0 + x] = sd[u];
                 const uint32_t pos = pos0 + (loc[u] & 0x1FFFu);                         // pos = index of the window's last base
                 if (WIDE) o_g64[s0 + x] = ((goff64 + pos) << 1) | (loc[u] >> 15);
                 o_g[s0 + x] = ((goff + pos) << 1) | (loc[u] >> 15);                     // SeedPosition (types.rs:131-138) in padded coordinates (a wide genome's records are replaced by indices later)
@@ -595,7 +595,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
     const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
-    struct Part { DBuf<uint32_t> seed, hash, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
+    struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
     std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);   // running totals at genome starts
@@ -658,11 +658,11 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
                        o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
         }
-        p.seed.alloc(p.ns); p.hash.alloc(p.ns); p.mk.alloc(p.nm);
+        p.seed.alloc(p.ns); p.mk.alloc(p.nm);
         p.g.alloc(p.ns); if (wide) p.g64.alloc(p.ns);
 #define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2, \
-                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.hash.p, p.g.p, p.g64.p, p.mk.p)
+                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.g.p, p.g64.p, p.mk.p)
         if (wide) SKH_COMPACT(true); else SKH_COMPACT(false);
 #undef SKH_COMPACT
         check_launch("seed_compact_kernel");
@@ -677,13 +677,13 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
     const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
     if (parts.size() == 1) {
-        out.seed = std::move(parts[0].seed); out.hash = std::move(parts[0].hash); out.g = std::move(parts[0].g); out.g64 = std::move(parts[0].g64); out.markers_raw = std::move(parts[0].mk);
+        out.seed = std::move(parts[0].seed); out.g = std::move(parts[0].g); out.g64 = std::move(parts[0].g64); out.markers_raw = std::move(parts[0].mk);
     } else {
-        out.seed.alloc(NS); out.hash.alloc(NS); out.markers_raw.alloc(NM);
+        out.seed.alloc(NS); out.markers_raw.alloc(NM);
         out.g.alloc(NS); if (wide) out.g64.alloc(NS);
         uint64_t so = 0, mo = 0;
         for (auto& p : parts) {
-            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream); d2d(out.hash.p + so, p.hash.p, p.ns * 4, ctx->stream);
+            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream);
             d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream); if (wide) d2d(out.g64.p + so, p.g64.p, p.ns * 8, ctx->stream);
             d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
             so += p.ns; mo += p.nm;

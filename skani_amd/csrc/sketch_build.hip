@@ -2,12 +2,14 @@
 //
 // Replaces the per-sketch HashMap<u32,u64> + multi_position_storage of types.rs:207-320 and the marker HashSet
 // (types.rs:272) with, per genome:
-//   position order : p_seed / p_hash (= mix32(seed), a bijection: equal hash <=> equal seed) / p_g, + p_rep = 1 bit per position: its seed occurs
+//   position order : p_seed / p_g, + p_rep = 1 bit per position: its seed occurs
 //                    more than index_chain_band times in this genome -- the enumeration side of the join
 //                    p_g = padded genome coordinate << 1 | canonical (common.h CTG_PAD): 4 bytes instead of (pos, contig|strand)
 //   seed table     : open addressing over n_buckets = 2 x positions home slots, slot = hash << 32 | position (seeds that occur once: 95 %) or
 //                    | a reference into the genome's list storage `ms` (count, positions ascending) -- the probe side: ONE memory request per hit.
 //                    Built slice by slice in LDS (build_tables_kernel): no sort, no global scatter.  + 1 bit per home slot: occupied.
+//                    hash = mix32(seed ^ salt) (common.h table_hash: a bijection, equal hash <=> equal seed) with the genome's salt, 0 unless its seeds
+//                    crowded a stretch of the hash range (a slice's slack slots overflow): such a genome is indexed again under the next salt.
 //   markers        : sorted unique u64
 #include <algorithm>
 
@@ -78,11 +80,6 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* src, co
 constexpr uint32_t BUILD_THREADS = 1024;
 constexpr uint32_t SLOT_PENDING = 0xFFFFFFFEu;          // pass B -> pass C: single seed whose position is still to be filled in
 
-__global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restrict__ p_seed, uint64_t n, uint32_t* __restrict__ p_hash) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p_hash[i] = mix32(p_seed[i]);
-}
-
 // The positions of a genome, dealt to the slices their seeds' home slots fall into: (position index, hash) slice by slice, in the genome's stretch
 // of p_slice (order within a slice: whatever the LDS atomics make it).  A slice's workgroup then reads its own ~2,000 positions instead of
 // testing all ~40,000 of the genome (that test was a third of build_tables_kernel's instructions).  One workgroup per genome, two passes over the
@@ -94,15 +91,18 @@ __global__ __launch_bounds__(256) void hash_seeds_kernel(const uint32_t* __restr
 // max_slices a genome's slices re-scan all its positions (mark_beyond; 3.9 s for a 2.3 Gbp pair before the second instantiation existed).
 constexpr uint32_t SLICE_LDS_MAX = 8192, SLICE_LDS_BIG = 32768;
 constexpr uint32_t SLICE_NO_LIST = 0xFFFFFFFFu;
+constexpr uint32_t BUILD_SKIP = 0xFFFFFFFFu;            // queue_pos of a genome that is not part of the build
 template <uint32_t SLICES>
-__global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_hash, const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
+__global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_seed, const uint32_t* __restrict__ salts, const uint32_t* __restrict__ queue_pos,
+                                                                      const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
                                                                       const uint32_t* __restrict__ slice_first, uint32_t min_slices, uint32_t max_slices, uint32_t mark_beyond,
                                                                       uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice) {
     SKH_DYN_SMEM(smem);
     uint32_t* cnt = (uint32_t*)smem;                                                 // SLICES counters
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
     const uint32_t g = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
-    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
+    if (queue_pos[g] == BUILD_SKIP) return;                                          // not part of this build (a rebuild of the genomes that overflowed)
+    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g], salt = salts[g];
     const uint32_t n_sl = (NB + TAB_SLICE - 1) / TAB_SLICE, s0 = slice_first[g];
     if (n_sl <= min_slices) return;                                                  // an earlier launch's genome
     if (n_sl > max_slices) {                                                         // (max_slices <= SLICES)
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
     for (uint32_t i0 = tid; i0 < P; i0 += 4 * BUILD_THREADS) {
         uint32_t hh[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? p_seed[pos0 + i] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (i0 + u * BUILD_THREADS < P) atomicAdd(&cnt[seed_bucket(hh[u], NB) >> TAB_SLICE_SHIFT], 1u);
+        for (uint32_t u = 0; u < 4; u++) if (i0 + u * BUILD_THREADS < P) atomicAdd(&cnt[seed_bucket(table_hash(hh[u], salt), NB) >> TAB_SLICE_SHIFT], 1u);
     }
     __syncthreads();
     constexpr uint32_t PER_MAX = SLICES / BUILD_THREADS;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
     for (uint32_t i0 = tid; i0 < P; i0 += 4 * BUILD_THREADS) {
         uint32_t hh[4], oo[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? p_hash[pos0 + i] : 0u; }
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t i = i0 + u * BUILD_THREADS; hh[u] = i < P ? table_hash(p_seed[pos0 + i], salt) : 0u; }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) oo[u] = i0 + u * BUILD_THREADS < P ? atomicAdd(&cnt[seed_bucket(hh[u], NB) >> TAB_SLICE_SHIFT], 1u) : 0u;
 #pragma unroll
@@ -156,15 +156,16 @@ __global__ __launch_bounds__(256) void table_blocks_kernel(uint32_t ng, const ui
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ng) return;
     const uint32_t n_sl = slice_first[g + 1] - slice_first[g], k0 = queue_pos[g], x = g & 7u;
+    if (k0 == BUILD_SKIP) return;
     for (uint32_t s = 0; s < n_sl; s++) blk[(size_t)(k0 + s) * 8 + x] = make_uint2(g, s);
 }
 
 __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2* __restrict__ blk, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ sl_start,
-                                                            const uint32_t* __restrict__ sl_cnt, const uint2* __restrict__ p_slice, const uint32_t* __restrict__ p_hash, const uint32_t* __restrict__ p_g,
+                                                            const uint32_t* __restrict__ sl_cnt, const uint2* __restrict__ p_slice, const uint32_t* __restrict__ p_seed, const uint32_t* __restrict__ salts, const uint32_t* __restrict__ p_g,
                                                             const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets, const uint64_t* __restrict__ tab_off,
                                                             const uint64_t* __restrict__ bmap_off, const uint64_t* __restrict__ ms_off, uint32_t band, uint32_t match_cap, uint32_t stage_cap,
                                                             uint64_t* __restrict__ tab, uint32_t* __restrict__ bmap, uint32_t* ms, uint32_t* ms_used, uint32_t* n_distinct,
-                                                            uint32_t* p_rep, uint32_t* err) {
+                                                            uint32_t* p_rep, uint32_t* err_g) {
     SKH_DYN_SMEM(smem);
     unsigned long long* slots = (unsigned long long*)smem;                          // TAB_SLICE + TAB_SLACK
     uint32_t* lbm = (uint32_t*)(smem + (size_t)(TAB_SLICE + TAB_SLACK) * 8);          // the slice's filter words (common.h): TAB_SLICE / TAB_FILTER_HOMES
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
     const uint2 gs = blk[blockIdx.x];
     if (gs.x == 0xFFFFFFFFu) return;
     const uint32_t g = gs.x, sl = gs.y, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
-    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g];
+    const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g], salt = salts[g];
+    uint32_t* const err = err_g + g;                                                 // per genome: it is indexed again under another salt (build_sketch_tables_finish)
     const uint32_t h0 = sl * TAB_SLICE, nh = (NB - h0 < TAB_SLICE ? NB - h0 : TAB_SLICE), phys = nh + TAB_SLACK;   // home slots / physical slots of this slice
     const uint64_t ms0 = ms_off[g]; const uint32_t ms_cap = (uint32_t)(ms_off[g + 1] - ms0);
     for (uint32_t a = tid; a < phys; a += TABLE_THREADS) slots[a] = TAB_EMPTY;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
     for (uint32_t u = 0; u < n_round; u++) {
         const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * TABLE_THREADS + tid;
         if (i >= P) continue;
-        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], home = seed_bucket(h, NB);
+        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : table_hash(p_seed[pos0 + i], salt), home = seed_bucket(h, NB);
         if (home - h0 >= nh) continue;
         uint32_t a = home - h0;
         for (;;) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
                 if (cur == TAB_EMPTY) { atomicOr(&lbm[(home - h0) >> TAB_FILTER_SHIFT], tab_filter_bits(h)); break; }
             }
             if ((uint32_t)(cur >> 32) == h) { atomicAdd(&slots[a], 1ull); break; }
-            if (++a + 1 >= phys) { atomicAdd(err, 1u); break; }                      // more than TAB_SLACK entries pushed past the slice's end (its last slot stays empty: it ends every walk)
+            if (++a + 1 >= phys) { atomicOr(err, 1u); break; }                      // more than TAB_SLACK entries pushed past the slice's end (its last slot stays empty: it ends every walk)
         }
     }
     __syncthreads();
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
     const uint32_t base = ms_base;
     uint32_t off = base + before + incl - need;
     const bool ms_ok = base + tot <= ms_cap && base + tot < TAB_OFF_MASK - 8;
-    if (!ms_ok && tid == 0) atomicAdd(err, 1u);
+    if (!ms_ok && tid == 0) atomicOr(err, 2u);                                       // (bit 1: the list storage's bounds -- not a matter of the salt)
     // the lists of this slice are filled and ordered in LDS and copied out whole; only a slice with more list words than that space fills them in memory
     uint32_t* stage = mlist;
     const bool staged = tot <= stage_cap;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
     for (uint32_t u = 0; u < n_round; u++) {
         const uint32_t i = dense ? own[u < MAX_OWN ? u : 0] : u * TABLE_THREADS + tid;
         if (i >= P) continue;
-        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : p_hash[pos0 + i], pg = p_g[pos0 + i];
+        const uint32_t h = dense ? own_h[u < MAX_OWN ? u : 0] : table_hash(p_seed[pos0 + i], salt), pg = p_g[pos0 + i];
         uint32_t a = seed_bucket(h, NB) - h0;
         if (a >= nh) continue;
         unsigned long long v = slots[a];
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void build_tables_kernel(const uint2
             else {                                                                    // a position beyond 2^31 does not fit beside the flag bit: list of one
                 const uint32_t o = atomicAdd(&ms_used[g], 2u);
                 if (o + 2 <= ms_cap && o + 2 < TAB_OFF_MASK - 8) { ms[ms0 + o] = 1; ms[ms0 + o + 1] = pg; slots[a] = ((unsigned long long)h << 32) | TAB_LISTED | o; }
-                else { atomicAdd(err, 1u); slots[a] = ((unsigned long long)h << 32) | TAB_REPETITIVE; }
+                else { atomicOr(err, 2u); slots[a] = ((unsigned long long)h << 32) | TAB_REPETITIVE; }
             }
         } else if (x & TAB_LISTED) {
             const uint32_t o = x & TAB_OFF_MASK;
@@ -369,6 +371,67 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
     build_sketch_tables_finish(ctx, ss, tb);
 }
 
+// The kernels of a table build over the genomes listed in `only` (null: all), queued on the context's stream; returns the device counters the build
+// fills: per genome an error word, the number of distinct seeds and the list words used.  The tables, their geometry and the position records exist.
+static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::vector<uint32_t>* only) {
+    const uint32_t ng = ss->n_genomes;
+    const uint64_t P = ss->pos_off[ng];
+    if (!ng) return nullptr;
+    std::vector<uint32_t> slice_first(ng + 1, 0);                                   // (genome, slice) -> index of the slice's position list
+    std::vector<uint32_t> queue_pos(ng + 1, BUILD_SKIP); uint32_t queue_len[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (genome, slice) pairs are dealt to eight queues by genome (table_blocks_kernel)
+    for (uint32_t g = 0; g < ng; g++) slice_first[g + 1] = slice_first[g] + (ss->n_buckets[g] + TAB_SLICE - 1) / TAB_SLICE;
+    auto enqueue = [&](uint32_t g) { queue_pos[g] = queue_len[g & 7u]; queue_len[g & 7u] += slice_first[g + 1] - slice_first[g]; };
+    if (only) for (uint32_t g : *only) enqueue(g); else for (uint32_t g = 0; g < ng; g++) enqueue(g);
+    size_t n_blk = 0; for (uint32_t x = 0; x < 8; x++) n_blk = std::max<size_t>(n_blk, queue_len[x]);
+    n_blk *= 8;
+    // the build's small tables in ONE upload (each copy in front of the first kernel is a 5 us blit plus its launch):
+    // tab_off, bmap_off, ms_off (u64 x ng+1) | slice_first, queue_pos (u32 x ng+1) | n_buckets, salt (u32 x ng) | the zeroed counters read back at the end
+    const size_t n_back = 3 * (size_t)ng;
+    const size_t n64 = 3 * ((size_t)ng + 1), n32 = 2 * ((size_t)ng + 1) + 2 * (size_t)ng + n_back;
+    std::vector<uint64_t> pack(n64 + (n32 + 1) / 2, 0);
+    uint64_t* h64 = pack.data(); uint32_t* h32 = (uint32_t*)(pack.data() + n64);
+    memcpy(h64, ss->tab_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + ng + 1, ss->bmap_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + 2 * ((size_t)ng + 1), ss->ms_off.data(), ((size_t)ng + 1) * 8);
+    memcpy(h32, slice_first.data(), ((size_t)ng + 1) * 4); memcpy(h32 + ng + 1, queue_pos.data(), ((size_t)ng + 1) * 4); memcpy(h32 + 2 * ((size_t)ng + 1), ss->n_buckets.data(), (size_t)ng * 4);
+    memcpy(h32 + 2 * ((size_t)ng + 1) + ng, ss->salt.data(), (size_t)ng * 4);
+    uint64_t* d_pack = ctx->arena.get<uint64_t>(pack.size()); h2d(d_pack, pack.data(), pack.size() * 8, ctx->stream);
+    uint64_t* d_to = d_pack; uint64_t* d_bo = d_pack + ng + 1; uint64_t* d_mo = d_pack + 2 * ((size_t)ng + 1);
+    uint32_t* d32 = (uint32_t*)(d_pack + n64);
+    uint32_t* d_sf = d32; uint32_t* d_qp = d32 + ng + 1; uint32_t* d_nb = d32 + 2 * ((size_t)ng + 1); uint32_t* d_salt = d_nb + ng; uint32_t* d_back = d_salt + ng;
+    uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
+    // LDS per workgroup: the slice (17 KB) + its filter words + stage_cap words in which the slice's seed lists are assembled: 22 KB, seven workgroups
+    // of 256 threads per CU.  A slice takes up to match_cap positions from its list (registers); slices with more re-scan the genome.
+    const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
+    const uint32_t stage_cap = ctx->tune.build_match_cap ? match_cap : 1024;       // list words of a slice assembled in LDS (~150 expected: 5 % of its ~2,000 positions are listed)
+    uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
+    uint2* d_ps = ctx->arena.get<uint2>(P + 1);
+    // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
+    SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
+    check_launch("table_blocks");
+    {
+        const uint32_t max_a = ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX;
+        uint32_t most = 0; for (uint32_t g = 0; g < ng; g++) most = std::max(most, slice_first[g + 1] - slice_first[g]);
+        const bool second = !ctx->tune.build_slice_max && most > SLICE_LDS_MAX;   // a genome beyond 8M positions: the instantiation with 128 KB of counters takes it
+        SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_MAX>, ng, BUILD_THREADS, SLICE_LDS_MAX * 4, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)d_qp,
+                   (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, 0u, max_a, second ? 0u : 1u, d_ss, d_sc, d_ps);
+        if (second) {
+            kernel_allow_lds(slice_positions_kernel<SLICE_LDS_BIG>, SLICE_LDS_BIG * 4);
+            SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_BIG>, ng, BUILD_THREADS, SLICE_LDS_BIG * 4, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)d_qp,
+                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, SLICE_LDS_MAX, SLICE_LDS_BIG, 1u, d_ss, d_sc, d_ps);
+        }
+    }
+    check_launch("slice_positions");
+    if (n_blk) {
+        const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
+        kernel_allow_lds(build_tables_kernel, lds);
+        SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
+                   (const uint2*)d_ps, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)ss->p_g.p,
+                   (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
+                   BP_CHAIN_BAND / ss->params.c, match_cap, stage_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 2 * (size_t)ng, d_back + ng, ss->p_rep.p, d_back);
+        check_launch("build_tables");
+    }
+    return d_back;
+}
+
 // queues the whole table build on the context's stream and returns without waiting; _finish reads the counts back
 TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
     const uint32_t ng = ss->n_genomes;
@@ -377,16 +440,15 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     // table geometry from the position counts alone (two home slots per POSITION, at least as many as per distinct seed): nothing has to come back
     // from the device before the tables are allocated
     ss->dist_off.assign(ng + 1, 0); ss->tab_off.assign(ng + 1, 0); ss->n_buckets.assign(ng, 0); ss->bmap_off.assign(ng + 1, 0); ss->ms_off.assign(ng + 1, 0);
-    std::vector<uint32_t> slice_first(ng + 1, 0);                                   // (genome, slice) -> index of the slice's position list
-    std::vector<uint32_t> queue_pos(ng + 1, 0); uint32_t queue_len[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (genome, slice) pairs are dealt to eight queues by genome (table_blocks_kernel)
+    ss->salt.assign(ng, 0);
+    uint64_t n_slices = 0;
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
         if (pg >= (1ull << 30)) throw Error("a genome with >= 2^30 seed positions does not fit the seed table's 32-bit slot fields");
         const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
         const uint32_t n_sl = (nb + TAB_SLICE - 1) / TAB_SLICE;
         ss->n_buckets[g] = nb;
-        if ((uint64_t)slice_first[g] + n_sl >= 0xFFFFFFF0ull) throw Error("too many table slices in one build; split the batch");
-        slice_first[g + 1] = slice_first[g] + n_sl;
+        if ((n_slices += n_sl) >= 0xFFFFFFF0ull) throw Error("too many table slices in one build; split the batch");
         ss->tab_off[g + 1] = ss->tab_off[g] + nb + (uint64_t)n_sl * TAB_SLACK;
         ss->bmap_off[g + 1] = ss->bmap_off[g] + (((uint64_t)n_sl * TAB_SLICE / TAB_FILTER_HOMES) + 3) / 4 * 4;     // whole slices, whole 16-byte groups
         // list storage: a seed with 2 .. band positions takes one word more than it has positions (<= 1.5 words per position); genomes whose padded
@@ -394,10 +456,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         const uint64_t span = (ss->wide && ss->wide_g[g]) ? 0 : ss->goff[ss->ctg_off[g + 1] + g];   // (a wide genome's records are indices below 2^30)
         ss->ms_off[g + 1] = ss->ms_off[g] + (span >= (1ull << 30) ? 2 * pg : pg + pg / 2) + 16;
         if (ss->ms_off[g + 1] - ss->ms_off[g] >= 0x7FFFFFF0ull) throw Error("a genome's seed-list storage passes 2^31 words");
-        queue_pos[g] = queue_len[g & 7u]; queue_len[g & 7u] += n_sl;
     }
-    size_t n_blk = 0; for (uint32_t x = 0; x < 8; x++) n_blk = std::max<size_t>(n_blk, queue_len[x]);
-    n_blk *= 8;
     if (P >= 0xFFFFFFF0ull) throw Error("sketch set too large for one build (>= 2^32 seed positions); split the batch");
     ss->tab.alloc(ss->tab_off[ng] + 8);                                              // (slack behind the last table)
     ss->bmap.alloc(ss->bmap_off[ng] ? ss->bmap_off[ng] : 1); ss->ms.alloc(ss->ms_off[ng] ? ss->ms_off[ng] : 1);
@@ -421,71 +480,33 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
         check_launch("index_positions");
     }
     ss->indexed = true;
-    if (ss->p_hash.n != P || !P) {                                                   // (the seeding path delivers the hashes with the seeds)
-        ss->p_hash.alloc(P ? P : 1);
-    if (P) {
-        SKH_LAUNCH(hash_seeds_kernel, (unsigned)((P + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)ss->p_seed.p, P, ss->p_hash.p);
-        check_launch("hash_seeds");
-    }
-    }
-    TableBuild tb; tb.n = 2 * (size_t)ng + 1;                                        // err, distinct seeds per genome, list words used per genome
-    if (ng) {
-        // the build's small tables in ONE upload (each copy in front of the first kernel is a 5 us blit plus its launch):
-        // tab_off, bmap_off, ms_off (u64 x ng+1) | slice_first, queue_pos (u32 x ng+1) | n_buckets (u32 x ng) | the zeroed counters read back at the end
-        const size_t n64 = 3 * ((size_t)ng + 1), n32 = 2 * ((size_t)ng + 1) + ng + tb.n;
-        std::vector<uint64_t> pack(n64 + (n32 + 1) / 2, 0);
-        uint64_t* h64 = pack.data(); uint32_t* h32 = (uint32_t*)(pack.data() + n64);
-        memcpy(h64, ss->tab_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + ng + 1, ss->bmap_off.data(), ((size_t)ng + 1) * 8); memcpy(h64 + 2 * ((size_t)ng + 1), ss->ms_off.data(), ((size_t)ng + 1) * 8);
-        memcpy(h32, slice_first.data(), ((size_t)ng + 1) * 4); memcpy(h32 + ng + 1, queue_pos.data(), ((size_t)ng + 1) * 4); memcpy(h32 + 2 * ((size_t)ng + 1), ss->n_buckets.data(), (size_t)ng * 4);
-        uint64_t* d_pack = ctx->arena.get<uint64_t>(pack.size()); h2d(d_pack, pack.data(), pack.size() * 8, ctx->stream);
-        uint64_t* d_to = d_pack; uint64_t* d_bo = d_pack + ng + 1; uint64_t* d_mo = d_pack + 2 * ((size_t)ng + 1);
-        uint32_t* d32 = (uint32_t*)(d_pack + n64);
-        uint32_t* d_sf = d32; uint32_t* d_qp = d32 + ng + 1; uint32_t* d_nb = d32 + 2 * ((size_t)ng + 1); uint32_t* d_back = d_nb + ng;
-        tb.d_back = d_back;
-        uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
-        // LDS per workgroup: the slice (17 KB) + its filter words + stage_cap words in which the slice's seed lists are assembled: 22 KB, seven workgroups
-        // of 256 threads per CU.  A slice takes up to match_cap positions from its list (registers); slices with more re-scan the genome.
-        const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
-        const uint32_t stage_cap = ctx->tune.build_match_cap ? match_cap : 1024;       // list words of a slice assembled in LDS (~150 expected: 5 % of its ~2,000 positions are listed)
-        uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
-        uint2* d_ps = ctx->arena.get<uint2>(P + 1);
-        // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
-        SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
-        check_launch("table_blocks");
-        {
-            const uint32_t max_a = ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX;
-            uint32_t most = 0; for (uint32_t g = 0; g < ng; g++) most = std::max(most, slice_first[g + 1] - slice_first[g]);
-            const bool second = !ctx->tune.build_slice_max && most > SLICE_LDS_MAX;   // a genome beyond 8M positions: the instantiation with 128 KB of counters takes it
-            SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_MAX>, ng, BUILD_THREADS, SLICE_LDS_MAX * 4, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
-                       (const uint32_t*)d_nb, (const uint32_t*)d_sf, 0u, max_a, second ? 0u : 1u, d_ss, d_sc, d_ps);
-            if (second) {
-                kernel_allow_lds(slice_positions_kernel<SLICE_LDS_BIG>, SLICE_LDS_BIG * 4);
-                SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_BIG>, ng, BUILD_THREADS, SLICE_LDS_BIG * 4, ctx->stream, (const uint32_t*)ss->p_hash.p, (const uint64_t*)ss->d_pos_off.p,
-                           (const uint32_t*)d_nb, (const uint32_t*)d_sf, SLICE_LDS_MAX, SLICE_LDS_BIG, 1u, d_ss, d_sc, d_ps);
-            }
-        }
-        check_launch("slice_positions");
-        if (n_blk) {
-            const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
-            kernel_allow_lds(build_tables_kernel, lds);
-            SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
-                       (const uint2*)d_ps, (const uint32_t*)ss->p_hash.p, (const uint32_t*)ss->p_g.p,
-                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
-                       BP_CHAIN_BAND / ss->params.c, match_cap, stage_cap, ss->tab.p, ss->bmap.p, ss->ms.p, d_back + 1 + ng, d_back + 1, ss->p_rep.p, d_back);
-            check_launch("build_tables");
-        }
-    }
+    TableBuild tb; tb.n = 3 * (size_t)ng;                                            // per genome: error bits, distinct seeds, list words used
+    tb.d_back = queue_table_build(ctx, ss, nullptr);
     tr.mark("build: seed tables queued");
     return tb;
 }
 
+// Reads the build's counters back (synchronises).  A genome whose seeds crowded one stretch of the hash range (more than TAB_SLACK entries pushed past the
+// end of a slice) is indexed again under the next salt -- the reference's HashMap takes any key set (types.rs:281-320) -- by a build over those genomes only.
 void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb) {
     const uint32_t ng = ss->n_genomes;
-    std::vector<uint32_t> back(tb.n, 0);
+    std::vector<uint32_t> back(tb.n, 0), distinct(ng, 0), again;
     if (tb.d_back) d2h(back.data(), tb.d_back, tb.n * 4, ctx->stream);               // the build's one read-back (synchronises)
     else dsync(ctx->stream);
-    for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + back[1 + g];
-    if (back[0]) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range");
+    for (uint32_t attempt = 0;; attempt++) {
+        again.clear();
+        for (uint32_t g = 0; g < ng; g++) {
+            if (back[g] & 2u) throw Error("seed table: a genome's seed lists do not fit their storage");
+            if (back[g] & 1u) again.push_back(g); else if (attempt == 0 || ss->salt[g] == attempt) distinct[g] = back[ng + g];
+        }
+        if (again.empty()) break;
+        if (attempt >= 15) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range under every salt tried");
+        for (uint32_t g : again) ss->salt[g] = attempt + 1;
+        uint32_t* d_back = queue_table_build(ctx, ss, &again);
+        std::fill(back.begin(), back.end(), 0u);
+        d2h(back.data(), d_back, tb.n * 4, ctx->stream);
+    }
+    for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + distinct[g];
     ss->tables_built = true;
 }
 

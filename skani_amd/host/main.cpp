@@ -223,7 +223,7 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
                     if (!parse_fasta_plain(files[i], slot[x] + off_in[i], (size_t)fsize[i] + 16, 500, &wrote, names, clens[i], per_file)) { { std::lock_guard<std::mutex> lk(slot_mu); fallback = true; } slot_cv.notify_all(); }
                     else if (names.empty()) state[i] = 2;
                     else { state[i] = 1; GenomeInfo& gi = per[i]; gi.file_name = files[i]; gi.contigs = std::move(names); for (uint64_t l : clens[i]) gi.contig_lengths.push_back((uint32_t)l); }
-                } catch (const std::exception&) { state[i] = 3; }                 // (a file that cannot be read: the other way of reading reports and skips it, see below)
+                } catch (const std::exception& e) { state[i] = 3; fprintf(stderr, "WARN %s; skipping.\n", e.what()); }
             }
             if (B.remaining.fetch_sub(1) != 1) continue;
             // this thread completed the buffer: hand it over, wait for its copy, free the slot for the buffer after next
@@ -253,10 +253,6 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
         const int nt = std::max(1, std::min<int>(a.threads, (int)nf));
         std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(worker); for (auto& t : th) t.join();
     }
-    // A file without a kept contig (or an unreadable one) would stay in the set as an EMPTY genome under its number in the file list -- which the marker
-    // screen's small-genome rescue pairs with every other genome (screen.rs:84-142).  The reference never makes a sketch for such a file (file_io.rs:176-214);
-    // they are rare, so the collection is read the other way, which numbers only the kept files (and prints the warnings).
-    for (uint32_t i = 0; i < nf && !fallback; i++) if (state[i] != 1) fallback = true;
     if (fallback) {
         (void)skh_genomes_finish(gs);                                              // drains the queued copies before the buffers go away
         skh_genomes_destroy(gs);
@@ -269,7 +265,11 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
     g_clock.mark("parse_upload_pack");
     out.kept_index.assign(nf, ~0u);
     for (uint32_t i = 0; i < nf; i++) {
-        out.kept_index[i] = (uint32_t)out.info.size(); out.info.push_back(std::move(per[i]));   // (every file was kept, or the collection went the other way above)
+        // (a file without a kept contig stays in the set as a genome WITHOUT CONTIGS under its number in the file list: the screen's small-genome rescue
+        // pairs it with every later genome, each such pair is chained as an empty one -- no join tiles, ani 0, dropped from the output -- and is counted in
+        // the driver's "chained" statistic; the reference makes no sketch for such a file, file_io.rs:176-214.  Rare, and cheaper than a second numbering.)
+        if (state[i] == 1) { out.kept_index[i] = (uint32_t)out.info.size(); out.info.push_back(std::move(per[i])); }
+        else if (state[i] == 2) fprintf(stderr, "WARN File %s consists of only contigs < 500 bp. Skipping this file.\n", files[i].c_str());
     }
     skh_sketch_params sp{a.c, a.k, a.m, (uint32_t)a.seeding_mode};
     cx.check(skh_sketch_genomes(cx.c, gs, &sp, nullptr, &out.ss), "skh_sketch_genomes");   // genome_rank = number in the sorted file list
