@@ -96,7 +96,7 @@ template <uint32_t SLICES>
 __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* __restrict__ p_seed, const uint32_t* __restrict__ salts, const uint32_t* __restrict__ queue_pos,
                                                                       const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ n_buckets,
                                                                       const uint32_t* __restrict__ slice_first, uint32_t min_slices, uint32_t max_slices, uint32_t mark_beyond,
-                                                                      uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice) {
+                                                                      uint32_t* __restrict__ sl_start, uint32_t* __restrict__ sl_cnt, uint2* __restrict__ p_slice, uint32_t* __restrict__ p_rep_clear) {
     SKH_DYN_SMEM(smem);
     uint32_t* cnt = (uint32_t*)smem;                                                 // SLICES counters
     __shared__ uint32_t lds_scan[BUILD_THREADS / 64];
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(1024) void slice_positions_kernel(const uint32_t* _
     if (queue_pos[g] == BUILD_SKIP) return;                                          // not part of this build (a rebuild of the genomes that overflowed)
     const uint64_t pos0 = pos_off[g]; const uint32_t P = (uint32_t)(pos_off[g + 1] - pos0), NB = n_buckets[g], salt = salts[g];
     const uint32_t n_sl = (NB + TAB_SLICE - 1) / TAB_SLICE, s0 = slice_first[g];
+    // the 'repetitive' bits (set by the table build behind this kernel) start at zero: every genome clears the words whose first bit is one of its positions
+    // (full builds, first launch; a rebuild of single genomes leaves the bits alone: they do not depend on the salt)
+    if (p_rep_clear && min_slices == 0) for (uint64_t w = (pos0 + 31) / 32 + tid; w * 32 < pos0 + P; w += BUILD_THREADS) p_rep_clear[w] = 0;
     if (n_sl <= min_slices) return;                                                  // an earlier launch's genome
     if (n_sl > max_slices) {                                                         // (max_slices <= SLICES)
         if (mark_beyond) for (uint32_t s = tid; s < n_sl; s += BUILD_THREADS) { sl_start[s0 + s] = 0; sl_cnt[s0 + s] = SLICE_NO_LIST; }
@@ -152,8 +155,11 @@ constexpr uint32_t TABLE_MATCH_MAX = 2048;              // positions of a slice 
 // The build's workgroup list: (genome, slice) pairs dealt to eight queues by genome -- the slices of a genome run on one XCD and share its seed
 // arrays through that L2 -- written by the device from two small per-genome tables (as a host array it was a 320 KB upload read over PCIe: 0.15 ms
 // in front of the build).  Entry k * 8 + x = the k-th (genome, slice) of queue x; unused entries keep genome = 0xFFFFFFFF.
-__global__ __launch_bounds__(256) void table_blocks_kernel(uint32_t ng, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ queue_pos, uint2* __restrict__ blk) {
+struct QueueLens { uint32_t len[8], longest; };         // entries of each queue, and of the longest: the list has 8 x longest entries
+__global__ __launch_bounds__(256) void table_blocks_kernel(uint32_t ng, const uint32_t* __restrict__ slice_first, const uint32_t* __restrict__ queue_pos, QueueLens ql, uint2* __restrict__ blk) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && (threadIdx.x >> 5) < 8u)                                  // the unused tail of every queue (no fill of the whole list beforehand: one launch less in front of the build)
+        for (uint32_t k = ql.len[threadIdx.x >> 5] + (threadIdx.x & 31u); k < ql.longest; k += 32u) blk[(size_t)k * 8 + (threadIdx.x >> 5)] = make_uint2(0xFFFFFFFFu, 0u);
     if (g >= ng) return;
     const uint32_t n_sl = slice_first[g + 1] - slice_first[g], k0 = queue_pos[g], x = g & 7u;
     if (k0 == BUILD_SKIP) return;
@@ -397,7 +403,8 @@ static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::
     uint64_t* d_to = d_pack; uint64_t* d_bo = d_pack + ng + 1; uint64_t* d_mo = d_pack + 2 * ((size_t)ng + 1);
     uint32_t* d32 = (uint32_t*)(d_pack + n64);
     uint32_t* d_sf = d32; uint32_t* d_qp = d32 + ng + 1; uint32_t* d_nb = d32 + 2 * ((size_t)ng + 1); uint32_t* d_salt = d_nb + ng; uint32_t* d_back = d_salt + ng;
-    uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1); dfill(d_blk, 0xFF, n_blk * sizeof(uint2), ctx->stream);
+    uint2* d_blk = ctx->arena.get<uint2>(n_blk ? n_blk : 1);
+    QueueLens ql; for (uint32_t x = 0; x < 8; x++) ql.len[x] = queue_len[x]; ql.longest = (uint32_t)(n_blk / 8);
     // LDS per workgroup: the slice (17 KB) + its filter words + stage_cap words in which the slice's seed lists are assembled: 22 KB, seven workgroups
     // of 256 threads per CU.  A slice takes up to match_cap positions from its list (registers); slices with more re-scan the genome.
     const uint32_t match_cap = std::min<uint32_t>(ctx->tune.build_match_cap ? ctx->tune.build_match_cap : TABLE_MATCH_MAX, TABLE_MATCH_MAX);
@@ -405,18 +412,18 @@ static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::
     uint32_t* d_ss = ctx->arena.get<uint32_t>(slice_first[ng] + 1); uint32_t* d_sc = ctx->arena.get<uint32_t>(slice_first[ng] + 1);
     uint2* d_ps = ctx->arena.get<uint2>(P + 1);
     // (kernels after the copies: a host-to-device copy queued behind a kernel took 130 us in the rocpd timeline of a bench step, 5 us behind another copy)
-    SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, d_blk);
+    SKH_LAUNCH(table_blocks_kernel, (ng + 255) / 256, 256, 0, ctx->stream, ng, (const uint32_t*)d_sf, (const uint32_t*)d_qp, ql, d_blk);
     check_launch("table_blocks");
     {
         const uint32_t max_a = ctx->tune.build_slice_max ? std::min<uint32_t>(ctx->tune.build_slice_max, SLICE_LDS_MAX) : SLICE_LDS_MAX;
         uint32_t most = 0; for (uint32_t g = 0; g < ng; g++) most = std::max(most, slice_first[g + 1] - slice_first[g]);
         const bool second = !ctx->tune.build_slice_max && most > SLICE_LDS_MAX;   // a genome beyond 8M positions: the instantiation with 128 KB of counters takes it
         SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_MAX>, ng, BUILD_THREADS, SLICE_LDS_MAX * 4, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)d_qp,
-                   (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, 0u, max_a, second ? 0u : 1u, d_ss, d_sc, d_ps);
+                   (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, 0u, max_a, second ? 0u : 1u, d_ss, d_sc, d_ps, only ? (uint32_t*)nullptr : ss->p_rep.p);
         if (second) {
             kernel_allow_lds(slice_positions_kernel<SLICE_LDS_BIG>, SLICE_LDS_BIG * 4);
             SKH_LAUNCH(slice_positions_kernel<SLICE_LDS_BIG>, ng, BUILD_THREADS, SLICE_LDS_BIG * 4, ctx->stream, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)d_qp,
-                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, SLICE_LDS_MAX, SLICE_LDS_BIG, 1u, d_ss, d_sc, d_ps);
+                       (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint32_t*)d_sf, SLICE_LDS_MAX, SLICE_LDS_BIG, 1u, d_ss, d_sc, d_ps, (uint32_t*)nullptr);
         }
     }
     check_launch("slice_positions");
@@ -464,7 +471,6 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     // (everything above is host work on the position counts: when the seeding's compaction kernel is still running, this is where it is overlapped --
     // the first copy below may wait for the stream)
     upload_set_offsets(ctx, ss);
-    dzero(ss->p_rep.p, (P / 32 + 1) * 4, ctx->stream);
     if (pos || cc || ss->p_g.n != P) { ss->p_g.alloc(P); ss->indexed = false; }
     if (ss->wide && (pos || cc || ss->p_g64.n != P)) ss->p_g64.alloc(P);
     if (P > 0 && pos && cc) {
