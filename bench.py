@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")
+    ap.add_argument("--tables", default="beside-screen", choices=["beside-screen", "at-sketch"], help="one GPU: the seed tables are built inside skh_triangle beside its marker screen "
+                    "(sketches made with SKH_SKETCH_DEFER_TABLES; default) or inside skh_sketch_genomes beside the marker sets (rounds 1-3)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0, host collectives over gloo (RCCL refuses two ranks on one GPU): runs this file's whole "
                     "multi-rank branch on a one-GPU box (tests/test_bench_multirank.py); the number it prints is not a multi-GPU measurement")
     ap.add_argument("--collection", type=int, default=0, help="strong scaling: a fixed collection of this many genomes (10000 = BASELINE config 4) in shuffled order at every "
@@ -525,7 +527,7 @@ def main():
         # genome_rank = global index: the collection's names sort like its indices
         # several GPUs: seed tables deferred -- every rank indexes only the sketches it ends up chaining (its own that stay + the ones it receives)
         t0 = time.perf_counter()
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=genome_rank, defer_tables=comm is not None)
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=genome_rank, defer_tables=comm is not None or args.tables == "beside-screen", screen_index=comm is None)
         t1 = time.perf_counter()
         if comm is None:
             i, j, res, n_chained = ctx.triangle(ss_local, mp)

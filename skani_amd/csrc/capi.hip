@@ -230,7 +230,8 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         if (flags & SKH_SKETCH_DEFER_TABLES) {                                       // markers only; the tables are built where (and if) the sketches are chained
             ss->dist_off.assign(ss->n_genomes + 1, 0);
             upload_set_offsets(ctx, ss);
-            build_markers(ctx, ss, so.markers_raw, so.mk_off);
+            if (flags & SKH_SKETCH_NO_SCREEN_INDEX) build_markers(ctx, ss, so.markers_raw, so.mk_off);
+            else { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }
             dsync(ctx->stream);
             book(); tail_guard.armed = false;
             return;
@@ -444,14 +445,38 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
     int rc = guarded(ctx, [&] {
         StageTrace tr(ctx);
         std::vector<uint32_t> a, b;
-        { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, ss, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b); }
-        ctx->arena.reset();
+        // A set sketched with deferred tables: its seed tables are queued on the main stream NOW, and the screen (marker incidences, count matrix, pair
+        // list read-back) and the host's pair descriptors are made beside them on the second stream -- the screen needs the marker sets only.
+        skh_sketch_set* ssm = const_cast<skh_sketch_set*>(ss);
+        std::unique_lock<std::mutex> build_lock(ssm->build_mu, std::defer_lock);
+        bool overlapped = false; TableBuild tb; DevEvent ev_b0, ev_b1;
+        if (!ss->tables_built) {
+            build_lock.lock();
+            if (!ss->tables_built) { overlapped = true; ev_b0.record(ctx->stream); tb = build_sketch_tables_begin(ctx, ssm, nullptr, nullptr); ev_b1.record(ctx->stream); }
+            else build_lock.unlock();
+        }
+        struct BuildGuard { bool* armed; ~BuildGuard() { if (*armed) device_sync_all(); } } build_guard{&overlapped};   // queued kernels never outlive the arena on an error
+        if (overlapped) {
+            std::swap(ctx->stream, ctx->stream2);
+            try { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, ss, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b); }
+            catch (...) { std::swap(ctx->stream, ctx->stream2); throw; }
+            std::swap(ctx->stream, ctx->stream2);
+        } else {
+            { Stopwatch sw(ctx, &ctx->timings.screen_ms); screen_pairs(ctx, ss, nullptr, identity, SKH_SCREEN_REFS, rescue_small, a, b); }
+            ctx->arena.reset();
+        }
         tr.mark("triangle: screen");
         std::vector<uint32_t> pi, pj;
         for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
         std::vector<skh_ani_result> res(pi.size());
         tr.mark("triangle: pair list");
-        { Stopwatch sw(ctx, &ctx->timings.chain_ms); chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr); }
+        const std::function<void()> finish_tables = [&] {
+            build_sketch_tables_finish(ctx, ssm, tb); overlapped = false;
+            ctx->timings.sketch_build_ms += DevEvent::ms(ev_b0, ev_b1);                // (the build's kernels as the main stream ran them, the screen beside them)
+            build_lock.unlock();
+        };
+        { Stopwatch sw(ctx, &ctx->timings.chain_ms);
+          chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr, false, overlapped ? &finish_tables : nullptr); }
         tr.mark("triangle: chain");
         if (n_chained) *n_chained = pi.size();
         size_t kept = 0;

@@ -385,8 +385,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
 
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs_all, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats, bool tie_by_rank) {
-    if (n_pairs_all == 0) return;
+                 skh_chain_stats* stats, bool tie_by_rank, const std::function<void()>* tables_pending) {
+    if (n_pairs_all == 0) { if (tables_pending) (*tables_pending)(); return; }
     if (n_pairs_all > 0x7FFFFFFFull) throw std::invalid_argument("too many pairs in one call");
     if (n_rsets == 0 || !Rsets[0]) throw std::invalid_argument("no reference sketch set");
     if (n_qsets == 0 || !Qsets[0]) throw std::invalid_argument("no query sketch set");
@@ -396,8 +396,12 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         if (!Rsets[x] || Rsets[x]->params.c != job.c || Rsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
     for (uint32_t x = 0; x < n_qsets; x++)
         if (!Qsets[x] || Qsets[x]->params.c != job.c || Qsets[x]->params.k != job.k) throw std::invalid_argument("ref and query sketches were built with different c/k");
-    for (uint32_t x = 0; x < n_rsets; x++) ensure_tables(ctx, Rsets[x]);            // (sets created with deferred tables)
-    for (uint32_t x = 0; x < n_qsets; x++) ensure_tables(ctx, Qsets[x]);
+    if (!tables_pending) {
+        for (uint32_t x = 0; x < n_rsets; x++) ensure_tables(ctx, Rsets[x]);        // (sets created with deferred tables)
+        for (uint32_t x = 0; x < n_qsets; x++) ensure_tables(ctx, Qsets[x]);
+    }
+    bool pending_done = false;
+    struct PendingGuard { const std::function<void()>* f; bool* done; ~PendingGuard() { if (f && !*done) { try { (*f)(); } catch (...) {} } } } pending_guard{tables_pending, &pending_done};   // never left queued
     job.band = BP_CHAIN_BAND / job.c;                                               // chain.rs:111-112 index_chain_band (ref sketch's c)
     if (mp.learned_ani) {
         job.model = std::abs((int)job.c - 125) < std::abs((int)job.c - 200) ? &ctx->model_c125 : &ctx->model_c200;   // regression.rs:15-22
@@ -478,6 +482,23 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             job.chunk_bound[i] = A.chunk_bound;
         }
         tr.mark("host: pair descriptors");
+        if (tables_pending && !pending_done) {
+            // the tables these descriptors point into were being built meanwhile: wait for them; a genome that had to take another salt (common.h
+            // table_hash; the descriptors carry salt 0) is rare -- then the salts are put in again
+            pending_done = true; (*tables_pending)();
+            bool salted = false;
+            for (uint32_t x = 0; x < n_rsets && !salted; x++) for (uint32_t v : Rsets[x]->salt) if (v) { salted = true; break; }
+            for (uint32_t x = 0; x < n_qsets && !salted; x++) for (uint32_t v : Qsets[x]->salt) if (v) { salted = true; break; }
+            if (salted) {
+                for (uint32_t x = 0; x < n_rsets; x++) { std::lock_guard<std::mutex> lk(Rsets[x]->cache_mu); Rsets[x]->halves.clear(); }
+                for (uint32_t x = 0; x < n_qsets; x++) { std::lock_guard<std::mutex> lk(Qsets[x]->cache_mu); Qsets[x]->halves.clear(); }
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t p = idx ? idx[i] : i;
+                    const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
+                    job.pds[i].b_salt = (job.pds[i].flags & 4u) ? Q->salt[pair_query[p]] : R->salt[pair_ref[p]];   // B = the query when switched
+                }
+            }
+        }
         if (!split) { chain_run<Narrow>(ctx, job, out, stats); break; }
         std::vector<skh_ani_result> part(n); std::vector<skh_chain_stats> part_st(stats ? n : 0);
         if (wide_run) chain_run<Wide>(ctx, job, part.data(), stats ? part_st.data() : nullptr);

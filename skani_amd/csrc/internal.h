@@ -1,6 +1,7 @@
 // internal.h -- host-side declarations shared by the translation units of libskani_hip.so.
 #pragma once
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -159,6 +160,7 @@ struct skh_sketch_set {
     // contexts share the set.
     mutable skh::DBuf<uint64_t> screen_keys;
     mutable std::mutex cache_mu;
+    mutable std::mutex build_mu;                   // the (one-time) build of deferred seed tables: ensure_tables / skh_triangle's build beside its screen
     bool tables_built = false;                     // seed tables / filter / list storage exist (skh_sketch_genomes_ex may defer them: a rank of a distributed
                                                    // triangle indexes only the sketches it ends up chaining; ensure_tables builds them on first use)
     skh::DBuf<uint64_t> d_pos_off, d_dist_off, d_mk_off, d_ctg_off;
@@ -264,6 +266,8 @@ void comm_selftest(skh_ctx* ctx, Transport& T);
 // chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
-                 skh_chain_stats* stats, bool tie_by_rank = false);   // tie_by_rank: switch_qr's tie (chain.rs:20-22) goes by genome_rank even when both sets carry file names
+                 skh_chain_stats* stats, bool tie_by_rank = false,   // tie_by_rank: switch_qr's tie (chain.rs:20-22) goes by genome_rank even when both sets carry file names
+                 const std::function<void()>* tables_pending = nullptr);   // the sets' table build is still queued (build_sketch_tables_begin): the pair descriptors are made
+                                                                           // while it runs, then this is called -- it must finish the build -- and the pairs are chained
 
 }  // namespace skh

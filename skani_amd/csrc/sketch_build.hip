@@ -519,7 +519,7 @@ void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss_c) {
     if (ss_c->tables_built) return;
     skh_sketch_set* ss = const_cast<skh_sketch_set*>(ss_c);
-    std::lock_guard<std::mutex> lk(ss->cache_mu);
+    std::lock_guard<std::mutex> lk(ss->build_mu);
     if (ss->tables_built) return;
     build_sketch_tables(ctx, ss, nullptr, nullptr);
 }

@@ -240,6 +240,15 @@ def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200), (
             assert nch == onch and np.array_equal(i, oi) and np.array_equal(j, oj), (mode, c, kw)
             for x in range(len(res)):
                 assert_result_close(res[x], ores[x], (mode, c, kw, int(i[x]), int(j[x])))
+            if not kw:
+                # sets sketched with deferred seed tables: the triangle builds the tables beside its screen (skh_triangle); with and without the screen
+                # index made at sketch time; a second triangle on the same set finds the tables built.  Byte for byte the result above.
+                for screen_index in (True, False):
+                    ssd = ctx.sketch_records(genomes, sk.SketchParams(c=c, seeding_mode=mode), names, defer_tables=True, screen_index=screen_index)
+                    for again in range(2):
+                        di, dj, dres, dn = ctx.triangle(ssd, mp)
+                        assert dn == nch and np.array_equal(di, i) and np.array_equal(dj, j) and dres.tobytes() == res.tobytes(), (mode, c, screen_index, again)
+                    ssd.close()
 
 
 def case_screen_rules(ctx):
