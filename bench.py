@@ -139,7 +139,7 @@ def run_search(args, torch, sk, ctx, device):
         torch.cuda.synchronize()
         gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
         del bases
-        shards.append(ctx.sketch_genomes(gs, params, genome_rank=np.arange(a, a + ng, dtype=np.uint32)))
+        shards.append(ctx.sketch_genomes(gs, params, genome_rank=np.arange(a, a + ng, dtype=np.uint32), compact=not args.no_compact))   # SKH_SKETCH_COMPACT: a resident database
         gs.close(); torch.cuda.empty_cache()
     db = sk.SketchDB(shards)
     build_s = time.perf_counter() - t0
@@ -422,6 +422,7 @@ def main():
     ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
     ap.add_argument("--workload", default="triangle", choices=["triangle", "search"], help="triangle = the headline metric; search = BASELINE config 5 (optional)")
     ap.add_argument("--db-genomes", type=int, default=10000)
+    ap.add_argument("--no-compact", action="store_true", help="search workload: database shards with the triangle's table geometry (2 home slots per position, full list storage) instead of SKH_SKETCH_COMPACT")
     ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")

@@ -118,8 +118,11 @@ int skh_sketch_genomes(skh_ctx*, const skh_genome_set*, const skh_sketch_params*
  * skh_sketch_sizes' n_distinct) or by skh_sketch_build_tables.  A rank of a distributed triangle sketches with this flag: it then indexes only the
  * sketches it ends up chaining (its own that stay + the ones it receives), not every genome it happened to read.  skh_triangle on such a set builds
  * the tables on one stream while the marker screen and the host's pair bookkeeping run beside them on the other (the set's screen index is made at
- * sketch time for that); SKH_SKETCH_NO_SCREEN_INDEX leaves the screen index out as well (a rank of a distributed triangle never screens its own set). */
-enum { SKH_SKETCH_DEFER_TABLES = 1, SKH_SKETCH_NO_SCREEN_INDEX = 2 };
+ * sketch time for that); SKH_SKETCH_NO_SCREEN_INDEX leaves the screen index out as well (a rank of a distributed triangle never screens its own set).
+ * SKH_SKETCH_COMPACT: a set that is made to stay resident (the shards of a search database, search.rs:97-282): its seed tables take 1.5 instead of 2 home
+ * slots per seed position and its list storage is cut to what the lists take -- about 21 instead of 31 bytes of HBM per seed position; probing such a
+ * table walks slightly longer clusters.  Results are the same. */
+enum { SKH_SKETCH_DEFER_TABLES = 1, SKH_SKETCH_NO_SCREEN_INDEX = 2, SKH_SKETCH_COMPACT = 4 };
 int skh_sketch_genomes_ex(skh_ctx*, const skh_genome_set*, const skh_sketch_params*, const uint32_t* genome_rank, uint32_t flags,
                           skh_sketch_set** out);
 int skh_sketch_build_tables(skh_ctx*, skh_sketch_set*);   /* no-op when they exist */

@@ -147,16 +147,16 @@ class Context:
         return GenomeSet(self, h, seeding_mode, None, None, n_genomes)
 
     # ---- sketch -------------------------------------------------------------------------------------------------
-    def sketch_genomes(self, gs, params, genome_rank=None, names=None, defer_tables=False, screen_index=True):
+    def sketch_genomes(self, gs, params, genome_rank=None, names=None, defer_tables=False, screen_index=True, compact=False):
         """defer_tables: seeding + marker sets only; the seed tables are built on first use (a rank of a distributed triangle indexes only what it chains;
         `triangle` builds them beside its screen).  screen_index=False (with defer_tables): no sorted marker incidences either (SKH_SKETCH_NO_SCREEN_INDEX)."""
         h = C.c_void_p()
         rank = np.ascontiguousarray(genome_rank, np.uint32) if genome_rank is not None else None
-        flags = (1 if defer_tables else 0) | (0 if screen_index else 2)
+        flags = (1 if defer_tables else 0) | (0 if screen_index else 2) | (4 if compact else 0)   # compact: SKH_SKETCH_COMPACT, a set that stays resident (search database)
         self.check(self.L.skh_sketch_genomes_ex(self.h, gs.h, C.byref(params), _p(rank), flags, C.byref(h)))
         return SketchSet(self, h, params, names)
 
-    def sketch_records(self, genomes, params, names=None, defer_tables=False, screen_index=True):
+    def sketch_records(self, genomes, params, names=None, defer_tables=False, screen_index=True, compact=False):
         """genomes: list of lists of (name, seq) records for one file each; applies file_io.rs:176 (>= 500 bp)."""
         kept = [[s for _, s in recs if len(s) >= MIN_LENGTH_CONTIG] for recs in genomes]
         rank = None
@@ -165,7 +165,7 @@ class Context:
             rank[order] = np.arange(len(names), dtype=np.uint32)
         gs = self.pack_genomes(kept, params.seeding_mode)
         try:
-            return self.sketch_genomes(gs, params, rank, names, defer_tables=defer_tables, screen_index=screen_index)
+            return self.sketch_genomes(gs, params, rank, names, defer_tables=defer_tables, screen_index=screen_index, compact=compact)
         finally:
             gs.close()
 

@@ -207,6 +207,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         if (gs->open) throw std::invalid_argument("the genome set is still being filled: call skh_genomes_finish first");
         if ((int)sp->seeding_mode != gs->seeding_mode) throw std::invalid_argument("genome set was packed for the other seeding_mode");
         ss = new_sketch_set(ctx, *sp, gs->n_genomes, genome_rank);
+        ss->compact = (flags & SKH_SKETCH_COMPACT) != 0;
         const uint32_t ng = gs->n_genomes;
         ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
         for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const uint32_t* __re
         for (uint32_t u = 0; u < 16; u++) { const uint64_t x = i + 256u * u; if (x < n && x < (i - threadIdx.x) + 4096) dst[dof + x] = src[so + x]; }
     }
 }
+}  // namespace
 void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::vector<uint64_t>& seg) {
     const uint32_t n_seg = (uint32_t)(seg.size() / 3);
     if (!n_seg) return;
@@ -98,6 +99,7 @@ void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::
     SKH_LAUNCH(copy_segments_kernel, dim3(n_seg, slices), 256, 0, ctx->stream, src, dst, (const uint64_t*)d_seg, n_seg);
     check_launch("copy_segments");
 }
+namespace {
 
 struct Dsu {
     std::vector<uint32_t> p;

@@ -127,6 +127,8 @@ struct skh_sketch_set {
     // genome << 1 | canonical instead: the seed tables and the join work on p_g exactly as they do otherwise (ascending index = ascending coordinate),
     // and the anchors of a pair with such a genome are translated to 64-bit coordinates before the chaining (chain.hip).  goff: exact for the others.
     bool wide = false, indexed = false;            // indexed: the wide genomes' p_g records have been made (sketch_build.hip)
+    bool compact = false;                          // SKH_SKETCH_COMPACT: a set made to stay resident (a search database): 1.5 instead of 2 home slots per position, list
+                                                   // storage cut to what the lists take -- 21 instead of 31 bytes per position, a slightly longer probe walk
     std::vector<uint8_t> wide_g;                   // per genome (wide sets only)
     std::vector<uint64_t> goff64;
     std::vector<uint64_t> total_len;
@@ -243,6 +245,7 @@ struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                
 TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
 void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);
 void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
+void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::vector<uint64_t>& seg);   // dist.hip: segments of 32-bit words (src offset, dst offset, words) x n
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);

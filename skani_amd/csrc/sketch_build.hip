@@ -452,7 +452,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t pg = ss->pos_off[g + 1] - ss->pos_off[g];
         if (pg >= (1ull << 30)) throw Error("a genome with >= 2^30 seed positions does not fit the seed table's 32-bit slot fields");
-        const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
+        const uint32_t nb = (uint32_t)((std::max<uint64_t>(64, ss->compact ? pg + pg / 2 : 2 * pg) + TAB_FILTER_HOMES - 1) / TAB_FILTER_HOMES * TAB_FILTER_HOMES);   // whole filter words
         const uint32_t n_sl = (nb + TAB_SLICE - 1) / TAB_SLICE;
         ss->n_buckets[g] = nb;
         if ((n_slices += n_sl) >= 0xFFFFFFF0ull) throw Error("too many table slices in one build; split the batch");
@@ -496,14 +496,14 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
 // end of a slice) is indexed again under the next salt -- the reference's HashMap takes any key set (types.rs:281-320) -- by a build over those genomes only.
 void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb) {
     const uint32_t ng = ss->n_genomes;
-    std::vector<uint32_t> back(tb.n, 0), distinct(ng, 0), again;
+    std::vector<uint32_t> back(tb.n, 0), distinct(ng, 0), ms_used(ng, 0), again;
     if (tb.d_back) d2h(back.data(), tb.d_back, tb.n * 4, ctx->stream);               // the build's one read-back (synchronises)
     else dsync(ctx->stream);
     for (uint32_t attempt = 0;; attempt++) {
         again.clear();
         for (uint32_t g = 0; g < ng; g++) {
             if (back[g] & 2u) throw Error("seed table: a genome's seed lists do not fit their storage");
-            if (back[g] & 1u) again.push_back(g); else if (attempt == 0 || ss->salt[g] == attempt) distinct[g] = back[ng + g];
+            if (back[g] & 1u) again.push_back(g); else if (attempt == 0 || ss->salt[g] == attempt) { distinct[g] = back[ng + g]; ms_used[g] = back[2 * (size_t)ng + g]; }
         }
         if (again.empty()) break;
         if (attempt >= 15) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range under every salt tried");
@@ -513,6 +513,15 @@ void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb
         d2h(back.data(), d_back, tb.n * 4, ctx->stream);
     }
     for (uint32_t g = 0; g < ng; g++) ss->dist_off[g + 1] = ss->dist_off[g] + distinct[g];
+    if (ss->compact && ng) {                                                         // a resident set: the list storage shrinks to what the lists take (offsets in the slots are genome-relative)
+        std::vector<uint64_t> off(ng + 1, 0), seg;
+        for (uint32_t g = 0; g < ng; g++) { off[g + 1] = off[g] + ms_used[g] + 4; if (ms_used[g]) seg.insert(seg.end(), {ss->ms_off[g], off[g], (uint64_t)ms_used[g]}); }   // (+4: the join may read two words past a short list)
+        DBuf<uint32_t> small(off[ng] ? off[ng] : 1);
+        dzero(small.p, small.bytes(), ctx->stream);
+        copy_segments(ctx, ss->ms.p, small.p, seg);
+        dsync(ctx->stream);
+        ss->ms = std::move(small); ss->ms_off = off;
+    }
     ss->tables_built = true;
 }
 

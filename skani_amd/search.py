@@ -67,7 +67,7 @@ def build_db(ctx, genomes, params, names=None, shard_genomes=None):
     shards = []
     for a in range(0, len(genomes), shard_genomes):
         nm = names[a:a + shard_genomes] if names is not None else None
-        shards.append(ctx.sketch_records(genomes[a:a + shard_genomes], params, nm))
+        shards.append(ctx.sketch_records(genomes[a:a + shard_genomes], params, nm, compact=True))   # resident: SKH_SKETCH_COMPACT
     return SketchDB(shards, names)
 
 
