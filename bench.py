@@ -426,8 +426,8 @@ def main():
     ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")
-    ap.add_argument("--tables", default="beside-screen", choices=["beside-screen", "at-sketch"], help="one GPU: the seed tables are built inside skh_triangle beside its marker screen "
-                    "(sketches made with SKH_SKETCH_DEFER_TABLES; default) or inside skh_sketch_genomes beside the marker sets (rounds 1-3)")
+    ap.add_argument("--tables", default="at-sketch", choices=["beside-screen", "at-sketch"], help="one GPU: the seed tables are built inside skh_sketch_genomes beside the marker sets (default) "
+                    "or inside skh_triangle beside its marker screen (sketches made with SKH_SKETCH_DEFER_TABLES; measured in round 4: the same step time)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0, host collectives over gloo (RCCL refuses two ranks on one GPU): runs this file's whole "
                     "multi-rank branch on a one-GPU box (tests/test_bench_multirank.py); the number it prints is not a multi-GPU measurement")
     ap.add_argument("--collection", type=int, default=0, help="strong scaling: a fixed collection of this many genomes (10000 = BASELINE config 4) in shuffled order at every "
