@@ -151,6 +151,8 @@ def run_search(args, torch, sk, ctx, device):
     del qb
     qs = ctx.sketch_genomes(gq, params, genome_rank=np.arange(10_000_000, 10_000_000 + nq, dtype=np.uint32))
     gq.close()
+    torch.cuda.empty_cache()
+    live_b, idle_b = ctx.device_memory(trim=True)                    # (the library's idle cache -- up to 32 GiB of freed build scratch -- handed back: the database itself is what stays)
     mem_gb = torch.cuda.mem_get_info(device)
     for _ in range(args.warmup):
         sk.search(ctx, db, qs, n_query_files=nq)
@@ -166,7 +168,8 @@ def run_search(args, torch, sk, ctx, device):
                       "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "skani search: %d synthetic queries vs %d-genome DB (c=%d) resident in HBM" % (nq, n_db, args.c), "db_genomes": n_db,
                                  "db_shards": len(shards), "queries": nq, "hits": int(len(q)), "hits_in_own_clade": int(own.sum()), "db_build_s": build_s,
-                                 "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9},
+                                 "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9, "library_live_gb": live_b / 1e9,
+                                 "bytes_per_seed_position": live_b / max(1.0, n_db * (args.mean_len / args.c)), "compact_shards": not args.no_compact},
                       "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None},
             (q, r, res, qclades))
 

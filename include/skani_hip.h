@@ -269,6 +269,11 @@ int skh_triangle_distributed(skh_ctx*, skh_comm*, const skh_sketch_set* local, d
 int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs, const uint64_t* weight, const uint32_t* holder,
                    int world, uint8_t* owner);
 
+/* Device memory the library holds (all contexts of the process): live_bytes = in use by sketch sets, genome sets, models and scratch; idle_bytes = freed
+ * blocks kept for reuse by its caching allocator (up to SKH_TUNE_ALLOC_CACHE_BYTES, default 32 GiB -- they look "used" to the driver).  trim != 0 hands the
+ * idle blocks back to the driver first.  Either pointer may be NULL. */
+int skh_device_memory(uint64_t* live_bytes, uint64_t* idle_bytes, int trim);
+
 /* last-call timing breakdown in milliseconds (HIP events on the library's stream), for bench.py */
 typedef struct { float pack_ms, seed_ms, sketch_build_ms, screen_ms, chain_ms, seed_kernel_ms; uint32_t seed_kernel_launches; float exchange_ms; } skh_timings;
 int skh_get_timings(const skh_ctx*, skh_timings* out);

@@ -88,6 +88,12 @@ class Context:
         t = B.Timings(); self.check(self.L.skh_get_timings(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in t._fields_ if n != "pad"}
 
+    def device_memory(self, trim=False):
+        """(live, idle) bytes of device memory the library holds: in use / freed blocks kept by its caching allocator (skh_device_memory)."""
+        live, idle = C.c_uint64(), C.c_uint64()
+        self.check(self.L.skh_device_memory(C.byref(live), C.byref(idle), int(trim)))
+        return live.value, idle.value
+
     # ---- ingest -------------------------------------------------------------------------------------------------
     def pack_genomes(self, genomes, seeding_mode=SEED_AVX2):
         """genomes: list (one per genome) of lists of contig byte strings (already >= 500 bp filtered)."""

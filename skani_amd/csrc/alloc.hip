@@ -60,6 +60,16 @@ void dfree(void* p) {
     dc.idle.emplace(sz, p); dc.idle_bytes += sz;
 }
 
+void dcache_stats(size_t* live_bytes, size_t* idle_bytes) {
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    size_t live = 0, idle = 0;
+    for (auto& kv : P.live) live += kv.second.first;
+    for (auto& kv : P.dev) idle += kv.second.idle_bytes;
+    if (live_bytes) *live_bytes = live;
+    if (idle_bytes) *idle_bytes = idle;
+}
+
 void dcache_trim() {
     Pool& P = pool();
     std::lock_guard<std::mutex> lk(P.mu);

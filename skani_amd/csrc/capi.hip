@@ -101,6 +101,15 @@ void skh_ctx_destroy(skh_ctx* ctx) {
 }
 
 const char* skh_last_error(const skh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int skh_device_memory(uint64_t* live_bytes, uint64_t* idle_bytes, int trim) {
+    try {
+        if (trim) dcache_trim();
+        size_t live = 0, idle = 0; dcache_stats(&live, &idle);
+        if (live_bytes) *live_bytes = live;
+        if (idle_bytes) *idle_bytes = idle;
+        return SKH_OK;
+    } catch (...) { return SKH_ERR_INTERNAL; }
+}
 void skh_free(void* p) { free(p); }
 
 int skh_load_models(skh_ctx* ctx, const char* p125, const char* p200) {

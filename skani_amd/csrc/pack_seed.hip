@@ -534,8 +534,11 @@ __global__ __launch_bounds__(256) void seed_overflow_kernel(const uint32_t* cnt_
     ovf_idx[t] = idx;
 }
 
-// one wave per tile: copy the tile's records to their final (contig,pos)-ordered place.  WIDE (a set with a genome beyond 31-bit coordinates): the
-// coordinates also go out as 64-bit records (o_g64); the table build replaces the 32-bit records of the wide genomes by position indices (sketch_build.hip)
+// A QUARTER of a wave per tile (16 lanes: a tile holds ~65 seeds and ~8 markers) copies the tile's records to their final (contig,pos)-ordered place.  WIDE (a
+// set with a genome beyond 31-bit coordinates): the coordinates also go out as 64-bit records (o_g64); the table build replaces the 32-bit records of the
+// wide genomes by position indices (sketch_build.hip).  The kernel is a chain of three dependent round trips per tile (tile record + offsets, contig record,
+// the tile's scratch): with a whole wave per tile it ran 604,000 short waves in 74 generations (0.31 ms, 88 % of the time waiting); four tiles per wave
+// make it a quarter of the waves with the same chain.
 template <bool WIDE>
 __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __restrict__ tiles, const ContigDesc* __restrict__ contigs,
                                                            uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m, const uint32_t* __restrict__ ovf_idx,
@@ -545,9 +548,10 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                                                            const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
                                                            uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_g,
                                                            uint64_t* __restrict__ o_g64, uint64_t* __restrict__ o_marker) {
-    const uint32_t lt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    constexpr uint32_t G = 16;                                                       // lanes per tile
+    const uint32_t lt = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (lt >= n_tiles) return;
-    const uint32_t ln = threadIdx.x & 63;
+    const uint32_t ln = threadIdx.x & (G - 1u);
     const SeedTile tile = tiles[lt];
     const uint32_t goff = contigs[tile.contig].goff;
     const uint64_t goff64 = ((uint64_t)contigs[tile.contig].goff_hi << 32) | goff;
@@ -556,15 +560,16 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
     const uint16_t* src_loc = ov == 0xFFFFFFFFu ? t_loc + (uint64_t)lt * cap_s : o_loc2 + (uint64_t)ov * SEED_TILE;
     const uint64_t* src_mk = ov == 0xFFFFFFFFu ? t_marker + (uint64_t)lt * cap_m : o_marker2 + (uint64_t)ov * SEED_TILE;
-    // a tile holds ~65 seeds and ~8 markers: the loads of up to four rounds (and the markers') are issued before the first store
+    // the loads of up to eight rounds (and the markers') are issued before the first store
     const uint32_t pos0 = (K_MARKER - 1) + tile.first * SEED_TILE;
-    for (uint32_t x0 = 0; x0 < ns; x0 += 256) {
-        uint32_t loc[4], sd[4];
+    const uint64_t mk0 = ln < nm ? src_mk[ln] : 0ull;
+    for (uint32_t x0 = 0; x0 < ns; x0 += 8 * G) {
+        uint32_t loc[8], sd[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t x = x0 + 64u * (uint32_t)u + ln; loc[u] = x < ns ? src_loc[x] : 0u; sd[u] = x < ns ? src_seed[x] : 0u; }
+        for (int u = 0; u < 8; u++) { const uint32_t x = x0 + G * (uint32_t)u + ln; loc[u] = x < ns ? src_loc[x] : 0u; sd[u] = x < ns ? src_seed[x] : 0u; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t x = x0 + 64u * (uint32_t)u + ln;
+        for (int u = 0; u < 8; u++) {
+            const uint32_t x = x0 + G * (uint32_t)u + ln;
             if (x < ns) {
                 o_seed[s0 + x] = sd[u];
                 const uint32_t pos = pos0 + (loc[u] & 0x1FFFu);                         // pos = index of the window's last base
@@ -573,7 +578,8 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
             }
         }
     }
-    for (uint32_t x = ln; x < nm; x += 64) o_marker[m0 + x] = src_mk[x];
+    if (ln < nm) o_marker[m0 + ln] = mk0;
+    for (uint32_t x = ln + G; x < nm; x += G) o_marker[m0 + x] = src_mk[x];
 }
 
 __global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out) {
@@ -660,7 +666,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         }
         p.seed.alloc(p.ns); p.mk.alloc(p.nm);
         p.g.alloc(p.ns); if (wide) p.g64.alloc(p.ns);
-#define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 3) / 4, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
+#define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 15) / 16, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2, \
                    (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.g.p, p.g64.p, p.mk.p)
         if (wide) SKH_COMPACT(true); else SKH_COMPACT(false);
