@@ -139,7 +139,7 @@ def run_search(args, torch, sk, ctx, device):
         torch.cuda.synchronize()
         gs = ctx.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
         del bases
-        shards.append(ctx.sketch_genomes(gs, params, genome_rank=np.arange(a, a + ng, dtype=np.uint32), compact=not args.no_compact))   # SKH_SKETCH_COMPACT: a resident database
+        shards.append(ctx.sketch_genomes(gs, params, genome_rank=np.arange(a, a + ng, dtype=np.uint32), compact=not getattr(args, "no_compact", False)))   # SKH_SKETCH_COMPACT: a resident database
         gs.close(); torch.cuda.empty_cache()
     db = sk.SketchDB(shards)
     build_s = time.perf_counter() - t0
@@ -169,7 +169,7 @@ def run_search(args, torch, sk, ctx, device):
                       "config": {"workload": "skani search: %d synthetic queries vs %d-genome DB (c=%d) resident in HBM" % (nq, n_db, args.c), "db_genomes": n_db,
                                  "db_shards": len(shards), "queries": nq, "hits": int(len(q)), "hits_in_own_clade": int(own.sum()), "db_build_s": build_s,
                                  "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9, "library_live_gb": live_b / 1e9,
-                                 "bytes_per_seed_position": live_b / max(1.0, n_db * (args.mean_len / args.c)), "compact_shards": not args.no_compact},
+                                 "bytes_per_seed_position": live_b / max(1.0, n_db * (args.mean_len / args.c)), "compact_shards": not getattr(args, "no_compact", False)},
                       "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None},
             (q, r, res, qclades))
 

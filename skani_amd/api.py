@@ -226,8 +226,9 @@ class Context:
         self.check(self.L.skh_screen(self.h, refs.h, queries.h if queries is not None else None, identity, rule, int(rescue_small),
                                      C.byref(a), C.byref(b), C.byref(n)))
         try:
-            first = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
-            second = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+            first = np.empty(n.value, np.uint32); second = np.empty(n.value, np.uint32)
+            if n.value:
+                C.memmove(first.ctypes.data, a, 4 * n.value); C.memmove(second.ctypes.data, b, 4 * n.value)
         finally:
             self.L.skh_free(a); self.L.skh_free(b)
         return first, second
@@ -237,8 +238,9 @@ class Context:
         a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self.check(self.L.skh_screen_rows(self.h, sketches.h, row0, n_rows, identity, int(rescue_small), C.byref(a), C.byref(b), C.byref(n)))
         try:
-            first = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
-            second = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+            first = np.empty(n.value, np.uint32); second = np.empty(n.value, np.uint32)
+            if n.value:
+                C.memmove(first.ctypes.data, a, 4 * n.value); C.memmove(second.ctypes.data, b, 4 * n.value)
         finally:
             self.L.skh_free(a); self.L.skh_free(b)
         return first, second
@@ -264,14 +266,18 @@ class Context:
         self.check(self.L.skh_triangle(self.h, sketches.h, identity, int(rescue_small), C.byref(map_params), part, n_parts,
                                        C.byref(oi), C.byref(oj), C.byref(orr), C.byref(n), C.byref(nch)))
         try:
-            k = n.value
-            i = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
-            j = np.ctypeslib.as_array(C.cast(oj, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
-            buf = (C.c_char * (max(k, 1) * B.RESULT_DTYPE.itemsize)).from_address(orr.value)
-            res = np.frombuffer(buf, B.RESULT_DTYPE)[:k].copy()
+            i, j, res = _take_rows(n.value, oi, oj, orr)
         finally:
             self.L.skh_free(oi); self.L.skh_free(oj); self.L.skh_free(orr)
         return i, j, res, nch.value
+
+
+def _take_rows(k, oi, oj, orr):
+    """Copies k result rows out of the library's malloc'd arrays (one memmove each: np.ctypeslib.as_array on a ctypes pointer costs ~0.1 ms per call)."""
+    i = np.empty(k, np.uint32); j = np.empty(k, np.uint32); res = np.empty(k, B.RESULT_DTYPE)
+    if k:
+        C.memmove(i.ctypes.data, oi, 4 * k); C.memmove(j.ctypes.data, oj, 4 * k); C.memmove(res.ctypes.data, orr, B.RESULT_DTYPE.itemsize * k)
+    return i, j, res
 
 
 class GenomeSet:

@@ -452,7 +452,9 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
                  uint32_t n_parts, uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained) {
     if (!ctx || !ss || !mp || !out_i || !out_j || !out_res || !n_kept || n_parts == 0 || part >= n_parts) return SKH_ERR_INVALID;
     *out_i = *out_j = nullptr; *out_res = nullptr; *n_kept = 0;
+    StageTrace tr_entry(ctx);
     int rc = guarded(ctx, [&] {
+        tr_entry.mark("triangle: entry");
         StageTrace tr(ctx);
         std::vector<uint32_t> a, b;
         // A set sketched with deferred tables: its seed tables are queued on the main stream NOW, and the screen (marker incidences, count matrix, pair
@@ -497,8 +499,11 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
         size_t q = 0;
         for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) { oi[q] = pi[p]; oj[q] = pj[p]; orr[q] = res[p]; q++; }
         *out_i = oi; *out_j = oj; *out_res = orr; *n_kept = kept;
+        tr.mark("triangle: results out");
     });
+    StageTrace tr_exit(ctx);
     ctx->arena.reset();
+    tr_exit.mark("triangle: arena reset");
     return rc;
 }
 

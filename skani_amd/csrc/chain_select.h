@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const
     __shared__ uint16_t idx[CAP];                                     // the candidates in sorted order
     __shared__ __attribute__((aligned(4))) uint16_t qh[GREEDY_BUCKETS], rh[GREEDY_BUCKETS];   // pairs of heads are exchanged as 32-bit words
     __shared__ uint16_t lng[GREEDY_LONG];
+    __shared__ __attribute__((aligned(4))) uint8_t cq[GREEDY_BUCKETS], cr[GREEDY_BUCKETS];   // candidates of the current batch per (hashed) chunk / reference bin; zero between batches
     if (blockIdx.x >= n_pairs) return;
     const uint32_t p = order[blockIdx.x];
     const uint32_t l = lane_id();
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const
             wave_sync_mem();
         }
     }
-    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = (uint16_t)GREEDY_NIL; rh[i] = (uint16_t)GREEDY_NIL; }
+    for (uint32_t i = l; i < GREEDY_BUCKETS; i += 64) { qh[i] = (uint16_t)GREEDY_NIL; rh[i] = (uint16_t)GREEDY_NIL; cq[i] = 0; cr[i] = 0; }
     wave_sync_mem();
     uint32_t nacc = 0, nlong = 0;
     bool long_overflow = false;                                                     // more than GREEDY_LONG wide intervals: fall back to scanning everything
@@ -144,7 +145,38 @@ __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const
             for (uint32_t t = 0; t < nlong; t++) add_r(acc[lng[t]]);
         }
         const uint32_t nb = n - base < 64 ? n - base : 64, nacc0 = nacc;
-        for (uint32_t b = 0; b < nb; b++) {
+        // Which candidates of the batch can influence each other at all?  Two intervals overlap on the query axis only inside one chunk, on the reference
+        // axis only if they share a 32 kb bin: every candidate counts itself into a (hashed) counter of its chunk and of its one or two bins, and one whose
+        // counters all read 1 shares neither with another candidate of the batch -- its decision is the one the accepted lists gave it, and it is taken for
+        // all such candidates AT ONCE.  Only the others (~a third) go through the sequential loop below, in their order.  (An interval over three or more
+        // bins is always taken sequentially; hash collisions only send more candidates there.)  The counters are taken back afterwards: no clearing pass.
+        const bool in_batch = l < nb;
+        const uint32_t cb0 = c.r0 >> GREEDY_BIN_SHIFT, cb1 = greedy_last_bin(c.r0, c.r1);
+        const uint32_t n_bins = cb1 - cb0 + 1u < 4u ? cb1 - cb0 + 1u : 4u;           // (an interval here is shorter than greedy_len_limit = 64 kb: at most three bins)
+        const uint32_t kq = c.chunk & (GREEDY_BUCKETS - 1u);
+        auto bump = [&](uint8_t* t, uint32_t k, int d) { atomicAdd((unsigned*)t + (k >> 2), (unsigned)d << ((k & 3u) * 8u)); };
+        if (in_batch) { bump(cq, kq, 1); for (uint32_t x = 0; x < n_bins; x++) bump(cr, greedy_rhash(c.rctg, cb0 + x), 1); }
+        wave_sync_mem();
+        bool alone = in_batch && n_bins <= 2u && cb1 - cb0 < 2u && cq[kq] == 1;
+        if (alone) {
+            const uint32_t k0 = greedy_rhash(c.rctg, cb0), k1 = greedy_rhash(c.rctg, cb1);
+            alone = n_bins == 1u ? cr[k0] == 1 : (k0 == k1 ? cr[k0] == 2 : (cr[k0] == 1 && cr[k1] == 1));
+        }
+        wave_sync_mem();
+        if (in_batch) { bump(cq, kq, -1); for (uint32_t x = 0; x < n_bins; x++) bump(cr, greedy_rhash(c.rctg, cb0 + x), -1); }
+        {   // the candidates that stand alone: accepted or not by the sums they have, all at once
+            const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
+            const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
+            const bool take = alone && ok_r && ok_q;
+            const unsigned long long tm = __ballot(take);
+            if (take) {
+                const uint32_t slot = nacc + (uint32_t)__popcll(tm & ((1ull << l) - 1ull));
+                acc[slot] = AccIvl{c.rctg, c.r0, c.q0, (c.r1 - c.r0) | ((c.q1 - c.q0) << 16), c.chunk | (ci << 16), GREEDY_NIL | (GREEDY_NIL << 10) | (GREEDY_NIL << 20)};
+            }
+            nacc += (uint32_t)__popcll(tm);
+        }
+        for (unsigned long long rest = __ballot(in_batch && !alone); rest; rest &= rest - 1ull) {
+            const uint32_t b = (uint32_t)__ffsll((long long)rest) - 1u;
             const bool ok_r = cnt_r == 0 || (float)sum_r < (float)(c.r1 - c.r0) * 0.5f;   // chain.rs:1046 OVERLAP_ORTHOLOGOUS_FRACTION
             const bool ok_q = cnt_q == 0 || (float)sum_q < (float)(c.q1 - c.q0) * 0.5f;   // chain.rs:1075
             const int okb = wave_readlane((int)((ok_r && ok_q) ? 1 : 0), (int)b);

@@ -89,11 +89,8 @@ class Comm:
         self.ctx.check(L.skh_triangle_distributed(self.ctx.h, self.h, ss_local.h, identity, int(rescue_small), C.byref(map_params),
                                                   C.byref(oi), C.byref(oj), C.byref(orr), C.byref(n), C.byref(nch), C.byref(st)))
         try:
-            k = n.value
-            i = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
-            j = np.ctypeslib.as_array(C.cast(oj, C.POINTER(C.c_uint32)), (max(k, 1),))[:k].copy()
-            buf = (C.c_char * (max(k, 1) * B.RESULT_DTYPE.itemsize)).from_address(orr.value)
-            res = np.frombuffer(buf, B.RESULT_DTYPE)[:k].copy()
+            from .api import _take_rows
+            i, j, res = _take_rows(n.value, oi, oj, orr)
         finally:
             L.skh_free(oi); L.skh_free(oj); L.skh_free(orr)
         return i, j, res, nch.value, {nm: getattr(st, nm) for nm, _ in st._fields_}
