@@ -71,7 +71,6 @@ int skh_ctx_create(int device, skh_ctx** out) {
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
         ctx->tune.seed_scratch_bytes = env("SKH_TUNE_SEED_SCRATCH_BYTES", ctx->tune.seed_scratch_bytes);
         ctx->tune.seed_tile_cap = (uint32_t)env("SKH_TUNE_SEED_TILE_CAP", ctx->tune.seed_tile_cap);
-        ctx->tune.seed_direct = (uint32_t)env("SKH_TUNE_SEED_DIRECT", ctx->tune.seed_direct);
         ctx->tune.screen_cells = env("SKH_TUNE_SCREEN_CELLS", ctx->tune.screen_cells);
         ctx->tune.chain_anchors = env("SKH_TUNE_CHAIN_ANCHORS", ctx->tune.chain_anchors);
         ctx->tune.chain_super_tiles = (uint32_t)env("SKH_TUNE_CHAIN_SUPER_TILES", ctx->tune.chain_super_tiles);

@@ -157,10 +157,6 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
                  "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return v;
 }
-// one 64-bit word handed from workgroup to workgroup (the seeding's chained tile scan): device-scope atomic store / load -- the word is all that travels,
-// so no fence goes with it (an agent-scope fence writes back the XCD's L2: hundreds of microseconds)
-__device__ __forceinline__ void dev_store_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long dev_load_u64(unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // in-kernel timing (SKH_TRACE_JOIN): the shader clock, and a point at which a loaded value must have arrived
 __device__ __forceinline__ unsigned long long wave_clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void wait_for_value(uint32_t v) { asm volatile("" ::"v"(v)); }

@@ -54,7 +54,6 @@ struct GbdtModel {  // flat table from tools/extract_gbdt_model.py (regression.r
 // (SKH_TUNE_* environment variables, read at context creation) to drive the multi-batch paths with small inputs.
 struct skh_tunables {
     uint64_t seed_scratch_bytes = (uint64_t)6 << 30;    // capped tile scratch per seeding launch
-    uint32_t seed_direct = 1;                           // seeding writes its final arrays itself (a chained scan over the tiles); 0: per-tile scratch + scans + compaction kernel (rounds 1-3)
     uint32_t seed_tile_cap = 0;                         // seeds a tile may list in the capped scratch (0 = 4x the expected number; tests use few: every tile then only counts and is re-run with full capacity)
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)

@@ -405,53 +405,15 @@ __device__ __forceinline__ HitRecord derive_hit(uint32_t a0, uint32_t a1, uint32
 }
 
 constexpr uint32_t SEED_DROP_MAX = 16;   // candidates-that-are-not-hits a tile notes per listing round (more: further rounds)
-
-// DIRECT mode (round 4): a tile writes its records straight to their final place.  Where that is -- the number of seeds and markers of all earlier tiles
-// of the launch -- comes from a chained scan over the tiles ("decoupled look-back"): a tile publishes its own counts in one 64-bit word per quantity
-// (flag | value, one device-scope store: nothing else has to be made visible with it), then wave 0 reads the words of its 64 predecessors at a time, adds
-// up own-count words until it meets one that already carries a prefix, and publishes its own prefix.  Workgroups are dispatched in the order of their
-// numbers, so a predecessor is running or done: the wait ends.  This takes the place of two device-wide scans, the per-tile scratch (4x the expected hits
-// per tile) and the compaction kernel that copied the records to their place (0.17 + 0.13 ms per 1000 genomes), and of the second pass over tiles whose
-// hits overflowed the scratch.
-struct SeedDirect {
-    unsigned long long* state_s; unsigned long long* state_m;     // per tile, zeroed before the launch: flag << 62 | value
-    uint32_t *o_seed, *o_g; uint64_t* o_g64; uint64_t* o_marker;  // final arrays of the launch (o_g64: wide sets)
-    uint64_t cap_s, cap_m;                                        // their capacities: a launch that needs more sets *overflow and is repeated with what it needs
-    unsigned long long* tile_excl;                                // 2 x (n_tiles + 1): (seeds, markers) before each tile; entry n_tiles = the totals
-    uint32_t* overflow; uint32_t n_tiles;
-};
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
-// exclusive prefix of `count` over the tiles before t; all lanes of ONE wave call it
-__device__ __forceinline__ unsigned long long lookback_excl(unsigned long long* st, uint32_t t, unsigned long long count, uint32_t lane) {
-    if (t == 0) { if (lane == 0) dev_store_u64(&st[0], LB_PFX | count); return 0; }
-    if (lane == 0) dev_store_u64(&st[t], LB_AGG | count);
-    unsigned long long run = 0;
-    for (long long look = (long long)t - 1;; look -= 64) {
-        const long long idx = look - (long long)lane;
-        unsigned long long v = LB_PFX;                                               // (before tile 0: a prefix of zero)
-        if (idx >= 0) do { v = dev_load_u64(&st[idx]); } while ((v >> 62) == 0);
-        const unsigned long long pm = __ballot((v >> 62) == 2);
-        const uint32_t first = pm ? (uint32_t)__ffsll((long long)pm) - 1u : 63u;     // the nearest predecessor that carries a prefix
-        unsigned long long x = lane <= first ? (v & LB_VAL) : 0ull;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
-        run += x;
-        if (pm) break;
-    }
-    if (lane == 0) dev_store_u64(&st[t], LB_PFX | (run + count));
-    return run;
-}
-
-template <bool K15, bool DIRECT = false, bool WIDE = false>   // k = 15 (every preset): one instruction less per window
+template <bool K15>   // k = 15 (every preset): one instruction less per window
 __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                                                          const ContigDesc* __restrict__ contigs, const SeedTile* __restrict__ tiles,
                                                          const uint32_t* __restrict__ tile_ids, uint32_t k, uint64_t thr, uint64_t thr_m,
                                                          int mode, uint32_t cap_s, uint32_t cap_m,
                                                          uint32_t* __restrict__ t_seed, uint16_t* __restrict__ t_loc,
                                                          uint64_t* __restrict__ t_marker, uint32_t* __restrict__ cnt_s,
-                                                         uint32_t* __restrict__ cnt_m, SeedDirect dir) {
+                                                         uint32_t* __restrict__ cnt_m) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[SEED_TILE / 16 + 8];
-    __shared__ unsigned long long lds_excl[2];
     __shared__ uint32_t lds_scan[16];
     __shared__ uint32_t lds_nm, lds_ndrop, lds_again;
     __shared__ uint16_t lds_drop[SEED_DROP_MAX];
@@ -513,7 +475,6 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     const uint32_t wv = tid >> 6, ln = tid & 63;
     const uint64_t obase = (uint64_t)blockIdx.x * cap_s, mbase = (uint64_t)blockIdx.x * cap_m;
     uint32_t tot = 0;
-    HitRecord first_hr{0, false, 0}; uint64_t first_h = 0; uint32_t first_code = 0;           // DIRECT
     for (;;) {
         // workgroup prefix sum of the hit counts
         const uint32_t c = (uint32_t)__popc(hits);
@@ -539,11 +500,6 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
                 const HitRecord hr = derive_hit(lds_w[2 * src], lds_w[2 * src + 1], lds_w[2 * src + 2], lds_w[2 * src + 3], code & 31u, smask);
                 const uint64_t h = seed_hash(hr.seed);
                 if (h >= thr) { SKH_SEED_DROP_NOTE(); const uint32_t d = atomicAdd(&lds_ndrop, 1u); if (d < SEED_DROP_MAX) lds_drop[d] = (uint16_t)code; continue; }
-                if (DIRECT) {                                                                  // counted now, written behind the look-back; the thread's first record stays in registers
-                    if (x == tid) { first_hr = hr; first_h = h; first_code = code; }
-                    if (h < thr_m) atomicAdd(&lds_nm, 1u);
-                    continue;
-                }
                 t_seed[obase + x] = hr.seed;
                 t_loc[obase + x] = (uint16_t)(code | (hr.canonical ? 0x8000u : 0u));        // code = SEED_RUN * thread + window
                 if (h < thr_m) { const uint32_t mo = atomicAdd(&lds_nm, 1u); if (mo < cap_m) t_marker[mbase + mo] = hr.kmer; }
@@ -565,40 +521,7 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
         __syncthreads();                                                                       // (lds_ndrop / lds_drop are rewritten by the next round)
     }
     __syncthreads();
-    if (!DIRECT) { if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; } return; }
-    // ---- DIRECT: where this tile's records go, then the records themselves
-    const uint32_t nm_tile = lds_nm;
-    if (wv == 0) {
-        const unsigned long long es = lookback_excl(dir.state_s, blockIdx.x, tot, ln), em = lookback_excl(dir.state_m, blockIdx.x, nm_tile, ln);
-        if (ln == 0) { lds_excl[0] = es; lds_excl[1] = em; }
-    }
-    __syncthreads();
-    const unsigned long long es = lds_excl[0], em = lds_excl[1];
-    if (tid == 0) {
-        lds_nm = 0;                                                                            // (now the tile's marker slot counter)
-        dir.tile_excl[2 * (size_t)blockIdx.x] = es; dir.tile_excl[2 * (size_t)blockIdx.x + 1] = em;
-        if (blockIdx.x + 1 == dir.n_tiles) { dir.tile_excl[2 * (size_t)dir.n_tiles] = es + tot; dir.tile_excl[2 * (size_t)dir.n_tiles + 1] = em + nm_tile; }
-        if (es + tot > dir.cap_s || em + nm_tile > dir.cap_m) atomicOr(dir.overflow, 1u);
-    }
-    __syncthreads();
-    const uint32_t pos0 = (K_MARKER - 1) + tile.first * SEED_TILE;
-    const uint64_t goff64 = ((uint64_t)cd.goff_hi << 32) | cd.goff;
-    for (uint32_t x = tid; x < tot; x += SEED_THREADS) {
-        HitRecord hr = first_hr; uint64_t h = first_h; uint32_t code = first_code;
-        if (x != tid) {
-            code = lds_hit[x]; const uint32_t src = code >> 5;
-            hr = derive_hit(lds_w[2 * src], lds_w[2 * src + 1], lds_w[2 * src + 2], lds_w[2 * src + 3], code & 31u, smask);
-            h = seed_hash(hr.seed);
-        }
-        const uint64_t o = es + x;
-        if (o < dir.cap_s) {
-            const uint32_t pos = pos0 + code;                                                 // code = SEED_RUN * thread + window: the index of the window's last base within the tile
-            dir.o_seed[o] = hr.seed;
-            dir.o_g[o] = ((cd.goff + pos) << 1) | (hr.canonical ? 1u : 0u);                  // SeedPosition (types.rs:131-138) in padded coordinates (a wide genome's records are replaced by indices later)
-            if (WIDE) dir.o_g64[o] = ((goff64 + pos) << 1) | (hr.canonical ? 1ull : 0ull);
-        }
-        if (h < thr_m) { const uint64_t mo = em + atomicAdd(&lds_nm, 1u); if (mo < dir.cap_m) dir.o_marker[mo] = hr.kmer; }
-    }
+    if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; }
 }
 
 // tiles whose counts exceed the capped scratch get a slot in the full-capacity overflow scratch
@@ -664,93 +587,6 @@ __global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src,
     if (i < n) out[i] = src[idx[i]];
 }
 
-__global__ __launch_bounds__(256) void gather_u64x2_at_kernel(const unsigned long long* src, const uint32_t* idx, uint32_t n, unsigned long long* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { out[2 * (size_t)i] = src[2 * (size_t)idx[i]]; out[2 * (size_t)i + 1] = src[2 * (size_t)idx[i] + 1]; }
-}
-
-// DIRECT seeding (seed_tiles_kernel<.., true, ..>): one kernel per launch writes the final arrays; the host sizes them by the expected number of hits plus
-// a quarter and repeats a launch that needed more (low-complexity sequence) with the exact sizes its chained scan reported.
-static void seed_genomes_direct(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool wide, uint64_t thr, uint64_t thr_m) {
-    const size_t n_tiles = gs->tiles.size();
-    const uint32_t ng = gs->n_genomes;
-    StageTrace tr(ctx);
-    struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
-    std::vector<Part> parts;
-    const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
-    std::vector<uint64_t> g_ns(ng + 1, 0), g_nm(ng + 1, 0);                           // running totals at genome starts
-    std::vector<std::pair<DevEvent, DevEvent>> evs;                                   // around every launch of the seeding kernel: bench.py's roofline figure
-    const size_t MAX_TILES = ctx->tune.seed_tile_cap ? 3 : ((size_t)1 << 22);        // (tests: a few tiles per launch)
-    uint64_t base_s = 0, base_m = 0;
-    for (size_t t0 = 0; t0 < n_tiles; t0 += MAX_TILES) {
-        const uint32_t nt = (uint32_t)std::min(MAX_TILES, n_tiles - t0);
-        const SeedTile* d_tiles = gs->d_tiles.p + t0;
-        const uint64_t windows = (uint64_t)nt * SEED_TILE;
-        uint64_t cap_s = ctx->tune.seed_tile_cap ? (uint64_t)ctx->tune.seed_tile_cap : windows / sp.c + windows / sp.c / 4 + 4096;
-        uint64_t cap_m = ctx->tune.seed_tile_cap ? 1 : windows / sp.marker_c + windows / sp.marker_c / 2 + 4096;
-        std::vector<uint32_t> want, want_g;                                           // local tile indices whose prefixes the host needs: genome starts, and the totals
-        for (uint32_t g = 0; g <= ng; g++) if (g_first[g] >= t0 && g_first[g] <= t0 + nt) { want.push_back((uint32_t)(g_first[g] - t0)); want_g.push_back(g); }
-        want.push_back(nt);
-        Part p;
-        for (int attempt = 0;; attempt++) {
-            p.seed.alloc(cap_s ? cap_s : 1); p.g.alloc(cap_s ? cap_s : 1); p.mk.alloc(cap_m ? cap_m : 1); if (wide) p.g64.alloc(cap_s ? cap_s : 1);
-            unsigned long long* state = ctx->arena.get<unsigned long long>(2 * (size_t)nt);
-            unsigned long long* tile_excl = ctx->arena.get<unsigned long long>(2 * ((size_t)nt + 1));
-            uint32_t* d_want = ctx->arena.get<uint32_t>(want.size());
-            unsigned long long* d_got = ctx->arena.get<unsigned long long>(2 * want.size() + 1);   // the gathered prefixes, then the overflow flag
-            dzero(state, 2 * (size_t)nt * 8, ctx->stream); dzero(d_got + 2 * want.size(), 8, ctx->stream);
-            h2d(d_want, want.data(), want.size() * 4, ctx->stream);
-            SeedDirect dir{state, state + nt, p.seed.p, p.g.p, p.g64.p, p.mk.p, cap_s, cap_m, tile_excl, (uint32_t*)(d_got + 2 * want.size()), nt};
-            evs.emplace_back();
-            evs.back().first.record(ctx->stream);
-#define SKH_SEED_DIRECT(K15, W) SKH_LAUNCH((seed_tiles_kernel<K15, true, W>), nt, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p, \
-                       (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE, \
-                       (uint32_t*)nullptr, (uint16_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, dir)
-            if (sp.k == 15) { if (wide) SKH_SEED_DIRECT(true, true); else SKH_SEED_DIRECT(true, false); }
-            else { if (wide) SKH_SEED_DIRECT(false, true); else SKH_SEED_DIRECT(false, false); }
-#undef SKH_SEED_DIRECT
-            check_launch("seed_tiles_kernel (direct)");
-            evs.back().second.record(ctx->stream);
-            SKH_LAUNCH(gather_u64x2_at_kernel, (unsigned)((want.size() + 255) / 256), 256, 0, ctx->stream, (const unsigned long long*)tile_excl, (const uint32_t*)d_want, (uint32_t)want.size(), d_got);
-            check_launch("gather_u64x2_at");
-            std::vector<unsigned long long> got(2 * want.size() + 1);
-            d2h(got.data(), d_got, got.size() * 8, ctx->stream);                         // the launch's one read-back (synchronises)
-            p.ns = got[2 * (want.size() - 1)]; p.nm = got[2 * (want.size() - 1) + 1];
-            if ((uint32_t)got[2 * want.size()] == 0) {
-                for (size_t x = 0; x < want_g.size(); x++) { g_ns[want_g[x]] = base_s + got[2 * x]; g_nm[want_g[x]] = base_m + got[2 * x + 1]; }
-                break;
-            }
-            if (attempt) throw Error("seeding: the repeated launch overflowed its arrays again");
-            cap_s = p.ns; cap_m = p.nm;                                                  // exact: the scan does not depend on what was written
-        }
-        tr.mark("seed: tiles kernel (direct) + readback");
-        p.seed.n = p.ns; p.g.n = p.ns; p.mk.n = p.nm; if (wide) p.g64.n = p.ns;           // (the arrays' logical sizes; the blocks behind them are larger)
-        base_s += p.ns; base_m += p.nm;
-        parts.push_back(std::move(p));
-        ctx->arena.reset();
-    }
-    g_ns[ng] = base_s; g_nm[ng] = base_m;
-    for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
-    const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
-    if (parts.size() == 1) {
-        out.seed = std::move(parts[0].seed); out.g = std::move(parts[0].g); out.g64 = std::move(parts[0].g64); out.markers_raw = std::move(parts[0].mk);
-    } else {
-        out.seed.alloc(NS ? NS : 1); out.markers_raw.alloc(NM ? NM : 1);
-        out.g.alloc(NS ? NS : 1); if (wide) out.g64.alloc(NS ? NS : 1);
-        uint64_t so = 0, mo = 0;
-        for (auto& p : parts) {
-            d2d(out.seed.p + so, p.seed.p, p.ns * 4, ctx->stream);
-            d2d(out.g.p + so, p.g.p, p.ns * 4, ctx->stream); if (wide) d2d(out.g64.p + so, p.g64.p, p.ns * 8, ctx->stream);
-            d2d(out.markers_raw.p + mo, p.mk.p, p.nm * 8, ctx->stream);
-            so += p.ns; mo += p.nm;
-        }
-        dsync(ctx->stream);
-        out.seed.n = NS; out.g.n = NS; out.markers_raw.n = NM; if (wide) out.g64.n = NS;
-    }
-    float ms = 0; for (auto& e : evs) ms += DevEvent::ms(e.first, e.second);           // (every launch was followed by a synchronising read-back)
-    ctx->timings.seed_kernel_ms += ms; ctx->timings.seed_kernel_launches += (uint32_t)evs.size();
-}
-
 // async_tail: a set seeded in ONE launch returns with its compaction kernel still queued (no wait, the arena not rewound): the caller queues the table
 // build behind it and prepares that build's host tables meanwhile; out.tail_pending says so
 void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail, bool wide) {
@@ -760,8 +596,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t ng = gs->n_genomes;
     StageTrace tr(ctx);
     out.pos_off.assign(ng + 1, 0); out.mk_off.assign(ng + 1, 0);
-    if (ctx->tune.seed_direct) { seed_genomes_direct(ctx, gs, sp, out, wide, thr, thr_m); return; }
-    // (rounds 1-3, SKH_TUNE_SEED_DIRECT=0) capped tile scratch: 4x the expected hits per tile; tiles that exceed it are re-run with full capacity
+    // capped tile scratch: 4x the expected hits per tile; tiles that exceed it are re-run with full capacity
     const uint32_t cap_s = ctx->tune.seed_tile_cap ? std::min<uint32_t>(SEED_TILE, ctx->tune.seed_tile_cap) : std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
@@ -788,10 +623,10 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         evs.back().first.record(ctx->stream);
         if (sp.k == 15) SKH_LAUNCH(seed_tiles_kernel<true>, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
-                   t_seed, t_loc, t_marker, cnt_s, cnt_m, SeedDirect{});
+                   t_seed, t_loc, t_marker, cnt_s, cnt_m);
         else SKH_LAUNCH(seed_tiles_kernel<false>, nt, SEED_THREADS, cap_s * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                    (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)nullptr, sp.k, thr, thr_m, gs->seeding_mode, cap_s, cap_m,
-                   t_seed, t_loc, t_marker, cnt_s, cnt_m, SeedDirect{});
+                   t_seed, t_loc, t_marker, cnt_s, cnt_m);
         check_launch("seed_tiles_kernel");
         evs.back().second.record(ctx->stream);
         tr.mark("seed: tiles kernel");
@@ -823,10 +658,10 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
             uint32_t* c2 = ctx->arena.get<uint32_t>(2 * (size_t)h_novf);
             if (sp.k == 15) SKH_LAUNCH(seed_tiles_kernel<true>, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                        (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
-                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf, SeedDirect{});
+                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             else SKH_LAUNCH(seed_tiles_kernel<false>, h_novf, SEED_THREADS, SEED_TILE * 2, ctx->stream, (const uint32_t*)gs->packed.p, (const uint32_t*)gs->nmask.p,
                        (const ContigDesc*)gs->d_contigs.p, d_tiles, (const uint32_t*)ovf_list, sp.k, thr, thr_m, gs->seeding_mode, SEED_TILE, SEED_TILE,
-                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf, SeedDirect{});
+                       o_seed2, o_loc2, o_marker2, c2, c2 + h_novf);
             check_launch("seed_tiles_kernel(overflow)");
         }
         p.seed.alloc(p.ns); p.mk.alloc(p.nm);

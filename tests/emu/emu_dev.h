@@ -58,8 +58,6 @@ inline unsigned wave_incl_scan(unsigned v) {
     for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(v, (unsigned)d, 64); if (l >= (unsigned)d) v += t; }
     return v;
 }
-inline void dev_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
-inline unsigned long long dev_load_u64(unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline unsigned long long wave_clock() { return 0; }
 inline void wait_for_value(uint32_t) {}
 inline uint32_t xcc_id() { return 0; }

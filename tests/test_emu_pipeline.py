@@ -124,16 +124,12 @@ def test_emu_seeding_drops_candidates_that_are_not_hits():
     drops = ctypes.c_ulonglong.in_dll(L, "skh_emu_seed_drops")
     g = pc.random_genome(600000, 99)
     low = np.frombuffer((b"ACGTTGCA" * 3000), np.uint8).copy()                # few distinct seeds: a tile beyond the capped scratch
-    # SKH_TUNE_SEED_TILE_CAP=8: the direct seeding's arrays are too small on the first attempt (the launch is repeated with the sizes its scan reported), and
-    # it runs three tiles per launch; with SKH_TUNE_SEED_DIRECT=0 (the per-tile scratch of rounds 1-3) every tile overflows the scratch, counts only, and is
-    # listed by the re-run
-    for tile_cap, direct in ((None, "1"), ("8", "1"), (None, "0"), ("8", "0")):
+    for tile_cap in (None, "8"):                                               # SKH_TUNE_SEED_TILE_CAP=8: every tile overflows the capped scratch, counts only, and is listed by the re-run
         if tile_cap: os.environ["SKH_TUNE_SEED_TILE_CAP"] = tile_cap
-        os.environ["SKH_TUNE_SEED_DIRECT"] = direct
         try:
             c = sk.Context(0, lib=L)
         finally:
-            os.environ.pop("SKH_TUNE_SEED_TILE_CAP", None); os.environ.pop("SKH_TUNE_SEED_DIRECT", None)
+            os.environ.pop("SKH_TUNE_SEED_TILE_CAP", None)
         try:
             before = drops.value
             for mode in (sk.SEED_SCALAR, sk.SEED_AVX2):
@@ -145,6 +141,6 @@ def test_emu_seeding_drops_candidates_that_are_not_hits():
                         e = ss.export(k); s, p, q = o.seeds(pos_order=True)
                         assert np.array_equal(e["seed"], s) and np.array_equal(e["pos"], p) and np.array_equal(e["ctgcanon"], q) and np.array_equal(e["markers"], o.markers())
                     ss.close()
-            assert drops.value - before > (40 if tile_cap else 20), (tile_cap, direct, drops.value - before)   # (with the small cap every drop happens twice)
+            assert drops.value - before > (40 if tile_cap else 20), (tile_cap, drops.value - before)   # (with the small cap every drop happens twice: counting, then listing)
         finally:
             c.close()
