@@ -253,9 +253,10 @@ typedef struct {
     uint64_t n_pairs_mine, n_units_mine, n_units_total;  /* this rank's share of the chaining */
     uint64_t cost_mine, cost_total;                      /* estimated chaining cost (sum of both genomes' marker counts per pair) */
     uint64_t n_genomes_received, bytes_received, bytes_sent;   /* sketches that crossed ranks */
-    uint64_t screen_row_begin, screen_row_end;           /* this rank's rows of the screen */
+    uint64_t screen_row_begin, screen_row_end;           /* this rank's rows of the screen when it is cut by rows (screen_by_key_range == 0) */
     uint64_t n_pairs_home;                               /* pairs of this rank with both sketches its own: chained while the other sketches travel */
     uint64_t exchange_async_us, exchange_wait_us;        /* the sketch exchange from start to last byte, and the part of it the chaining had to wait for */
+    uint64_t screen_by_key_range;                        /* 1: every rank screened a W-th of the markers' key range for all cells (collections whose count matrix fits); 0: its rows */
 } skh_dist_stats;
 /* Collective: every rank of the communicator calls it with its own local set.  Results (global indices, sorted by (i, j), ani > 0.1 as
  * triangle.rs:99) are returned on EVERY rank; n_chained = candidate pairs chained over all ranks.  stats may be NULL. */

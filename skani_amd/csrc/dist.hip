@@ -363,26 +363,56 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         rb[W] = N;
     }
     st.screen_row_begin = rb[me]; st.screen_row_end = rb[me + 1];
-    std::vector<uint32_t> my_i, my_j;
-    local([&] {                                                                     // (local phase 3)
-        if (rb[me + 1] <= rb[me]) return;
-        Stopwatch sw(ctx, &ctx->timings.screen_ms);
-        screen_pairs(ctx, &S, nullptr, identity, SKH_SCREEN_REFS, rescue_small, my_i, my_j, rb[me], rb[me + 1]);
-    });
-    ctx->arena.reset();
-    tr.mark("dist: screen rows");
-    // ---- 4. the candidate list, everywhere (host memory; sorted by (i, j) because the row blocks ascend with the rank), with the status of the phases above
-    struct Cand { uint32_t i, j; };
     std::vector<uint32_t> pi, pj;
-    ex_begin();
-    {
-        std::vector<Cand> mine_c(my_i.size()), all_c; std::vector<uint64_t> np_all;
-        for (size_t x = 0; x < my_i.size(); x++) mine_c[x] = Cand{my_i[x], my_j[x]};
-        gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, np_all, [&](int r) { stop_together("marker sets / screen", r); });
-        pi.resize(all_c.size()); pj.resize(all_c.size());
-        for (size_t x = 0; x < all_c.size(); x++) { pi[x] = all_c[x].i; pj[x] = all_c[x].j; }
+    if (screen_parts_fit(ctx, N)) {
+        // ---- 3. screen by KEY RANGE (round 4; screen.hip): this rank sorts and walks the incidences of a W-th of the markers' leading 16 bases and gets partial counts
+        // for all cells; the non-zero cells are gathered -- with the status of the phases so far -- and every rank adds them up and applies the rule to all rows
+        // itself: the same candidate list everywhere, no list to gather.  (Cut by rows, every rank sorted and walked ALL incidences: the screen did not shrink with W.)
+        st.screen_by_key_range = 1;
+        struct Cell { uint32_t i, j, c, pad; };
+        std::vector<Cell> mine_c, all_c; std::vector<uint64_t> n_all;
+        local([&] {                                                                 // (local phase 3)
+            Stopwatch sw(ctx, &ctx->timings.screen_ms);
+            std::vector<uint32_t> ci, cj, cc;
+            screen_partial_cells(ctx, &S, (uint32_t)me, (uint32_t)W, ci, cj, cc);
+            mine_c.resize(ci.size());
+            for (size_t x = 0; x < ci.size(); x++) mine_c[x] = Cell{ci[x], cj[x], cc[x], 0u};
+        });
+        ctx->arena.reset();
+        tr.mark("dist: screen, my key range");
+        ex_begin();
+        gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, n_all, [&](int r) { stop_together("marker sets / screen", r); });
+        ex_end();
+        local([&] {                                                                 // (local phase 4; a failure is agreed on in front of the sketch exchange)
+            Stopwatch sw(ctx, &ctx->timings.screen_ms);
+            std::vector<uint32_t> ci(all_c.size()), cj(all_c.size()), cc(all_c.size());
+            for (size_t x = 0; x < all_c.size(); x++) { ci[x] = all_c[x].i; cj[x] = all_c[x].j; cc[x] = all_c[x].c; }
+            screen_from_cells(ctx, &S, ci.data(), cj.data(), cc.data(), all_c.size(), identity, rescue_small, pi, pj);
+        });
+        ctx->arena.reset();
+        tr.mark("dist: cells gathered, candidates");
+    } else {
+        // ---- 3'. a collection whose dense count matrix is beyond the screen's budget: cut by rows (every rank walks all incidences and keeps its rows' cells), candidate lists gathered
+        std::vector<uint32_t> my_i, my_j;
+        local([&] {                                                                 // (local phase 3)
+            if (rb[me + 1] <= rb[me]) return;
+            Stopwatch sw(ctx, &ctx->timings.screen_ms);
+            screen_pairs(ctx, &S, nullptr, identity, SKH_SCREEN_REFS, rescue_small, my_i, my_j, rb[me], rb[me + 1]);
+        });
+        local_phase++;                                                              // (the key-range form has two screen phases: the numbering of the later ones stays the same)
+        ctx->arena.reset();
+        tr.mark("dist: screen rows");
+        struct Cand { uint32_t i, j; };
+        ex_begin();
+        {
+            std::vector<Cand> mine_c(my_i.size()), all_c; std::vector<uint64_t> np_all;
+            for (size_t x = 0; x < my_i.size(); x++) mine_c[x] = Cand{my_i[x], my_j[x]};
+            gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, np_all, [&](int r) { stop_together("marker sets / screen", r); });
+            pi.resize(all_c.size()); pj.resize(all_c.size());
+            for (size_t x = 0; x < all_c.size(); x++) { pi[x] = all_c[x].i; pj[x] = all_c[x].j; }
+        }
+        ex_end();
     }
-    ex_end();
     const size_t NP = pi.size();
     st.n_candidate_pairs_total = NP;
     if (n_chained) *n_chained = NP;
@@ -442,7 +472,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     uint32_t *d_send = nullptr, *d_recv = nullptr;
     // the exchange buffers live outside the arena: the chaining of the home pairs resets it while they are in flight
     DBuf<uint32_t> send_buf, recv_buf;
-    local([&] {                                                                     // (local phase 4)
+    local([&] {                                                                     // (local phase 5)
         send_buf.alloc(sw + 1); recv_buf.alloc(rw + 1); d_send = send_buf.p; d_recv = recv_buf.p;
         copy_segments(ctx, L->p_seed.p, d_send, seg_s);
         if (wide_any) {
@@ -476,7 +506,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         finalize_metadata(X);
         X->markers.alloc(1);                                                        // (the chaining takes the marker COUNTS, chain.rs:625-649; the sets themselves stay in S)
     };
-    local([&] {                                                                     // (local phase 5)
+    local([&] {                                                                     // (local phase 6)
         if (!compact_home) { for (uint32_t g : home_ids) { wk_set[g] = 0; wk_index[g] = (uint32_t)(g - base[me]); } return; }
         Wh.reset(new skh_sketch_set());
         describe(Wh.get(), home_ids, 0);
@@ -487,7 +517,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         copy_segments(ctx, L->p_seed.p, Wh->p_seed.p, seg); copy_segments(ctx, L->p_g.p, Wh->p_g.p, seg);
         H = Wh.get();
     });
-    local([&] { if (home_ids.empty()) return; Stopwatch swb(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, H); });   // (local phase 6)
+    local([&] { if (home_ids.empty()) return; Stopwatch swb(ctx, &ctx->timings.sketch_build_ms); ensure_tables(ctx, H); });   // (local phase 7)
     ctx->arena.reset();
     tr.mark("dist: home set indexed");
     // this rank's pairs: ref = genome i, query = genome j (triangle.rs:89-98); home pairs first
@@ -515,7 +545,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         chain_pairs(ctx, sets, Wr ? 2u : 1u, rs.data(), sets, Wr ? 2u : 1u, qs.data(), rr.data(), qq.data(), sel.size(), mp, part.data(), nullptr, true);
         for (size_t x = 0; x < sel.size(); x++) res[sel[x]] = part[x];
     };
-    local([&] { chain_selected(sel_home); });                                       // (local phase 7)
+    local([&] { chain_selected(sel_home); });                                       // (local phase 8)
     ctx->arena.reset();
     tr.mark("dist: home pairs chained");
     // -- the sketches have arrived (whatever happened above, the exchange is waited for: nobody may be left inside it)
@@ -525,7 +555,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         dsync(ctx->stream);
         exch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
-    local([&] {                                                                     // (local phase 8)
+    local([&] {                                                                     // (local phase 9)
         if (!nR) return;
         Wr.reset(new skh_sketch_set());
         describe(Wr.get(), away_ids, 1);
@@ -548,7 +578,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     });
     ctx->arena.reset();
     tr.mark("dist: received sketches indexed");
-    local([&] { chain_selected(sel_away); });                                       // (local phase 9)
+    local([&] { chain_selected(sel_away); });                                       // (local phase 10)
     ctx->arena.reset();
     tr.mark("dist: away pairs chained");
     T.exchange_times(&st.exchange_async_us, &st.exchange_wait_us);

@@ -258,6 +258,13 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)
 
+// the triangle screen cut by key range (the distributed triangle): the non-zero cells of the partial count matrix of part `part` of the markers' leading
+// 16 bases, and the candidate pairs from the gathered cells of all parts (every rank gets the same list).  screen_parts_fit: the dense matrix is within the screen's budget.
+bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes);
+void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint32_t>& ci, std::vector<uint32_t>& cj, std::vector<uint32_t>& cc);
+void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n_cells, double identity, int rescue_small,
+                       std::vector<uint32_t>& first, std::vector<uint32_t>& second);
+
 // ---- dist.hip
 void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std::vector<uint32_t>& pj, const std::vector<uint64_t>& weight, const std::vector<int>& holder,
                   int world, std::vector<uint8_t>& owner, std::vector<uint64_t>& units_of, std::vector<uint64_t>& load);

@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* q
 }
 
 struct ScreenRule { double cutoff; int rule; int rescue_small; int triangle; };
+constexpr int SCREEN_RULE_NONZERO = 100;                                          // internal: "the cell has a count" (the partial counts of a key range, screen_partial_cells)
 
 __device__ __forceinline__ bool cell_passes(const ScreenRule& sr, uint32_t count, uint64_t m_row, uint64_t m_col, uint32_t row, uint32_t col) {
     if (sr.triangle && col <= row) return false;                                 // triangle.rs:90
+    if (sr.rule == SCREEN_RULE_NONZERO) return count != 0;
     const uint64_t mn = m_row < m_col ? m_row : m_col;
     if (sr.rule == SKH_SCREEN_QUICK) {                                           // screen.rs:84-142
         if (mn < SCREEN_MIN_KMERS && sr.rescue_small) return true;
@@ -113,7 +115,7 @@ __device__ __forceinline__ bool cell_passes(const ScreenRule& sr, uint32_t count
 // one workgroup per row: pass 0 counts passing cells, pass 1 writes them in column order
 __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t ncols, ScreenRule sr,
                                                                const uint64_t* mk_off_rows, const uint64_t* mk_off_cols, int pass,
-                                                               uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second) {
+                                                               uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second, uint32_t* out_count /* may be null */) {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t running;
     const uint32_t r = blockIdx.x, row = row0 + r;
@@ -124,9 +126,8 @@ __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* c
     const uint32_t base_out = pass ? row_off[r] : 0;
     for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
         const uint32_t col = c0 + threadIdx.x;
-        bool ok = false;
+        bool ok = false; uint32_t count = 0;
         if (col < ncols) {
-            uint32_t count = 0;
             for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + col];
             ok = cell_passes(sr, count, m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
         }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* c
         uint32_t before = 0, tot = 0;
         for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { uint32_t t = lds[i]; if (i < w) before += t; tot += t; }
         const uint32_t run = running;
-        if (pass && ok) { const uint32_t o = base_out + run + before + incl - 1; out_first[o] = row; out_second[o] = col; }
+        if (pass && ok) { const uint32_t o = base_out + run + before + incl - 1; out_first[o] = row; out_second[o] = col; if (out_count) out_count[o] = count; }
         __syncthreads();
         if (threadIdx.x == 0) running = run + tot;
         __syncthreads();
@@ -239,7 +240,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
             check_launch("screen_count");
         }
         SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
-                   (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                   (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
         check_launch("screen_threshold0");
         exclusive_scan_u32(ctx, row_cnt, rows, row_off);
         uint32_t total = 0;
@@ -247,7 +248,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         if (total) {
             uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total);
             SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
-                       (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os);
+                       (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os, (uint32_t*)nullptr);
             check_launch("screen_threshold1");
             size_t old = first.size(); first.resize(old + total); second.resize(old + total);
             d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
@@ -255,6 +256,102 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     }
     dsync(ctx->stream);
     tr.mark("screen: count + threshold");
+}
+
+// ---- the triangle screen cut by KEY RANGE (the distributed triangle, dist.hip).  Every rank holds all marker sets; cutting the triangle by rows made every
+// rank sort and walk ALL (marker, genome) incidences and only spared it the increments of the other ranks' rows -- the screen did not get faster with the
+// number of GPUs.  Cut by the marker's leading 16 bases instead, a rank sorts and walks a W-th of the incidences (a marker's incidences all lie in one
+// range) and gets PARTIAL counts for all cells; the non-zero cells (the pairs that share a marker of the range: a few per related pair) are gathered, every
+// rank adds them up in a dense matrix and applies the rule to all rows itself -- the same candidate list on every rank, no list to gather.
+// A genome's markers are sorted, and the key's sorted field (marker >> 10) rises with the marker: the markers of a range are a stretch of every genome's set.
+__global__ __launch_bounds__(256) void screen_part_ranges_kernel(const uint64_t* markers, const uint64_t* mk_off, uint32_t ng, uint64_t lo_marker, uint64_t hi_marker /* 0 = no upper bound */,
+                                                                 uint64_t* range_lo, uint32_t* range_cnt) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const uint64_t a = mk_off[g], b = mk_off[g + 1];
+    auto first_ge = [&](uint64_t v) { uint64_t lo = a, hi = b; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (markers[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
+    const uint64_t x = first_ge(lo_marker), y = hi_marker ? first_ge(hi_marker) : b;
+    range_lo[g] = x; range_cnt[g] = (uint32_t)(y - x);
+}
+__global__ __launch_bounds__(256) void screen_part_keys_kernel(const uint64_t* markers, const uint64_t* range_lo, const uint32_t* part_off, uint32_t ng, uint32_t n, uint64_t* keys) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    uint32_t lo = 0, hi = ng;                                                        // the genome of output e: largest g with part_off[g] <= e
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (part_off[mid] <= e) lo = mid; else hi = mid; }
+    keys[e] = screen_key(markers[range_lo[lo] + (e - part_off[lo])], 0u, lo);
+}
+__global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n, uint32_t ncols, uint32_t* cnt) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) atomicAdd(&cnt[(uint64_t)ci[e] * ncols + cj[e]], cc[e]);
+}
+
+// rows [0, rows) of a dense count matrix through the rule: the passing (row, col[, count]) cells in (row, col) order, on the host
+static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t rows, uint32_t ncols, const ScreenRule& sr, const uint64_t* d_mk_rows,
+                           const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, std::vector<uint32_t>* counts) {
+    uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows); uint32_t* row_off = ctx->arena.get<uint32_t>(rows + 1);
+    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    check_launch("screen_threshold0");
+    exclusive_scan_u32(ctx, row_cnt, rows, row_off);
+    uint32_t total = 0;
+    d2h(&total, row_off + rows, 4, ctx->stream);
+    if (!total) return;
+    uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total); uint32_t* oc = counts ? ctx->arena.get<uint32_t>(total) : nullptr;
+    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 1, row_cnt, (const uint32_t*)row_off, of, os, oc);
+    check_launch("screen_threshold1");
+    const size_t old = first.size(); first.resize(old + total); second.resize(old + total);
+    d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
+    if (counts) { counts->resize(old + total); d2h(counts->data() + old, oc, (size_t)total * 4, ctx->stream); }
+}
+
+bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes) { return n_genomes && (uint64_t)n_genomes * n_genomes <= ctx->tune.screen_cells && n_genomes <= ID_MASK; }
+
+// the non-zero cells of the triangle's count matrix over the markers whose leading 16 bases fall into part `part` of `n_parts`
+void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint32_t>& ci, std::vector<uint32_t>& cj, std::vector<uint32_t>& cc) {
+    ci.clear(); cj.clear(); cc.clear();
+    const uint32_t N = S->n_genomes;
+    if (!screen_parts_fit(ctx, N)) throw Error("screen_partial_cells: the count matrix does not fit");
+    if (!S->mk_off[N]) return;
+    auto bound = [&](uint32_t r) { return r >= n_parts ? 0ull : ((((uint64_t)r << 32) + n_parts - 1) / n_parts) << 10; };   // the smallest marker of part r (its sorted field is marker >> 10)
+    uint64_t* range_lo = ctx->arena.get<uint64_t>(N); uint32_t* range_cnt = ctx->arena.get<uint32_t>(N); uint32_t* part_off = ctx->arena.get<uint32_t>(N + 1);
+    SKH_LAUNCH(screen_part_ranges_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)S->d_mk_off.p, N, bound(part), bound(part + 1), range_lo, range_cnt);
+    check_launch("screen_part_ranges");
+    exclusive_scan_u32(ctx, range_cnt, N, part_off);
+    uint32_t n = 0;
+    d2h(&n, part_off + N, 4, ctx->stream);
+    if (!n) return;
+    uint64_t* raw = ctx->arena.get<uint64_t>(n); uint64_t* keys = ctx->arena.get<uint64_t>(n);
+    SKH_LAUNCH(screen_part_keys_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)range_lo, (const uint32_t*)part_off, N, n, raw);
+    check_launch("screen_part_keys");
+    sort_keys_u64_into(ctx, raw, keys, n, SCREEN_SORT_BITS);
+    const uint64_t plane = (uint64_t)N * N;
+    uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
+    dzero(cnt, plane * 4, ctx->stream);
+    SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, 1u, plane);
+    check_launch("screen_count(part)");
+    const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
+    threshold_rows(ctx, cnt, 1, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, ci, cj, &cc);
+    dsync(ctx->stream);
+}
+
+// the triangle's candidate pairs from the gathered cells of all parts: counts added up in a dense matrix, every row through the rule (triangle.rs:71-90 with screen_refs)
+void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n_cells, double identity, int rescue_small,
+                       std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
+    first.clear(); second.clear();
+    if (identity == 0.) identity = 0.80;
+    const uint32_t N = S->n_genomes;
+    if (!screen_parts_fit(ctx, N)) throw Error("screen_from_cells: the count matrix does not fit");
+    const uint64_t plane = (uint64_t)N * N;
+    uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
+    dzero(cnt, plane * 4, ctx->stream);
+    if (n_cells) {
+        uint32_t* d = ctx->arena.get<uint32_t>(3 * n_cells);
+        h2d_big(d, ci, n_cells * 4, ctx->stream); h2d_big(d + n_cells, cj, n_cells * 4, ctx->stream); h2d_big(d + 2 * n_cells, cc, n_cells * 4, ctx->stream);
+        SKH_LAUNCH(screen_add_cells_kernel, (unsigned)((n_cells + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)d, (const uint32_t*)(d + n_cells), (const uint32_t*)(d + 2 * n_cells), n_cells, N, cnt);
+        check_launch("screen_add_cells");
+    }
+    const ScreenRule sr{powi21(identity), SKH_SCREEN_REFS, rescue_small, 1};
+    threshold_rows(ctx, cnt, 1, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, first, second, nullptr);
+    dsync(ctx->stream);
 }
 
 }  // namespace skh

@@ -58,6 +58,7 @@ def _worker(rank, world, port, q, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if _wide_span_of(case, rank) is not None: os.environ["SKH_TUNE_WIDE_SPAN"] = _wide_span_of(case, rank)
+        if case == "uneven": os.environ["SKH_TUNE_SCREEN_CELLS"] = "40"      # a count matrix of 12 x 12 cells does not fit: the screen is cut by rows (the form of very large collections)
         ctx = sk.Context(0, lib=emu_lib())
         genomes, held = _case(case)
         base = sum(held[:rank])
@@ -107,6 +108,7 @@ def test_multi_rank_triangle_matches_single_process(case):
     # the shares: every candidate pair is chained exactly once, the screen rows tile [0, N)
     stats = [g[5] for g in got]
     assert sum(s["n_pairs_mine"] for s in stats) == n and all(s["n_candidate_pairs_total"] == n and s["n_genomes_total"] == len(genomes) for s in stats)
+    assert all(s["screen_by_key_range"] == (0 if case == "uneven" else 1) for s in stats)
     assert stats[0]["screen_row_begin"] == 0 and stats[-1]["screen_row_end"] == len(genomes)
     assert all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))
     if case == "blocks":        # one cluster per rank: nothing travels
@@ -144,11 +146,12 @@ def _failing_worker(rank, world, port, q, fail_rank, phase):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("phase", [1, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("phase", [1, 3, 4, 5, 7, 8, 9, 10])
 def test_failure_on_one_rank_stops_every_rank(phase):
-    """One rank fails in a local phase (injected: marker buffers, screen, exchange buffers, home tables, home pairs -- while the sketch exchange is in
-    flight --, received sketches, away pairs): at the next exchange point all ranks agree on it and return an error -- nobody waits in a collective
-    for a rank that has left, and the asynchronous exchange is closed on every path (dist.hip `agree`, ExchangeGuard)."""
+    """One rank fails in a local phase (injected: marker buffers, the screen of its key range, the candidate list from the gathered cells, exchange buffers,
+    home tables, home pairs -- while the sketch exchange is in flight --, received sketches, away pairs): at the next exchange point all ranks agree on it
+    and return an error -- nobody waits in a collective for a rank that has left, and the asynchronous exchange is closed on every path (dist.hip `agree`,
+    ExchangeGuard)."""
     import multiprocessing as mp
     from tests.emu_lib import emu_lib
     emu_lib()
