@@ -364,7 +364,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.screen_row_begin = rb[me]; st.screen_row_end = rb[me + 1];
     std::vector<uint32_t> pi, pj;
-    if (screen_parts_fit(ctx, N)) {
+    if (W > 1 && screen_parts_fit(ctx, N)) {                                        // (a world of one has nothing to cut: the row form, which is skh_triangle's own screen)
         // ---- 3. screen by KEY RANGE (round 4; screen.hip): this rank sorts and walks the incidences of a W-th of the markers' leading 16 bases and gets partial counts
         // for all cells; the non-zero cells are gathered -- with the status of the phases so far -- and every rank adds them up and applies the rule to all rows
         // itself: the same candidate list everywhere, no list to gather.  (Cut by rows, every rank sorted and walked ALL incidences: the screen did not shrink with W.)

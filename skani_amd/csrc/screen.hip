@@ -324,12 +324,15 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
     check_launch("screen_part_keys");
     sort_keys_u64_into(ctx, raw, keys, n, SCREEN_SORT_BITS);
     const uint64_t plane = (uint64_t)N * N;
-    uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
-    dzero(cnt, plane * 4, ctx->stream);
-    SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, 1u, plane);
+    // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
+    const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
+    const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
+    uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
+    dzero(cnt, plane * n_planes * 4, ctx->stream);
+    SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane);
     check_launch("screen_count(part)");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
-    threshold_rows(ctx, cnt, 1, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, ci, cj, &cc);
+    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, ci, cj, &cc);
     dsync(ctx->stream);
 }
 

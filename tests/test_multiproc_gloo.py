@@ -462,7 +462,7 @@ def test_rccl_world_size_one():
         assert "librccl" in open("/proc/self/maps").read()
         si, sj, sres, sn = ctx.triangle(ss, mp_)
         assert n == sn == 380 and np.array_equal(i, si) and np.array_equal(j, sj) and res.tobytes() == sres.tobytes()
-        assert st["n_pairs_mine"] == 380 and st["n_genomes_received"] == 0 and st["screen_row_begin"] == 0 and st["screen_row_end"] == 40
+        assert st["n_pairs_mine"] == 380 and st["n_genomes_received"] == 0 and st["screen_row_begin"] == 0 and st["screen_row_end"] == 40 and st["screen_by_key_range"] == 0
         osk = [ora.sketch_records(g, file_name="s%05d.fa" % k) for k, g in enumerate(host)]
         oi, oj, ores, onch, _ = ora.triangle(osk, model=ora.Model(MODEL_C125))
         assert onch == 380 and np.array_equal(i, oi) and np.array_equal(j, oj)
