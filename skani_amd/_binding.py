@@ -47,7 +47,7 @@ class HostCollectives(C.Structure):
 EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "skh_load_models", "skh_genomes_pack",
            "skh_host_alloc", "skh_host_free", "skh_genomes_begin", "skh_genomes_append", "skh_genomes_wait", "skh_genomes_finish",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
-           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_is_wide", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_chain_pairs", "skh_chain_pairs_multi",
+           "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_is_wide", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_screen_part", "skh_screen_from_cells", "skh_chain_pairs", "skh_chain_pairs_multi",
            "skh_triangle", "skh_get_timings", "skh_device_memory", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_comm_selftest", "skh_triangle_distributed", "skh_plan_pairs"]
 RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
 
@@ -89,6 +89,8 @@ def load(path):
     L.skh_sketch_import_flat.argtypes = [vp, C.POINTER(SketchParams), u32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp]
     L.skh_screen.restype = i32; L.skh_screen.argtypes = [vp, vp, vp, dbl, i32, i32, pp, pp, C.POINTER(u64)]
     L.skh_screen_rows.restype = i32; L.skh_screen_rows.argtypes = [vp, vp, u32, u32, dbl, i32, pp, pp, C.POINTER(u64)]
+    L.skh_screen_part.restype = i32; L.skh_screen_part.argtypes = [vp, vp, u32, u32, pp, pp, pp, C.POINTER(u64)]
+    L.skh_screen_from_cells.restype = i32; L.skh_screen_from_cells.argtypes = [vp, vp, vp, vp, vp, u64, dbl, i32, pp, pp, C.POINTER(u64)]
     L.skh_chain_pairs.restype = i32; L.skh_chain_pairs.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp, vp]
     L.skh_chain_pairs_multi.restype = i32; L.skh_chain_pairs_multi.argtypes = [vp, vp, u32, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp]
     L.skh_triangle.restype = i32
