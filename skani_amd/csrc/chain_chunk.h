@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
         if (sampled) narrow_by_samples<true>(ss, ns_s, 0, q_pair_last, sf_lo, sf_hi);
         uint32_t s_final = 0;                                                       // the pair's final chunk ends its seed range here (chain.rs:794-824): searched beside the first contigs' searches
         // 64 query contigs per round, one per lane: the contig's anchor range [ca, ce), its first position rc0 and its number of end points;
-        // then the (contig, k) items of the round are worked off 256 at a time, FOUR PER LANE (round 4: their eight boundary searches advance together --
-        // three dependent round trips to memory per 256 items instead of per 64; the kernel is a chain of such round trips, ~30 per pair before, ~12 now)
+        // then the (contig, k) items of the round are worked off 64 at a time -- a genome in a thousand contigs costs rounds of searches by the
+        // sixty-fourth of its contigs, not by the contig.  (Round 4 measured FOUR items per lane, their eight searches advancing together -- a third of the
+        // dependent round trips: 0.78 instead of 0.45 ms, the search state of eight ranges does not stay in registers (scratch), so every step pays for it.)
         uint32_t carry_cid = NONE, carry_t = 0, carry_s = 0; int32_t carry_uu = 0;
         for (uint32_t c0 = 0; c0 < nctg; c0 += 64) {
             const uint32_t cl = c0 + l; const bool cv = cl < nctg;
@@ -137,94 +138,52 @@ __global__ __launch_bounds__(256) void chunk_kernel(uint32_t n_pairs, const Pair
             const Co q_first = has ? anc_q[ca] : (Co)0, q_last = has ? anc_q[ce - 1] : (Co)0;
             const uint32_t kmax = has ? (uint32_t)((q_last - q_first) / CHUNK_SIZE) + 1u : 0u;  // lim_k reaches the contig's last anchor no later than this
             const uint32_t P = wave_incl_scan(kmax), M = __shfl(P, 63, 64);
-            constexpr int IP = 4;                                                   // items per lane: lane l owns items j0 + IP l .. + IP - 1 (consecutive: the running maximum stays in the lane)
-            for (uint32_t j0 = 0; j0 < M; j0 += 64 * IP) {
-                bool iv[IP]; uint32_t k[IP], a_c[IP], e_c[IP], r_c[IP], cid[IP], qcs[IP]; Co lim[IP], cs_[IP];
-                uint32_t lo8[2 * IP], hi8[2 * IP]; Co vv[2 * IP];
+            for (uint32_t j0 = 0; j0 < M; j0 += 64) {
+                const uint32_t j = j0 + l; const bool iv = j < M;
+                uint32_t slo = 0, shi = 63;                                        // the lane (contig) that owns item j: first with P > j
 #pragma unroll
-                for (int u = 0; u < IP; u++) {
-                    const uint32_t j = j0 + (uint32_t)IP * l + (uint32_t)u; iv[u] = j < M;
-                    uint32_t slo = 0, shi = 63;                                    // the lane (contig) that owns item j: first with P > j
-#pragma unroll
-                    for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; const uint32_t pm = __shfl(P, (int)mid, 64); if (pm > j) shi = mid; else slo = mid + 1; }
-                    const int src = (int)(iv[u] ? slo : 63u);
-                    const uint32_t o_kmax = __shfl(kmax, src, 64), o_P = __shfl(P, src, 64);
-                    a_c[u] = __shfl(ca, src, 64); e_c[u] = __shfl(ce, src, 64); r_c[u] = __shfl(rc0, src, 64);
-                    const Co qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64); cs_[u] = __shfl(cstart, src, 64);
-                    k[u] = j - (o_P - o_kmax) + 1u;
-                    const uint64_t end64 = (uint64_t)qf + (uint64_t)k[u] * CHUNK_SIZE;
-                    lim[u] = end64 < (uint64_t)(cn - 1) ? (Co)end64 : cn - 1;    // beyond it: another contig, or past the window
-                    cid[u] = iv[u] ? c0 + (uint32_t)src : 0xFFFFFF00u + (uint32_t)IP * l + (uint32_t)u;   // items that do not exist: segments of their own
-                    qcs[u] = c0 + (uint32_t)src;
-                    //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
-                    //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
-                    lo8[2 * u] = a_c[u]; hi8[2 * u] = iv[u] ? A1 : a_c[u]; lo8[2 * u + 1] = 0; hi8[2 * u + 1] = iv[u] ? Q1 : 0;
-                    if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim[u], lo8[2 * u], hi8[2 * u]); narrow_by_samples<true>(ss, ns_s, 0, lim[u], lo8[2 * u + 1], hi8[2 * u + 1]); }
-                    vv[2 * u] = lim[u]; vv[2 * u + 1] = lim[u];
-                }
+                for (int st = 0; st < 6; st++) { const uint32_t mid = (slo + shi) >> 1; const uint32_t pm = __shfl(P, (int)mid, 64); if (pm > j) shi = mid; else slo = mid + 1; }
+                const int src = (int)(iv ? slo : 63u);
+                const uint32_t o_kmax = __shfl(kmax, src, 64), o_P = __shfl(P, src, 64), a_c = __shfl(ca, src, 64), e_c = __shfl(ce, src, 64), r_c = __shfl(rc0, src, 64);
+                const Co qf = __shfl(q_first, src, 64), cn = __shfl(cnext, src, 64), cs = __shfl(cstart, src, 64);
+                const uint32_t k = j - (o_P - o_kmax) + 1u;
+                const uint64_t end64 = (uint64_t)qf + (uint64_t)k * CHUNK_SIZE;
+                const Co lim = end64 < (uint64_t)(cn - 1) ? (Co)end64 : cn - 1;   // beyond it: another contig, or past the window
+                //   b  = first anchor beyond lim (searching all of the pair's later anchors gives the same answer as searching the contig,
+                //        because the contig's successor already lies beyond lim);  sb = first position beyond lim = seed list boundary after chunk k
+                uint32_t lo_b = a_c, hi_b = iv ? A1 : a_c, lo_s = 0, hi_s = iv ? Q1 : 0;
+                if (sampled) { narrow_by_samples<true>(sa, ns_a, A0, lim, lo_b, hi_b); narrow_by_samples<true>(ss, ns_s, 0, lim, lo_s, hi_s); }
                 {
-                    const Arr arr[2 * IP] = {anc_arr, ag, anc_arr, ag, anc_arr, ag, anc_arr, ag}; const uint32_t sh[2 * IP] = {0, 1, 0, 1, 0, 1, 0, 1};
-                    const bool up[2 * IP] = {true, true, true, true, true, true, true, true};
-                    search_together<2 * IP, Arr, Co>(arr, sh, lo8, hi8, vv, up);
+                    const Arr arr[2] = {anc_arr, ag}; const uint32_t sh[2] = {0, 1}; const Co vv[2] = {lim, lim}; const bool up[2] = {true, true};
+                    uint32_t lo2[2] = {lo_b, lo_s}, hi2[2] = {hi_b, hi_s};
+                    search_together<2, Arr, Co>(arr, sh, lo2, hi2, vv, up);
+                    lo_b = lo2[0]; lo_s = lo2[1];
                 }
-                // u_k = bnd - k, running maximum within the contig: inside the lane over its items, then across the lanes (a lane hands on its last item's value
-                // when all its items belong to one contig, else the value of its last contig's run), then applied to the lane's leading run
-                int32_t v[IP]; uint32_t sb[IP];
+                const uint32_t bnd = lo_b, sb = lo_s;
+                const uint32_t cid = iv ? c0 + (uint32_t)src : 0xFFFFFF00u + l;    // lanes without an item: segments of their own
+                int32_t v = (int32_t)bnd - (int32_t)k;                              // u_k
+                if (k == 1) v = v > (int32_t)a_c ? v : (int32_t)a_c;                // u_0 = t_0 = the contig's first anchor
+                if (l == 0 && cid == carry_cid) v = v > carry_uu ? v : carry_uu;    // the contig continues from the previous batch
 #pragma unroll
-                for (int u = 0; u < IP; u++) {
-                    sb[u] = lo8[2 * u + 1];
-                    v[u] = (int32_t)lo8[2 * u] - (int32_t)k[u];                    // u_k
-                    if (k[u] == 1) v[u] = v[u] > (int32_t)a_c[u] ? v[u] : (int32_t)a_c[u];   // u_0 = t_0 = the contig's first anchor
-                    if (u > 0 && cid[u] == cid[u - 1]) v[u] = v[u - 1] > v[u] ? v[u - 1] : v[u];
+                for (int d = 1; d < 64; d <<= 1) {                                  // running maximum within the contig
+                    const int32_t tv = __shfl_up(v, d, 64); const uint32_t tc = __shfl_up(cid, d, 64);
+                    if (l >= (uint32_t)d && tc == cid) v = tv > v ? tv : v;
                 }
-                bool one = true;
-#pragma unroll
-                for (int u = 1; u < IP; u++) one = one && cid[u] == cid[0];
-                // inclusive scan over the lanes of (last contig, its running value, "the whole lane is that contig")
-                uint32_t sc = cid[IP - 1]; int32_t sv = v[IP - 1]; bool sone = one;
-                if (l == 0 && cid[0] == carry_cid) { if (one) sv = sv > carry_uu ? sv : carry_uu; }   // (the carry enters lane 0's leading run below as well)
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t tc = __shfl_up(sc, d, 64); const int32_t tv = __shfl_up(sv, d, 64); const bool tone = __shfl_up((int)sone, d, 64) != 0;
-                    if (l >= (uint32_t)d && sone && tc == sc) { sv = tv > sv ? tv : sv; sone = tone; }
+                const uint32_t t = (uint32_t)(v + (int32_t)k);                      // t_k (may run past e: the chunk is then cut at e)
+                uint32_t t_prev = __shfl_up(t, 1, 64), s_prev = __shfl_up(sb, 1, 64);
+                if (l == 0) { t_prev = carry_t; s_prev = carry_s; }
+                if (k == 1) { t_prev = a_c; s_prev = r_c; }
+                const bool valid = iv && t_prev < e_c;                              // chunk k exists
+                Chunk ck; ck.a_begin = t_prev; ck.a_end = t < e_c ? t : e_c; ck.s_begin = s_prev; ck.s_end = sb; ck.qoff = (uint32_t)cs; ck.qctg = c0 + (uint32_t)src;
+                if (valid && ck.a_end == A1) ck.s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
+                const unsigned long long vm = __ballot(valid);
+                const uint32_t slot = C0 + nc + (uint32_t)__popcll(vm & ((1ull << l) - 1ull));
+                if (valid) {
+                    if (slot < C1) { chunks[slot] = ck; chunk_pair[slot] = p; }
+                    else atomicAdd(err, 1u);
                 }
-                // what arrives from the lane before: its last contig and running value
-                uint32_t in_c = __shfl_up(sc, 1, 64); int32_t in_v = __shfl_up(sv, 1, 64);
-                if (l == 0) { in_c = carry_cid; in_v = carry_uu; }
-#pragma unroll
-                for (int u = 0; u < IP; u++) {
-                    bool lead = cid[u] == cid[0];
-#pragma unroll
-                    for (int w = 1; w <= u; w++) lead = lead && cid[w] == cid[0];
-                    if (lead && cid[0] == in_c) v[u] = v[u] > in_v ? v[u] : in_v;
-                }
-                uint32_t t[IP];
-#pragma unroll
-                for (int u = 0; u < IP; u++) t[u] = (uint32_t)(v[u] + (int32_t)k[u]);  // t_k (may run past e: the chunk is then cut at e)
-                uint32_t t_in = __shfl_up(t[IP - 1], 1, 64), s_in = __shfl_up(sb[IP - 1], 1, 64);
-                if (l == 0) { t_in = carry_t; s_in = carry_s; }
-                bool valid[IP]; Chunk ck[IP]; uint32_t n_valid = 0;
-#pragma unroll
-                for (int u = 0; u < IP; u++) {
-                    uint32_t t_prev = u ? t[u - 1] : t_in, s_prev = u ? sb[u - 1] : s_in;
-                    if (k[u] == 1) { t_prev = a_c[u]; s_prev = r_c[u]; }
-                    valid[u] = iv[u] && t_prev < e_c[u];                            // chunk k exists
-                    ck[u].a_begin = t_prev; ck[u].a_end = t[u] < e_c[u] ? t[u] : e_c[u]; ck[u].s_begin = s_prev; ck[u].s_end = sb[u]; ck[u].qoff = (uint32_t)cs_[u]; ck[u].qctg = qcs[u];
-                    if (valid[u] && ck[u].a_end == A1) ck[u].s_end = s_final > s_prev ? s_final : s_prev;   // the pair's final chunk
-                    n_valid += valid[u] ? 1u : 0u;
-                }
-                const uint32_t incl = wave_incl_scan(n_valid), tot_valid = __shfl(incl, 63, 64);
-                uint32_t slot = C0 + nc + incl - n_valid;
-#pragma unroll
-                for (int u = 0; u < IP; u++) {
-                    if (valid[u]) {
-                        if (slot < C1) { chunks[slot] = ck[u]; chunk_pair[slot] = p; }
-                        else atomicAdd(err, 1u);
-                        slot++;
-                    }
-                }
-                nc += tot_valid;
-                carry_cid = __shfl(cid[IP - 1], 63, 64); carry_uu = __shfl(v[IP - 1], 63, 64); carry_t = __shfl(t[IP - 1], 63, 64); carry_s = __shfl(sb[IP - 1], 63, 64);
+                nc += (uint32_t)__popcll(vm);
+                carry_cid = __shfl(cid, 63, 64); carry_uu = __shfl(v, 63, 64); carry_t = __shfl(t, 63, 64); carry_s = __shfl(sb, 63, 64);
             }
         }
     }
