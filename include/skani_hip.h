@@ -205,13 +205,13 @@ int skh_screen_rows(skh_ctx*, const skh_sketch_set* set, uint32_t row0, uint32_t
                     uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs);
 
 /* The triangle's screen cut by KEY RANGE instead of by rows -- how skh_triangle_distributed shares it among GPUs that all hold the marker sets, exposed for
- * hosts that run their own distribution.  skh_screen_part: the non-zero cells (i < j, count of shared markers) of the triangle's count matrix over the
+ * hosts that run their own distribution.  skh_screen_part: the non-zero cells (i < j, count of shared markers; one 64-bit word each) of the triangle's count matrix over the
  * markers whose leading 16 bases fall into part `part` of `n_parts` -- a marker's incidences all lie in one part, so the parts' cells add up to the full
  * matrix; skh_screen_from_cells: the candidate pairs (screen_refs with sketch i as the query, triangle.rs:71-90) from the concatenated cells of all parts.
  * Both need n_genomes^2 counters of scratch (an error beyond the screen's budget); arrays are library-allocated (skh_free). */
-int skh_screen_part(skh_ctx*, const skh_sketch_set* set, uint32_t part, uint32_t n_parts, uint32_t** cell_i, uint32_t** cell_j, uint32_t** cell_count, uint64_t* n_cells);
-int skh_screen_from_cells(skh_ctx*, const skh_sketch_set* set, const uint32_t* cell_i, const uint32_t* cell_j, const uint32_t* cell_count, uint64_t n_cells,
-                          double identity, int rescue_small, uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs);
+int skh_screen_part(skh_ctx*, const skh_sketch_set* set, uint32_t part, uint32_t n_parts, uint64_t** cells, uint64_t* n_cells);   /* a cell: i << 43 | j << 22 | count */
+int skh_screen_from_cells(skh_ctx*, const skh_sketch_set* set, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
+                          uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs);
 
 /* ------------------------------------------------------------------ triangle body (triangle.rs:55-105):
  * screen rows, chain pairs j>i, keep ani > 0.1.  part/n_parts shard the screened pair list round-robin

@@ -89,8 +89,8 @@ def load(path):
     L.skh_sketch_import_flat.argtypes = [vp, C.POINTER(SketchParams), u32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp]
     L.skh_screen.restype = i32; L.skh_screen.argtypes = [vp, vp, vp, dbl, i32, i32, pp, pp, C.POINTER(u64)]
     L.skh_screen_rows.restype = i32; L.skh_screen_rows.argtypes = [vp, vp, u32, u32, dbl, i32, pp, pp, C.POINTER(u64)]
-    L.skh_screen_part.restype = i32; L.skh_screen_part.argtypes = [vp, vp, u32, u32, pp, pp, pp, C.POINTER(u64)]
-    L.skh_screen_from_cells.restype = i32; L.skh_screen_from_cells.argtypes = [vp, vp, vp, vp, vp, u64, dbl, i32, pp, pp, C.POINTER(u64)]
+    L.skh_screen_part.restype = i32; L.skh_screen_part.argtypes = [vp, vp, u32, u32, pp, C.POINTER(u64)]
+    L.skh_screen_from_cells.restype = i32; L.skh_screen_from_cells.argtypes = [vp, vp, vp, u64, dbl, i32, pp, pp, C.POINTER(u64)]
     L.skh_chain_pairs.restype = i32; L.skh_chain_pairs.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp, vp]
     L.skh_chain_pairs_multi.restype = i32; L.skh_chain_pairs_multi.argtypes = [vp, vp, u32, vp, vp, vp, vp, u64, C.POINTER(MapParams), vp]
     L.skh_triangle.restype = i32

@@ -246,22 +246,27 @@ class Context:
         return first, second
 
     def screen_part(self, sketches, part, n_parts):
-        """The triangle's screen cut by key range: the non-zero cells (i, j, shared markers) over part `part` of `n_parts` of the markers' leading 16 bases."""
-        a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
-        self.check(self.L.skh_screen_part(self.h, sketches.h, part, n_parts, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        """The triangle's screen cut by key range: the non-zero cells over part `part` of `n_parts` of the markers' leading 16 bases, one uint64 each
+        (i << 43 | j << 22 | shared markers; `unpack_cells`)."""
+        a, n = C.c_void_p(), C.c_uint64()
+        self.check(self.L.skh_screen_part(self.h, sketches.h, part, n_parts, C.byref(a), C.byref(n)))
         try:
-            out = [np.empty(n.value, np.uint32) for _ in range(3)]
-            for arr, ptr in zip(out, (a, b, c)):
-                if n.value: C.memmove(arr.ctypes.data, ptr, 4 * n.value)
+            cells = np.empty(n.value, np.uint64)
+            if n.value: C.memmove(cells.ctypes.data, a, 8 * n.value)
         finally:
-            self.L.skh_free(a); self.L.skh_free(b); self.L.skh_free(c)
-        return tuple(out)
+            self.L.skh_free(a)
+        return cells
 
-    def screen_from_cells(self, sketches, cell_i, cell_j, cell_count, identity=0.0, rescue_small=True):
+    @staticmethod
+    def unpack_cells(cells):
+        c = np.asarray(cells, np.uint64)
+        return (c >> np.uint64(43)).astype(np.uint32), ((c >> np.uint64(22)) & np.uint64(0x1FFFFF)).astype(np.uint32), (c & np.uint64(0x3FFFFF)).astype(np.uint32)
+
+    def screen_from_cells(self, sketches, cells, identity=0.0, rescue_small=True):
         """Candidate pairs (i, j > i) of the triangle from the concatenated cells of all key-range parts (skh_screen_from_cells)."""
-        ci = np.ascontiguousarray(cell_i, np.uint32); cj = np.ascontiguousarray(cell_j, np.uint32); cc = np.ascontiguousarray(cell_count, np.uint32)
+        c = np.ascontiguousarray(cells, np.uint64)
         a, b, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
-        self.check(self.L.skh_screen_from_cells(self.h, sketches.h, _p(ci), _p(cj), _p(cc), len(ci), identity, int(rescue_small), C.byref(a), C.byref(b), C.byref(n)))
+        self.check(self.L.skh_screen_from_cells(self.h, sketches.h, _p(c), len(c), identity, int(rescue_small), C.byref(a), C.byref(b), C.byref(n)))
         try:
             first = np.empty(n.value, np.uint32); second = np.empty(n.value, np.uint32)
             if n.value:

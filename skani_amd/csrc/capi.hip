@@ -444,29 +444,30 @@ static void out_u32(const std::vector<uint32_t>& v, uint32_t** out) {
     *out = p;
 }
 
-int skh_screen_part(skh_ctx* ctx, const skh_sketch_set* set, uint32_t part, uint32_t n_parts, uint32_t** cell_i, uint32_t** cell_j, uint32_t** cell_count, uint64_t* n_cells) {
-    if (!ctx || !set || !cell_i || !cell_j || !cell_count || !n_cells || !n_parts || part >= n_parts) return SKH_ERR_INVALID;
-    *cell_i = *cell_j = *cell_count = nullptr; *n_cells = 0;
+int skh_screen_part(skh_ctx* ctx, const skh_sketch_set* set, uint32_t part, uint32_t n_parts, uint64_t** cells, uint64_t* n_cells) {
+    if (!ctx || !set || !cells || !n_cells || !n_parts || part >= n_parts) return SKH_ERR_INVALID;
+    *cells = nullptr; *n_cells = 0;
     int rc = guarded(ctx, [&] {
         if (!screen_parts_fit(ctx, set->n_genomes) && set->n_genomes) throw std::invalid_argument("the count matrix of this set is beyond the screen's budget");
-        std::vector<uint32_t> ci, cj, cc;
-        { Stopwatch sw(ctx, &ctx->timings.screen_ms); if (set->n_genomes) screen_partial_cells(ctx, set, part, n_parts, ci, cj, cc); }
-        out_u32(ci, cell_i); out_u32(cj, cell_j); out_u32(cc, cell_count); *n_cells = ci.size();
+        std::vector<uint64_t> c;
+        { Stopwatch sw(ctx, &ctx->timings.screen_ms); if (set->n_genomes) screen_partial_cells(ctx, set, part, n_parts, c); }
+        uint64_t* p = (uint64_t*)malloc((c.size() + 1) * 8);
+        if (!p) throw std::bad_alloc();
+        if (!c.empty()) memcpy(p, c.data(), c.size() * 8);
+        *cells = p; *n_cells = c.size();
     });
-    if (rc != SKH_OK) { free(*cell_i); free(*cell_j); free(*cell_count); *cell_i = *cell_j = *cell_count = nullptr; }
     ctx->arena.reset();
     return rc;
 }
 
-int skh_screen_from_cells(skh_ctx* ctx, const skh_sketch_set* set, const uint32_t* cell_i, const uint32_t* cell_j, const uint32_t* cell_count, uint64_t n_cells,
-                          double identity, int rescue_small, uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs) {
-    if (!ctx || !set || !pair_i || !pair_j || !n_pairs || (n_cells && (!cell_i || !cell_j || !cell_count))) return SKH_ERR_INVALID;
+int skh_screen_from_cells(skh_ctx* ctx, const skh_sketch_set* set, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
+                          uint32_t** pair_i, uint32_t** pair_j, uint64_t* n_pairs) {
+    if (!ctx || !set || !pair_i || !pair_j || !n_pairs || (n_cells && !cells)) return SKH_ERR_INVALID;
     *pair_i = *pair_j = nullptr; *n_pairs = 0;
     int rc = guarded(ctx, [&] {
         if (!screen_parts_fit(ctx, set->n_genomes) && set->n_genomes) throw std::invalid_argument("the count matrix of this set is beyond the screen's budget");
-        for (uint64_t x = 0; x < n_cells; x++) if (cell_i[x] >= set->n_genomes || cell_j[x] >= set->n_genomes) throw std::invalid_argument("cell index out of range");
         std::vector<uint32_t> a, b;
-        { Stopwatch sw(ctx, &ctx->timings.screen_ms); if (set->n_genomes) screen_from_cells(ctx, set, cell_i, cell_j, cell_count, n_cells, identity, rescue_small, a, b); }
+        { Stopwatch sw(ctx, &ctx->timings.screen_ms); if (set->n_genomes) screen_from_cells(ctx, set, cells, n_cells, identity, rescue_small, a, b); }
         out_u32(a, pair_i); out_u32(b, pair_j); *n_pairs = a.size();
     });
     if (rc != SKH_OK) { free(*pair_i); free(*pair_j); *pair_i = *pair_j = nullptr; }

@@ -261,8 +261,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
 // the triangle screen cut by key range (the distributed triangle): the non-zero cells of the partial count matrix of part `part` of the markers' leading
 // 16 bases, and the candidate pairs from the gathered cells of all parts (every rank gets the same list).  screen_parts_fit: the dense matrix is within the screen's budget.
 bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes);
-void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint32_t>& ci, std::vector<uint32_t>& cj, std::vector<uint32_t>& cc);
-void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n_cells, double identity, int rescue_small,
+void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint64_t>& cells);   // a cell: i << 43 | j << 22 | count
+void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second);
 
 // ---- dist.hip

@@ -280,14 +280,25 @@ __global__ __launch_bounds__(256) void screen_part_keys_kernel(const uint64_t* m
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (part_off[mid] <= e) lo = mid; else hi = mid; }
     keys[e] = screen_key(markers[range_lo[lo] + (e - part_off[lo])], 0u, lo);
 }
-__global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n, uint32_t ncols, uint32_t* cnt) {
+// a cell on the wire: i << 43 | j << 22 | count (i, j < 2^21; a count beyond 2^22 - 1 -- genomes with millions of markers -- saturates, which no threshold notices)
+constexpr uint32_t CELL_COUNT_MAX = (1u << 22) - 1u;
+__global__ __launch_bounds__(256) void screen_pack_cells_kernel(const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint32_t n, uint64_t* out) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = ((uint64_t)ci[e] << 43) | ((uint64_t)cj[e] << 22) | (cc[e] < CELL_COUNT_MAX ? cc[e] : CELL_COUNT_MAX);
+}
+__global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint64_t* cells, uint64_t n, uint32_t ng, uint32_t* cnt, uint32_t* bad) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) atomicAdd(&cnt[(uint64_t)ci[e] * ncols + cj[e]], cc[e]);
+    if (e >= n) return;
+    const uint64_t c = cells[e]; const uint32_t i = (uint32_t)(c >> 43), j = (uint32_t)(c >> 22) & 0x1FFFFFu;
+    if (i >= ng || j >= ng) { atomicAdd(bad, 1u); return; }
+    uint32_t* cell = &cnt[(uint64_t)i * ng + j];
+    const uint32_t add = (uint32_t)c & CELL_COUNT_MAX, old = atomicAdd(cell, add);
+    if (old + add < old) atomicMax(cell, 0xFFFFFFFFu);                                // (saturate instead of wrapping)
 }
 
 // rows [0, rows) of a dense count matrix through the rule: the passing (row, col[, count]) cells in (row, col) order, on the host
 static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t rows, uint32_t ncols, const ScreenRule& sr, const uint64_t* d_mk_rows,
-                           const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, std::vector<uint32_t>* counts) {
+                           const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, std::vector<uint64_t>* cells /* packed (row, col, count) instead of first / second */) {
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows); uint32_t* row_off = ctx->arena.get<uint32_t>(rows + 1);
     SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     check_launch("screen_threshold0");
@@ -295,19 +306,27 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
     uint32_t total = 0;
     d2h(&total, row_off + rows, 4, ctx->stream);
     if (!total) return;
-    uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total); uint32_t* oc = counts ? ctx->arena.get<uint32_t>(total) : nullptr;
+    uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total); uint32_t* oc = cells ? ctx->arena.get<uint32_t>(total) : nullptr;
     SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 1, row_cnt, (const uint32_t*)row_off, of, os, oc);
     check_launch("screen_threshold1");
+    if (cells) {
+        uint64_t* packed = ctx->arena.get<uint64_t>(total);
+        SKH_LAUNCH(screen_pack_cells_kernel, (total + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)of, (const uint32_t*)os, (const uint32_t*)oc, total, packed);
+        check_launch("screen_pack_cells");
+        const size_t old = cells->size(); cells->resize(old + total);
+        d2h(cells->data() + old, packed, (size_t)total * 8, ctx->stream);
+        return;
+    }
     const size_t old = first.size(); first.resize(old + total); second.resize(old + total);
     d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
-    if (counts) { counts->resize(old + total); d2h(counts->data() + old, oc, (size_t)total * 4, ctx->stream); }
 }
 
 bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes) { return n_genomes && (uint64_t)n_genomes * n_genomes <= ctx->tune.screen_cells && n_genomes <= ID_MASK; }
 
 // the non-zero cells of the triangle's count matrix over the markers whose leading 16 bases fall into part `part` of `n_parts`
-void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint32_t>& ci, std::vector<uint32_t>& cj, std::vector<uint32_t>& cc) {
-    ci.clear(); cj.clear(); cc.clear();
+void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint64_t>& cells) {
+    cells.clear();
+    std::vector<uint32_t> none_a, none_b;
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_partial_cells: the count matrix does not fit");
     if (!S->mk_off[N]) return;
@@ -332,12 +351,12 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
     SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane);
     check_launch("screen_count(part)");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
-    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, ci, cj, &cc);
+    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, &cells);
     dsync(ctx->stream);
 }
 
 // the triangle's candidate pairs from the gathered cells of all parts: counts added up in a dense matrix, every row through the rule (triangle.rs:71-90 with screen_refs)
-void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint32_t* ci, const uint32_t* cj, const uint32_t* cc, uint64_t n_cells, double identity, int rescue_small,
+void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
     first.clear(); second.clear();
     if (identity == 0.) identity = 0.80;
@@ -347,10 +366,13 @@ void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint32_t* ci
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
     dzero(cnt, plane * 4, ctx->stream);
     if (n_cells) {
-        uint32_t* d = ctx->arena.get<uint32_t>(3 * n_cells);
-        h2d_big(d, ci, n_cells * 4, ctx->stream); h2d_big(d + n_cells, cj, n_cells * 4, ctx->stream); h2d_big(d + 2 * n_cells, cc, n_cells * 4, ctx->stream);
-        SKH_LAUNCH(screen_add_cells_kernel, (unsigned)((n_cells + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)d, (const uint32_t*)(d + n_cells), (const uint32_t*)(d + 2 * n_cells), n_cells, N, cnt);
+        uint64_t* d = ctx->arena.get<uint64_t>(n_cells + 1);
+        uint32_t* bad = (uint32_t*)(d + n_cells); dzero(bad, 8, ctx->stream);
+        h2d_big(d, cells, n_cells * 8, ctx->stream);
+        SKH_LAUNCH(screen_add_cells_kernel, (unsigned)((n_cells + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)d, n_cells, N, cnt, bad);
         check_launch("screen_add_cells");
+        uint32_t h_bad = 0; d2h(&h_bad, bad, 4, ctx->stream);
+        if (h_bad) throw std::invalid_argument("screen_from_cells: a cell names a genome beyond the set");
     }
     const ScreenRule sr{powi21(identity), SKH_SCREEN_REFS, rescue_small, 1};
     threshold_rows(ctx, cnt, 1, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, first, second, nullptr);

@@ -236,9 +236,16 @@ def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200), (
         exp = [(i, int(j)) for i in range(len(osk) - 1) for j in ora.screen_refs(osk, osk[i], 0.8, 0, True) if j > i]
         assert list(zip(a.tolist(), b.tolist())) == sorted(exp)
         for n_parts in (1, 3, 8) if key_range_fits(ctx, ss) else ():                 # the same screen cut by key range: the parts' cells add up to the full count matrix
-            cells = [ctx.screen_part(ss, part, n_parts) for part in range(n_parts)]
-            a3, b3 = ctx.screen_from_cells(ss, np.concatenate([x[0] for x in cells]), np.concatenate([x[1] for x in cells]), np.concatenate([x[2] for x in cells]), 0.0, True)
-            assert list(zip(a3.tolist(), b3.tolist())) == sorted(exp) and all((x[0] < x[1]).all() and (x[2] > 0).all() for x in cells), (mode, c, n_parts)
+            cells = np.concatenate([ctx.screen_part(ss, part, n_parts) for part in range(n_parts)])
+            a3, b3 = ctx.screen_from_cells(ss, cells, 0.0, True)
+            ci, cj, cc = ctx.unpack_cells(cells)
+            assert list(zip(a3.tolist(), b3.tolist())) == sorted(exp) and (ci < cj).all() and (cc > 0).all(), (mode, c, n_parts)
+            if n_parts == 3:                                                          # a cell that names a genome beyond the set is refused, not added somewhere
+                bad = np.append(cells, np.uint64((len(osk) << 43) | (1 << 22) | 5))
+                try:
+                    ctx.screen_from_cells(ss, bad, 0.0, True); raise AssertionError("cell beyond the set accepted")
+                except sk.SkaniHipError as e:
+                    assert "beyond the set" in str(e)
         for r0, nr in ((0, len(osk)), (1, 3), (len(osk) - 1, 1), (2, 0)):             # row blocks of the same screen
             a2, b2 = ctx.screen_rows(ss, r0, nr, 0.0, True)
             assert list(zip(a2.tolist(), b2.tolist())) == [e for e in sorted(exp) if r0 <= e[0] < r0 + nr]
@@ -285,8 +292,8 @@ def case_screen_rules(ctx):
             exp = [(i, int(j)) for i in range(len(orefs) - 1) for j in ora.screen_refs(orefs, orefs[i], 0.8, 0, rescue) if j > i]
             assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri")
             if not key_range_fits(ctx, refs): continue
-            cells = [ctx.screen_part(refs, part, 4) for part in range(4)]               # the triangle cut by key range (the small genome's rescue: a row that passes without a count)
-            a, b = ctx.screen_from_cells(refs, np.concatenate([x[0] for x in cells]), np.concatenate([x[1] for x in cells]), np.concatenate([x[2] for x in cells]), 0.8, rescue)
+            cells = np.concatenate([ctx.screen_part(refs, part, 4) for part in range(4)])   # the triangle cut by key range (the small genome's rescue: a row that passes without a count)
+            a, b = ctx.screen_from_cells(refs, cells, 0.8, rescue)
             assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri by key range")
 
 

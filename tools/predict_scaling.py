@@ -40,18 +40,18 @@ out["chained_pairs"] = int(nch)
 scr = {}
 for W in (1, 2, 4, 8):
     cells = [ctx.screen_part(ss, p, W) for p in range(W)]
-    ci, cj, cc = (np.concatenate([c[x] for c in cells]) for x in range(3))
+    allc = np.concatenate(cells)
     best = None
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ctx.screen_part(ss, 0, W)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        a, b = ctx.screen_from_cells(ss, ci, cj, cc, 0.0, True)
+        a, b = ctx.screen_from_cells(ss, allc, 0.0, True)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         cur = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
         best = cur if best is None or sum(cur) < sum(best) else best
     assert len(a) == nch, (len(a), nch)
-    scr[str(W)] = {"part_ms": best[0], "from_cells_ms": best[1], "cells_of_part_0": int(len(cells[0][0])), "cells_total": int(len(ci))}
+    scr[str(W)] = {"part_ms": best[0], "from_cells_ms": best[1], "cells_of_part_0": int(len(cells[0])), "cells_total": int(len(allc))}
 out["screen_by_key_range_ms"] = scr
 ctx.timings()
 a, b = ctx.screen(ss, None, 0.0, 0, True)
