@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include <cmath>
 
 namespace skh {
 
@@ -330,7 +331,15 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_partial_cells: the count matrix does not fit");
     if (!S->mk_off[N]) return;
-    auto bound = [&](uint32_t r) { return r >= n_parts ? 0ull : ((((uint64_t)r << 32) + n_parts - 1) / n_parts) << 10; };   // the smallest marker of part r (its sorted field is marker >> 10)
+    // the smallest marker of part r (its sorted field is marker >> 10, 32 bits).  A marker is the smaller of a 21-mer and its reverse complement, so a fraction 1 - (1 - x)^2 of
+    // them lies below x of the range: the parts are cut at the quantiles of that distribution, not at equal widths (two equal halves would hold 75 % and 25 % of the keys).
+    // Every rank computes the same bounds: IEEE division and square root are exactly rounded.
+    auto bound = [&](uint32_t r) -> uint64_t {
+        if (r == 0) return 0ull;
+        if (r >= n_parts) return 0ull;                                               // (no upper bound)
+        const double x = 1.0 - std::sqrt(1.0 - (double)r / (double)n_parts);
+        return std::max<uint64_t>((uint64_t)(x * 4294967296.0), 1ull) << 10;
+    };
     uint64_t* range_lo = ctx->arena.get<uint64_t>(N); uint32_t* range_cnt = ctx->arena.get<uint32_t>(N); uint32_t* part_off = ctx->arena.get<uint32_t>(N + 1);
     SKH_LAUNCH(screen_part_ranges_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)S->d_mk_off.p, N, bound(part), bound(part + 1), range_lo, range_cnt);
     check_launch("screen_part_ranges");

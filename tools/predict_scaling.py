@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Inputs for DESIGN.md's PREDICTED 1/2/4/8-GPU series of the strong-scaling mode (bench.py --collection 10000), measured on ONE uncontended MI355X:
 the phases that shard linearly (seeding, marker sets, seed tables, chaining) are timed once on the whole collection; the screen, which does not, is timed
-per world size W through the public key-range entry points (skh_screen_part for part 0 of W + skh_screen_from_cells over the cells of all parts = what
+per world size W through the public key-range entry points (skh_screen_part for every part of W, the slowest counted + skh_screen_from_cells over the cells of all parts = what
 one rank of a world of W runs).  Prints one JSON object; nothing here is a multi-GPU measurement.
 usage: predict_scaling.py [genomes=10000]"""
 import json
@@ -41,17 +41,21 @@ scr = {}
 for W in (1, 2, 4, 8):
     cells = [ctx.screen_part(ss, p, W) for p in range(W)]
     allc = np.concatenate(cells)
-    best = None
+    part_ms = []
+    for p in range(W):                                                          # every part timed: the slowest rank is what a step waits for
+        b = None
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ctx.screen_part(ss, p, W)
+            torch.cuda.synchronize(); b = min(b or 1e9, (time.perf_counter() - t0) * 1e3)
+        part_ms.append(b)
+    fc = None
     for rep in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        ctx.screen_part(ss, 0, W)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         a, b = ctx.screen_from_cells(ss, allc, 0.0, True)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        cur = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
-        best = cur if best is None or sum(cur) < sum(best) else best
+        torch.cuda.synchronize(); fc = min(fc or 1e9, (time.perf_counter() - t1) * 1e3)
     assert len(a) == nch, (len(a), nch)
-    scr[str(W)] = {"part_ms": best[0], "from_cells_ms": best[1], "cells_of_part_0": int(len(cells[0])), "cells_total": int(len(allc))}
+    scr[str(W)] = {"part_ms_max": max(part_ms), "part_ms": [round(x, 3) for x in part_ms], "from_cells_ms": fc, "cells_per_part": [int(len(c)) for c in cells], "cells_total": int(len(allc))}
 out["screen_by_key_range_ms"] = scr
 ctx.timings()
 a, b = ctx.screen(ss, None, 0.0, 0, True)
