@@ -81,6 +81,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
+        ctx->tune.dist_key_range_w1 = (uint32_t)env("SKH_TUNE_DIST_KEY_RANGE_W1", 0);
         ctx->tune.greedy_big_min = (uint32_t)env("SKH_TUNE_GREEDY_BIG_MIN", ctx->tune.greedy_big_min);
         ctx->tune.wide_span = std::min<uint64_t>(ctx->tune.wide_span, env("SKH_TUNE_WIDE_SPAN", ctx->tune.wide_span));
         ctx->tune.greedy_len_limit = (uint32_t)std::min<uint64_t>(0x10000, env("SKH_TUNE_GREEDY_LEN_LIMIT", 0x10000));

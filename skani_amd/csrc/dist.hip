@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const uint32_t* __re
         for (uint32_t u = 0; u < 16; u++) { const uint64_t x = i + 256u * u; if (x < n && x < (i - threadIdx.x) + 4096) dst[dof + x] = src[so + x]; }
     }
 }
+// the two head words of every block of a gathered buffer, side by side
+__global__ __launch_bounds__(256) void block_heads_kernel(const uint64_t* blocks, uint64_t block_words, uint32_t n_blocks, uint64_t* heads) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * n_blocks) heads[t] = blocks[(uint64_t)(t >> 1) * block_words + (t & 1u)];
+}
 }  // namespace
 void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::vector<uint64_t>& seg) {
     const uint32_t n_seg = (uint32_t)(seg.size() / 3);
@@ -366,24 +371,59 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.screen_row_begin = rb[me]; st.screen_row_end = rb[me + 1];
     std::vector<uint32_t> pi, pj;
-    if (W > 1 && screen_parts_fit(ctx, N)) {                                        // (a world of one has nothing to cut: the row form, which is skh_triangle's own screen)
+    if ((W > 1 || ctx->tune.dist_key_range_w1) && screen_parts_fit(ctx, N)) {                                        // (a world of one has nothing to cut: the row form, which is skh_triangle's own screen)
         // ---- 3. screen by KEY RANGE (round 4; screen.hip): this rank sorts and walks the incidences of a W-th of the markers' leading 16 bases and gets partial counts
         // for all cells; the non-zero cells are gathered -- with the status of the phases so far -- and every rank adds them up and applies the rule to all rows
         // itself: the same candidate list everywhere, no list to gather.  (Cut by rows, every rank sorted and walked ALL incidences: the screen did not shrink with W.)
+        // The cells (a 64-bit word each: i << 43 | j << 22 | count) never visit the host: they go from the arena into the communicator's own device buffers, blocks of
+        // [count, status, cells ...] sized by what its previous call saw (a larger count makes every rank enlarge its buffers, agree, and go round once more).
         st.screen_by_key_range = 1;
-        std::vector<uint64_t> mine_c, all_c, n_all;                                  // a cell: i << 43 | j << 22 | count (screen.hip)
+        uint64_t* d_mine = nullptr; uint64_t n_mine = 0;
         local([&] {                                                                 // (local phase 3)
             Stopwatch sw(ctx, &ctx->timings.screen_ms);
-            screen_partial_cells(ctx, &S, (uint32_t)me, (uint32_t)W, mine_c);
+            screen_partial_cells_dev(ctx, &S, (uint32_t)me, (uint32_t)W, &d_mine, &n_mine);
         });
-        ctx->arena.reset();
         tr.mark("dist: screen, my key range");
         ex_begin();
-        gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, n_all, [&](int r) { stop_together("marker sets / screen", r); });
+        std::vector<uint64_t> heads(2 * (size_t)W);
+        auto heads_say = [&](uint64_t& mx) {                                          // every rank reads the same heads: a failed rank stops all, the largest count
+            mx = 0;
+            for (int r = 0; r < W; r++) { if (heads[2 * r + 1]) stop_together("marker sets / screen", r); mx = std::max(mx, heads[2 * r]); }
+        };
+        auto grow = [&](uint64_t want) {                                              // (not one of the numbered local phases: it happens in a communicator's first call and when a collection grew)
+            if (local_err.empty()) {
+                try { T.cells_send.alloc(want + 2); T.cells_recv.alloc((want + 2) * (size_t)W); T.cap_cells = want; }
+                catch (const std::exception& e) { local_err = e.what(); }
+            }
+            agree("cell buffers");
+        };
+        uint64_t mx = 0;
+        if (T.cap_cells == 0) {                                                     // no buffers yet: the counts travel alone
+            const uint64_t h[2] = {n_mine, local_err.empty() ? 0ull : 1ull};
+            T.all_gather(ctx, h, heads.data(), 16, false);
+            heads_say(mx);
+            grow(std::max<uint64_t>(mx, 1));
+        }
+        for (int round = 0;; round++) {
+            const uint64_t bw = T.cap_cells + 2;
+            const uint64_t h[2] = {n_mine, local_err.empty() ? 0ull : 1ull};
+            h2d(T.cells_send.p, h, 16, ctx->stream);
+            if (n_mine && n_mine <= T.cap_cells && local_err.empty()) d2d(T.cells_send.p + 2, d_mine, n_mine * 8, ctx->stream);
+            T.all_gather(ctx, T.cells_send.p, T.cells_recv.p, bw * 8, true);
+            uint64_t* d_heads = ctx->arena.get<uint64_t>(2 * (size_t)W);
+            SKH_LAUNCH(block_heads_kernel, (2 * W + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)T.cells_recv.p, bw, (uint32_t)W, d_heads);
+            check_launch("block_heads");
+            d2h(heads.data(), d_heads, heads.size() * 8, ctx->stream);
+            heads_say(mx);
+            if (mx <= T.cap_cells) break;
+            if (round) throw Error("distributed triangle: the second round of the cell gather did not fit (ranks disagree on the sizes)");
+            grow(mx);
+        }
         ex_end();
+        ctx->arena.reset();
         local([&] {                                                                 // (local phase 4; a failure is agreed on in front of the sketch exchange)
             Stopwatch sw(ctx, &ctx->timings.screen_ms);
-            screen_from_cells(ctx, &S, all_c.data(), all_c.size(), identity, rescue_small, pi, pj);
+            screen_from_cells_dev(ctx, &S, T.cells_recv.p, (uint32_t)W, T.cap_cells + 2, mx, identity, rescue_small, pi, pj);
         });
         ctx->arena.reset();
         tr.mark("dist: cells gathered, candidates");

@@ -65,6 +65,7 @@ struct skh_tunables {
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
     uint32_t greedy_len_limit = 0x10000;               // chain intervals at least this long on either axis send their pair to the general selection kernel (tests use a small value to drive that hand-over)
     uint32_t greedy_big_min = 2049;                    // candidate intervals from which a pair's selection runs in global memory (greedy_big_kernel); tests use small values
+    uint32_t dist_key_range_w1 = 0;                     // tests: a world of one screens by key range too (the cell gather on device buffers through the transport)
     uint32_t dist_fail = 0;                             // tests: the n-th local phase of a distributed triangle fails on this rank (0 = never)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
     uint64_t wide_span = (1ull << 31) - 8192;           // a genome of at least this many padded bases makes its sketch set "wide" (tests use small values to run everything through the 64-bit path)
@@ -177,6 +178,8 @@ struct Transport {
     // Sizes of the communicator's previous distributed triangle (largest per-rank genome / contig / marker / candidate-pair / result-row counts): the next
     // call lays its gathers out by them and needs one collective where counts-then-payload would need two (dist.hip gather_records).
     uint64_t cap_n = 0, cap_c = 0, cap_m = 0, cap_pairs = 0, cap_rows = 0;
+    // the key-range screen's cell gather runs on device buffers the communicator keeps (cap_cells + 2 words per rank: a head and the cells)
+    uint64_t cap_cells = 0; DBuf<uint64_t> cells_send, cells_recv;
     virtual ~Transport() {}
     // every rank contributes `bytes` bytes; recv gets world * bytes in rank order.  device: both buffers are device memory.
     virtual void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) = 0;
@@ -264,6 +267,10 @@ bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes);
 void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint64_t>& cells);   // a cell: i << 43 | j << 22 | count
 void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second);
+// the device forms (the distributed triangle: the cells never visit the host): cells left in the arena; cells read from blocks [count, -, cells...] of block_words words
+void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells);
+void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* d_blocks, uint32_t n_blocks, uint64_t block_words, uint64_t max_cells, double identity, int rescue_small,
+                           std::vector<uint32_t>& first, std::vector<uint32_t>& second);
 
 // ---- dist.hip
 void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std::vector<uint32_t>& pj, const std::vector<uint64_t>& weight, const std::vector<int>& holder,

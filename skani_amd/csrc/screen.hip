@@ -287,10 +287,14 @@ __global__ __launch_bounds__(256) void screen_pack_cells_kernel(const uint32_t* 
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) out[e] = ((uint64_t)ci[e] << 43) | ((uint64_t)cj[e] << 22) | (cc[e] < CELL_COUNT_MAX ? cc[e] : CELL_COUNT_MAX);
 }
-__global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint64_t* cells, uint64_t n, uint32_t ng, uint32_t* cnt, uint32_t* bad) {
+// cells in blocks of `block_words` words (one per part, as the gather of the distributed triangle leaves them): word 0 = the block's number of cells, word 1 unused,
+// the cells from word 2 on; blockIdx.y = the block
+__global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint64_t* blocks, uint64_t block_words, uint32_t ng, uint32_t* cnt, uint32_t* bad) {
+    const uint64_t* blk = blocks + (uint64_t)blockIdx.y * block_words;
+    const uint64_t n = blk[0];
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const uint64_t c = cells[e]; const uint32_t i = (uint32_t)(c >> 43), j = (uint32_t)(c >> 22) & 0x1FFFFFu;
+    if (e >= n || e + 2 >= block_words) return;
+    const uint64_t c = blk[2 + e]; const uint32_t i = (uint32_t)(c >> 43), j = (uint32_t)(c >> 22) & 0x1FFFFFu;
     if (i >= ng || j >= ng) { atomicAdd(bad, 1u); return; }
     uint32_t* cell = &cnt[(uint64_t)i * ng + j];
     const uint32_t add = (uint32_t)c & CELL_COUNT_MAX, old = atomicAdd(cell, add);
@@ -299,7 +303,10 @@ __global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint64_t* c
 
 // rows [0, rows) of a dense count matrix through the rule: the passing (row, col[, count]) cells in (row, col) order, on the host
 static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t rows, uint32_t ncols, const ScreenRule& sr, const uint64_t* d_mk_rows,
-                           const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, std::vector<uint64_t>* cells /* packed (row, col, count) instead of first / second */) {
+                           const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, uint64_t** d_cells = nullptr /* packed (row, col, count) words left in the arena instead of first / second */,
+                           uint64_t* n_cells = nullptr) {
+    const bool cells = d_cells != nullptr;
+    if (cells) { *d_cells = nullptr; *n_cells = 0; }
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows); uint32_t* row_off = ctx->arena.get<uint32_t>(rows + 1);
     SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     check_launch("screen_threshold0");
@@ -314,8 +321,7 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
         uint64_t* packed = ctx->arena.get<uint64_t>(total);
         SKH_LAUNCH(screen_pack_cells_kernel, (total + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)of, (const uint32_t*)os, (const uint32_t*)oc, total, packed);
         check_launch("screen_pack_cells");
-        const size_t old = cells->size(); cells->resize(old + total);
-        d2h(cells->data() + old, packed, (size_t)total * 8, ctx->stream);
+        *d_cells = packed; *n_cells = total;
         return;
     }
     const size_t old = first.size(); first.resize(old + total); second.resize(old + total);
@@ -327,6 +333,14 @@ bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes) { return n_genomes
 // the non-zero cells of the triangle's count matrix over the markers whose leading 16 bases fall into part `part` of `n_parts`
 void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, std::vector<uint64_t>& cells) {
     cells.clear();
+    uint64_t* d = nullptr; uint64_t n = 0;
+    screen_partial_cells_dev(ctx, S, part, n_parts, &d, &n);
+    cells.resize(n);
+    if (n) d2h(cells.data(), d, n * 8, ctx->stream);
+}
+// the same, the cells left in the context's arena (valid until its next reset)
+void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells) {
+    *d_cells = nullptr; *n_cells = 0;
     std::vector<uint32_t> none_a, none_b;
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_partial_cells: the count matrix does not fit");
@@ -360,7 +374,7 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
     SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane);
     check_launch("screen_count(part)");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
-    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, &cells);
+    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, d_cells, n_cells);
     dsync(ctx->stream);
 }
 
@@ -368,17 +382,27 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
 void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
     first.clear(); second.clear();
+    if (!screen_parts_fit(ctx, S->n_genomes)) throw Error("screen_from_cells: the count matrix does not fit");
+    uint64_t* d = ctx->arena.get<uint64_t>(n_cells + 2);                              // one block: its head, the cells
+    const uint64_t head[2] = {n_cells, 0};
+    h2d(d, head, 16, ctx->stream);
+    if (n_cells) h2d_big(d + 2, cells, n_cells * 8, ctx->stream);
+    screen_from_cells_dev(ctx, S, d, 1, n_cells + 2, n_cells, identity, rescue_small, first, second);
+}
+// the cells in device memory, in `n_blocks` blocks of `block_words` words (screen_add_cells_kernel); max_cells: the largest block's number of cells
+void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* d_blocks, uint32_t n_blocks, uint64_t block_words, uint64_t max_cells, double identity, int rescue_small,
+                           std::vector<uint32_t>& first, std::vector<uint32_t>& second) {
+    first.clear(); second.clear();
     if (identity == 0.) identity = 0.80;
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_from_cells: the count matrix does not fit");
+    if (max_cells + 2 > block_words || max_cells > 0x7FFFFFFFull * 256) throw Error("screen_from_cells: bad block layout");
     const uint64_t plane = (uint64_t)N * N;
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
     dzero(cnt, plane * 4, ctx->stream);
-    if (n_cells) {
-        uint64_t* d = ctx->arena.get<uint64_t>(n_cells + 1);
-        uint32_t* bad = (uint32_t*)(d + n_cells); dzero(bad, 8, ctx->stream);
-        h2d_big(d, cells, n_cells * 8, ctx->stream);
-        SKH_LAUNCH(screen_add_cells_kernel, (unsigned)((n_cells + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)d, n_cells, N, cnt, bad);
+    if (max_cells && n_blocks) {
+        uint32_t* bad = ctx->arena.get<uint32_t>(2); dzero(bad, 8, ctx->stream);
+        SKH_LAUNCH(screen_add_cells_kernel, dim3((unsigned)((max_cells + 255) / 256), n_blocks), 256, 0, ctx->stream, d_blocks, block_words, N, cnt, bad);
         check_launch("screen_add_cells");
         uint32_t h_bad = 0; d2h(&h_bad, bad, 4, ctx->stream);
         if (h_bad) throw std::invalid_argument("screen_from_cells: a cell names a genome beyond the set");

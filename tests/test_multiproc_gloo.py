@@ -468,6 +468,25 @@ def test_rccl_world_size_one():
         assert onch == 380 and np.array_equal(i, oi) and np.array_equal(j, oj)
         for x in range(len(res)):
             assert_result_close(res[x], ores[x], (int(i[x]), int(j[x])))
+        # the screen by key range through RCCL (a world of one takes the row form unless told otherwise): the cells are gathered in the communicator's own device
+        # buffers -- counts first and buffers made in its first call, one device all-gather in the second
+        os.environ["SKH_TUNE_DIST_KEY_RANGE_W1"] = "1"
+        try:
+            ctx2 = sk.Context(0)
+        finally:
+            del os.environ["SKH_TUNE_DIST_KEY_RANGE_W1"]
+        try:
+            meta = ss.export_meta(); n_pos, n_mk, _ = ss.totals()
+            arrs = dict(seed=np.zeros(n_pos, np.uint32), pos=np.zeros(n_pos, np.uint32), ctgcanon=np.zeros(n_pos, np.uint32), markers=np.zeros(n_mk, np.uint64))
+            ss.export_arrays(**arrs)
+            ss2 = ctx2.import_flat(ss.params, meta, **arrs)
+            comm2 = Comm.rccl(ctx2, None, 0, 1, torch=torch, device=dev)
+            for call in range(2):
+                i2, j2, res2, n2, st2 = comm2.triangle(ss2, mp_)
+                assert st2["screen_by_key_range"] == 1 and n2 == 380 and np.array_equal(i2, si) and np.array_equal(j2, sj) and res2.tobytes() == sres.tobytes(), call
+            comm2.close(); ss2.close()
+        finally:
+            ctx2.close()
         ss.close()
     finally:
         ctx.close()
