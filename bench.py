@@ -152,7 +152,7 @@ def run_search(args, torch, sk, ctx, device):
     qs = ctx.sketch_genomes(gq, params, genome_rank=np.arange(10_000_000, 10_000_000 + nq, dtype=np.uint32))
     gq.close()
     torch.cuda.empty_cache()
-    live_b, idle_b = ctx.device_memory(trim=True)                    # (the library's idle cache -- up to 32 GiB of freed build scratch -- handed back: the database itself is what stays)
+    live_b, idle_b = ctx.device_memory(trim=True)                    # (the library's idle cache of freed build scratch handed back: the database itself is what stays)
     mem_gb = torch.cuda.mem_get_info(device)
     for _ in range(args.warmup):
         sk.search(ctx, db, qs, n_query_files=nq)
@@ -404,6 +404,19 @@ class stdout_to_stderr:
         return False
 
 
+def cpu_stat():
+    """The container's CPU accounting (cgroup v2): a step that waits although the GPU is done may have been throttled by the CPU quota."""
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat") if len(l.split()) == 2)}
+    except (OSError, ValueError):
+        return {}
+
+
+def cpu_stat_delta(before):
+    now = cpu_stat()
+    return {k: now[k] - before.get(k, 0) for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in now}
+
+
 def file_sha(path):
     import hashlib
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -555,6 +568,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu_stat0 = cpu_stat()
     t0 = time.perf_counter()
     kept = chained = 0
     for _ in range(args.steps):
@@ -565,8 +579,8 @@ def main():
     dt = time.perf_counter() - t0
     tm = ctx.timings()
     if os.environ.get("BENCH_STEP_TIMES"):
-        print("host view of a step (ms): sketch_genomes %.3f, triangle %.3f, sketch set close %.3f; library timers: %s" %
-              tuple([1e3 * x / args.steps for x in host_t] + [{k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms")}]), file=sys.stderr)
+        print("host view of a step (ms): sketch_genomes %.3f, triangle %.3f, sketch set close %.3f; library timers: %s; cgroup cpu.stat over the timed steps: %s" %
+              tuple([1e3 * x / args.steps for x in host_t] + [{k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms")}, cpu_stat_delta(cpu_stat0)]), file=sys.stderr)
     per_rank = None
     if comm is not None:
         t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())

@@ -2,7 +2,9 @@
 //
 // Freed blocks are kept, per device, and handed out again to requests of (nearly) the same size: a pipeline that sketches
 // and compares batch after batch asks for the same array sizes every time.  The cache is bounded (SKH_TUNE_ALLOC_CACHE_BYTES,
-// default 32 GiB per device; 0 disables it) and is flushed before an allocation is allowed to fail.
+// default a third of the device's memory, beyond 32 GiB only while an eighth of the device stays free; 0 disables it) and is flushed before an allocation is allowed to fail.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -19,11 +21,25 @@ struct Pool {
     std::mutex mu;
     std::unordered_map<void*, std::pair<size_t, int>> live;   // block -> (size, device)
     std::map<int, DeviceCache> dev;
-    size_t cap;
-    Pool() { const char* v = getenv("SKH_TUNE_ALLOC_CACHE_BYTES"); cap = v && *v ? (size_t)strtoull(v, nullptr, 10) : ((size_t)32 << 30); }
+    size_t cap = 0; bool cap_known = false, cap_from_env = false;
+    Pool() { const char* v = getenv("SKH_TUNE_ALLOC_CACHE_BYTES"); if (v && *v) { cap = (size_t)strtoull(v, nullptr, 10); cap_known = cap_from_env = true; } }
+    // default bound: a third of the device's memory (96 GB on an MI355X).  A step over 10,000 genomes frees and asks again for ~45 GB of arrays; with the earlier 32 GiB
+    // bound 9.4 GB of them went back to the driver and came from it again in every step, and the driver's clearing of fresh memory held the step's first kernel back by 10-20 ms.
+    size_t bound() {
+        if (!cap_known) { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) cap = tot / 3; else { (void)hipGetLastError(); cap = (size_t)32 << 30; } cap_known = true; }
+        return cap;
+    }
     void flush(DeviceCache& dc) { for (auto& kv : dc.idle) (void)hipFree(kv.second); dc.idle.clear(); dc.idle_bytes = 0; }
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }   // leaked on purpose: outlives every static DBuf
+
+// SKH_TRACE_ALLOC=1: every request that reaches the driver (a cache miss, a block the cache has no room for) is printed with its size and how long the call took
+bool trace_alloc() { static const bool on = [] { const char* v = getenv("SKH_TRACE_ALLOC"); return v && *v && *v != '0'; }(); return on; }
+struct DriverCall {
+    const char* what; size_t bytes; std::chrono::steady_clock::time_point t0;
+    DriverCall(const char* w, size_t b) : what(w), bytes(b) { if (trace_alloc()) t0 = std::chrono::steady_clock::now(); }
+    ~DriverCall() { if (trace_alloc()) fprintf(stderr, "[skh alloc] %s %.1f MB  %.3f ms\n", what, bytes / 1048576.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 }  // namespace
 
@@ -40,6 +56,7 @@ void* dmalloc(size_t n) {
         return p;
     }
     void* p = nullptr;
+    DriverCall dc_trace("hipMalloc", n);
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) { (void)hipGetLastError(); P.flush(dc); e = hipMalloc(&p, n); }
     hip_check(e, "hipMalloc");
@@ -52,11 +69,18 @@ void dfree(void* p) {
     Pool& P = pool();
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.live.find(p);
-    if (it == P.live.end()) { (void)hipFree(p); return; }
+    if (it == P.live.end()) { DriverCall t("hipFree (unknown block)", 0); (void)hipFree(p); return; }
     const size_t sz = it->second.first; const int device = it->second.second;
     P.live.erase(it);
     DeviceCache& dc = P.dev[device];
-    if (sz > P.cap || dc.idle_bytes + sz > P.cap) { (void)hipFree(p); return; }
+    const size_t cap = P.bound();
+    bool keep = sz <= cap && dc.idle_bytes + sz <= cap;
+    if (keep && !P.cap_from_env && dc.idle_bytes + sz > ((size_t)32 << 30)) {       // a large cache only while the device has room to spare for others (a resident database, the caller's own allocations)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); keep = false; }
+        else keep = fr >= tot / 8;
+    }
+    if (!keep) { DriverCall t("hipFree (cache full)", sz); (void)hipFree(p); return; }
     dc.idle.emplace(sz, p); dc.idle_bytes += sz;
 }
 

@@ -212,6 +212,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
     *out = nullptr;
     skh_genome_set* gs = const_cast<skh_genome_set*>(gs_c);
     skh_sketch_set* ss = nullptr;
+    StageTrace tr(ctx);
     int rc = guarded(ctx, [&] {
         check_params(sp);
         if (gs->open) throw std::invalid_argument("the genome set is still being filled: call skh_genomes_finish first");
@@ -222,6 +223,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
         for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
         finalize_metadata(ss);
+        tr.mark("sketch: metadata");
         SeedOutput so;
         // Phase times from three events on the main stream, read when the call is over: nothing waits between the seeding's last kernel (the
         // compaction, ~0.3 ms) and the table build, whose host-side tables are prepared while that kernel runs.
@@ -233,6 +235,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         };
         seed_genomes(ctx, gs, *sp, so, true, ss->wide);
         ev[1].record(ctx->stream);
+        tr.mark("sketch: seeded");
         // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)
         struct TailGuard { bool armed = true; ~TailGuard() { if (armed) device_sync_all(); } } tail_guard;
         ss->p_seed = std::move(so.seed); ss->p_g = std::move(so.g); ss->p_g64 = std::move(so.g64); ss->pos_off = so.pos_off;
@@ -248,6 +251,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             return;
         }
         TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
+        tr.mark("sketch: tables queued");
         ev[1].make_wait(ctx->stream2);                                                // the raw markers come out of the compaction kernel
         // (letting the second stream start only beside the table build's big kernels -- instead of beside the small copies and fills in front of them,
         //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
@@ -256,10 +260,13 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
+        tr.mark("sketch: markers + screen index");
         build_sketch_tables_finish(ctx, ss, tb);
         book(); tail_guard.armed = false;
+        tr.mark("sketch: tables finished");
     });
     ctx->arena.reset();
+    tr.mark("sketch: arena reset");
     if (rc != SKH_OK) { delete ss; return rc; }
     *out = ss;
     return SKH_OK;

@@ -10,6 +10,9 @@ def main():
     rows = list(db.execute("select name, start, end from kernels order by start"))
     starts = [i for i, r in enumerate(rows) if "seed_tiles_kernel" in r[0]]
     i0 = starts[-1]
+    # a large collection is seeded in several launches: the step starts at the first of them, i.e. behind the previous step's last estimate kernel
+    prev = [i for i, r in enumerate(rows[:i0]) if "finalize_kernel" in r[0]]
+    i0 = next(i for i in starts if i > (prev[-1] if prev else -1))
     step = rows[i0:]
     # cut at the last skh:: kernel (the torch kernels of the harness follow)
     last = max(i for i, r in enumerate(step) if "skh::" in r[0])

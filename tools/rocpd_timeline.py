@@ -13,6 +13,9 @@ def main():
     wcol = next((c for c in ("workgroup_x", "workgroup_size_x", "workgroup_size") if c in cols), None)
     rows = list(db.execute("select name, start, end, %s, %s, %s from kernels order by start" % (qcol or "0", gcol or "0", wcol or "0")))
     i0 = [i for i, r in enumerate(rows) if "seed_tiles_kernel" in r[0]][-1]
+    # a large collection is seeded in several launches: the step starts at the first of them, i.e. behind the previous step's last estimate kernel
+    prev = [i for i, r in enumerate(rows[:i0]) if "finalize_kernel" in r[0]]
+    i0 = next(i for i in range(prev[-1] + 1 if prev else 0, i0 + 1) if "seed_tiles_kernel" in rows[i][0])
     step = rows[i0:]
     last = max(i for i, r in enumerate(step) if "skh::" in r[0])
     step = step[:last + 1]
