@@ -192,29 +192,31 @@ void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std
 // first round fits; when some rank has more records than the capacity -- every rank reads that from the same gathered heads -- all ranks raise the
 // capacity to the largest count and go round once more.  Returns the records of all ranks back to back (rank order) and the per-rank counts; a rank whose
 // status word is set stops every rank (on_failed).
+template <class Rec> struct Gathered { std::vector<const Rec*> block; std::vector<uint64_t> counts; uint64_t total = 0; };   // rank r's records: block[r][0 .. counts[r])
 template <class Rec, class Failed>
-static void gather_records(skh_ctx* ctx, Transport& T, const std::vector<Rec>& mine, bool my_status, uint64_t& cap, std::vector<Rec>& all, std::vector<uint64_t>& counts, Failed&& on_failed) {
+static Gathered<Rec> gather_records(skh_ctx* ctx, Transport& T, const std::vector<Rec>& mine, bool my_status, uint64_t& cap, Failed&& on_failed) {
     static_assert(sizeof(Rec) % 8 == 0, "records keep the block 8-byte aligned");
     const int W = T.world;
-    counts.assign(W, 0);
+    Gathered<Rec> G; G.block.assign(W, nullptr); G.counts.assign(W, 0);
     for (int round = 0;; round++) {
         const size_t block = 16 + (size_t)cap * sizeof(Rec);
-        std::vector<char> send(block, 0), recv((size_t)W * block);
+        // the communicator's own staging (grown, never shrunk, not cleared: only a block's head and its first `count` records mean anything) -- fresh vectors of
+        // config 4's result rows were 7 MB of page faults and zeroes on every rank and call
+        if (T.g_send.size() < block) T.g_send.resize(block);
+        if (T.g_recv.size() < (size_t)W * block) T.g_recv.resize((size_t)W * block);
+        char* send = T.g_send.data(); char* recv = T.g_recv.data();
         uint64_t head[2] = {mine.size(), my_status ? 1ull : 0ull};
-        memcpy(send.data(), head, 16);
-        if (mine.size() <= cap && !mine.empty()) memcpy(send.data() + 16, mine.data(), mine.size() * sizeof(Rec));
-        T.all_gather(ctx, send.data(), recv.data(), block, false);
-        uint64_t mx = 0, tot = 0;
+        memcpy(send, head, 16);
+        if (mine.size() <= cap && !mine.empty()) memcpy(send + 16, mine.data(), mine.size() * sizeof(Rec));
+        T.all_gather(ctx, send, recv, block, false);
+        uint64_t mx = 0; G.total = 0;
         for (int r = 0; r < W; r++) {
-            uint64_t h[2]; memcpy(h, recv.data() + (size_t)r * block, 16);
-            counts[r] = h[0]; mx = std::max(mx, h[0]); tot += h[0];
+            uint64_t h[2]; memcpy(h, recv + (size_t)r * block, 16);
+            G.counts[r] = h[0]; mx = std::max(mx, h[0]); G.total += h[0];
             if (h[1]) on_failed(r);
+            G.block[r] = (const Rec*)(recv + (size_t)r * block + 16);
         }
-        if (mx <= cap) {
-            all.clear(); all.reserve(tot);
-            for (int r = 0; r < W; r++) { const Rec* b = (const Rec*)(recv.data() + (size_t)r * block + 16); all.insert(all.end(), b, b + counts[r]); }
-            return;
-        }
+        if (mx <= cap) return G;                                                    // (valid until the communicator's next gather)
         if (round) throw Error("gather_records: the second round did not fit (ranks disagree on the sizes)");
         cap = mx;
     }
@@ -441,11 +443,11 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         struct Cand { uint32_t i, j; };
         ex_begin();
         {
-            std::vector<Cand> mine_c(my_i.size()), all_c; std::vector<uint64_t> np_all;
+            std::vector<Cand> mine_c(my_i.size());
             for (size_t x = 0; x < my_i.size(); x++) mine_c[x] = Cand{my_i[x], my_j[x]};
-            gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, all_c, np_all, [&](int r) { stop_together("marker sets / screen", r); });
-            pi.resize(all_c.size()); pj.resize(all_c.size());
-            for (size_t x = 0; x < all_c.size(); x++) { pi[x] = all_c[x].i; pj[x] = all_c[x].j; }
+            const Gathered<Cand> G = gather_records(ctx, T, mine_c, !local_err.empty(), T.cap_pairs, [&](int r) { stop_together("marker sets / screen", r); });
+            pi.clear(); pj.clear(); pi.reserve(G.total); pj.reserve(G.total);
+            for (int r = 0; r < W; r++) for (uint64_t x = 0; x < G.counts[r]; x++) { pi.push_back(G.block[r][x].i); pj.push_back(G.block[r][x].j); }
         }
         ex_end();
     }
@@ -620,24 +622,23 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     T.exchange_times(&st.exchange_async_us, &st.exchange_wait_us);
     // ---- 8. results (ani > 0.1, triangle.rs:99) gathered on every rank, sorted by (i, j)
     struct Row { uint32_t i, j; skh_ani_result r; };
-    std::vector<Row> rows, all;
+    std::vector<Row> rows;
     for (size_t p = 0; p < res.size(); p++) if (local_err.empty() && res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
     ex_begin();
-    std::vector<uint64_t> rows_all;
-    gather_records(ctx, T, rows, !local_err.empty(), T.cap_rows, all, rows_all, [&](int r) { stop_together("seed tables / chaining", r); });
+    const Gathered<Row> G = gather_records(ctx, T, rows, !local_err.empty(), T.cap_rows, [&](int r) { stop_together("seed tables / chaining", r); });
     ex_end();
     // The rows into (i, j) order.  Every rank sent its rows in the order of the candidate list, which every rank holds: one walk over that list with a cursor
     // per rank puts them in place (a sort of 95,000 rows of 72 bytes took milliseconds on every rank of config 4).
-    out_i.clear(); out_j.clear(); out_res.clear(); out_i.reserve(all.size()); out_j.reserve(all.size()); out_res.reserve(all.size());
+    out_i.clear(); out_j.clear(); out_res.clear(); out_i.reserve(G.total); out_j.reserve(G.total); out_res.reserve(G.total);
     {
-        std::vector<size_t> cur(W + 1, 0);
-        for (int r = 0; r < W; r++) cur[r + 1] = cur[r] + rows_all[r];
-        std::vector<size_t> end(cur.begin() + 1, cur.end());
+        std::vector<uint64_t> cur(W, 0);
         for (size_t p2 = 0; p2 < NP; p2++) {
-            const int r = owner[p2]; const size_t x = cur[r];
-            if (x < end[r] && all[x].i == pi[p2] && all[x].j == pj[p2]) { out_i.push_back(all[x].i); out_j.push_back(all[x].j); out_res.push_back(all[x].r); cur[r]++; }
+            const int r = owner[p2]; const uint64_t x = cur[r];
+            if (x >= G.counts[r]) continue;
+            const Row& row = G.block[r][x];
+            if (row.i == pi[p2] && row.j == pj[p2]) { out_i.push_back(row.i); out_j.push_back(row.j); out_res.push_back(row.r); cur[r]++; }
         }
-        if (out_i.size() != all.size()) throw Error("distributed triangle: the gathered result rows do not follow the candidate list");
+        if (out_i.size() != G.total) throw Error("distributed triangle: the gathered result rows do not follow the candidate list");
     }
     ctx->timings.exchange_ms += (float)exch_ms;
     if (stats) *stats = st;

@@ -180,6 +180,7 @@ struct Transport {
     uint64_t cap_n = 0, cap_c = 0, cap_m = 0, cap_pairs = 0, cap_rows = 0;
     // the key-range screen's cell gather runs on device buffers the communicator keeps (cap_cells + 2 words per rank: a head and the cells)
     uint64_t cap_cells = 0; DBuf<uint64_t> cells_send, cells_recv;
+    std::vector<char> g_send, g_recv;                                               // host staging of gather_records (dist.hip)
     virtual ~Transport() {}
     // every rank contributes `bytes` bytes; recv gets world * bytes in rank order.  device: both buffers are device memory.
     virtual void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) = 0;
