@@ -15,7 +15,7 @@ N = inp["genomes"]
 LINK = 76.5e9 * 0.6            # one xGMI link, one direction: 153 GB/s bidirectional, 60 % of it assumed reachable by RCCL
 MARKER_BYTES = 5000 * 8 * N   # ~5,000 markers per 5 Mbp genome at marker_c = 1000
 MARKERS_MS, TABLES_MS = 2.3, ph["sketch_build_ms"] - 2.3       # the sketch phase's two parts at N = 10,000 (SKH_TRACE: markers 2.3 ms beside the tables)
-PLAN_MS, RESULTS_MS = 0.6, 1.0                                  # measured at 10,000 genomes with a world of one (SKH_TRACE=1 marks)
+PLAN_MS, RESULTS_MS = 0.6, 2.4                                  # measured at 10,000 genomes with a world of one (SKH_TRACE=1 marks: plan 0.60; result rows 1.3-2.4, the slower one used)
 HOST_MS = n1["ms_per_step"] - sum(ph.values())                  # what the N = 1 step spends outside the library's phase timers (Python, result copies, waits)
 # sketches a rank receives, GB: the plan (skh_plan_pairs, host code) run on config 4's shape for every world size -- 2,102 / ~1,600 / ~950 genomes of 39,600
 # positions x 8 B; 8 ranks on one device measured 0.298-0.313 GB
