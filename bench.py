@@ -561,6 +561,8 @@ def main():
     with stdout_to_stderr():                      # (the first collective may still print)
         for _ in range(args.warmup):
             step()
+            if os.environ.get("BENCH_WARMUP_PAUSE"):      # diagnostic (profiles/r04_first_steps_transient.md): an idle stretch behind each warm-up step
+                time.sleep(float(os.environ["BENCH_WARMUP_PAUSE"]))
         if comm is not None and args.warmup == 0:
             dist.barrier()
     ctx.timings()
