@@ -160,10 +160,10 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     const WidePair* d_wide_all = nullptr;
     if (W::wide) d_wide_all = upload(ctx, job.wps);
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
-    uint32_t* d_err = ctx->arena.get<uint32_t>(1); dzero(d_err, 4, ctx->stream);
+    uint32_t* d_err = ctx->arena.get<uint32_t>(1);
     uint32_t* tile_anch = ctx->arena.get<uint32_t>((size_t)NT + 1); uint32_t* tile_hits = ctx->arena.get<uint32_t>((size_t)NT + 1);
     uint32_t* d_pair_anch = ctx->arena.get<uint32_t>(NP); uint32_t* d_pair_inq = ctx->arena.get<uint32_t>(NP);
-    dzero(d_pair_anch, (size_t)NP * 4, ctx->stream); dzero(d_pair_inq, (size_t)NP * 4, ctx->stream);
+    { FillRegions fr; fr.add(d_err, 1, 0u); fr.add(d_pair_anch, NP, 0u); fr.add(d_pair_inq, NP, 0u); fill_regions(ctx, fr); }
 
     const uint64_t ANCH_BUDGET = ctx->tune.chain_anchors;        // anchors per batch (~30 B of scratch each)
     const uint32_t SUPER_TILES = ctx->tune.chain_super_tiles;    // join tiles per count pass (up to 8 KiB of hit records each)
@@ -269,7 +269,8 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         Interval* ivls = ctx->arena.get<Interval>(NI + 1); uint32_t* ivl_cnt = ctx->arena.get<uint32_t>(np);
         uint32_t* ivl_next = ctx->arena.get<uint32_t>(NI + 1); uint32_t* greedy_scratch = ctx->arena.get<uint32_t>((size_t)NS * GREEDY_BIG_WORDS + 1);
         uint32_t* chunk_head = ctx->arena.get<uint32_t>(NC + 1); uint32_t* n_acc = ctx->arena.get<uint32_t>(np);
-        dzero(ivl_cnt, np * 4, ctx->stream); dfill(chunk_head, 0xFF, ((uint64_t)NC + 1) * 4, ctx->stream);
+        FillRegions stage_fills; stage_fills.add(ivl_cnt, np, 0u); stage_fills.add(chunk_head, (uint64_t)NC + 1, 0xFFFFFFFFu);   // (+ the DP order's histogram below: one launch)
+        bool stage_filled = false;
         const EmitCtxT<W> ec{anc_q, anc_r, d_pairs, d_wide, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
             bool chained = false;
@@ -283,7 +284,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 uint4* emit_q = ctx->arena.get<uint4>((size_t)DP_EMIT_Q * gt * T);
                 const unsigned ob = (NC + DP_ORDER_BLOCK - 1) / DP_ORDER_BLOCK;
                 uint32_t* order = ctx->arena.get<uint32_t>(NC); uint32_t* ohist = ctx->arena.get<uint32_t>(2 * DP_ORDER_KEYS);   // histogram | scatter cursors
-                dzero(ohist, 2 * DP_ORDER_KEYS * 4, ctx->stream);
+                stage_fills.add(ohist, 2 * DP_ORDER_KEYS, 0u); fill_regions(ctx, stage_fills); stage_filled = true;
                 SKH_LAUNCH(dp_order_hist_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, ohist);
                 SKH_LAUNCH(dp_order_scatter_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)ohist, ohist + DP_ORDER_KEYS, order);
                 check_launch("dp_order");
@@ -297,6 +298,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 check_launch("chain_dp_thread");
             }
             if (!chained) {     // wave-per-chunk sweep + per-anchor argmax records + emit
+                fill_regions(ctx, stage_fills); stage_filled = true;
                 unsigned long long* best = ctx->arena.get<unsigned long long>((size_t)NA + 64);
                 dzero(best, ((uint64_t)NA + 64) * 8, ctx->stream);
                 const unsigned gb = (NC + 3) / 4;
@@ -310,13 +312,19 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 check_launch("interval_emit");
             }
         }
+        if (!stage_filled) fill_regions(ctx, stage_fills);
 #define SKH_GREEDY(CAP) SKH_LAUNCH(greedy_fast_kernel<CAP>, np, 64, 0, ctx->stream, np, (const uint32_t*)g_order, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0, \
                    (const uint32_t*)ivl_cnt, (const Interval*)ivls, ctx->tune.greedy_len_limit, big_min, ivl_next, chunk_head, n_acc); check_launch("greedy_fast")
         tr.mark("dp (+order sort)");
         uint32_t* g_keys = ctx->arena.get<uint32_t>(np); uint32_t* g_order = ctx->arena.get<uint32_t>(np);
-        SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);
-        check_launch("greedy_order_keys");
-        sort_pairs_u32_u32(ctx, g_keys, g_order, np, 16);
+        if (np <= GREEDY_ORDER_ONE_MAX) {                                             // one launch (it was six: keys + a radix sort of 9,500 values)
+            SKH_LAUNCH(greedy_order_kernel, 1u, 1024, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_order);
+            check_launch("greedy_order");
+        } else {
+            SKH_LAUNCH(greedy_order_keys_kernel, (np + 255) / 256, 256, 0, ctx->stream, np, (const uint32_t*)ivl_cnt, g_keys, g_order);
+            check_launch("greedy_order_keys");
+            sort_pairs_u32_u32(ctx, g_keys, g_order, np, 16);
+        }
         SKH_GREEDY(256); SKH_GREEDY(512); SKH_GREEDY(1024);
 #undef SKH_GREEDY
         SKH_LAUNCH(greedy_kernel, (np + 3) / 4, 256, 0, ctx->stream, np, (const uint32_t*)d_pi0, (const uint32_t*)d_pc0,
@@ -346,9 +354,10 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
 #define SKH_FIN(CAP, MIN, MAX, THR) SKH_LAUNCH((finalize_kernel<CAP, MIN, MAX, THR>), np, THR, 0, ctx->stream, fa, d_pairs, (const uint32_t*)d_pc0, (const uint32_t*)n_chunks, \
                    (const double*)chunk_est, (const uint32_t*)chunk_w, (const uint4*)chunk_sums, fs, n_est, d_out + p0); \
         check_launch("finalize")
-        SKH_FIN(320, 0, 320, FIN_THREADS); SKH_FIN(1024, 321, 1024, FIN_THREADS);
-        bool any_long = false;                                                        // a pair that may have more than 1024 chunks: the global-memory instantiation
-        for (uint32_t i = 0; i < np && !any_long; i++) any_long = pc0[i + 1] - pc0[i] > 1024;
+        bool any_mid = false, any_long = false;                                       // a pair that may have more than 320 / 1024 chunks (the latter: the global-memory instantiation)
+        for (uint32_t i = 0; i < np && !any_long; i++) { any_mid = any_mid || pc0[i + 1] - pc0[i] > 320; any_long = pc0[i + 1] - pc0[i] > 1024; }
+        SKH_FIN(320, 0, 320, FIN_THREADS);
+        if (any_mid) { SKH_FIN(1024, 321, 1024, FIN_THREADS); }
         if (any_long) { SKH_FIN(1, 1025, 0xFFFFFFFFu, 1024); }
 #undef SKH_FIN
         tr.mark("finalize");

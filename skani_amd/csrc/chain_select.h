@@ -51,6 +51,29 @@ __global__ __launch_bounds__(256) void greedy_order_keys_kernel(uint32_t n_pairs
     const uint32_t n = ivl_cnt[p];
     keys[p] = 0xFFFFu - (n > 0xFFFFu ? 0xFFFFu : n); vals[p] = p;
 }
+// The same order for up to GREEDY_ORDER_ONE_MAX pairs in one launch: a counting sort in LDS by min(candidates, 2047), most candidates first.  Pairs of one class come
+// out in no particular order -- the order only decides which pair starts when.
+constexpr uint32_t GREEDY_ORDER_ONE_MAX = 1u << 17, GREEDY_ORDER_CLASSES = 2048;
+__global__ __launch_bounds__(1024) void greedy_order_kernel(uint32_t n_pairs, const uint32_t* ivl_cnt, uint32_t* order) {
+    __shared__ uint32_t cls[GREEDY_ORDER_CLASSES];
+    __shared__ uint32_t wsum[16];
+    for (uint32_t x = threadIdx.x; x < GREEDY_ORDER_CLASSES; x += 1024) cls[x] = 0;
+    __syncthreads();
+    auto klass = [&](uint32_t p) { const uint32_t n = ivl_cnt[p]; return GREEDY_ORDER_CLASSES - 1u - (n < GREEDY_ORDER_CLASSES ? n : GREEDY_ORDER_CLASSES - 1u); };   // class 0 = the most candidates
+    for (uint32_t p = threadIdx.x; p < n_pairs; p += 1024) atomicAdd(&cls[klass(p)], 1u);
+    __syncthreads();
+    // exclusive scan of the 2048 class sizes: two per thread
+    const uint32_t a = cls[2 * threadIdx.x], b = cls[2 * threadIdx.x + 1];
+    const uint32_t incl = wave_incl_scan(a + b), w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    if (l == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; i++) base += wsum[i];
+    const uint32_t off = base + incl - (a + b);
+    cls[2 * threadIdx.x] = off; cls[2 * threadIdx.x + 1] = off + a;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n_pairs; p += 1024) order[atomicAdd(&cls[klass(p)], 1u)] = p;
+}
 template <uint32_t CAP>
 __global__ __launch_bounds__(64) void greedy_fast_kernel(uint32_t n_pairs, const uint32_t* order, const uint32_t* pi0, const uint32_t* pc0, const uint32_t* ivl_cnt,
                                                          const Interval* ivls, uint32_t len_limit, uint32_t big_min, uint32_t* ivl_next, uint32_t* chunk_head, uint32_t* n_accepted) {

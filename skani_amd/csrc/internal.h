@@ -65,6 +65,7 @@ struct skh_tunables {
     uint32_t build_match_cap = 0;                       // positions a table slice may list in LDS on the first attempt (0 = as many as the slice has home slots; tests use few to force the re-scanning path)
     uint32_t greedy_len_limit = 0x10000;               // chain intervals at least this long on either axis send their pair to the general selection kernel (tests use a small value to drive that hand-over)
     uint32_t greedy_big_min = 2049;                    // candidate intervals from which a pair's selection runs in global memory (greedy_big_kernel); tests use small values
+    uint64_t scan_one_max = ~0ull, scan_two_max = ~0ull; // tests: the largest arrays the one-launch / two-launch prefix sums take (scan.hip; smaller values push small inputs through the other forms)
     uint32_t dist_key_range_w1 = 0;                     // tests: a world of one screens by key range too (the cell gather on device buffers through the transport)
     uint32_t dist_fail = 0;                             // tests: the n-th local phase of a distributed triangle fails on this rank (0 = never)
     uint32_t chain_dp_lds_slots = 8;                    // live-chain slots per DP lane kept in LDS (8, or 1 to exercise the spill path)
@@ -82,6 +83,7 @@ struct skh_ctx {
     skh_timings timings{};
     skh::PinBuf pin_pairs;                               // the chaining's pair descriptors (host side)
     skh::PinRing ring;                                   // pinned staging of this context's small uploads (dev.h h2d); entry points bind it to their thread
+    skh::DBuf<uint32_t> scan_ticket;                     // two counters (one per stream), zero between scans (scan.hip)
     bool screen_planes_checked = false;                  // the per-XCD count planes of the triangle screen passed their self-test (screen.hip)
 };
 
@@ -102,6 +104,7 @@ struct skh_genome_set {
     std::vector<uint32_t> genome_first_tile;       // n_genomes + 1: index of each genome's first tile (genomes without tiles: their successor's)
     std::vector<uint32_t> tile_cached_for;         // {mode} the tile list was built for
     skh::DBuf<skh::SeedTile> d_tiles;
+    skh::DBuf<uint32_t> d_genome_first_tile;       // genome_first_tile on the device
     // filling state (pack_seed.hip genomes_begin / _append / _finish)
     bool open = false; uint64_t cap_units = 0, n_units = 0; uint32_t cap_contigs = 0, n_batches = 0;
     skh::DBuf<uint8_t> stage[2];                   // device staging of the batches' ASCII (host sources), alternating
@@ -221,6 +224,12 @@ struct Stopwatch {   // wall-clock around stream-synchronous phases
 
 // ---- scan.hip
 void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t* d_out /* n+1 entries */);
+// up to eight regions of 32-bit words set to a value each, in one launch
+struct FillRegions {
+    uint32_t* p[8]; uint64_t words[8]; uint32_t value[8]; uint32_t blocks[8]; uint32_t n = 0;
+    void add(void* ptr, uint64_t n_words, uint32_t v) { if (n_words) { p[n] = (uint32_t*)ptr; words[n] = n_words; value[n] = v; n++; } }
+};
+void fill_regions(skh_ctx* ctx, FillRegions& fr);
 
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit);   // may redirect the pointers to the sorted arrays (arena)

@@ -272,6 +272,8 @@ void genomes_finish(skh_ctx* ctx, skh_genome_set* gs) {
     for (uint32_t g = ng; g-- > 0;) gs->genome_first_tile[g] = std::min(gs->genome_first_tile[g], gs->genome_first_tile[g + 1]);
     gs->d_tiles.alloc(gs->tiles.size() ? gs->tiles.size() : 1);
     h2d(gs->d_tiles.p, gs->tiles.data(), gs->tiles.size() * sizeof(SeedTile), ctx->stream);
+    gs->d_genome_first_tile.alloc(ng + 1);                                           // (seed_offsets_kernel reads the genomes' offsets out by it)
+    h2d(gs->d_genome_first_tile.p, gs->genome_first_tile.data(), ((size_t)ng + 1) * 4, ctx->stream);
     dsync(ctx->stream);
 }
 
@@ -524,14 +526,82 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; }
 }
 
-// tiles whose counts exceed the capped scratch get a slot in the full-capacity overflow scratch
-__global__ __launch_bounds__(256) void seed_overflow_kernel(const uint32_t* cnt_s, const uint32_t* cnt_m, uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m,
-                                                            uint32_t* ovf_idx, uint32_t* ovf_list, uint32_t* n_ovf) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    uint32_t idx = 0xFFFFFFFFu;
-    if (cnt_s[t] > cap_s || cnt_m[t] > cap_m) { idx = atomicAdd(n_ovf, 1u); ovf_list[idx] = t; }
-    ovf_idx[t] = idx;
+// What lies between the seeding kernel and its compaction, in ONE launch (it was fourteen: an overflow pass, two scans of four launches each, an upload, two gathers,
+// two copies -- 70 us of small kernels):
+//   * every workgroup takes 1024 tiles: a tile whose counts exceed the capped scratch gets a slot in the full-capacity overflow scratch; the tiles' seed and marker
+//     counts are scanned inside the workgroup (loc_*: a tile's offset within its block of 1024) and the block's totals are published;
+//   * the workgroup that finishes LAST (a ticket) scans the block totals (blk_*: exclusive, one more entry = the grand total) and reads out what the host wants to know:
+//     the offsets at the first tile of every genome that starts inside this launch, the totals and the overflow count.
+// A tile's offset is loc[t] + blk[t >> 10]: the compaction kernel adds the two itself.
+constexpr uint32_t OFFS_T = 1024, OFFS_MAX_BLOCKS = 4096;                            // (a launch covers at most 4 M tiles)
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* total, uint32_t* lds /* 16 words */) {
+    const uint32_t incl = wave_incl_scan(v), w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    if (l == 63) lds[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t i = 0; i < 16; i++) { const uint32_t t = lds[i]; if (i < w) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+__global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_s, const uint32_t* cnt_m, uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m,
+                                                            uint32_t* ovf_idx, uint32_t* ovf_list, uint32_t* n_ovf /* [0] overflow count, [1] ticket: both zero at launch */,
+                                                            uint32_t* loc_s, uint32_t* loc_m, uint32_t* blk_s, uint32_t* blk_m /* gridDim.x + 1 entries each */,
+                                                            const uint32_t* genome_first_tile, uint32_t n_genomes, uint32_t tile0, uint32_t* got /* 2 (n_genomes + 1) + 3 */) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t last;
+    const uint32_t t = blockIdx.x * OFFS_T + threadIdx.x;
+    const uint32_t cs = t < n_tiles ? cnt_s[t] : 0u, cm = t < n_tiles ? cnt_m[t] : 0u;
+    if (t < n_tiles) {
+        uint32_t idx = 0xFFFFFFFFu;
+        if (cs > cap_s || cm > cap_m) { idx = atomicAdd(&n_ovf[0], 1u); ovf_list[idx] = t; }
+        ovf_idx[t] = idx;
+    }
+    uint32_t tot_s, tot_m;
+    const uint32_t os = block_excl_scan_1024(cs, &tot_s, lds), om = block_excl_scan_1024(cm, &tot_m, lds);
+    if (t < n_tiles) { loc_s[t] = os; loc_m[t] = om; }
+    if (threadIdx.x == 0) {
+        blk_s[blockIdx.x] = tot_s; blk_m[blockIdx.x] = tot_m;                         // (totals for now; the last workgroup turns them into offsets)
+        __threadfence();
+        last = atomicAdd(&n_ovf[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // the last workgroup: exclusive scan of the block totals, four blocks per thread (what the other workgroups wrote is read past this CU's L1)
+    const uint32_t nb = gridDim.x;
+    uint32_t vs[4], vm[4], ss = 0, sm = 0;
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t b = threadIdx.x * 4 + i;
+        vs[i] = b < nb ? __atomic_load_n(&blk_s[b], __ATOMIC_RELAXED) : 0u; vm[i] = b < nb ? __atomic_load_n(&blk_m[b], __ATOMIC_RELAXED) : 0u;
+        ss += vs[i]; sm += vm[i];
+    }
+    uint32_t all_s, all_m;
+    uint32_t bs = block_excl_scan_1024(ss, &all_s, lds), bm = block_excl_scan_1024(sm, &all_m, lds);
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t b = threadIdx.x * 4 + i;
+        if (b < nb) { blk_s[b] = bs; blk_m[b] = bm; }
+        bs += vs[i]; bm += vm[i];
+    }
+    if (threadIdx.x == 0) { blk_s[nb] = all_s; blk_m[nb] = all_m; }
+    __threadfence(); __syncthreads();
+    // the host's numbers: got[g], got[n_genomes + 1 + g] = the seed / marker offset at genome g's first tile if that lies in [tile0, tile0 + n_tiles] (else untouched)
+    for (uint32_t g = threadIdx.x; g <= n_genomes; g += OFFS_T) {
+        const uint32_t f = genome_first_tile[g];
+        if (f < tile0 || f > tile0 + n_tiles) continue;
+        const uint32_t lt = f - tile0;
+        uint32_t a, b;
+        if (lt == n_tiles) { a = all_s; b = all_m; }
+        else {
+            a = __atomic_load_n(&loc_s[lt], __ATOMIC_RELAXED) + __atomic_load_n(&blk_s[lt >> 10], __ATOMIC_RELAXED);
+            b = __atomic_load_n(&loc_m[lt], __ATOMIC_RELAXED) + __atomic_load_n(&blk_m[lt >> 10], __ATOMIC_RELAXED);
+        }
+        got[g] = a; got[n_genomes + 1 + g] = b;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* tail = got + 2 * (n_genomes + 1);
+        tail[0] = all_s; tail[1] = all_m; tail[2] = __atomic_load_n(&n_ovf[0], __ATOMIC_RELAXED);
+    }
 }
 
 // A QUARTER of a wave per tile (16 lanes: a tile holds ~65 seeds and ~8 markers) copies the tile's records to their final (contig,pos)-ordered place.  WIDE (a
@@ -545,7 +615,9 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
                                                            const uint32_t* __restrict__ t_seed, const uint16_t* __restrict__ t_loc,
                                                            const uint64_t* __restrict__ t_marker, const uint32_t* __restrict__ o_seed2,
                                                            const uint16_t* __restrict__ o_loc2, const uint64_t* __restrict__ o_marker2,
-                                                           const uint32_t* __restrict__ off_s, const uint32_t* __restrict__ off_m,
+                                                           const uint32_t* __restrict__ cnt_s, const uint32_t* __restrict__ cnt_m,
+                                                           const uint32_t* __restrict__ loc_s, const uint32_t* __restrict__ loc_m,
+                                                           const uint32_t* __restrict__ blk_s, const uint32_t* __restrict__ blk_m,
                                                            uint32_t* __restrict__ o_seed, uint32_t* __restrict__ o_g,
                                                            uint64_t* __restrict__ o_g64, uint64_t* __restrict__ o_marker) {
     constexpr uint32_t G = 16;                                                       // lanes per tile
@@ -555,7 +627,7 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     const SeedTile tile = tiles[lt];
     const uint32_t goff = contigs[tile.contig].goff;
     const uint64_t goff64 = ((uint64_t)contigs[tile.contig].goff_hi << 32) | goff;
-    const uint32_t s0 = off_s[lt], ns = off_s[lt + 1] - s0, m0 = off_m[lt], nm = off_m[lt + 1] - m0;
+    const uint32_t s0 = loc_s[lt] + blk_s[lt >> 10], ns = cnt_s[lt], m0 = loc_m[lt] + blk_m[lt >> 10], nm = cnt_m[lt];   // (seed_offsets_kernel)
     const uint32_t ov = ovf_idx[lt];
     const uint32_t* src_seed = ov == 0xFFFFFFFFu ? t_seed + (uint64_t)lt * cap_s : o_seed2 + (uint64_t)ov * SEED_TILE;
     const uint16_t* src_loc = ov == 0xFFFFFFFFu ? t_loc + (uint64_t)lt * cap_s : o_loc2 + (uint64_t)ov * SEED_TILE;
@@ -582,11 +654,6 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
     for (uint32_t x = ln + G; x < nm; x += G) o_marker[m0 + x] = src_mk[x];
 }
 
-__global__ __launch_bounds__(256) void gather_u32_at_kernel(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
-}
-
 // async_tail: a set seeded in ONE launch returns with its compaction kernel still queued (no wait, the arena not rewound): the caller queues the table
 // build behind it and prepares that build's host tables meanwhile; out.tail_pending says so
 void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail, bool wide) {
@@ -600,7 +667,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_s = ctx->tune.seed_tile_cap ? std::min<uint32_t>(SEED_TILE, ctx->tune.seed_tile_cap) : std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
-    const size_t MAX_TILES = std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes);   // tile scratch per launch
+    const size_t MAX_TILES = std::min<size_t>(std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes), (size_t)OFFS_MAX_BLOCKS * OFFS_T);   // tile scratch per launch
     struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)
@@ -614,10 +681,13 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         uint16_t* t_loc = ctx->arena.get<uint16_t>((size_t)nt * cap_s);
         uint64_t* t_marker = ctx->arena.get<uint64_t>((size_t)nt * cap_m);
         uint32_t* cnt_s = ctx->arena.get<uint32_t>(nt); uint32_t* cnt_m = ctx->arena.get<uint32_t>(nt);
-        uint32_t* off_s = ctx->arena.get<uint32_t>(nt + 1); uint32_t* off_m = ctx->arena.get<uint32_t>(nt + 1);
+        const uint32_t nblk = (nt + OFFS_T - 1) / OFFS_T;
+        uint32_t* loc_s = ctx->arena.get<uint32_t>(nt); uint32_t* loc_m = ctx->arena.get<uint32_t>(nt);
+        uint32_t* blk_s = ctx->arena.get<uint32_t>(nblk + 1); uint32_t* blk_m = ctx->arena.get<uint32_t>(nblk + 1);
         uint32_t* ovf_idx = ctx->arena.get<uint32_t>(nt); uint32_t* ovf_list = ctx->arena.get<uint32_t>(nt);
-        uint32_t* n_ovf = ctx->arena.get<uint32_t>(1);
-        dzero(n_ovf, 4, ctx->stream);
+        uint32_t* n_ovf = ctx->arena.get<uint32_t>(2);                                  // overflow count, the offsets kernel's ticket
+        uint32_t* d_got = ctx->arena.get<uint32_t>(2 * ((size_t)ng + 1) + 3);
+        dzero(n_ovf, 8, ctx->stream);
         const SeedTile* d_tiles = gs->d_tiles.p + t0;
         evs.emplace_back();
         evs.back().first.record(ctx->stream);
@@ -630,27 +700,16 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         check_launch("seed_tiles_kernel");
         evs.back().second.record(ctx->stream);
         tr.mark("seed: tiles kernel");
-        SKH_LAUNCH(seed_overflow_kernel, (nt + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf);
-        check_launch("seed_overflow");
-        exclusive_scan_u32(ctx, cnt_s, nt, off_s);
-        exclusive_scan_u32(ctx, cnt_m, nt, off_m);
-        // genome boundaries inside this launch + totals + overflow count in one small read-back
-        std::vector<uint32_t> want;   // local tile indices whose offsets we need
-        std::vector<uint32_t> want_g;
-        for (uint32_t g = 0; g <= ng; g++) if (g_first[g] >= t0 && g_first[g] <= t0 + nt) { want.push_back((uint32_t)(g_first[g] - t0)); want_g.push_back(g); }
-        want.push_back(nt);
-        uint32_t* d_want = ctx->arena.get<uint32_t>(want.size()); uint32_t* d_got = ctx->arena.get<uint32_t>(2 * want.size() + 1);
-        h2d(d_want, want.data(), want.size() * 4, ctx->stream);
-        SKH_LAUNCH(gather_u32_at_kernel, (unsigned)((want.size() + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)off_s, (const uint32_t*)d_want, (uint32_t)want.size(), d_got);
-        SKH_LAUNCH(gather_u32_at_kernel, (unsigned)((want.size() + 255) / 256), 256, 0, ctx->stream, (const uint32_t*)off_m, (const uint32_t*)d_want, (uint32_t)want.size(), d_got + want.size());
-        check_launch("gather_u32_at");
-        d2d(d_got + 2 * want.size(), n_ovf, 4, ctx->stream);
-        std::vector<uint32_t> got(2 * want.size() + 1);
+        // overflow slots, the tiles' offsets and the numbers the host needs (genome boundaries inside this launch, totals, overflow count) in one launch and one read-back
+        SKH_LAUNCH(seed_offsets_kernel, nblk, OFFS_T, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf,
+                   loc_s, loc_m, blk_s, blk_m, (const uint32_t*)gs->d_genome_first_tile.p, ng, (uint32_t)t0, d_got);
+        check_launch("seed_offsets");
+        std::vector<uint32_t> got(2 * ((size_t)ng + 1) + 3);
         d2h(got.data(), d_got, got.size() * 4, ctx->stream);
-        const uint32_t h_novf = got[2 * want.size()];
+        const uint32_t h_novf = got[2 * ((size_t)ng + 1) + 2];
         tr.mark("seed: scans + readback");
-        Part p; p.ns = got[want.size() - 1]; p.nm = got[2 * want.size() - 1];
-        for (size_t x = 0; x < want_g.size(); x++) { g_ns[want_g[x]] = base_s + got[x]; g_nm[want_g[x]] = base_m + got[want.size() + x]; }
+        Part p; p.ns = got[2 * ((size_t)ng + 1)]; p.nm = got[2 * ((size_t)ng + 1) + 1];
+        for (uint32_t g = 0; g <= ng; g++) if (g_first[g] >= t0 && g_first[g] <= t0 + nt) { g_ns[g] = base_s + got[g]; g_nm[g] = base_m + got[(size_t)ng + 1 + g]; }
         uint32_t *o_seed2 = nullptr; uint16_t* o_loc2 = nullptr; uint64_t* o_marker2 = nullptr;
         if (h_novf) {   // second pass over the overflowing tiles with worst-case capacity
             o_seed2 = ctx->arena.get<uint32_t>((size_t)h_novf * SEED_TILE); o_loc2 = ctx->arena.get<uint16_t>((size_t)h_novf * SEED_TILE);
@@ -668,7 +727,8 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         p.g.alloc(p.ns); if (wide) p.g64.alloc(p.ns);
 #define SKH_COMPACT(W) SKH_LAUNCH(seed_compact_kernel<W>, (nt + 15) / 16, 256, 0, ctx->stream, d_tiles, (const ContigDesc*)gs->d_contigs.p, nt, cap_s, cap_m, \
                    (const uint32_t*)ovf_idx, (const uint32_t*)t_seed, (const uint16_t*)t_loc, (const uint64_t*)t_marker, (const uint32_t*)o_seed2, \
-                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)off_s, (const uint32_t*)off_m, p.seed.p, p.g.p, p.g64.p, p.mk.p)
+                   (const uint16_t*)o_loc2, (const uint64_t*)o_marker2, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, (const uint32_t*)loc_s, (const uint32_t*)loc_m, \
+                   (const uint32_t*)blk_s, (const uint32_t*)blk_m, p.seed.p, p.g.p, p.g64.p, p.mk.p)
         if (wide) SKH_COMPACT(true); else SKH_COMPACT(false);
 #undef SKH_COMPACT
         check_launch("seed_compact_kernel");

@@ -247,12 +247,13 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         uint32_t total = 0;
         d2h(&total, row_off + rows, 4, ctx->stream);
         if (total) {
-            uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total);
+            uint32_t* of = ctx->arena.get<uint32_t>(2 * (size_t)total); uint32_t* os = of + total;   // (side by side: one read-back)
             SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
                        (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os, (uint32_t*)nullptr);
             check_launch("screen_threshold1");
-            size_t old = first.size(); first.resize(old + total); second.resize(old + total);
-            d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
+            std::vector<uint32_t> both(2 * (size_t)total);
+            d2h(both.data(), of, both.size() * 4, ctx->stream);
+            first.insert(first.end(), both.begin(), both.begin() + total); second.insert(second.end(), both.begin() + total, both.end());
         }
     }
     dsync(ctx->stream);
@@ -314,7 +315,7 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
     uint32_t total = 0;
     d2h(&total, row_off + rows, 4, ctx->stream);
     if (!total) return;
-    uint32_t* of = ctx->arena.get<uint32_t>(total); uint32_t* os = ctx->arena.get<uint32_t>(total); uint32_t* oc = cells ? ctx->arena.get<uint32_t>(total) : nullptr;
+    uint32_t* of = ctx->arena.get<uint32_t>(2 * (size_t)total); uint32_t* os = of + total; uint32_t* oc = cells ? ctx->arena.get<uint32_t>(total) : nullptr;
     SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 1, row_cnt, (const uint32_t*)row_off, of, os, oc);
     check_launch("screen_threshold1");
     if (cells) {
@@ -324,8 +325,9 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
         *d_cells = packed; *n_cells = total;
         return;
     }
-    const size_t old = first.size(); first.resize(old + total); second.resize(old + total);
-    d2h(first.data() + old, of, (size_t)total * 4, ctx->stream); d2h(second.data() + old, os, (size_t)total * 4, ctx->stream);
+    std::vector<uint32_t> both(2 * (size_t)total);
+    d2h(both.data(), of, both.size() * 4, ctx->stream);
+    first.insert(first.end(), both.begin(), both.begin() + total); second.insert(second.end(), both.begin() + total, both.end());
 }
 
 bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes) { return n_genomes && (uint64_t)n_genomes * n_genomes <= ctx->tune.screen_cells && n_genomes <= ID_MASK; }

@@ -61,6 +61,14 @@ def test_emu_small_budgets_force_multi_batch_paths(monkeypatch):
     monkeypatch.setenv("SKH_TUNE_BUILD_MATCH_CAP", "64")                # table slices with more than 64 positions re-scan the genome instead of listing them in LDS
     monkeypatch.setenv("SKH_TUNE_GREEDY_LEN_LIMIT", "3000")             # pairs with a chain interval of 3 kb or more are handed from the all-LDS selection kernel to the general one
     monkeypatch.setenv("SKH_TUNE_GREEDY_BIG_MIN", "4")                  # pairs with four or more candidate intervals select in global memory (greedy_big_kernel)
+    monkeypatch.setenv("SKH_TUNE_SCAN_ONE_MAX", "16")                   # prefix sums over more than 16 values take the two-launch form (a ticketed reduce pass + the down pass) ...
+    monkeypatch.setenv("SKH_TUNE_SCAN_TWO_MAX", "16")                   # ... here: the recursive form of arrays beyond 134 M values
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        pc.case_triangle_synthetic(c, params=((1, 125),), length=60000)
+    finally:
+        c.close()
+    monkeypatch.delenv("SKH_TUNE_SCAN_TWO_MAX")
     c = sk.Context(0, lib=emu_lib())
     try:
         pc.case_triangle_synthetic(c, params=((1, 125), (0, 30)), length=60000)
