@@ -394,10 +394,17 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         };
         auto grow = [&](uint64_t want) {                                              // (not one of the numbered local phases: it happens in a communicator's first call and when a collection grew)
             if (local_err.empty()) {
-                try { T.cells_send.alloc(want + 2); T.cells_recv.alloc((want + 2) * (size_t)W); T.cap_cells = want; }
+                try { T.cells_send.alloc(want + 2); T.cells_recv.alloc((want + 2) * (size_t)W); }
                 catch (const std::exception& e) { local_err = e.what(); }
             }
-            agree("cell buffers");
+            // every rank ends with the same capacity: the new one, or -- when any rank could not get its buffers -- none (the communicator's next call then starts
+            // like its first on every rank, whatever this one throws)
+            uint64_t mine_ok = local_err.empty() ? 0 : 1; std::vector<uint64_t> all(W);
+            T.all_gather(ctx, &mine_ok, all.data(), 8, false);
+            int failed = -1;
+            for (int r = 0; r < W && failed < 0; r++) if (all[r]) failed = r;
+            if (failed >= 0) { T.cells_send.release(); T.cells_recv.release(); T.cap_cells = 0; stop_together("cell buffers", failed); }
+            T.cap_cells = want;
         };
         uint64_t mx = 0;
         if (T.cap_cells == 0) {                                                     // no buffers yet: the counts travel alone

@@ -227,7 +227,7 @@ void exclusive_scan_u32(skh_ctx* ctx, const uint32_t* d_in, uint64_t n, uint32_t
 // up to eight regions of 32-bit words set to a value each, in one launch
 struct FillRegions {
     uint32_t* p[8]; uint64_t words[8]; uint32_t value[8]; uint32_t blocks[8]; uint32_t n = 0;
-    void add(void* ptr, uint64_t n_words, uint32_t v) { if (n_words) { p[n] = (uint32_t*)ptr; words[n] = n_words; value[n] = v; n++; } }
+    void add(void* ptr, uint64_t n_words, uint32_t v) { if (!n_words) return; if (n >= 8) throw skh::Error("FillRegions: more than eight regions"); p[n] = (uint32_t*)ptr; words[n] = n_words; value[n] = v; n++; }
 };
 void fill_regions(skh_ctx* ctx, FillRegions& fr);
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, GPU run 24: fewer launches (seeding tail in one kernel, one-launch scans, merged fills, one-launch selection order): parity, A/B against the previous library, launch count
+# round 4, GPU run 25: fewer launches (seeding tail in one kernel, one-launch scans, merged fills, one-launch selection order): parity, A/B against the previous library, launch count
 mkdir -p gpurun_out
 tag=r4z
 short() { python -c "
