@@ -157,11 +157,15 @@ def run_search(args, torch, sk, ctx, device):
     for _ in range(args.warmup):
         sk.search(ctx, db, qs, n_query_files=nq)
     ctx.timings()
+    host_times = {} if os.environ.get("BENCH_STEP_TIMES") else None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
-        q, r, res = sk.search(ctx, db, qs, n_query_files=nq)
+        q, r, res = sk.search(ctx, db, qs, n_query_files=nq, host_times=host_times)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     tm = ctx.timings()
+    if host_times is not None:
+        print("host view of a search step (ms): %s; library timers: %s" % ({k: round(1e3 * v / args.steps, 3) for k, v in host_times.items()},
+                                                                           {k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms") and v}), file=sys.stderr)
     own = (r // CLADE) == qclades[q]
     db.close(); qs.close()
     return ({"metric": "search queries/sec vs resident sketch DB", "value": nq / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

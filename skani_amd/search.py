@@ -72,33 +72,48 @@ def build_db(ctx, genomes, params, names=None, shard_genomes=None):
 
 
 def search(ctx, db, queries, screen_val=0.0, n_query_files=None, use_index=None, n_max=10000000, min_af=-1.0, robust=False, median=False,
-           learned_ani=None, compute_ci=True, ani_min=0.5):
-    """Returns (query_idx, ref_idx, results) sorted by query then ANI descending, at most n_max rows per query."""
+           learned_ani=None, compute_ci=True, ani_min=0.5, host_times=None):
+    """Returns (query_idx, ref_idx, results) sorted by query then ANI descending, at most n_max rows per query.
+    host_times: a dict that collects the wall time of the call's stages as the host sees them (seconds, added up over calls)."""
+    import time
+    t_last = [time.perf_counter()]
+    def lap(name):
+        if host_times is not None:
+            now = time.perf_counter(); host_times[name] = host_times.get(name, 0.0) + now - t_last[0]; t_last[0] = now
     c = db.shards[0].params.c if db.shards else 125
     if learned_ani is None:
         learned_ani = use_learned_ani(c, False, False, median)                   # search.rs:53
     if use_index is None:
         use_index = (n_query_files if n_query_files is not None else len(queries)) > FULL_INDEX_THRESH    # parse.rs:960
     mp = MapParams(min_af=min_af, robust=robust, median=median, learned_ani=learned_ani, compute_ci=compute_ci)
-    qs, rs, res = [], [], []
     if not db.shards:
         return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
     # one screen of all queries against the whole database's markers, then chaining shard by shard
+    lap("before the screen")
     q_all, r_all = ctx.screen(db.marker_index(ctx), queries, screen_val, SCREEN_REFS_INDICES if use_index else SCREEN_QUICK, False)
+    lap("screen call")
     if len(q_all) == 0:
         return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
     shard_of = (np.searchsorted(db.offsets, r_all, side="right") - 1).astype(np.uint32)
     local = (r_all.astype(np.int64) - db.offsets[shard_of]).astype(np.uint32)
+    lap("shard of every hit")
     out = ctx.chain_pairs_multi(db.shards, queries, shard_of, local, q_all, mp)    # chain_seeds(ref_sketch, query_sketch): search.rs:175
-    keep = out["ani"] > ani_min                                                    # search.rs:176
-    qs.append(q_all[keep]); rs.append(r_all[keep].astype(np.int64)); res.append(out[keep])
-    if not qs:
-        return np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, B.RESULT_DTYPE)
-    q = np.concatenate(qs); r = np.concatenate(rs); o = np.concatenate(res)
-    order = np.lexsort((r, -o["ani"].astype(np.float64), q))
-    q, r, o = q[order], r[order], o[order]
-    if n_max is not None:
+    lap("chain call")
+    # keep ani > 0.5 (search.rs:176), rows by query, then ANI descending, then reference (file_io.rs:640-655), at most n_max per query.  One stable sort on
+    # (query, ~ANI bits): a positive float32 orders like its bit pattern, and ties keep the reference-ascending order the screen returned (re-made if it is not there).
+    # np.take, not out[idx]: fancy indexing of a structured array goes field by field (2.4 ms for 20,000 rows of 64 B where take needs 0.15).
+    ani = np.ascontiguousarray(out["ani"])
+    keep = np.flatnonzero(ani > ani_min)
+    q = q_all[keep]; r = r_all[keep].astype(np.int64)
+    key = (q.astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ani[keep].view(np.uint32).astype(np.uint64))
+    if len(q) > 1 and not ((q[1:] > q[:-1]) | ((q[1:] == q[:-1]) & (r[1:] >= r[:-1]))).all():
+        pre = np.lexsort((r, q)); keep = keep[pre]; q = q[pre]; r = r[pre]; key = key[pre]
+    order = np.argsort(key, kind="stable")
+    q = q[order]; r = r[order]; idx = keep[order]
+    if n_max is not None and n_max < len(q):
         rank = np.arange(len(q)) - np.searchsorted(q, q, side="left")
         sel = rank < n_max
-        q, r, o = q[sel], r[sel], o[sel]
+        q, r, idx = q[sel], r[sel], idx[sel]
+    o = np.take(out, idx)
+    lap("rows kept, sorted, cut")
     return q, r, o
