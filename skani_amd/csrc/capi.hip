@@ -527,8 +527,10 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
         }
         tr.mark("triangle: screen");
         std::vector<uint32_t> pi, pj;
-        for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
-        std::vector<skh_ani_result> res(pi.size());
+        if (n_parts == 1) { pi.swap(a); pj.swap(b); }
+        else for (size_t p = part; p < a.size(); p += n_parts) { pi.push_back(a[p]); pj.push_back(b[p]); }   // triangle.rs:89-98: ref = i, query = j
+        const size_t n_res = pi.size();
+        skh_ani_result* res = (skh_ani_result*)ctx->pin_results.need((n_res + 1) * sizeof(skh_ani_result));   // (every row is written by the chaining or the call fails)
         tr.mark("triangle: pair list");
         const std::function<void()> finish_tables = [&] {
             build_sketch_tables_finish(ctx, ssm, tb); overlapped = false;
@@ -536,16 +538,16 @@ int skh_triangle(skh_ctx* ctx, const skh_sketch_set* ss, double identity, int re
             build_lock.unlock();
         };
         { Stopwatch sw(ctx, &ctx->timings.chain_ms);
-          chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res.data(), nullptr, false, overlapped ? &finish_tables : nullptr); }
+          chain_pairs(ctx, &ss, 1, nullptr, &ss, 1, nullptr, pi.data(), pj.data(), pi.size(), *mp, res, nullptr, false, overlapped ? &finish_tables : nullptr); }
         tr.mark("triangle: chain");
         if (n_chained) *n_chained = pi.size();
         size_t kept = 0;
-        for (auto& r : res) if (r.ani > 0.1f) kept++;                                                      // triangle.rs:99
+        for (size_t p = 0; p < n_res; p++) if (res[p].ani > 0.1f) kept++;                                  // triangle.rs:99
         uint32_t* oi = (uint32_t*)malloc((kept + 1) * 4); uint32_t* oj = (uint32_t*)malloc((kept + 1) * 4);
         skh_ani_result* orr = (skh_ani_result*)malloc((kept + 1) * sizeof(skh_ani_result));
         if (!oi || !oj || !orr) { free(oi); free(oj); free(orr); throw std::bad_alloc(); }
         size_t q = 0;
-        for (size_t p = 0; p < res.size(); p++) if (res[p].ani > 0.1f) { oi[q] = pi[p]; oj[q] = pj[p]; orr[q] = res[p]; q++; }
+        for (size_t p = 0; p < n_res; p++) if (res[p].ani > 0.1f) { oi[q] = pi[p]; oj[q] = pj[p]; orr[q] = res[p]; q++; }
         *out_i = oi; *out_j = oj; *out_res = orr; *n_kept = kept;
         tr.mark("triangle: results out");
     });
