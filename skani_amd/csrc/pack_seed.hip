@@ -560,6 +560,10 @@ __global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_
     uint32_t tot_s, tot_m;
     const uint32_t os = block_excl_scan_1024(cs, &tot_s, lds), om = block_excl_scan_1024(cm, &tot_m, lds);
     if (t < n_tiles) { loc_s[t] = os; loc_m[t] = om; }
+    // EVERY thread's stores must be out before the workgroup's ticket is taken: the last workgroup reads other workgroups' loc_* (the genomes' first tiles).  A fence
+    // by thread 0 alone orders thread 0's stores only -- with eight processes sharing the GPU the last workgroup then read offsets that had not arrived yet.
+    __threadfence();
+    __syncthreads();
     if (threadIdx.x == 0) {
         blk_s[blockIdx.x] = tot_s; blk_m[blockIdx.x] = tot_m;                         // (totals for now; the last workgroup turns them into offsets)
         __threadfence();
