@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--tables", default="at-sketch", choices=["beside-screen", "at-sketch"], help="one GPU: the seed tables are built inside skh_sketch_genomes beside the marker sets (default) "
                     "or inside skh_triangle beside its marker screen (sketches made with SKH_SKETCH_DEFER_TABLES; measured in round 4: the same step time)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on cuda:0, host collectives over gloo (RCCL refuses two ranks on one GPU): runs this file's whole "
-                    "multi-rank branch on a one-GPU box (tests/test_bench_multirank.py); the number it prints is not a multi-GPU measurement")
+                    "multi-rank branch on a one-GPU box (tests/test_zz_bench_multirank.py); the number it prints is not a multi-GPU measurement")
     ap.add_argument("--collection", type=int, default=0, help="strong scaling: a fixed collection of this many genomes (10000 = BASELINE config 4) in shuffled order at every "
                     "--gpus N, collection / N genomes per rank")
     ap.add_argument("--cpu-sample-clades", type=int, default=50, help="--collection on one GPU: whole clades (taken evenly from the collection) the oracle chains beside the GPU for delta_vs_oracle")
