@@ -500,3 +500,53 @@ def test_screen_counter_planes_agree(monkeypatch):
     sizes = [len(a[0]) for a in got["8"]]
     assert sizes[0] > 0 and sizes[0] > sizes[-1] and len(set(sizes)) >= 3, sizes      # the identities do separate the pairs
 
+
+
+def test_sketch_offsets_exact_while_the_gpu_is_busy():
+    """The per-genome offsets a sketch call reads back must not depend on what else the GPU is doing: the same genomes are sketched 25 times while three other
+    streams of this process keep the device busy with short kernels, and every run's offsets equal the quiet run's.
+    What this test is NOT: a reproducer of round 4's missing barrier in seed_offsets_kernel.  The library without that barrier passes it too
+    (checked on an MI355X) -- only eight PROCESSES sharing the GPU brought that race out (tests/test_zz_bench_multirank.py, test_config4_eight_ranks_one_device)."""
+    import threading
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    c = sk.Context(0)
+    try:
+        bases, coff, cgen, ng, _ = bench.make_genomes(torch, dev, np.arange(300), mean_len=1_000_000)
+        torch.cuda.synchronize()
+        gs = c.pack_buffer(None, coff, cgen, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+        del bases
+        params = sk.SketchParams()
+        def offsets():
+            ss = c.sketch_genomes(gs, params, genome_rank=np.arange(ng, dtype=np.uint32))
+            try:
+                m = ss.export_meta()
+                return m["pos_off"].copy(), m["marker_off"].copy()
+            finally:
+                ss.close()
+        quiet = offsets()
+        stop = threading.Event()
+        def noise():
+            s = torch.cuda.Stream(device=dev)
+            a = torch.ones(1 << 16, device=dev)
+            with torch.cuda.stream(s):
+                while not stop.is_set():
+                    for _ in range(200):
+                        a = a * 1.0001 + 1.0
+                    s.synchronize()
+        th = [threading.Thread(target=noise) for _ in range(3)]
+        for t in th:
+            t.start()
+        try:
+            for rep in range(25):
+                busy = offsets()
+                assert np.array_equal(busy[0], quiet[0]) and np.array_equal(busy[1], quiet[1]), rep
+        finally:
+            stop.set()
+            for t in th:
+                t.join()
+        gs.close()
+    finally:
+        c.close()
+        torch.cuda.empty_cache()
