@@ -526,12 +526,12 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
     if (tid == 0) { cnt_s[blockIdx.x] = tot; cnt_m[blockIdx.x] = lds_nm; }
 }
 
-// What lies between the seeding kernel and its compaction, in ONE launch (it was fourteen: an overflow pass, two scans of four launches each, an upload, two gathers,
+// What lies between the seeding kernel and its compaction, in TWO launches (it was fourteen: an overflow pass, two scans of four launches each, an upload, two gathers,
 // two copies -- 70 us of small kernels):
 //   * every workgroup takes 1024 tiles: a tile whose counts exceed the capped scratch gets a slot in the full-capacity overflow scratch; the tiles' seed and marker
 //     counts are scanned inside the workgroup (loc_*: a tile's offset within its block of 1024) and the block's totals are published;
-//   * the workgroup that finishes LAST (a ticket) scans the block totals (blk_*: exclusive, one more entry = the grand total) and reads out what the host wants to know:
-//     the offsets at the first tile of every genome that starts inside this launch, the totals and the overflow count.
+//   * the workgroup that finishes LAST (a ticket) scans the block totals (blk_*: exclusive, one more entry = the grand total);
+//   * seed_got_kernel reads out what the host wants to know: the offsets at the first tile of every genome that starts inside this launch, the totals and the overflow count.
 // A tile's offset is loc[t] + blk[t >> 10]: the compaction kernel adds the two itself.
 constexpr uint32_t OFFS_T = 1024, OFFS_MAX_BLOCKS = 4096;                            // (a launch covers at most 4 M tiles)
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* total, uint32_t* lds /* 16 words */) {
@@ -546,8 +546,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* t
 }
 __global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_s, const uint32_t* cnt_m, uint32_t n_tiles, uint32_t cap_s, uint32_t cap_m,
                                                             uint32_t* ovf_idx, uint32_t* ovf_list, uint32_t* n_ovf /* [0] overflow count, [1] ticket: both zero at launch */,
-                                                            uint32_t* loc_s, uint32_t* loc_m, uint32_t* blk_s, uint32_t* blk_m /* gridDim.x + 1 entries each */,
-                                                            const uint32_t* genome_first_tile, uint32_t n_genomes, uint32_t tile0, uint32_t* got /* 2 (n_genomes + 1) + 3 */) {
+                                                            uint32_t* loc_s, uint32_t* loc_m, uint32_t* blk_s, uint32_t* blk_m /* gridDim.x + 1 entries each */) {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t last;
     const uint32_t t = blockIdx.x * OFFS_T + threadIdx.x;
@@ -560,10 +559,9 @@ __global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_
     uint32_t tot_s, tot_m;
     const uint32_t os = block_excl_scan_1024(cs, &tot_s, lds), om = block_excl_scan_1024(cm, &tot_m, lds);
     if (t < n_tiles) { loc_s[t] = os; loc_m[t] = om; }
-    // EVERY thread's stores must be out before the workgroup's ticket is taken: the last workgroup reads other workgroups' loc_* (the genomes' first tiles).  A fence
-    // by thread 0 alone orders thread 0's stores only -- with eight processes sharing the GPU the last workgroup then read offsets that had not arrived yet.
-    __threadfence();
-    __syncthreads();
+    // The last workgroup reads nothing but the block totals, which thread 0 writes and fences itself.  (Round 4's version also read other workgroups' loc_* here --
+    // the genomes' first tiles, for the host -- which needed an agent-scope fence by EVERY thread in front of the ticket: 9,440 waves each writing the XCD's L2
+    // back took the kernel from 0.04 to 0.20 ms.  Those reads now sit behind a kernel boundary: seed_got_kernel.)
     if (threadIdx.x == 0) {
         blk_s[blockIdx.x] = tot_s; blk_m[blockIdx.x] = tot_m;                         // (totals for now; the last workgroup turns them into offsets)
         __threadfence();
@@ -588,24 +586,21 @@ __global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_
         bs += vs[i]; bm += vm[i];
     }
     if (threadIdx.x == 0) { blk_s[nb] = all_s; blk_m[nb] = all_m; }
-    __threadfence(); __syncthreads();
-    // the host's numbers: got[g], got[n_genomes + 1 + g] = the seed / marker offset at genome g's first tile if that lies in [tile0, tile0 + n_tiles] (else untouched)
-    for (uint32_t g = threadIdx.x; g <= n_genomes; g += OFFS_T) {
-        const uint32_t f = genome_first_tile[g];
-        if (f < tile0 || f > tile0 + n_tiles) continue;
-        const uint32_t lt = f - tile0;
-        uint32_t a, b;
-        if (lt == n_tiles) { a = all_s; b = all_m; }
-        else {
-            a = __atomic_load_n(&loc_s[lt], __ATOMIC_RELAXED) + __atomic_load_n(&blk_s[lt >> 10], __ATOMIC_RELAXED);
-            b = __atomic_load_n(&loc_m[lt], __ATOMIC_RELAXED) + __atomic_load_n(&blk_m[lt >> 10], __ATOMIC_RELAXED);
-        }
-        got[g] = a; got[n_genomes + 1 + g] = b;
-    }
-    if (threadIdx.x == 0) {
-        uint32_t* tail = got + 2 * (n_genomes + 1);
-        tail[0] = all_s; tail[1] = all_m; tail[2] = __atomic_load_n(&n_ovf[0], __ATOMIC_RELAXED);
-    }
+}
+// the host's numbers, behind the kernel boundary that orders every workgroup's loc_* / blk_* stores: got[g], got[n_genomes + 1 + g] = the seed / marker offset at genome
+// g's first tile if that lies in [tile0, tile0 + n_tiles] (else untouched); the tail: totals and overflow count
+__global__ __launch_bounds__(256) void seed_got_kernel(const uint32_t* __restrict__ loc_s, const uint32_t* __restrict__ loc_m, const uint32_t* __restrict__ blk_s,
+                                                       const uint32_t* __restrict__ blk_m, uint32_t n_blocks, const uint32_t* __restrict__ n_ovf, uint32_t n_tiles,
+                                                       const uint32_t* __restrict__ genome_first_tile, uint32_t n_genomes, uint32_t tile0, uint32_t* __restrict__ got /* 2 (n_genomes + 1) + 3 */) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t all_s = blk_s[n_blocks], all_m = blk_m[n_blocks];
+    if (g == 0) { uint32_t* tail = got + 2 * (n_genomes + 1); tail[0] = all_s; tail[1] = all_m; tail[2] = n_ovf[0]; }
+    if (g > n_genomes) return;
+    const uint32_t f = genome_first_tile[g];
+    if (f < tile0 || f > tile0 + n_tiles) return;
+    const uint32_t lt = f - tile0;
+    got[g] = lt == n_tiles ? all_s : loc_s[lt] + blk_s[lt >> 10];
+    got[n_genomes + 1 + g] = lt == n_tiles ? all_m : loc_m[lt] + blk_m[lt >> 10];
 }
 
 // A QUARTER of a wave per tile (16 lanes: a tile holds ~65 seeds and ~8 markers) copies the tile's records to their final (contig,pos)-ordered place.  WIDE (a
@@ -706,8 +701,11 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         tr.mark("seed: tiles kernel");
         // overflow slots, the tiles' offsets and the numbers the host needs (genome boundaries inside this launch, totals, overflow count) in one launch and one read-back
         SKH_LAUNCH(seed_offsets_kernel, nblk, OFFS_T, 0, ctx->stream, (const uint32_t*)cnt_s, (const uint32_t*)cnt_m, nt, cap_s, cap_m, ovf_idx, ovf_list, n_ovf,
-                   loc_s, loc_m, blk_s, blk_m, (const uint32_t*)gs->d_genome_first_tile.p, ng, (uint32_t)t0, d_got);
+                   loc_s, loc_m, blk_s, blk_m);
         check_launch("seed_offsets");
+        SKH_LAUNCH(seed_got_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)loc_s, (const uint32_t*)loc_m, (const uint32_t*)blk_s, (const uint32_t*)blk_m, nblk,
+                   (const uint32_t*)n_ovf, nt, (const uint32_t*)gs->d_genome_first_tile.p, ng, (uint32_t)t0, d_got);
+        check_launch("seed_got");
         std::vector<uint32_t> got(2 * ((size_t)ng + 1) + 3);
         d2h(got.data(), d_got, got.size() * 4, ctx->stream);
         const uint32_t h_novf = got[2 * ((size_t)ng + 1) + 2];
