@@ -223,13 +223,17 @@ int skh_triangle(skh_ctx*, const skh_sketch_set*, double identity, int rescue_sm
 /* ------------------------------------------------------------------ the triangle over several GPUs (one process per GPU)
  * The reference parallelises triangle.rs:71-105 with a work-stealing thread pool over one shared Vec<Sketch>.  Here every GPU (rank) sketches
  * its own block of the genomes and skh_triangle_distributed() does the rest below this boundary:
- *   1. the marker sets of all ranks are all-gathered (device memory); every rank screens an equal share of the triangle's cells;
- *   2. the candidate pair lists are all-gathered (host memory) and every rank computes the SAME assignment of pairs to ranks: connected
- *      components of the candidate graph (clusters of related genomes) are kept whole, components too large for an even split are cut into
- *      (row-block x column-block) tiles, and the units are dealt out by estimated cost, longest first -- the balanced stand-in for the
- *      reference's work stealing; it does not depend on the order of the genomes;
- *   3. every rank receives, point-to-point, exactly the sketches its units need and it does not own (seed + position arrays, device memory),
- *      builds their seed tables, and chains its pairs; 4. the result rows are all-gathered, so every rank returns the whole triangle.
+ *   1. one all-gather of per-rank tables (who holds which genomes, their sizes, contig lengths) and one of the marker sets (device memory);
+ *   2. the screen is cut by KEY RANGE: rank r sorts and walks the (marker, genome) incidences whose leading 16 bases fall into its part of the key range and
+ *      gets partial counts for every cell; the non-zero cells are gathered on the device and every rank adds them up and applies screen_refs' rule to
+ *      every row itself -- the same candidate list on every rank, nothing to gather (a collection whose N x N count matrix is beyond the screen's budget is
+ *      cut by rows instead and the candidate lists are gathered);
+ *   3. every rank computes the SAME assignment of pairs to ranks: connected components of the candidate graph (clusters of related genomes) are kept
+ *      whole, components too large for an even split are cut into (row-block x column-block) tiles, and the units are dealt out by estimated cost,
+ *      longest first -- the balanced stand-in for the reference's work stealing; it does not depend on the order of the genomes;
+ *   4. every rank receives, point-to-point and asynchronously, exactly the sketches its units need and it does not own (seed + position arrays, device
+ *      memory), chains the pairs of its own sketches meanwhile, builds the seed tables of what arrived and chains the rest;
+ *   5. the result rows are gathered: on every rank (skh_triangle_distributed) or on rank 0 only (SKH_DIST_ROWS_TO_ROOT).
  * Global genome index = (number of genomes on lower ranks) + local index; ranks may hold different numbers of genomes (also none).
  * genome_rank of the local set must be the genome's rank in ONE ordering common to all ranks, consistent with the file names' order where
  * names were set: inside this call the switch_qr tie (chain.rs:20-22) always goes by genome_rank -- names are not exchanged, and which rank
@@ -272,6 +276,13 @@ typedef struct {
 int skh_triangle_distributed(skh_ctx*, skh_comm*, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params*,
                              uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained,
                              skh_dist_stats* stats);
+/* The same with flags.  SKH_DIST_ROWS_TO_ROOT: the result rows travel to rank 0 only (triangle.rs:99-105 collects them in one place, and a host whose rank 0
+ * writes the matrix needs them nowhere else): rank 0 returns the whole triangle, every other rank the rows of the pairs it chained itself (both in (i, j)
+ * order).  n_chained is the total on every rank either way. */
+enum { SKH_DIST_ROWS_TO_ROOT = 1 };
+int skh_triangle_distributed_ex(skh_ctx*, skh_comm*, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params*, uint32_t flags,
+                                uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained,
+                                skh_dist_stats* stats);
 
 /* The assignment step of skh_triangle_distributed on its own (host only, no communicator): owner[p] = rank that would chain candidate pair
  * (pair_i[p], pair_j[p]); weight[g] = cost proxy of genome g (the distributed triangle uses the marker count); holder[g] = rank whose GPU

@@ -48,7 +48,7 @@ EXPORTS = ["skh_ctx_create", "skh_ctx_destroy", "skh_last_error", "skh_free", "s
            "skh_host_alloc", "skh_host_free", "skh_genomes_begin", "skh_genomes_append", "skh_genomes_wait", "skh_genomes_finish",
            "skh_genomes_destroy", "skh_genomes_total_bases", "skh_sketch_genomes", "skh_sketch_genomes_ex", "skh_sketch_build_tables", "skh_sketch_batch", "skh_sketch_set_destroy",
            "skh_sketch_set_names", "skh_sketch_n_genomes", "skh_sketch_is_wide", "skh_sketch_sizes", "skh_sketch_export", "skh_sketch_import", "skh_sketch_totals", "skh_sketch_export_flat", "skh_sketch_import_flat", "skh_screen", "skh_screen_rows", "skh_screen_part", "skh_screen_from_cells", "skh_chain_pairs", "skh_chain_pairs_multi",
-           "skh_triangle", "skh_get_timings", "skh_device_memory", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_comm_selftest", "skh_triangle_distributed", "skh_plan_pairs"]
+           "skh_triangle", "skh_get_timings", "skh_device_memory", "skh_comm_unique_id", "skh_comm_create_rccl", "skh_comm_create_host", "skh_comm_destroy", "skh_comm_selftest", "skh_triangle_distributed", "skh_triangle_distributed_ex", "skh_plan_pairs"]
 RCCL_ONLY = ("skh_comm_unique_id", "skh_comm_create_rccl")   # absent from the test-only simulator build (tests/emu)
 
 
@@ -102,6 +102,8 @@ def load(path):
     L.skh_comm_selftest.restype = i32; L.skh_comm_selftest.argtypes = [vp, vp]
     L.skh_triangle_distributed.restype = i32
     L.skh_triangle_distributed.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(MapParams), pp, pp, pp, C.POINTER(u64), C.POINTER(u64), C.POINTER(DistStats)]
+    L.skh_triangle_distributed_ex.restype = i32
+    L.skh_triangle_distributed_ex.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(MapParams), u32, pp, pp, pp, C.POINTER(u64), C.POINTER(u64), C.POINTER(DistStats)]
     L.skh_plan_pairs.restype = i32; L.skh_plan_pairs.argtypes = [u32, vp, vp, u64, vp, vp, i32, vp]
     if hasattr(L, "skh_comm_create_rccl"):
         L.skh_comm_unique_id.restype = i32; L.skh_comm_unique_id.argtypes = [vp]

@@ -57,7 +57,7 @@ HOST_BIN = os.path.join(HERE, "bin", "skani-hip")
 
 def build_host(force=False):
     """C++ host side (FASTA ingest, writers, triangle/dist drivers): g++ only, links the C ABI library."""
-    srcs = [os.path.join(HOST, f) for f in ("fastx.cpp", "writers.cpp", "formats.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("fastx.cpp", "writers.cpp", "formats.cpp", "node.cpp")]
     deps = srcs + [os.path.join(HOST, "host.hpp"), os.path.join(HOST, "capi_db.cpp"), os.path.join(HOST, "main.cpp"), LIB]
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     def run(cmd):

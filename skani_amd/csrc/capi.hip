@@ -591,11 +591,16 @@ int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* p
 
 int skh_triangle_distributed(skh_ctx* ctx, skh_comm* comm, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params* mp,
                              uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained, skh_dist_stats* stats) {
+    return skh_triangle_distributed_ex(ctx, comm, local, identity, rescue_small, mp, 0, out_i, out_j, out_res, n_kept, n_chained, stats);
+}
+
+int skh_triangle_distributed_ex(skh_ctx* ctx, skh_comm* comm, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params* mp, uint32_t flags,
+                                uint32_t** out_i, uint32_t** out_j, skh_ani_result** out_res, uint64_t* n_kept, uint64_t* n_chained, skh_dist_stats* stats) {
     if (!ctx || !comm || !comm->t || !local || !mp || !out_i || !out_j || !out_res || !n_kept) return SKH_ERR_INVALID;
     *out_i = *out_j = nullptr; *out_res = nullptr; *n_kept = 0;
     int rc = guarded(ctx, [&] {
         std::vector<uint32_t> a, b; std::vector<skh_ani_result> r;
-        triangle_distributed(ctx, *comm->t, local, identity, rescue_small, *mp, a, b, r, n_chained, stats);
+        triangle_distributed(ctx, *comm->t, local, identity, rescue_small, *mp, flags, a, b, r, n_chained, stats);
         const size_t kept = a.size();
         uint32_t* oi = (uint32_t*)malloc((kept + 1) * 4); uint32_t* oj = (uint32_t*)malloc((kept + 1) * 4);
         skh_ani_result* orr = (skh_ani_result*)malloc((kept + 1) * sizeof(skh_ani_result));

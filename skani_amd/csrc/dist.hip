@@ -222,7 +222,7 @@ static Gathered<Rec> gather_records(skh_ctx* ctx, Transport& T, const std::vecto
     }
 }
 
-void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, double identity, int rescue_small, const skh_map_params& mp,
+void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, double identity, int rescue_small, const skh_map_params& mp, uint32_t flags,
                           std::vector<uint32_t>& out_i, std::vector<uint32_t>& out_j, std::vector<skh_ani_result>& out_res, uint64_t* n_chained, skh_dist_stats* stats) {
     const int W = T.world, me = T.rank;
     if (W < 1 || me < 0 || me >= W || W > 255) throw std::invalid_argument("bad communicator");
@@ -632,6 +632,38 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::vector<Row> rows;
     for (size_t p = 0; p < res.size(); p++) if (local_err.empty() && res[p].ani > 0.1f) rows.push_back(Row{c_i[p], c_j[p], res[p]});
     ex_begin();
+    if (flags & SKH_DIST_ROWS_TO_ROOT) {
+        // "results gathered to rank 0".  The counts and the status of the chaining phases go round in a 16-byte gather (every rank must learn of a failure);
+        // the rows themselves travel to rank 0 only -- an all-to-all in which every rank sends one block there -- and the other ranks return their own rows.
+        uint64_t head[2] = {rows.size(), local_err.empty() ? 0ull : 1ull}; std::vector<uint64_t> heads(2 * (size_t)W);
+        T.all_gather(ctx, head, heads.data(), 16, false);
+        for (int r = 0; r < W; r++) if (heads[2 * (size_t)r + 1]) stop_together("seed tables / chaining", r);
+        std::vector<uint64_t> sc(W, 0), so(W, 0), rc(W, 0), ro(W, 0); uint64_t total = 0;
+        sc[0] = rows.size() * sizeof(Row);
+        for (int r = 1; r < W; r++) so[r] = sc[0];                                   // (offsets in rank order without gaps: what MPI_Alltoallv-like callbacks expect)
+        if (me == 0) for (int r = 0; r < W; r++) { rc[r] = heads[2 * (size_t)r] * sizeof(Row); ro[r] = total * sizeof(Row); total += heads[2 * (size_t)r]; }
+        if (T.g_recv.size() < total * sizeof(Row) + 8) T.g_recv.resize(total * sizeof(Row) + 8);
+        Row none{}; const void* sp = rows.empty() ? (const void*)&none : (const void*)rows.data();
+        T.all_to_all_v(ctx, sp, sc.data(), so.data(), T.g_recv.data(), rc.data(), ro.data(), false);
+        ex_end();
+        out_i.clear(); out_j.clear(); out_res.clear();
+        if (me != 0) {                                                              // own rows, already in (i, j) order (the order of the candidate list)
+            out_i.reserve(rows.size()); out_j.reserve(rows.size()); out_res.reserve(rows.size());
+            for (const Row& row : rows) { out_i.push_back(row.i); out_j.push_back(row.j); out_res.push_back(row.r); }
+        } else {
+            out_i.reserve(total); out_j.reserve(total); out_res.reserve(total);
+            const Row* all = (const Row*)T.g_recv.data();
+            std::vector<uint64_t> cur(W, 0), first(W, 0);
+            for (int r = 0; r < W; r++) first[r] = ro[r] / sizeof(Row);
+            for (size_t p2 = 0; p2 < NP; p2++) {
+                const int r = owner[p2]; const uint64_t x = cur[r];
+                if (x >= heads[2 * (size_t)r]) continue;
+                const Row& row = all[first[r] + x];
+                if (row.i == pi[p2] && row.j == pj[p2]) { out_i.push_back(row.i); out_j.push_back(row.j); out_res.push_back(row.r); cur[r]++; }
+            }
+            if (out_i.size() != total) throw Error("distributed triangle: the gathered result rows do not follow the candidate list");
+        }
+    } else {
     const Gathered<Row> G = gather_records(ctx, T, rows, !local_err.empty(), T.cap_rows, [&](int r) { stop_together("seed tables / chaining", r); });
     ex_end();
     // The rows into (i, j) order.  Every rank sent its rows in the order of the candidate list, which every rank holds: one walk over that list with a cursor
@@ -646,6 +678,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             if (row.i == pi[p2] && row.j == pj[p2]) { out_i.push_back(row.i); out_j.push_back(row.j); out_res.push_back(row.r); cur[r]++; }
         }
         if (out_i.size() != G.total) throw Error("distributed triangle: the gathered result rows do not follow the candidate list");
+    }
     }
     ctx->timings.exchange_ms += (float)exch_ms;
     if (stats) *stats = st;

@@ -286,7 +286,7 @@ void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t
 // ---- dist.hip
 void assign_pairs(uint32_t n_genomes, const std::vector<uint32_t>& pi, const std::vector<uint32_t>& pj, const std::vector<uint64_t>& weight, const std::vector<int>& holder,
                   int world, std::vector<uint8_t>& owner, std::vector<uint64_t>& units_of, std::vector<uint64_t>& load);
-void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params& mp,
+void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* local, double identity, int rescue_small, const skh_map_params& mp, uint32_t flags,
                           std::vector<uint32_t>& out_i, std::vector<uint32_t>& out_j, std::vector<skh_ani_result>& out_res, uint64_t* n_chained, skh_dist_stats* stats);
 void comm_selftest(skh_ctx* ctx, Transport& T);
 

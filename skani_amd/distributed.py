@@ -81,13 +81,14 @@ class Comm:
         ctx.check(ctx.L.skh_comm_create_host(ctx.h, C.byref(hc), rank, world, C.byref(h)))
         return Comm(ctx, h, rank, world, keep=hc)        # the callbacks must outlive the communicator
 
-    def triangle(self, ss_local, map_params, identity=0.0, rescue_small=True):
-        """Collective.  Returns (i, j, results, n_chained_total, stats) with global genome indices, on every rank."""
+    def triangle(self, ss_local, map_params, identity=0.0, rescue_small=True, rows_to_root=False):
+        """Collective.  Returns (i, j, results, n_chained_total, stats) with global genome indices: the whole triangle on every rank, or -- rows_to_root
+        (SKH_DIST_ROWS_TO_ROOT) -- on rank 0 only, the other ranks getting the rows of the pairs they chained."""
         L = self.ctx.L
         oi, oj, orr, n, nch = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
         st = B.DistStats()
-        self.ctx.check(L.skh_triangle_distributed(self.ctx.h, self.h, ss_local.h, identity, int(rescue_small), C.byref(map_params),
-                                                  C.byref(oi), C.byref(oj), C.byref(orr), C.byref(n), C.byref(nch), C.byref(st)))
+        self.ctx.check(L.skh_triangle_distributed_ex(self.ctx.h, self.h, ss_local.h, identity, int(rescue_small), C.byref(map_params), 1 if rows_to_root else 0,
+                                                     C.byref(oi), C.byref(oj), C.byref(orr), C.byref(n), C.byref(nch), C.byref(st)))
         try:
             from .api import _take_rows
             i, j, res = _take_rows(n.value, oi, oj, orr)
@@ -111,7 +112,7 @@ class Comm:
 
 
 def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, identity=0.0, rescue_small=True, torch=None, device=None, comm=None,
-                         with_stats=False):
+                         with_stats=False, rows_to_root=False):
     """ss_local: this rank's sketches (any number, also none), created with genome_rank = the genome's rank in an ordering common to all
     ranks.  Global genome index = genomes on lower ranks + local index.  Returns (i, j, results, n_chained_total) on every rank.
     Without `comm` a host-collective communicator over `dist` is made for the call (tests); bench.py passes an RCCL one."""
@@ -122,7 +123,7 @@ def distributed_triangle(ctx, ss_local, params, map_params, dist, rank, world, i
     if own:
         comm = Comm.host(ctx, dist, rank, world, torch=torch)
     try:
-        i, j, res, n, st = comm.triangle(ss_local, map_params, identity, rescue_small)
+        i, j, res, n, st = comm.triangle(ss_local, map_params, identity, rescue_small, rows_to_root=rows_to_root)
     finally:
         if own:
             comm.close()

@@ -88,4 +88,18 @@ std::vector<SketchBlob> read_sketch_files(const std::vector<std::string>& files,
 // a `skani sketch` output folder (either flavour), all sketches loaded (search.rs:16-100 without the lazy fetch)
 SketchDb read_sketch_db(const std::string& dir_or_marker_file);
 
+// ---- the GPUs of one node (node.cpp): `triangle --gpus N` forks one process per GPU; the ranks meet in shared memory ----
+struct Node;
+Node* node_create(int world);                                   // before anything touches the HIP runtime
+int node_launch(Node*);                                         // forks the ranks; returns in every rank with its number; the launcher waits for them and exits
+int node_rank(const Node*);
+int node_world(const Node*);
+bool node_barrier(Node*);                                       // false: some rank failed (every collective below likewise)
+bool node_all_gather(Node*, const void* send, void* recv, uint64_t bytes);
+bool node_all_to_all_v(Node*, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt, const uint64_t* recv_off);
+bool node_all_gather_v(Node*, const std::string& mine, std::vector<std::string>& all);   // ragged: every rank's bytes, by rank
+bool node_claim_failure(Node*);                                 // marks the run as failed (ends every collective); true for the first caller only: its message is the run's error
+bool node_failed(const Node*);
+skh_host_collectives node_collectives(Node*);                   // the same collectives as the library's host transport (skh_comm_create_host)
+
 }  // namespace skhost

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <csignal>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "host.hpp"
 
@@ -33,11 +35,21 @@ struct Args {
     bool robust = false, median = false, no_learned = false, fast = false, slow = false, medium = false, small_genomes = false, faster_small = false;
     bool sparse = false, individual = false, qi = false, ri = false, marker_index = false, no_marker_index = false, separate_sketches = false;
     size_t n = 10000000; int threads = 3, device = 0, seeding_mode = SKH_SEED_AVX2;
+    int gpus = 1; bool one_device = false;                                        // triangle --gpus N: one process per GPU (--one-device: all ranks on --device, host collectives)
     uint64_t shard_positions = 1500000000ull;                                     // seed positions per resident database shard (search)
     OutOpts o;
 };
 
-[[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR %s\n", m.c_str()); exit(1); }
+// A rank of `triangle --gpus N` (g_node set) that fails ends the whole run: the first rank to claim the failure prints its message -- the run's ONE error --, the
+// others leave quietly (their collectives fail once the flag is up; a rank that only learnt of a peer's failure waits a moment so that the peer's own message wins).
+Node* g_node = nullptr;
+[[noreturn]] void die(const std::string& m) {
+    if (!g_node) { fprintf(stderr, "ERROR %s\n", m.c_str()); exit(1); }
+    if (m.find("all ranks stop") != std::string::npos || m.find("host all_") != std::string::npos) usleep(300000);
+    if (node_claim_failure(g_node)) fprintf(stderr, "ERROR [rank %d] %s\n", node_rank(g_node), m.c_str());
+    fflush(stderr); fflush(stdout);
+    _exit(1);
+}
 
 std::vector<std::string> read_list(const std::string& p) {
     std::ifstream f(p); if (!f) die("cannot read list file " + p);
@@ -93,6 +105,8 @@ Args parse(int argc, char** argv) {
         else if (x == "--shard-positions") a.shard_positions = (uint64_t)atoll(need(i).c_str());
         else if (x == "--keep-refs") {}                                        // every reference sketch is HBM-resident anyway
         else if (x == "--device") a.device = atoi(need(i).c_str());
+        else if (x == "--gpus") a.gpus = atoi(need(i).c_str());
+        else if (x == "--one-device") a.one_device = true;
         else if (x == "--seeding") { std::string v = need(i); a.seeding_mode = v == "scalar" ? SKH_SEED_SCALAR : SKH_SEED_AVX2; }
         else if (x == "--models") a.models_dir = need(i);
         else if (x == "-v" || x == "--debug" || x == "--trace") {}
@@ -121,12 +135,12 @@ std::string models_dir(const Args& a, const char* argv0) {
     return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/../data";
 }
 
-skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a) {
+skh_sketch_set* sketch(Ctx& cx, const LoadedGenomes& lg, const Args& a, const uint32_t* genome_rank = nullptr) {
     skh_sketch_params sp{a.c, a.k, a.m, (uint32_t)a.seeding_mode};
     skh_sketch_set* ss = nullptr;
-    // genome order is already the sorted file-name order => genome_rank = index (chain.rs:20-22 tie rule)
+    // genome order is already the sorted file-name order => genome_rank = index (chain.rs:20-22 tie rule); a rank of several passes its genomes' places in the whole list
     cx.check(skh_sketch_batch(cx.c, (const uint8_t*)lg.bases.data(), lg.contig_off.data(), lg.contig_genome.data(), (uint32_t)lg.contig_genome.size(),
-                              (uint32_t)lg.info.size(), &sp, nullptr, &ss), "skh_sketch_batch");
+                              (uint32_t)lg.info.size(), &sp, genome_rank, &ss), "skh_sketch_batch");
     std::vector<const char*> names; for (auto& g : lg.info) names.push_back(g.file_name.c_str());
     cx.check(skh_sketch_set_names(ss, names.data()), "skh_sketch_set_names");      // exact switch_qr tie-break across ref/query sets
     return ss;
@@ -171,7 +185,9 @@ struct PinnedPool {
 PinnedPool g_pinned;
 
 struct Streamed { bool ok = false; skh_sketch_set* ss = nullptr; std::vector<GenomeInfo> info; std::vector<uint32_t> kept_index; };   // kept_index[set genome] = index into info, or ~0u
-Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Args& a) {
+// rank_base / sketch_flags: a rank of `triangle --gpus N` streams its share of the sorted list -- genome_rank = rank_base + the file's place in the share, the seed
+// tables deferred (skh_triangle_distributed indexes only what the rank ends up chaining)
+Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Args& a, uint32_t rank_base = 0, uint32_t sketch_flags = 0) {
     Streamed out;
     std::vector<std::string> files = files_in;
     std::stable_sort(files.begin(), files.end());
@@ -272,10 +288,11 @@ Streamed stream_side(Ctx& cx, const std::vector<std::string>& files_in, const Ar
         else if (state[i] == 2) fprintf(stderr, "WARN File %s consists of only contigs < 500 bp. Skipping this file.\n", files[i].c_str());
     }
     skh_sketch_params sp{a.c, a.k, a.m, (uint32_t)a.seeding_mode};
-    cx.check(skh_sketch_genomes(cx.c, gs, &sp, nullptr, &out.ss), "skh_sketch_genomes");   // genome_rank = number in the sorted file list
+    std::vector<uint32_t> granks(nf); for (uint32_t i = 0; i < nf; i++) granks[i] = rank_base + i;
+    cx.check(skh_sketch_genomes_ex(cx.c, gs, &sp, granks.data(), sketch_flags, &out.ss), "skh_sketch_genomes");   // genome_rank = number in the sorted file list
     skh_genomes_destroy(gs);
     std::vector<const char*> nm(nf); for (uint32_t i = 0; i < nf; i++) nm[i] = files[i].c_str();
-    cx.check(skh_sketch_set_names(out.ss, nm.data()), "skh_sketch_set_names");
+    if (nf) cx.check(skh_sketch_set_names(out.ss, nm.data()), "skh_sketch_set_names");
     g_clock.mark("sketch");
     out.ok = true;
     return out;
@@ -288,7 +305,7 @@ bool all_sketch_files(const std::vector<std::string>& files) {                  
 }
 
 // sketches read from disk -> one device-resident sketch set (sketches_from_sketch + the HBM upload)
-skh_sketch_set* import_blobs(Ctx& cx, const SketchFileParams& fp, const std::vector<SketchBlob>& blobs, int seeding_mode) {
+skh_sketch_set* import_blobs(Ctx& cx, const SketchFileParams& fp, const std::vector<SketchBlob>& blobs, int seeding_mode, const uint32_t* genome_rank = nullptr) {
     std::vector<uint64_t> pos_off{0}, mk_off{0}, ctg_off{0}, total;
     std::vector<uint32_t> seed, pos, cc, clen; std::vector<uint64_t> markers;
     for (const SketchBlob& b : blobs) {
@@ -300,7 +317,7 @@ skh_sketch_set* import_blobs(Ctx& cx, const SketchFileParams& fp, const std::vec
     skh_sketch_params sp{(uint32_t)fp.c, (uint32_t)fp.k, (uint32_t)fp.marker_c, (uint32_t)seeding_mode};
     skh_sketch_set* ss = nullptr;
     cx.check(skh_sketch_import(cx.c, &sp, (uint32_t)blobs.size(), pos_off.data(), seed.data(), pos.data(), cc.data(), mk_off.data(), markers.data(),
-                               ctg_off.data(), clen.data(), total.data(), nullptr, &ss), "skh_sketch_import");
+                               ctg_off.data(), clen.data(), total.data(), genome_rank, &ss), "skh_sketch_import");
     std::vector<const char*> names; for (auto& b : blobs) names.push_back(b.file_name.c_str());
     cx.check(skh_sketch_set_names(ss, names.data()), "skh_sketch_set_names");
     return ss;
@@ -391,6 +408,156 @@ int run_triangle(Args& a, Ctx& cx) {
     g_clock.mark("write");
     skh_sketch_set_destroy(ss);
     return 0;
+}
+
+// ---- `triangle --gpus N` (triangle.rs:13-169 on the GPUs of one node; node.cpp has the launcher and the ranks' shared-memory collectives).
+// Rank r ingests and sketches a contiguous share of the name-sorted file list (file_io.rs:250: the sorted list IS the genome order, so global genome = genomes on
+// lower ranks + local genome, which is skh_triangle_distributed's numbering), with deferred seed tables; the library does the rest below the C ABI; the result rows
+// come to rank 0 (SKH_DIST_ROWS_TO_ROOT), which writes the matrix / edge list through the same writers as the one-process run.
+void put_u64(std::string& b, uint64_t v) { b.append((const char*)&v, 8); }
+void put_str(std::string& b, const std::string& x) { put_u64(b, x.size()); b += x; }
+struct Reader {
+    const std::string& b; size_t at = 0;
+    uint64_t u64() { if (at + 8 > b.size()) die("a rank's genome table is cut short"); uint64_t v; memcpy(&v, b.data() + at, 8); at += 8; return v; }
+    std::string str() { const uint64_t n = u64(); if (at + n > b.size()) die("a rank's genome table is cut short"); std::string x = b.substr(at, n); at += n; return x; }
+};
+
+int run_triangle_node(Args& a, const char* argv0) {
+    std::vector<std::string> files = a.files;
+    if (!a.list.empty()) { auto l = read_list(a.list); files.insert(files.end(), l.begin(), l.end()); }
+    if (files.empty()) die("No reference inputs found.");
+    const int W = a.gpus;
+    const bool sketch_inputs = all_sketch_files(files);
+    std::stable_sort(files.begin(), files.end());
+    // shares of the sorted list, cut by bytes (a share = consecutive files; sketch files are read by every rank and cut by count afterwards)
+    std::vector<uint32_t> cut(W + 1, 0);
+    {
+        std::vector<uint64_t> cum(files.size() + 1, 0);
+        for (size_t i = 0; i < files.size(); i++) { struct stat sb; cum[i + 1] = cum[i] + (stat(files[i].c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 1) + 1; }
+        for (int r = 1; r < W; r++) {
+            const uint64_t want = cum.back() / (uint64_t)W * (uint64_t)r;
+            cut[r] = std::max<uint32_t>(cut[r - 1], (uint32_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin()));
+        }
+        cut[W] = (uint32_t)files.size();
+    }
+    Node* node = node_create(W);
+    const int rank = node_launch(node);                                           // (the launcher stays in there)
+    g_node = node;
+    g_clock = PhaseClock();
+    a.threads = std::max(1, a.threads / W);
+    if (const char* fr = getenv("SKH_TUNE_DIST_FAIL_RANK")) if (atoi(fr) != rank) unsetenv("SKH_TUNE_DIST_FAIL");   // (fault injection of the tests: SKH_TUNE_DIST_FAIL on one rank only)
+    Ctx cx;
+    if (skh_ctx_create(a.one_device ? a.device : a.device + rank, &cx.c) != 0) die("no usable MI355X device " + std::to_string(a.one_device ? a.device : a.device + rank) + " (skani-hip has no CPU path)");
+    const std::string md = models_dir(a, argv0);
+    cx.check(skh_load_models(cx.c, (md + "/gbdt_c125.bin").c_str(), (md + "/gbdt_c200.bin").c_str()), "skh_load_models");
+    // ---- the communicator: RCCL inside the library (rank 0's unique id goes round through shared memory), tried out by its self-test; all ranks together fall back to
+    // host collectives over shared memory when any of them could not use it, or when they share one device
+    skh_comm* comm = nullptr;
+    if (!a.one_device && !getenv("SKANI_HIP_HOST_COLLECTIVES")) {
+        struct IdMsg { uint8_t id[SKH_COMM_ID_BYTES]; uint64_t ok; } mine{}; std::vector<IdMsg> all(W);
+        if (rank == 0) mine.ok = skh_comm_unique_id(mine.id) == 0;
+        if (!node_all_gather(node, &mine, all.data(), sizeof mine)) die("a rank failed; all ranks stop");
+        uint64_t bad = 1;
+        if (all[0].ok) {
+            bad = skh_comm_create_rccl(cx.c, all[0].id, rank, W, &comm) != 0;
+            if (!bad) bad = skh_comm_selftest(cx.c, comm) != 0;
+        }
+        std::vector<uint64_t> bads(W);
+        if (!node_all_gather(node, &bad, bads.data(), 8)) die("a rank failed; all ranks stop");
+        bool any = false; for (uint64_t b : bads) any = any || b;
+        if (any) {
+            if (comm) { skh_comm_destroy(comm); comm = nullptr; }
+            if (rank == 0) fprintf(stderr, "WARN RCCL is not usable between the %d ranks (%s); the ranks exchange through host memory instead.\n", W, all[0].ok ? "communicator self-test" : "librccl");
+        }
+    }
+    skh_host_collectives hc = node_collectives(node);
+    if (!comm) cx.check(skh_comm_create_host(cx.c, &hc, rank, W, &comm), "skh_comm_create_host");
+    g_clock.mark("startup");
+    // ---- this rank's genomes
+    const uint32_t f0 = cut[rank], f1 = cut[rank + 1];
+    Side sd; std::vector<uint32_t> kept_index;                                    // local set genome -> local row of `info` (streamed ingest), else the identity
+    const uint32_t flags = SKH_SKETCH_DEFER_TABLES | SKH_SKETCH_NO_SCREEN_INDEX;
+    if (sketch_inputs) {
+        SketchFileParams fp; std::vector<SketchBlob> blobs = read_sketch_files(files, fp);   // (sorted by the name inside the sketch: every rank reads all, keeps its stretch)
+        for (auto& b : blobs) if (!b.has_seeds) die("sketch " + b.file_name + " holds markers only; it cannot be aligned");
+        a.c = (uint32_t)fp.c; a.k = (uint32_t)fp.k; a.m = (uint32_t)fp.marker_c;
+        const size_t b0 = blobs.size() * (size_t)rank / (size_t)W, b1 = blobs.size() * (size_t)(rank + 1) / (size_t)W;
+        std::vector<SketchBlob> part(std::make_move_iterator(blobs.begin() + b0), std::make_move_iterator(blobs.begin() + b1));
+        std::vector<uint32_t> gr(part.size()); for (size_t x = 0; x < part.size(); x++) gr[x] = (uint32_t)(b0 + x);
+        sd.ss = import_blobs(cx, fp, part, a.seeding_mode, gr.data()); sd.info = infos_of(part); sd.from_sketch = true;
+        g_clock.mark("load_sketch");
+    } else {
+        const std::vector<std::string> share(files.begin() + f0, files.begin() + f1);
+        if (!a.individual) {
+            Streamed st = stream_side(cx, share, a, f0, flags);
+            if (st.ok) { sd.ss = st.ss; sd.info = std::move(st.info); kept_index = std::move(st.kept_index); }
+        }
+        if (!sd.ss) {                                                               // gzip / FASTQ / -i: the record reader
+            LoadedGenomes lg = load_genomes(share, a.individual, a.threads);
+            std::vector<uint32_t> gr(lg.info.size());                               // the file's place in the whole list (the contigs of a file under -i share it: equal names, no switch)
+            for (size_t x = 0; x < lg.info.size(); x++) gr[x] = f0 + (uint32_t)(std::lower_bound(share.begin(), share.end(), lg.info[x].file_name) - share.begin());
+            sd.ss = sketch(cx, lg, a, gr.data()); sd.info = std::move(lg.info);
+            g_clock.mark("load_sketch");
+        }
+    }
+    const uint32_t n_set = skh_sketch_n_genomes(sd.ss);
+    // ---- everybody's genome names to rank 0 (the writers need them); the parameters the ranks ended up with must agree (sketch files carry their own)
+    std::string mine_tab; put_u64(mine_tab, a.c); put_u64(mine_tab, a.k); put_u64(mine_tab, a.m); put_u64(mine_tab, n_set); put_u64(mine_tab, sd.info.size());
+    for (uint32_t g = 0; g < n_set; g++) put_u64(mine_tab, kept_index.empty() ? g : kept_index[g]);
+    for (const GenomeInfo& gi : sd.info) {
+        put_str(mine_tab, gi.file_name); put_u64(mine_tab, gi.contig_order); put_u64(mine_tab, gi.contigs.size());
+        put_str(mine_tab, gi.contigs.empty() ? std::string() : gi.contigs[0]);
+        uint64_t tot = 0; for (uint32_t l : gi.contig_lengths) tot += l;
+        put_u64(mine_tab, tot);
+    }
+    std::vector<std::string> tabs;
+    if (!node_all_gather_v(node, mine_tab, tabs)) die("a rank failed; all ranks stop");
+    std::vector<GenomeInfo> info_all; std::vector<uint32_t> row_of;                 // row_of[global set genome] = row of info_all, or ~0u
+    uint64_t n_info_total = 0;
+    for (int r = 0; r < W; r++) {
+        Reader rd{tabs[r]};
+        const uint64_t c = rd.u64(), k = rd.u64(), m = rd.u64(), ns = rd.u64(), ni = rd.u64();
+        if (c != a.c || k != a.k || m != a.m) die("the ranks' sketch parameters differ (sketch files made with different -c / -k / -m?)");
+        n_info_total += ni;
+        if (rank != 0) continue;
+        const uint32_t row0 = (uint32_t)info_all.size();
+        for (uint64_t g = 0; g < ns; g++) { const uint64_t x = rd.u64(); row_of.push_back(x == 0xFFFFFFFFull ? ~0u : row0 + (uint32_t)x); }
+        for (uint64_t x = 0; x < ni; x++) {
+            GenomeInfo gi; gi.file_name = rd.str(); gi.contig_order = rd.u64();
+            const uint64_t nc = rd.u64(); const std::string first = rd.str(); const uint64_t tot = rd.u64();
+            // (the writers read a genome's first contig name, its number of contigs and its total length: the other names stay on their rank)
+            gi.contigs.assign(nc ? nc : 1, std::string()); gi.contigs[0] = first;
+            gi.contig_lengths.assign(1, (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull));
+            info_all.push_back(std::move(gi));
+        }
+    }
+    if (!n_info_total) die("No genomes/sketches found.");                          // triangle.rs:46-49
+    const bool learned = !a.no_learned && a.c >= 70 && !a.individual && !a.median;   // regression.rs:8-10, parse.rs:885-889
+    skh_map_params mp = map_params(a, learned);
+    const bool rescue_small = !a.faster_small && !a.small_genomes;              // parse.rs:798
+    uint32_t *oi = nullptr, *oj = nullptr; skh_ani_result* res = nullptr; uint64_t kept = 0, chained = 0;
+    if (const char* kr = getenv("SKH_TUNE_NODE_KILL_RANK")) if (atoi(kr) == rank) raise(SIGKILL);   // (fault injection of the tests: a rank that is gone without a word)
+    cx.check(skh_triangle_distributed_ex(cx.c, comm, sd.ss, a.s / 100., rescue_small, &mp, SKH_DIST_ROWS_TO_ROOT, &oi, &oj, &res, &kept, &chained, nullptr), "skh_triangle_distributed");
+    g_clock.mark("triangle");
+    if (rank == 0) {
+        std::vector<PairResult> pr(kept);
+        for (uint64_t x = 0; x < kept; x++) pr[x] = PairResult{row_of[oi[x]], row_of[oj[x]], res[x]};   // ref = i, query = j (triangle.rs:98)
+        if (a.sparse) emit(a.out, format_sparse(info_all, pr, a.o));
+        else {
+            std::string ani, af; format_phylip(info_all, pr, a.individual, a.o, ani, af);
+            emit(a.out, ani); emit(a.out.empty() ? std::string("skani_matrix.af") : a.out + ".af", af);   // file_io.rs:428,467
+        }
+        g_clock.mark("write");
+    }
+    skh_free(oi); skh_free(oj); skh_free(res);
+    if (!node_barrier(node)) die("a rank failed; all ranks stop");                 // (nobody takes its communicator down while a peer is still inside it)
+    skh_comm_destroy(comm);
+    skh_sketch_set_destroy(sd.ss);
+    g_pinned.release();
+    skh_ctx_destroy(cx.c);
+    if (rank == 0) g_clock.done();
+    fflush(stdout); fflush(stderr);
+    _exit(0);                                                                       // (a forked rank: the launcher's static state is not this process's to take down)
 }
 
 int run_dist(Args& a, Ctx& cx) {
@@ -510,6 +677,11 @@ int run_search(Args& a, Ctx& cx) {                                              
 
 int main(int argc, char** argv) {
     Args a = parse(argc, argv);
+    if (a.gpus < 1 || a.gpus > 64) die("--gpus: between 1 and 64");
+    if (a.gpus > 1) {
+        if (a.cmd != "triangle") die("--gpus is for `triangle` (dist and search run on one GPU)");
+        try { return run_triangle_node(a, argv[0]); } catch (const std::exception& e) { die(e.what()); }
+    }
     Ctx cx;
     if (skh_ctx_create(a.device, &cx.c) != 0) die("no usable MI355X device (skani-hip has no CPU path)");
     const std::string md = models_dir(a, argv[0]);

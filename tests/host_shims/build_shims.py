@@ -19,5 +19,26 @@ def build(force=False):
     return LIB
 
 
+CLI_EMU = os.path.join(HERE, "skani-hip-emu")
+
+
+def build_cli_emu(force=False):
+    """TEST-ONLY: the product's CLI sources (host/main.cpp, node.cpp, ...) linked against the kernel simulator build instead of libskani_hip.so, so that the drivers --
+    `triangle --gpus N` with its launcher and shared-memory collectives above all -- run in a container without a GPU.  rccl_stub.cpp stands in for the two RCCL entry
+    points the simulator build lacks (they fail: the ranks then agree on host collectives, the path `--one-device` takes on a one-GPU box)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("build_emu", os.path.join(ROOT, "tests", "emu", "build_emu.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    emu = m.build()
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "fastx.cpp", "writers.cpp", "formats.cpp", "node.cpp")] + [os.path.join(HERE, "rccl_stub.cpp")]
+    deps = srcs + [os.path.join(HOST, "host.hpp"), emu]
+    if force or not os.path.exists(CLI_EMU) or any(os.path.getmtime(d) > os.path.getmtime(CLI_EMU) for d in deps):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-o", CLI_EMU] + srcs +
+                           ["-L", os.path.dirname(emu), "-lskani_emu", "-lz", "-pthread", "-Wl,-rpath," + os.path.dirname(emu)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed:\n" + r.stderr[-6000:])
+    return CLI_EMU
+
+
 if __name__ == "__main__":
     print(build(force=True))

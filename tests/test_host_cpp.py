@@ -290,3 +290,96 @@ def test_cli_sketch_then_search_reproduces_the_reference_golden_rows(tmp_path):
     s = run("search", "-d", "db_i", "--qi", "viruses.fna"); t = run("dist", "--qi", "--ri", "-q", "viruses.fna", "-r", "viruses.fna")
     assert s.returncode == 0 and t.returncode == 0, s.stderr + t.stderr
     assert set(s.stdout.splitlines()) <= set(t.stdout.splitlines()) and len(s.stdout.splitlines()) >= 1 + 3      # screens differ (no small-genome rescue in search)
+
+
+# ---------------------------------------------------------------- `triangle --gpus N`: one process per GPU from the one command (host/node.cpp, main.cpp run_triangle_node)
+def _write_fasta(path, recs, width=80, eol=b"\n"):
+    with open(path, "wb") as f:
+        f.write(b"".join(b">" + n.encode() + eol + eol.join(s[k:k + width] for k in range(0, len(s), width)) + eol for n, s in recs))
+
+
+def _node_case_files(tmp_path, n_clades=3, members=4, length=60000, seed=51):
+    """clades dealt out so that most candidate pairs cross the ranks' shares of the name-sorted list (sketches travel)"""
+    from tests.parity_cases import synthetic_clades
+    g = synthetic_clades(n_clades=n_clades, members=members, length=length, seed=seed, tiny=False)
+    g = [g[(k % n_clades) * members + k // n_clades] for k in range(n_clades * members)]
+    files = []
+    for k, recs in enumerate(g):
+        p = tmp_path / ("g%02d.fa" % k); _write_fasta(p, recs); files.append(str(p))
+    return files
+
+
+def _run_cli(exe, args, cwd, env, timeout=600):
+    return subprocess.run([exe] + args, capture_output=True, text=True, cwd=cwd, env=env, timeout=timeout)
+
+
+def test_cli_triangle_gpus_on_the_simulator(tmp_path):
+    """The whole multi-rank driver in a container without a GPU: the product's CLI sources linked against the kernel simulator (tests/host_shims build_cli_emu).
+    `triangle --gpus N --one-device` forks N ranks, each ingests its share of the sorted file list, the ranks meet in shared memory (the launcher's collectives as
+    skh_comm_create_host's callbacks), rank 0 writes: the output must be the one-process run's byte for byte -- matrix + AF matrix, edge list, -i, gzip in the list
+    (the record reader instead of the streaming ingest), sketch files as inputs, more ranks than files -- and a failure on ONE rank must end all ranks with one error."""
+    from tests.host_shims.build_shims import build_cli_emu
+    exe = build_cli_emu()
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"))
+    files = _node_case_files(tmp_path)
+    lst = tmp_path / "list.txt"; lst.write_text("\n".join(files[::-1]) + "\n")
+    one = _run_cli(exe, ["triangle", "-l", str(lst), "-o", "one.txt"], tmp_path, env)
+    assert one.returncode == 0, one.stderr
+    ref, ref_af = (tmp_path / "one.txt").read_bytes(), (tmp_path / "one.txt.af").read_bytes()
+    assert ref.splitlines()[0] == b"12" and sum(c not in (b"0.00",) for l in ref.splitlines()[2:] for c in l.split(b"\t")[1:]) >= 18   # 3 clades x 6 pairs
+    for w in (2, 3, 16):
+        r = _run_cli(exe, ["triangle", "-l", str(lst), "-o", "w.txt", "--gpus", str(w), "--one-device", "-t", "4"], tmp_path, env)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "w.txt").read_bytes() == ref and (tmp_path / "w.txt.af").read_bytes() == ref_af, w
+    # the edge list on stdout; contigs as genomes; a gzipped file in the list; sketch files
+    gz = tmp_path / "g03.fa.gz"; gz.write_bytes(gzip.compress((tmp_path / "g03.fa").read_bytes(), 1))
+    with_gz = [f if not f.endswith("g03.fa") else str(gz) for f in files]
+    sk_dir = tmp_path / "sk"
+    assert _run_cli(exe, ["sketch", "-o", str(sk_dir), "--separate-sketches"] + files, tmp_path, env).returncode == 0
+    sketches = sorted(str(sk_dir / f) for f in os.listdir(sk_dir) if f.endswith(".sketch"))
+    for extra, inputs in ((["-E"], files), (["-E", "-i"], files), (["-E", "--ci"], with_gz), (["-E"], sketches)):
+        a = _run_cli(exe, ["triangle"] + extra + inputs, tmp_path, env)
+        b = _run_cli(exe, ["triangle", "--gpus", "3", "--one-device"] + extra + inputs, tmp_path, env)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout and len(a.stdout.splitlines()) >= 19, (extra, a.stdout[:300], b.stdout[:300])
+    # a failure on one rank (the library's fault injection, rank 1 only) ends every rank: one error message, from the rank that failed, no hang
+    for phase in (3, 8):
+        f = _run_cli(exe, ["triangle", "-l", str(lst), "-o", "f.txt", "--gpus", "3", "--one-device"], tmp_path, dict(env, SKH_TUNE_DIST_FAIL=str(phase), SKH_TUNE_DIST_FAIL_RANK="1"), timeout=120)
+        errs = [l for l in f.stderr.splitlines() if l.startswith("ERROR")]
+        assert f.returncode == 1 and len(errs) == 1 and "[rank 1]" in errs[0] and "injected failure" in errs[0], f.stderr
+    # a rank that is gone without a word (killed): the launcher notices, the others' collectives end, one error
+    bad = _run_cli(exe, ["triangle", "-l", str(lst), "-o", "f.txt", "--gpus", "3", "--one-device"], tmp_path, dict(env, SKH_TUNE_NODE_KILL_RANK="2"), timeout=120)
+    errs = [l for l in bad.stderr.splitlines() if l.startswith("ERROR")]
+    assert bad.returncode == 128 + 9 and len(errs) == 1 and "signal 9" in errs[0], bad.stderr
+
+
+@pytest.mark.gpu
+def test_cli_triangle_gpus_one_device(tmp_path):
+    """`skani-hip triangle --gpus 2 --one-device` on the MI355X: two ranks forked by the command, sharing the one GPU, exchanging through the launcher's shared
+    memory; over W + its five derivatives (BASELINE config 2's set) and over a 40-file synthetic set the output equals the one-process run byte for byte; with
+    three ranks on the synthetic set as well; a failure on one rank ends all of them with one error."""
+    _, exe = build_host()
+    env = dict(os.environ, SKANI_HIP_DATA=os.path.join(os.path.dirname(sk.library_path()), "data"), SKH_TIMING="1")
+    W = golden_records("e.coli-W.fasta.gz")
+    wdir = tmp_path / "w"; wdir.mkdir()
+    wfiles = []
+    for i, rate in enumerate((0.0, 0.005, 0.01, 0.02, 0.04, 0.08)):
+        seq = W[0][1] if rate == 0 else mutate(W[0][1], rate, 0x5EED0000 + i)
+        p = wdir / ("w%d.fa" % i); _write_fasta(p, [(W[0][0], seq)]); wfiles.append(str(p))
+    sdir = tmp_path / "s"; sdir.mkdir()
+    sfiles = _node_case_files(sdir, n_clades=8, members=5, length=300000, seed=77)
+    for files, d in ((wfiles, wdir), (sfiles, sdir)):
+        one = _run_cli(exe, ["triangle", "-t", "8", "-o", "one.txt"] + files, d, env)
+        assert one.returncode == 0, one.stderr
+        for w in ((2,) if files is wfiles else (2, 3)):
+            r = _run_cli(exe, ["triangle", "-t", "8", "-o", "w%d.txt" % w, "--gpus", str(w), "--one-device"] + files[::-1], d, env)
+            assert r.returncode == 0, r.stderr
+            assert '"triangle_s"' in r.stderr                                      # rank 0's phase clock
+            assert (d / ("w%d.txt" % w)).read_bytes() == (d / "one.txt").read_bytes() and (d / ("w%d.txt.af" % w)).read_bytes() == (d / "one.txt.af").read_bytes()
+        a = _run_cli(exe, ["triangle", "-E", "--ci"] + files, d, env); b = _run_cli(exe, ["triangle", "-E", "--ci", "--gpus", "2", "--one-device"] + files, d, env)
+        assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout.splitlines()) > 10
+    lines = (wdir / "one.txt").read_bytes().splitlines()
+    assert lines[0] == b"6" and all(float(c) > 80 for l in lines[2:] for c in l.split(b"\t")[1:])   # all 15 pairs of config 2 are related
+    f = _run_cli(exe, ["triangle", "-o", "f.txt", "--gpus", "2", "--one-device"] + sfiles, sdir, dict(env, SKH_TUNE_DIST_FAIL="8", SKH_TUNE_DIST_FAIL_RANK="1"), timeout=300)
+    errs = [l for l in f.stderr.splitlines() if l.startswith("ERROR")]
+    assert f.returncode == 1 and len(errs) == 1 and "[rank 1]" in errs[0], f.stderr

@@ -19,6 +19,11 @@ def _free_port():
 
 # case -> (genomes, number of genomes held by each rank)
 def _case(case):
+    if case.endswith("_root"): case = case[:-5]                                  # the same collection, result rows gathered on rank 0 only (SKH_DIST_ROWS_TO_ROOT)
+    return _case_genomes(case)
+
+
+def _case_genomes(case):
     """interleave / interleave4: 3 clades x 4 members dealt out so that most candidate pairs cross the rank blocks (sketches travel);
     blocks: 2 clades x 6, one per rank -- nothing has to move;
     uneven: 3 clades x 4 spread over four ranks holding 5, 0, 4 and 3 genomes (clades span the rank boundaries; one rank holds nothing);
@@ -58,6 +63,7 @@ def _worker(rank, world, port, q, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if _wide_span_of(case, rank) is not None: os.environ["SKH_TUNE_WIDE_SPAN"] = _wide_span_of(case, rank)
+        to_root = case.endswith("_root"); case = case[:-5] if to_root else case
         if case == "uneven": os.environ["SKH_TUNE_SCREEN_CELLS"] = "40"      # a count matrix of 12 x 12 cells does not fit: the screen is cut by rows (the form of very large collections)
         ctx = sk.Context(0, lib=emu_lib())
         genomes, held = _case(case)
@@ -68,13 +74,13 @@ def _worker(rank, world, port, q, case):
         # half of the cases sketch with deferred seed tables (what bench.py does on several GPUs): a rank then indexes only the sketches it chains
         ss_local = ctx.sketch_genomes(gs, params, genome_rank=list(range(base, base + held[rank])), defer_tables=case in ("interleave4", "uneven", "dense", "blocks", "interleave8", "wide_mixed"))
         if case.startswith("wide"): assert ss_local.wide == (case == "wide_mixed" or rank == 0)
-        i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, with_stats=True)
+        i, j, res, n, st = distributed_triangle(ctx, ss_local, params, sk.MapParams(learned_ani=True, compute_ci=True), dist, rank, world, with_stats=True, rows_to_root=to_root)
         q.put((rank, i, j, res, n, st))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense", "interleave8", "wide_one_rank", "wide_mixed"])
+@pytest.mark.parametrize("case", ["interleave", "blocks", "interleave4", "uneven", "dense", "interleave8", "wide_one_rank", "wide_mixed", "interleave4_root", "uneven_root", "dense_root"])
 def test_multi_rank_triangle_matches_single_process(case):
     import multiprocessing as mp
     import skani_amd as sk
@@ -92,7 +98,18 @@ def test_multi_rank_triangle_matches_single_process(case):
     for p in procs:
         p.join(timeout=60); assert p.exitcode == 0
     _, i, j, res, n, st0 = got[0]
-    for r in range(1, world):      # every rank returns the whole triangle
+    to_root = case.endswith("_root"); case = case[:-5] if to_root else case
+    if to_root:                    # rank 0 returns the whole triangle, every other rank the rows of the pairs it chained: disjoint stretches of it, in (i, j) order
+        where = {(int(a), int(b)): x for x, (a, b) in enumerate(zip(i, j))}; seen = set(); others = 0
+        for r in range(1, world):
+            ri, rj, rres = got[r][1], got[r][2], got[r][3]
+            assert got[r][4] == n and len(ri) <= got[r][5]["n_pairs_mine"]
+            keys = [(int(a), int(b)) for a, b in zip(ri, rj)]
+            assert keys == sorted(keys) and not (set(keys) & seen) and all(k in where for k in keys)
+            assert all(rres[x].tobytes() == res[where[k]].tobytes() for x, k in enumerate(keys))
+            seen |= set(keys); others += len(keys)
+        assert others < len(i) or got[0][5]["n_pairs_mine"] == 0
+    for r in range(1, world if not to_root else 1):      # every rank returns the whole triangle
         assert np.array_equal(got[r][1], i) and np.array_equal(got[r][2], j) and got[r][3].tobytes() == res.tobytes() and got[r][4] == n
     # oracle: genome ranks are the global indices (names sort like indices)
     osk = [ora.sketch_records(g, file_name="g%03d" % k) for k, g in enumerate(genomes)]
