@@ -167,6 +167,25 @@ def run_search(args, torch, sk, ctx, device):
         print("host view of a search step (ms): %s; library timers: %s" % ({k: round(1e3 * v / args.steps, 3) for k, v in host_times.items()},
                                                                            {k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms") and v}), file=sys.stderr)
     own = (r // CLADE) == qclades[q]
+    # ---- roofline: the chaining stage dominates the step; SURVEY 8d's figure: both sketches of a chained pair read once, 12 B per seed position (positions = bases / c);
+    # the screen: 8 B per marker of the database and of the queries, read once
+    pos_per_genome = args.mean_len / args.c
+    chain_s = tm["chain_ms"] / args.steps * 1e-3; screen_s = tm["screen_ms"] / args.steps * 1e-3
+    n_hits_chained = int(len(q))                                        # (every screened pair of this workload is kept: all hits lie in the query's clade)
+    chain_bytes = 12.0 * 2.0 * pos_per_genome * n_hits_chained
+    screen_bytes = 8.0 * (n_db + nq) * (args.mean_len / M)
+    roof = {"stage": "join + chunk + chain + select + estimate over the screened (query, reference) pairs", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9 if chain_s > 0 else 0.0,
+            "peak": 8000.0, "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0 if chain_s > 0 else 0.0, "traffic": None, "bytes_per_step": chain_bytes, "ms": chain_s * 1e3,
+            "note": "12 B x (positions of query + reference) per chained pair (SURVEY 8d); irregular, latency-bound stages -- the same kernels as the triangle's chaining, whose counters are in profiles/r05_pmc.md",
+            "screen": {"bound": "hbm", "achieved": screen_bytes / screen_s / 1e9 if screen_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                       "frac": screen_bytes / screen_s / 1e9 / 8000.0 if screen_s > 0 else 0.0, "bytes_per_step": screen_bytes, "ms": screen_s * 1e3,
+                       "note": "8 B per marker of the database and the queries; the database's sorted incidence list is cached, a step sorts the queries' and probes"}}
+    cpu = None
+    if getattr(args, "cpu_queries", 0):
+        try:
+            cpu = search_cpu_baseline(args, torch, sk, device, db, qclades, q, r, res, n_db, nq)
+        except Exception as e:                                           # the line must not depend on the oracle leg
+            cpu = {"error": repr(e)}
     db.close(); qs.close()
     return ({"metric": "search queries/sec vs resident sketch DB", "value": nq / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -174,8 +193,64 @@ def run_search(args, torch, sk, ctx, device):
                                  "db_shards": len(shards), "queries": nq, "hits": int(len(q)), "hits_in_own_clade": int(own.sum()), "db_build_s": build_s,
                                  "hbm_used_gb": (mem_gb[1] - mem_gb[0]) / 1e9, "library_live_gb": live_b / 1e9,
                                  "bytes_per_seed_position": live_b / max(1.0, n_db * (args.mean_len / args.c)), "compact_shards": not getattr(args, "no_compact", False)},
-                      "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": None, "cpu_baseline": None},
+                      "phase_ms_per_step": {k: tm[k] / args.steps for k in ("screen_ms", "chain_ms")}, "roofline": roof, "cpu_baseline": cpu},
             (q, r, res, qclades))
+
+
+def search_cpu_baseline(args, torch, sk, device, db, qclades, q, r, res, n_db, nq):
+    """The CPU side of the search metric on a BOUNDED sample: `--cpu-queries` of the queries against a sample of the database -- the queries' own clades (every
+    reference the GPU chained for them) + other clades up to 100 -- through the oracle's search loop (ora_search: search.rs:97-200 with every reference resident;
+    inverted marker index, screen_refs_indices, chain_seeds, ani > 0.5).  The reference sketches are the GPU database's own, exported (sketching a database is
+    `skani sketch`'s job, not the search's); the queries are sketched by the oracle from their bytes (not timed: the GPU step takes sketched queries too).
+    Scaled to the workload: index build x (database / sample refs), screen x (queries / sampled queries) (a probe's cost goes with the query's markers and the
+    postings it meets, i.e. with its clade, not with the database), chain x (hits / sampled hits)."""
+    from oracle import oracle_py as ora
+    nsq = min(int(args.cpu_queries), nq)
+    pick = np.unique(np.linspace(0, nq - 1, nsq).astype(np.int64))
+    clades = list(dict.fromkeys(int(qclades[x]) for x in pick))
+    n_cl = max(1, n_db // CLADE)
+    for cl in (np.arange(100, dtype=np.int64) * n_cl // 100).tolist():             # other clades, evenly from the database
+        if len(clades) >= 100: break
+        if cl not in clades: clades.append(cl)
+    ref_ids = np.sort(np.concatenate([np.arange(cl * CLADE, min(n_db, (cl + 1) * CLADE)) for cl in clades]))
+    orefs = []
+    for g in ref_ids:
+        sh = int(np.searchsorted(db.offsets, g, side="right") - 1); e = db.shards[sh].export(int(g - db.offsets[sh]))
+        orefs.append(ora.Sketch.from_arrays(args.c, K, M, "s%07d.fa" % int(g), e["seed"], e["pos"], e["ctgcanon"], e["markers"], e["contig_lengths"], e["total_len"]))
+    oqs = []
+    for x in pick:
+        qb, _, _, _ = make_queries(torch, device, [int(qclades[x])], args.mean_len, first=int(x))
+        oqs.append(ora.sketch_records([("q", qb.cpu().numpy())], args.c, K, M, "t%07d.fa" % int(x)))   # (query names sort after every database name, as in the GPU run)
+    model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin" if abs(args.c - 125) < abs(args.c - 200) else "gbdt_c200.bin")) if args.c >= 70 else None
+    logical, physical, model_name = host_cores(); quota = cpu_quota()
+    threads = max(1, min(logical, int(round(quota)) if quota else physical))
+    ora.search(orefs, oqs[:2], 0.0, True, min_af=-1.0, model=model, threads=threads)         # (first touch of the heap)
+    t0 = time.perf_counter()
+    oq, orf, ores, nch = ora.search(orefs, oqs, 0.0, True, min_af=-1.0, model=model, threads=threads)
+    wall = time.perf_counter() - t0
+    ix, sc, ch = ora.triangle_phases()
+    # the same pairs and values as the GPU's rows of these queries
+    want = {}
+    for a, b, x in zip(q, r, res):
+        want[(int(a), int(b))] = x
+    delta = {"pairs_compared": int(len(oq)), "same_pair_set": True}
+    gq_rows = {(int(a), int(b)) for a, b in zip(q, r) if int(a) in set(int(x) for x in pick)}
+    o_rows = {(int(pick[a]), int(ref_ids[b])) for a, b in zip(oq, orf)}
+    delta["same_pair_set"] = gq_rows == o_rows
+    if delta["same_pair_set"] and len(oq):
+        for f in ("ani", "af_ref", "af_query"):
+            delta["max_abs_d_" + f] = float(max(abs(float(want[(int(pick[a]), int(ref_ids[b]))][f]) - float(x[f])) for a, b, x in zip(oq, orf, ores)))
+    hits_per_query = len(q) / max(nq, 1)
+    scaled = {"marker_index": ix * n_db / len(orefs), "screen": sc * nq / len(oqs), "chain": ch * (len(q) / max(int(nch), 1))}
+    scaled["total"] = sum(scaled.values())
+    return {"value": nq / scaled["total"], "unit": "queries/s", "cores": threads, "threads": threads, "cpus_granted": quota if quota else logical, "kind": "port",
+            "sample": "%d of the %d queries against %d of the %d database genomes (the sampled queries' clades + other clades, %d in all; reference sketches exported from the "
+                      "GPU database, queries sketched by the oracle, neither timed): oracle marker index %.3f s + screen %.3f s + chain of %d pairs %.3f s on %d threads; scaled to the "
+                      "workload: index x %.1f, screen x %.1f, chain x %.1f = %.2f s per %d queries (%.1f hits per query)"
+                      % (len(oqs), nq, len(orefs), n_db, len(clades), ix, sc, int(nch), ch, threads, n_db / len(orefs), nq / len(oqs), len(q) / max(int(nch), 1), scaled["total"], nq, hits_per_query),
+            "seconds": {"marker_index": ix, "screen": sc, "chain": ch, "total": wall}, "seconds_scaled_to_workload": scaled, "chained_pairs": int(nch),
+            "chained_pairs_per_s": int(nch) / ch if ch > 0 else None, "delta_vs_oracle": delta,
+            "host": {"logical_cpus": logical, "physical_cores": physical, "model": model_name, "cgroup_cpu_quota": quota}}
 
 
 def cpu_quota():
@@ -326,7 +401,7 @@ def write_fasta(path, recs, width=80):
                 f.write(a[rows * width:].tobytes() + b"\n")
 
 
-def e2e_leg(host_genomes, threads):
+def e2e_leg(host_genomes, threads, gpus=1, one_device=False):
     """End to end: the collection as FASTA files on a RAM disk -> `skani-hip triangle` (parse on `threads` threads, copy + pack while
     the next files are parsed, sketch, screen, chain, matrix writer) -> the ANI matrix file; wall clock of the whole process (HIP start-up and model load
     included) and the driver's own phase clock.  Beside it the oracle on the same files: read + sketch on the same number of threads, marker index,
@@ -348,10 +423,11 @@ def e2e_leg(host_genomes, threads):
         lst = os.path.join(d, "files.txt"); open(lst, "w").write("\n".join(names) + "\n")
         nbytes = sum(os.path.getsize(f) for f in names)
         env = dict(os.environ, SKH_TIMING="1", SKANI_HIP_DATA=os.path.join(ROOT, "skani_amd", "data"))
+        node_args = (["--gpus", str(gpus)] + (["--one-device"] if one_device else [])) if gpus > 1 else []   # several GPUs: the command forks one rank per GPU itself
         runs = []
         for _ in range(3):                                            # the fastest run is the one reported, all are listed (the first pages the binary and the files in)
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "triangle", "-t", str(threads), "-l", lst, "-o", os.path.join(d, "matrix.txt")], capture_output=True, text=True, env=env)
+            r = subprocess.run([exe, "triangle", "-t", str(threads), "-l", lst, "-o", os.path.join(d, "matrix.txt")] + node_args, capture_output=True, text=True, env=env)
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": "skani-hip triangle failed: " + r.stderr[-400:]}
@@ -364,7 +440,8 @@ def e2e_leg(host_genomes, threads):
         n = len(host_genomes); pairs = n * (n - 1) // 2
         rows = open(os.path.join(d, "matrix.txt")).read().count("\n")
         out = {"genomes": n, "fasta_bytes": nbytes, "threads": threads, "wall_s": wall, "runs_wall_s": [round(r[0], 4) for r in runs], "pairs_per_s": pairs / wall,
-               "phases_s": phases, "matrix_rows": rows - 1, "command": "skani-hip triangle -t %d -l files.txt -o matrix.txt (FASTA on %s)" % (threads, base or "the temp dir")}
+               "phases_s": phases, "matrix_rows": rows - 1, "gpus": gpus,
+               "command": "skani-hip triangle -t %d -l files.txt -o matrix.txt%s (FASTA on %s)" % (threads, " " + " ".join(node_args) if node_args else "", base or "the temp dir")}
         model = ora.Model(os.path.join(ROOT, "skani_amd", "data", "gbdt_c125.bin" if abs(C - 125) < abs(C - 200) else "gbdt_c200.bin")) if C >= 70 else None
         t0 = time.perf_counter()
         sks = ora.sketch_files(names, C, K, M, 1, 500, threads)
@@ -426,6 +503,218 @@ def file_sha(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def pick_sample(canon, n_total, clades):
+    """Global indices (ascending) of the members of `clades` whole clades taken evenly from the collection."""
+    n_cl = n_total // CLADE; take = max(1, min(n_cl, clades))
+    cl = set((np.arange(take, dtype=np.int64) * n_cl // take).tolist())
+    return np.nonzero(np.isin(canon // CLADE, list(cl)))[0]
+
+
+def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, steps, warmup, want_cpu, want_e2e):
+    """One measured triangle workload: every rank makes its n_local genomes of the collection (n_local * world, in `order`), W warm-up steps, `steps` timed steps
+    between barriers, the MAX over ranks.  Rank 0 returns the bench line (a dict), the others None.  want_cpu: the oracle beside it (`cpu_baseline`, rank 0 only:
+    on the genomes rank 0 holds when that is the whole workload, else on whole clades sampled from the collection, which rank 0 generates for itself)."""
+    n_total = n_local * world
+    assert n_total % CLADE == 0, "the collection must consist of whole clades"
+    canon = genome_order(n_total, order)                               # global genome index -> canonical id
+    mine = canon[rank * n_local:(rank + 1) * n_local]
+    # genomes the oracle runs on beside the GPU: the full workload by default on one GPU; with --collection, or on several GPUs, whole clades taken evenly from
+    # the collection (their members are spread over the shuffled order and over the ranks).  cpu_ids = their global indices, ascending.
+    cpu_ids = np.zeros(0, np.int64)
+    sampled = strong or world > 1
+    if rank == 0 and want_cpu and args.cpu_clades != 0:
+        if sampled:
+            cpu_ids = pick_sample(canon, n_total, args.cpu_sample_clades if args.cpu_clades < 0 else args.cpu_clades)
+        else:
+            cpu_ids = np.arange(n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE), dtype=np.int64)
+    local_ids = cpu_ids if world == 1 else np.zeros(0, np.int64)      # (several ranks: the sample is made after the timed steps, its members live on every rank)
+    keep = np.zeros(n_local, bool); keep[local_ids] = True
+    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=keep if len(local_ids) else False)
+    host_genomes = [host_genomes[int(x)] for x in local_ids]
+    torch.cuda.synchronize()
+    gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
+    total_bases_local = int(contig_off[-1])
+    del bases
+    torch.cuda.empty_cache()
+    params = sk.SketchParams(C, K, M, sk.SEED_AVX2)
+    mp = sk.MapParams(learned_ani=sk.use_learned_ani(C), compute_ci=not args.no_ci)
+    ctx.timings()
+    last = {}
+    host_t = [0.0, 0.0, 0.0]                      # BENCH_STEP_TIMES=1: wall time of a step's three calls as the host sees them (stderr)
+    genome_rank = np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32)
+    rows_to_root = comm is not None and not args.rows_everywhere
+
+    def step():
+        # genome_rank = global index: the collection's names sort like its indices
+        # several GPUs: seed tables deferred -- every rank indexes only the sketches it ends up chaining (its own that stay + the ones it receives)
+        t0 = time.perf_counter()
+        ss_local = ctx.sketch_genomes(gs, params, genome_rank=genome_rank, defer_tables=comm is not None or args.tables == "beside-screen", screen_index=comm is None)
+        t1 = time.perf_counter()
+        if comm is None:
+            i, j, res, n_chained = ctx.triangle(ss_local, mp)
+        else:
+            i, j, res, n_chained, last["stats"] = comm.triangle(ss_local, mp, rows_to_root=rows_to_root)   # SURVEY 8e: the result rows are gathered on rank 0
+        t2 = time.perf_counter()
+        ss_local.close()
+        t3 = time.perf_counter()
+        host_t[0] += t1 - t0; host_t[1] += t2 - t1; host_t[2] += t3 - t2
+        last["result"] = (i, j, res)
+        return len(i), n_chained
+
+    with stdout_to_stderr():                      # (the first collective may still print)
+        for _ in range(warmup):
+            step()
+            if os.environ.get("BENCH_WARMUP_PAUSE"):      # diagnostic (profiles/r04_first_steps_transient.md): an idle stretch behind each warm-up step
+                time.sleep(float(os.environ["BENCH_WARMUP_PAUSE"]))
+        if comm is not None and warmup == 0:
+            dist.barrier()
+    ctx.timings()
+    host_t[:] = [0.0, 0.0, 0.0]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    cpu_stat0 = cpu_stat()
+    t0 = time.perf_counter()
+    kept = chained = 0
+    step_wall = []
+    for _ in range(steps):
+        ts = time.perf_counter()
+        kept, chained = step()
+        step_wall.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tm = ctx.timings()
+    gs.close()
+    torch.cuda.empty_cache()
+    if os.environ.get("BENCH_STEP_TIMES"):
+        print("host view of a step (ms): sketch_genomes %.3f, triangle %.3f, sketch set close %.3f; library timers: %s; cgroup cpu.stat over the timed steps: %s" %
+              tuple([1e3 * x / steps for x in host_t] + [{k: round(v / steps, 3) for k, v in tm.items() if k.endswith("_ms")}, cpu_stat_delta(cpu_stat0)]), file=sys.stderr)
+    per_rank = None
+    if comm is not None:
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        st = last["stats"]
+        mine_t = torch.tensor([st["n_pairs_mine"], st["n_genomes_received"], st["bytes_received"], int(tm["chain_ms"] * 1000), int(tm["exchange_ms"] * 1000),
+                               int(tm["seed_ms"] * 1000), int(tm["sketch_build_ms"] * 1000), int(tm["screen_ms"] * 1000), total_bases_local,
+                               int(tm.get("exchange_wait_ms", 0.0) * 1000), kept], dtype=torch.int64)
+        allt = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        per_rank = [[int(x) for x in a] for a in allt]
+    if rank != 0:
+        return None
+    ms_per_step = dt / steps * 1e3
+    pairs = n_total * (n_total - 1) // 2
+    value = pairs / (dt / steps)
+    # roofline of the seeding kernel: algorithmic bytes = 0.25 B/base packed read + 12/c B seeds + 8/m B markers (SURVEY 8d)
+    alg_bytes_per_base = 0.25 + 12.0 / C + 8.0 / M
+    launches = max(tm["seed_kernel_launches"], 1)
+    seed_ms_per_launch = tm["seed_kernel_ms"] / launches
+    bytes_per_launch = alg_bytes_per_base * total_bases_local * steps / launches
+    achieved = bytes_per_launch / (seed_ms_per_launch * 1e-3) / 1e9 if seed_ms_per_launch > 0 else 0.0
+    # counters that were measured offline (separate rocprofv3 --pmc passes) are only quoted while the kernel source they were measured on is unchanged
+    seed_src_sha = file_sha(os.path.join(ROOT, "skani_amd", "csrc", "pack_seed.hip"))
+    traffic, traffic_note, valu, valu_waves, rocprof_ms = None, "no profiles/seed_traffic.json", None, None, None
+    tpath = os.path.join(ROOT, "profiles", "seed_traffic.json")
+    if os.path.exists(tpath) and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha256_16") == seed_src_sha:
+                traffic = tj.get("hbm_bytes_per_launch"); traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s (%s)" % (tj.get("commit"), tj.get("source"))
+                valu = tj.get("valu"); valu_waves = tj.get("waves_per_launch"); rocprof_ms = tj.get("rocprof_avg_ms")
+            else:
+                traffic_note = "profiles/seed_traffic.json was measured on another version of pack_seed.hip (%s, now %s): not quoted" % (tj.get("kernel_source_sha256_16"), seed_src_sha)
+        except Exception as e:
+            traffic_note = "unreadable profiles/seed_traffic.json: %r" % (e,)
+    elif os.path.exists(tpath):
+        traffic_note = "counters were measured on the default workload only"
+    roof = {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "traffic_source": traffic_note, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch,
+            "launches_per_step": launches / steps,
+            "note": "0.354 algorithmic B/base; the kernel is bound by VALU issue, not by HBM: see valu_frac and profiles/r02_valu_rates.md.  achieved / frac use this run's "
+                    "HIP-event time per launch; frac_rocprof the average duration of the committed rocprofv3 kernel trace of the same kernel source (a few per cent longer)"}
+    if rocprof_ms:
+        roof["ms_per_launch_rocprof"] = rocprof_ms
+        roof["frac_rocprof"] = bytes_per_launch / (rocprof_ms * 1e-3) / 1e9 / 8000.0
+    if valu:
+        # VALU issue cycles the kernel's instructions need (static count per wave x measured cycles per instruction class, tools/isa_mix.py) over the
+        # SIMD cycles its launch had: 1024 SIMDs x shader clock x kernel time
+        simd_cycles = 1024 * valu["clock_ghz"] * 1e9 * seed_ms_per_launch * 1e-3
+        waves = valu_waves or total_bases_local / 8192.0 * 4.0          # SQ_WAVES of the launch (else: one workgroup of 4 waves per 8192 windows)
+        roof["valu_frac"] = waves * valu["issue_cycles_per_wave"] / simd_cycles
+        roof["valu"] = valu
+    out = {
+        "metric": "genome-pairs/sec (triangle, ~5 Mbp genomes)", "value": value, "unit": "genome-pairs/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence, %s), -c %d -k %d -m %d -s 80, learned ANI on%s"
+                               % (n_total, args.mean_len / 1e6, CLADE, "listed clade by clade" if order == "clade" else "file order shuffled: clades span the GPUs", C, K, M,
+                                  "" if world == 1 else ", tiled across %d %s (%d genomes each) via %s" % (world, "processes on ONE GPU" if args.one_device else "GPUs", n_local,
+                                                                                                   "RCCL" if transport == "rccl" else "host collectives (gloo)")),
+                   "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
+                   "kept_pairs": kept, "order": order,
+                   "mode": ("strong scaling: a fixed collection of %d genomes at every N" % n_total) if strong else
+                   ("weak scaling: %d genomes per GPU" % n_local if world > 1 else "one GPU"), "one_device": bool(args.one_device),
+                   "transport": transport, "result_rows": "single GPU" if comm is None else ("gathered on rank 0" if rows_to_root else "gathered on every rank"),
+                   "parallelism": "single GPU" if world == 1 else
+                                  "one process per GPU; every rank sketches its genomes; markers all-gathered; the screen is cut by key range (every rank counts the "
+                                  "incidences of a W-th of the markers' leading 16 bases, the non-zero cells are gathered on the device and every rank applies the rule "
+                                  "itself); candidate pairs assigned to ranks cluster by cluster (balanced, order-independent); only the needed sketches travel, "
+                                  "point-to-point and asynchronously; result rows gathered on rank 0"},
+        "phase_ms_per_step": {k: tm[k] / steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "exchange_ms")},
+        "step_wall_ms_rank0": [round(1e3 * x, 3) for x in step_wall],
+        "roofline": roof,
+    }
+    # what compares across N and across the weak / strong modes: the pair count grows with the square of the collection, the work with its size
+    step_s = dt / steps
+    total_bases = sum(r[8] for r in per_rank) if per_rank else total_bases_local
+    out["bases_per_s_per_gpu"] = total_bases / step_s / world
+    out["chained_pairs_per_s_per_gpu"] = chained / step_s / world
+    out["genomes_per_s_per_gpu"] = n_total / step_s / world
+    if per_rank:
+        names = ("chained_pairs", "sketches_received", "bytes_received", "chain_us", "exchange_us", "seed_us", "sketch_build_us", "screen_us", "bases", "exchange_wait_us", "rows_returned")
+        out["per_rank"] = {nm: [r[x] // (steps if nm.endswith("_us") else 1) for r in per_rank] for x, nm in enumerate(names)}
+    # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
+    # (SURVEY 8d: ~0.96 MB per pair of 5 Mbp genomes at c=125)
+    chain_s = tm["chain_ms"] / steps * 1e-3
+    if chain_s > 0 and chained:
+        chain_bytes = 12.0 * 2.0 * (total_bases_local / max(n_local, 1) / C) * (chained / world)
+        out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
+                                 "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes, "traffic": None,
+                                 "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in profiles/r05_pmc.md"}
+        # measured HBM bytes of the stage per step (separate rocprofv3 --pmc passes, tools/make_chain_traffic.py), quoted while the chaining sources are unchanged
+        cpath = os.path.join(ROOT, "profiles", "chain_traffic.json")
+        if os.path.exists(cpath) and world == 1 and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
+            try:
+                import hashlib
+                cj = json.load(open(cpath))
+                srcs = sorted(f for f in os.listdir(os.path.join(ROOT, "skani_amd", "csrc")) if f.startswith("chain"))
+                sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "skani_amd", "csrc", f), "rb").read() for f in srcs)).hexdigest()[:16]
+                if cj.get("chain_sources_sha256_16") == sha:
+                    out["roofline_chain"]["traffic"] = cj["hbm_bytes_per_step"]
+                    out["roofline_chain"]["traffic_over_algorithmic"] = cj["hbm_bytes_per_step"] / chain_bytes
+                    out["roofline_chain"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s, %s" % (cj.get("commit"), cj.get("rule"))
+                else:
+                    out["roofline_chain"]["traffic_source"] = "profiles/chain_traffic.json was measured on other chaining sources: not quoted"
+            except Exception as e:
+                out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
+    out["cpu_baseline"] = None
+    if len(cpu_ids):
+        if world > 1:                                                  # the sample's members live on every rank: rank 0 makes them again for the oracle (genomes are pure functions of their ids)
+            b2, _, _, _, host_genomes = make_genomes(torch, device, canon[cpu_ids], mean_len=args.mean_len, members=CLADE, keep_host=True)
+            del b2
+            torch.cuda.empty_cache()
+        gpu_result = last.get("result")
+        out["cpu_baseline"] = cpu_baseline(host_genomes, gpu_result, n_total, ids=cpu_ids)
+        if want_e2e:
+            try:
+                q = cpu_quota()
+                out["e2e"] = e2e_leg(host_genomes, max(4, min(host_cores()[1], 64, int(round(q)) * 2 if q else 64)), gpus=world, one_device=args.one_device)
+            except Exception as e:                                   # the headline line must not depend on a RAM disk
+                out["e2e"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -435,7 +724,8 @@ def main():
     ap.add_argument("--mean-len", type=int, default=5_000_000)
     ap.add_argument("--order", default="", choices=["", "clade", "shuffled"], help="order of the collection: clade by clade, or shuffled like unrelated file names "
                     "(default on several GPUs: members of a clade sit on different ranks and their sketches have to travel)")
-    ap.add_argument("--cpu-clades", type=int, default=-1, help="clades (x20 genomes) the CPU baseline runs on; default -1 = the full workload, 0 disables")
+    ap.add_argument("--cpu-clades", type=int, default=-1, help="clades (x20 genomes) the CPU baseline runs on; default -1 = the full workload on one GPU, --cpu-sample-clades "
+                    "sampled clades with --collection or on several GPUs; 0 disables")
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (FASTA files on a RAM disk through the skani-hip binary, ~20 s)")
     ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
@@ -444,6 +734,7 @@ def main():
     ap.add_argument("--db-genomes", type=int, default=10000)
     ap.add_argument("--no-compact", action="store_true", help="search workload: database shards with the triangle's table geometry (2 home slots per position, full list storage) instead of SKH_SKETCH_COMPACT")
     ap.add_argument("--queries", type=int, default=200)
+    ap.add_argument("--cpu-queries", type=int, default=20, help="search workload: queries the oracle searches beside the GPU (cpu_baseline; 0 disables)")
     ap.add_argument("--force-dist", action="store_true", help="one GPU: still go through the RCCL communicator and skh_triangle_distributed (world size 1; exercises the multi-GPU code path)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="several GPUs: the library's own RCCL communicator (default) or host collectives over torch.distributed (debug)")
     ap.add_argument("--tables", default="at-sketch", choices=["beside-screen", "at-sketch"], help="one GPU: the seed tables are built inside skh_sketch_genomes beside the marker sets (default) "
@@ -452,7 +743,13 @@ def main():
                     "multi-rank branch on a one-GPU box (tests/test_zz_bench_multirank.py); the number it prints is not a multi-GPU measurement")
     ap.add_argument("--collection", type=int, default=0, help="strong scaling: a fixed collection of this many genomes (10000 = BASELINE config 4) in shuffled order at every "
                     "--gpus N, collection / N genomes per rank")
-    ap.add_argument("--cpu-sample-clades", type=int, default=50, help="--collection on one GPU: whole clades (taken evenly from the collection) the oracle chains beside the GPU for delta_vs_oracle")
+    ap.add_argument("--cpu-sample-clades", type=int, default=50, help="--collection, or several GPUs: whole clades (taken evenly from the collection) the oracle runs on beside the GPUs "
+                    "(cpu_baseline scaled to the collection, delta_vs_oracle)")
+    ap.add_argument("--strong-collection", type=int, default=None, help="the default (weak) mode also measures this fixed collection at the same N and reports it as the line's "
+                    "`strong` block -- a driver sweep --gpus 1/2/4/8 then carries a strong-scaling series beside the weak one; default: 10000 for the default workload shape, "
+                    "else 0 = none")
+    ap.add_argument("--strong-steps", type=int, default=4)
+    ap.add_argument("--rows-everywhere", action="store_true", help="several GPUs: gather the result rows on every rank (skh_triangle_distributed) instead of on rank 0 (SKH_DIST_ROWS_TO_ROOT)")
     args = ap.parse_args()
 
     import torch
@@ -492,32 +789,7 @@ def main():
         n_local = args.collection // world
     else:
         n_local = args.genomes_per_gpu or (1000 if world == 1 else 1250)
-    n_total = n_local * world
-    assert n_total % CLADE == 0, "the collection must consist of whole clades"
     order = args.order or ("clade" if world == 1 and not strong else "shuffled")
-    canon = genome_order(n_total, order)                               # global genome index -> canonical id
-    mine = canon[rank * n_local:(rank + 1) * n_local]
-    # genomes the oracle runs on beside the GPU (rank 0 of a one-GPU run): the full workload by default; with --collection whole clades taken evenly from
-    # the collection (their members are spread over the shuffled order).  cpu_ids = their global indices, ascending.
-    cpu_ids = np.zeros(0, np.int64)
-    if rank == 0 and world == 1 and args.cpu_clades != 0:
-        if strong:
-            n_cl = n_total // CLADE; take = max(1, min(n_cl, args.cpu_sample_clades if args.cpu_clades < 0 else args.cpu_clades))
-            cl = set((np.arange(take, dtype=np.int64) * n_cl // take).tolist())
-            cpu_ids = np.nonzero(np.isin(canon // CLADE, list(cl)))[0]
-        else:
-            cpu_ids = np.arange(n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE), dtype=np.int64)
-    keep = np.zeros(n_local, bool); keep[cpu_ids] = True
-    bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=keep if len(cpu_ids) else False)
-    host_genomes = [host_genomes[int(x)] for x in cpu_ids]
-    torch.cuda.synchronize()
-    gs = ctx.pack_buffer(None, contig_off, contig_genome, ng, sk.SEED_AVX2, device_ptr=bases.data_ptr())
-    total_bases_local = int(contig_off[-1])
-    del bases
-    torch.cuda.empty_cache()
-    params = sk.SketchParams(C, K, M, sk.SEED_AVX2)
-    mp = sk.MapParams(learned_ani=sk.use_learned_ani(C), compute_ci=not args.no_ci)
-    ctx.timings()
 
     from skani_amd.distributed import Comm
     comm, transport = None, None
@@ -540,170 +812,35 @@ def main():
                     transport = "torch"
             if comm is None:
                 comm = Comm.host(ctx, dist, rank, world, torch=torch)
-    last = {}
 
-    host_t = [0.0, 0.0, 0.0]                      # BENCH_STEP_TIMES=1: wall time of a step's three calls as the host sees them (stderr)
-
-    def step():
-        # genome_rank = global index: the collection's names sort like its indices
-        # several GPUs: seed tables deferred -- every rank indexes only the sketches it ends up chaining (its own that stay + the ones it receives)
-        t0 = time.perf_counter()
-        ss_local = ctx.sketch_genomes(gs, params, genome_rank=genome_rank, defer_tables=comm is not None or args.tables == "beside-screen", screen_index=comm is None)
-        t1 = time.perf_counter()
-        if comm is None:
-            i, j, res, n_chained = ctx.triangle(ss_local, mp)
+    out = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, args.steps, args.warmup,
+                       want_cpu=True, want_e2e=not args.no_e2e and not strong)
+    # the same N on the fixed collection (BASELINE config 4's 10,000 genomes): the strong-scaling point that belongs to this line.  A default sweep --gpus 1/2/4/8 then
+    # yields the weak series (`value`) AND the strong one (`strong.ms_per_step`) without a second sweep.
+    default_shape = not args.genomes_per_gpu and args.mean_len == 5_000_000 and CLADE == 20 and C == 125 and not args.force_dist
+    if args.strong_collection is None:
+        args.strong_collection = 10000 if default_shape else 0
+    if not strong and args.strong_collection > 0 and args.strong_collection % world == 0 and (args.strong_collection // world) % CLADE == 0:
+        sn = args.strong_collection // world
+        if sn == n_local and order == "shuffled":                      # (8 GPUs: the weak default IS config 4)
+            s = out
         else:
-            i, j, res, n_chained, last["stats"] = comm.triangle(ss_local, mp)
-        t2 = time.perf_counter()
-        ss_local.close()
-        t3 = time.perf_counter()
-        host_t[0] += t1 - t0; host_t[1] += t2 - t1; host_t[2] += t3 - t2
-        last["result"] = (i, j, res)
-        return len(i), n_chained
-
-    genome_rank = np.arange(rank * n_local, (rank + 1) * n_local, dtype=np.uint32)
-    with stdout_to_stderr():                      # (the first collective may still print)
-        for _ in range(args.warmup):
-            step()
-            if os.environ.get("BENCH_WARMUP_PAUSE"):      # diagnostic (profiles/r04_first_steps_transient.md): an idle stretch behind each warm-up step
-                time.sleep(float(os.environ["BENCH_WARMUP_PAUSE"]))
-        if comm is not None and args.warmup == 0:
-            dist.barrier()
-    ctx.timings()
-    host_t[:] = [0.0, 0.0, 0.0]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    cpu_stat0 = cpu_stat()
-    t0 = time.perf_counter()
-    kept = chained = 0
-    for _ in range(args.steps):
-        kept, chained = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tm = ctx.timings()
-    if os.environ.get("BENCH_STEP_TIMES"):
-        print("host view of a step (ms): sketch_genomes %.3f, triangle %.3f, sketch set close %.3f; library timers: %s; cgroup cpu.stat over the timed steps: %s" %
-              tuple([1e3 * x / args.steps for x in host_t] + [{k: round(v / args.steps, 3) for k, v in tm.items() if k.endswith("_ms")}, cpu_stat_delta(cpu_stat0)]), file=sys.stderr)
-    per_rank = None
-    if comm is not None:
-        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        st = last["stats"]
-        mine_t = torch.tensor([st["n_pairs_mine"], st["n_genomes_received"], st["bytes_received"], int(tm["chain_ms"] * 1000), int(tm["exchange_ms"] * 1000),
-                               int(tm["seed_ms"] * 1000), int(tm["sketch_build_ms"] * 1000), int(tm["screen_ms"] * 1000), total_bases_local,
-                               int(tm.get("exchange_wait_ms", 0.0) * 1000)], dtype=torch.int64)
-        allt = [torch.empty_like(mine_t) for _ in range(world)]
-        dist.all_gather(allt, mine_t)
-        per_rank = [[int(x) for x in a] for a in allt]
-    if rank != 0:
-        if comm is not None:
-            comm.close()
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
-    ms_per_step = dt / args.steps * 1e3
-    pairs = n_total * (n_total - 1) // 2
-    value = pairs / (dt / args.steps)
-    # roofline of the seeding kernel: algorithmic bytes = 0.25 B/base packed read + 12/c B seeds + 8/m B markers
-    alg_bytes_per_base = 0.25 + 12.0 / C + 8.0 / M
-    launches = max(tm["seed_kernel_launches"], 1)
-    seed_ms_per_launch = tm["seed_kernel_ms"] / launches
-    bytes_per_launch = alg_bytes_per_base * total_bases_local * args.steps / launches
-    achieved = bytes_per_launch / (seed_ms_per_launch * 1e-3) / 1e9 if seed_ms_per_launch > 0 else 0.0
-    # counters that were measured offline (separate rocprofv3 --pmc passes) are only quoted while the kernel source they were measured on is unchanged
-    seed_src_sha = file_sha(os.path.join(ROOT, "skani_amd", "csrc", "pack_seed.hip"))
-    traffic, traffic_note, valu, valu_waves = None, "no profiles/seed_traffic.json", None, None
-    tpath = os.path.join(ROOT, "profiles", "seed_traffic.json")
-    if os.path.exists(tpath) and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("kernel_source_sha256_16") == seed_src_sha:
-                traffic = tj.get("hbm_bytes_per_launch"); traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s (%s)" % (tj.get("commit"), tj.get("source"))
-                valu = tj.get("valu"); valu_waves = tj.get("waves_per_launch")
-            else:
-                traffic_note = "profiles/seed_traffic.json was measured on another version of pack_seed.hip (%s, now %s): not quoted" % (tj.get("kernel_source_sha256_16"), seed_src_sha)
-        except Exception as e:
-            traffic_note = "unreadable profiles/seed_traffic.json: %r" % (e,)
-    elif os.path.exists(tpath):
-        traffic_note = "counters were measured on the default workload only"
-    roof = {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "traffic_source": traffic_note, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch,
-            "launches_per_step": launches / args.steps,
-            "note": "0.354 algorithmic B/base; the kernel is bound by VALU issue, not by HBM: see valu_frac and profiles/r02_valu_rates.md"}
-    if valu:
-        # VALU issue cycles the kernel's instructions need (static count per wave x measured cycles per instruction class, tools/isa_mix.py) over the
-        # SIMD cycles its launch had: 1024 SIMDs x shader clock x kernel time
-        simd_cycles = 1024 * valu["clock_ghz"] * 1e9 * seed_ms_per_launch * 1e-3
-        waves = valu_waves or total_bases_local / 8192.0 * 4.0          # SQ_WAVES of the launch (else: one workgroup of 4 waves per 8192 windows)
-        roof["valu_frac"] = waves * valu["issue_cycles_per_wave"] / simd_cycles
-        roof["valu"] = valu
-    out = {
-        "metric": "genome-pairs/sec (triangle, ~5 Mbp genomes)", "value": value, "unit": "genome-pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "skani triangle over %d synthetic ~%.1f Mbp genomes (clades of %d, 0.5-8%% divergence, %s), -c %d -k %d -m %d -s 80, learned ANI on%s"
-                               % (n_total, args.mean_len / 1e6, CLADE, "listed clade by clade" if order == "clade" else "file order shuffled: clades span the GPUs", C, K, M,
-                                  "" if world == 1 else ", tiled across %d %s (%d genomes each) via %s" % (world, "processes on ONE GPU" if args.one_device else "GPUs", n_local,
-                                                                                                   "RCCL" if transport == "rccl" else "host collectives (gloo)")),
-                   "genomes": n_total, "genomes_per_gpu": n_local, "bases_per_gpu": total_bases_local, "pairs": pairs, "chained_pairs": chained,
-                   "kept_pairs": kept, "order": order, "mode": ("strong scaling: a fixed collection of %d genomes at every N" % n_total) if strong else
-                   ("weak scaling: %d genomes per GPU" % n_local if world > 1 else "one GPU"), "one_device": bool(args.one_device),
-                   "transport": transport,
-                   "parallelism": "single GPU" if world == 1 else
-                                  "one process per GPU; every rank sketches its genomes; markers all-gathered, screen sharded by rows, candidate pairs assigned "
-                                  "to ranks cluster by cluster (balanced, order-independent), only the needed sketches travel point-to-point, results all-gathered"},
-        "phase_ms_per_step": {k: tm[k] / args.steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "exchange_ms")},
-        "roofline": roof,
-    }
-    # what compares across N and across the weak / strong modes: the pair count grows with the square of the collection, the work with its size
-    step_s = dt / args.steps
-    total_bases = sum(r[8] for r in per_rank) if per_rank else total_bases_local
-    out["bases_per_s_per_gpu"] = total_bases / step_s / world
-    out["chained_pairs_per_s_per_gpu"] = chained / step_s / world
-    out["genomes_per_s_per_gpu"] = n_total / step_s / world
-    if per_rank:
-        names = ("chained_pairs", "sketches_received", "bytes_received", "chain_us", "exchange_us", "seed_us", "sketch_build_us", "screen_us", "bases", "exchange_wait_us")
-        out["per_rank"] = {nm: [r[x] // (args.steps if nm.endswith("_us") else 1) for r in per_rank] for x, nm in enumerate(names)}
-    # the chaining pipeline against the north star's algorithmic figure: both sketches of a chained pair read once, 12 B per position
-    # (~0.96 MB per pair of 5 Mbp genomes at c=125)
-    chain_s = tm["chain_ms"] / args.steps * 1e-3
-    if chain_s > 0 and chained:
-        chain_bytes = 12.0 * 2.0 * (total_bases_local / max(n_local, 1) / C) * (chained / world)
-        out["roofline_chain"] = {"stage": "join + chunk + chain + select + estimate", "bound": "hbm", "achieved": chain_bytes / chain_s / 1e9, "peak": 8000.0,
-                                 "unit": "GB/s", "frac": chain_bytes / chain_s / 1e9 / 8000.0, "bytes_per_step": chain_bytes, "traffic": None,
-                                 "note": "irregular, latency-bound stages: per-kernel traffic, occupancy and LDS figures in profiles/r03_pmc.md"}
-        # measured HBM bytes of the stage per step (separate rocprofv3 --pmc passes, tools/make_chain_traffic.py), quoted while the chaining sources are unchanged
-        cpath = os.path.join(ROOT, "profiles", "chain_traffic.json")
-        if os.path.exists(cpath) and world == 1 and n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade":
-            try:
-                import hashlib
-                cj = json.load(open(cpath))
-                srcs = sorted(f for f in os.listdir(os.path.join(ROOT, "skani_amd", "csrc")) if f.startswith("chain"))
-                sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "skani_amd", "csrc", f), "rb").read() for f in srcs)).hexdigest()[:16]
-                if cj.get("chain_sources_sha256_16") == sha:
-                    out["roofline_chain"]["traffic"] = cj["hbm_bytes_per_step"]
-                    out["roofline_chain"]["traffic_over_algorithmic"] = cj["hbm_bytes_per_step"] / chain_bytes
-                    out["roofline_chain"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s, %s" % (cj.get("commit"), cj.get("rule"))
-                else:
-                    out["roofline_chain"]["traffic_source"] = "profiles/chain_traffic.json was measured on other chaining sources: not quoted"
-            except Exception as e:
-                out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
-    if host_genomes:
-        out["cpu_baseline"] = cpu_baseline(host_genomes, last.get("result"), n_total, ids=cpu_ids)
-        if not args.no_e2e and not strong:
-            try:
-                q = cpu_quota()
-                out["e2e"] = e2e_leg(host_genomes, max(4, min(host_cores()[1], 64, int(round(q)) * 2 if q else 64)))
-            except Exception as e:                                   # the headline line must not depend on a RAM disk
-                out["e2e"] = {"error": repr(e)}
-    else:
-        out["cpu_baseline"] = None
-    print(json.dumps(out))
+            s = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, sn, "shuffled", True, max(1, args.strong_steps), max(args.warmup, 4 if world == 1 else 2),
+                             want_cpu=False, want_e2e=False)
+        if rank == 0:
+            out["strong"] = {k: s[k] for k in ("ms_per_step", "value", "steps", "warmup", "bases_per_s_per_gpu", "chained_pairs_per_s_per_gpu", "genomes_per_s_per_gpu", "phase_ms_per_step")}
+            out["strong"].update({"collection": args.strong_collection, "genomes_per_gpu": sn, "chained_pairs": s["config"]["chained_pairs"], "order": "shuffled",
+                                  "note": "the same N on a FIXED collection (BASELINE config 4's %d shuffled genomes, %d per GPU): speed-up over N = this block's ms_per_step at "
+                                          "N = 1 / at N; the start-of-process transient at this size (profiles/r04_first_steps_transient.md) is why its warm-up is at least 4 steps on one GPU"
+                                          % (args.strong_collection, sn)})
+            if "per_rank" in s:
+                out["strong"]["per_rank"] = s["per_rank"]
+    if rank == 0:
+        print(json.dumps(out))
     if comm is not None:
         comm.close()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -291,7 +291,7 @@ int skh_plan_pairs(uint32_t n_genomes, const uint32_t* pair_i, const uint32_t* p
                    int world, uint8_t* owner);
 
 /* Device memory the library holds (all contexts of the process): live_bytes = in use by sketch sets, genome sets, models and scratch; idle_bytes = freed
- * blocks kept for reuse by its caching allocator (up to SKH_TUNE_ALLOC_CACHE_BYTES; default: a third of the device, beyond 32 GiB only while an eighth of the
+ * blocks kept for reuse by its caching allocator (up to SKH_TUNE_ALLOC_CACHE_BYTES; default: a third of the device, beyond 8 GiB only while an eighth of the
  * device is free -- they look "used" to the driver).  trim != 0 hands the
  * idle blocks back to the driver first.  Either pointer may be NULL. */
 int skh_device_memory(uint64_t* live_bytes, uint64_t* idle_bytes, int trim);

@@ -73,6 +73,8 @@ def lib():
         L.ora_screen_refs.restype = u64; L.ora_screen_refs.argtypes = [vp, u32, vp, dbl, i32, i32, vp]
         L.ora_triangle.restype = u64
         L.ora_triangle.argtypes = [vp, u32, dbl, i32, C.POINTER(MapOpts), vp, i32, vp, vp, vp, u64, vp, vp]
+        L.ora_search.restype = u64
+        L.ora_search.argtypes = [vp, u32, vp, u32, dbl, i32, C.POINTER(MapOpts), vp, i32, vp, vp, vp, u64, vp]
         L.ora_triangle_phases.restype = None; L.ora_triangle_phases.argtypes = [C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
         L.ora_mm_hash64.restype = u64; L.ora_mm_hash64.argtypes = [u64]
         L.ora_powi.restype = dbl; L.ora_powi.argtypes = [dbl, i32]
@@ -197,6 +199,17 @@ def triangle(sketches, screen_val=0.0, rescue_small=True, min_af=0.15, both_min_
     kept = lib().ora_triangle(arr, n, screen_val, int(rescue_small), C.byref(mo), model.h if model else None, threads,
                               _p(oi), _p(oj), _p(res), cap, C.byref(nch), C.byref(nsp))
     return oi[:kept].copy(), oj[:kept].copy(), res[:kept].copy(), nch.value, nsp.value
+
+
+def search(refs, queries, screen_val=0.0, use_index=True, min_af=0.15, both_min_af=-0.01, robust=False, median=False, model=None, threads=0, cap=None):
+    """search.rs:97-200 with every reference resident: (query, ref, results, n_chained), ani > 0.5, in (query, ref) order; phases through triangle_phases()."""
+    nr, nq = len(refs), len(queries)
+    ra = (C.c_void_p * max(nr, 1))(*[s.h for s in refs]); qa = (C.c_void_p * max(nq, 1))(*[s.h for s in queries])
+    cap = cap or (nr * nq + 1)
+    oq = np.empty(cap, np.uint32); orf = np.empty(cap, np.uint32); res = np.zeros(cap, RESULT_DTYPE)
+    mo = MapOpts(min_af, both_min_af, int(robust), int(median)); nch = C.c_uint64()
+    kept = lib().ora_search(ra, nr, qa, nq, screen_val, int(use_index), C.byref(mo), model.h if model else None, threads, _p(oq), _p(orf), _p(res), cap, C.byref(nch))
+    return oq[:kept].copy(), orf[:kept].copy(), res[:kept].copy(), nch.value
 
 
 def triangle_phases():

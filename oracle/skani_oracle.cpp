@@ -961,4 +961,45 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
     return kept;
 }
 
+// search.rs:97-200 (all reference sketches resident)
+uint64_t ora_search(const ora_sketch* const* refs, uint32_t n_refs, const ora_sketch* const* queries, uint32_t n_queries, double screen_val, int use_index,
+                    const ora_map_opts* mo, const ora_model* model, int threads, uint32_t* out_q, uint32_t* out_r, ora_ani_result* out_res, uint64_t cap,
+                    uint64_t* n_chained) {
+    if (screen_val == 0.) screen_val = 0.80;                            // SEARCH_ANI_CUTOFF_DEFAULT (params.rs)
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    tune_malloc_once();
+    const auto t_start = std::chrono::steady_clock::now();
+    InvIndex ix; if (use_index) ix.build(refs, n_refs, threads);       // search.rs:60-66
+    const auto t_index = std::chrono::steady_clock::now();
+    std::vector<std::vector<uint32_t>> pass(n_queries);
+    std::atomic<uint32_t> next{0};
+    auto screen_worker = [&]() {
+        std::vector<uint32_t> cnt(n_refs, 0), touched, out;
+        for (;;) {
+            const uint32_t q = next.fetch_add(1); if (q >= n_queries) break;
+            if (use_index) { screen_row(ix, refs, n_refs, queries[q], screen_val, 2, 0, cnt, touched, out); pass[q] = out; std::sort(pass[q].begin(), pass[q].end()); }   // search.rs:133-140
+            else for (uint32_t r = 0; r < n_refs; r++) if (ora_check_markers_quickly(queries[q], refs[r], screen_val, 0)) pass[q].push_back(r);   // search.rs:122-131 (argument order as there)
+        }
+    };
+    { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(screen_worker); for (auto& t : th) t.join(); }
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    for (uint32_t q = 0; q < n_queries; q++) for (uint32_t r : pass[q]) pairs.push_back({q, r});
+    const auto t_screen = std::chrono::steady_clock::now();
+    std::vector<ora_ani_result> res(pairs.size());
+    std::atomic<uint64_t> nextp{0};
+    auto chain_worker = [&]() {
+        for (;;) { const uint64_t p = nextp.fetch_add(1); if (p >= pairs.size()) break;
+            chain_seeds(*refs[pairs[p].second], *queries[pairs[p].first], *mo, model, res[p], nullptr); }   // search.rs:176
+    };
+    { std::vector<std::thread> th; for (int t = 0; t < threads; t++) th.emplace_back(chain_worker); for (auto& t : th) t.join(); }
+    if (n_chained) *n_chained = pairs.size();
+    const auto t_chain = std::chrono::steady_clock::now();
+    g_tri_phase[0] = std::chrono::duration<double>(t_index - t_start).count(); g_tri_phase[1] = std::chrono::duration<double>(t_screen - t_index).count();
+    g_tri_phase[2] = std::chrono::duration<double>(t_chain - t_screen).count();
+    uint64_t kept = 0;
+    for (size_t p = 0; p < pairs.size(); p++)
+        if (res[p].ani > 0.5f) { if (kept < cap) { out_q[kept] = pairs[p].first; out_r[kept] = pairs[p].second; out_res[kept] = res[p]; } kept++; }   // search.rs:178
+    return kept;
+}
+
 }  // extern "C"

@@ -102,6 +102,15 @@ uint64_t ora_triangle(const ora_sketch* const* sk, uint32_t n, double screen_val
 /* wall-clock seconds of the last ora_triangle call: marker index build, screen of all rows, chaining of the passing pairs */
 void ora_triangle_phases(double* index_s, double* screen_s, double* chain_s);
 
+/* search.rs:97-200 with every reference sketch resident (--keep-refs): for every query, refs that pass the marker screen -- use_index != 0:
+ * screen_refs_indices through the inverted index built once over all refs (search.rs:60-66, parse.rs:960: more than 50 query files); else
+ * check_markers_quickly(query, ref, screen_val, false) ref by ref (search.rs:122-131) -- are chained, chain_seeds(ref, query), and the results with
+ * ani > 0.5 kept (search.rs:178).  Threads pull queries (the reference nests par_iters over queries, refs and hits).  Output in (query, ref) order;
+ * returns the number kept; *n_chained = chain_seeds calls.  The phases' wall clock through ora_triangle_phases (index, screen, chain). */
+uint64_t ora_search(const ora_sketch* const* refs, uint32_t n_refs, const ora_sketch* const* queries, uint32_t n_queries, double screen_val, int use_index,
+                    const ora_map_opts*, const ora_model*, int threads, uint32_t* out_q, uint32_t* out_r, ora_ani_result* out_res, uint64_t cap,
+                    uint64_t* n_chained);
+
 /* pure helpers exposed for known-answer tests */
 uint64_t ora_mm_hash64(uint64_t key);               /* types.rs:86-96 */
 double ora_powi(double x, int n);                   /* compiler-rt __powidf2 as used by f64::powi */

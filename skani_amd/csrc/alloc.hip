@@ -2,7 +2,7 @@
 //
 // Freed blocks are kept, per device, and handed out again to requests of (nearly) the same size: a pipeline that sketches
 // and compares batch after batch asks for the same array sizes every time.  The cache is bounded (SKH_TUNE_ALLOC_CACHE_BYTES,
-// default a third of the device's memory, beyond 32 GiB only while an eighth of the device stays free; 0 disables it) and is flushed before an allocation is allowed to fail.
+// default a third of the block's device, beyond 8 GiB only while an eighth of that device stays free; 0 disables it) and is flushed before an allocation is allowed to fail.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,18 +16,32 @@ namespace skh {
 
 namespace {
 
-struct DeviceCache { std::multimap<size_t, void*> idle; size_t idle_bytes = 0; };
+struct DeviceCache { std::multimap<size_t, void*> idle; size_t idle_bytes = 0; size_t cap = 0; bool cap_known = false; };
+// the calling thread on `device` for the scope (memory queries answer for the current device), its previous device back afterwards
+struct OnDevice {
+    int prev = -1; bool moved = false;
+    explicit OnDevice(int device) { if (hipGetDevice(&prev) == hipSuccess && prev != device) moved = hipSetDevice(device) == hipSuccess; else (void)hipGetLastError(); }
+    ~OnDevice() { if (moved) (void)hipSetDevice(prev); }
+};
 struct Pool {
     std::mutex mu;
     std::unordered_map<void*, std::pair<size_t, int>> live;   // block -> (size, device)
     std::map<int, DeviceCache> dev;
-    size_t cap = 0; bool cap_known = false, cap_from_env = false;
-    Pool() { const char* v = getenv("SKH_TUNE_ALLOC_CACHE_BYTES"); if (v && *v) { cap = (size_t)strtoull(v, nullptr, 10); cap_known = cap_from_env = true; } }
-    // default bound: a third of the device's memory (96 GB on an MI355X).  A step over 10,000 genomes frees and asks again for ~45 GB of arrays; with the earlier 32 GiB
+    size_t env_cap = 0; bool cap_from_env = false, touch = false;
+    Pool() {
+        const char* v = getenv("SKH_TUNE_ALLOC_CACHE_BYTES"); if (v && *v) { env_cap = (size_t)strtoull(v, nullptr, 10); cap_from_env = true; }
+        const char* t = getenv("SKH_TUNE_ALLOC_TOUCH"); touch = t && *t && *t != '0';
+    }
+    // default bound, per device: a third of ITS memory (96 GB on an MI355X).  A step over 10,000 genomes frees and asks again for ~45 GB of arrays; with the earlier 32 GiB
     // bound 9.4 GB of them went back to the driver and came from it again in every step, and the driver's clearing of fresh memory held the step's first kernel back by 10-20 ms.
-    size_t bound() {
-        if (!cap_known) { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) cap = tot / 3; else { (void)hipGetLastError(); cap = (size_t)32 << 30; } cap_known = true; }
-        return cap;
+    size_t bound(int device, DeviceCache& dc) {
+        if (cap_from_env) return env_cap;
+        if (!dc.cap_known) {
+            OnDevice on(device); size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) dc.cap = tot / 3; else { (void)hipGetLastError(); dc.cap = (size_t)32 << 30; }
+            dc.cap_known = true;
+        }
+        return dc.cap;
     }
     void flush(DeviceCache& dc) { for (auto& kv : dc.idle) (void)hipFree(kv.second); dc.idle.clear(); dc.idle_bytes = 0; }
 };
@@ -60,6 +74,9 @@ void* dmalloc(size_t n) {
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) { (void)hipGetLastError(); P.flush(dc); e = hipMalloc(&p, n); }
     hip_check(e, "hipMalloc");
+    // SKH_TUNE_ALLOC_TOUCH=1 (diagnosis of profiles/r04_first_steps_transient.md): a block fresh from the driver is written once here, so that whatever the driver defers
+    // to a block's first use is paid at the allocation and not by the first kernel that touches it
+    if (P.touch && n >= ((size_t)1 << 20)) { (void)hipMemset(p, 0, n); (void)hipDeviceSynchronize(); }
     P.live[p] = {n, device};
     return p;
 }
@@ -73,10 +90,12 @@ void dfree(void* p) {
     const size_t sz = it->second.first; const int device = it->second.second;
     P.live.erase(it);
     DeviceCache& dc = P.dev[device];
-    const size_t cap = P.bound();
+    const size_t cap = P.bound(device, dc);
     bool keep = sz <= cap && dc.idle_bytes + sz <= cap;
-    if (keep && !P.cap_from_env && dc.idle_bytes + sz > ((size_t)32 << 30)) {       // a large cache only while the device has room to spare for others (a resident database, the caller's own allocations)
-        size_t fr = 0, tot = 0;
+    // a cache beyond 8 GiB only while the block's device has room to spare for others (a resident database, the caller's own allocations, other processes: eight
+    // ranks on one GPU each keep a cache of their own)
+    if (keep && !P.cap_from_env && dc.idle_bytes + sz > ((size_t)8 << 30)) {
+        OnDevice on(device); size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); keep = false; }
         else keep = fr >= tot / 8;
     }

@@ -495,17 +495,17 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             // the tables these descriptors point into were being built meanwhile: wait for them; a genome that had to take another salt (common.h
             // table_hash; the descriptors carry salt 0) is rare -- then the salts are put in again
             pending_done = true; (*tables_pending)();
-            bool salted = false;
-            for (uint32_t x = 0; x < n_rsets && !salted; x++) for (uint32_t v : Rsets[x]->salt) if (v) { salted = true; break; }
-            for (uint32_t x = 0; x < n_qsets && !salted; x++) for (uint32_t v : Qsets[x]->salt) if (v) { salted = true; break; }
-            if (salted) {
-                for (uint32_t x = 0; x < n_rsets; x++) { std::lock_guard<std::mutex> lk(Rsets[x]->cache_mu); Rsets[x]->halves.clear(); }
-                for (uint32_t x = 0; x < n_qsets; x++) { std::lock_guard<std::mutex> lk(Qsets[x]->cache_mu); Qsets[x]->halves.clear(); }
-                for (uint32_t i = 0; i < n; i++) {
-                    const uint32_t p = idx ? idx[i] : i;
-                    const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
-                    job.pds[i].b_salt = (job.pds[i].flags & 4u) ? Q->salt[pair_query[p]] : R->salt[pair_ref[p]];   // B = the query when switched
-                }
+            // What the build fixed only now: the salts of crowded genomes, and -- a set made with SKH_SKETCH_COMPACT | SKH_SKETCH_DEFER_TABLES -- the place of the
+            // list storage, which the build cuts to size and moves.  The cached halves were made before: they go, and the probed side of this batch's
+            // descriptors is filled in again from fresh ones (the later batches of a split call are made from them anyway).
+            for (uint32_t x = 0; x < n_rsets; x++) { { std::lock_guard<std::mutex> lk(Rsets[x]->cache_mu); Rsets[x]->halves.clear(); } genome_halves(Rsets[x]); }
+            for (uint32_t x = 0; x < n_qsets; x++) { { std::lock_guard<std::mutex> lk(Qsets[x]->cache_mu); Qsets[x]->halves.clear(); } genome_halves(Qsets[x]); }
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t p = idx ? idx[i] : i;
+                const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
+                const skh_sketch_set::GenomeHalf& B = (job.pds[i].flags & 4u) ? Q->halves[pair_query[p]] : R->halves[pair_ref[p]];   // B = the query when switched
+                PairDesc& pd = job.pds[i];
+                pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap; pd.b_salt = B.salt;
             }
         }
         if (!split) { chain_run<Narrow>(ctx, job, out, stats); break; }

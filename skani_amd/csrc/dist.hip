@@ -252,7 +252,12 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         Transport& T; skh_ctx* ctx; bool open = false;
         void close() { if (open) { open = false; T.exchange_end(ctx); } }
         ~ExchangeGuard() { try { close(); } catch (...) {} }
-    } xg{T, ctx};
+    };
+    // What an open exchange reads and writes -- the count / offset arrays the transport keeps pointers to, the two device buffers -- is declared BEFORE the guard: whatever
+    // unwinds, the guard closes the exchange (waiting for the worker thread / the second stream) while these still exist.
+    std::vector<uint64_t> s_cnt, s_off, r_cnt, r_off;
+    DBuf<uint32_t> send_buf, recv_buf;
+    ExchangeGuard xg{T, ctx};
     auto stop_together = [&](const char* phase, int r) {                           // rank r reported a failure: every rank throws
         try { xg.close(); } catch (...) {}
         device_sync_all();                                                          // nothing queued may outlive the buffers the unwinding frees
@@ -292,6 +297,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         std::vector<uint64_t> send(tab_words, 0); tab_all.assign((size_t)W * tab_words, 0);
         memcpy(send.data(), mine, sizeof(mine));
         send[8] = (markers_early && !local_err.empty()) ? 1 : 0;
+        send[9] = ctx->tune.screen_cells ^ ((uint64_t)ctx->tune.dist_key_range_w1 << 63);   // what decides between the key-range and the row form of the screen (SKH_TUNE_*): must agree
         if (nL <= cn && mine[3] <= cc) {
             for (uint32_t g = 0; g < nL; g++) {
                 uint64_t* f = send.data() + HDR + (size_t)g * GF;
@@ -306,6 +312,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             memcpy(cnt.data() + (size_t)r * 8, h, 64);
             if (h[4] != mine[4] || h[5] != mine[5] || h[6] != mine[6] || (h[7] & 255u) != (mine[7] & 255u))
                 throw std::invalid_argument("the ranks sketched with different c / k / marker_c / seeding mode");
+            if (h[9] != (ctx->tune.screen_cells ^ ((uint64_t)ctx->tune.dist_key_range_w1 << 63)))
+                throw std::invalid_argument("the ranks run with different screen budgets (SKH_TUNE_SCREEN_CELLS / SKH_TUNE_DIST_KEY_RANGE_W1): they would take different collective sequences");
             max_n = std::max(max_n, h[0]); max_m = std::max(max_m, h[2]); max_c = std::max(max_c, h[3]);
         }
         for (int r = 0; r < W; r++) if (tab_all[(size_t)r * tab_words + 8]) stop_together("marker buffers", r);
@@ -493,7 +501,8 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     std::unique_ptr<skh_sketch_set> Wh, Wr;
     std::vector<uint32_t> wk_set(N, 0), wk_index(N, 0xFFFFFFFFu);                   // global genome -> (0 = H, 1 = Wr, index in that set)
     const uint64_t NF = wide_any ? 3 : 2;                                           // 32-bit fields per seed position on the wire
-    std::vector<uint64_t> s_cnt(W, 0), s_off(W, 0), r_cnt(W, 0), r_off(W, 0), seg_s, seg_g, seg_c, r_words(W, 0), recv_at(N, 0);
+    s_cnt.assign(W, 0); s_off.assign(W, 0); r_cnt.assign(W, 0); r_off.assign(W, 0);
+    std::vector<uint64_t> seg_s, seg_g, seg_c, r_words(W, 0), recv_at(N, 0);
     uint64_t sw = 0, rw = 0;
     // send buffer per destination: [seeds of all its genomes][padded positions of all its genomes]  (32-bit words; with a wide set somewhere:
     // [seeds][positions in contig][contig << 1 | canonical])
@@ -515,8 +524,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.bytes_sent = sw * 4; st.bytes_received = rw * 4;
     uint32_t *d_send = nullptr, *d_recv = nullptr;
-    // the exchange buffers live outside the arena: the chaining of the home pairs resets it while they are in flight
-    DBuf<uint32_t> send_buf, recv_buf;
+    // (the exchange buffers -- send_buf / recv_buf, declared in front of the guard -- live outside the arena: the chaining of the home pairs resets it while they are in flight)
     local([&] {                                                                     // (local phase 5)
         send_buf.alloc(sw + 1); recv_buf.alloc(rw + 1); d_send = send_buf.p; d_recv = recv_buf.p;
         copy_segments(ctx, L->p_seed.p, d_send, seg_s);

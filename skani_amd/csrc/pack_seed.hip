@@ -183,12 +183,15 @@ void genomes_append(skh_ctx* ctx, skh_genome_set* gs, const uint8_t* bases, cons
     // everything that can refuse the batch is checked before the set is touched: a refused append leaves the set as it was
     {
         uint64_t units = 0;
+        std::vector<uint8_t> seen;                                                   // genomes that started a run earlier in THIS batch (one flag per genome: a batch may be a whole collection)
         for (uint32_t i = 0; i < nc; i++) {
             const uint32_t g = contig_genome[i];
             if (g >= ng) throw std::invalid_argument("contig_genome must be < n_genomes");
             if (i == 0 || contig_genome[i - 1] != g) {
                 if (gs->genome_contig_off[(size_t)g + 1]) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
-                for (uint32_t y = 0; y < i; y++) if (contig_genome[y] == g) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
+                if (seen.empty()) seen.assign(ng, 0);
+                if (seen[g]) throw std::invalid_argument("the contigs of a genome must arrive together, in one batch");
+                seen[g] = 1;
             }
             if (contig_len[i] > 0xFFFFFFF0ull) throw std::invalid_argument("contig longer than 2^32 bases");
             units += (contig_len[i] + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN / 32;

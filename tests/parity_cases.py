@@ -262,11 +262,12 @@ def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200), (
             if not kw:
                 # sets sketched with deferred seed tables: the triangle builds the tables beside its screen (skh_triangle); with and without the screen
                 # index made at sketch time; a second triangle on the same set finds the tables built.  Byte for byte the result above.
-                for screen_index in (True, False):
-                    ssd = ctx.sketch_records(genomes, sk.SketchParams(c=c, seeding_mode=mode), names, defer_tables=True, screen_index=screen_index)
+                # compact: SKH_SKETCH_COMPACT | SKH_SKETCH_DEFER_TABLES -- the build then also MOVES the list storage, which the pair descriptors made beside it point into
+                for screen_index, compact in ((True, False), (False, False), (True, True)):
+                    ssd = ctx.sketch_records(genomes, sk.SketchParams(c=c, seeding_mode=mode), names, defer_tables=True, screen_index=screen_index, compact=compact)
                     for again in range(2):
                         di, dj, dres, dn = ctx.triangle(ssd, mp)
-                        assert dn == nch and np.array_equal(di, i) and np.array_equal(dj, j) and dres.tobytes() == res.tobytes(), (mode, c, screen_index, again)
+                        assert dn == nch and np.array_equal(di, i) and np.array_equal(dj, j) and dres.tobytes() == res.tobytes(), (mode, c, screen_index, compact, again)
                     ssd.close()
 
 
@@ -432,6 +433,12 @@ def case_search_resident_db(ctx):
             for a, b, x in zip(q, r, res):
                 assert_result_close(x, want[(int(a), int(b))], (c, use_index, int(a), int(b)))
             assert all(res["ani"][i] >= res["ani"][i + 1] for i in range(len(q) - 1) if q[i] == q[i + 1])
+            # the oracle's own search loop (ora_search: what bench.py --workload search times as its cpu_baseline) = its pieces put together above
+            sq, sr, sres, nch = ora.search(orefs, oqs, 0.8, use_index, min_af=-1.0, model=model, threads=3)
+            assert sorted(zip(sq.tolist(), sr.tolist())) == sorted(want) and nch >= len(want)
+            for a, b, x in zip(sq, sr, sres):
+                o = want[(int(a), int(b))]
+                assert x["ani"] == np.float32(o.ani) and x["af_ref"] == np.float32(o.af_ref) and x["af_query"] == np.float32(o.af_query) and x["total_bases_covered"] == o.total_bases_covered
         q1, r1, res1 = sk.search(ctx, db, qs, n_max=2)
         assert max(np.bincount(q1)) <= 2 and not (q1 == 4).any()
         db.close()
