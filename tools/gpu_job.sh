@@ -1,0 +1,54 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root; through gpurun): tools/gpu_job.sh <tag> <section> [<section> ...]
+# One parameterised job instead of a script per GPU run.  Everything lands in gpurun_out/ under names that carry <tag>.
+# sections: suite | suite:<pytest -k expr> | smoke | bench | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | cli
+mkdir -p gpurun_out
+tag=$1; shift
+short() { python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+cb = d.get("cpu_baseline") or {}
+print(sys.argv[1], "ms/step", round(d["ms_per_step"], 3), {k: round(v, 2) for k, v in d["phase_ms_per_step"].items()}, "value", round(d["value"]),
+      {k: d["config"].get(k) for k in ("chained_pairs", "hits", "library_live_gb") if d["config"].get(k) is not None},
+      "cpu", round(cb["value"]) if cb.get("value") else None, cb.get("delta_vs_oracle"), "strong", (d.get("strong") or {}).get("ms_per_step"),
+      "steps", d.get("step_wall_ms_rank0"))
+PY
+}
+for sec in "$@"; do
+  echo "== $sec"; date
+  case $sec in
+    suite) timeout 2700 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/gpu_tests_$tag.log 2>&1; grep -v "^Hostname\|^Librccl\|^RCCL\|^HIP\|^ROCm" gpurun_out/gpu_tests_$tag.log | tail -12 ;;
+    suite:*) timeout 2700 python -m pytest tests -m gpu -x -q -k "${sec#suite:}" --durations=6 > gpurun_out/gpu_tests_$tag.log 2>&1; grep -v "^Hostname\|^Librccl\|^RCCL\|^HIP\|^ROCm" gpurun_out/gpu_tests_$tag.log | tail -25 ;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+    bench) timeout 1200 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || tail -5 gpurun_out/bench_$tag.err; short gpurun_out/bench_$tag.json
+           python -c "
+import json; d=json.load(open('gpurun_out/bench_$tag.json')); r=d['roofline']; print('roofline', r['frac'], r.get('frac_rocprof'), r.get('valu_frac'), r['ms_per_launch'], r['traffic'], (d.get('roofline_chain') or {}).get('traffic'), 'e2e', (d.get('e2e') or {}).get('wall_s'), (d.get('e2e') or {}).get('error'))" ;;
+    benchquick) timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/benchq_$tag.json 2> gpurun_out/benchq_$tag.err || tail -5 gpurun_out/benchq_$tag.err; short gpurun_out/benchq_$tag.json ;;
+    trace) tools/prof.sh $tag --no-e2e --strong-collection 0 > /dev/null 2>&1; head -40 gpurun_out/trace_$tag.txt | cut -c1-66,70-110 ;;
+    gaps) db=$(find /tmp/prof_$tag -name "*.db" | head -1); python tools/rocpd_gaps.py $db gpurun_out/gaps_$tag.txt | head -3; python tools/rocpd_timeline.py $db gpurun_out/timeline_$tag.txt > /dev/null ;;
+    pmc) tools/pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1; tail -2 gpurun_out/pmc_$tag.log | cut -c1-160 ;;
+    traffic) timeout 300 python bench.py --no-e2e --cpu-clades 0 --strong-collection 0 > gpurun_out/bench_pre_$tag.json 2>/dev/null
+             python tools/make_seed_traffic.py gpurun_out/pmc_$tag.json "profiles/r05_pmc.json (tools/pmc.sh, $tag)" gpurun_out/trace_$tag.md | tail -3
+             python tools/make_chain_traffic.py gpurun_out/pmc_$tag.json gpurun_out/bench_pre_$tag.json "profiles/r05_pmc.json (tools/pmc.sh, $tag)" | tail -2
+             cp profiles/seed_traffic.json gpurun_out/seed_traffic_$tag.json; cp profiles/chain_traffic.json gpurun_out/chain_traffic_$tag.json ;;
+    forcedist) timeout 300 python bench.py --force-dist --cpu-clades 0 --no-e2e --steps 20 > gpurun_out/${tag}_fd.json 2> gpurun_out/${tag}_fd.err; short gpurun_out/${tag}_fd.json ;;
+    config4) timeout 900 python bench.py --collection 10000 --steps 8 --warmup 4 > gpurun_out/${tag}_config4_n1.json 2> gpurun_out/${tag}_config4_n1.err || tail -5 gpurun_out/${tag}_config4_n1.err; short gpurun_out/${tag}_config4_n1.json ;;
+    config4dist) SKH_TUNE_DIST_KEY_RANGE_W1=1 timeout 900 python bench.py --force-dist --collection 10000 --no-e2e --cpu-clades 0 --steps 8 --warmup 4 > gpurun_out/${tag}_config4_dist_w1.json 2> gpurun_out/${tag}_config4_dist_w1.err || tail -5 gpurun_out/${tag}_config4_dist_w1.err
+                 short gpurun_out/${tag}_config4_dist_w1.json
+                 SKH_TUNE_DIST_KEY_RANGE_W1=1 SKH_TRACE=1 timeout 600 python bench.py --force-dist --no-e2e --cpu-clades 0 --collection 10000 --steps 1 --warmup 2 2>&1 >/dev/null | grep "skh trace\] dist" | tail -12 ;;
+    touch) for t in 0 1; do SKH_TUNE_ALLOC_TOUCH=$t timeout 900 python bench.py --collection 10000 --steps 7 --warmup 1 --cpu-clades 0 --no-e2e > gpurun_out/${tag}_touch$t.json 2> gpurun_out/${tag}_touch$t.err || tail -3 gpurun_out/${tag}_touch$t.err; short gpurun_out/${tag}_touch$t.json; done ;;
+    ranks8) timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --one-device --steps 3 --warmup 1 --cpu-sample-clades 5 > gpurun_out/${tag}_8ranks.json 2> gpurun_out/${tag}_8ranks.err || tail -5 gpurun_out/${tag}_8ranks.err
+            short gpurun_out/${tag}_8ranks.json ;;
+    search) timeout 1200 python bench.py --workload search --db-genomes 65000 --queries 1000 --steps 3 --warmup 1 > gpurun_out/${tag}_search_65k.json 2> gpurun_out/${tag}_search_65k.err && short gpurun_out/${tag}_search_65k.json || tail -5 gpurun_out/${tag}_search_65k.err
+            python -c "
+import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.dumps(d['roofline'])[:600]); print(json.dumps(d['cpu_baseline'])[:1500])" ;;
+    search113k) timeout 1200 python bench.py --workload search --db-genomes 113000 --queries 1000 --steps 3 --warmup 1 --cpu-queries 0 > gpurun_out/${tag}_search_113k.json 2> gpurun_out/${tag}_search_113k.err && short gpurun_out/${tag}_search_113k.json || tail -5 gpurun_out/${tag}_search_113k.err ;;
+    presets) for c in 30 70 200; do timeout 300 python bench.py --c $c --cpu-clades 0 --no-e2e --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c=$c', round(d['ms_per_step'],2))"; done
+             timeout 300 python bench.py --genomes-per-gpu 5000 --cpu-clades 0 --no-e2e --steps 4 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('n5000', round(d['ms_per_step'],2), round(d['value']/1e6,1))"
+             timeout 300 python bench.py --clade 1000 --cpu-clades 0 --no-e2e --steps 2 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dense', round(d['ms_per_step'],1), d['config']['chained_pairs'])" ;;
+    fuzz*) n=${sec#fuzz}; n=${n#:}; timeout 600 python tools/fuzz_parity.py ${n:-400} $RANDOM | tail -1 ;;
+    cli) timeout 900 python -m pytest tests/test_host_cpp.py -m gpu -x -q 2>&1 | tail -5 ;;
+    *) echo "unknown section $sec" ;;
+  esac
+done
+date
