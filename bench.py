@@ -820,7 +820,7 @@ def main():
     default_shape = not args.genomes_per_gpu and args.mean_len == 5_000_000 and CLADE == 20 and C == 125 and not args.force_dist
     if args.strong_collection is None:
         args.strong_collection = 10000 if default_shape else 0
-    if not strong and args.strong_collection > 0 and args.strong_collection % world == 0 and (args.strong_collection // world) % CLADE == 0:
+    if not strong and args.strong_collection > 0 and args.strong_collection % world == 0 and args.strong_collection % CLADE == 0:
         sn = args.strong_collection // world
         if sn == n_local and order == "shuffled":                      # (8 GPUs: the weak default IS config 4)
             s = out

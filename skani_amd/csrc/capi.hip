@@ -81,6 +81,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.build_slice_max = (uint32_t)env("SKH_TUNE_BUILD_SLICE_MAX", ctx->tune.build_slice_max);
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
+        ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
         ctx->tune.scan_one_max = env("SKH_TUNE_SCAN_ONE_MAX", ctx->tune.scan_one_max); ctx->tune.scan_two_max = env("SKH_TUNE_SCAN_TWO_MAX", ctx->tune.scan_two_max);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
         ctx->tune.dist_key_range_w1 = (uint32_t)env("SKH_TUNE_DIST_KEY_RANGE_W1", 0);
@@ -97,7 +98,7 @@ void skh_ctx_destroy(skh_ctx* ctx) {
     if (!ctx) return;
     dev_drain(ctx->device, ctx->stream, ctx->stream2);
     ctx->arena.release_all();
-    ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel(); ctx->scan_ticket.release();
+    ctx->model_c125 = GbdtModel(); ctx->model_c200 = GbdtModel(); ctx->scan_ticket.release(); ctx->part_cnt.release();
     dcache_trim();                                   // hand the allocator's idle blocks back to the driver
     dev_close(ctx->stream, ctx->stream2);
     delete ctx;

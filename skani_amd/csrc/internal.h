@@ -58,6 +58,7 @@ struct skh_tunables {
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
+    uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
     uint32_t build_slice_max = 0;                       // table slices per genome the slice-list kernel handles (0 = 8192; tests use 1: larger genomes' slices re-scan)
@@ -86,6 +87,9 @@ struct skh_ctx {
     skh::PinRing ring;                                   // pinned staging of this context's small uploads (dev.h h2d); entry points bind it to their thread
     skh::DBuf<uint32_t> scan_ticket;                     // two counters (one per stream), zero between scans (scan.hip)
     bool screen_planes_checked = false;                  // the per-XCD count planes of the triangle screen passed their self-test (screen.hip)
+    // the key-range screen's count matrix of a large collection (one plane, N x N words) stays with the context, all zero between calls: the kernel that emits the
+    // non-zero cells puts them back to zero, so no call zeroes 4 N^2 bytes (screen.hip screen_partial_cells_dev); part_cnt_clean is false while a call is in between
+    skh::DBuf<uint32_t> part_cnt; bool part_cnt_clean = false;
 };
 
 namespace skh { struct Transport; }

@@ -54,8 +54,11 @@ __global__ __launch_bounds__(256) void screen_planes_selftest_kernel(uint32_t* c
     for (uint32_t r = 0; r < 4; r++) count_local(&plane[(threadIdx.x + r) & 63u]);
 }
 
+// FIRST (one plane only): the increment that finds a cell at zero also counts the cell in its row's number of non-zero cells (row_nz): the emission of the cells then
+// needs no counting pass over the matrix
+template <bool FIRST>
 __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
-                                                               uint32_t* cnt, uint32_t n_planes, uint64_t plane) {
+                                                               uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const uint64_t key = keys[e];
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
         const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
         if (lo < row0 || lo >= row0 + rows) continue;
         uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
-        if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
+        if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u); }
+        else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
     }
 }
 
@@ -236,7 +240,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
-            if (tri) SKH_LAUNCH(screen_count_tri_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane);
+            if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
             else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
         }
@@ -300,6 +304,100 @@ __global__ __launch_bounds__(256) void screen_add_cells_kernel(const uint64_t* b
     uint32_t* cell = &cnt[(uint64_t)i * ng + j];
     const uint32_t add = (uint32_t)c & CELL_COUNT_MAX, old = atomicAdd(cell, add);
     if (old + add < old) atomicMax(cell, 0xFFFFFFFFu);                                // (saturate instead of wrapping)
+}
+
+// ---- the gathered cells WITHOUT the dense matrix (round 5).  Every part's cells come out of threshold_rows in (i, j) order, so row i of the count matrix is a stretch of
+// every block: a workgroup per row finds the stretches (one binary search pair per block), adds them up in an LDS row of N counters and puts that row through the
+// rule -- the same two passes as screen_threshold_kernel (count, then write in column order), reading LDS where that one reads N x N words of HBM.  What the dense form
+// cost at 10,000 genomes: 400 MB zeroed, 400 MB read twice -- the same on every rank, whatever the world.
+__global__ __launch_bounds__(256) void screen_cells_check_kernel(const uint64_t* blocks, uint64_t block_words, uint32_t ng, uint32_t* flags /* [0] a genome beyond the set, [1] a block out of row order */) {
+    const uint64_t* blk = blocks + (uint64_t)blockIdx.y * block_words;
+    const uint64_t n = blk[0];
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || e + 2 >= block_words) return;
+    const uint64_t c = blk[2 + e]; const uint32_t i = (uint32_t)(c >> 43), j = (uint32_t)(c >> 22) & 0x1FFFFFu;
+    if (i >= ng || j >= ng) atomicOr(&flags[0], 1u);
+    if (e + 1 < n && e + 3 < block_words && (uint32_t)(blk[3 + e] >> 43) < i) atomicOr(&flags[1], 1u);
+}
+__global__ __launch_bounds__(256) void screen_rows_from_cells_kernel(const uint64_t* blocks, uint64_t block_words, uint32_t n_blocks, uint32_t ng, ScreenRule sr, const uint64_t* mk_off, int pass,
+                                                                     uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second) {
+    SKH_DYN_SMEM(smem);
+    uint32_t* cnt = (uint32_t*)smem;                                                  // ng counters: this row of the count matrix
+    __shared__ uint32_t seg_lo[256], seg_hi[256];
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t running, any;
+    const uint32_t row = blockIdx.x;
+    if (threadIdx.x == 0) { running = 0; any = 0; }
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) {                   // this row's stretch of block b: [first cell with i >= row, first with i > row)
+        const uint64_t* blk = blocks + (uint64_t)b * block_words;
+        const uint32_t n = (uint32_t)blk[0];
+        auto first_ge = [&](uint32_t v) { uint32_t lo = 0, hi = n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(blk[2 + mid] >> 43) < v) lo = mid + 1; else hi = mid; } return lo; };
+        const uint32_t a = first_ge(row), z = first_ge(row + 1);
+        seg_lo[b] = a; seg_hi[b] = z;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) if (seg_hi[b] > seg_lo[b]) any = 1;   // (benign race: every writer stores 1)
+    __syncthreads();
+    const uint64_t m_row = mk_off[row + 1] - mk_off[row];
+    const bool all_pass = sr.rule == SKH_SCREEN_REFS && m_row < SCREEN_MIN_KMERS && sr.rescue_small;   // screen.rs:158-160: every later genome passes, counted or not
+    if (!any && !all_pass) { if (!pass && threadIdx.x == 0) row_cnt[row] = 0; return; }               // (a row nobody shares a marker with: most rows of a collection of unrelated clades)
+    for (uint32_t c = threadIdx.x; c < ng; c += blockDim.x) cnt[c] = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const uint64_t* blk = blocks + (uint64_t)b * block_words + 2;
+        for (uint32_t e = seg_lo[b] + threadIdx.x; e < seg_hi[b]; e += blockDim.x) {
+            const uint64_t c = blk[e]; const uint32_t j = (uint32_t)(c >> 22) & 0x1FFFFFu;
+            if (j < ng) atomicAdd(&cnt[j], (uint32_t)c & CELL_COUNT_MAX);              // (at most 255 parts x 2^22: no wrap)
+        }
+    }
+    __syncthreads();
+    const uint32_t base_out = pass ? row_off[row] : 0;
+    for (uint32_t c0 = (row + 1) & ~255u; c0 < ng; c0 += blockDim.x) {                // triangle.rs:90: columns beyond the row only
+        const uint32_t col = c0 + threadIdx.x;
+        const bool ok = col < ng && cell_passes(sr, cnt[col < ng ? col : 0], m_row, mk_off[(col < ng ? col : 0) + 1] - mk_off[col < ng ? col : 0], row, col);
+        const uint32_t incl = wave_incl_scan(ok ? 1u : 0u);
+        const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 63) lds[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { const uint32_t t = lds[i]; if (i < w) before += t; tot += t; }
+        const uint32_t run = running;
+        if (pass && ok) { const uint32_t o = base_out + run + before + incl - 1; out_first[o] = row; out_second[o] = col; }
+        __syncthreads();
+        if (threadIdx.x == 0) running = run + tot;
+        __syncthreads();
+    }
+    if (!pass && threadIdx.x == 0) row_cnt[row] = running;
+}
+
+// one workgroup per row of a single-plane count matrix: the row's non-zero cells (columns beyond the row) go out as packed words in column order at row_off[row] --
+// the numbers of non-zero cells per row are known from the counting (row_nz) -- and every cell read is put back to ZERO: the matrix leaves the call as it entered it
+__global__ __launch_bounds__(256) void screen_emit_cells_kernel(uint32_t* cnt, uint32_t ncols, const uint32_t* row_nz, const uint32_t* row_off, uint64_t* out) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t running;
+    const uint32_t row = blockIdx.x;
+    if (row_nz[row] == 0) return;
+    uint32_t* crow = cnt + (uint64_t)row * ncols;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const uint32_t base_out = row_off[row];
+    for (uint32_t c0 = (row + 1) & ~255u; c0 < ncols; c0 += blockDim.x) {
+        const uint32_t col = c0 + threadIdx.x;
+        const uint32_t count = (col < ncols && col > row) ? crow[col] : 0u;
+        const bool ok = count != 0;
+        if (ok) crow[col] = 0;
+        const uint32_t incl = wave_incl_scan(ok ? 1u : 0u);
+        const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 63) lds[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { const uint32_t t = lds[i]; if (i < w) before += t; tot += t; }
+        const uint32_t run = running;
+        if (ok) out[base_out + run + before + incl - 1] = ((uint64_t)row << 43) | ((uint64_t)col << 22) | (count < CELL_COUNT_MAX ? count : CELL_COUNT_MAX);
+        __syncthreads();
+        if (threadIdx.x == 0) running = run + tot;
+        __syncthreads();
+    }
 }
 
 // rows [0, rows) of a dense count matrix through the rule: the passing (row, col[, count]) cells in (row, col) order, on the host
@@ -371,9 +469,32 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
+    if (n_planes == 1) {
+        // a large collection (at 10,000 genomes the matrix is 400 MB): the context's own matrix, zero between calls; counting notes every row's number of non-zero cells,
+        // emitting puts the cells back to zero.  (Before: the matrix zeroed, counted, then read twice -- 1.2 GB of traffic for ~160,000 cells on every rank.)
+        if (ctx->part_cnt.n < plane || !ctx->part_cnt_clean) {
+            if (ctx->part_cnt.n < plane) ctx->part_cnt.alloc(plane);
+            dzero(ctx->part_cnt.p, ctx->part_cnt.n * 4, ctx->stream);
+        }
+        ctx->part_cnt_clean = false;
+        uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
+        dzero(row_nz, (size_t)N * 4, ctx->stream);
+        SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
+        check_launch("screen_count(part)");
+        exclusive_scan_u32(ctx, row_nz, N, row_off);
+        uint32_t total = 0;
+        d2h(&total, row_off + N, 4, ctx->stream);
+        uint64_t* packed = ctx->arena.get<uint64_t>(total ? total : 1);
+        SKH_LAUNCH(screen_emit_cells_kernel, N, 256, 0, ctx->stream, ctx->part_cnt.p, N, (const uint32_t*)row_nz, (const uint32_t*)row_off, packed);
+        check_launch("screen_emit_cells");
+        dsync(ctx->stream);
+        ctx->part_cnt_clean = true;
+        *d_cells = total ? packed : nullptr; *n_cells = total;
+        return;
+    }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
-    SKH_LAUNCH(screen_count_tri_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane);
+    SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
     threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, d_cells, n_cells);
@@ -399,6 +520,38 @@ void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_from_cells: the count matrix does not fit");
     if (max_cells + 2 > block_words || max_cells > 0x7FFFFFFFull * 256) throw Error("screen_from_cells: bad block layout");
+    const ScreenRule sr{powi21(identity), SKH_SCREEN_REFS, rescue_small, 1};
+    // The sparse form: blocks in row order (what screen_partial_cells_dev makes), a row of counters that fits the LDS, at most 256 blocks.  Anything else -- cells a
+    // caller put together some other way, a collection beyond ~40,000 genomes -- takes the dense matrix below.
+    const size_t row_bytes = (size_t)N * 4;
+    if (!ctx->tune.screen_cells_dense && n_blocks <= 256 && row_bytes <= ((size_t)150 << 10)) {
+        uint32_t* flags = ctx->arena.get<uint32_t>(2); dzero(flags, 8, ctx->stream);
+        if (max_cells && n_blocks) {
+            SKH_LAUNCH(screen_cells_check_kernel, dim3((unsigned)((max_cells + 255) / 256), n_blocks), 256, 0, ctx->stream, d_blocks, block_words, N, flags);
+            check_launch("screen_cells_check");
+        }
+        uint32_t h_flags[2] = {0, 0}; d2h(h_flags, flags, 8, ctx->stream);
+        if (h_flags[0]) throw std::invalid_argument("screen_from_cells: a cell names a genome beyond the set");
+        if (!h_flags[1]) {
+            uint32_t* row_cnt = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
+            SKH_LAUNCH(screen_rows_from_cells_kernel, N, 256, row_bytes, ctx->stream, d_blocks, block_words, n_blocks, N, sr, (const uint64_t*)S->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr);
+            check_launch("screen_rows_from_cells0");
+            exclusive_scan_u32(ctx, row_cnt, N, row_off);
+            uint32_t total = 0;
+            d2h(&total, row_off + N, 4, ctx->stream);
+            if (total) {
+                uint32_t* of = ctx->arena.get<uint32_t>(2 * (size_t)total); uint32_t* os = of + total;
+                SKH_LAUNCH(screen_rows_from_cells_kernel, N, 256, row_bytes, ctx->stream, d_blocks, block_words, n_blocks, N, sr, (const uint64_t*)S->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os);
+                check_launch("screen_rows_from_cells1");
+                std::vector<uint32_t> both(2 * (size_t)total);
+                d2h(both.data(), of, both.size() * 4, ctx->stream);
+                first.assign(both.begin(), both.begin() + total); second.assign(both.begin() + total, both.end());
+            }
+            dsync(ctx->stream);
+            return;
+        }
+    }
     const uint64_t plane = (uint64_t)N * N;
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane);
     dzero(cnt, plane * 4, ctx->stream);
@@ -409,7 +562,6 @@ void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t
         uint32_t h_bad = 0; d2h(&h_bad, bad, 4, ctx->stream);
         if (h_bad) throw std::invalid_argument("screen_from_cells: a cell names a genome beyond the set");
     }
-    const ScreenRule sr{powi21(identity), SKH_SCREEN_REFS, rescue_small, 1};
     threshold_rows(ctx, cnt, 1, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, first, second, nullptr);
     dsync(ctx->stream);
 }

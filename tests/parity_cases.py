@@ -240,6 +240,10 @@ def case_triangle_synthetic(ctx, params=((1, 125), (0, 30), (1, 70), (1, 200), (
             a3, b3 = ctx.screen_from_cells(ss, cells, 0.0, True)
             ci, cj, cc = ctx.unpack_cells(cells)
             assert list(zip(a3.tolist(), b3.tolist())) == sorted(exp) and (ci < cj).all() and (cc > 0).all(), (mode, c, n_parts)
+            # cells in row order are added up row by row in LDS (what the distributed triangle's gathered blocks get); the concatenation of several parts is not in row
+            # order and takes the dense matrix: the same list either way (a cell of a pair appears once per part that saw one of its markers)
+            a4, b4 = ctx.screen_from_cells(ss, np.sort(cells), 0.0, True)
+            assert np.array_equal(a4, a3) and np.array_equal(b4, b3), (mode, c, n_parts)
             if n_parts == 3:                                                          # a cell that names a genome beyond the set is refused, not added somewhere
                 bad = np.append(cells, np.uint64((len(osk) << 43) | (1 << 22) | 5))
                 try:
@@ -294,8 +298,9 @@ def case_screen_rules(ctx):
             assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri")
             if not key_range_fits(ctx, refs): continue
             cells = np.concatenate([ctx.screen_part(refs, part, 4) for part in range(4)])   # the triangle cut by key range (the small genome's rescue: a row that passes without a count)
-            a, b = ctx.screen_from_cells(refs, cells, 0.8, rescue)
-            assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri by key range")
+            for form in (cells, np.sort(cells)):                                      # as concatenated (dense matrix) / in row order (row by row in LDS)
+                a, b = ctx.screen_from_cells(refs, form, 0.8, rescue)
+                assert list(zip(a.tolist(), b.tolist())) == sorted(exp), (m, rescue, "tri by key range")
 
 
 def case_screen_marker_prefix_groups(ctx):

@@ -64,6 +64,7 @@ def _worker(rank, world, port, q, case):
     try:
         if _wide_span_of(case, rank) is not None: os.environ["SKH_TUNE_WIDE_SPAN"] = _wide_span_of(case, rank)
         to_root = case.endswith("_root"); case = case[:-5] if to_root else case
+        if case == "interleave8": os.environ["SKH_TUNE_SCREEN_CELLS_DENSE"] = "1"   # the gathered cells through the dense count matrix (every other case: row by row in LDS)
         if case == "uneven": os.environ["SKH_TUNE_SCREEN_CELLS"] = "40"      # a count matrix of 12 x 12 cells does not fit: the screen is cut by rows (the form of very large collections)
         ctx = sk.Context(0, lib=emu_lib())
         genomes, held = _case(case)
