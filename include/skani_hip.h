@@ -270,6 +270,7 @@ typedef struct {
     uint64_t n_pairs_home;                               /* pairs of this rank with both sketches its own: chained while the other sketches travel */
     uint64_t exchange_async_us, exchange_wait_us;        /* the sketch exchange from start to last byte, and the part of it the chaining had to wait for */
     uint64_t screen_by_key_range;                        /* 1: every rank screened a W-th of the markers' key range for all cells (collections whose count matrix fits); 0: its rows */
+    uint64_t marker_bytes_received;                      /* marker sets that reached this rank from the others: its own part of the key range (key-range form) or everything (row form) */
 } skh_dist_stats;
 /* Collective: every rank of the communicator calls it with its own local set.  Results (global indices, sorted by (i, j), ani > 0.1 as
  * triangle.rs:99) are returned on EVERY rank; n_chained = candidate pairs chained over all ranks.  stats may be NULL. */

@@ -32,7 +32,7 @@ class DistStats(C.Structure):
     """skh_dist_stats"""
     _fields_ = [(n, C.c_uint64) for n in ("n_genomes_total", "n_candidate_pairs_total", "n_pairs_mine", "n_units_mine", "n_units_total", "cost_mine", "cost_total",
                                           "n_genomes_received", "bytes_received", "bytes_sent", "screen_row_begin", "screen_row_end",
-                                          "n_pairs_home", "exchange_async_us", "exchange_wait_us", "screen_by_key_range")]
+                                          "n_pairs_home", "exchange_async_us", "exchange_wait_us", "screen_by_key_range", "marker_bytes_received")]
 
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)

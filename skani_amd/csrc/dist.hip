@@ -270,25 +270,17 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         for (int r = 0; r < W; r++) if (all[r]) stop_together(phase, r);
     };
     // ---- 1. who holds what, in ONE all-gather: per rank a head (genomes, seed positions, markers, contigs, c, k, marker_c, seeding mode, status), its per-genome
-    // table and its contig lengths, in a block laid out by the capacities of the communicator's previous call (as gather_records does)
+    // table and its contig lengths, in a block laid out by the capacities of the communicator's previous call (as gather_records does).  Round 5: the table also says,
+    // per genome, how many of its markers fall into each of the W parts of the screen's key range (screen.hip part bounds) -- what the marker exchange of step 2 and
+    // the marker-only sets on every rank are sized by.
     const uint32_t nL = L->n_genomes;
-    constexpr uint32_t GF = 5, HDR = 10;                                            // per genome: seed positions, markers, contigs, total length, rank
+    const bool by_parts = W > 1 || ctx->tune.dist_key_range_w1;                       // (a world of one has nothing to cut: the row form, which is skh_triangle's own screen)
+    const uint32_t PW = by_parts ? ((uint32_t)W + 1) / 2 : 0;                        // 64-bit words per genome that hold its W part counts (32 bits each)
+    const uint32_t GF = 5 + PW; constexpr uint32_t HDR = 10;                        // per genome: seed positions, markers, contigs, total length, rank[, part counts]
     const uint64_t mine[8] = {nL, L->pos_off[nL], L->mk_off[nL], L->ctg_off[nL], L->params.c, L->params.k, L->params.marker_c, (uint64_t)L->params.seeding_mode | (L->wide ? 256u : 0u)};
-    // this rank's marker set, padded, in the staging buffers of the marker all-gather further down: sized by the remembered capacity, so that how that went
-    // can travel with the table
-    uint64_t pad = 0; uint64_t *d_mk_send = nullptr, *d_mk_recv = nullptr;
-    auto prepare_markers = [&](uint64_t p) {
-        pad = std::max<uint64_t>(p, 1);
-        local([&] {                                                                 // (local phase 1)
-            d_mk_send = ctx->arena.get<uint64_t>(pad); d_mk_recv = ctx->arena.get<uint64_t>(pad * W);
-            if (mine[2]) d2d(d_mk_send, L->markers.p, mine[2] * 8, ctx->stream);
-            if (pad > mine[2]) dzero(d_mk_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
-            dsync(ctx->stream);
-        });
-    };
+    std::vector<uint64_t> part_lo; std::vector<uint32_t> part_n;                     // [g * W + r]: the stretch of local genome g's (sorted) marker set that lies in part r
+    local([&] { if (by_parts && nL) screen_marker_parts(ctx, L, (uint32_t)W, part_lo, part_n); });   // (local phase 1; its status rides on the table gather)
     ex_begin();
-    const bool markers_early = T.cap_m >= mine[2] && T.cap_m > 0;
-    if (markers_early) prepare_markers(T.cap_m);
     std::vector<uint64_t> cnt((size_t)W * 8), tab_all; size_t tab_words = 0;        // tab_all: the gathered blocks, tab_words each
     uint64_t max_n = 0, max_m = 0, max_c = 0;
     for (int round = 0;; round++) {
@@ -296,12 +288,13 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         tab_words = HDR + cn * GF + (cc + 1) / 2;
         std::vector<uint64_t> send(tab_words, 0); tab_all.assign((size_t)W * tab_words, 0);
         memcpy(send.data(), mine, sizeof(mine));
-        send[8] = (markers_early && !local_err.empty()) ? 1 : 0;
+        send[8] = local_err.empty() ? 0 : 1;
         send[9] = ctx->tune.screen_cells ^ ((uint64_t)ctx->tune.dist_key_range_w1 << 63);   // what decides between the key-range and the row form of the screen (SKH_TUNE_*): must agree
         if (nL <= cn && mine[3] <= cc) {
             for (uint32_t g = 0; g < nL; g++) {
                 uint64_t* f = send.data() + HDR + (size_t)g * GF;
                 f[0] = L->pos_off[g + 1] - L->pos_off[g]; f[1] = L->mk_off[g + 1] - L->mk_off[g]; f[2] = L->ctg_off[g + 1] - L->ctg_off[g]; f[3] = L->total_len[g]; f[4] = L->rank[g];
+                if (PW && !part_n.empty()) memcpy(f + 5, part_n.data() + (size_t)g * W, (size_t)W * 4);
             }
             if (!L->ctg_len.empty()) memcpy(send.data() + HDR + cn * GF, L->ctg_len.data(), L->ctg_len.size() * 4);
         }
@@ -316,7 +309,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
                 throw std::invalid_argument("the ranks run with different screen budgets (SKH_TUNE_SCREEN_CELLS / SKH_TUNE_DIST_KEY_RANGE_W1): they would take different collective sequences");
             max_n = std::max(max_n, h[0]); max_m = std::max(max_m, h[2]); max_c = std::max(max_c, h[3]);
         }
-        for (int r = 0; r < W; r++) if (tab_all[(size_t)r * tab_words + 8]) stop_together("marker buffers", r);
+        for (int r = 0; r < W; r++) if (tab_all[(size_t)r * tab_words + 8]) stop_together("marker sets", r);
         if (max_n <= cn && max_c <= cc) break;
         if (round) throw Error("distributed triangle: the second table round did not fit (ranks disagree on the sizes)");
         T.cap_n = max_n; T.cap_c = max_c;
@@ -331,13 +324,9 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     if (N64 >= (1ull << 21)) throw std::invalid_argument("more than 2M genomes in one distributed triangle");
     const uint32_t N = (uint32_t)N64;
     st.n_genomes_total = N;
-    if (T.cap_m == 0 || max_m > T.cap_m) {                                          // first call of the communicator, or a larger marker set than it has seen (the same test on every rank): buffers now, agreement of its own
-        prepare_markers(max_m);
-        agree("marker buffers");
-    }
-    T.cap_m = std::max(T.cap_m, max_m);
     std::vector<int> rank_of(N); std::vector<uint64_t> g_npos(N), g_nmk(N), g_nctg(N), g_len(N), g_rank(N);
     std::vector<uint32_t> cl_all; std::vector<uint64_t> g_ctg0(N);                  // contig lengths of all genomes, global genome order; g_ctg0: a genome's first
+    std::vector<uint64_t> g_mine(N, 0);                                              // markers of genome g that fall into THIS rank's part of the key range
     {
         uint32_t g = 0;
         for (int r = 0; r < W; r++) {
@@ -347,24 +336,63 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
             for (uint64_t x = 0; x < cnt[r * 8]; x++, g++) {
                 const uint64_t* f = blk + HDR + x * GF;
                 rank_of[g] = r; g_npos[g] = f[0]; g_nmk[g] = f[1]; g_nctg[g] = f[2]; g_len[g] = f[3]; g_rank[g] = f[4]; g_ctg0[g] = cl_all.size();
+                if (PW) g_mine[g] = ((const uint32_t*)(f + 5))[me];
                 if (c0 + f[2] > cnt[r * 8 + 3]) throw Error("distributed triangle: a rank's contig table is inconsistent");
                 cl_all.insert(cl_all.end(), cl + c0, cl + c0 + f[2]); c0 += f[2];
             }
         }
     }
-    // ---- 2. all marker sets, on every rank (device memory), as a markers-only sketch set in global genome order
+    // ---- 2. the marker sets.  S: every genome's marker COUNT (what the rule's thresholds and the chaining's role decision take), and -- the row form only -- the sets
+    // themselves.  The key-range form (the usual one) never needs a marker outside a rank's own part of the key range: ONE all-to-all moves, from every rank to every
+    // rank, the stretches of its genomes' sorted marker sets that lie in the receiver's part -- a W-th of what the all-gather of rounds 3-4 moved to every rank
+    // (config 4: 400 MB to each of eight ranks) -- straight into Sp, the marker-only set this rank screens.
+    const bool key_range = by_parts && screen_parts_fit(ctx, N);
     skh_sketch_set S; S.ctx = ctx; S.params = L->params; S.n_genomes = N;
     S.mk_off.assign(N + 1, 0); for (uint32_t g = 0; g < N; g++) S.mk_off[g + 1] = S.mk_off[g] + g_nmk[g];
+    skh_sketch_set Sp; Sp.ctx = ctx; Sp.params = L->params; Sp.n_genomes = N;
     const uint64_t MT = S.mk_off[N];
-    {
-        T.all_gather(ctx, d_mk_send, d_mk_recv, pad * 8, true);
-        local([&] {                                                                 // (local phase 2; agreed on with the candidate counts)
+    if (key_range) {
+        Sp.mk_off.assign(N + 1, 0); for (uint32_t g = 0; g < N; g++) Sp.mk_off[g + 1] = Sp.mk_off[g] + g_mine[g];
+        std::vector<uint64_t> m_sc(W, 0), m_so(W, 0), m_rc(W, 0), m_ro(W, 0); uint64_t sw = 0;
+        std::vector<uint64_t> seg;                                                  // 32-bit words: (source, destination, length) of every (genome, part) stretch
+        for (int r = 0; r < W; r++) {
+            m_so[r] = sw * 8;
+            for (uint32_t g = 0; g < nL && !part_n.empty(); g++) {
+                const uint64_t n = part_n[(size_t)g * W + r];
+                if (n) { seg.insert(seg.end(), {part_lo[(size_t)g * W + r] * 2, sw * 2, n * 2}); sw += n; }
+            }
+            m_sc[r] = sw * 8 - m_so[r];
+            m_ro[r] = Sp.mk_off[base[r]] * 8; m_rc[r] = (Sp.mk_off[base[r + 1]] - Sp.mk_off[base[r]]) * 8;
+        }
+        uint64_t* d_send = nullptr;
+        local([&] {                                                                 // (local phase 2; agreed on in front of the exchange)
+            S.markers.alloc(1); S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
+            Sp.markers.alloc(Sp.mk_off[N] ? Sp.mk_off[N] : 1); Sp.d_mk_off.alloc(N + 1); h2d(Sp.d_mk_off.p, Sp.mk_off.data(), (N + 1) * 8, ctx->stream);
+            d_send = ctx->arena.get<uint64_t>(sw ? sw : 1);
+            copy_segments(ctx, (const uint32_t*)L->markers.p, (uint32_t*)d_send, seg);
+            dsync(ctx->stream);
+        });
+        agree("marker sets");
+        T.all_to_all_v(ctx, d_send, m_sc.data(), m_so.data(), Sp.markers.p, m_rc.data(), m_ro.data(), true);
+        for (int r = 0; r < W; r++) if (r != me) st.marker_bytes_received += m_rc[r];
+    } else {
+        // the row form (a collection whose N x N count matrix is beyond the screen's budget; a world of one): every rank needs every marker
+        uint64_t pad = std::max<uint64_t>(max_m, 1); uint64_t *d_mk_send = nullptr, *d_mk_recv = nullptr;
+        local([&] {                                                                 // (local phase 2)
+            d_mk_send = ctx->arena.get<uint64_t>(pad); d_mk_recv = ctx->arena.get<uint64_t>(pad * W);
+            if (mine[2]) d2d(d_mk_send, L->markers.p, mine[2] * 8, ctx->stream);
+            if (pad > mine[2]) dzero(d_mk_send + mine[2], (pad - mine[2]) * 8, ctx->stream);
             S.markers.alloc(MT ? MT : 1);
-            for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_mk_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
             S.d_mk_off.alloc(N + 1); h2d(S.d_mk_off.p, S.mk_off.data(), (N + 1) * 8, ctx->stream);
             dsync(ctx->stream);
         });
+        agree("marker sets");
+        T.all_gather(ctx, d_mk_send, d_mk_recv, pad * 8, true);
+        for (int r = 0; r < W; r++) if (r != me) st.marker_bytes_received += cnt[r * 8 + 2] * 8;
+        for (int r = 0; r < W; r++) if (cnt[r * 8 + 2]) d2d(S.markers.p + S.mk_off[base[r]], d_mk_recv + (uint64_t)r * pad, cnt[r * 8 + 2] * 8, ctx->stream);
+        dsync(ctx->stream);
     }
+    T.cap_m = std::max(T.cap_m, max_m);
     ex_end();
     ctx->arena.reset();
     tr.mark("dist: tables + markers gathered");
@@ -381,7 +409,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
     }
     st.screen_row_begin = rb[me]; st.screen_row_end = rb[me + 1];
     std::vector<uint32_t> pi, pj;
-    if ((W > 1 || ctx->tune.dist_key_range_w1) && screen_parts_fit(ctx, N)) {                                        // (a world of one has nothing to cut: the row form, which is skh_triangle's own screen)
+    if (key_range) {
         // ---- 3. screen by KEY RANGE (round 4; screen.hip): this rank sorts and walks the incidences of a W-th of the markers' leading 16 bases and gets partial counts
         // for all cells; the non-zero cells are gathered -- with the status of the phases so far -- and every rank adds them up and applies the rule to all rows
         // itself: the same candidate list everywhere, no list to gather.  (Cut by rows, every rank sorted and walked ALL incidences: the screen did not shrink with W.)
@@ -391,7 +419,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         uint64_t* d_mine = nullptr; uint64_t n_mine = 0;
         local([&] {                                                                 // (local phase 3)
             Stopwatch sw(ctx, &ctx->timings.screen_ms);
-            screen_partial_cells_dev(ctx, &S, (uint32_t)me, (uint32_t)W, &d_mine, &n_mine);
+            screen_partial_cells_dev(ctx, &Sp, 0u, 1u, &d_mine, &n_mine);             // (Sp holds this rank's part of the key range and nothing else)
         });
         tr.mark("dist: screen, my key range");
         ex_begin();

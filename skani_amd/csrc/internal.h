@@ -284,6 +284,8 @@ void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* ce
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second);
 // the device forms (the distributed triangle: the cells never visit the host): cells left in the arena; cells read from blocks [count, -, cells...] of block_words words
 void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells);
+uint64_t screen_part_bound(uint32_t r, uint32_t n_parts);
+void screen_marker_parts(skh_ctx* ctx, const skh_sketch_set* S, uint32_t n_parts, std::vector<uint64_t>& lo, std::vector<uint32_t>& cnt);
 void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* d_blocks, uint32_t n_blocks, uint64_t block_words, uint64_t max_cells, double identity, int rescue_small,
                            std::vector<uint32_t>& first, std::vector<uint32_t>& second);
 

@@ -428,6 +428,36 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
     first.insert(first.end(), both.begin(), both.begin() + total); second.insert(second.end(), both.begin() + total, both.end());
 }
 
+// the smallest marker of part r of n_parts (0 for r = 0 and for r >= n_parts: no bound)
+uint64_t screen_part_bound(uint32_t r, uint32_t n_parts) {
+    if (r == 0 || r >= n_parts) return 0ull;
+    const double x = 1.0 - std::sqrt(1.0 - (double)r / (double)n_parts);
+    return std::max<uint64_t>((uint64_t)(x * 4294967296.0), 1ull) << 10;
+}
+// per genome of S and part r of n_parts: where the genome's markers of that part begin (an index into S->markers) and how many they are -- the stretches a rank of the
+// distributed triangle sends to the rank that screens part r (dist.hip)
+__global__ __launch_bounds__(256) void screen_all_part_ranges_kernel(const uint64_t* markers, const uint64_t* mk_off, uint32_t ng, const uint64_t* bounds /* n_parts + 1; 0 = none */, uint32_t n_parts,
+                                                                     uint64_t* lo_out, uint32_t* cnt_out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (g >= ng) return;
+    const uint64_t a = mk_off[g], b = mk_off[g + 1];
+    auto first_ge = [&](uint64_t v) { uint64_t lo = a, hi = b; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (markers[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
+    const uint64_t x = first_ge(bounds[r]), y = bounds[r + 1] ? first_ge(bounds[r + 1]) : b;
+    lo_out[(uint64_t)g * n_parts + r] = x; cnt_out[(uint64_t)g * n_parts + r] = (uint32_t)(y - x);
+}
+void screen_marker_parts(skh_ctx* ctx, const skh_sketch_set* S, uint32_t n_parts, std::vector<uint64_t>& lo, std::vector<uint32_t>& cnt) {
+    const uint32_t N = S->n_genomes;
+    lo.assign((size_t)N * n_parts, 0); cnt.assign((size_t)N * n_parts, 0);
+    if (!N || !S->mk_off[N]) return;
+    std::vector<uint64_t> bounds(n_parts + 1);
+    for (uint32_t r = 0; r <= n_parts; r++) bounds[r] = screen_part_bound(r, n_parts);
+    uint64_t* d_b = ctx->arena.get<uint64_t>(n_parts + 1); uint64_t* d_lo = ctx->arena.get<uint64_t>(lo.size()); uint32_t* d_cnt = ctx->arena.get<uint32_t>(cnt.size());
+    h2d(d_b, bounds.data(), bounds.size() * 8, ctx->stream);
+    SKH_LAUNCH(screen_all_part_ranges_kernel, dim3((N + 255) / 256, n_parts), 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)S->d_mk_off.p, N, (const uint64_t*)d_b, n_parts, d_lo, d_cnt);
+    check_launch("screen_all_part_ranges");
+    d2h(lo.data(), d_lo, lo.size() * 8, ctx->stream); d2h(cnt.data(), d_cnt, cnt.size() * 4, ctx->stream);
+}
+
 bool screen_parts_fit(const skh_ctx* ctx, uint32_t n_genomes) { return n_genomes && (uint64_t)n_genomes * n_genomes <= ctx->tune.screen_cells && n_genomes <= ID_MASK; }
 
 // the non-zero cells of the triangle's count matrix over the markers whose leading 16 bases fall into part `part` of `n_parts`
@@ -448,12 +478,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     // the smallest marker of part r (its sorted field is marker >> 10, 32 bits).  A marker is the smaller of a 21-mer and its reverse complement, so a fraction 1 - (1 - x)^2 of
     // them lies below x of the range: the parts are cut at the quantiles of that distribution, not at equal widths (two equal halves would hold 75 % and 25 % of the keys).
     // Every rank computes the same bounds: IEEE division and square root are exactly rounded.
-    auto bound = [&](uint32_t r) -> uint64_t {
-        if (r == 0) return 0ull;
-        if (r >= n_parts) return 0ull;                                               // (no upper bound)
-        const double x = 1.0 - std::sqrt(1.0 - (double)r / (double)n_parts);
-        return std::max<uint64_t>((uint64_t)(x * 4294967296.0), 1ull) << 10;
-    };
+    auto bound = [&](uint32_t r) -> uint64_t { return screen_part_bound(r, n_parts); };
     uint64_t* range_lo = ctx->arena.get<uint64_t>(N); uint32_t* range_cnt = ctx->arena.get<uint32_t>(N); uint32_t* part_off = ctx->arena.get<uint32_t>(N + 1);
     SKH_LAUNCH(screen_part_ranges_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)S->d_mk_off.p, N, bound(part), bound(part + 1), range_lo, range_cnt);
     check_launch("screen_part_ranges");

@@ -127,6 +127,13 @@ def test_multi_rank_triangle_matches_single_process(case):
     stats = [g[5] for g in got]
     assert sum(s["n_pairs_mine"] for s in stats) == n and all(s["n_candidate_pairs_total"] == n and s["n_genomes_total"] == len(genomes) for s in stats)
     assert all(s["screen_by_key_range"] == (0 if case == "uneven" else 1) for s in stats)
+    # the marker sets: cut by key range, a rank receives its own part of the range from the others -- the parts together are every marker once; the row form gathers all
+    all_markers = 8 * sum(o.n_markers for o in osk)
+    got_markers = sum(s["marker_bytes_received"] for s in stats)
+    if case == "uneven":
+        assert got_markers == (world - 1) * all_markers
+    else:
+        assert got_markers < all_markers and got_markers >= all_markers * (world - 1) // world - 8 * len(osk) * world
     assert stats[0]["screen_row_begin"] == 0 and stats[-1]["screen_row_end"] == len(genomes)
     assert all(stats[r]["screen_row_end"] == stats[r + 1]["screen_row_begin"] for r in range(world - 1))
     if case == "blocks":        # one cluster per rank: nothing travels
