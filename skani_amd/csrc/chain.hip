@@ -57,6 +57,43 @@ static void genome_halves(const skh_sketch_set* S) {
     }
 }
 
+// the set's halves on the device (cached in the set; made from the host halves, which must exist)
+static const GenomeDev* dev_halves(skh_ctx* ctx, const skh_sketch_set* S) {
+    std::lock_guard<std::mutex> lk(S->cache_mu);
+    if (!S->d_halves_ok) {
+        std::vector<GenomeDev> v(S->n_genomes);
+        for (uint32_t g = 0; g < S->n_genomes; g++) {
+            const skh_sketch_set::GenomeHalf& h = S->halves[g]; GenomeDev& d = v[g];
+            d.seed = h.seed; d.g = h.g; d.rep = h.rep; d.ms = h.ms; d.bmap = h.bmap; d.goff = h.goff; d.tab = h.tab;
+            d.n_pos = h.n_pos; d.pos0 = h.pos0; d.nbk = h.nbk; d.salt = h.salt; d.nctg = h.nctg; d.pad = 0; d.total_len = h.total_len; d.q10 = h.q10; d.q50 = h.q50; d.q90 = h.q90; d.pad2 = 0;
+        }
+        S->d_halves.alloc(v.size() * sizeof(GenomeDev) + 16);
+        h2d(S->d_halves.p, v.data(), v.size() * sizeof(GenomeDev), ctx->stream);
+        if (v.size() * sizeof(GenomeDev) > ((size_t)1 << 20)) dsync(ctx->stream);     // (beyond the pinned ring the copy reads `v` itself)
+        if (!S->d_halves_ev) S->d_halves_ev.reset(new DevEvent());
+        S->d_halves_ev->record(ctx->stream); S->d_halves_stream = ctx->stream; S->d_halves_ok = true;
+    } else if (S->d_halves_stream != ctx->stream) S->d_halves_ev->make_wait(ctx->stream);
+    return (const GenomeDev*)S->d_halves.p;
+}
+static void drop_halves(const skh_sketch_set* S) { std::lock_guard<std::mutex> lk(S->cache_mu); S->halves.clear(); S->d_halves_ok = false; }
+
+// PairRec -> PairDesc: A = the enumerated side (the reference when switched), B = the probed side; the finalisation inputs by ref / query
+__global__ __launch_bounds__(256) void expand_pairs_kernel(const PairRec* __restrict__ recs, uint32_t n, const GenomeDev* const* __restrict__ tabs /* the reference sets' tables, then the query sets' */,
+                                                           uint32_t n_rsets, PairDesc* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const PairRec rec = recs[p];
+    const GenomeDev hr = tabs[(rec.flags >> 8) & 0xFFFu][rec.r], hq = tabs[n_rsets + (rec.flags >> 20)][rec.q];
+    const bool sw = (rec.flags & 4u) != 0;
+    const GenomeDev& A = sw ? hr : hq; const GenomeDev& B = sw ? hq : hr;
+    PairDesc pd;
+    pd.a_seed = A.seed; pd.a_g = A.g; pd.a_rep = A.rep; pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_bmap = B.bmap; pd.a_goff = A.goff; pd.b_goff = B.goff;
+    pd.a_n = (rec.flags & 8u) ? 0u : A.n_pos; pd.a_pos0 = A.pos0; pd.b_nbk = B.nbk; pd.b_salt = B.salt; pd.flags = rec.flags & 4u; pd.tile0 = rec.tile0;
+    pd.a_nctg = A.nctg; pd.b_nctg = B.nctg; pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg; pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;
+    pd.q10_q = hq.q10; pd.q50_q = hq.q50; pd.q90_q = hq.q90; pd.q10_r = hr.q10; pd.q50_r = hr.q50; pd.q90_r = hr.q90;
+    out[p] = pd;
+}
+
 // same checksum as the oracle's ora_chain_stats.anchor_checksum: (query contig, query pos, ref contig, ref pos, reverse) per anchor
 template <class Co, class Arr>
 uint64_t fnv_anchors(const std::vector<Co>& anc, const std::vector<Co>& anc_r, size_t a0, size_t a1, const Arr& a_go, uint32_t a_n, const Arr& b_go, uint32_t b_n) {
@@ -78,6 +115,9 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 
 }  // namespace
 
+// what the host keeps of a pair (the descriptor itself is made on the device: expand_pairs_kernel)
+struct HostPair { uint32_t a_n, b_nbk, tile0, flags, a_nctg, b_nctg; };
+
 // Slot table of the join kernels, written on the device from per-pair records: workgroup b runs the JOIN_GROUP tiles from (tile, pair) = slot[b] on; the tile groups of pairs
 // [p0, p1) are dealt to eight queues by the probed sketch (queue = key % 8) and queue x owns slots x, x + 8, x + 16, ... (-> XCD x on MI355X), so
 // all tiles probing one sketch run on the XCD whose L2 holds its table.  The host only computes each pair's first position in its queue.
@@ -90,7 +130,7 @@ __global__ __launch_bounds__(256) void slot_tile_kernel(uint32_t p0, uint32_t p1
     for (uint32_t t = 0; t < ngr; t++) slot_tile[(size_t)(first + t) * 8 + x] = make_uint2(t0 + t * JOIN_GROUP, p);
 }
 // returns the device slot table for pairs [p0, p1) and its length
-static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const PairDesc* pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
+static uint2* xcd_slots(skh_ctx* ctx, uint32_t p0, uint32_t p1, const HostPair* pds, const PairDesc* d_pairs_all, const std::vector<uint32_t>& pair_key,
                         unsigned* n_slots) {
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> qp(p1 - p0);
@@ -127,7 +167,9 @@ __global__ __launch_bounds__(256) void widen_anchors_kernel(uint32_t n_anchors, 
 namespace {
 
 struct ChainJob {                                        // what one run over a list of pairs needs (chain_pairs fills it)
-    PairDesc* pds = nullptr; uint32_t n_pairs = 0;       // in the context's pinned buffer: copied to the device as they are
+    PairRec* recs = nullptr; uint32_t n_pairs = 0;       // in the context's pinned buffer: copied to the device as they are, expanded there
+    std::vector<HostPair> hp;                            // the host's view of the same pairs
+    std::vector<const GenomeDev*> tabs; uint32_t n_rsets = 0;   // device tables of the reference sets, then of the query sets
     std::vector<WidePair> wps;                           // a run with a wide sketch set: one per pair
     std::vector<CoArr> host_go_a64, host_go_b64;         //   (host tables for the stats' checksum)
     std::vector<uint32_t> chunk_bound, pair_key;
@@ -143,20 +185,26 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
     using Co = typename W::Co;
     // (A join that walks all tiles of a pair in one workgroup and writes the anchors in one pass -- no probe records, no pair counts on the host -- was
     //  built and measured in round 2: 4.7 ms against 3.4 ms for count + fill; long-lived workgroups hide the probe latency worse.  DESIGN.md section 5.)
-    PairDesc* pds = job.pds;
+    HostPair* pds = job.hp.data();
     const uint32_t NP = job.n_pairs, band = job.band, c = job.c, k = job.k;
     const GbdtModel* model = job.model; const skh_map_params& mp = job.mp;
     StageTrace tr(ctx);
     const bool join_trace = getenv("SKH_TRACE_JOIN") != nullptr;
     uint64_t n_tiles_all = 0;
     for (uint32_t p = 0; p < NP; p++) {
-        pds[p].tile0 = (uint32_t)n_tiles_all;
+        pds[p].tile0 = job.recs[p].tile0 = (uint32_t)n_tiles_all;
         n_tiles_all += (pds[p].a_n + JOIN_TILE - 1) / JOIN_TILE;
         if (n_tiles_all >= 0xFFFFFFF0ull) throw std::invalid_argument("too many sketch positions in one chain call; split the pair list");
     }
     const uint32_t NT = (uint32_t)n_tiles_all;
     PairDesc* d_pairs_all = ctx->arena.get<PairDesc>(NP ? NP : 1);
-    h2d(d_pairs_all, pds, (size_t)NP * sizeof(PairDesc), ctx->stream);
+    {   // 16 bytes per pair go up; the descriptors are made from the sets' resident per-genome tables
+        PairRec* d_recs = ctx->arena.get<PairRec>(NP ? NP : 1);
+        h2d_big(d_recs, job.recs, (size_t)NP * sizeof(PairRec), ctx->stream);
+        const GenomeDev* const* d_tabs = upload(ctx, job.tabs);
+        SKH_LAUNCH(expand_pairs_kernel, (NP + 255) / 256, 256, 0, ctx->stream, (const PairRec*)d_recs, NP, d_tabs, job.n_rsets, d_pairs_all);
+        check_launch("expand_pairs");
+    }
     const WidePair* d_wide_all = nullptr;
     if (W::wide) d_wide_all = upload(ctx, job.wps);
     skh_ani_result* d_out = ctx->arena.get<skh_ani_result>(NP);
@@ -441,12 +489,19 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         if (sel[1].empty()) sel[0].clear();                                            // nothing wide after all: one run over the call's pairs as they are
     }
     const bool split = !sel[1].empty();
+    if (n_rsets > PAIR_MAX_SETS || n_qsets > PAIR_MAX_SETS) throw std::invalid_argument("more than 4096 sketch sets on one side of a chaining call");
+    auto device_tables = [&] {                                                        // the sets' per-genome tables on the device: reference sets, then query sets
+        job.tabs.clear(); job.n_rsets = n_rsets;
+        for (uint32_t x = 0; x < n_rsets; x++) job.tabs.push_back(dev_halves(ctx, Rsets[x]));
+        for (uint32_t x = 0; x < n_qsets; x++) job.tabs.push_back(dev_halves(ctx, Qsets[x]));
+    };
+    device_tables();
     for (int run = 0; run < (split ? 2 : 1); run++) {
         const bool wide_run = split && run == 1;
         const uint32_t* idx = split ? sel[run].data() : nullptr;
         const uint32_t n = split ? (uint32_t)sel[run].size() : NP;
         if (n == 0) continue;
-        job.pds = (PairDesc*)ctx->pin_pairs.need((size_t)n * sizeof(PairDesc)); job.n_pairs = n;
+        job.recs = (PairRec*)ctx->pin_pairs.need((size_t)n * sizeof(PairRec)); job.n_pairs = n; job.hp.assign(n, HostPair{});
         job.chunk_bound.assign(n, 0); job.pair_key.assign(n, 0);
         job.wps.clear(); job.host_go_a.clear(); job.host_go_b.clear(); job.host_go_a64.clear(); job.host_go_b64.clear();
         if (wide_run) job.wps.resize(n);
@@ -456,7 +511,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
             const uint32_t r = pair_ref[p], q = pair_query[p];
             const skh_sketch_set::GenomeHalf& hr = R->halves[r]; const skh_sketch_set::GenomeHalf& hq = Q->halves[q];
-            PairDesc& pd = job.pds[i];
             const bool empty = hr.nctg == 0 || hq.nctg == 0;                          // chain.rs:618-620
             // chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
             const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
@@ -466,15 +520,8 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             else sw = sq > sr;
             const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
             const uint32_t gb = sw ? q : r;
-            pd.a_n = empty ? 0 : A.n_pos;
-            pd.a_seed = A.seed; pd.a_g = A.g; pd.a_rep = A.rep; pd.a_pos0 = A.pos0;
-            pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap; pd.b_salt = B.salt;
-            pd.flags = sw ? 4u : 0u;
-            pd.tile0 = 0;
-            pd.ref_total_len = hr.total_len; pd.query_total_len = hq.total_len;
-            pd.q10_q = hq.q10; pd.q50_q = hq.q50; pd.q90_q = hq.q90; pd.q10_r = hr.q10; pd.q50_r = hr.q50; pd.q90_r = hr.q90;
-            pd.nctg_q = hq.nctg; pd.nctg_r = hr.nctg;
-            pd.a_goff = A.goff; pd.b_goff = B.goff; pd.a_nctg = A.nctg; pd.b_nctg = B.nctg;
+            job.recs[i] = PairRec{r, q, (sw ? 4u : 0u) | (empty ? 8u : 0u) | (rs << 8) | (qs << 20), 0u};
+            job.hp[i] = HostPair{empty ? 0u : A.n_pos, B.nbk, 0u, sw ? 4u : 0u, A.nctg, B.nctg};
             if (stats) { job.host_go_a[i] = A.host_goff; job.host_go_b[i] = B.host_goff; }
             if (wide_run) {
                 const bool aw = A.g64 != nullptr, bw = B.g64 != nullptr;
@@ -498,14 +545,13 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             // What the build fixed only now: the salts of crowded genomes, and -- a set made with SKH_SKETCH_COMPACT | SKH_SKETCH_DEFER_TABLES -- the place of the
             // list storage, which the build cuts to size and moves.  The cached halves were made before: they go, and the probed side of this batch's
             // descriptors is filled in again from fresh ones (the later batches of a split call are made from them anyway).
-            for (uint32_t x = 0; x < n_rsets; x++) { { std::lock_guard<std::mutex> lk(Rsets[x]->cache_mu); Rsets[x]->halves.clear(); } genome_halves(Rsets[x]); }
-            for (uint32_t x = 0; x < n_qsets; x++) { { std::lock_guard<std::mutex> lk(Qsets[x]->cache_mu); Qsets[x]->halves.clear(); } genome_halves(Qsets[x]); }
+            for (uint32_t x = 0; x < n_rsets; x++) { drop_halves(Rsets[x]); genome_halves(Rsets[x]); }
+            for (uint32_t x = 0; x < n_qsets; x++) { drop_halves(Qsets[x]); genome_halves(Qsets[x]); }
+            device_tables();                                                          // (the pair records name genomes, not addresses: nothing else to put right)
             for (uint32_t i = 0; i < n; i++) {
                 const uint32_t p = idx ? idx[i] : i;
                 const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
-                const skh_sketch_set::GenomeHalf& B = (job.pds[i].flags & 4u) ? Q->halves[pair_query[p]] : R->halves[pair_ref[p]];   // B = the query when switched
-                PairDesc& pd = job.pds[i];
-                pd.b_ms = B.ms; pd.b_tab = B.tab; pd.b_nbk = B.nbk; pd.b_bmap = B.bmap; pd.b_salt = B.salt;
+                job.hp[i].b_nbk = ((job.hp[i].flags & 4u) ? Q->halves[pair_query[p]] : R->halves[pair_ref[p]]).nbk;   // B = the query when switched
             }
         }
         if (!split) { chain_run<Narrow>(ctx, job, out, stats); break; }

@@ -24,6 +24,18 @@ struct PairDesc {
     float q10_q, q50_q, q90_q, q10_r, q50_r, q90_r;
 };
 
+// What a pair's descriptor takes from ONE genome, resident on the device: one table per sketch set, uploaded once (chain.hip dev_halves).  A chaining call then
+// uploads 16 bytes per pair (PairRec) and expand_pairs_kernel makes the descriptors from the two tables -- the host used to fill 136 bytes per pair and copy them over
+// PCIe (1.3 MB for the headline's 9,500 pairs, in front of the join on the step's critical path).
+struct GenomeDev {
+    const uint32_t *seed, *g, *rep, *ms, *bmap, *goff; const uint64_t* tab;
+    uint32_t n_pos, pos0, nbk, salt, nctg, pad;
+    uint64_t total_len; float q10, q50, q90, pad2;
+};
+// flags: bit 2 switched (chain.rs:649); bit 3 a genome without contigs (chain.rs:618-620: no tiles); bits 8..19 the reference's set, 20..31 the query's set
+struct PairRec { uint32_t r, q, flags, tile0; };
+constexpr uint32_t PAIR_MAX_SETS = 4096;
+
 // ------------------------------------------------------------------------------------------------ coordinate width
 // A run over pairs of ordinary sketch sets keeps every coordinate in 32 bits (Narrow).  A run that involves a WIDE set (internal.h: a genome beyond
 // 2^31 padded bases) works on 64-bit coordinates from the chunking on (Wide): the join is the same -- a wide set's position records and table

@@ -672,7 +672,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         // "results gathered to rank 0".  The counts and the status of the chaining phases go round in a 16-byte gather (every rank must learn of a failure);
         // the rows themselves travel to rank 0 only -- an all-to-all in which every rank sends one block there -- and the other ranks return their own rows.
         uint64_t head[2] = {rows.size(), local_err.empty() ? 0ull : 1ull}; std::vector<uint64_t> heads(2 * (size_t)W);
-        T.all_gather(ctx, head, heads.data(), 16, false);
+        if (W == 1) { heads[0] = head[0]; heads[1] = head[1]; } else T.all_gather(ctx, head, heads.data(), 16, false);
         for (int r = 0; r < W; r++) if (heads[2 * (size_t)r + 1]) stop_together("seed tables / chaining", r);
         std::vector<uint64_t> sc(W, 0), so(W, 0), rc(W, 0), ro(W, 0); uint64_t total = 0;
         sc[0] = rows.size() * sizeof(Row);
@@ -680,10 +680,10 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         if (me == 0) for (int r = 0; r < W; r++) { rc[r] = heads[2 * (size_t)r] * sizeof(Row); ro[r] = total * sizeof(Row); total += heads[2 * (size_t)r]; }
         if (T.g_recv.size() < total * sizeof(Row) + 8) T.g_recv.resize(total * sizeof(Row) + 8);
         Row none{}; const void* sp = rows.empty() ? (const void*)&none : (const void*)rows.data();
-        T.all_to_all_v(ctx, sp, sc.data(), so.data(), T.g_recv.data(), rc.data(), ro.data(), false);
+        if (W > 1) T.all_to_all_v(ctx, sp, sc.data(), so.data(), T.g_recv.data(), rc.data(), ro.data(), false);
         ex_end();
         out_i.clear(); out_j.clear(); out_res.clear();
-        if (me != 0) {                                                              // own rows, already in (i, j) order (the order of the candidate list)
+        if (me != 0 || W == 1) {                                                    // own rows, already in (i, j) order (the order of the candidate list)
             out_i.reserve(rows.size()); out_j.reserve(rows.size()); out_res.reserve(rows.size());
             for (const Row& row : rows) { out_i.push_back(row.i); out_j.push_back(row.j); out_res.push_back(row.r); }
         } else {

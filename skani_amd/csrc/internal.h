@@ -151,6 +151,9 @@ struct skh_sketch_set {
         double score_markers, score_len;                  // switch_qr's two candidate scores (chain.rs:625-649)
     };
     mutable std::vector<GenomeHalf> halves;
+    // the device's copy of what its kernels need of the halves (chain_types.h GenomeDev; chain.hip dev_halves): uploaded with the first chaining call that uses the set,
+    // on that context's stream; a context with another stream waits for the upload's event
+    mutable skh::DBuf<char> d_halves; mutable bool d_halves_ok = false; mutable devStream_t d_halves_stream{}; mutable std::shared_ptr<skh::DevEvent> d_halves_ev;
     std::vector<uint32_t> rank;
     std::vector<std::string> names;                // optional file names (switch_qr tie-break)
     // device arrays

@@ -75,12 +75,29 @@ struct RcclTransport : Transport {
                       const uint64_t* recv_off, bool device) override {
         uint64_t sb = 0, rb = 0;
         for (int r = 0; r < world; r++) { sb = std::max(sb, send_off[r] + send_cnt[r]); rb = std::max(rb, recv_off[r] + recv_cnt[r]); }
-        const char* s = (const char*)send; char* rv = (char*)recv; DBuf<char> ds, dr;
-        if (!device) { ds.alloc(sb + 1); dr.alloc(rb + 1); h2d(ds.p, send, sb, ctx->stream); s = ds.p; rv = dr.p; }
-        if (send_cnt[rank]) {                                                       // own share: a device copy, not a message
-            if (send_cnt[rank] != recv_cnt[rank]) throw Error("all_to_all_v: own send and receive sizes differ");
-            d2d(rv + recv_off[rank], s + send_off[rank], send_cnt[rank], ctx->stream);
+        if (send_cnt[rank] != recv_cnt[rank]) throw Error("all_to_all_v: own send and receive sizes differ");
+        if (!device) {
+            // host buffers: the rank's own share never visits the device (the result rows of a world of one -- 6.8 MB for config 4 -- made a PCIe round trip), and
+            // only what peers send or get is staged
+            if (send_cnt[rank]) memcpy((char*)recv + recv_off[rank], (const char*)send + send_off[rank], send_cnt[rank]);
+            bool peers = false;
+            for (int r = 0; r < world; r++) if (r != rank && (send_cnt[r] || recv_cnt[r])) peers = true;
+            if (!peers) return;
+            DBuf<char> ds(sb + 1), dr(rb + 1);
+            for (int r = 0; r < world; r++) if (r != rank && send_cnt[r]) h2d_big(ds.p + send_off[r], (const char*)send + send_off[r], send_cnt[r], ctx->stream);
+            rccl_check(api().GroupStart(), "ncclGroupStart");
+            for (int r = 0; r < world; r++) {
+                if (r == rank) continue;
+                if (send_cnt[r]) rccl_check(api().Send(ds.p + send_off[r], send_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclSend");
+                if (recv_cnt[r]) rccl_check(api().Recv(dr.p + recv_off[r], recv_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclRecv");
+            }
+            rccl_check(api().GroupEnd(), "ncclGroupEnd");
+            for (int r = 0; r < world; r++) if (r != rank && recv_cnt[r]) d2h_async((char*)recv + recv_off[r], dr.p + recv_off[r], recv_cnt[r], ctx->stream);
+            dsync(ctx->stream);                                                       // (the staging buffers go with this scope: nothing of theirs may still be queued)
+            return;
         }
+        const char* s = (const char*)send; char* rv = (char*)recv;
+        if (send_cnt[rank]) d2d(rv + recv_off[rank], s + send_off[rank], send_cnt[rank], ctx->stream);   // own share: a device copy, not a message
         rccl_check(api().GroupStart(), "ncclGroupStart");
         for (int r = 0; r < world; r++) {
             if (r == rank) continue;
@@ -88,8 +105,7 @@ struct RcclTransport : Transport {
             if (recv_cnt[r]) rccl_check(api().Recv(rv + recv_off[r], recv_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclRecv");
         }
         rccl_check(api().GroupEnd(), "ncclGroupEnd");
-        if (!device) d2h(recv, dr.p, rb, ctx->stream);
-        else dsync(ctx->stream);
+        dsync(ctx->stream);
     }
     // asynchronous form: the grouped send/recv runs on the context's SECOND stream behind an event of the first (the send buffer is complete there); _end
     // makes the first stream wait for it on the device -- the host never blocks, and what is queued on the first stream in between (the home pairs'
