@@ -260,7 +260,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
         //  and the sketch phase grows from 1.60 to 1.81 ms)
         std::swap(ctx->stream, ctx->stream2);
-        try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }   // + the screen's sorted incidence list, ready for skh_triangle / skh_screen
+        try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw, /*async=*/keys_raw != nullptr); }   // + the screen's sorted incidence list: queued, not waited for
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         tr.mark("sketch: markers + screen index");

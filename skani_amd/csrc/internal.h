@@ -173,6 +173,11 @@ struct skh_sketch_set {
     // sorted by marker (screen.hip).  The set is otherwise immutable; the mutex makes the one-time build safe when several
     // contexts share the set.
     mutable skh::DBuf<uint64_t> screen_keys;
+    // The index made at sketch time is sorted on the context's second stream and the sketch call does NOT wait for it (round 5): its last passes run while the host
+    // returns to its caller and comes back with the screen -- they used to be a 0.18 ms tail behind the table build in front of ~0.1 ms of host time.  What the
+    // sort still works on belongs to the set until a screen has waited for screen_keys_ev on the device and synchronised (screen.hip), or the set goes away.
+    mutable skh::DBuf<uint64_t> screen_keys_raw; mutable skh::DBuf<char> screen_sort_tmp; mutable std::shared_ptr<skh::DevEvent> screen_keys_ev;
+    ~skh_sketch_set() { if (screen_keys_ev) { try { screen_keys_ev->wait(); } catch (...) {} } }
     mutable std::mutex cache_mu;
     mutable std::mutex build_mu;                   // the (one-time) build of deferred seed tables: ensure_tables / skh_triangle's build beside its screen
     bool tables_built = false;                     // seed tables / filter / list storage exist (skh_sketch_genomes_ex may defer them: a rank of a distributed
@@ -242,7 +247,7 @@ void fill_regions(skh_ctx* ctx, FillRegions& fr);
 // ---- sort (sort.hip): stable LSD radix sorts (rocPRIM) used while building sketches and the screen index
 void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t n, int end_bit);   // may redirect the pointers to the sorted arrays (arena)
 void sort_keys_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, int end_bit, int begin_bit = 0);   // stable on bits [begin_bit, end_bit)
-void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit);  // bits [0, end_bit); the result lands in `out`
+void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit, DBuf<char>* tmp = nullptr);  // bits [0, end_bit); the result lands in `out`; tmp: the sort's scratch outside the arena (a sort that outlives the call)
 uint64_t* sort_segments_u64(skh_ctx* ctx, uint64_t* keys, uint64_t n, uint32_t n_seg, const uint64_t* d_off, const uint64_t* h_off, int end_bit);   // every segment [off[s], off[s+1]) on bits [0, end_bit); returns the sorted array
 
 // ---- pack_seed.hip
@@ -274,7 +279,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr);
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr, bool async = false);   // async: the sort is queued, screen_keys_ev recorded behind it, nothing waited for
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)

@@ -160,7 +160,7 @@ static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __p
 
 // fills the set's cache of sorted (marker, genome) incidences on the context's current stream (no-op when present)
 // `premade`: the set's keys in (genome, marker) order, already written by the marker build (scratch: sorted from there into the cache)
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade) {
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade, bool async) {
     const uint32_t ng = set->n_genomes;
     if (!ng || ng > ID_MASK) return;
     const uint64_t MR = set->mk_off[ng];
@@ -170,13 +170,16 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* prem
     if (MR) {
         uint64_t* raw = premade;
         if (!raw) {
-            raw = ctx->arena.get<uint64_t>(MR);
+            if (async) { set->screen_keys_raw.alloc(MR); raw = set->screen_keys_raw.p; } else raw = ctx->arena.get<uint64_t>(MR);
             SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
             check_launch("screen_keys");
         }
-        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS);
+        // async (premade must then be the set's own screen_keys_raw): the sort is queued and the caller returns; whoever uses the index waits for the event on its stream
+        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS, async ? &set->screen_sort_tmp : nullptr);
+        if (async) { set->screen_keys_ev.reset(new DevEvent()); set->screen_keys_ev->record(ctx->stream); return; }
     }
     dsync(ctx->stream);
+    set->screen_keys_raw.release();
 }
 
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
@@ -190,6 +193,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     StageTrace tr(ctx);
     if (ncols > ID_MASK || nrows > ID_MASK) throw Error("more than 2M genomes in one screen call");
     const uint64_t MR = refs->mk_off[ncols], MQ = tri ? 0 : queries->mk_off[nrows], M = MR + MQ;
+    bool keys_pending = false;
     const uint64_t* keys = nullptr;      // triangle: the one sorted incidence list; two sets: the queries' list
     const uint64_t* rkeys = nullptr;     // two sets: the refs' sorted incidence list (cached in the set)
     auto make_keys = [&](const skh_sketch_set* set, uint32_t n_genomes, uint64_t n, uint32_t is_query, uint64_t* out) {
@@ -205,6 +209,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     {
         std::lock_guard<std::mutex> lk(refs->cache_mu);
         if (refs->screen_keys.n != MR || MR == 0) { refs->screen_keys.alloc(MR ? MR : 1); make_keys(refs, ncols, MR, 0u, refs->screen_keys.p); dsync(ctx->stream); }
+        else if (refs->screen_keys_ev) { refs->screen_keys_ev->make_wait(ctx->stream); keys_pending = true; }   // made at sketch time, possibly still being sorted on that context's second stream
     }
     if (tri) keys = refs->screen_keys.p;
     else {
@@ -261,6 +266,10 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         }
     }
     dsync(ctx->stream);
+    if (keys_pending) {                                                              // this stream waited for the sort and is idle now: the sort is over, its scratch can go
+        std::lock_guard<std::mutex> lk(refs->cache_mu);
+        refs->screen_keys_ev.reset(); refs->screen_keys_raw.release(); refs->screen_sort_tmp.release();
+    }
     tr.mark("screen: count + threshold");
 }
 

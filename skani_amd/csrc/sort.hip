@@ -22,12 +22,13 @@ void sort_pairs_u32_u32(skh_ctx* ctx, uint32_t*& keys, uint32_t*& vals, uint64_t
 }
 
 // keys -> out (another array of n entries; `keys` is scratch afterwards): no copy back
-void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit) {
+void sort_keys_u64_into(skh_ctx* ctx, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit, DBuf<char>* own_tmp) {
     if (n == 0) return;
     if (n == 1) { d2d(out, keys, 8, ctx->stream); return; }
     size_t tmp_bytes = 0;
     hip_check(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, out, n, 0, end_bit, ctx->stream), "radix_sort_keys size");
-    void* tmp = ctx->arena.take(tmp_bytes ? tmp_bytes : 16);
+    void* tmp;
+    if (own_tmp) { own_tmp->alloc(tmp_bytes ? tmp_bytes : 16); tmp = own_tmp->p; } else tmp = ctx->arena.take(tmp_bytes ? tmp_bytes : 16);
     hip_check(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, out, n, 0, end_bit, ctx->stream), "radix_sort_keys");
 }
 

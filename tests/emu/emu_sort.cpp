@@ -17,7 +17,7 @@ void sort_pairs_u32_u32(skh_ctx*, uint32_t*& keys, uint32_t*& vals, uint64_t n, 
     memcpy(keys, k.data(), n * 4); memcpy(vals, v.data(), n * 4);
 }
 
-void sort_keys_u64_into(skh_ctx*, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit) {
+void sort_keys_u64_into(skh_ctx*, uint64_t* keys, uint64_t* out, uint64_t n, int end_bit, DBuf<char>*) {
     if (n == 0) return;
     const uint64_t mask = end_bit < 64 ? (1ull << end_bit) - 1ull : ~0ull;
     memcpy(out, keys, n * 8);
