@@ -322,7 +322,7 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
         const EmitCtxT<W> ec{anc_q, anc_r, d_pairs, d_wide, d_pc0, d_pi0, ivl_cnt, ivls, d_err};
         if (NC) {
             bool chained = false;
-            if constexpr (!W::wide) if (band <= 84) {   // fused thread-per-chunk chaining + interval emission (32-bit coordinates only)
+            if (band <= (W::wide ? 40u : 84u) && !(W::wide && ctx->tune.wide_sweep_dp)) {   // fused thread-per-chunk chaining + interval emission (64-bit coordinates: rings up to 40 slots, chain_dp.h)
                 chained = true;
                 constexpr int T = 64;
                 const unsigned gt = (NC + T - 1) / T;
@@ -336,11 +336,12 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 SKH_LAUNCH(dp_order_hist_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, ohist);
                 SKH_LAUNCH(dp_order_scatter_kernel, ob, 256, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)ohist, ohist + DP_ORDER_KEYS, order);
                 check_launch("dp_order");
-#define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
+#define SKH_DPT2(NB, LS, EX) SKH_LAUNCH((chain_dp_thread_kernel<NB, T, LS, EX, W>), gt, T, 0, ctx->stream, NC, (const Chunk*)chunks, (const uint32_t*)chunk_pair, (const uint32_t*)order, band, ec, spill_best, spill_rr, emit_q, ls == 1 ? 1u : (uint32_t)DP_EMIT_Q)   /* test mode: queue of one, the rest written directly */
 #define SKH_DPT(NB, EX) do { if (ls == 1) SKH_DPT2(NB, 1, EX); else SKH_DPT2(NB, 8, EX); } while (0)
                 // the presets' bands (2500 / c for c = 200, 125, 70, 30) get kernels with exactly that many ring slots
-                if (band == 12) SKH_DPT(12, true); else if (band == 20) SKH_DPT(20, true); else if (band == 35) SKH_DPT(35, true); else if (band == 83) SKH_DPT(83, true);
-                else if (band <= 12) SKH_DPT(12, false); else if (band <= 20) SKH_DPT(20, false); else if (band <= 28) SKH_DPT(28, false); else if (band <= 40) SKH_DPT(40, false); else SKH_DPT(84, false);
+                if (band == 12) SKH_DPT(12, true); else if (band == 20) SKH_DPT(20, true); else if (band == 35) SKH_DPT(35, true);
+                else if (band <= 12) SKH_DPT(12, false); else if (band <= 20) SKH_DPT(20, false); else if (band <= 28) SKH_DPT(28, false); else if (band <= 40) SKH_DPT(40, false);
+                else if constexpr (!W::wide) { if (band == 83) SKH_DPT(83, true); else SKH_DPT(84, false); }
 #undef SKH_DPT
 #undef SKH_DPT2
                 check_launch("chain_dp_thread");

@@ -195,9 +195,15 @@ __global__ __launch_bounds__(256) void dp_order_scatter_kernel(uint32_t n_slots,
 #ifndef DP_LINE
 #define DP_LINE 8     // anchors per fetched line: 8 (32 B) measured best (2.04 ms; 16: 2.44 ms, 4: 2.06 ms) -- less LDS, one more wave per SIMD
 #endif
-template <int NB, int T, uint32_t DP_LDS_SLOTS, bool EXACT>   // EXACT: band == NB (the presets' bands), no per-slot band test
+// W = Wide (round 5): a run on 64-bit coordinates rings the LOW words.  The query coordinates of a chunk lie within one fragment of each other, so their low-word
+// differences are the differences; on the reference side two anchors may be 2^32 (or 2^33, ...) apart, their low words a legal gap apart -- so the ring also keeps the
+// high word of every anchor's strand-signed reference coordinate and a link counts only when the 64-bit difference has a zero high word (a subtract, a compare and an
+// and per slot).  Everything else -- scores, components, the live-chain table, the emission -- is the 32-bit kernel's.  (Before: a wide run chained with the wave-per-
+// chunk sweep kernel, which keeps band / 64 of its lanes busy: every genome forced wide, the headline's chaining took 2.5 x as long.)
+template <int NB, int T, uint32_t DP_LDS_SLOTS, bool EXACT, class W = Narrow>   // EXACT: band == NB (the presets' bands), no per-slot band test
 __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, const Chunk* chunks, const uint32_t* chunk_pair, const uint32_t* order, uint32_t band,
-                                                            EmitCtx ec, unsigned long long* spill_best, uint32_t* spill_rr, uint4* emit_q, uint32_t emit_cap) {
+                                                            EmitCtxT<W> ec, unsigned long long* spill_best, uint32_t* spill_rr, uint4* emit_q, uint32_t emit_cap) {
+    using Co = typename W::Co;
     __shared__ unsigned long long lds_best[DP_LDS_SLOTS * T];                       // [slot][lane]
     __shared__ uint32_t lds_rr[DP_LDS_SLOTS * T];                                   // [slot][lane]: root << 8 | refcount
     const uint32_t C = band + 1, tid = threadIdx.x;
@@ -234,8 +240,11 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     //    0 <= dq - 1 < 2500 a negative dr - 1 is >= 2^31 as unsigned and the difference far above MAX_GAP.
     //  * empty slots hold 0, which is more than BP_CHAIN_BAND below any real coordinate.
     uint32_t rq[NB], rr[NB], rs[NB], rd[NB];
+    uint32_t rh[W::wide ? NB : 1];                                                  // Wide: high word of the slot's strand-signed reference coordinate + 1
 #pragma unroll
     for (int k = 0; k < NB; k++) { rq[k] = 0; rr[k] = 0; rs[k] = 0; rd[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < (W::wide ? NB : 1); k++) rh[k] = 0;
     // Anchor fetch.  A lane walks its own chunk, so a plain per-lane load touches 64 different cache lines per instruction and
     // uses 4 bytes of each; with ~50k such streams per XCD the lines are evicted before their next element is wanted and every
     // anchor costs a 64-byte HBM fetch (measured: 15 GB read for 2.4 GB of anchors).  Instead every lane pulls whole lines
@@ -244,17 +253,19 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
     // predecessor ("virtual" index v; elements before the chunk are skipped), which keeps the LDS reads conflict-free and
     // the refill branch wave-uniform.
     constexpr uint32_t LINE = DP_LINE;                       // anchors per fetched line (16 = 64 bytes)
-    constexpr int LQ = LINE / 4;
+    constexpr int APL = W::wide ? 2 : 4;                     // anchors per 16-byte load
+    constexpr int LQ = LINE / APL;
     __shared__ uint32_t lds_q[LINE * T], lds_r[LINE * T];
+    __shared__ uint32_t lds_rh[W::wide ? LINE * T : 1];     // Wide: the reference coordinates' high words (the query side needs its low words only)
     const uint32_t voff = ck.a_begin & (LINE - 1);
     const uint32_t vtot = n ? n + voff : 0;
-    const uint32_t* line_q = ec.anc_q + (ck.a_begin - voff); const uint32_t* line_r = ec.anc_r + (ck.a_begin - voff);
+    const Co* line_q = ec.anc_q + (ck.a_begin - voff); const Co* line_r = ec.anc_r + (ck.a_begin - voff);
     uint4 pq[LQ], pr[LQ];
 #pragma unroll
     for (int j = 0; j < LQ; j++) { pq[j] = make_uint4(0, 0, 0, 0); pr[j] = make_uint4(0, 0, 0, 0); }
     if (vtot) {
 #pragma unroll
-        for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + 4 * j); pr[j] = *(const uint4*)(line_r + 4 * j); }
+        for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + APL * j); pr[j] = *(const uint4*)(line_r + APL * j); }
     }
     for (uint32_t v = 0;; v++) {
         const uint32_t kk = v & (LINE - 1);
@@ -262,18 +273,29 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
             if (__ballot(v < vtot) == 0) break;
 #pragma unroll
             for (int j = 0; j < LQ; j++) {
-                lds_q[(4 * j + 0) * T + tid] = pq[j].x; lds_q[(4 * j + 1) * T + tid] = pq[j].y; lds_q[(4 * j + 2) * T + tid] = pq[j].z; lds_q[(4 * j + 3) * T + tid] = pq[j].w;
-                lds_r[(4 * j + 0) * T + tid] = pr[j].x; lds_r[(4 * j + 1) * T + tid] = pr[j].y; lds_r[(4 * j + 2) * T + tid] = pr[j].z; lds_r[(4 * j + 3) * T + tid] = pr[j].w;
+                if constexpr (W::wide) {                                            // two 64-bit anchors per load: (lo, hi, lo, hi)
+                    lds_q[(2 * j + 0) * T + tid] = pq[j].x; lds_q[(2 * j + 1) * T + tid] = pq[j].z;
+                    lds_r[(2 * j + 0) * T + tid] = pr[j].x; lds_r[(2 * j + 1) * T + tid] = pr[j].z;
+                    lds_rh[(2 * j + 0) * T + tid] = pr[j].y; lds_rh[(2 * j + 1) * T + tid] = pr[j].w;
+                } else {
+                    lds_q[(4 * j + 0) * T + tid] = pq[j].x; lds_q[(4 * j + 1) * T + tid] = pq[j].y; lds_q[(4 * j + 2) * T + tid] = pq[j].z; lds_q[(4 * j + 3) * T + tid] = pq[j].w;
+                    lds_r[(4 * j + 0) * T + tid] = pr[j].x; lds_r[(4 * j + 1) * T + tid] = pr[j].y; lds_r[(4 * j + 2) * T + tid] = pr[j].z; lds_r[(4 * j + 3) * T + tid] = pr[j].w;
+                }
             }
             if (v + LINE < vtot) {
 #pragma unroll
-                for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + v + LINE + 4 * j); pr[j] = *(const uint4*)(line_r + v + LINE + 4 * j); }
+                for (int j = 0; j < LQ; j++) { pq[j] = *(const uint4*)(line_q + v + LINE + APL * j); pr[j] = *(const uint4*)(line_r + v + LINE + APL * j); }
             }
         }
         if (v < voff || v >= vtot) continue;
         const uint32_t i = v - voff;
         const uint2 a = make_uint2(lds_q[kk * T + tid], lds_r[kk * T + tid]);
-        const uint32_t q = a.x, r = (a.y & 1u) ? ~(a.y >> 1) : (a.y >> 1);
+        uint32_t q = a.x, r, sh = 0;                                                 // r, sh: low / high word of s = reverse ? ~(coordinate) : coordinate
+        if constexpr (W::wide) {
+            const uint32_t ah = lds_rh[kk * T + tid];
+            const uint64_t co = (((uint64_t)ah << 32) | a.y) >> 1, sv = (a.y & 1u) ? ~co : co;
+            r = (uint32_t)sv; sh = (uint32_t)(sv >> 32);
+        } else r = (a.y & 1u) ? ~(a.y >> 1) : (a.y >> 1);
         int32_t bscore = 0; uint32_t bdc = NONE;
         // predecessors j = i-1-k for k = 0..band-1 (downward scan; strict '>' keeps the largest j among equal maxima, chain.rs:852-880).
         // Anchors ascend in q, so once the slot just examined is out of reach for every lane the older ones are too: the scan
@@ -290,7 +312,8 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
                         const uint32_t gap = abs_diff_u32(dr1, dq1);
                         const int32_t sc = (int32_t)(rs[k] - gap);
                         // 0 < dq <= 2500 and gap <= 300 bound dr by 2800 < D_MAX_LIN_LENGTH (chain.rs:856-863, 564-597)
-                        const bool ok = (dq1 < BP_CHAIN_BAND) & (gap <= (uint32_t)MAX_GAP) & (sc > bscore);
+                        bool ok = (dq1 < BP_CHAIN_BAND) & (gap <= (uint32_t)MAX_GAP) & (sc > bscore);
+                        if constexpr (W::wide) ok = ok & ((sh - rh[k]) == (r < rr[k] ? 1u : 0u));   // the 64-bit s_i - (s_j + 1) has a zero high word: dr1 IS the difference
                         bscore = ok ? sc : bscore; bdc = ok ? rd[k] : bdc;
                     }
                 }
@@ -321,6 +344,11 @@ __global__ __launch_bounds__(T) void chain_dp_thread_kernel(uint32_t n_slots, co
         }
 #pragma unroll
         for (int k = NB - 1; k > 0; k--) { rq[k] = rq[k - 1]; rr[k] = rr[k - 1]; rs[k] = rs[k - 1]; rd[k] = rd[k - 1]; }
+        if constexpr (W::wide) {
+#pragma unroll
+            for (int k = NB - 1; k > 0; k--) rh[k] = rh[k - 1];
+            rh[0] = sh + (r == 0xFFFFFFFFu ? 1u : 0u);                               // (s + 1)'s high word
+        }
         rq[0] = q + 1u; rr[0] = r + 1u; rs[0] = (uint32_t)(bscore + ANCHOR_SCORE); rd[0] = (depth << 8) | comp;
     }
     // chunk end: every component still referenced by the ring is final now

@@ -50,7 +50,10 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
 // CTG_PAD exceeds every distance the chaining DP can bridge (D_MAX_LIN_LENGTH, BP_CHAIN_BAND), so "same contig" is implied
 // by "close enough" and an anchor needs no contig field; the margins at both ends of the coordinate range let the DP fold
 // the strand test into the same comparison (chain.hip).  A position is stored as gpos << 1 | canonical-strand bit.
-constexpr uint32_t CTG_PAD = 8192;
+#ifndef SKH_CTG_PAD
+#define SKH_CTG_PAD 8192            // (a build parameter so that a test build can put a handful of small contigs 2^32 coordinates apart: tests/emu/build_emu.py, variant "bigpad")
+#endif
+constexpr uint32_t CTG_PAD = SKH_CTG_PAD;
 static_assert(CTG_PAD > (uint32_t)MAX_LIN && CTG_PAD > BP_CHAIN_BAND, "contig padding must exceed the chaining reach");
 template <class Arr, class Co>
 __host__ __device__ __forceinline__ uint32_t ctg_of(const Arr& goff, uint32_t n_ctg, Co gpos) {   // largest c with goff[c] <= gpos

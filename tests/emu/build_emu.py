@@ -13,8 +13,16 @@ FLAGS = ["-O2", "-g", "-ffp-contract=off", "-std=c++17", "-fPIC", "-DSKANI_EMU",
          "-Wno-attributes", "-fno-strict-aliasing"]
 
 
-def build(force=False):
-    objdir = os.path.join(HERE, "build"); os.makedirs(objdir, exist_ok=True)
+# variant "bigpad": contigs 2^30 - 5450 padded coordinates apart instead of 8192 (common.h SKH_CTG_PAD): two contigs are a wide genome, the fifth contig starts beyond
+# 2^32 -- the 64-bit paths (high words of the ring DP's reference coordinates above all) meet coordinates that really need them, on inputs of a few kilobases
+VARIANTS = {None: [], "bigpad": ["-DSKH_CTG_PAD=1073736374"]}
+
+
+def build(force=False, variant=None):
+    global LIB
+    extra = VARIANTS[variant]
+    objdir = os.path.join(HERE, "build" + ("_" + variant if variant else "")); os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(HERE, "libskani_emu%s.so" % ("_" + variant if variant else ""))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "emu.h"), os.path.join(HERE, "emu_dev.h"),
             os.path.join(ROOT, "include", "skani_hip.h")]
     jobs = []
@@ -23,7 +31,7 @@ def build(force=False):
     srcs.append((os.path.join(HERE, "emu_sort.cpp"), os.path.join(objdir, "emu_sort.o")))
     for src, obj in srcs:
         if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + deps):
-            jobs.append(["g++"] + FLAGS + ["-x", "c++", "-c", src, "-o", obj])
+            jobs.append(["g++"] + FLAGS + extra + ["-x", "c++", "-c", src, "-o", obj])
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -31,9 +39,9 @@ def build(force=False):
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     objs = [o for _, o in srcs]
-    if force or jobs or not os.path.exists(LIB):
-        run(["g++", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or not os.path.exists(lib):
+        run(["g++", "-shared", "-fPIC", "-pthread", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

@@ -5,13 +5,13 @@ import os
 from skani_amd import _binding
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIB = {}
 
 
-def emu_lib():
-    global _LIB
-    if _LIB is None:
+def emu_lib(variant=None):
+    """variant: None, or "bigpad" (tests/emu/build_emu.py VARIANTS: contigs ~2^30 padded coordinates apart)"""
+    if variant not in _LIB:
         spec = importlib.util.spec_from_file_location("build_emu", os.path.join(_HERE, "emu", "build_emu.py"))
         m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-        _LIB = _binding.load(m.build())
-    return _LIB
+        _LIB[variant] = _binding.load(m.build(variant=variant))
+    return _LIB[variant]

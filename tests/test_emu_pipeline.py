@@ -152,3 +152,38 @@ def test_emu_seeding_drops_candidates_that_are_not_hits():
             assert drops.value - before > (40 if tile_cap else 20), (tile_cap, drops.value - before)   # (with the small cap every drop happens twice: counting, then listing)
         finally:
             c.close()
+
+
+def test_emu_reference_copies_2_to_the_32_apart(monkeypatch):
+    """The ring DP of a 64-bit run compares LOW words and accepts a link only when the 64-bit difference of the reference coordinates has a zero high word
+    (chain_dp.h).  A simulator build with contigs 2^30 - 5450 padded coordinates apart (tests/emu/build_emu.py "bigpad") makes the case that needs the high words
+    out of a few kilobases: the reference holds a 20 kb contig A, three short contigs, and A again -- the second copy starts EXACTLY 2^32 coordinates behind the
+    first (4 paddings + 20,000 + 3 x 600 bases), so every anchor on the copy has the low word of its twin on the original: a DP that looked at low words only would
+    chain across the two copies (gap 0, a tie the larger index wins).  Against the oracle, whose coordinates are (contig, position); through the sweep kernel too."""
+    from tests.helpers import MODEL_C125, mutate, ora, random_genome
+    from tests.parity_cases import assert_result_close
+    A = random_genome(20000, 911)
+    ref = [("A", A), ("f1", random_genome(600, 912)), ("f2", random_genome(600, 913)), ("f3", random_genome(600, 914)), ("A2", A), ("tail", random_genome(30000, 915))]
+    # (eight short contigs keep the query's mean contig length, hence its switch_qr score, below the reference's: the reference is the PROBED side, chain.rs:15-26)
+    qry = [("qa", mutate(A, 0.01, 916)), ("qt", mutate(ref[5][1], 0.02, 917))] + [("s%d" % i, random_genome(600, 930 + i)) for i in range(8)]
+    names = ["ref.fa", "qry.fa"]
+    osk = [ora.sketch_records(ref, file_name=names[0]), ora.sketch_records(qry, file_name=names[1])]
+    want, wst = ora.chain_seeds(osk[0], osk[1], model=ora.Model(MODEL_C125), stats=True)
+    assert wst.n_anchors > 300 and wst.n_accepted >= 2 and not wst.switched
+    got = []
+    for sweep in ("0", "1"):
+        monkeypatch.setenv("SKH_TUNE_WIDE_SWEEP_DP", sweep)
+        c = sk.Context(0, lib=emu_lib("bigpad"))
+        try:
+            ss = c.sketch_records([ref, qry], sk.SketchParams(), names)
+            assert ss.wide
+            for g in range(2):
+                pc.assert_sketch_equal(ss, g, osk[g])
+            res, st = c.chain_pairs(ss, None, [0], [1], sk.MapParams(learned_ani=True, compute_ci=True), stats=True)
+            assert_result_close(res[0], want, ("bigpad", sweep))
+            assert (int(st[0]["n_anchors"]), int(st[0]["n_chunks"]), int(st[0]["n_intervals"]), int(st[0]["n_accepted"]), int(st[0]["n_estimates"]), int(st[0]["anchor_checksum"])) == \
+                (wst.n_anchors, wst.n_chunks, wst.n_intervals, wst.n_accepted, wst.n_estimates, wst.anchor_checksum), sweep
+            got.append(res[0].tobytes())
+        finally:
+            c.close()
+    assert got[0] == got[1]
