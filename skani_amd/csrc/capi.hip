@@ -266,6 +266,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         std::swap(ctx->stream, ctx->stream2);
         tr.mark("sketch: markers + screen index");
         build_sketch_tables_finish(ctx, ss, tb);
+        prepare_halves(ctx, ss);                                                      // (host work + an upload while the last kernels run; chain.hip)
         book(); tail_guard.armed = false;
         tr.mark("sketch: tables finished");
     });

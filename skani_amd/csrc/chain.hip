@@ -55,6 +55,11 @@ static void genome_halves(const skh_sketch_set* S) {
         // chunks per contig <= len/20000 + 2 (every close advances the end point by 20000 inside the contig)
         h.chunk_bound = (uint32_t)(S->total_len[g] / CHUNK_SIZE + 2 * (uint64_t)h.nctg + 2);
     }
+    S->lite.resize(S->n_genomes);
+    for (uint32_t g = 0; g < S->n_genomes; g++) {
+        const skh_sketch_set::GenomeHalf& h = S->halves[g];
+        S->lite[g] = skh_sketch_set::HalfLite{h.score_markers, h.score_len, h.total_len, h.n_pos, h.nbk, h.nctg, h.chunk_bound, (uint8_t)(h.g64 != nullptr)};
+    }
 }
 
 // the set's halves on the device (cached in the set; made from the host halves, which must exist)
@@ -75,7 +80,7 @@ static const GenomeDev* dev_halves(skh_ctx* ctx, const skh_sketch_set* S) {
     } else if (S->d_halves_stream != ctx->stream) S->d_halves_ev->make_wait(ctx->stream);
     return (const GenomeDev*)S->d_halves.p;
 }
-static void drop_halves(const skh_sketch_set* S) { std::lock_guard<std::mutex> lk(S->cache_mu); S->halves.clear(); S->d_halves_ok = false; }
+static void drop_halves(const skh_sketch_set* S) { std::lock_guard<std::mutex> lk(S->cache_mu); S->halves.clear(); S->lite.clear(); S->d_halves_ok = false; }
 
 // PairRec -> PairDesc: A = the enumerated side (the reference when switched), B = the probed side; the finalisation inputs by ref / query
 __global__ __launch_bounds__(256) void expand_pairs_kernel(const PairRec* __restrict__ recs, uint32_t n, const GenomeDev* const* __restrict__ tabs /* the reference sets' tables, then the query sets' */,
@@ -114,6 +119,10 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 }
 
 }  // namespace
+
+// the host's and the device's per-genome tables of a set whose seed tables exist, made ahead of the first chaining call (the sketch call does it while it waits for its last
+// kernels: ~30 us of host work and an upload that would otherwise sit between the screen and the join)
+void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S) { if (S->tables_built && S->n_genomes) { genome_halves(S); (void)dev_halves(ctx, S); } }
 
 // what the host keeps of a pair (the descriptor itself is made on the device: expand_pairs_kernel)
 struct HostPair { uint32_t a_n, b_nbk, tile0, flags, a_nctg, b_nctg; };
@@ -485,7 +494,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
     if (any_wide_set) {
         for (uint32_t p = 0; p < NP; p++) {
             const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
-            sel[(R->halves[pair_ref[p]].g64 || Q->halves[pair_query[p]].g64) ? 1 : 0].push_back(p);
+            sel[(R->lite[pair_ref[p]].wide || Q->lite[pair_query[p]].wide) ? 1 : 0].push_back(p);
         }
         if (sel[1].empty()) sel[0].clear();                                            // nothing wide after all: one run over the call's pairs as they are
     }
@@ -511,7 +520,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             const uint32_t p = idx ? idx[i] : i;
             const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
             const uint32_t r = pair_ref[p], q = pair_query[p];
-            const skh_sketch_set::GenomeHalf& hr = R->halves[r]; const skh_sketch_set::GenomeHalf& hq = Q->halves[q];
+            const skh_sketch_set::HalfLite& hr = R->lite[r]; const skh_sketch_set::HalfLite& hq = Q->lite[q];
             const bool empty = hr.nctg == 0 || hq.nctg == 0;                          // chain.rs:618-620
             // chain.rs:15-26 switch_qr with the inputs of chain.rs:625-649
             const bool both_long = hq.total_len > 100000 && hr.total_len > 100000;
@@ -519,10 +528,12 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             bool sw;
             if (sq == sr) sw = (!tie_by_rank && !Q->names.empty() && !R->names.empty()) ? Q->names[q] > R->names[r] : Q->rank[q] > R->rank[r];   // query_file_name > ref_file_name
             else sw = sq > sr;
-            const skh_sketch_set::GenomeHalf& A = sw ? hr : hq; const skh_sketch_set::GenomeHalf& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
+            const skh_sketch_set::HalfLite& A = sw ? hr : hq; const skh_sketch_set::HalfLite& B = sw ? hq : hr;   // A: enumerated side (chain.rs:652-660)
             const uint32_t gb = sw ? q : r;
             job.recs[i] = PairRec{r, q, (sw ? 4u : 0u) | (empty ? 8u : 0u) | (rs << 8) | (qs << 20), 0u};
             job.hp[i] = HostPair{empty ? 0u : A.n_pos, B.nbk, 0u, sw ? 4u : 0u, A.nctg, B.nctg};
+            if (stats || wide_run) {                                                   // (the rare paths take the full records)
+            const skh_sketch_set::GenomeHalf& A = sw ? R->halves[r] : Q->halves[q]; const skh_sketch_set::GenomeHalf& B = sw ? Q->halves[q] : R->halves[r];
             if (stats) { job.host_go_a[i] = A.host_goff; job.host_go_b[i] = B.host_goff; }
             if (wide_run) {
                 const bool aw = A.g64 != nullptr, bw = B.g64 != nullptr;
@@ -534,6 +545,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
                     job.host_go_a64[i] = aw ? CoArr{A.host_goff64, 1u} : CoArr{A.host_goff, 0u};
                     job.host_go_b64[i] = bw ? CoArr{B.host_goff64, 1u} : CoArr{B.host_goff, 0u};
                 }
+            }
             }
             job.pair_key[i] = gb + 3u * (sw ? n_rsets + qs : rs);                    // tiles probing the same sketch share an XCD
             job.chunk_bound[i] = A.chunk_bound;
@@ -552,7 +564,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             for (uint32_t i = 0; i < n; i++) {
                 const uint32_t p = idx ? idx[i] : i;
                 const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
-                job.hp[i].b_nbk = ((job.hp[i].flags & 4u) ? Q->halves[pair_query[p]] : R->halves[pair_ref[p]]).nbk;   // B = the query when switched
+                job.hp[i].b_nbk = ((job.hp[i].flags & 4u) ? Q->lite[pair_query[p]] : R->lite[pair_ref[p]]).nbk;   // B = the query when switched
             }
         }
         if (!split) { chain_run<Narrow>(ctx, job, out, stats); break; }

@@ -8,9 +8,16 @@
 //   * a component too heavy for an even split is cut into (row-block x column-block) tiles of its genome list;
 //   * units (components and tiles) are dealt out longest-first to the least loaded rank (cost of a pair = both genomes' marker counts, a proxy
 //     for the two sketches the join has to read).
-// Exchange steps (Transport: RCCL on device buffers, or caller-supplied host collectives): 3 small all-gathers of per-rank / per-genome
-// tables, 1 all-gather of the marker sets (device), 2 of the candidate pairs, 1 all-to-all of the sketches that have to move (device:
-// seed + padded-position arrays, 8 bytes per seed position), 2 all-gathers of the results.  No collective inside the pair pipeline.
+// Exchange steps (Transport: RCCL on device buffers, or caller-supplied host collectives), round 5:
+//   1. ONE all-gather of per-rank tables (genomes, sizes, contig lengths, and per genome how many of its markers fall into each rank's part of the key range);
+//   2. an 8-byte agreement, then ONE all-to-all of marker sets by key range (every rank receives its own part of every genome's sorted set: 1/W of the bytes an
+//      all-gather would move; the row form of very large collections still all-gathers);
+//   3. ONE all-gather of the non-zero cells of every rank's partial count matrix (device buffers the communicator keeps); every rank adds them up row by row in LDS
+//      and applies the rule itself -- no candidate list travels;
+//   4. an 8-byte agreement, then the asynchronous all-to-all of exactly the sketches that have to move (seed + padded-position arrays, 8 bytes per seed position),
+//      hidden behind the home set's table build and the home pairs;
+//   5. the result rows: a 16-byte gather of counts + status, then the rows to rank 0 (SKH_DIST_ROWS_TO_ROOT) or an all-gather (every rank returns the triangle).
+// No collective inside the pair pipeline.
 #include <algorithm>
 #include <cmath>
 #include <numeric>

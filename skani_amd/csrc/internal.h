@@ -152,6 +152,9 @@ struct skh_sketch_set {
         double score_markers, score_len;                  // switch_qr's two candidate scores (chain.rs:625-649)
     };
     mutable std::vector<GenomeHalf> halves;
+    // what the per-pair host loop of a chaining call reads of a genome, in one cache line (the full halves take three): role decision, tile and chunk bounds
+    struct HalfLite { double score_markers, score_len; uint64_t total_len; uint32_t n_pos, nbk, nctg, chunk_bound; uint8_t wide; };
+    mutable std::vector<HalfLite> lite;
     // the device's copy of what its kernels need of the halves (chain_types.h GenomeDev; chain.hip dev_halves): uploaded with the first chaining call that uses the set,
     // on that context's stream; a context with another stream waits for the upload's event
     mutable skh::DBuf<char> d_halves; mutable bool d_halves_ok = false; mutable devStream_t d_halves_stream{}; mutable std::shared_ptr<skh::DevEvent> d_halves_ev;
@@ -306,6 +309,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* loca
 void comm_selftest(skh_ctx* ctx, Transport& T);
 
 // ---- chain.hip
+void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S);   // per-genome tables (host + device) ahead of the first chaining call
 // chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,
