@@ -49,13 +49,19 @@ for W in (1, 2, 4, 8):
             ctx.screen_part(ss, p, W)
             torch.cuda.synchronize(); b = min(b or 1e9, (time.perf_counter() - t0) * 1e3)
         part_ms.append(b)
-    fc = None
-    for rep in range(3):
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        a, b = ctx.screen_from_cells(ss, allc, 0.0, True)
-        torch.cuda.synchronize(); fc = min(fc or 1e9, (time.perf_counter() - t1) * 1e3)
-    assert len(a) == nch, (len(a), nch)
-    scr[str(W)] = {"part_ms_max": max(part_ms), "part_ms": [round(x, 3) for x in part_ms], "from_cells_ms": fc, "cells_per_part": [int(len(c)) for c in cells], "cells_total": int(len(allc))}
+    # the cells of all parts through the rule: in row order (what the distributed call's gathered blocks are: added up row by row in LDS, round 5) and as concatenated
+    # (out of row order: the dense N x N matrix, the form of rounds 3-4).  (The host copy of the cells up to the device is inside both: the distributed call has them there.)
+    fc = {}
+    for form, arr in (("rows", np.sort(allc)), ("dense", allc)):
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            a, b = ctx.screen_from_cells(ss, arr, 0.0, True)
+            torch.cuda.synchronize(); best = min(best or 1e9, (time.perf_counter() - t1) * 1e3)
+        assert len(a) == nch, (len(a), nch)
+        fc[form] = best
+    scr[str(W)] = {"part_ms_max": max(part_ms), "part_ms": [round(x, 3) for x in part_ms], "from_cells_ms": fc["rows"], "from_cells_dense_ms": fc["dense"],
+                   "cells_per_part": [int(len(c)) for c in cells], "cells_total": int(len(allc))}
 out["screen_by_key_range_ms"] = scr
 ctx.timings()
 a, b = ctx.screen(ss, None, 0.0, 0, True)
