@@ -678,7 +678,7 @@ int run_search(Args& a, Ctx& cx) {                                              
 int main(int argc, char** argv) {
     Args a = parse(argc, argv);
     if (a.gpus < 1 || a.gpus > 64) die("--gpus: between 1 and 64");
-    if (a.gpus > 1) {
+    if (a.gpus > 1 || (a.cmd == "triangle" && getenv("SKANI_HIP_FORCE_NODE"))) {     // (SKANI_HIP_FORCE_NODE: the rank driver with a world of one -- a forked rank, the RCCL communicator and its self-test on a one-GPU box)
         if (a.cmd != "triangle") die("--gpus is for `triangle` (dist and search run on one GPU)");
         try { return run_triangle_node(a, argv[0]); } catch (const std::exception& e) { die(e.what()); }
     }

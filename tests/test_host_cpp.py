@@ -378,6 +378,11 @@ def test_cli_triangle_gpus_one_device(tmp_path):
             assert (d / ("w%d.txt" % w)).read_bytes() == (d / "one.txt").read_bytes() and (d / ("w%d.txt.af" % w)).read_bytes() == (d / "one.txt.af").read_bytes()
         a = _run_cli(exe, ["triangle", "-E", "--ci"] + files, d, env); b = _run_cli(exe, ["triangle", "-E", "--ci", "--gpus", "2", "--one-device"] + files, d, env)
         assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout.splitlines()) > 10
+    # the rank driver with a world of ONE (SKANI_HIP_FORCE_NODE): a forked rank that makes the library's RCCL communicator from the id rank 0 published, runs its self-test
+    # and skh_triangle_distributed_ex through it -- all of the RCCL path a one-GPU box can run
+    r1 = _run_cli(exe, ["triangle", "-t", "8", "-o", "rccl1.txt"] + sfiles, sdir, dict(env, SKANI_HIP_FORCE_NODE="1"))
+    assert r1.returncode == 0 and "RCCL is not usable" not in r1.stderr, r1.stderr
+    assert (sdir / "rccl1.txt").read_bytes() == (sdir / "one.txt").read_bytes()
     lines = (wdir / "one.txt").read_bytes().splitlines()
     assert lines[0] == b"6" and all(float(c) > 80 for l in lines[2:] for c in l.split(b"\t")[1:])   # all 15 pairs of config 2 are related
     f = _run_cli(exe, ["triangle", "-o", "f.txt", "--gpus", "2", "--one-device"] + sfiles, sdir, dict(env, SKH_TUNE_DIST_FAIL="8", SKH_TUNE_DIST_FAIL_RANK="1"), timeout=300)
