@@ -561,6 +561,12 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
         last["result"] = (i, j, res)
         return len(i), n_chained
 
+    # The interpreter's cyclic garbage collector is kept out of the steps: a full collection walks every container object alive -- after the generation of 10,000
+    # genomes that is tens of milliseconds, with the GIL held -- and starts whenever the allocation counters say so, i.e. in the middle of some step (the "start-of-process
+    # transient" of profiles/r04_first_steps_transient.md: a step's first launch 20-25 ms late, a polling THREAD of the same interpreter just as late, nothing on the device).
+    # What is alive now is collected once and frozen; the steps' own garbage is reference-counted away.
+    import gc
+    gc.collect(); gc.freeze()
     with stdout_to_stderr():                      # (the first collective may still print)
         for _ in range(warmup):
             step()
@@ -585,6 +591,7 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     tm = ctx.timings()
     gs.close()
     torch.cuda.empty_cache()
@@ -662,7 +669,7 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
                                   "itself); candidate pairs assigned to ranks cluster by cluster (balanced, order-independent); only the needed sketches travel, "
                                   "point-to-point and asynchronously; result rows gathered on rank 0"},
         "phase_ms_per_step": {k: tm[k] / steps for k in ("seed_ms", "sketch_build_ms", "screen_ms", "chain_ms", "exchange_ms")},
-        "step_wall_ms_rank0": [round(1e3 * x, 3) for x in step_wall],
+        "step_wall_ms_rank0": [round(1e3 * x, 3) for x in step_wall], "ms_per_step_median_rank0": round(1e3 * float(np.median(step_wall)), 3),
         "roofline": roof,
     }
     # what compares across N and across the weak / strong modes: the pair count grows with the square of the collection, the work with its size
@@ -828,7 +835,8 @@ def main():
             s = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, sn, "shuffled", True, max(1, args.strong_steps), max(args.warmup, 4 if world == 1 else 2),
                              want_cpu=False, want_e2e=False)
         if rank == 0:
-            out["strong"] = {k: s[k] for k in ("ms_per_step", "value", "steps", "warmup", "bases_per_s_per_gpu", "chained_pairs_per_s_per_gpu", "genomes_per_s_per_gpu", "phase_ms_per_step")}
+            out["strong"] = {k: s[k] for k in ("ms_per_step", "ms_per_step_median_rank0", "step_wall_ms_rank0", "value", "steps", "warmup", "bases_per_s_per_gpu", "chained_pairs_per_s_per_gpu",
+                                               "genomes_per_s_per_gpu", "phase_ms_per_step")}
             out["strong"].update({"collection": args.strong_collection, "genomes_per_gpu": sn, "chained_pairs": s["config"]["chained_pairs"], "order": "shuffled",
                                   "note": "the same N on a FIXED collection (BASELINE config 4's %d shuffled genomes, %d per GPU): speed-up over N = this block's ms_per_step at "
                                           "N = 1 / at N; the start-of-process transient at this size (profiles/r04_first_steps_transient.md) is why its warm-up is at least 4 steps on one GPU"

@@ -14,7 +14,7 @@ namespace {
 // ring for the duration of the call; nothing unwinds across the boundary.
 template <class F> int guarded(skh_ctx* ctx, F&& f) {
     try {
-        if (ctx) { PinScope scope(ctx->device, &ctx->ring); f(); } else f();
+        if (ctx) { PinScope scope(ctx->device, &ctx->ring); if (!ctx->pending_sorts.empty()) reap_pending_sorts(ctx); f(); } else f();
         return SKH_OK;
     }
     catch (const std::bad_alloc&) { if (ctx) ctx->err = "out of host memory"; return SKH_ERR_NOMEM; }

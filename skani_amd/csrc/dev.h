@@ -108,6 +108,7 @@ struct DevEvent {
     DevEvent(DevEvent&& o) noexcept : e(o.e) { o.e = nullptr; }
     void record(devStream_t s) { hip_check(hipEventRecord(e, s), "hipEventRecord"); }
     void wait() { hip_check(hipEventSynchronize(e), "hipEventSynchronize"); }
+    bool done() { const hipError_t r = hipEventQuery(e); if (r == hipSuccess) return true; (void)hipGetLastError(); return false; }
     void make_wait(devStream_t s) { hip_check(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }   // `s` continues after this event
     static float ms(const DevEvent& a, const DevEvent& b) { float t = 0; hip_check(hipEventElapsedTime(&t, a.e, b.e), "hipEventElapsedTime"); return t; }
 };

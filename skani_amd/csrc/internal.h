@@ -74,6 +74,13 @@ struct skh_tunables {
     uint64_t wide_span = (1ull << 31) - 8192;           // a genome of at least this many padded bases makes its sketch set "wide" (tests use small values to run everything through the 64-bit path)
 };
 
+namespace skh {
+struct PendingSort {
+    DBuf<uint64_t> raw; DBuf<char> tmp; DevEvent ev; std::mutex mu;
+    void release() { std::lock_guard<std::mutex> lk(mu); raw.release(); tmp.release(); }   // (only once the event is done)
+};
+}  // namespace skh
+
 struct skh_ctx {
     skh_tunables tune;
     int device = 0;
@@ -91,6 +98,7 @@ struct skh_ctx {
     // the key-range screen's count matrix of a large collection (one plane, N x N words) stays with the context, all zero between calls: the kernel that emits the
     // non-zero cells puts them back to zero, so no call zeroes 4 N^2 bytes (screen.hip screen_partial_cells_dev); part_cnt_clean is false while a call is in between
     skh::DBuf<uint32_t> part_cnt; bool part_cnt_clean = false;
+    std::vector<std::shared_ptr<skh::PendingSort>> pending_sorts;   // index sorts this context queued and did not wait for (screen.hip reap_pending_sorts)
 };
 
 namespace skh { struct Transport; }
@@ -179,9 +187,11 @@ struct skh_sketch_set {
     mutable skh::DBuf<uint64_t> screen_keys;
     // The index made at sketch time is sorted on the context's second stream and the sketch call does NOT wait for it (round 5): its last passes run while the host
     // returns to its caller and comes back with the screen -- they used to be a 0.18 ms tail behind the table build in front of ~0.1 ms of host time.  What the
-    // sort still works on belongs to the set until a screen has waited for screen_keys_ev on the device and synchronised (screen.hip), or the set goes away.
-    mutable skh::DBuf<uint64_t> screen_keys_raw; mutable skh::DBuf<char> screen_sort_tmp; mutable std::shared_ptr<skh::DevEvent> screen_keys_ev;
-    ~skh_sketch_set() { if (screen_keys_ev) { try { screen_keys_ev->wait(); } catch (...) {} } }
+    // sort still works on is let go when the event behind it is done: by the screen that waited for it, by the context's next call, or with the set.
+    // (PendingSort: the unsorted keys, rocPRIM's scratch and the event behind the sort; shared with the context that queued it, which lets go of the two buffers as soon
+    //  as it sees the event done -- a resident database's shards are never screened themselves and would keep 16 bytes per marker for ever)
+    mutable std::shared_ptr<skh::PendingSort> screen_sort;
+    ~skh_sketch_set() { if (screen_sort) { try { screen_sort->ev.wait(); } catch (...) {} } }
     mutable std::mutex cache_mu;
     mutable std::mutex build_mu;                   // the (one-time) build of deferred seed tables: ensure_tables / skh_triangle's build beside its screen
     bool tables_built = false;                     // seed tables / filter / list storage exist (skh_sketch_genomes_ex may defer them: a rank of a distributed
@@ -283,7 +293,8 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr, bool async = false);   // async: the sort is queued, screen_keys_ev recorded behind it, nothing waited for
+void reap_pending_sorts(skh_ctx* ctx);   // lets go of the scratch of index sorts that have finished
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr, bool async = false);   // async: the sort is queued, the set's PendingSort event recorded behind it, nothing waited for
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)

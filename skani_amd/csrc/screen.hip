@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
         const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
         if (lo < row0 || lo >= row0 + rows) continue;
         uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
-        if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u); }
+        if (FIRST) {
+            // a cell takes ~2,000 increments (the markers a related pair shares) and only the first needs its result back: whoever reads the cell as non-zero adds without
+            // waiting for the old value.  (With every increment a returning one a clade-ordered collection -- a clade's cells share a few cache lines -- took 28 instead of 10 ms.)
+            if (__atomic_load_n(cell, __ATOMIC_RELAXED) != 0u) atomicAdd(cell, 1u);
+            else if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u);
+        }
         else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
     }
 }
@@ -160,26 +165,30 @@ static double powi21(double a) {   // f64::powi(x, 21) lowers to compiler-rt __p
 
 // fills the set's cache of sorted (marker, genome) incidences on the context's current stream (no-op when present)
 // `premade`: the set's keys in (genome, marker) order, already written by the marker build (scratch: sorted from there into the cache)
+void reap_pending_sorts(skh_ctx* ctx) {
+    auto& v = ctx->pending_sorts;
+    for (size_t x = 0; x < v.size();) { if (v[x]->ev.done()) { v[x]->release(); v[x] = v.back(); v.pop_back(); } else x++; }
+}
 void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade, bool async) {
     const uint32_t ng = set->n_genomes;
-    if (!ng || ng > ID_MASK) return;
+    if (!ng || ng > ID_MASK) { set->screen_sort.reset(); return; }
     const uint64_t MR = set->mk_off[ng];
     std::lock_guard<std::mutex> lk(set->cache_mu);
     if (set->screen_keys.n == MR && MR) return;
     set->screen_keys.alloc(MR ? MR : 1);
     if (MR) {
-        uint64_t* raw = premade;
+        uint64_t* raw = premade;                                                     // (premade: the set's own screen_sort->raw, written by the marker build)
         if (!raw) {
-            if (async) { set->screen_keys_raw.alloc(MR); raw = set->screen_keys_raw.p; } else raw = ctx->arena.get<uint64_t>(MR);
+            if (async) { if (!set->screen_sort) set->screen_sort.reset(new PendingSort()); set->screen_sort->raw.alloc(MR); raw = set->screen_sort->raw.p; } else raw = ctx->arena.get<uint64_t>(MR);
             SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
             check_launch("screen_keys");
         }
-        // async (premade must then be the set's own screen_keys_raw): the sort is queued and the caller returns; whoever uses the index waits for the event on its stream
-        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS, async ? &set->screen_sort_tmp : nullptr);
-        if (async) { set->screen_keys_ev.reset(new DevEvent()); set->screen_keys_ev->record(ctx->stream); return; }
+        // async: the sort is queued and the caller returns; whoever uses the index waits for the event on its stream
+        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS, async ? &set->screen_sort->tmp : nullptr);
+        if (async) { set->screen_sort->ev.record(ctx->stream); ctx->pending_sorts.push_back(set->screen_sort); return; }
     }
     dsync(ctx->stream);
-    set->screen_keys_raw.release();
+    set->screen_sort.reset();
 }
 
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule, int rescue_small,
@@ -209,7 +218,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     {
         std::lock_guard<std::mutex> lk(refs->cache_mu);
         if (refs->screen_keys.n != MR || MR == 0) { refs->screen_keys.alloc(MR ? MR : 1); make_keys(refs, ncols, MR, 0u, refs->screen_keys.p); dsync(ctx->stream); }
-        else if (refs->screen_keys_ev) { refs->screen_keys_ev->make_wait(ctx->stream); keys_pending = true; }   // made at sketch time, possibly still being sorted on that context's second stream
+        else if (refs->screen_sort) { refs->screen_sort->ev.make_wait(ctx->stream); keys_pending = true; }   // made at sketch time, possibly still being sorted on that context's second stream
     }
     if (tri) keys = refs->screen_keys.p;
     else {
@@ -268,7 +277,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     dsync(ctx->stream);
     if (keys_pending) {                                                              // this stream waited for the sort and is idle now: the sort is over, its scratch can go
         std::lock_guard<std::mutex> lk(refs->cache_mu);
-        refs->screen_keys_ev.reset(); refs->screen_keys_raw.release(); refs->screen_sort_tmp.release();
+        if (refs->screen_sort) { refs->screen_sort->release(); refs->screen_sort.reset(); }
     }
     tr.mark("screen: count + threshold");
 }

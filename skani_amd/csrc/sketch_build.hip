@@ -630,7 +630,7 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
         if (MU) {
             uint64_t* keys = nullptr;                                                  // the screen's incidence keys, made on the way: the set's own array (their sort outlives this call)
-            if (screen_keys_raw && ng <= SCREEN_ID_MASK) { ss->screen_keys_raw.alloc(MU); keys = ss->screen_keys_raw.p; }
+            if (screen_keys_raw && ng <= SCREEN_ID_MASK) { if (!ss->screen_sort) ss->screen_sort.reset(new PendingSort()); ss->screen_sort->raw.alloc(MU); keys = ss->screen_sort->raw.p; }
             SKH_LAUNCH(marker_gather_kernel, ng, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ss->markers.p, keys);
             check_launch("marker_gather");
             if (screen_keys_raw) *screen_keys_raw = keys;

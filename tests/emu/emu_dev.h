@@ -40,6 +40,7 @@ inline void dev_close(devStream_t, devStream_t) noexcept {}
 struct DevEvent {
     void record(devStream_t) {}
     void wait() {}
+    bool done() { return true; }
     void make_wait(devStream_t) {}
     static float ms(const DevEvent&, const DevEvent&) { return 0.f; }
 };
