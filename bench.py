@@ -566,7 +566,8 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
     # transient" of profiles/r04_first_steps_transient.md: a step's first launch 20-25 ms late, a polling THREAD of the same interpreter just as late, nothing on the device).
     # What is alive now is collected once and frozen; the steps' own garbage is reference-counted away.
     import gc
-    gc.collect(); gc.freeze()
+    if not os.environ.get("BENCH_NO_GC_FREEZE"):            # (the switch of the experiment that showed it: tools/gpu_job.sh gcfreeze)
+        gc.collect(); gc.freeze()
     with stdout_to_stderr():                      # (the first collective may still print)
         for _ in range(warmup):
             step()
