@@ -561,13 +561,6 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
         last["result"] = (i, j, res)
         return len(i), n_chained
 
-    # The interpreter's cyclic garbage collector is kept out of the steps: a full collection walks every container object alive -- after the generation of 10,000
-    # genomes that is tens of milliseconds, with the GIL held -- and starts whenever the allocation counters say so, i.e. in the middle of some step (the "start-of-process
-    # transient" of profiles/r04_first_steps_transient.md: a step's first launch 20-25 ms late, a polling THREAD of the same interpreter just as late, nothing on the device).
-    # What is alive now is collected once and frozen; the steps' own garbage is reference-counted away.
-    import gc
-    if not os.environ.get("BENCH_NO_GC_FREEZE"):            # (the switch of the experiment that showed it: tools/gpu_job.sh gcfreeze)
-        gc.collect(); gc.freeze()
     with stdout_to_stderr():                      # (the first collective may still print)
         for _ in range(warmup):
             step()
@@ -592,7 +585,6 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    gc.unfreeze()
     tm = ctx.timings()
     gs.close()
     torch.cuda.empty_cache()
