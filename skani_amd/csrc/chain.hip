@@ -435,7 +435,9 @@ void chain_run(skh_ctx* ctx, ChainJob& job, skh_ani_result* out, skh_chain_stats
                 if (pair_anch[p0 + i] == 0) { st.switched = 1; st.n_qpos = 0; }   // reference returns (default, true) when there are no anchors (chain.rs:619,719)
             }
         }
-        d2h(out + p0, d_out + p0, (size_t)np * sizeof(skh_ani_result), ctx->stream);   // the batch's results; this is also the batch's synchronisation
+        // the batch's results; this is also the batch's synchronisation (skh_triangle hands a pinned array: one DMA; a caller's own array: through the pinned ring, dev.h d2h)
+        if (ctx->pin_results.holds(out + p0)) d2h_pinned(out + p0, d_out + p0, (size_t)np * sizeof(skh_ani_result), ctx->stream);
+        else d2h(out + p0, d_out + p0, (size_t)np * sizeof(skh_ani_result), ctx->stream);
         ctx->arena.rewind(arena_mark);
         p0 = p1;
         }

@@ -58,25 +58,57 @@ struct PinScope {                                                               
     }
     ~PinScope() { pin_ring_of_thread() = prev; if (prev_dev >= 0) (void)hipSetDevice(prev_dev); }
 };
+// SKH_TUNE_PAGEABLE_DIRECT=1: large copies from / to pageable host memory go to the runtime as they are (the form before round 5; see d2h)
+inline bool pageable_direct() { static const bool on = [] { const char* v = getenv("SKH_TUNE_PAGEABLE_DIRECT"); return v && *v && *v != '0'; }(); return on; }
+inline bool pin_ring_ready(PinRing* r, devStream_t s) {
+    constexpr size_t PIN_RING = (size_t)8 << 20;
+    if (!r || !(s == r->s0 || s == r->s1)) return false;
+    if (!r->tried) { r->tried = true; void* q = nullptr; if (hipHostMalloc(&q, PIN_RING, hipHostMallocPortable) == hipSuccess) { r->p = (char*)q; r->cap = PIN_RING; } else (void)hipGetLastError(); }
+    return r->p != nullptr;
+}
+inline char* pin_ring_take(PinRing* r, size_t n) {                                   // n <= cap / 2; a slot is reused only after both streams of the ring's context have been waited for
+    const size_t need = (n + 255) & ~(size_t)255;
+    if (r->off + need > r->cap) { hip_check(hipStreamSynchronize(r->s0), "pinned ring wrap"); hip_check(hipStreamSynchronize(r->s1), "pinned ring wrap"); r->off = 0; }
+    char* p = r->p + r->off; r->off += need; return p;
+}
+constexpr size_t PIN_CHUNK = (size_t)4 << 20;
 inline void h2d(void* d, const void* h, size_t n, devStream_t s) {
     if (!n) return;
-    constexpr size_t PIN_RING = (size_t)8 << 20, PIN_MAX = (size_t)1 << 20;
+    constexpr size_t PIN_MAX = (size_t)1 << 20;
     PinRing* r = pin_ring_of_thread();
-    if (r && n <= PIN_MAX && (s == r->s0 || s == r->s1)) {
-        if (!r->tried) { r->tried = true; void* q = nullptr; if (hipHostMalloc(&q, PIN_RING, hipHostMallocPortable) == hipSuccess) { r->p = (char*)q; r->cap = PIN_RING; } else (void)hipGetLastError(); }
-        if (r->p) {
-            const size_t need = (n + 255) & ~(size_t)255;
-            if (r->off + need > r->cap) { hip_check(hipStreamSynchronize(r->s0), "pinned ring wrap"); hip_check(hipStreamSynchronize(r->s1), "pinned ring wrap"); r->off = 0; }
-            memcpy(r->p + r->off, h, n);
-            hip_check(hipMemcpyAsync(d, r->p + r->off, n, hipMemcpyHostToDevice, s), "h2d");
-            r->off += need;
-            return;
+    if ((n <= PIN_MAX || !pageable_direct()) && pin_ring_ready(r, s)) {              // (larger than the ring's half: in chunks, the same way)
+        for (size_t at = 0; at < n; at += PIN_CHUNK) {
+            const size_t m = n - at < PIN_CHUNK ? n - at : PIN_CHUNK;
+            char* q = pin_ring_take(r, m);
+            memcpy(q, (const char*)h + at, m);
+            hip_check(hipMemcpyAsync((char*)d + at, q, m, hipMemcpyHostToDevice, s), "h2d");
         }
+        return;
     }
     hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d");
 }
-inline void h2d_big(void* d, const void* h, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d"); }   // large uploads: asynchronous when h is pinned
-inline void d2h(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }
+inline void h2d_big(void* d, const void* h, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "h2d"); }   // large uploads from PINNED memory: asynchronous
+// Device -> pageable host memory, synchronous.  A copy of more than a few pages into pageable memory makes the runtime pin the caller's buffer for the transfer and let go
+// of the pin later, behind the caller's back -- and the FIRST KERNEL LAUNCH OF THE NEXT CALL then reached the device 20-40 ms late (round 5: a 5 MB read-back in one
+// call, the next call's first launch 23-40 ms late, every time; this is the "start-of-process transient" of rounds 3-4, profiles/r05_first_steps_transient.md).  Such copies
+// go through the context's pinned ring in 4 MB pieces instead: one more memcpy on the host, no pinning by the runtime.  (A destination that IS pinned: d2h_pinned.)
+inline void d2h(void* h, const void* d, size_t n, devStream_t s) {
+    if (!n) return;
+    constexpr size_t DIRECT_MAX = (size_t)64 << 10;
+    PinRing* r = pin_ring_of_thread();
+    if (n > DIRECT_MAX && !pageable_direct() && pin_ring_ready(r, s)) {
+        for (size_t at = 0; at < n; at += PIN_CHUNK) {
+            const size_t m = n - at < PIN_CHUNK ? n - at : PIN_CHUNK;
+            char* q = pin_ring_take(r, m);
+            hip_check(hipMemcpyAsync(q, (const char*)d + at, m, hipMemcpyDeviceToHost, s), "d2h");
+            hip_check(hipStreamSynchronize(s), "d2h sync");
+            memcpy((char*)h + at, q, m);
+        }
+        return;
+    }
+    hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync");
+}
+inline void d2h_pinned(void* h, const void* d, size_t n, devStream_t s) { if (n) { hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); hip_check(hipStreamSynchronize(s), "d2h sync"); } }   // h: pinned memory
 inline void d2h_async(void* h, const void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "d2h"); }   // h: pinned memory; the caller synchronises
 inline void d2d(void* d, const void* s_, size_t n, devStream_t s) { if (n) hip_check(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s), "d2d"); }
 inline void dzero(void* d, size_t n, devStream_t s) { if (n) hip_check(hipMemsetAsync(d, 0, n, s), "memset"); }
@@ -174,6 +206,7 @@ namespace skh {
 struct PinBuf {
     void* p = nullptr; size_t cap = 0;
     ~PinBuf() { if (p) pin_free(p); }
+    bool holds(const void* q) const { return p && (const char*)q >= (const char*)p && (const char*)q < (const char*)p + cap; }
     void* need(size_t bytes) { if (bytes > cap) { if (p) pin_free(p); p = nullptr; cap = 0; p = pin_alloc(bytes + bytes / 2); cap = bytes + bytes / 2; } return p; }
 };
 

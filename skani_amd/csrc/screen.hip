@@ -492,6 +492,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     const uint32_t N = S->n_genomes;
     if (!screen_parts_fit(ctx, N)) throw Error("screen_partial_cells: the count matrix does not fit");
     if (!S->mk_off[N]) return;
+    StageTrace tr(ctx);
     // the smallest marker of part r (its sorted field is marker >> 10, 32 bits).  A marker is the smaller of a 21-mer and its reverse complement, so a fraction 1 - (1 - x)^2 of
     // them lies below x of the range: the parts are cut at the quantiles of that distribution, not at equal widths (two equal halves would hold 75 % and 25 % of the keys).
     // Every rank computes the same bounds: IEEE division and square root are exactly rounded.
@@ -499,14 +500,19 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     uint64_t* range_lo = ctx->arena.get<uint64_t>(N); uint32_t* range_cnt = ctx->arena.get<uint32_t>(N); uint32_t* part_off = ctx->arena.get<uint32_t>(N + 1);
     SKH_LAUNCH(screen_part_ranges_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)S->d_mk_off.p, N, bound(part), bound(part + 1), range_lo, range_cnt);
     check_launch("screen_part_ranges");
+    tr.mark("screen part: ranges kernel");
     exclusive_scan_u32(ctx, range_cnt, N, part_off);
+    tr.mark("screen part: scan");
     uint32_t n = 0;
     d2h(&n, part_off + N, 4, ctx->stream);
+    tr.mark("screen part: d2h n");
     if (!n) return;
     uint64_t* raw = ctx->arena.get<uint64_t>(n); uint64_t* keys = ctx->arena.get<uint64_t>(n);
     SKH_LAUNCH(screen_part_keys_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)range_lo, (const uint32_t*)part_off, N, n, raw);
     check_launch("screen_part_keys");
+    tr.mark("screen part: ranges + keys");
     sort_keys_u64_into(ctx, raw, keys, n, SCREEN_SORT_BITS);
+    tr.mark("screen part: sort");
     const uint64_t plane = (uint64_t)N * N;
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
@@ -523,6 +529,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         dzero(row_nz, (size_t)N * 4, ctx->stream);
         SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
         check_launch("screen_count(part)");
+        tr.mark("screen part: count (first touch)");
         exclusive_scan_u32(ctx, row_nz, N, row_off);
         uint32_t total = 0;
         d2h(&total, row_off + N, 4, ctx->stream);
@@ -530,6 +537,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         SKH_LAUNCH(screen_emit_cells_kernel, N, 256, 0, ctx->stream, ctx->part_cnt.p, N, (const uint32_t*)row_nz, (const uint32_t*)row_off, packed);
         check_launch("screen_emit_cells");
         dsync(ctx->stream);
+        tr.mark("screen part: emit");
         ctx->part_cnt_clean = true;
         *d_cells = total ? packed : nullptr; *n_cells = total;
         return;
@@ -538,9 +546,11 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     dzero(cnt, plane * n_planes * 4, ctx->stream);
     SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
+    tr.mark("screen part: zero + count");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
     threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, d_cells, n_cells);
     dsync(ctx->stream);
+    tr.mark("screen part: threshold + pack");
 }
 
 // the triangle's candidate pairs from the gathered cells of all parts: counts added up in a dense matrix, every row through the rule (triangle.rs:71-90 with screen_refs)

@@ -26,6 +26,7 @@ inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d
 inline void h2d_big(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
 inline void d2h(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
 inline void d2h_async(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
+inline void d2h_pinned(void* h, const void* d, size_t n, devStream_t) { if (n) memcpy(h, d, n); }
 inline void d2d(void* d, const void* s, size_t n, devStream_t) { if (n) memmove(d, s, n); }
 inline void dzero(void* d, size_t n, devStream_t) { if (n) memset(d, 0, n); }
 inline void dfill(void* d, int byte, size_t n, devStream_t) { if (n) memset(d, byte, n); }
