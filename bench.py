@@ -825,15 +825,14 @@ def main():
         if sn == n_local and order == "shuffled":                      # (8 GPUs: the weak default IS config 4)
             s = out
         else:
-            s = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, sn, "shuffled", True, max(1, args.strong_steps), max(args.warmup, 4 if world == 1 else 2),
+            s = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, sn, "shuffled", True, max(1, args.strong_steps), max(args.warmup, 2),
                              want_cpu=False, want_e2e=False)
         if rank == 0:
             out["strong"] = {k: s[k] for k in ("ms_per_step", "ms_per_step_median_rank0", "step_wall_ms_rank0", "value", "steps", "warmup", "bases_per_s_per_gpu", "chained_pairs_per_s_per_gpu",
                                                "genomes_per_s_per_gpu", "phase_ms_per_step")}
             out["strong"].update({"collection": args.strong_collection, "genomes_per_gpu": sn, "chained_pairs": s["config"]["chained_pairs"], "order": "shuffled",
                                   "note": "the same N on a FIXED collection (BASELINE config 4's %d shuffled genomes, %d per GPU): speed-up over N = this block's ms_per_step at "
-                                          "N = 1 / at N; the start-of-process transient at this size (profiles/r04_first_steps_transient.md) is why its warm-up is at least 4 steps on one GPU"
-                                          % (args.strong_collection, sn)})
+                                          "N = 1 / at N; every step's wall time on rank 0 is listed (step_wall_ms_rank0)" % (args.strong_collection, sn)})
             if "per_rank" in s:
                 out["strong"]["per_rank"] = s["per_rank"]
     if rank == 0:

@@ -259,7 +259,7 @@ void genomes_finish(skh_ctx* ctx, skh_genome_set* gs) {
     for (uint32_t i = 1; i < nc && sorted; i++) sorted = gs->contigs[i - 1].genome <= gs->contigs[i].genome;
     if (!sorted) {
         std::stable_sort(gs->contigs.begin(), gs->contigs.end(), [](const ContigDesc& a, const ContigDesc& b) { return a.genome < b.genome; });
-        h2d_big(gs->d_contigs.p, gs->contigs.data(), (size_t)nc * sizeof(ContigDesc), ctx->stream);
+        h2d(gs->d_contigs.p, gs->contigs.data(), (size_t)nc * sizeof(ContigDesc), ctx->stream);
     }
     // tile list in (genome, contig, window) order
     gs->tiles.clear();

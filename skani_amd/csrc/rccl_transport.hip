@@ -84,7 +84,7 @@ struct RcclTransport : Transport {
             for (int r = 0; r < world; r++) if (r != rank && (send_cnt[r] || recv_cnt[r])) peers = true;
             if (!peers) return;
             DBuf<char> ds(sb + 1), dr(rb + 1);
-            for (int r = 0; r < world; r++) if (r != rank && send_cnt[r]) h2d_big(ds.p + send_off[r], (const char*)send + send_off[r], send_cnt[r], ctx->stream);
+            for (int r = 0; r < world; r++) if (r != rank && send_cnt[r]) h2d(ds.p + send_off[r], (const char*)send + send_off[r], send_cnt[r], ctx->stream);   // (pageable source: through the pinned ring, dev.h)
             rccl_check(api().GroupStart(), "ncclGroupStart");
             for (int r = 0; r < world; r++) {
                 if (r == rank) continue;
@@ -92,8 +92,8 @@ struct RcclTransport : Transport {
                 if (recv_cnt[r]) rccl_check(api().Recv(dr.p + recv_off[r], recv_cnt[r], ncclUint8, r, comm, ctx->stream), "ncclRecv");
             }
             rccl_check(api().GroupEnd(), "ncclGroupEnd");
-            for (int r = 0; r < world; r++) if (r != rank && recv_cnt[r]) d2h_async((char*)recv + recv_off[r], dr.p + recv_off[r], recv_cnt[r], ctx->stream);
-            dsync(ctx->stream);                                                       // (the staging buffers go with this scope: nothing of theirs may still be queued)
+            dsync(ctx->stream);
+            for (int r = 0; r < world; r++) if (r != rank && recv_cnt[r]) d2h((char*)recv + recv_off[r], dr.p + recv_off[r], recv_cnt[r], ctx->stream);   // (pageable destination: through the pinned ring)                                                       // (the staging buffers go with this scope: nothing of theirs may still be queued)
             return;
         }
         const char* s = (const char*)send; char* rv = (char*)recv;

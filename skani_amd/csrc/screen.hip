@@ -561,7 +561,7 @@ void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* ce
     uint64_t* d = ctx->arena.get<uint64_t>(n_cells + 2);                              // one block: its head, the cells
     const uint64_t head[2] = {n_cells, 0};
     h2d(d, head, 16, ctx->stream);
-    if (n_cells) h2d_big(d + 2, cells, n_cells * 8, ctx->stream);
+    if (n_cells) h2d(d + 2, cells, n_cells * 8, ctx->stream);                         // (the caller's array is pageable: through the pinned ring, dev.h)
     screen_from_cells_dev(ctx, S, d, 1, n_cells + 2, n_cells, identity, rescue_small, first, second);
 }
 // the cells in device memory, in `n_blocks` blocks of `block_words` words (screen_add_cells_kernel); max_cells: the largest block's number of cells
