@@ -82,7 +82,6 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
-        ctx->tune.screen_first_touch_max = (uint32_t)env("SKH_TUNE_SCREEN_FIRST_TOUCH_MAX", ctx->tune.screen_first_touch_max);
         ctx->tune.wide_sweep_dp = (uint32_t)env("SKH_TUNE_WIDE_SWEEP_DP", 0);
         ctx->tune.scan_one_max = env("SKH_TUNE_SCAN_ONE_MAX", ctx->tune.scan_one_max); ctx->tune.scan_two_max = env("SKH_TUNE_SCAN_TWO_MAX", ctx->tune.scan_two_max);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);

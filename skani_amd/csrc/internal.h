@@ -59,7 +59,6 @@ struct skh_tunables {
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
     uint32_t wide_sweep_dp = 0;                         // 1: a run on 64-bit coordinates chains with the wave-per-chunk sweep kernel whatever its band (the form before round 5; tests)
-    uint32_t screen_first_touch_max = 32u << 20;        // keys of a key-range part up to which its cells are counted with first-touch row counts into the context's persistent matrix (screen.hip)
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged

@@ -71,10 +71,8 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
         const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
         if (lo < row0 || lo >= row0 + rows) continue;
         uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
-        // (FIRST pays for the increment's old value.  Measured at 10,000 genomes: parts of a world of 2 / 4 / 8 take 4.0 / 2.2 / 1.35 ms against 4.4 / 2.6 / 1.8 ms with plain
-        // increments + zeroing + a counting pass; ONE part over all 50 M keys of a CLADE-ORDERED collection -- the 19 cells of a genome's relatives share a cache line, and a wave
-        // now waits for increments that queue on that line -- takes 28 ms against 9.7: such a part keeps the plain form, screen_partial_cells_dev.  Reading the cell first and
-        // asking for the old value only where it reads zero was slower everywhere: 6.5 / 3.5 / 1.95 ms.)
+        // (FIRST asks for the increment's old value.  Measured at 10,000 genomes: the parts of a world of 2 / 4 / 8 take 3.9 / 2.2 / 1.34 ms against 4.4 / 2.6 / 1.8 ms with plain
+        // increments + zeroing + a counting pass over the matrix; one part over all 50 M keys 7.5 ms (clade order) / 6.9 ms (shuffled) against 8.0 / 7.2 ms.)
         if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u); }
         else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
     }
@@ -517,7 +515,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
-    if (n_planes == 1 && n <= ctx->tune.screen_first_touch_max) {
+    if (n_planes == 1) {
         // a large collection (at 10,000 genomes the matrix is 400 MB): the context's own matrix, zero between calls; counting notes every row's number of non-zero cells,
         // emitting puts the cells back to zero.  (Before: the matrix zeroed, counted, then read twice -- 1.2 GB of traffic for ~160,000 cells on every rank.)
         if (ctx->part_cnt.n < plane || !ctx->part_cnt_clean) {
