@@ -224,10 +224,21 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         ss = new_sketch_set(ctx, *sp, gs->n_genomes, genome_rank);
         ss->compact = (flags & SKH_SKETCH_COMPACT) != 0;
         const uint32_t ng = gs->n_genomes;
-        ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
-        for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
-        finalize_metadata(ss);
-        tr.mark("sketch: metadata");
+        // The set's host metadata (contig tables, padded contig starts, length quantiles: ~0.1 ms per 1000 genomes) is made WHILE the seeding kernel runs, not in front of
+        // it -- the device used to idle for it at the start of every sketch call.  The one thing the seeding needs beforehand is whether the set is a wide one.
+        bool wide = false;
+        {
+            std::vector<uint64_t> span(ng, CTG_PAD);
+            for (uint32_t i = 0; i < gs->n_contigs; i++) span[gs->contigs[i].genome] += (uint64_t)gs->contigs[i].len + CTG_PAD;
+            for (uint32_t g = 0; g < ng && !wide; g++) wide = span[g] >= ctx->tune.wide_span;
+        }
+        const std::function<void()> metadata = [&] {
+            ss->ctg_off = gs->genome_contig_off; ss->ctg_len.resize(gs->n_contigs); ss->total_len.assign(ng, 0);
+            for (uint32_t i = 0; i < gs->n_contigs; i++) { ss->ctg_len[i] = gs->contigs[i].len; ss->total_len[gs->contigs[i].genome] += gs->contigs[i].len; }
+            finalize_metadata(ss);
+            if (ss->wide != wide) throw Error("internal: the set's width was misjudged ahead of its metadata");
+        };
+        tr.mark("sketch: set made");
         SeedOutput so;
         // Phase times from three events on the main stream, read when the call is over: nothing waits between the seeding's last kernel (the
         // compaction, ~0.3 ms) and the table build, whose host-side tables are prepared while that kernel runs.
@@ -237,7 +248,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             ev[2].record(ctx->stream); ev[2].wait();
             ctx->timings.seed_ms += DevEvent::ms(ev[0], ev[1]); ctx->timings.sketch_build_ms += DevEvent::ms(ev[1], ev[2]);
         };
-        seed_genomes(ctx, gs, *sp, so, true, ss->wide);
+        seed_genomes(ctx, gs, *sp, so, true, wide, &metadata);
         ev[1].record(ctx->stream);
         tr.mark("sketch: seeded");
         // (from here on kernels may still be queued that read the arena's scratch and write `so`: no buffer goes away on an error before they are done)

@@ -275,7 +275,8 @@ struct SeedOutput {   // position-ordered raw seeding output for a whole genome 
     std::vector<uint64_t> pos_off, mk_off;   // per genome, n_genomes+1
     bool tail_pending = false;               // the last kernel writing these arrays is still queued on the context's stream
 };
-void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail = false, bool wide = false);
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail = false, bool wide = false,
+                  const std::function<void()>* meanwhile = nullptr);   // meanwhile: host work done once, behind the first seeding launch and in front of its read-back (the kernel runs for milliseconds)
 
 // ---- sketch_build.hip
 // needs p_seed, pos_off, contig tables (finalize_metadata) filled, and either p_g (pos == cc == null) or pos / cc = device

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void seed_compact_kernel(const SeedTile* __res
 
 // async_tail: a set seeded in ONE launch returns with its compaction kernel still queued (no wait, the arena not rewound): the caller queues the table
 // build behind it and prepares that build's host tables meanwhile; out.tail_pending says so
-void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail, bool wide) {
+void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp, SeedOutput& out, bool async_tail, bool wide, const std::function<void()>* meanwhile) {
     out.tail_pending = false; out.wide = wide;
     const uint64_t thr = ~0ull / (uint64_t)sp.c, thr_m = ~0ull / (uint64_t)sp.marker_c;   // seeding.rs:258-259
     const size_t n_tiles = gs->tiles.size();
@@ -709,6 +709,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         SKH_LAUNCH(seed_got_kernel, (ng + 1 + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)loc_s, (const uint32_t*)loc_m, (const uint32_t*)blk_s, (const uint32_t*)blk_m, nblk,
                    (const uint32_t*)n_ovf, nt, (const uint32_t*)gs->d_genome_first_tile.p, ng, (uint32_t)t0, d_got);
         check_launch("seed_got");
+        if (meanwhile && t0 == 0) { try { (*meanwhile)(); } catch (...) { device_sync_all(); throw; } }   // (the device is busy for ~3 ms per 5 Gbases: the caller's host work belongs here, not in front of the launch; nothing queued may outlive the arena on an error)
         std::vector<uint32_t> got(2 * ((size_t)ng + 1) + 3);
         d2h(got.data(), d_got, got.size() * 4, ctx->stream);
         const uint32_t h_novf = got[2 * ((size_t)ng + 1) + 2];
@@ -744,6 +745,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
         dsync(ctx->stream);
         ctx->arena.reset();
     }
+    if (meanwhile && n_tiles == 0) (*meanwhile)();                                    // (nothing was launched: the caller's work is still to be done)
     g_ns[ng] = base_s; g_nm[ng] = base_m;
     for (uint32_t g = 0; g <= ng; g++) { out.pos_off[g] = g_ns[g]; out.mk_off[g] = g_nm[g]; }
     const uint64_t NS = out.pos_off[ng], NM = out.mk_off[ng];
