@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["alloc.hip", "scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "dist.hip", "rccl_transport.hip", "capi.hip"]
+SOURCES = ["alloc.hip", "scan.hip", "sort.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "screen_keys.hip", "chain.hip", "dist.hip", "rccl_transport.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libskani_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-ffp-contract=off"]

@@ -82,6 +82,9 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
+        ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);
+        ctx->tune.skeys_avg = (uint32_t)env("SKH_TUNE_SKEYS_AVG", ctx->tune.skeys_avg);
+        ctx->tune.skeys_cap = (uint32_t)env("SKH_TUNE_SKEYS_CAP", 0);
         ctx->tune.wide_sweep_dp = (uint32_t)env("SKH_TUNE_WIDE_SWEEP_DP", 0);
         ctx->tune.scan_one_max = env("SKH_TUNE_SCAN_ONE_MAX", ctx->tune.scan_one_max); ctx->tune.scan_two_max = env("SKH_TUNE_SCAN_TWO_MAX", ctx->tune.scan_two_max);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
@@ -260,7 +263,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             ss->dist_off.assign(ss->n_genomes + 1, 0);
             upload_set_offsets(ctx, ss);
             if (flags & SKH_SKETCH_NO_SCREEN_INDEX) build_markers(ctx, ss, so.markers_raw, so.mk_off);
-            else { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw); }
+            else { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss); }
             dsync(ctx->stream);
             book(); tail_guard.armed = false;
             return;
@@ -272,7 +275,7 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
         //  and the sketch phase grows from 1.60 to 1.81 ms)
         std::swap(ctx->stream, ctx->stream2);
-        try { uint64_t* keys_raw = nullptr; build_markers(ctx, ss, so.markers_raw, so.mk_off, &keys_raw); prepare_screen_keys(ctx, ss, keys_raw, /*async=*/keys_raw != nullptr); }   // + the screen's sorted incidence list: queued, not waited for
+        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss, /*async=*/true); }   // + the screen's sorted incidence list: its last kernel queued, not waited for
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         tr.mark("sketch: markers + screen index");

@@ -426,7 +426,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         uint64_t* d_mine = nullptr; uint64_t n_mine = 0;
         local([&] {                                                                 // (local phase 3)
             Stopwatch sw(ctx, &ctx->timings.screen_ms);
-            screen_partial_cells_dev(ctx, &Sp, 0u, 1u, &d_mine, &n_mine);             // (Sp holds this rank's part of the key range and nothing else)
+            screen_partial_cells_dev(ctx, &Sp, 0u, 1u, &d_mine, &n_mine, screen_part_bound((uint32_t)me, (uint32_t)W), screen_part_bound((uint32_t)me + 1, (uint32_t)W));   // (Sp holds this rank's part of the key range and nothing else)
         });
         tr.mark("dist: screen, my key range");
         ex_begin();

@@ -59,6 +59,9 @@ struct skh_tunables {
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
     uint32_t wide_sweep_dp = 0;                         // 1: a run on 64-bit coordinates chains with the wave-per-chunk sweep kernel whatever its band (the form before round 5; tests)
+    uint32_t screen_sort_radix = 0;                     // 1: the screen's incidence keys go through the device-wide radix sort (the form before round 5; tests, A/B runs)
+    uint32_t skeys_avg = 1400;                          // keys per bucket the incidence sort aims at (screen_keys.hip)
+    uint32_t skeys_cap = 0;                             // != 0: a lower limit than SKEYS_CAP_MAX on the keys of a bucket sorted in LDS (tests of the radix-sort way out)
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
@@ -290,12 +293,17 @@ void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, uint64_t** screen_keys_raw = nullptr);   // screen_keys_raw: also the screen's unsorted incidence keys (arena), when the fast path can make them
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
 void reap_pending_sorts(skh_ctx* ctx);   // lets go of the scratch of index sorts that have finished
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade = nullptr, bool async = false);   // async: the sort is queued, the set's PendingSort event recorded behind it, nothing waited for
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async = false);   // async: the sort's last kernel is queued, the set's PendingSort event recorded behind it, not waited for
+// screen_keys.hip: the incidence keys of the stretches [lo_g, lo_g + cnt_g) of every genome's (sorted) marker set, sorted by the marker's leading 16 bases, into out[0, n)
+struct ScreenKeysIn { const uint64_t* markers; const uint64_t* mk_off; const uint64_t* range_lo /* null: mk_off[g] */; const uint32_t* range_cnt /* null: the whole set */; uint32_t ng; uint32_t is_query; };
+bool sorted_screen_keys_fits(uint64_t n);
+void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64_t marker_lo, uint64_t marker_hi /* 0: none; the range all stretches lie in */, uint64_t* out,
+                        PendingSort* own /* null: scratch from the arena; else the sort's buffers, which outlive the call */);
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,
                   int rescue_small, std::vector<uint32_t>& first, std::vector<uint32_t>& second,
                   uint32_t row_begin = 0, uint32_t row_end = 0xFFFFFFFFu);   // rows = queries (or refs when queries == NULL) restricted to [row_begin, row_end)
@@ -307,7 +315,8 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
 void screen_from_cells(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* cells, uint64_t n_cells, double identity, int rescue_small,
                        std::vector<uint32_t>& first, std::vector<uint32_t>& second);
 // the device forms (the distributed triangle: the cells never visit the host): cells left in the arena; cells read from blocks [count, -, cells...] of block_words words
-void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells);
+void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells,
+                              uint64_t all_from = 0, uint64_t all_below = 0);   // n_parts == 1: S holds markers of [all_from, all_below) only (0: no bound) -- what the sort's buckets are laid over
 uint64_t screen_part_bound(uint32_t r, uint32_t n_parts);
 void screen_marker_parts(skh_ctx* ctx, const skh_sketch_set* S, uint32_t n_parts, std::vector<uint64_t>& lo, std::vector<uint32_t>& cnt);
 void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t* d_blocks, uint32_t n_blocks, uint64_t block_words, uint64_t max_cells, double identity, int rescue_small,

@@ -2,8 +2,8 @@
 //
 // Replaces screen.rs:190-210 (kmer_to_sketch_from_refs, the marker -> genome-ids inverted index), :148-189
 // (screen_refs), :39-77 (screen_refs_indices) and :84-142 (check_markers_quickly).
-// GPU formulation: all (marker, genome) incidences are radix-sorted by marker (the inverted index becomes runs of
-// equal markers); every incidence adds 1 to count[row][col] for each co-occurring genome on the other side; a
+// GPU formulation: all (marker, genome) incidences are sorted by marker (the inverted index becomes runs of
+// equal markers; screen_keys.hip); every incidence adds 1 to count[row][col] for each co-occurring genome on the other side; a
 // second pass applies the reference's exact cut-off rule per cell and compacts the passing pairs in
 // (row, col) order.  Counts are exact integers, so the pass set is identical to the reference's.
 #include <algorithm>
@@ -26,7 +26,8 @@ __device__ __forceinline__ uint32_t seg_of64(const uint64_t* off, uint32_t n_seg
 // the marker's leading 16 bases: half the radix passes of a full sort; the incidences of one marker then sit somewhere inside their prefix group,
 // in no particular order, and the count kernels walk the group and compare whole markers.  Distinct markers that share a prefix are rare (tens
 // of millions of markers over 2^32 prefixes).  The sorted field sits in the low bits because rocPRIM 4.2's radix_sort_keys with begin_bit > 0
-// returns unsorted output for 1,200 .. 1,000,000 keys (tools/exp/rocprim_bits.hip; sorting bits [0, 32) is fine at every size).
+// returns unsorted output for 1,200 .. 1,000,000 keys (tools/exp/rocprim_bits.hip; sorting bits [0, 32) is fine at every size) -- the radix sort is what
+// rounds 1-4 sorted the lists with and what screen_keys.hip still hands a list to when one of its buckets does not fit the LDS.
 constexpr int SCREEN_SORT_BITS = 32;
 constexpr uint64_t SCREEN_MARKER_MASK = ~(((1ull << (ID_BITS + 1)) - 1ull) << 32);         // everything but is_query and genome
 __device__ __forceinline__ uint32_t skey_genome(uint64_t key) { return (uint32_t)(key >> 32) & (uint32_t)ID_MASK; }
@@ -166,22 +167,19 @@ void reap_pending_sorts(skh_ctx* ctx) {
     auto& v = ctx->pending_sorts;
     for (size_t x = 0; x < v.size();) { if (v[x]->ev.done()) { v[x]->release(); v[x] = v.back(); v.pop_back(); } else x++; }
 }
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, uint64_t* premade, bool async) {
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async) {
     const uint32_t ng = set->n_genomes;
     if (!ng || ng > ID_MASK) { set->screen_sort.reset(); return; }
     const uint64_t MR = set->mk_off[ng];
     std::lock_guard<std::mutex> lk(set->cache_mu);
     if (set->screen_keys.n == MR && MR) return;
+    if (!sorted_screen_keys_fits(MR)) return;                                        // (the screen makes them itself then, the long way)
     set->screen_keys.alloc(MR ? MR : 1);
     if (MR) {
-        uint64_t* raw = premade;                                                     // (premade: the set's own screen_sort->raw, written by the marker build)
-        if (!raw) {
-            if (async) { if (!set->screen_sort) set->screen_sort.reset(new PendingSort()); set->screen_sort->raw.alloc(MR); raw = set->screen_sort->raw.p; } else raw = ctx->arena.get<uint64_t>(MR);
-            SKH_LAUNCH(screen_keys_kernel, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, ng, MR, 0u, raw);
-            check_launch("screen_keys");
-        }
-        // async: the sort is queued and the caller returns; whoever uses the index waits for the event on its stream
-        sort_keys_u64_into(ctx, raw, set->screen_keys.p, MR, SCREEN_SORT_BITS, async ? &set->screen_sort->tmp : nullptr);
+        // async: the last kernel is queued and the caller returns; whoever uses the index waits for the event on its stream.  The sort's scratch is the set's own then.
+        if (async && !set->screen_sort) set->screen_sort.reset(new PendingSort());
+        const ScreenKeysIn in{set->markers.p, set->d_mk_off.p, nullptr, nullptr, ng, 0u};
+        sorted_screen_keys(ctx, in, MR, 0, 0, set->screen_keys.p, async ? set->screen_sort.get() : nullptr);
         if (async) { set->screen_sort->ev.record(ctx->stream); ctx->pending_sorts.push_back(set->screen_sort); return; }
     }
     dsync(ctx->stream);
@@ -204,7 +202,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     const uint64_t* rkeys = nullptr;     // two sets: the refs' sorted incidence list (cached in the set)
     auto make_keys = [&](const skh_sketch_set* set, uint32_t n_genomes, uint64_t n, uint32_t is_query, uint64_t* out) {
         if (!n) return;
-        uint64_t* raw = ctx->arena.get<uint64_t>(n);
+        if (sorted_screen_keys_fits(n)) { sorted_screen_keys(ctx, ScreenKeysIn{set->markers.p, set->d_mk_off.p, nullptr, nullptr, n_genomes, is_query}, n, 0, 0, out, nullptr); return; }
+        uint64_t* raw = ctx->arena.get<uint64_t>(n);                                   // beyond 2^32 incidences: keys in set order, a device-wide radix sort
         SKH_LAUNCH(screen_keys_kernel, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, (const uint64_t*)set->markers.p, (const uint64_t*)set->d_mk_off.p, n_genomes, n,
                    is_query, raw);
         check_launch("screen_keys");
@@ -293,13 +292,6 @@ __global__ __launch_bounds__(256) void screen_part_ranges_kernel(const uint64_t*
     auto first_ge = [&](uint64_t v) { uint64_t lo = a, hi = b; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (markers[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
     const uint64_t x = first_ge(lo_marker), y = hi_marker ? first_ge(hi_marker) : b;
     range_lo[g] = x; range_cnt[g] = (uint32_t)(y - x);
-}
-__global__ __launch_bounds__(256) void screen_part_keys_kernel(const uint64_t* markers, const uint64_t* range_lo, const uint32_t* part_off, uint32_t ng, uint32_t n, uint64_t* keys) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    uint32_t lo = 0, hi = ng;                                                        // the genome of output e: largest g with part_off[g] <= e
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (part_off[mid] <= e) lo = mid; else hi = mid; }
-    keys[e] = screen_key(markers[range_lo[lo] + (e - part_off[lo])], 0u, lo);
 }
 // a cell on the wire: i << 43 | j << 22 | count (i, j < 2^21; a count beyond 2^22 - 1 -- genomes with millions of markers -- saturates, which no threshold notices)
 constexpr uint32_t CELL_COUNT_MAX = (1u << 22) - 1u;
@@ -484,7 +476,7 @@ void screen_partial_cells(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, 
     if (n) d2h(cells.data(), d, n * 8, ctx->stream);
 }
 // the same, the cells left in the context's arena (valid until its next reset)
-void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells) {
+void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t part, uint32_t n_parts, uint64_t** d_cells, uint64_t* n_cells, uint64_t all_from, uint64_t all_below) {
     *d_cells = nullptr; *n_cells = 0;
     std::vector<uint32_t> none_a, none_b;
     const uint32_t N = S->n_genomes;
@@ -505,12 +497,9 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     d2h(&n, part_off + N, 4, ctx->stream);
     tr.mark("screen part: d2h n");
     if (!n) return;
-    uint64_t* raw = ctx->arena.get<uint64_t>(n); uint64_t* keys = ctx->arena.get<uint64_t>(n);
-    SKH_LAUNCH(screen_part_keys_kernel, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)S->markers.p, (const uint64_t*)range_lo, (const uint32_t*)part_off, N, n, raw);
-    check_launch("screen_part_keys");
-    tr.mark("screen part: ranges + keys");
-    sort_keys_u64_into(ctx, raw, keys, n, SCREEN_SORT_BITS);
-    tr.mark("screen part: sort");
+    uint64_t* keys = ctx->arena.get<uint64_t>(n);
+    sorted_screen_keys(ctx, ScreenKeysIn{S->markers.p, S->d_mk_off.p, range_lo, range_cnt, N, 0u}, n, n_parts == 1 ? all_from : bound(part), n_parts == 1 ? all_below : bound(part + 1), keys, nullptr);
+    tr.mark("screen part: keys, sorted");
     const uint64_t plane = (uint64_t)N * N;
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);

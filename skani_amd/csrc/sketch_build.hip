@@ -591,21 +591,16 @@ __global__ __launch_bounds__(MARKER_THREADS) void marker_set_kernel(uint64_t* __
     for (uint32_t u = 0; u < PER; u++) if (head[u]) raw[r0 + at++] = mine[u];
     if (tid == 0) uniq[g] = tot;
 }
-// the sets, one behind the other: markers[mk_off[g] + x] = raw[raw_off[g] + x]; with `keys` also the screen's (marker, genome) incidence keys of the
-// same entries (screen.hip screen_key), still in (genome, marker) order.  One workgroup per genome: no search for the genome of an entry.
+// the sets, one behind the other: markers[mk_off[g] + x] = raw[raw_off[g] + x].  One workgroup per genome: no search for the genome of an entry.
+// (Rounds 2-4 also wrote the screen's incidence keys here, for a radix sort; the screen's keys are now made where they are bucketed, screen_keys.hip.)
 __global__ __launch_bounds__(256) void marker_gather_kernel(const uint64_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint64_t* __restrict__ mk_off,
-                                                            uint64_t* __restrict__ out, uint64_t* __restrict__ keys) {
+                                                            uint64_t* __restrict__ out) {
     const uint32_t g = blockIdx.x;
     const uint64_t r0 = raw_off[g], m0 = mk_off[g]; const uint32_t n = (uint32_t)(mk_off[g + 1] - m0);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t m = raw[r0 + i];
-        out[m0 + i] = m;
-        if (keys) keys[m0 + i] = screen_key(m, 0u, g);
-    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[m0 + i] = raw[r0 + i];
 }
 
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, uint64_t** screen_keys_raw) {
-    if (screen_keys_raw) *screen_keys_raw = nullptr;
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
     StageTrace tr(ctx);
@@ -629,11 +624,8 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
         ss->markers.alloc(MU);
         ss->d_mk_off.alloc(ng + 1); h2d(ss->d_mk_off.p, ss->mk_off.data(), (ng + 1) * 8, ctx->stream);
         if (MU) {
-            uint64_t* keys = nullptr;                                                  // the screen's incidence keys, made on the way: the set's own array (their sort outlives this call)
-            if (screen_keys_raw && ng <= SCREEN_ID_MASK) { if (!ss->screen_sort) ss->screen_sort.reset(new PendingSort()); ss->screen_sort->raw.alloc(MU); keys = ss->screen_sort->raw.p; }
-            SKH_LAUNCH(marker_gather_kernel, ng, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ss->markers.p, keys);
+            SKH_LAUNCH(marker_gather_kernel, ng, 256, 0, ctx->stream, (const uint64_t*)raw.p, (const uint64_t*)d_ro, (const uint64_t*)ss->d_mk_off.p, ss->markers.p);
             check_launch("marker_gather");
-            if (screen_keys_raw) *screen_keys_raw = keys;
         }
         dsync(ctx->stream);
         tr.mark("build: markers");

@@ -1,5 +1,6 @@
-// sort.hip -- stable LSD radix sorts over whole device arrays (rocPRIM).  Utility, not a hot kernel: it runs
-// once per sketch set (marker sets of oversized genomes, the screen's incidence list) and twice per chain batch (work orders of a few thousand keys).
+// sort.hip -- stable LSD radix sorts over whole device arrays (rocPRIM).  Utility, not a hot kernel: the marker sets of genomes beyond the LDS sort, the work
+// order of a chain batch of more than 131,072 pairs, and the screen's incidence list when a bucket of its own sort (screen_keys.hip) outgrows the LDS -- none
+// of which happens in the headline step, whose kernel trace holds no rocPRIM kernel since round 5.
 // (The test suite's CPU kernel simulator links tests/emu/emu_sort.cpp in place of this file.)
 #include <cstring>  // rocprim's texture iterator needs memset declared first
 

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "skani_amd", "csrc")
-SOURCES = ["scan.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "chain.hip", "dist.hip", "capi.hip"]   # not part of the simulator build: rccl_transport.hip (RCCL, GPU only), sort.hip (rocPRIM; emu_sort.cpp stands in), alloc.hip
+SOURCES = ["scan.hip", "pack_seed.hip", "sketch_build.hip", "screen.hip", "screen_keys.hip", "chain.hip", "dist.hip", "capi.hip"]   # not part of the simulator build: rccl_transport.hip (RCCL, GPU only), sort.hip (rocPRIM; emu_sort.cpp stands in), alloc.hip
 LIB = os.path.join(HERE, "libskani_emu.so")
 FLAGS = ["-O2", "-g", "-ffp-contract=off", "-std=c++17", "-fPIC", "-DSKANI_EMU", "-I", HERE, "-I", CSRC, "-pthread", "-Wall", "-Wno-unknown-pragmas",
          "-Wno-attributes", "-fno-strict-aliasing"]

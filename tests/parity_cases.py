@@ -333,6 +333,76 @@ def case_screen_marker_prefix_groups(ctx):
     refs.close()
 
 
+def _marker_set_import(ctx, sets):
+    rng = np.random.default_rng(11)
+    recs = []
+    for mk in sets:
+        n = 20
+        recs.append(dict(seed=rng.integers(0, 1 << 30, n, dtype=np.uint32), pos=np.arange(n, dtype=np.uint32) * 100, ctgcanon=np.zeros(n, np.uint32), markers=np.sort(mk),
+                         contig_lengths=np.array([600000], np.uint32), total_len=600000))
+    return ctx.import_sketches(sk.SketchParams(), recs, names=["g%04d" % g for g in range(len(sets))])
+
+
+def _shared_marker_counts(sets):
+    """(i, j) -> number of common markers, i < j, exactly (sparse incidence matrix times its transpose)."""
+    import scipy.sparse as sp
+    allm, inv = np.unique(np.concatenate(sets), return_inverse=True)
+    rows = np.concatenate([np.full(len(m), g, np.int64) for g, m in enumerate(sets)])
+    A = sp.csr_matrix((np.ones(len(rows), np.int64), (rows, inv)), shape=(len(sets), len(allm)))
+    C = sp.triu(A @ A.T, k=1).tocoo()
+    return {(int(i), int(j)): int(c) for i, j, c in zip(C.row, C.col, C.data) if c}
+
+
+def case_screen_incidence_sort(make_ctx):
+    """The screen's incidence list is sorted by a hand-written bucket sort (screen_keys.hip): tiles of (bucket range) x (genome group) count and scatter the keys,
+    a workgroup per bucket orders them.  Crafted marker sets -- canonical-k-mer-like values (density 2(1 - x)), clades sharing most of their markers, one marker in
+    every genome (a fine group of one prefix), two neighbouring prefixes in a hundred genomes each (a long fine group that has to be ranked), same-prefix look-alikes
+    -- through the key-range screen, whose cells are the count matrix itself: every count must equal the exact number of common markers.  Run with the default
+    bucket size, with tiny buckets (several bucket ranges per genome, thousands of buckets), with an LDS capacity the largest bucket exceeds (the radix-sort way
+    out), with the radix sort alone (the form of rounds 1-4), and with two large genomes (bucket ranges narrower than the bucket count: one genome per tile)."""
+    rng = np.random.default_rng(2026)
+    def canon(n): return np.minimum(rng.integers(0, 1 << 42, n, dtype=np.uint64), rng.integers(0, 1 << 42, n, dtype=np.uint64))
+    G, CL = 160, 8
+    universal = np.uint64(0x2AAAAAAAAAA)
+    twin = (np.uint64(123456789) << np.uint64(10)) | np.uint64(5)
+    twins = [twin, twin + np.uint64(1 << 10)]                                          # neighbouring prefixes
+    sets = []
+    for c in range(G // CL):
+        base = canon(300)
+        for m in range(CL):
+            g = c * CL + m
+            own = [base[rng.random(len(base)) < 0.7], canon(60), [universal]]
+            if g < 100: own.append([twins[0]])
+            if 60 <= g: own.append([twins[1]])
+            if g % 5 == 0: own.append(base[:20] ^ np.uint64(1))                          # look-alikes: same prefix, other low bits
+            sets.append(np.unique(np.concatenate([np.asarray(x, np.uint64) for x in own])))
+    big = [np.unique(canon(150000)) for _ in range(2)]
+    big[1] = np.unique(np.concatenate([big[1], big[0][::3]]))
+    runs = (({}, sets), ({"SKH_TUNE_SKEYS_AVG": "16"}, sets), ({"SKH_TUNE_SKEYS_AVG": "16", "SKH_TUNE_SKEYS_CAP": "64"}, sets), ({"SKH_TUNE_SCREEN_SORT_RADIX": "1"}, sets),
+            ({}, big), ({"SKH_TUNE_SKEYS_AVG": "100"}, big))
+    pairs_seen = {}
+    for env, ms in runs:
+        want = _shared_marker_counts(ms)
+        ctx = make_ctx(env)
+        try:
+            refs = _marker_set_import(ctx, ms)
+            for n_parts in (1, 3):
+                cells = np.concatenate([ctx.screen_part(refs, part, n_parts) for part in range(n_parts)])
+                i, j, c = ctx.unpack_cells(cells)
+                got = {}
+                for a, b, n in zip(i.tolist(), j.tolist(), c.tolist()): got[(a, b)] = got.get((a, b), 0) + n
+                assert got == want, (env, n_parts, len(got), len(want))
+            tri = tuple(map(tuple, (x.tolist() for x in ctx.screen(refs, None, 0.8, 0, True))))
+            qr = tuple(map(tuple, (x.tolist() for x in ctx.screen(refs, refs, 0.8, 0, True))))
+            key = len(ms)
+            if key in pairs_seen: assert pairs_seen[key] == (tri, qr), env
+            pairs_seen[key] = (tri, qr)
+            assert len(tri[0]) > 0
+            refs.close()
+        finally:
+            ctx.close()
+
+
 def case_marker_set_sizes(ctx):
     """Marker sets of a batch are made by one workgroup per genome in LDS (up to 8192 raw markers per genome), else by device-wide passes: genomes just
     below the capacity, a batch with one genome above it, an empty one."""

@@ -187,3 +187,13 @@ def test_emu_reference_copies_2_to_the_32_apart(monkeypatch):
         finally:
             c.close()
     assert got[0] == got[1]
+
+
+def test_emu_screen_incidence_sort(monkeypatch):
+    def make_ctx(env):
+        import os
+        for k, v in env.items(): os.environ[k] = v
+        try: return sk.Context(0, lib=emu_lib())
+        finally:
+            for k in env: os.environ.pop(k, None)
+    pc.case_screen_incidence_sort(make_ctx)

@@ -42,6 +42,13 @@ def test_triangle_dense_sketches(ctx): pc.case_triangle_synthetic(ctx, params=((
 def test_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_screen_marker_prefix_groups(ctx): pc.case_screen_marker_prefix_groups(ctx)
 def test_marker_set_sizes(ctx): pc.case_marker_set_sizes(ctx)
+def test_screen_incidence_sort():
+    def make_ctx(env):
+        for k, v in env.items(): os.environ[k] = v
+        try: return sk.Context(0)
+        finally:
+            for k in env: os.environ.pop(k, None)
+    pc.case_screen_incidence_sort(make_ctx)
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
 def test_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
