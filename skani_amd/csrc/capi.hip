@@ -82,6 +82,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
+        ctx->tune.build_resalt_all = (uint32_t)env("SKH_TUNE_BUILD_RESALT_ALL", 0);
         ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);
         ctx->tune.skeys_avg = (uint32_t)env("SKH_TUNE_SKEYS_AVG", ctx->tune.skeys_avg);
         ctx->tune.skeys_cap = (uint32_t)env("SKH_TUNE_SKEYS_CAP", 0);
@@ -279,8 +280,8 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         tr.mark("sketch: markers + screen index");
-        build_sketch_tables_finish(ctx, ss, tb);
-        prepare_halves(ctx, ss);                                                      // (host work + an upload while the last kernels run; chain.hip)
+        if (!ss->compact) prepare_halves(ctx, ss, /*ahead=*/true);                    // (host work + an upload while the build's kernels run; chain.hip)
+        if (build_sketch_tables_finish(ctx, ss, tb) || ss->compact) prepare_halves(ctx, ss, false, /*again=*/true);
         book(); tail_guard.armed = false;
         tr.mark("sketch: tables finished");
     });

@@ -122,7 +122,13 @@ template <class T> T* upload(skh_ctx* ctx, const std::vector<T>& v) {
 
 // the host's and the device's per-genome tables of a set whose seed tables exist, made ahead of the first chaining call (the sketch call does it while it waits for its last
 // kernels: ~30 us of host work and an upload that would otherwise sit between the screen and the join)
-void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S) { if (S->tables_built && S->n_genomes) { genome_halves(S); (void)dev_halves(ctx, S); } }
+// Round 5: made AHEAD, while the table build's kernels still run -- everything in the tables is known when the build is queued except a genome's salt (another one only
+// when its seeds crowd a stretch of the hash range: rare) and, for a compact set, the place of its list storage; the build's finish says when either changed and the tables
+// are made again.  (After the build's read-back the device is idle: 30-40 us per step.)
+void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S, bool ahead, bool again) {
+    if (again) drop_halves(S);
+    if ((S->tables_built || ahead) && S->n_genomes) { genome_halves(S); (void)dev_halves(ctx, S); }
+}
 
 // what the host keeps of a pair (the descriptor itself is made on the device: expand_pairs_kernel)
 struct HostPair { uint32_t a_n, b_nbk, tile0, flags, a_nctg, b_nctg; };

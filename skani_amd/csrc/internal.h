@@ -59,6 +59,7 @@ struct skh_tunables {
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)
     uint32_t chain_super_tiles = 1u << 20;              // join tiles per count pass (6 KiB of probe records each)
     uint32_t wide_sweep_dp = 0;                         // 1: a run on 64-bit coordinates chains with the wave-per-chunk sweep kernel whatever its band (the form before round 5; tests)
+    uint32_t build_resalt_all = 0;                      // 1: the table build treats every genome as crowded once (tests: the second salt, and what was derived from the set ahead of the build's end)
     uint32_t screen_sort_radix = 0;                     // 1: the screen's incidence keys go through the device-wide radix sort (the form before round 5; tests, A/B runs)
     uint32_t skeys_avg = 1400;                          // keys per bucket the incidence sort aims at (screen_keys.hip)
     uint32_t skeys_cap = 0;                             // != 0: a lower limit than SKEYS_CAP_MAX on the keys of a bucket sorted in LDS (tests of the radix-sort way out)
@@ -287,7 +288,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
 struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                    // a table build that is queued but not yet waited for
 TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
-void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);
+bool build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);   // true: a salt changed or the list storage moved
 void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
 void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::vector<uint64_t>& seg);   // dist.hip: segments of 32-bit words (src offset, dst offset, words) x n
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
@@ -330,7 +331,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* loca
 void comm_selftest(skh_ctx* ctx, Transport& T);
 
 // ---- chain.hip
-void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S);   // per-genome tables (host + device) ahead of the first chaining call
+void prepare_halves(skh_ctx* ctx, const skh_sketch_set* S, bool ahead = false, bool again = false);   // per-genome tables (host + device) ahead of the first chaining call; ahead: while the set's table build is still running; again: drop what was made ahead
 // chain_seeds for a list of pairs; pair p takes its reference from Rsets[pair_rset[p]] and its query from Qsets[pair_qset[p]] (null set-index array: set 0)
 void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rsets, const uint32_t* pair_rset, const skh_sketch_set* const* Qsets, uint32_t n_qsets,
                  const uint32_t* pair_qset, const uint32_t* pair_ref, const uint32_t* pair_query, uint64_t n_pairs, const skh_map_params& mp, skh_ani_result* out,

@@ -494,13 +494,16 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
 
 // Reads the build's counters back (synchronises).  A genome whose seeds crowded one stretch of the hash range (more than TAB_SLACK entries pushed past the
 // end of a slice) is indexed again under the next salt -- the reference's HashMap takes any key set (types.rs:281-320) -- by a build over those genomes only.
-void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb) {
+// returns true when what was derived from the set while the build ran is stale: a genome took another salt, or the list storage moved (chain.hip prepare_halves)
+bool build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb) {
     const uint32_t ng = ss->n_genomes;
+    bool moved = false;
     std::vector<uint32_t> back(tb.n, 0), distinct(ng, 0), ms_used(ng, 0), again;
     if (tb.d_back) d2h(back.data(), tb.d_back, tb.n * 4, ctx->stream);               // the build's one read-back (synchronises)
     else dsync(ctx->stream);
     for (uint32_t attempt = 0;; attempt++) {
         again.clear();
+        if (attempt == 0 && ctx->tune.build_resalt_all) for (uint32_t g = 0; g < ng; g++) back[g] |= 1u;   // tests: every genome is indexed again under salt 1
         for (uint32_t g = 0; g < ng; g++) {
             if (back[g] & 2u) throw Error("seed table: a genome's seed lists do not fit their storage");
             if (back[g] & 1u) again.push_back(g); else if (attempt == 0 || ss->salt[g] == attempt) { distinct[g] = back[ng + g]; ms_used[g] = back[2 * (size_t)ng + g]; }
@@ -508,6 +511,7 @@ void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb
         if (again.empty()) break;
         if (attempt >= 15) throw Error("seed table overflow: a genome's seeds crowd one stretch of the hash range under every salt tried");
         for (uint32_t g : again) ss->salt[g] = attempt + 1;
+        moved = true;
         uint32_t* d_back = queue_table_build(ctx, ss, &again);
         std::fill(back.begin(), back.end(), 0u);
         d2h(back.data(), d_back, tb.n * 4, ctx->stream);
@@ -521,8 +525,10 @@ void build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb
         copy_segments(ctx, ss->ms.p, small.p, seg);
         dsync(ctx->stream);
         ss->ms = std::move(small); ss->ms_off = off;
+        moved = true;
     }
     ss->tables_built = true;
+    return moved;
 }
 
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss_c) {

@@ -197,3 +197,15 @@ def test_emu_screen_incidence_sort(monkeypatch):
         finally:
             for k in env: os.environ.pop(k, None)
     pc.case_screen_incidence_sort(make_ctx)
+
+
+def test_emu_every_genome_resalted(monkeypatch):
+    """SKH_TUNE_BUILD_RESALT_ALL=1: the table build indexes every genome a second time under salt 1 -- the path of a genome whose seeds crowd a stretch of the hash
+    range, which no ordinary genome takes -- after the sketch call has made the per-genome tables of the pair descriptors AHEAD of the build's end (with salt 0):
+    they must be made again, or the join probes with the wrong hash and finds nothing."""
+    monkeypatch.setenv("SKH_TUNE_BUILD_RESALT_ALL", "1")
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        pc.case_triangle_synthetic(c, params=((1, 125),), length=60000)
+    finally:
+        c.close()

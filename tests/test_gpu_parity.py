@@ -42,6 +42,16 @@ def test_triangle_dense_sketches(ctx): pc.case_triangle_synthetic(ctx, params=((
 def test_screen_rules(ctx): pc.case_screen_rules(ctx)
 def test_screen_marker_prefix_groups(ctx): pc.case_screen_marker_prefix_groups(ctx)
 def test_marker_set_sizes(ctx): pc.case_marker_set_sizes(ctx)
+def test_every_genome_resalted(monkeypatch):
+    """SKH_TUNE_BUILD_RESALT_ALL=1 (tests/test_emu_pipeline.py has the why): the second salt through the sketch call, whose per-genome tables are made ahead of the build's end."""
+    monkeypatch.setenv("SKH_TUNE_BUILD_RESALT_ALL", "1")
+    c = sk.Context(0)
+    try:
+        pc.case_triangle_synthetic(c)
+    finally:
+        c.close()
+
+
 def test_screen_incidence_sort():
     def make_ctx(env):
         for k, v in env.items(): os.environ[k] = v
