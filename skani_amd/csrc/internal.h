@@ -95,6 +95,7 @@ struct skh_ctx {
     skh::GbdtModel model_c125, model_c200;
     skh_timings timings{};
     skh::PinBuf pin_pairs;                               // the chaining's pair descriptors (host side)
+    skh::PinBuf pin_mail;                                // a few pinned words kernels write results into that the host waits for (no copy kernel to get them: screen_keys.hip)
     skh::PinBuf pin_results;                             // skh_triangle's result rows on their way back (pinned: the read-back is one DMA, and no fresh pages are touched per call)
     skh::PinRing ring;                                   // pinned staging of this context's small uploads (dev.h h2d); entry points bind it to their thread
     skh::DBuf<uint32_t> scan_ticket;                     // two counters (one per stream), zero between scans (scan.hip)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void skeys_scan_kernel(const uint32_t* hist, 
     atomicMax(&wmax, mx);
     for (uint32_t b = b0; b < b1; b++) { off[b] = run; cursor[b] = run; run += hist[b]; }
     __syncthreads();
-    if (tid == 0) { off[nb] = tot; *max_out = wmax; }
+    if (tid == 0) { off[nb] = tot; *max_out = wmax; __threadfence_system(); }          // (max_out: pinned host memory)
 }
 
 __global__ __launch_bounds__(SKEYS_T) void skeys_bucket_sort_kernel(const uint64_t* bucketed, const uint32_t* off, BucketMap bm, uint32_t cap, uint64_t* out) {
@@ -201,24 +201,30 @@ void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64
     while ((in.ng + gg - 1) / gg > 65535u) gg <<= 1;
     if (gg > SKEYS_GG_MAX) throw Error("sorted_screen_keys: too many genomes");
     const uint32_t n_groups = (in.ng + gg - 1) / gg;
-    // scratch: the bucketed keys; hist[nbp] off[nbp + 1] cursor[nbp] max[1].  A sort that outlives the call keeps them in its own buffers.
+    // scratch: the bucketed keys; hist[nbp] off[nbp + 1] cursor[nbp].  A sort that outlives the call keeps them in its own buffers.
     const size_t n_words = (size_t)3 * nbp + 8;
     uint64_t* bucketed; uint32_t* words;
     if (own) { own->raw.alloc(n); own->tmp.alloc(n_words * 4); bucketed = own->raw.p; words = (uint32_t*)own->tmp.p; }
     else { bucketed = ctx->arena.get<uint64_t>(n); words = ctx->arena.get<uint32_t>(n_words); }
-    uint32_t* hist = words; uint32_t* off = hist + nbp; uint32_t* cursor = off + nbp + 1; uint32_t* d_max = cursor + nbp;
+    uint32_t* hist = words; uint32_t* off = hist + nbp; uint32_t* cursor = off + nbp + 1;
+    // The largest bucket goes to the host through a pinned word the scan kernel writes itself, and the host waits for THAT kernel only (an event), with the scatter already
+    // queued behind it.  (A 4-byte hipMemcpy is a copy kernel of one 1024-thread workgroup: beside the table build it waited 0.7 ms for a CU with sixteen free wave slots.)
+    volatile uint32_t* mail = (volatile uint32_t*)ctx->pin_mail.need(64);
+    *mail = 0xFFFFFFFFu;
     dzero(hist, (size_t)nbp * 4, ctx->stream);
     SKH_LAUNCH(skeys_tile_kernel<false>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, hist, (uint64_t*)nullptr);
     check_launch("skeys_hist");
-    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)hist, bm.nb, off, cursor, d_max);
+    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)hist, bm.nb, off, cursor, (uint32_t*)mail);
     check_launch("skeys_scan");
+    DevEvent scanned; scanned.record(ctx->stream);
     SKH_LAUNCH(skeys_tile_kernel<true>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, cursor, bucketed);
     check_launch("skeys_scatter");
-    uint32_t h_max = 0;
-    d2h(&h_max, d_max, 4, ctx->stream);                                              // (synchronises: the counters are dead from here on)
-    tr.mark("screen keys: bucketed");
+    scanned.wait();
+    const uint32_t h_max = *mail;
+    tr.mark("screen keys: counted");
     const uint32_t cap_max = std::min<uint32_t>(ctx->tune.skeys_cap ? ctx->tune.skeys_cap : SKEYS_CAP_MAX, SKEYS_CAP_MAX);
     if (radix_only || h_max > cap_max) {
+        dsync(ctx->stream);                                                          // (the scatter reads its cursors out of the scratch the radix sort is about to take)
         sort_keys_u64_into(ctx, bucketed, out, n, 32, own ? &own->tmp : nullptr);
         tr.mark("screen keys: radix sort (a bucket beyond the LDS)");
         return;

@@ -50,7 +50,7 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     wide) for sw in 1 0; do SKH_TUNE_WIDE_SPAN=0 SKH_TUNE_WIDE_SWEEP_DP=$sw timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 10 > gpurun_out/${tag}_wide_sweep$sw.json 2> gpurun_out/${tag}_wide_sweep$sw.err || tail -3 gpurun_out/${tag}_wide_sweep$sw.err; short gpurun_out/${tag}_wide_sweep$sw.json; done
           SKH_TUNE_WIDE_SPAN=0 timeout 900 python bench.py --cpu-clades 5 --no-e2e --strong-collection 0 --steps 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('forced wide vs oracle', d['cpu_baseline']['delta_vs_oracle'])" ;;
     sortab) for r in 1 0; do SKH_TUNE_SCREEN_SORT_RADIX=$r timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_sort_radix$r.json 2> gpurun_out/${tag}_sort_radix$r.err || tail -3 gpurun_out/${tag}_sort_radix$r.err; short gpurun_out/${tag}_sort_radix$r.json; done ;;
-    skeysavg) for a in 700 2800; do SKH_TUNE_SKEYS_AVG=$a timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_skeys_avg$a.json 2> gpurun_out/${tag}_skeys_avg$a.err || tail -3 gpurun_out/${tag}_skeys_avg$a.err; short gpurun_out/${tag}_skeys_avg$a.json; done ;;
+    skeysavg) for a in 350 700 2800; do SKH_TUNE_SKEYS_AVG=$a timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_skeys_avg$a.json 2> gpurun_out/${tag}_skeys_avg$a.err || tail -3 gpurun_out/${tag}_skeys_avg$a.err; short gpurun_out/${tag}_skeys_avg$a.json; done ;;
     predict) timeout 900 python tools/predict_scaling.py > gpurun_out/${tag}_predict_inputs.json 2> gpurun_out/${tag}_predict.err || tail -3 gpurun_out/${tag}_predict.err; cut -c1-400 gpurun_out/${tag}_predict_inputs.json ;;
     mergejoin) timeout 300 tools/exp/merge_join > gpurun_out/mergejoin_$tag.txt 2>&1; cat gpurun_out/mergejoin_$tag.txt ;;
     cli) timeout 900 python -m pytest tests/test_host_cpp.py -m gpu -x -q 2>&1 | tail -5 ;;
