@@ -214,13 +214,15 @@ void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64
     dzero(hist, (size_t)nbp * 4, ctx->stream);
     SKH_LAUNCH(skeys_tile_kernel<false>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, hist, (uint64_t*)nullptr);
     check_launch("skeys_hist");
-    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)hist, bm.nb, off, cursor, (uint32_t*)mail);
+    uint32_t* d_max = cursor + nbp;
+    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)hist, bm.nb, off, cursor, ctx->tune.skeys_no_mail ? d_max : (uint32_t*)mail);
     check_launch("skeys_scan");
     DevEvent scanned; scanned.record(ctx->stream);
     SKH_LAUNCH(skeys_tile_kernel<true>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, cursor, bucketed);
     check_launch("skeys_scatter");
-    scanned.wait();
-    const uint32_t h_max = *mail;
+    uint32_t h_max;
+    if (ctx->tune.skeys_no_mail) d2h(&h_max, d_max, 4, ctx->stream);                  // (A/B runs: the copy kernel and a wait for the whole stream)
+    else { scanned.wait(); h_max = *mail; }
     tr.mark("screen keys: counted");
     const uint32_t cap_max = std::min<uint32_t>(ctx->tune.skeys_cap ? ctx->tune.skeys_cap : SKEYS_CAP_MAX, SKEYS_CAP_MAX);
     if (radix_only || h_max > cap_max) {
