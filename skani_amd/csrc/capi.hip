@@ -86,7 +86,6 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);
         ctx->tune.skeys_avg = (uint32_t)env("SKH_TUNE_SKEYS_AVG", ctx->tune.skeys_avg);
         ctx->tune.skeys_cap = (uint32_t)env("SKH_TUNE_SKEYS_CAP", 0);
-        ctx->tune.skeys_no_mail = (uint32_t)env("SKH_TUNE_SKEYS_NO_MAIL", 0);
         ctx->tune.wide_sweep_dp = (uint32_t)env("SKH_TUNE_WIDE_SWEEP_DP", 0);
         ctx->tune.scan_one_max = env("SKH_TUNE_SCAN_ONE_MAX", ctx->tune.scan_one_max); ctx->tune.scan_two_max = env("SKH_TUNE_SCAN_TWO_MAX", ctx->tune.scan_two_max);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);
@@ -277,7 +276,11 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
         //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
         //  and the sketch phase grows from 1.60 to 1.81 ms)
         std::swap(ctx->stream, ctx->stream2);
-        try { build_markers(ctx, ss, so.markers_raw, so.mk_off); prepare_screen_keys(ctx, ss, /*async=*/true); }   // + the screen's sorted incidence list: its last kernel queued, not waited for
+        try {                                                                          // + the screen's sorted incidence list: counted beside the marker sets, its last kernel queued, not waited for
+            ScreenKeysPlan plan; uint32_t plan_max = 0;
+            build_markers(ctx, ss, so.markers_raw, so.mk_off, &plan, &plan_max);
+            prepare_screen_keys(ctx, ss, /*async=*/true, &plan, plan_max);
+        }
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
         std::swap(ctx->stream, ctx->stream2);
         tr.mark("sketch: markers + screen index");

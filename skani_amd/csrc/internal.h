@@ -62,7 +62,6 @@ struct skh_tunables {
     uint32_t build_resalt_all = 0;                      // 1: the table build treats every genome as crowded once (tests: the second salt, and what was derived from the set ahead of the build's end)
     uint32_t screen_sort_radix = 0;                     // 1: the screen's incidence keys go through the device-wide radix sort (the form before round 5; tests, A/B runs)
     uint32_t skeys_avg = 1400;                          // keys per bucket the incidence sort aims at (screen_keys.hip)
-    uint32_t skeys_no_mail = 0;                         // 1: the largest bucket comes back by a 4-byte copy instead of the pinned word (A/B runs)
     uint32_t skeys_cap = 0;                             // != 0: a lower limit than SKEYS_CAP_MAX on the keys of a bucket sorted in LDS (tests of the radix-sort way out)
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
@@ -96,7 +95,6 @@ struct skh_ctx {
     skh::GbdtModel model_c125, model_c200;
     skh_timings timings{};
     skh::PinBuf pin_pairs;                               // the chaining's pair descriptors (host side)
-    skh::PinBuf pin_mail;                                // a few pinned words kernels write results into that the host waits for (no copy kernel to get them: screen_keys.hip)
     skh::PinBuf pin_results;                             // skh_triangle's result rows on their way back (pinned: the read-back is one DMA, and no fresh pages are touched per call)
     skh::PinRing ring;                                   // pinned staging of this context's small uploads (dev.h h2d); entry points bind it to their thread
     skh::DBuf<uint32_t> scan_ticket;                     // two counters (one per stream), zero between scans (scan.hip)
@@ -296,15 +294,22 @@ void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::
 void ensure_tables(skh_ctx* ctx, const skh_sketch_set* ss);                         // builds deferred tables (once; the set's mutex makes it safe across contexts)
 // inverse of the padded-coordinate packing for export: fills device arrays pos / cc (either may be null) for entries [p0, p0+n)
 void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint64_t n, uint32_t* pos, uint32_t* cc);
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off);
+struct ScreenKeysPlan {                                   // the sort's first half (buckets laid out, counted, scanned), kept for its second half
+    bool valid = false, radix_only = false;
+    uint32_t t_base = 0, shift = 0, nb = 0, rb = 0, gg = 0, n_ranges = 0, n_groups = 0, nbp = 0;
+    uint32_t *hist = nullptr, *off = nullptr, *cursor = nullptr;
+};
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan = nullptr, uint32_t* plan_max = nullptr);   // plan: also the first half of the screen's incidence sort (its scratch: the set's PendingSort), the largest bucket read back with the set sizes
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip
 void reap_pending_sorts(skh_ctx* ctx);   // lets go of the scratch of index sorts that have finished
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async = false);   // async: the sort's last kernel is queued, the set's PendingSort event recorded behind it, not waited for
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async = false, const ScreenKeysPlan* plan = nullptr, uint32_t plan_max = 0);   // async: the sort's last kernel is queued, the set's PendingSort event recorded behind it, not waited for
 // screen_keys.hip: the incidence keys of the stretches [lo_g, lo_g + cnt_g) of every genome's (sorted) marker set, sorted by the marker's leading 16 bases, into out[0, n)
 struct ScreenKeysIn { const uint64_t* markers; const uint64_t* mk_off; const uint64_t* range_lo /* null: mk_off[g] */; const uint32_t* range_cnt /* null: the whole set */; uint32_t ng; uint32_t is_query; };
 bool sorted_screen_keys_fits(uint64_t n);
+void screen_keys_count(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n_planned, uint64_t marker_lo, uint64_t marker_hi, PendingSort* own, uint32_t* d_max /* device: the largest bucket */, ScreenKeysPlan& plan);
+void screen_keys_place(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, const ScreenKeysPlan& plan, uint32_t h_max, uint64_t* out, PendingSort* own);
 void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64_t marker_lo, uint64_t marker_hi /* 0: none; the range all stretches lie in */, uint64_t* out,
                         PendingSort* own /* null: scratch from the arena; else the sort's buffers, which outlive the call */);
 void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set* queries, double identity, int rule,

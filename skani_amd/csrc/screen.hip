@@ -167,7 +167,7 @@ void reap_pending_sorts(skh_ctx* ctx) {
     auto& v = ctx->pending_sorts;
     for (size_t x = 0; x < v.size();) { if (v[x]->ev.done()) { v[x]->release(); v[x] = v.back(); v.pop_back(); } else x++; }
 }
-void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async) {
+void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async, const ScreenKeysPlan* plan, uint32_t plan_max) {
     const uint32_t ng = set->n_genomes;
     if (!ng || ng > ID_MASK) { set->screen_sort.reset(); return; }
     const uint64_t MR = set->mk_off[ng];
@@ -179,7 +179,8 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async) {
         // async: the last kernel is queued and the caller returns; whoever uses the index waits for the event on its stream.  The sort's scratch is the set's own then.
         if (async && !set->screen_sort) set->screen_sort.reset(new PendingSort());
         const ScreenKeysIn in{set->markers.p, set->d_mk_off.p, nullptr, nullptr, ng, 0u};
-        sorted_screen_keys(ctx, in, MR, 0, 0, set->screen_keys.p, async ? set->screen_sort.get() : nullptr);
+        if (plan && plan->valid && async) screen_keys_place(ctx, in, MR, *plan, plan_max, set->screen_keys.p, set->screen_sort.get());   // (counted by the marker build already)
+        else sorted_screen_keys(ctx, in, MR, 0, 0, set->screen_keys.p, async ? set->screen_sort.get() : nullptr);
         if (async) { set->screen_sort->ev.record(ctx->stream); ctx->pending_sorts.push_back(set->screen_sort); return; }
     }
     dsync(ctx->stream);

@@ -29,7 +29,7 @@ constexpr uint32_t SKEYS_GG_MAX = 256;                // genomes of a tile (one 
 constexpr uint32_t SKEYS_CAP_MAX = 8192;              // keys of a bucket the second step holds in LDS (12 B per key)
 constexpr uint32_t SKEYS_NB_MAX = 1u << 20;
 
-struct BucketMap { uint32_t t_base, shift, nb; };
+struct BucketMap { uint32_t t_base, shift, nb; };   // (what the kernels take of a ScreenKeysPlan)
 
 // x -> 2x - x^2 on 32-bit fractions, non-decreasing: (x + 1)^2 - x^2 < 2^33, so the subtracted floor grows by at most 2 per step of x
 __host__ __device__ __forceinline__ uint32_t skeys_t(uint32_t prefix) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void skeys_scan_kernel(const uint32_t* hist, 
     atomicMax(&wmax, mx);
     for (uint32_t b = b0; b < b1; b++) { off[b] = run; cursor[b] = run; run += hist[b]; }
     __syncthreads();
-    if (tid == 0) { off[nb] = tot; *max_out = wmax; __threadfence_system(); }          // (max_out: pinned host memory)
+    if (tid == 0) { off[nb] = tot; *max_out = wmax; }
 }
 
 __global__ __launch_bounds__(SKEYS_T) void skeys_bucket_sort_kernel(const uint64_t* bucketed, const uint32_t* off, BucketMap bm, uint32_t cap, uint64_t* out) {
@@ -178,55 +178,59 @@ uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v && p < (1u << 30))
 
 bool sorted_screen_keys_fits(uint64_t n) { return n < 0xFFFFFFF0ull; }
 
-void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64_t marker_lo, uint64_t marker_hi, uint64_t* out, PendingSort* own) {
-    if (n == 0 || in.ng == 0) return;
-    if (!sorted_screen_keys_fits(n)) throw Error("sorted_screen_keys: more than 2^32 incidences in one list");
-    StageTrace tr(ctx);
+// Step 1 up to the scan: the buckets are laid out for ~n_planned keys (the exact number may come later), counted and turned into offsets; the largest count lands in *d_max
+// (device memory of the caller: it travels to the host with whatever the caller reads back next).
+void screen_keys_count(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n_planned, uint64_t marker_lo, uint64_t marker_hi, PendingSort* own, uint32_t* d_max, ScreenKeysPlan& pl) {
+    pl = ScreenKeysPlan{};
+    if (n_planned == 0 || in.ng == 0) return;
+    if (!sorted_screen_keys_fits(n_planned)) throw Error("sorted_screen_keys: more than 2^32 incidences in one list");
     // the buckets: equal slices of t over the stated range of markers, ~skeys_avg keys each
     const uint32_t t_base = skeys_t((uint32_t)(marker_lo >> 10));
     const uint64_t t_last = marker_hi ? skeys_t((uint32_t)(marker_hi >> 10)) : 0xFFFFFFFFull, span = t_last > t_base ? t_last - t_base : 0;
-    const bool radix_only = ctx->tune.screen_sort_radix != 0;                          // the form before round 5: one bucket, the radix sort over all of it
+    pl.radix_only = ctx->tune.screen_sort_radix != 0;                                  // the form before round 5: one bucket, the radix sort over all of it
     const uint32_t avg = std::max<uint32_t>(ctx->tune.skeys_avg, 16u);
-    const uint32_t want = radix_only ? 1u : std::min<uint32_t>(pow2_ceil((n + avg - 1) / avg), SKEYS_NB_MAX);
-    BucketMap bm{t_base, 0u, 0u};
-    while ((span >> bm.shift) + 1 > want) bm.shift++;
-    bm.nb = (uint32_t)((span >> bm.shift) + 1);
+    const uint32_t want = pl.radix_only ? 1u : std::min<uint32_t>(pow2_ceil((n_planned + avg - 1) / avg), SKEYS_NB_MAX);
+    pl.t_base = t_base; pl.shift = 0;
+    while ((span >> pl.shift) + 1 > want) pl.shift++;
+    pl.nb = (uint32_t)((span >> pl.shift) + 1);
     // a tile: ~8,192 keys -- (the buckets of a range) x (the genomes of a group).  Many small genomes: 1,024 buckets, several genomes; a few large ones: fewer buckets, one genome
-    const double per_genome_bucket = (double)n / (double)in.ng / (double)bm.nb;
-    uint32_t rb = std::min<uint32_t>(pow2_ceil(bm.nb), SKEYS_RB_MAX);
-    while (rb > 16 && per_genome_bucket * rb > 8192.) rb >>= 1;
-    const uint32_t n_ranges = (bm.nb + rb - 1) / rb, nbp = n_ranges * rb;
-    const uint64_t per_genome_range = std::max<uint64_t>(1, (uint64_t)(per_genome_bucket * rb));
-    uint32_t gg = (uint32_t)std::min<uint64_t>(pow2_ceil(std::max<uint64_t>(1, 8192 / per_genome_range)), SKEYS_GG_MAX);
-    while ((in.ng + gg - 1) / gg > 65535u) gg <<= 1;
-    if (gg > SKEYS_GG_MAX) throw Error("sorted_screen_keys: too many genomes");
-    const uint32_t n_groups = (in.ng + gg - 1) / gg;
-    // scratch: the bucketed keys; hist[nbp] off[nbp + 1] cursor[nbp].  A sort that outlives the call keeps them in its own buffers.
-    const size_t n_words = (size_t)3 * nbp + 8;
-    uint64_t* bucketed; uint32_t* words;
-    if (own) { own->raw.alloc(n); own->tmp.alloc(n_words * 4); bucketed = own->raw.p; words = (uint32_t*)own->tmp.p; }
-    else { bucketed = ctx->arena.get<uint64_t>(n); words = ctx->arena.get<uint32_t>(n_words); }
-    uint32_t* hist = words; uint32_t* off = hist + nbp; uint32_t* cursor = off + nbp + 1;
-    // The largest bucket goes to the host through a pinned word the scan kernel writes itself, and the host waits for THAT kernel only (an event), with the scatter already
-    // queued behind it.  (A 4-byte hipMemcpy is a copy kernel of one 1024-thread workgroup: beside the table build it waited 0.7 ms for a CU with sixteen free wave slots.)
-    volatile uint32_t* mail = (volatile uint32_t*)ctx->pin_mail.need(64);
-    *mail = 0xFFFFFFFFu;
-    dzero(hist, (size_t)nbp * 4, ctx->stream);
-    SKH_LAUNCH(skeys_tile_kernel<false>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, hist, (uint64_t*)nullptr);
+    const double per_genome_bucket = (double)n_planned / (double)in.ng / (double)pl.nb;
+    pl.rb = std::min<uint32_t>(pow2_ceil(pl.nb), SKEYS_RB_MAX);
+    while (pl.rb > 16 && per_genome_bucket * pl.rb > 8192.) pl.rb >>= 1;
+    pl.n_ranges = (pl.nb + pl.rb - 1) / pl.rb; pl.nbp = pl.n_ranges * pl.rb;
+    const uint64_t per_genome_range = std::max<uint64_t>(1, (uint64_t)(per_genome_bucket * pl.rb));
+    pl.gg = (uint32_t)std::min<uint64_t>(pow2_ceil(std::max<uint64_t>(1, 8192 / per_genome_range)), SKEYS_GG_MAX);
+    while ((in.ng + pl.gg - 1) / pl.gg > 65535u) pl.gg <<= 1;
+    if (pl.gg > SKEYS_GG_MAX) throw Error("sorted_screen_keys: too many genomes");
+    pl.n_groups = (in.ng + pl.gg - 1) / pl.gg;
+    // scratch: hist[nbp] off[nbp + 1] cursor[nbp].  A sort that outlives the call keeps them in its own buffer.
+    const size_t n_words = (size_t)3 * pl.nbp + 8;
+    uint32_t* words;
+    if (own) { own->tmp.alloc(n_words * 4); words = (uint32_t*)own->tmp.p; } else words = ctx->arena.get<uint32_t>(n_words);
+    pl.hist = words; pl.off = pl.hist + pl.nbp; pl.cursor = pl.off + pl.nbp + 1;
+    const BucketMap bm{pl.t_base, pl.shift, pl.nb};
+    dzero(pl.hist, (size_t)pl.nbp * 4, ctx->stream);
+    SKH_LAUNCH(skeys_tile_kernel<false>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.hist, (uint64_t*)nullptr);
     check_launch("skeys_hist");
-    uint32_t* d_max = cursor + nbp;
-    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)hist, bm.nb, off, cursor, ctx->tune.skeys_no_mail ? d_max : (uint32_t*)mail);
+    SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)pl.hist, pl.nb, pl.off, pl.cursor, d_max);
     check_launch("skeys_scan");
-    DevEvent scanned; scanned.record(ctx->stream);
-    SKH_LAUNCH(skeys_tile_kernel<true>, dim3(n_ranges, n_groups), SKEYS_T, 0, ctx->stream, in, bm, rb, gg, cursor, bucketed);
+    pl.valid = true;
+}
+
+// The rest: the keys into their buckets, every bucket ordered into `out` -- or, when the largest bucket (h_max, read back by the caller) does not fit the LDS, through the
+// radix sort.  `in` names the same marker stretches as the count did (they may have moved: the marker build counts them where they were deduplicated).
+void screen_keys_place(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, const ScreenKeysPlan& pl, uint32_t h_max, uint64_t* out, PendingSort* own) {
+    if (n == 0 || in.ng == 0) return;
+    if (!pl.valid || !sorted_screen_keys_fits(n)) throw Error("screen_keys_place: no plan");
+    StageTrace tr(ctx);
+    uint64_t* bucketed;
+    if (own) { own->raw.alloc(n); bucketed = own->raw.p; } else bucketed = ctx->arena.get<uint64_t>(n);
+    const BucketMap bm{pl.t_base, pl.shift, pl.nb};
+    SKH_LAUNCH(skeys_tile_kernel<true>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.cursor, bucketed);
     check_launch("skeys_scatter");
-    uint32_t h_max;
-    if (ctx->tune.skeys_no_mail) d2h(&h_max, d_max, 4, ctx->stream);                  // (A/B runs: the copy kernel and a wait for the whole stream)
-    else { scanned.wait(); h_max = *mail; }
-    tr.mark("screen keys: counted");
     const uint32_t cap_max = std::min<uint32_t>(ctx->tune.skeys_cap ? ctx->tune.skeys_cap : SKEYS_CAP_MAX, SKEYS_CAP_MAX);
-    if (radix_only || h_max > cap_max) {
-        dsync(ctx->stream);                                                          // (the scatter reads its cursors out of the scratch the radix sort is about to take)
+    if (pl.radix_only || h_max > cap_max) {
+        if (own) dsync(ctx->stream);                                                 // (the scatter reads its cursors out of the buffer the radix sort is about to take)
         sort_keys_u64_into(ctx, bucketed, out, n, 32, own ? &own->tmp : nullptr);
         tr.mark("screen keys: radix sort (a bucket beyond the LDS)");
         return;
@@ -234,9 +238,20 @@ void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64
     const uint32_t cap = std::max<uint32_t>((h_max + 255u) & ~255u, 256u);
     const size_t lds = (size_t)cap * 12;
     kernel_allow_lds(skeys_bucket_sort_kernel, lds);
-    SKH_LAUNCH(skeys_bucket_sort_kernel, bm.nb, SKEYS_T, lds, ctx->stream, (const uint64_t*)bucketed, (const uint32_t*)off, bm, cap, out);
+    SKH_LAUNCH(skeys_bucket_sort_kernel, pl.nb, SKEYS_T, lds, ctx->stream, (const uint64_t*)bucketed, (const uint32_t*)pl.off, bm, cap, out);
     check_launch("skeys_bucket_sort");
-    tr.mark("screen keys: buckets sorted");
+    tr.mark("screen keys: placed");
+}
+
+// both at once (callers with nothing else to read back: a 4-byte copy in between)
+void sorted_screen_keys(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, uint64_t marker_lo, uint64_t marker_hi, uint64_t* out, PendingSort* own) {
+    if (n == 0 || in.ng == 0) return;
+    ScreenKeysPlan pl;
+    uint32_t* d_max = ctx->arena.get<uint32_t>(4);
+    screen_keys_count(ctx, in, n, marker_lo, marker_hi, own, d_max, pl);
+    uint32_t h_max = 0;
+    d2h(&h_max, d_max, 4, ctx->stream);
+    screen_keys_place(ctx, in, n, pl, h_max, out, own);
 }
 
 }  // namespace skh

@@ -606,7 +606,8 @@ __global__ __launch_bounds__(256) void marker_gather_kernel(const uint64_t* __re
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[m0 + i] = raw[r0 + i];
 }
 
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off) {
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan, uint32_t* plan_max) {
+    if (plan) *plan = ScreenKeysPlan{};
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
     StageTrace tr(ctx);
@@ -617,14 +618,21 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
     const uint32_t lds_max = ctx->tune.marker_lds_max ? std::min<uint32_t>(ctx->tune.marker_lds_max, MARKER_LDS_MAX) : MARKER_LDS_MAX;
     if (M > 0 && max_raw <= lds_max) {                                               // one workgroup per genome, everything in LDS
         uint64_t* d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
-        uint32_t* d_uq = ctx->arena.get<uint32_t>(ng);
+        uint32_t* d_uq = ctx->arena.get<uint32_t>(ng + 1);                             // (+ the largest bucket of the screen's incidence sort)
         uint32_t N = 64; while (N < max_raw) N <<= 1;
         const size_t lds = (size_t)N * 8;
         kernel_allow_lds(marker_set_kernel, lds);
         SKH_LAUNCH(marker_set_kernel, ng, MARKER_THREADS, lds, ctx->stream, raw.p, (const uint64_t*)d_ro, d_uq);
         check_launch("marker_set");
-        std::vector<uint32_t> h_uq(ng);
-        d2h(h_uq.data(), d_uq, (size_t)ng * 4, ctx->stream);
+        // the screen's incidence sort (screen_keys.hip) counts its buckets HERE, over the sets where they were deduplicated (duplicates counted in its plan: a few per cent):
+        // its largest bucket -- what decides how its second half runs -- comes back with the set sizes, and its two kernels run while the host adds those up
+        if (plan && ng <= SCREEN_ID_MASK && sorted_screen_keys_fits(M)) {
+            if (!ss->screen_sort) ss->screen_sort.reset(new PendingSort());
+            screen_keys_count(ctx, ScreenKeysIn{raw.p, nullptr, d_ro, d_uq, ng, 0u}, M, 0, 0, ss->screen_sort.get(), d_uq + ng, *plan);
+        } else dzero(d_uq + ng, 4, ctx->stream);
+        std::vector<uint32_t> h_uq(ng + 1);
+        d2h(h_uq.data(), d_uq, (size_t)(ng + 1) * 4, ctx->stream);
+        if (plan_max) *plan_max = h_uq[ng];
         for (uint32_t g = 0; g < ng; g++) ss->mk_off[g + 1] = ss->mk_off[g] + h_uq[g];
         const uint64_t MU = ss->mk_off[ng];
         ss->markers.alloc(MU);
