@@ -577,10 +577,12 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
     t0 = time.perf_counter()
     kept = chained = 0
     step_wall = []
-    for _ in range(steps):
-        ts = time.perf_counter()
+    for k in range(steps):
+        ts = time.perf_counter(); h0 = list(host_t)
         kept, chained = step()
         step_wall.append(time.perf_counter() - ts)
+        if os.environ.get("BENCH_STEP_TIMES"):    # (interleaves with SKH_TRACE_ALLOC=1 on stderr: which call of which step went to the driver)
+            print("step %d of %d genomes: sketch_genomes %.3f ms, triangle %.3f ms, close %.3f ms" % ((k, n_local) + tuple(1e3 * (host_t[x] - h0[x]) for x in range(3))), file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

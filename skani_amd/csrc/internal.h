@@ -297,7 +297,7 @@ void unpack_positions(skh_ctx* ctx, const skh_sketch_set* ss, uint64_t p0, uint6
 struct ScreenKeysPlan {                                   // the sort's first half (buckets laid out, counted, scanned), kept for its second half
     bool valid = false, radix_only = false;
     uint32_t t_base = 0, shift = 0, nb = 0, rb = 0, gg = 0, n_ranges = 0, n_groups = 0, nbp = 0;
-    uint32_t *hist = nullptr, *off = nullptr, *cursor = nullptr;
+    uint32_t *hist = nullptr, *off = nullptr, *cursor = nullptr, *bounds = nullptr;
 };
 void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan = nullptr, uint32_t* plan_max = nullptr);   // plan: also the first half of the screen's incidence sort (its scratch: the set's PendingSort), the largest bucket read back with the set sizes
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts

@@ -42,40 +42,66 @@ __device__ __forceinline__ uint32_t skeys_bucket(const BucketMap& bm, uint64_t m
     return b < bm.nb ? b : bm.nb - 1;                                                // (a marker of the stated range never needs the clamp)
 }
 
+// where, inside genome g's stretch, the markers of bucket range r begin: bounds[g * (n_ranges + 1) + r]; entry n_ranges is the stretch's length.  A thread per entry: the
+// binary searches of all tiles at once (made by the tiles themselves, each tile began with two dozen dependent loads per genome, twice).
+__global__ __launch_bounds__(SKEYS_T) void skeys_bounds_kernel(ScreenKeysIn in, BucketMap bm, uint32_t rb, uint32_t n_ranges, uint32_t* bounds) {
+    const uint64_t t = (uint64_t)blockIdx.x * SKEYS_T + threadIdx.x; const uint32_t per = n_ranges + 1;
+    if (t >= (uint64_t)in.ng * per) return;
+    const uint32_t g = (uint32_t)(t / per), r = (uint32_t)(t % per);
+    const uint64_t a = in.range_lo ? in.range_lo[g] : in.mk_off[g];
+    const uint64_t e = a + (in.range_cnt ? (uint64_t)in.range_cnt[g] : in.mk_off[g + 1] - in.mk_off[g]);
+    uint64_t lo = a, hi = e;
+    if (r == 0) hi = a;
+    else if (r == n_ranges) lo = e;
+    else { const uint32_t v = r * rb; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (skeys_bucket(bm, in.markers[mid]) < v) lo = mid + 1; else hi = mid; } }
+    bounds[t] = (uint32_t)(lo - a);
+}
+
+// A tile: the markers of bucket range blockIdx.x in the stretches of genomes [g0, g0 + gg).  Its keys are walked as ONE list (a key's genome by a search in the LDS prefix of
+// the stretch lengths): with a loop per genome, stretches shorter than the workgroup -- 10,000 genomes, 150 keys each -- left most threads idle behind one load at a time.
 template <bool SCATTER>
-__global__ __launch_bounds__(SKEYS_T) void skeys_tile_kernel(ScreenKeysIn in, BucketMap bm, uint32_t rb, uint32_t gg, uint32_t* counters /* hist | cursors */, uint64_t* out) {
+__global__ __launch_bounds__(SKEYS_T) void skeys_tile_kernel(ScreenKeysIn in, BucketMap bm, uint32_t rb, uint32_t gg, uint32_t n_ranges, const uint32_t* __restrict__ bounds,
+                                                             uint32_t* counters /* hist | cursors */, uint64_t* out) {
     __shared__ uint32_t cnt[SKEYS_RB_MAX];
     __shared__ uint32_t base[SCATTER ? SKEYS_RB_MAX : 1];
     __shared__ uint64_t sx[SKEYS_GG_MAX];
-    __shared__ uint32_t sn[SKEYS_GG_MAX];
-    const uint32_t tid = threadIdx.x, b0 = blockIdx.x * rb, g0 = blockIdx.y * gg;
+    __shared__ uint32_t sp[SKEYS_GG_MAX + 1];
+    __shared__ uint32_t wsum[SKEYS_T / 64];
+    const uint32_t tid = threadIdx.x, b0 = blockIdx.x * rb, g0 = blockIdx.y * gg, per = n_ranges + 1;
     for (uint32_t b = tid; b < rb; b += SKEYS_T) cnt[b] = 0;
-    if (tid < gg) {
+    {
         const uint32_t g = g0 + tid;
         uint64_t x = 0; uint32_t n = 0;
-        if (g < in.ng) {
+        if (tid < gg && g < in.ng) {
             const uint64_t a = in.range_lo ? in.range_lo[g] : in.mk_off[g];
-            const uint64_t e = a + (in.range_cnt ? (uint64_t)in.range_cnt[g] : in.mk_off[g + 1] - in.mk_off[g]);
-            auto first_ge = [&](uint32_t v) { uint64_t lo = a, hi = e; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (skeys_bucket(bm, in.markers[mid]) < v) lo = mid + 1; else hi = mid; } return lo; };
-            x = first_ge(b0);
-            const uint64_t y = b0 + rb >= bm.nb ? e : first_ge(b0 + rb);
-            n = (uint32_t)(y - x);
+            const uint32_t lo = bounds[(uint64_t)g * per + blockIdx.x], hi = bounds[(uint64_t)g * per + blockIdx.x + 1];
+            x = a + lo; n = hi - lo;
         }
-        sx[tid] = x; sn[tid] = n;
+        sx[tid] = x;
+        const uint32_t incl = wave_incl_scan(n), l = tid & 63u, w = tid >> 6;
+        if (l == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t q = 0; q < w; q++) before += wsum[q];
+        sp[tid] = before + incl - n;
+        if (tid == SKEYS_T - 1) sp[SKEYS_T] = before + incl;
     }
     __syncthreads();
+    const uint32_t total = sp[gg];
     constexpr uint32_t U = 4;                                                        // loads in flight per thread
-    for (uint32_t gi = 0; gi < gg; gi++) {
-        const uint64_t x = sx[gi]; const uint32_t n = sn[gi];
-        for (uint32_t i0 = tid; i0 < n; i0 += U * SKEYS_T) {
-            uint64_t m[U];
+    auto genome_of = [&](uint32_t i) { uint32_t lo = 0, hi = gg; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= i) lo = mid; else hi = mid; } return lo; };
+    for (uint32_t i0 = tid; i0 < total; i0 += U * SKEYS_T) {
+        uint64_t m[U];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t i = i0 + u * SKEYS_T; m[u] = i < n ? in.markers[x + i] : 0ull; }
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * SKEYS_T;
+            m[u] = 0ull;
+            if (i < total) { const uint32_t gi = genome_of(i); m[u] = in.markers[sx[gi] + (i - sp[gi])]; }
+        }
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t b = skeys_bucket(bm, m[u]) - b0;
-                if (i0 + u * SKEYS_T < n && b < rb) atomicAdd(&cnt[b], 1u);
-            }
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t b = skeys_bucket(bm, m[u]) - b0;
+            if (i0 + u * SKEYS_T < total && b < rb) atomicAdd(&cnt[b], 1u);
         }
     }
     __syncthreads();
@@ -85,17 +111,18 @@ __global__ __launch_bounds__(SKEYS_T) void skeys_tile_kernel(ScreenKeysIn in, Bu
     }
     for (uint32_t b = tid; b < rb; b += SKEYS_T) { const uint32_t c = cnt[b]; base[SCATTER ? b : 0] = c ? atomicAdd(&counters[b0 + b], c) : 0u; cnt[b] = 0; }
     __syncthreads();
-    for (uint32_t gi = 0; gi < gg; gi++) {
-        const uint64_t x = sx[gi]; const uint32_t n = sn[gi];
-        for (uint32_t i0 = tid; i0 < n; i0 += U * SKEYS_T) {
-            uint64_t m[U];
+    for (uint32_t i0 = tid; i0 < total; i0 += U * SKEYS_T) {
+        uint64_t m[U]; uint32_t gi[U];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t i = i0 + u * SKEYS_T; m[u] = i < n ? in.markers[x + i] : 0ull; }
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * SKEYS_T;
+            m[u] = 0ull; gi[u] = 0;
+            if (i < total) { gi[u] = genome_of(i); m[u] = in.markers[sx[gi[u]] + (i - sp[gi[u]])]; }
+        }
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t b = skeys_bucket(bm, m[u]) - b0;
-                if (i0 + u * SKEYS_T < n && b < rb) out[base[SCATTER ? b : 0] + atomicAdd(&cnt[b], 1u)] = screen_key(m[u], in.is_query, g0 + gi);
-            }
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t b = skeys_bucket(bm, m[u]) - b0;
+            if (i0 + u * SKEYS_T < total && b < rb) out[base[SCATTER ? b : 0] + atomicAdd(&cnt[b], 1u)] = screen_key(m[u], in.is_query, g0 + gi[u]);
         }
     }
 }
@@ -203,14 +230,16 @@ void screen_keys_count(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n_planned,
     while ((in.ng + pl.gg - 1) / pl.gg > 65535u) pl.gg <<= 1;
     if (pl.gg > SKEYS_GG_MAX) throw Error("sorted_screen_keys: too many genomes");
     pl.n_groups = (in.ng + pl.gg - 1) / pl.gg;
-    // scratch: hist[nbp] off[nbp + 1] cursor[nbp].  A sort that outlives the call keeps them in its own buffer.
-    const size_t n_words = (size_t)3 * pl.nbp + 8;
+    // scratch: hist[nbp] off[nbp + 1] cursor[nbp], the genomes' range bounds.  A sort that outlives the call keeps them in its own buffer.
+    const size_t n_bounds = (size_t)in.ng * (pl.n_ranges + 1), n_words = (size_t)3 * pl.nbp + 8 + n_bounds;
     uint32_t* words;
     if (own) { own->tmp.alloc(n_words * 4); words = (uint32_t*)own->tmp.p; } else words = ctx->arena.get<uint32_t>(n_words);
-    pl.hist = words; pl.off = pl.hist + pl.nbp; pl.cursor = pl.off + pl.nbp + 1;
+    pl.hist = words; pl.off = pl.hist + pl.nbp; pl.cursor = pl.off + pl.nbp + 1; pl.bounds = pl.cursor + pl.nbp + 4;
     const BucketMap bm{pl.t_base, pl.shift, pl.nb};
     dzero(pl.hist, (size_t)pl.nbp * 4, ctx->stream);
-    SKH_LAUNCH(skeys_tile_kernel<false>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.hist, (uint64_t*)nullptr);
+    SKH_LAUNCH(skeys_bounds_kernel, (unsigned)((n_bounds + SKEYS_T - 1) / SKEYS_T), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.n_ranges, pl.bounds);
+    check_launch("skeys_bounds");
+    SKH_LAUNCH(skeys_tile_kernel<false>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.n_ranges, (const uint32_t*)pl.bounds, pl.hist, (uint64_t*)nullptr);
     check_launch("skeys_hist");
     SKH_LAUNCH(skeys_scan_kernel, 1u, 1024, 0, ctx->stream, (const uint32_t*)pl.hist, pl.nb, pl.off, pl.cursor, d_max);
     check_launch("skeys_scan");
@@ -226,7 +255,7 @@ void screen_keys_place(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, const S
     uint64_t* bucketed;
     if (own) { own->raw.alloc(n); bucketed = own->raw.p; } else bucketed = ctx->arena.get<uint64_t>(n);
     const BucketMap bm{pl.t_base, pl.shift, pl.nb};
-    SKH_LAUNCH(skeys_tile_kernel<true>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.cursor, bucketed);
+    SKH_LAUNCH(skeys_tile_kernel<true>, dim3(pl.n_ranges, pl.n_groups), SKEYS_T, 0, ctx->stream, in, bm, pl.rb, pl.gg, pl.n_ranges, (const uint32_t*)pl.bounds, pl.cursor, bucketed);
     check_launch("skeys_scatter");
     const uint32_t cap_max = std::min<uint32_t>(ctx->tune.skeys_cap ? ctx->tune.skeys_cap : SKEYS_CAP_MAX, SKEYS_CAP_MAX);
     if (pl.radix_only || h_max > cap_max) {
