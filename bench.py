@@ -510,7 +510,7 @@ def pick_sample(canon, n_total, clades):
     return np.nonzero(np.isin(canon // CLADE, list(cl)))[0]
 
 
-def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, steps, warmup, want_cpu, want_e2e):
+def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, steps, warmup, want_cpu, want_e2e, defer_cpu_legs=False):
     """One measured triangle workload: every rank makes its n_local genomes of the collection (n_local * world, in `order`), W warm-up steps, `steps` timed steps
     between barriers, the MAX over ranks.  Rank 0 returns the bench line (a dict), the others None.  want_cpu: the oracle beside it (`cpu_baseline`, rank 0 only:
     on the genomes rank 0 holds when that is the whole workload, else on whole clades sampled from the collection, which rank 0 generates for itself)."""
@@ -701,7 +701,11 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
             except Exception as e:
                 out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
     out["cpu_baseline"] = None
-    if len(cpu_ids):
+    def cpu_legs(host_genomes=host_genomes):
+        """The legs that load the host's cores (the oracle's thread sweep, the command line with its ingest threads): run by the caller AFTER every GPU measurement of the
+        line -- a `strong` block measured right behind them had one step in two 25-40 ms late (the container's CPU quota, spent by the sweep, throttles the thread that
+        drives the GPU); measured in front of them, none."""
+        if not len(cpu_ids): return
         if world > 1:                                                  # the sample's members live on every rank: rank 0 makes them again for the oracle (genomes are pure functions of their ids)
             b2, _, _, _, host_genomes = make_genomes(torch, device, canon[cpu_ids], mean_len=args.mean_len, members=CLADE, keep_host=True)
             del b2
@@ -714,6 +718,10 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
                 out["e2e"] = e2e_leg(host_genomes, max(4, min(host_cores()[1], 64, int(round(q)) * 2 if q else 64)), gpus=world, one_device=args.one_device)
             except Exception as e:                                   # the headline line must not depend on a RAM disk
                 out["e2e"] = {"error": repr(e)}
+    if defer_cpu_legs:
+        out["_cpu_legs"] = cpu_legs
+    else:
+        cpu_legs()
     return out
 
 
@@ -816,7 +824,7 @@ def main():
                 comm = Comm.host(ctx, dist, rank, world, torch=torch)
 
     out = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, args.steps, args.warmup,
-                       want_cpu=True, want_e2e=not args.no_e2e and not strong)
+                       want_cpu=True, want_e2e=not args.no_e2e and not strong, defer_cpu_legs=True)
     # the same N on the fixed collection (BASELINE config 4's 10,000 genomes): the strong-scaling point that belongs to this line.  A default sweep --gpus 1/2/4/8 then
     # yields the weak series (`value`) AND the strong one (`strong.ms_per_step`) without a second sweep.
     default_shape = not args.genomes_per_gpu and args.mean_len == 5_000_000 and CLADE == 20 and C == 125 and not args.force_dist
@@ -838,6 +846,7 @@ def main():
             if "per_rank" in s:
                 out["strong"]["per_rank"] = s["per_rank"]
     if rank == 0:
+        out.pop("_cpu_legs")()                                         # (cpu_baseline, e2e: behind every GPU measurement, see run_triangle)
         print(json.dumps(out))
     if comm is not None:
         comm.close()
