@@ -80,7 +80,7 @@ struct skh_tunables {
 
 namespace skh {
 struct PendingSort {
-    DBuf<uint64_t> raw; DBuf<char> tmp; DevEvent ev; std::mutex mu;
+    DBuf<uint64_t> raw; DBuf<char> tmp; DevEvent ev; std::mutex mu;                  // raw: the keys in their buckets; tmp: bucket counters, offsets, cursors, range bounds (screen_keys.hip)
     void release() { std::lock_guard<std::mutex> lk(mu); raw.release(); tmp.release(); }   // (only once the event is done)
 };
 }  // namespace skh
@@ -192,7 +192,7 @@ struct skh_sketch_set {
     // The index made at sketch time is sorted on the context's second stream and the sketch call does NOT wait for it (round 5): its last passes run while the host
     // returns to its caller and comes back with the screen -- they used to be a 0.18 ms tail behind the table build in front of ~0.1 ms of host time.  What the
     // sort still works on is let go when the event behind it is done: by the screen that waited for it, by the context's next call, or with the set.
-    // (PendingSort: the unsorted keys, rocPRIM's scratch and the event behind the sort; shared with the context that queued it, which lets go of the two buffers as soon
+    // (PendingSort: the bucketed keys, the sort's counters and bounds -- or the radix sort's scratch -- and the event behind the sort; shared with the context that queued it, which lets go of the two buffers as soon
     //  as it sees the event done -- a resident database's shards are never screened themselves and would keep 16 bytes per marker for ever)
     mutable std::shared_ptr<skh::PendingSort> screen_sort;
     ~skh_sketch_set() { if (screen_sort) { try { screen_sort->ev.wait(); } catch (...) {} } }
