@@ -86,7 +86,6 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);
         ctx->tune.skeys_avg = (uint32_t)env("SKH_TUNE_SKEYS_AVG", ctx->tune.skeys_avg);
         ctx->tune.skeys_cap = (uint32_t)env("SKH_TUNE_SKEYS_CAP", 0);
-        ctx->tune.skeys_flags = (uint32_t)env("SKH_TUNE_SKEYS_FLAGS", ctx->tune.skeys_flags);
         ctx->tune.wide_sweep_dp = (uint32_t)env("SKH_TUNE_WIDE_SWEEP_DP", 0);
         ctx->tune.scan_one_max = env("SKH_TUNE_SCAN_ONE_MAX", ctx->tune.scan_one_max); ctx->tune.scan_two_max = env("SKH_TUNE_SCAN_TWO_MAX", ctx->tune.scan_two_max);
         ctx->tune.dist_fail = (uint32_t)env("SKH_TUNE_DIST_FAIL", 0);

@@ -62,7 +62,6 @@ struct skh_tunables {
     uint32_t build_resalt_all = 0;                      // 1: the table build treats every genome as crowded once (tests: the second salt, and what was derived from the set ahead of the build's end)
     uint32_t screen_sort_radix = 0;                     // 1: the screen's incidence keys go through the device-wide radix sort (the form before round 5; tests, A/B runs)
     uint32_t skeys_avg = 1400;                          // keys per bucket the incidence sort aims at (screen_keys.hip)
-    uint32_t skeys_flags = 0;                           // 1: the bucket kernel finds its one-prefix fine groups by a compare pass instead of min / max atomics (A/B runs)
     uint32_t skeys_cap = 0;                             // != 0: a lower limit than SKEYS_CAP_MAX on the keys of a bucket sorted in LDS (tests of the radix-sort way out)
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)

@@ -147,21 +147,18 @@ __global__ __launch_bounds__(1024) void skeys_scan_kernel(const uint32_t* hist, 
     if (tid == 0) { off[nb] = tot; *max_out = wmax; }
 }
 
-// FLAGS: whether a fine group holds more than one prefix is found by comparing every key with its group's first (a pass of LDS reads) instead of by a minimum and a maximum
-// per group (two more LDS atomics per key, lanes with equal prefixes serialised)
-template <bool FLAGS>
 __global__ __launch_bounds__(SKEYS_T) void skeys_bucket_sort_kernel(const uint64_t* bucketed, const uint32_t* off, BucketMap bm, uint32_t cap, uint64_t* out) {
     SKH_DYN_SMEM(smem);
     uint64_t* k = (uint64_t*)smem;                                                   // the bucket's keys as they arrived
     uint16_t* rnk = (uint16_t*)(k + cap);                                            // a key's arrival number inside its fine group
     uint16_t* grp = rnk + cap;                                                       // the keys' indices, fine group by fine group
-    __shared__ uint32_t fcnt[256], fmin[256], fmax[FLAGS ? 1 : 256], foff[257];   // (FLAGS: fmin holds the groups' flags)
+    __shared__ uint32_t fcnt[256], fmin[256], fmax[256], foff[257];
     __shared__ uint32_t wsum[SKEYS_T / 64];
     const uint32_t tid = threadIdx.x, s0 = off[blockIdx.x], n = off[blockIdx.x + 1] - s0;
     if (n == 0 || n > cap) return;                                                   // (n > cap: the host has looked at the maximum and does not launch this kernel then)
     const uint32_t fbits = bm.shift < 8u ? bm.shift : 8u, fshift = bm.shift - fbits, fmask = (1u << fbits) - 1u;
     auto fine = [&](uint32_t prefix) { return (skeys_rel(bm, prefix) >> fshift) & fmask; };
-    fcnt[tid] = 0; fmin[tid] = FLAGS ? 0u : 0xFFFFFFFFu; if (!FLAGS) fmax[tid] = 0;
+    fcnt[tid] = 0; fmin[tid] = 0xFFFFFFFFu; fmax[tid] = 0;
     __syncthreads();
     for (uint32_t i0 = tid; i0 < n; i0 += 4 * SKEYS_T) {                               // (four loads in flight)
         uint64_t key[4];
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(SKEYS_T) void skeys_bucket_sort_kernel(const uint64
             const uint32_t prefix = (uint32_t)key[u], f = fine(prefix);
             k[i] = key[u];
             rnk[i] = (uint16_t)atomicAdd(&fcnt[f], 1u);
-            if (!FLAGS) { atomicMin(&fmin[f], prefix); atomicMax(&fmax[FLAGS ? 0 : f], prefix); }
+            atomicMin(&fmin[f], prefix); atomicMax(&fmax[f], prefix);
         }
     }
     __syncthreads();
@@ -190,18 +187,11 @@ __global__ __launch_bounds__(SKEYS_T) void skeys_bucket_sort_kernel(const uint64
     __syncthreads();
     for (uint32_t i = tid; i < n; i += SKEYS_T) grp[foff[fine((uint32_t)k[i])] + rnk[i]] = (uint16_t)i;
     __syncthreads();
-    if (FLAGS) {
-        for (uint32_t p = tid; p < n; p += SKEYS_T) {
-            const uint32_t prefix = (uint32_t)k[grp[p]], f = fine(prefix);
-            if ((uint32_t)k[grp[foff[f]]] != prefix) fmin[f] = 1u;                      // (every writer writes the same value)
-        }
-        __syncthreads();
-    }
     for (uint32_t p = tid; p < n; p += SKEYS_T) {
         const uint64_t key = k[grp[p]];
         const uint32_t prefix = (uint32_t)key, f = fine(prefix), s = foff[f], e = foff[f + 1];
         uint32_t r = p - s;                                                          // one prefix in the whole group: any order will do
-        if (FLAGS ? fmin[f] != 0u : fmin[f] != fmax[FLAGS ? 0 : f]) {
+        if (fmin[f] != fmax[f]) {
             r = 0;
             for (uint32_t q = s; q < e; q++) { const uint32_t o = (uint32_t)k[grp[q]]; r += (o < prefix || (o == prefix && q < p)) ? 1u : 0u; }
         }
@@ -276,13 +266,8 @@ void screen_keys_place(skh_ctx* ctx, const ScreenKeysIn& in, uint64_t n, const S
     }
     const uint32_t cap = std::max<uint32_t>((h_max + 255u) & ~255u, 256u);
     const size_t lds = (size_t)cap * 12;
-    if (ctx->tune.skeys_flags) {
-        kernel_allow_lds(skeys_bucket_sort_kernel<true>, lds);
-        SKH_LAUNCH(skeys_bucket_sort_kernel<true>, pl.nb, SKEYS_T, lds, ctx->stream, (const uint64_t*)bucketed, (const uint32_t*)pl.off, bm, cap, out);
-    } else {
-        kernel_allow_lds(skeys_bucket_sort_kernel<false>, lds);
-        SKH_LAUNCH(skeys_bucket_sort_kernel<false>, pl.nb, SKEYS_T, lds, ctx->stream, (const uint64_t*)bucketed, (const uint32_t*)pl.off, bm, cap, out);
-    }
+    kernel_allow_lds(skeys_bucket_sort_kernel, lds);
+    SKH_LAUNCH(skeys_bucket_sort_kernel, pl.nb, SKEYS_T, lds, ctx->stream, (const uint64_t*)bucketed, (const uint32_t*)pl.off, bm, cap, out);
     check_launch("skeys_bucket_sort");
     tr.mark("screen keys: placed");
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root; through gpurun): tools/gpu_job.sh <tag> <section> [<section> ...]
 # One parameterised job instead of a script per GPU run.  Everything lands in gpurun_out/ under names that carry <tag>.
-# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | flagsab | benchmini (first: stops the job when bench.py fails)
+# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | benchmini (first: stops the job when bench.py fails)
 mkdir -p gpurun_out
 tag=$1; shift
 short() { python - "$1" <<'PY'
@@ -55,8 +55,6 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     config4trace) tools/prof.sh ${tag}c4 --no-e2e --collection 10000 > /dev/null 2>&1; head -24 gpurun_out/trace_${tag}c4.txt | cut -c1-66,70-110 ;;
     benchmini) timeout 600 python bench.py --steps 2 --warmup 1 --cpu-clades 2 --strong-steps 2 > gpurun_out/benchmini_$tag.json 2> gpurun_out/benchmini_$tag.err || { tail -20 gpurun_out/benchmini_$tag.err; echo "bench.py is broken: stopping the job"; exit 1; }; short gpurun_out/benchmini_$tag.json ;;
     hosttrace) SKH_TRACE=2 timeout 300 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 3 --warmup 2 2>&1 >/dev/null | grep "skh trace" | tail -75 > gpurun_out/${tag}_hosttrace.txt; tail -75 gpurun_out/${tag}_hosttrace.txt ;;
-    flagsab) for r in 0 1 0 1; do SKH_TUNE_SKEYS_FLAGS=$r timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 30 > gpurun_out/${tag}_flags$r.json 2> gpurun_out/${tag}_flags$r.err || tail -3 gpurun_out/${tag}_flags$r.err; short gpurun_out/${tag}_flags$r.json | cut -c1-230; done
-             for r in 0 1; do SKH_TUNE_SKEYS_FLAGS=$r SKH_TUNE_DIST_KEY_RANGE_W1=1 timeout 600 python bench.py --force-dist --collection 10000 --no-e2e --cpu-clades 0 --steps 6 --warmup 3 > gpurun_out/${tag}_c4d_flags$r.json 2> gpurun_out/${tag}_c4d_flags$r.err || tail -3 gpurun_out/${tag}_c4d_flags$r.err; short gpurun_out/${tag}_c4d_flags$r.json | cut -c1-260; done ;;
     predict) timeout 900 python tools/predict_scaling.py > gpurun_out/${tag}_predict_inputs.json 2> gpurun_out/${tag}_predict.err || tail -3 gpurun_out/${tag}_predict.err; cut -c1-400 gpurun_out/${tag}_predict_inputs.json ;;
     mergejoin) timeout 300 tools/exp/merge_join > gpurun_out/mergejoin_$tag.txt 2>&1; cat gpurun_out/mergejoin_$tag.txt ;;
     cli) timeout 900 python -m pytest tests/test_host_cpp.py -m gpu -x -q 2>&1 | tail -5 ;;
