@@ -514,7 +514,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         for (uint32_t x = 0; x < n_qsets; x++) job.tabs.push_back(dev_halves(ctx, Qsets[x]));
     };
     device_tables();
-    tr.mark("host: genome tables");
     for (int run = 0; run < (split ? 2 : 1); run++) {
         const bool wide_run = split && run == 1;
         const uint32_t* idx = split ? sel[run].data() : nullptr;
@@ -525,7 +524,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         job.wps.clear(); job.host_go_a.clear(); job.host_go_b.clear(); job.host_go_a64.clear(); job.host_go_b64.clear();
         if (wide_run) job.wps.resize(n);
         if (stats) { job.host_go_a.resize(n); job.host_go_b.resize(n); if (wide_run) { job.host_go_a64.resize(n); job.host_go_b64.resize(n); } }
-        tr.mark("host: pair arrays sized");
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t p = idx ? idx[i] : i;
             const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
