@@ -209,3 +209,17 @@ def test_emu_every_genome_resalted(monkeypatch):
         pc.case_triangle_synthetic(c, params=((1, 125),), length=60000)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("env", [{"SKH_TUNE_SKEYS_AVG": "16"}, {"SKH_TUNE_SKEYS_AVG": "16", "SKH_TUNE_SKEYS_CAP": "16"}, {"SKH_TUNE_SCREEN_SORT_RADIX": "1"}])
+def test_emu_incidence_sort_through_the_sketch_call(monkeypatch, env):
+    """The sketch call's own way through the incidence sort -- buckets counted beside the marker sets, their largest read back with the set sizes, keys placed after the
+    gather, the last kernel not waited for -- with tiny buckets, with a capacity the largest bucket exceeds (the radix sort takes the bucketed keys, in the set's own
+    scratch) and with the radix sort alone; the triangle's candidates and results against the oracle."""
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    c = sk.Context(0, lib=emu_lib())
+    try:
+        pc.case_triangle_synthetic(c, params=((1, 125),), length=60000)
+        pc.case_screen_rules(c)
+    finally:
+        c.close()

@@ -52,6 +52,18 @@ def test_every_genome_resalted(monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("env", [{"SKH_TUNE_SKEYS_AVG": "16"}, {"SKH_TUNE_SKEYS_AVG": "16", "SKH_TUNE_SKEYS_CAP": "16"}, {"SKH_TUNE_SCREEN_SORT_RADIX": "1"}])
+def test_incidence_sort_through_the_sketch_call(monkeypatch, env):
+    """tests/test_emu_pipeline.py has the why: the sketch call's two-halves way through the incidence sort with tiny buckets, with the radix-sort way out, with the radix sort alone."""
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    c = sk.Context(0)
+    try:
+        pc.case_triangle_synthetic(c)
+        pc.case_screen_rules(c)
+    finally:
+        c.close()
+
+
 def test_screen_incidence_sort():
     def make_ctx(env):
         for k, v in env.items(): os.environ[k] = v
