@@ -26,7 +26,8 @@ typedef enum {
     SKH_ERR_INVALID = -1,   /* bad argument (k > 16, c > marker_c, ...: seeding.rs:239, params.rs:183-185) */
     SKH_ERR_DEVICE = -2,    /* HIP runtime failure / no device */
     SKH_ERR_NOMEM = -3,
-    SKH_ERR_INTERNAL = -4
+    SKH_ERR_INTERNAL = -4,
+    SKH_ERR_PEER = -5       /* skh_triangle_distributed: ANOTHER rank failed (or a collective was cut short because one did); that rank's own error says why */
 } skh_status;
 
 typedef struct skh_ctx skh_ctx;
@@ -223,7 +224,9 @@ int skh_triangle(skh_ctx*, const skh_sketch_set*, double identity, int rescue_sm
 /* ------------------------------------------------------------------ the triangle over several GPUs (one process per GPU)
  * The reference parallelises triangle.rs:71-105 with a work-stealing thread pool over one shared Vec<Sketch>.  Here every GPU (rank) sketches
  * its own block of the genomes and skh_triangle_distributed() does the rest below this boundary:
- *   1. one all-gather of per-rank tables (who holds which genomes, their sizes, contig lengths) and one of the marker sets (device memory);
+ *   1. one all-gather of per-rank tables (who holds which genomes, their sizes, contig lengths, and per genome how many of its markers fall into each rank's part
+ *      of the key range), then ONE all-to-all of marker sets by key range: every rank receives its own part of every genome's sorted set (device memory; 1/W of the
+ *      bytes an all-gather of the sets would move).  Only the row form of step 2 all-gathers the whole sets;
  *   2. the screen is cut by KEY RANGE: rank r sorts and walks the (marker, genome) incidences whose leading 16 bases fall into its part of the key range and
  *      gets partial counts for every cell; the non-zero cells are gathered on the device and every rank adds them up and applies screen_refs' rule to
  *      every row itself -- the same candidate list on every rank, nothing to gather (a collection whose N x N count matrix is beyond the screen's budget is

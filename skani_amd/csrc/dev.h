@@ -13,6 +13,7 @@
 
 namespace skh {
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+struct PeerError : Error { using Error::Error; };          // a distributed call stops because ANOTHER rank failed (SKH_ERR_PEER): the caller's message is not the run's error
 }
 
 #ifdef SKANI_EMU
@@ -45,6 +46,7 @@ void dcache_stats(size_t* live_bytes, size_t* idle_bytes);   // device memory th
 struct PinRing {
     char* p = nullptr; size_t cap = 0, off = 0; bool tried = false;
     hipStream_t s0 = nullptr, s1 = nullptr;                                          // the owning context's streams
+    bool used0 = false, used1 = false;                                               // which of them has copied from / into a slot since the last wrap
     ~PinRing() { if (p) (void)hipHostFree(p); }
 };
 inline PinRing*& pin_ring_of_thread() { static thread_local PinRing* r = nullptr; return r; }
@@ -66,9 +68,14 @@ inline bool pin_ring_ready(PinRing* r, devStream_t s) {
     if (!r->tried) { r->tried = true; void* q = nullptr; if (hipHostMalloc(&q, PIN_RING, hipHostMallocPortable) == hipSuccess) { r->p = (char*)q; r->cap = PIN_RING; } else (void)hipGetLastError(); }
     return r->p != nullptr;
 }
-inline char* pin_ring_take(PinRing* r, size_t n) {                                   // n <= cap / 2; a slot is reused only after both streams of the ring's context have been waited for
-    const size_t need = (n + 255) & ~(size_t)255;
-    if (r->off + need > r->cap) { hip_check(hipStreamSynchronize(r->s0), "pinned ring wrap"); hip_check(hipStreamSynchronize(r->s1), "pinned ring wrap"); r->off = 0; }
+inline char* pin_ring_take(PinRing* r, size_t n, hipStream_t s) {                    // n <= cap / 2; a slot is reused only after the streams that used the ring since its last wrap have been waited for
+    const size_t need = (n + 255) & ~(size_t)255;                                    // (only those: a read-back on the main stream must not sit out an exchange or an index sort the second stream is busy with)
+    if (r->off + need > r->cap) {
+        if (r->used0) hip_check(hipStreamSynchronize(r->s0), "pinned ring wrap");
+        if (r->used1) hip_check(hipStreamSynchronize(r->s1), "pinned ring wrap");
+        r->used0 = r->used1 = false; r->off = 0;
+    }
+    if (s == r->s0) r->used0 = true; else r->used1 = true;
     char* p = r->p + r->off; r->off += need; return p;
 }
 constexpr size_t PIN_CHUNK = (size_t)4 << 20;
@@ -79,7 +86,7 @@ inline void h2d(void* d, const void* h, size_t n, devStream_t s) {
     if ((n <= PIN_MAX || !pageable_direct()) && pin_ring_ready(r, s)) {              // (larger than the ring's half: in chunks, the same way)
         for (size_t at = 0; at < n; at += PIN_CHUNK) {
             const size_t m = n - at < PIN_CHUNK ? n - at : PIN_CHUNK;
-            char* q = pin_ring_take(r, m);
+            char* q = pin_ring_take(r, m, s);
             memcpy(q, (const char*)h + at, m);
             hip_check(hipMemcpyAsync((char*)d + at, q, m, hipMemcpyHostToDevice, s), "h2d");
         }
@@ -99,7 +106,7 @@ inline void d2h(void* h, const void* d, size_t n, devStream_t s) {
     if (n > DIRECT_MAX && !pageable_direct() && pin_ring_ready(r, s)) {
         for (size_t at = 0; at < n; at += PIN_CHUNK) {
             const size_t m = n - at < PIN_CHUNK ? n - at : PIN_CHUNK;
-            char* q = pin_ring_take(r, m);
+            char* q = pin_ring_take(r, m, s);
             hip_check(hipMemcpyAsync(q, (const char*)d + at, m, hipMemcpyDeviceToHost, s), "d2h");
             hip_check(hipStreamSynchronize(s), "d2h sync");
             memcpy((char*)h + at, q, m);

@@ -36,20 +36,20 @@ namespace {
 struct HostTransport : Transport {
     skh_host_collectives hc;
     void all_gather(skh_ctx* ctx, const void* send, void* recv, size_t bytes, bool device) override {
-        if (!device) { if (hc.all_gather(hc.user, send, recv, bytes)) throw Error("host all_gather failed"); return; }
+        if (!device) { if (hc.all_gather(hc.user, send, recv, bytes)) throw PeerError("host all_gather failed"); return; }
         std::vector<char> hs(bytes ? bytes : 1), hr((size_t)world * bytes + 1);
         d2h(hs.data(), send, bytes, ctx->stream); dsync(ctx->stream);
-        if (hc.all_gather(hc.user, hs.data(), hr.data(), bytes)) throw Error("host all_gather failed");
+        if (hc.all_gather(hc.user, hs.data(), hr.data(), bytes)) throw PeerError("host all_gather failed");
         h2d(recv, hr.data(), (size_t)world * bytes, ctx->stream); dsync(ctx->stream);
     }
     void all_to_all_v(skh_ctx* ctx, const void* send, const uint64_t* send_cnt, const uint64_t* send_off, void* recv, const uint64_t* recv_cnt,
                       const uint64_t* recv_off, bool device) override {
-        if (!device) { if (hc.all_to_all_v(hc.user, send, send_cnt, send_off, recv, recv_cnt, recv_off)) throw Error("host all_to_all_v failed"); return; }
+        if (!device) { if (hc.all_to_all_v(hc.user, send, send_cnt, send_off, recv, recv_cnt, recv_off)) throw PeerError("host all_to_all_v failed"); return; }
         uint64_t sb = 0, rb = 0;
         for (int r = 0; r < world; r++) { sb = std::max(sb, send_off[r] + send_cnt[r]); rb = std::max(rb, recv_off[r] + recv_cnt[r]); }
         std::vector<char> hs(sb + 1), hr(rb + 1);
         d2h(hs.data(), send, sb, ctx->stream); dsync(ctx->stream);
-        if (hc.all_to_all_v(hc.user, hs.data(), send_cnt, send_off, hr.data(), recv_cnt, recv_off)) throw Error("host all_to_all_v failed");
+        if (hc.all_to_all_v(hc.user, hs.data(), send_cnt, send_off, hr.data(), recv_cnt, recv_off)) throw PeerError("host all_to_all_v failed");
         h2d(recv, hr.data(), rb, ctx->stream); dsync(ctx->stream);
     }
     // asynchronous form: the send buffer comes to the host at once, the caller's collective runs on a thread of its own (the calling thread is inside the
@@ -75,8 +75,8 @@ struct HostTransport : Transport {
         const auto w0 = std::chrono::steady_clock::now();
         worker.join();
         a_wait_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
-        if (a_rc) throw Error("host all_to_all_v failed");
-        h2d_big(a_dst, a_recv.data(), a_rb, ctx->stream); dsync(ctx->stream);
+        if (a_rc) throw PeerError("host all_to_all_v failed");
+        h2d(a_dst, a_recv.data(), a_rb, ctx->stream); dsync(ctx->stream);          // (a pageable source: through the pinned ring, dev.h)
     }
     void exchange_times(uint64_t* total_us, uint64_t* wait_us) override {
         if (total_us) *total_us = (uint64_t)std::chrono::duration<double, std::micro>(a_t1 - a_t0).count();
@@ -269,7 +269,7 @@ void triangle_distributed(skh_ctx* ctx, Transport& T, const skh_sketch_set* L, d
         try { xg.close(); } catch (...) {}
         device_sync_all();                                                          // nothing queued may outlive the buffers the unwinding frees
         if (r == me) throw Error(std::string("distributed triangle, ") + phase + ": " + local_err);
-        throw Error(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
+        throw PeerError(std::string("distributed triangle, ") + phase + ": rank " + std::to_string(r) + " failed (its own error message says why); all ranks stop");
     };
     auto agree = [&](const char* phase) {
         uint64_t mine_ok = local_err.empty() ? 0 : 1; std::vector<uint64_t> all(W);
@@ -755,7 +755,7 @@ void comm_selftest(skh_ctx* ctx, Transport& T) {
         std::vector<uint32_t> h(sw + 1), back(rw + 1);
         for (int q = 0; q < W; q++) for (uint64_t x = 0; x < words(me, q); x++) h[so[q] / 4 + x] = (uint32_t)((me << 24) ^ (q << 16) ^ x);
         DBuf<uint32_t> ds(sw + 1), dr(rw + 1);
-        h2d_big(ds.p, h.data(), sw * 4, ctx->stream); dsync(ctx->stream);
+        h2d(ds.p, h.data(), sw * 4, ctx->stream); dsync(ctx->stream);
         if (async) { T.exchange_begin(ctx, ds.p, sc.data(), so.data(), dr.p, rc.data(), ro.data()); T.exchange_end(ctx); }
         else T.all_to_all_v(ctx, ds.p, sc.data(), so.data(), dr.p, rc.data(), ro.data(), true);
         d2h(back.data(), dr.p, rw * 4, ctx->stream);

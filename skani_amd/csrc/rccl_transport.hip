@@ -35,9 +35,7 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-RcclApi& api() {
-    static RcclApi a;
-    if (a.lib) return a;
+static void load_api(RcclApi& a) {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -53,6 +51,11 @@ RcclApi& api() {
     a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
     a.lib = h;
+}
+// (contexts of different host threads may create their communicators at the same moment: the function table is filled once, under the static's own guard; a load that
+// throws leaves the guard open and the next caller tries again)
+RcclApi& api() {
+    static RcclApi a = [] { RcclApi x; load_api(x); return x; }();
     return a;
 }
 

@@ -79,6 +79,47 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
     }
 }
 
+// The same counting with the walk in LDS (round 6).  In the kernel above every step of a key's walk is a global load the lane waits for, and -- the vector-memory
+// counter being one in-order counter -- that wait also sits out the increment issued in front of it: a group of twenty genomes is twenty round trips of
+// load + atomic per lane (85 % of the wave cycles waiting, profiles/r05_pmc.md).  Here a workgroup stages COUNT_TILE keys and the COUNT_HALO keys behind them
+// in LDS with coalesced loads, the walks read LDS, and the increments leave the lane one after the other with nothing waiting behind them; only a prefix group
+// that runs past the halo (a marker shared by hundreds of genomes) goes on in global memory.  Same cells, same increments: the counts are the same integers.
+constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 512;
+template <bool FIRST>
+__global__ __launch_bounds__(256) void screen_count_tri_lds_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
+                                                                   uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz) {
+    __shared__ uint64_t sk[COUNT_TILE + COUNT_HALO];
+    const uint64_t base = (uint64_t)blockIdx.x * COUNT_TILE;
+    const uint32_t have = (uint32_t)(n - base < COUNT_TILE + COUNT_HALO ? n - base : COUNT_TILE + COUNT_HALO);
+    for (uint32_t x = threadIdx.x; x < have; x += blockDim.x) sk[x] = keys[base + x];
+    __syncthreads();
+    uint32_t* mine = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull);
+    const uint32_t own = have < COUNT_TILE ? have : COUNT_TILE;
+    for (uint32_t el = threadIdx.x; el < own; el += blockDim.x) {
+        const uint64_t key = sk[el];
+        const uint32_t a = skey_genome(key), prefix = skey_prefix(key);
+        auto pair_with = [&](uint64_t k2) {
+            if (!skey_same_marker(k2, key)) return;
+            const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
+            if (lo < row0 || lo >= row0 + rows) return;
+            uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
+            if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u); }
+            else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
+        };
+        uint32_t fl = el + 1; bool open = true;
+        for (; fl < have; fl++) {
+            const uint64_t k2 = sk[fl];
+            if (skey_prefix(k2) != prefix) { open = false; break; }
+            pair_with(k2);
+        }
+        if (open) for (uint64_t f = base + fl; f < n; f++) {                          // the group runs past what is staged
+            const uint64_t k2 = keys[f];
+            if (skey_prefix(k2) != prefix) break;
+            pair_with(k2);
+        }
+    }
+}
+
 // two sets, separately sorted key arrays: a query incidence (m, q) finds m's prefix group in the refs' keys by binary search.  The refs'
 // sorted keys are cached in the sketch set (a database is screened many times; its index is built once).
 __global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* qkeys, uint64_t nq, const uint64_t* rkeys, uint64_t nr, uint32_t row0, uint32_t rows,
@@ -251,7 +292,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
-            if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
+            if (tri && ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
+            else if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
             else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
         }
@@ -515,7 +557,8 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         ctx->part_cnt_clean = false;
         uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
         dzero(row_nz, (size_t)N * 4, ctx->stream);
-        SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
+        if (ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
+        else SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
         check_launch("screen_count(part)");
         tr.mark("screen part: count (first touch)");
         exclusive_scan_u32(ctx, row_nz, N, row_off);
@@ -532,7 +575,8 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
-    SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
+    if (ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
+    else SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
     tr.mark("screen part: zero + count");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
@@ -574,6 +618,7 @@ void screen_from_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, const uint64_t
         if (h_flags[0]) throw std::invalid_argument("screen_from_cells: a cell names a genome beyond the set");
         if (!h_flags[1]) {
             uint32_t* row_cnt = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
+            kernel_allow_lds(screen_rows_from_cells_kernel, row_bytes);              // (a row of more than 16,384 genomes is beyond the 64 KB a launch may ask for unannounced, dev.h)
             SKH_LAUNCH(screen_rows_from_cells_kernel, N, 256, row_bytes, ctx->stream, d_blocks, block_words, n_blocks, N, sr, (const uint64_t*)S->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off,
                        (uint32_t*)nullptr, (uint32_t*)nullptr);
             check_launch("screen_rows_from_cells0");

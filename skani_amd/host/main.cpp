@@ -43,9 +43,9 @@ struct Args {
 // A rank of `triangle --gpus N` (g_node set) that fails ends the whole run: the first rank to claim the failure prints its message -- the run's ONE error --, the
 // others leave quietly (their collectives fail once the flag is up; a rank that only learnt of a peer's failure waits a moment so that the peer's own message wins).
 Node* g_node = nullptr;
-[[noreturn]] void die(const std::string& m) {
+[[noreturn]] void die(const std::string& m, bool secondary = false) {               // secondary: this rank only learnt that a PEER failed (SKH_ERR_PEER, a node collective cut short)
     if (!g_node) { fprintf(stderr, "ERROR %s\n", m.c_str()); exit(1); }
-    if (m.find("all ranks stop") != std::string::npos || m.find("host all_") != std::string::npos) usleep(300000);
+    for (int w = 0; secondary && w < 300 && !node_failed(g_node); w++) usleep(1000);  // the peer's own message is the run's error: wait (a moment at most) until it has claimed it
     if (node_claim_failure(g_node)) fprintf(stderr, "ERROR [rank %d] %s\n", node_rank(g_node), m.c_str());
     fflush(stderr); fflush(stdout);
     _exit(1);
@@ -125,7 +125,7 @@ Args parse(int argc, char** argv) {
 
 struct Ctx {
     skh_ctx* c = nullptr;
-    void check(int rc, const char* what) { if (rc != 0) die(std::string(what) + ": " + (c ? skh_last_error(c) : "no context")); }
+    void check(int rc, const char* what) { if (rc != 0) die(std::string(what) + ": " + (c ? skh_last_error(c) : "no context"), rc == SKH_ERR_PEER); }
 };
 
 std::string models_dir(const Args& a, const char* argv0) {
@@ -456,14 +456,14 @@ int run_triangle_node(Args& a, const char* argv0) {
     if (!a.one_device && !getenv("SKANI_HIP_HOST_COLLECTIVES")) {
         struct IdMsg { uint8_t id[SKH_COMM_ID_BYTES]; uint64_t ok; } mine{}; std::vector<IdMsg> all(W);
         if (rank == 0) mine.ok = skh_comm_unique_id(mine.id) == 0;
-        if (!node_all_gather(node, &mine, all.data(), sizeof mine)) die("a rank failed; all ranks stop");
+        if (!node_all_gather(node, &mine, all.data(), sizeof mine)) die("a rank failed; all ranks stop", true);
         uint64_t bad = 1;
         if (all[0].ok) {
             bad = skh_comm_create_rccl(cx.c, all[0].id, rank, W, &comm) != 0;
             if (!bad) bad = skh_comm_selftest(cx.c, comm) != 0;
         }
         std::vector<uint64_t> bads(W);
-        if (!node_all_gather(node, &bad, bads.data(), 8)) die("a rank failed; all ranks stop");
+        if (!node_all_gather(node, &bad, bads.data(), 8)) die("a rank failed; all ranks stop", true);
         bool any = false; for (uint64_t b : bads) any = any || b;
         if (any) {
             if (comm) { skh_comm_destroy(comm); comm = nullptr; }
@@ -511,7 +511,7 @@ int run_triangle_node(Args& a, const char* argv0) {
         put_u64(mine_tab, tot);
     }
     std::vector<std::string> tabs;
-    if (!node_all_gather_v(node, mine_tab, tabs)) die("a rank failed; all ranks stop");
+    if (!node_all_gather_v(node, mine_tab, tabs)) die("a rank failed; all ranks stop", true);
     std::vector<GenomeInfo> info_all; std::vector<uint32_t> row_of;                 // row_of[global set genome] = row of info_all, or ~0u
     uint64_t n_info_total = 0;
     for (int r = 0; r < W; r++) {
@@ -550,7 +550,7 @@ int run_triangle_node(Args& a, const char* argv0) {
         g_clock.mark("write");
     }
     skh_free(oi); skh_free(oj); skh_free(res);
-    if (!node_barrier(node)) die("a rank failed; all ranks stop");                 // (nobody takes its communicator down while a peer is still inside it)
+    if (!node_barrier(node)) die("a rank failed; all ranks stop", true);                 // (nobody takes its communicator down while a peer is still inside it)
     skh_comm_destroy(comm);
     skh_sketch_set_destroy(sd.ss);
     g_pinned.release();

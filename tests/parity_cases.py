@@ -403,6 +403,71 @@ def case_screen_incidence_sort(make_ctx):
             ctx.close()
 
 
+def case_screen_count_walks(make_ctx, G=1700):
+    """The triangle's count kernel stages 1024 keys + the 512 behind them in LDS and walks a marker's incidences there (screen.hip screen_count_tri_lds_kernel); a group
+    that runs past the staged keys goes on in global memory.  Crafted sets: one marker in ALL genomes (a group several tiles long), one in 600 of them, clades of eight
+    sharing most of their markers, same-prefix look-alikes.  Every cell of the key-range screen must hold the exact number of common markers, with the staged walk and
+    with the walk in global memory (SKH_TUNE_SCREEN_COUNT_LDS=0, the kernel of rounds 1-5), and both must give the same candidate list."""
+    rng = np.random.default_rng(606)
+    def canon(n): return np.minimum(rng.integers(0, 1 << 42, n, dtype=np.uint64), rng.integers(0, 1 << 42, n, dtype=np.uint64))
+    universal, wide = np.uint64(0x155555555AA), np.uint64((987654321 << 10) | 77)
+    sets = []
+    for c in range(G // 8):
+        base = canon(40)
+        for m in range(8):
+            g = c * 8 + m
+            own = [base[rng.random(len(base)) < 0.8], canon(6), [universal]]
+            if 300 <= g < 900: own.append([wide])
+            if g % 7 == 0: own.append(base[:5] ^ np.uint64(3))
+            sets.append(np.unique(np.concatenate([np.asarray(x, np.uint64) for x in own])))
+    want = _shared_marker_counts(sets)
+    seen = []
+    for env in ({}, {"SKH_TUNE_SCREEN_COUNT_LDS": "0"}, {"SKH_TUNE_SCREEN_PLANES": "1"}):
+        ctx = make_ctx(env)
+        try:
+            refs = _marker_set_import(ctx, sets)
+            for n_parts in (1, 3):
+                cells = np.concatenate([ctx.screen_part(refs, part, n_parts) for part in range(n_parts)])
+                i, j, c = ctx.unpack_cells(cells)
+                got = {}
+                for a, b, n in zip(i.tolist(), j.tolist(), c.tolist()): got[(a, b)] = got.get((a, b), 0) + n
+                assert got == want, (env, n_parts, len(got), len(want))
+            seen.append(tuple(x.tobytes() for x in ctx.screen(refs, None, 0.8, 0, False)) + tuple(x.tobytes() for x in ctx.screen_rows(refs, 5, G // 2, 0.8, False)))
+            refs.close()
+        finally:
+            ctx.close()
+    assert seen[0] == seen[1] == seen[2] and len(seen[0][0]) > 0
+
+
+def case_screen_from_cells_large_rows(ctx, N=17000):
+    """The gathered cells of the key-range screen are added up row by row in an LDS row of N counters (screen_rows_from_cells_kernel): beyond 16,384 genomes that row is
+    more than the 64 KB a launch may ask for unannounced.  17,000 genomes with a dozen markers each, clades of four: the candidate list from the cells equals the
+    list of the one-call screen and the exact one."""
+    rng = np.random.default_rng(17)
+    sets = []
+    for c in range(N // 4):
+        base = np.minimum(rng.integers(0, 1 << 42, 9, dtype=np.uint64), rng.integers(0, 1 << 42, 9, dtype=np.uint64))
+        for m in range(4):
+            sets.append(np.unique(np.concatenate([base[: 9 - m], rng.integers(0, 1 << 42, 3, dtype=np.uint64)])))
+    meta = dict(pos_off=np.arange(N + 1, dtype=np.uint64), marker_off=np.concatenate([[0], np.cumsum([len(x) for x in sets])]).astype(np.uint64),
+                contig_off=np.arange(N + 1, dtype=np.uint64), contig_lengths=np.full(N, 600000, np.uint32), total_len=np.full(N, 600000, np.uint64),
+                genome_rank=np.arange(N, dtype=np.uint32))
+    refs = ctx.import_flat(sk.SketchParams(), meta, seed=rng.integers(0, 1 << 30, N, dtype=np.uint32), pos=np.full(N, 100, np.uint32), ctgcanon=np.zeros(N, np.uint32),
+                           markers=np.concatenate(sets))
+    try:
+        want = sorted(p for p, n in _shared_marker_counts(sets).items() if n > 1)    # screen.rs:176-187: more than max(floor(0.8^21 x 12), 1) common markers
+        a, b = ctx.screen(refs, None, 0.8, 0, False)
+        assert list(zip(a.tolist(), b.tolist())) == want and len(want) >= N
+        cells = ctx.screen_part(refs, 0, 1)                                          # one part: in row order, the form that is added up in LDS
+        a2, b2 = ctx.screen_from_cells(refs, cells, 0.8, False)
+        assert np.array_equal(a, a2) and np.array_equal(b, b2)
+        two = np.concatenate([ctx.screen_part(refs, part, 2) for part in range(2)])  # two parts concatenated: not in row order, the dense matrix
+        a3, b3 = ctx.screen_from_cells(refs, two, 0.8, False)
+        assert np.array_equal(a, a3) and np.array_equal(b, b3)
+    finally:
+        refs.close()
+
+
 def case_marker_set_sizes(ctx):
     """Marker sets of a batch are made by one workgroup per genome in LDS (up to 8192 raw markers per genome), else by device-wide passes: genomes just
     below the capacity, a batch with one genome above it, an empty one."""

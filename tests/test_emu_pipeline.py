@@ -199,6 +199,16 @@ def test_emu_screen_incidence_sort(monkeypatch):
     pc.case_screen_incidence_sort(make_ctx)
 
 
+def test_emu_screen_count_walks(monkeypatch):
+    def make_ctx(env):
+        import os
+        for k, v in env.items(): os.environ[k] = v
+        try: return sk.Context(0, lib=emu_lib())
+        finally:
+            for k in env: os.environ.pop(k, None)
+    pc.case_screen_count_walks(make_ctx)
+
+
 def test_emu_every_genome_resalted(monkeypatch):
     """SKH_TUNE_BUILD_RESALT_ALL=1: the table build indexes every genome a second time under salt 1 -- the path of a genome whose seeds crowd a stretch of the hash
     range, which no ordinary genome takes -- after the sketch call has made the per-genome tables of the pair descriptors AHEAD of the build's end (with salt 0):

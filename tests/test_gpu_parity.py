@@ -71,6 +71,14 @@ def test_screen_incidence_sort():
         finally:
             for k in env: os.environ.pop(k, None)
     pc.case_screen_incidence_sort(make_ctx)
+def test_screen_count_walks():
+    def make_ctx(env):
+        for k, v in env.items(): os.environ[k] = v
+        try: return sk.Context(0)
+        finally:
+            for k in env: os.environ.pop(k, None)
+    pc.case_screen_count_walks(make_ctx)
+def test_screen_from_cells_large_rows(ctx): pc.case_screen_from_cells_large_rows(ctx)
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
 def test_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
