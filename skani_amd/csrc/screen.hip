@@ -79,43 +79,40 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
     }
 }
 
-// The same counting with the walk in LDS (round 6).  In the kernel above every step of a key's walk is a global load the lane waits for, and -- the vector-memory
-// counter being one in-order counter -- that wait also sits out the increment issued in front of it: a group of twenty genomes is twenty round trips of
-// load + atomic per lane (85 % of the wave cycles waiting, profiles/r05_pmc.md).  Here a workgroup stages COUNT_TILE keys and the COUNT_HALO keys behind them
-// in LDS with coalesced loads, the walks read LDS, and the increments leave the lane one after the other with nothing waiting behind them; only a prefix group
-// that runs past the halo (a marker shared by hundreds of genomes) goes on in global memory.  Same cells, same increments: the counts are the same integers.
-constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 512;
+// The same counting, a ROW of the matrix per instruction (round 6).  What the count costs is requests to the L2's atomic units, and a request is a 64-byte LINE, not a
+// word: tools/exp/atomic_rates.hip (profiles/r06_atomic_rates.md) measures 27 G increments/s when every lane of an instruction hits a line of its own -- whatever the
+// number of hot words, the scope, the planes -- and 395 G/s when the 16 lanes of a quarter wave hit the 16 words of one line.  In the kernel above lane = incidence e and
+// step s pairs it with incidence e + s: the lanes of one instruction are in different rows, one line each.  Here the lanes of a marker's group walk the group TOGETHER
+// from its first incidence: at step i every lane of the group meets member i, and the lanes whose genome is the larger of the two add to cell (member i, own genome) --
+// one row, columns as far apart as the group's genomes are.  Genomes that share markers tend to sit next to each other in a collection sorted by file name (the
+// clades of the synthetic collections do): a group of m then costs ~m line requests instead of m (m - 1) / 2.  Where they do not, it is one line per increment as before.
+// Every unordered pair of a group is met once (by its larger genome), so the counts are the same integers.  A workgroup stages its COUNT_TILE keys and COUNT_HALO keys
+// on either side in LDS; the part of a group beyond that (a marker shared by hundreds of genomes) is read from global memory.
+constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 256;
 template <bool FIRST>
-__global__ __launch_bounds__(256) void screen_count_tri_lds_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
-                                                                   uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz) {
-    __shared__ uint64_t sk[COUNT_TILE + COUNT_HALO];
+__global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
+                                                                    uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz) {
+    __shared__ uint64_t sk[COUNT_TILE + 2 * COUNT_HALO];
     const uint64_t base = (uint64_t)blockIdx.x * COUNT_TILE;
-    const uint32_t have = (uint32_t)(n - base < COUNT_TILE + COUNT_HALO ? n - base : COUNT_TILE + COUNT_HALO);
-    for (uint32_t x = threadIdx.x; x < have; x += blockDim.x) sk[x] = keys[base + x];
+    const uint64_t st_lo = base >= COUNT_HALO ? base - COUNT_HALO : 0, st_hi = n - base < COUNT_TILE + COUNT_HALO ? n : base + COUNT_TILE + COUNT_HALO;
+    for (uint32_t x = threadIdx.x; x < (uint32_t)(st_hi - st_lo); x += blockDim.x) sk[x] = keys[st_lo + x];
     __syncthreads();
+    auto key_at = [&](uint64_t p) { return (p >= st_lo && p < st_hi) ? sk[p - st_lo] : keys[p]; };
     uint32_t* mine = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull);
-    const uint32_t own = have < COUNT_TILE ? have : COUNT_TILE;
-    for (uint32_t el = threadIdx.x; el < own; el += blockDim.x) {
-        const uint64_t key = sk[el];
-        const uint32_t a = skey_genome(key), prefix = skey_prefix(key);
-        auto pair_with = [&](uint64_t k2) {
-            if (!skey_same_marker(k2, key)) return;
-            const uint32_t b = skey_genome(k2), lo = a < b ? a : b, hi = a < b ? b : a;
-            if (lo < row0 || lo >= row0 + rows) return;
-            uint32_t* cell = mine + (uint64_t)(lo - row0) * ncols + hi;
-            if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[lo - row0], 1u); }
-            else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
-        };
-        uint32_t fl = el + 1; bool open = true;
-        for (; fl < have; fl++) {
-            const uint64_t k2 = sk[fl];
-            if (skey_prefix(k2) != prefix) { open = false; break; }
-            pair_with(k2);
-        }
-        if (open) for (uint64_t f = base + fl; f < n; f++) {                          // the group runs past what is staged
-            const uint64_t k2 = keys[f];
+    const uint64_t own_hi = n - base < COUNT_TILE ? n : base + COUNT_TILE;
+    for (uint64_t e = base + threadIdx.x; e < own_hi; e += blockDim.x) {
+        const uint64_t key = key_at(e);
+        const uint32_t b = skey_genome(key), prefix = skey_prefix(key);
+        uint64_t gs = e;                                                               // the prefix group's first incidence
+        while (gs > 0 && skey_prefix(key_at(gs - 1)) == prefix) gs--;
+        for (uint64_t p = gs; p < n; p++) {
+            const uint64_t k2 = key_at(p);
             if (skey_prefix(k2) != prefix) break;
-            pair_with(k2);
+            const uint32_t a = skey_genome(k2);
+            if (a >= b || !skey_same_marker(k2, key) || a < row0 || a >= row0 + rows) continue;   // (a == b: the incidence itself)
+            uint32_t* cell = mine + (uint64_t)(a - row0) * ncols + b;
+            if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[a - row0], 1u); }
+            else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
         }
     }
 }
@@ -292,7 +289,7 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
-            if (tri && ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
+            if (tri && ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
             else if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
             else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
@@ -557,7 +554,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         ctx->part_cnt_clean = false;
         uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
         dzero(row_nz, (size_t)N * 4, ctx->stream);
-        if (ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
+        if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
         else SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
         check_launch("screen_count(part)");
         tr.mark("screen part: count (first touch)");
@@ -575,7 +572,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
-    if (ctx->tune.screen_count_lds) SKH_LAUNCH(screen_count_tri_lds_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
+    if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     else SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
     tr.mark("screen part: zero + count");

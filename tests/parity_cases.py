@@ -404,10 +404,11 @@ def case_screen_incidence_sort(make_ctx):
 
 
 def case_screen_count_walks(make_ctx, G=1700):
-    """The triangle's count kernel stages 1024 keys + the 512 behind them in LDS and walks a marker's incidences there (screen.hip screen_count_tri_lds_kernel); a group
-    that runs past the staged keys goes on in global memory.  Crafted sets: one marker in ALL genomes (a group several tiles long), one in 600 of them, clades of eight
-    sharing most of their markers, same-prefix look-alikes.  Every cell of the key-range screen must hold the exact number of common markers, with the staged walk and
-    with the walk in global memory (SKH_TUNE_SCREEN_COUNT_LDS=0, the kernel of rounds 1-5), and both must give the same candidate list."""
+    """The triangle's count kernel stages 1024 keys and 256 on either side in LDS; the lanes of a marker's group walk the group together from its first incidence
+    (screen.hip screen_count_tri_rows_kernel), and what lies beyond the staged keys is read from global memory.  Crafted sets: one marker in ALL genomes (a group several
+    tiles long, reached from both sides), one in 600 of them, clades of eight sharing most of their markers, same-prefix look-alikes.  Every cell of the key-range
+    screen must hold the exact number of common markers, with this kernel and with the one of rounds 1-5 (SKH_TUNE_SCREEN_COUNT_ROWS=0), and both must give
+    the same candidate list."""
     rng = np.random.default_rng(606)
     def canon(n): return np.minimum(rng.integers(0, 1 << 42, n, dtype=np.uint64), rng.integers(0, 1 << 42, n, dtype=np.uint64))
     universal, wide = np.uint64(0x155555555AA), np.uint64((987654321 << 10) | 77)
@@ -422,7 +423,7 @@ def case_screen_count_walks(make_ctx, G=1700):
             sets.append(np.unique(np.concatenate([np.asarray(x, np.uint64) for x in own])))
     want = _shared_marker_counts(sets)
     seen = []
-    for env in ({}, {"SKH_TUNE_SCREEN_COUNT_LDS": "0"}, {"SKH_TUNE_SCREEN_PLANES": "1"}):
+    for env in ({}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}, {"SKH_TUNE_SCREEN_PLANES": "1"}):
         ctx = make_ctx(env)
         try:
             refs = _marker_set_import(ctx, sets)
