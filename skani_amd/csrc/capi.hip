@@ -83,6 +83,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.join_bitmap_words = (uint32_t)env("SKH_TUNE_JOIN_BITMAP_WORDS", ctx->tune.join_bitmap_words);
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.screen_count_rows = (uint32_t)env("SKH_TUNE_SCREEN_COUNT_ROWS", ctx->tune.screen_count_rows);
+        ctx->tune.screen_col_order = (uint32_t)env("SKH_TUNE_SCREEN_COL_ORDER", ctx->tune.screen_col_order);
         ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
         ctx->tune.build_resalt_all = (uint32_t)env("SKH_TUNE_BUILD_RESALT_ALL", 0);
         ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);

@@ -202,6 +202,8 @@ __device__ __forceinline__ unsigned long long wave_clock() { return __builtin_re
 __device__ __forceinline__ void wait_for_value(uint32_t v) { asm volatile("" ::"v"(v)); }
 // the XCD (0..7 on MI355X) this wave runs on, and an increment performed in that XCD's L2 (workgroup scope): screen.hip's per-XCD count planes
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xFu; }
+// a word other CUs change with atomics while this kernel runs, read past this CU's L1 (screen.hip: the union-find's parents)
+__device__ __forceinline__ uint32_t load_past_l1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void atomic_inc_xcd_local(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 }  // namespace skh

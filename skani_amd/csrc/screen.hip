@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
 constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 256;
 template <bool FIRST>
 __global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
-                                                                    uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz) {
+                                                                    uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz, const uint32_t* col_of /* null: columns = genomes */) {
     __shared__ uint64_t sk[COUNT_TILE + 2 * COUNT_HALO];
     const uint64_t base = (uint64_t)blockIdx.x * COUNT_TILE;
     const uint64_t st_lo = base >= COUNT_HALO ? base - COUNT_HALO : 0, st_hi = n - base < COUNT_TILE + COUNT_HALO ? n : base + COUNT_TILE + COUNT_HALO;
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64
     for (uint64_t e = base + threadIdx.x; e < own_hi; e += blockDim.x) {
         const uint64_t key = key_at(e);
         const uint32_t b = skey_genome(key), prefix = skey_prefix(key);
+        const uint32_t bcol = col_of ? col_of[b] : b;
         uint64_t gs = e;                                                               // the prefix group's first incidence
         while (gs > 0 && skey_prefix(key_at(gs - 1)) == prefix) gs--;
         for (uint64_t p = gs; p < n; p++) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64
             if (skey_prefix(k2) != prefix) break;
             const uint32_t a = skey_genome(k2);
             if (a >= b || !skey_same_marker(k2, key) || a < row0 || a >= row0 + rows) continue;   // (a == b: the incidence itself)
-            uint32_t* cell = mine + (uint64_t)(a - row0) * ncols + b;
+            uint32_t* cell = mine + (uint64_t)(a - row0) * ncols + bcol;
             if (FIRST) { if (atomicAdd(cell, 1u) == 0u) atomicAdd(&row_nz[a - row0], 1u); }
             else if (n_planes > 1) count_local(cell); else atomicAdd(cell, 1u);
         }
@@ -134,6 +135,85 @@ __global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* q
         const uint64_t k2 = rkeys[f];
         if (skey_prefix(k2) != prefix) break;
         if (skey_same_marker(k2, key)) atomicAdd(&row[skey_genome(k2)], 1u);
+    }
+}
+
+// ---- the COLUMN ORDER of the triangle's count matrix (round 6).  The row-per-instruction kernel above pays one line request per increment again when the genomes of a
+// group are far apart in the collection -- related genomes under unrelated file names.  The matrix is the screen's own scratch, so its columns may stand in any order:
+// genomes are grouped by the connected component they fall into when the incidences of a quarter of the key range tie them together (a lock-free union-find on the sorted
+// list: neighbours of one marker are united; parents only ever decrease), components in the order of their smallest genome, genomes inside a component by number
+// (a collection that IS in clade order keeps its order).  Cell (row a, genome b) then sits in column col_of[b]; the rule kernels walk the columns and name genome
+// genome_of[column]; the host orders every row's few columns again (screen_pairs).  Which genomes end up next to each other changes no count: the pass set is the same.
+__global__ __launch_bounds__(256) void colorder_init_kernel(uint32_t* parent, uint32_t n) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) parent[g] = g;
+}
+__device__ __forceinline__ uint32_t uf_root(uint32_t* parent, uint32_t x) {          // (a stale parent is an earlier ancestor: still in the component, still leads to the root)
+    for (;;) { const uint32_t q = load_past_l1(&parent[x]); if (q == x) return x; x = q; }
+}
+__global__ __launch_bounds__(256) void colorder_union_kernel(const uint64_t* keys, uint64_t n_pairs /* incidences e, e + 1 with e < n_pairs */, uint32_t* parent) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_pairs) return;
+    const uint64_t k1 = keys[e], k2 = keys[e + 1];
+    if (skey_prefix(k1) != skey_prefix(k2) || !skey_same_marker(k1, k2)) return;
+    uint32_t a = skey_genome(k1), b = skey_genome(k2);
+    for (;;) {
+        a = uf_root(parent, a); b = uf_root(parent, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }                             // a > b: hook a under b
+        const uint32_t old = atomicMin(&parent[a], b);
+        if (old == a) return;                                                         // a was a root: done
+        a = old;                                                                      // a had been hooked meanwhile: its former parent and b still have to meet
+    }
+}
+__global__ __launch_bounds__(256) void colorder_label_kernel(const uint32_t* parent, uint32_t n, uint64_t* lab) {   // (its own launch: every parent is final)
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint32_t r = g; for (uint32_t q; (q = parent[r]) != r;) r = q;
+    lab[g] = (uint64_t)r << 32 | g;
+}
+constexpr uint32_t COLORDER_LDS_MAX = 4096;
+__global__ __launch_bounds__(1024) void colorder_rank_kernel(const uint64_t* lab, uint32_t n, uint32_t* col_of, uint32_t* genome_of) {   // n <= COLORDER_LDS_MAX, one workgroup
+    __shared__ uint64_t s[COLORDER_LDS_MAX];
+    for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) s[g] = lab[g];
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) {
+        const uint64_t mine = s[g]; uint32_t rank = 0;
+        for (uint32_t x = 0; x < n; x++) rank += s[x] < mine ? 1u : 0u;                 // (labels are distinct: the genome is part of them)
+        col_of[g] = rank; genome_of[rank] = g;
+    }
+}
+__global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sorted, uint32_t n, uint32_t* col_of, uint32_t* genome_of) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t g = (uint32_t)sorted[x];
+    genome_of[x] = g; col_of[g] = x;
+}
+// col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes)
+static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t** col_of, uint32_t** genome_of) {
+    *col_of = nullptr; *genome_of = nullptr;
+    if (!ctx->tune.screen_col_order || N < 2 || n_keys < 2) return;
+    uint32_t* parent = ctx->arena.get<uint32_t>(N); uint64_t* lab = ctx->arena.get<uint64_t>(N);
+    uint32_t* co = ctx->arena.get<uint32_t>(N); uint32_t* go = ctx->arena.get<uint32_t>(N);
+    const uint64_t n_pairs = std::min<uint64_t>(n_keys - 1, std::max<uint64_t>(n_keys / 4, (uint64_t)1 << 20));
+    SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, parent, N);
+    SKH_LAUNCH(colorder_union_kernel, (unsigned)((n_pairs + 255) / 256), 256, 0, ctx->stream, keys, n_pairs, parent);
+    SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
+    if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, 1, 1024, 0, ctx->stream, (const uint64_t*)lab, N, co, go);
+    else {
+        uint64_t* sorted = ctx->arena.get<uint64_t>(N);
+        sort_keys_u64_into(ctx, lab, sorted, N, 64);
+        SKH_LAUNCH(colorder_place_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)sorted, N, co, go);
+    }
+    check_launch("screen column order");
+    *col_of = co; *genome_of = go;
+}
+// the candidates of rows [from, end) of `first` come out of the rule kernels in column order: every row's genomes ascending again (triangle.rs:90 walks them that way)
+static void order_rows_columns(const std::vector<uint32_t>& first, std::vector<uint32_t>& second, size_t from) {
+    for (size_t x = from; x < first.size();) {
+        size_t y = x + 1; while (y < first.size() && first[y] == first[x]) y++;
+        if (y - x > 1) std::sort(second.begin() + x, second.begin() + y);
+        x = y;
     }
 }
 
@@ -161,7 +241,8 @@ __device__ __forceinline__ bool cell_passes(const ScreenRule& sr, uint32_t count
 // one workgroup per row: pass 0 counts passing cells, pass 1 writes them in column order
 __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t ncols, ScreenRule sr,
                                                                const uint64_t* mk_off_rows, const uint64_t* mk_off_cols, int pass,
-                                                               uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second, uint32_t* out_count /* may be null */) {
+                                                               uint32_t* row_cnt, const uint32_t* row_off, uint32_t* out_first, uint32_t* out_second, uint32_t* out_count /* may be null */,
+                                                               const uint32_t* genome_of /* null: column c is genome c; else the column order of make_column_order */) {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t running;
     const uint32_t r = blockIdx.x, row = row0 + r;
@@ -171,10 +252,11 @@ __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* c
     __syncthreads();
     const uint32_t base_out = pass ? row_off[r] : 0;
     for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
-        const uint32_t col = c0 + threadIdx.x;
-        bool ok = false; uint32_t count = 0;
-        if (col < ncols) {
-            for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + col];
+        const uint32_t at = c0 + threadIdx.x;
+        bool ok = false; uint32_t count = 0, col = at;
+        if (at < ncols) {
+            for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + at];
+            if (genome_of) col = genome_of[at];
             ok = cell_passes(sr, count, m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
         }
         // workgroup exclusive scan of the flags
@@ -285,17 +367,19 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
     row_end = std::min(row_end, nrows);
+    uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // triangle: the count matrix's columns in an order of their own
+    if (tri && M && ctx->tune.screen_count_rows) make_column_order(ctx, keys, MR, ncols, &col_of, &genome_of);
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
-            if (tri && ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
+            if (tri && ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr, (const uint32_t*)col_of);
             else if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
             else if (MQ && MR) SKH_LAUNCH(screen_count_qr2_kernel, (unsigned)((MQ + 255) / 256), 256, 0, ctx->stream, keys, MQ, rkeys, MR, row0, rows, ncols, cnt);
             check_launch("screen_count");
         }
         SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
-                   (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                   (const uint64_t*)refs->d_mk_off.p, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)genome_of);
         check_launch("screen_threshold0");
         exclusive_scan_u32(ctx, row_cnt, rows, row_off);
         uint32_t total = 0;
@@ -303,11 +387,13 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
         if (total) {
             uint32_t* of = ctx->arena.get<uint32_t>(2 * (size_t)total); uint32_t* os = of + total;   // (side by side: one read-back)
             SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, (const uint32_t*)cnt, n_planes, plane, row0, ncols, sr, (const uint64_t*)rowset->d_mk_off.p,
-                       (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os, (uint32_t*)nullptr);
+                       (const uint64_t*)refs->d_mk_off.p, 1, row_cnt, (const uint32_t*)row_off, of, os, (uint32_t*)nullptr, (const uint32_t*)genome_of);
             check_launch("screen_threshold1");
             std::vector<uint32_t> both(2 * (size_t)total);
             d2h(both.data(), of, both.size() * 4, ctx->stream);
+            const size_t from = first.size();
             first.insert(first.end(), both.begin(), both.begin() + total); second.insert(second.end(), both.begin() + total, both.end());
+            if (genome_of) order_rows_columns(first, second, from);
         }
     }
     dsync(ctx->stream);
@@ -419,7 +505,7 @@ __global__ __launch_bounds__(256) void screen_rows_from_cells_kernel(const uint6
 
 // one workgroup per row of a single-plane count matrix: the row's non-zero cells (columns beyond the row) go out as packed words in column order at row_off[row] --
 // the numbers of non-zero cells per row are known from the counting (row_nz) -- and every cell read is put back to ZERO: the matrix leaves the call as it entered it
-__global__ __launch_bounds__(256) void screen_emit_cells_kernel(uint32_t* cnt, uint32_t ncols, const uint32_t* row_nz, const uint32_t* row_off, uint64_t* out) {
+__global__ __launch_bounds__(256) void screen_emit_cells_kernel(uint32_t* cnt, uint32_t ncols, const uint32_t* row_nz, const uint32_t* row_off, uint64_t* out, const uint32_t* genome_of /* null: column = genome */) {
     __shared__ uint32_t lds[16];
     __shared__ uint32_t running;
     const uint32_t row = blockIdx.x;
@@ -428,11 +514,12 @@ __global__ __launch_bounds__(256) void screen_emit_cells_kernel(uint32_t* cnt, u
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
     const uint32_t base_out = row_off[row];
-    for (uint32_t c0 = (row + 1) & ~255u; c0 < ncols; c0 += blockDim.x) {
-        const uint32_t col = c0 + threadIdx.x;
-        const uint32_t count = (col < ncols && col > row) ? crow[col] : 0u;
+    for (uint32_t c0 = genome_of ? 0u : (row + 1) & ~255u; c0 < ncols; c0 += blockDim.x) {   // (in genome order the row's cells lie beyond the diagonal; in column order anywhere)
+        const uint32_t at = c0 + threadIdx.x;
+        const uint32_t count = (at < ncols && (genome_of || at > row)) ? crow[at] : 0u;
         const bool ok = count != 0;
-        if (ok) crow[col] = 0;
+        const uint32_t col = ok && genome_of ? genome_of[at] : at;
+        if (ok) crow[at] = 0;
         const uint32_t incl = wave_incl_scan(ok ? 1u : 0u);
         const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
         if (l == 63) lds[w] = incl;
@@ -450,18 +537,18 @@ __global__ __launch_bounds__(256) void screen_emit_cells_kernel(uint32_t* cnt, u
 // rows [0, rows) of a dense count matrix through the rule: the passing (row, col[, count]) cells in (row, col) order, on the host
 static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t row0, uint32_t rows, uint32_t ncols, const ScreenRule& sr, const uint64_t* d_mk_rows,
                            const uint64_t* d_mk_cols, std::vector<uint32_t>& first, std::vector<uint32_t>& second, uint64_t** d_cells = nullptr /* packed (row, col, count) words left in the arena instead of first / second */,
-                           uint64_t* n_cells = nullptr) {
+                           uint64_t* n_cells = nullptr, const uint32_t* genome_of = nullptr /* the matrix's column order (make_column_order) */) {
     const bool cells = d_cells != nullptr;
     if (cells) { *d_cells = nullptr; *n_cells = 0; }
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows); uint32_t* row_off = ctx->arena.get<uint32_t>(rows + 1);
-    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 0, row_cnt, (const uint32_t*)row_off, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, genome_of);
     check_launch("screen_threshold0");
     exclusive_scan_u32(ctx, row_cnt, rows, row_off);
     uint32_t total = 0;
     d2h(&total, row_off + rows, 4, ctx->stream);
     if (!total) return;
     uint32_t* of = ctx->arena.get<uint32_t>(2 * (size_t)total); uint32_t* os = of + total; uint32_t* oc = cells ? ctx->arena.get<uint32_t>(total) : nullptr;
-    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 1, row_cnt, (const uint32_t*)row_off, of, os, oc);
+    SKH_LAUNCH(screen_threshold_kernel, rows, 256, 0, ctx->stream, cnt, n_planes, plane, row0, ncols, sr, d_mk_rows, d_mk_cols, 1, row_cnt, (const uint32_t*)row_off, of, os, oc, genome_of);
     check_launch("screen_threshold1");
     if (cells) {
         uint64_t* packed = ctx->arena.get<uint64_t>(total);
@@ -472,7 +559,9 @@ static void threshold_rows(skh_ctx* ctx, const uint32_t* cnt, uint32_t n_planes,
     }
     std::vector<uint32_t> both(2 * (size_t)total);
     d2h(both.data(), of, both.size() * 4, ctx->stream);
+    const size_t from = first.size();
     first.insert(first.end(), both.begin(), both.begin() + total); second.insert(second.end(), both.begin() + total, both.end());
+    if (genome_of) order_rows_columns(first, second, from);
 }
 
 // the smallest marker of part r of n_parts (0 for r = 0 and for r >= n_parts: no bound)
@@ -541,6 +630,8 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     sorted_screen_keys(ctx, ScreenKeysIn{S->markers.p, S->d_mk_off.p, range_lo, range_cnt, N, 0u}, n, n_parts == 1 ? all_from : bound(part), n_parts == 1 ? all_below : bound(part + 1), keys, nullptr);
     tr.mark("screen part: keys, sorted");
     const uint64_t plane = (uint64_t)N * N;
+    uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // (each part orders the columns by what ITS keys tie together: the cells name genomes)
+    if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, &col_of, &genome_of);
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
@@ -554,7 +645,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         ctx->part_cnt_clean = false;
         uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
         dzero(row_nz, (size_t)N * 4, ctx->stream);
-        if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
+        if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz, (const uint32_t*)col_of);
         else SKH_LAUNCH(screen_count_tri_kernel<true>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz);
         check_launch("screen_count(part)");
         tr.mark("screen part: count (first touch)");
@@ -562,7 +653,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
         uint32_t total = 0;
         d2h(&total, row_off + N, 4, ctx->stream);
         uint64_t* packed = ctx->arena.get<uint64_t>(total ? total : 1);
-        SKH_LAUNCH(screen_emit_cells_kernel, N, 256, 0, ctx->stream, ctx->part_cnt.p, N, (const uint32_t*)row_nz, (const uint32_t*)row_off, packed);
+        SKH_LAUNCH(screen_emit_cells_kernel, N, 256, 0, ctx->stream, ctx->part_cnt.p, N, (const uint32_t*)row_nz, (const uint32_t*)row_off, packed, (const uint32_t*)genome_of);
         check_launch("screen_emit_cells");
         dsync(ctx->stream);
         tr.mark("screen part: emit");
@@ -572,12 +663,12 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
-    if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
+    if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr, (const uint32_t*)col_of);
     else SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
     tr.mark("screen part: zero + count");
     const ScreenRule sr{0., SCREEN_RULE_NONZERO, 0, 1};
-    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, d_cells, n_cells);
+    threshold_rows(ctx, cnt, n_planes, plane, 0, N, N, sr, S->d_mk_off.p, S->d_mk_off.p, none_a, none_b, d_cells, n_cells, genome_of);
     dsync(ctx->stream);
     tr.mark("screen part: threshold + pack");
 }

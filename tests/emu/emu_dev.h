@@ -64,5 +64,6 @@ inline unsigned long long wave_clock() { return 0; }
 inline void wait_for_value(uint32_t) {}
 inline uint32_t xcc_id() { return 0; }
 inline void atomic_inc_xcd_local(uint32_t* p) { atomicAdd(p, 1u); }
+inline uint32_t load_past_l1(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 
 }  // namespace skh

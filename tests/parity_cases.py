@@ -421,9 +421,10 @@ def case_screen_count_walks(make_ctx, G=1700):
             if 300 <= g < 900: own.append([wide])
             if g % 7 == 0: own.append(base[:5] ^ np.uint64(3))
             sets.append(np.unique(np.concatenate([np.asarray(x, np.uint64) for x in own])))
+    sets = [sets[g] for g in rng.permutation(len(sets))]                               # related genomes far apart: the count matrix's column order brings them together
     want = _shared_marker_counts(sets)
     seen = []
-    for env in ({}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}, {"SKH_TUNE_SCREEN_PLANES": "1"}):
+    for env in ({}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}, {"SKH_TUNE_SCREEN_PLANES": "1"}, {"SKH_TUNE_SCREEN_COL_ORDER": "0"}):
         ctx = make_ctx(env)
         try:
             refs = _marker_set_import(ctx, sets)
@@ -437,7 +438,7 @@ def case_screen_count_walks(make_ctx, G=1700):
             refs.close()
         finally:
             ctx.close()
-    assert seen[0] == seen[1] == seen[2] and len(seen[0][0]) > 0
+    assert seen[0] == seen[1] == seen[2] == seen[3] and len(seen[0][0]) > 0
 
 
 def case_screen_from_cells_large_rows(ctx, N=17000):

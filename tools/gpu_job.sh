@@ -57,8 +57,8 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     hosttrace) SKH_TRACE=2 timeout 300 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 3 --warmup 2 2>&1 >/dev/null | grep "skh trace" | tail -75 > gpurun_out/${tag}_hosttrace.txt; tail -75 gpurun_out/${tag}_hosttrace.txt ;;
     predict) timeout 900 python tools/predict_scaling.py > gpurun_out/${tag}_predict_inputs.json 2> gpurun_out/${tag}_predict.err || tail -3 gpurun_out/${tag}_predict.err; cut -c1-400 gpurun_out/${tag}_predict_inputs.json ;;
     mergejoin) timeout 300 tools/exp/merge_join > gpurun_out/mergejoin_$tag.txt 2>&1; cat gpurun_out/mergejoin_$tag.txt ;;
-    screenab) for o in clade shuffled; do for v in 0 1 0 1; do SKH_TUNE_SCREEN_COUNT_ROWS=$v timeout 600 python bench.py --order $o --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_screen_rows${v}_$o.json 2> gpurun_out/${tag}_screen_rows${v}_$o.err || tail -3 gpurun_out/${tag}_screen_rows${v}_$o.err; short gpurun_out/${tag}_screen_rows${v}_$o.json; done; done
-              for v in 0 1; do SKH_TUNE_SCREEN_COUNT_ROWS=$v timeout 900 python bench.py --collection 10000 --steps 4 --warmup 2 --cpu-clades 0 --no-e2e > gpurun_out/${tag}_c4_screen_rows$v.json 2> gpurun_out/${tag}_c4_screen_rows$v.err || tail -3 gpurun_out/${tag}_c4_screen_rows$v.err; short gpurun_out/${tag}_c4_screen_rows$v.json; done ;;
+    screenab) for o in clade shuffled; do for v in "0 0" "1 0" "1 1" "1 0" "1 1"; do set -- $v; SKH_TUNE_SCREEN_COUNT_ROWS=$1 SKH_TUNE_SCREEN_COL_ORDER=$2 timeout 600 python bench.py --order $o --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_screen_rows$1_order$2_$o.json 2> gpurun_out/${tag}_screen_rows$1_order$2_$o.err || tail -3 gpurun_out/${tag}_screen_rows$1_order$2_$o.err; short gpurun_out/${tag}_screen_rows$1_order$2_$o.json | cut -c1-200; done; done
+              for v in "0 0" "1 0" "1 1"; do set -- $v; SKH_TUNE_SCREEN_COUNT_ROWS=$1 SKH_TUNE_SCREEN_COL_ORDER=$2 timeout 900 python bench.py --collection 10000 --steps 4 --warmup 2 --cpu-clades 0 --no-e2e > gpurun_out/${tag}_c4_screen_rows$1_order$2.json 2> gpurun_out/${tag}_c4_screen_rows$1_order$2.err || tail -3 gpurun_out/${tag}_c4_screen_rows$1_order$2.err; short gpurun_out/${tag}_c4_screen_rows$1_order$2.json | cut -c1-200; done ;;
     overlap) timeout 600 python tools/exp/two_halves.py > gpurun_out/${tag}_two_halves.txt 2> gpurun_out/${tag}_two_halves.err || tail -5 gpurun_out/${tag}_two_halves.err; cat gpurun_out/${tag}_two_halves.txt ;;
     probe) { echo "gfx950 agents: $(rocminfo 2>/dev/null | grep -c 'Name: *gfx950')"; rocminfo 2>/dev/null | grep -i "Marketing Name\|Compute Unit\|Name: *gfx" | head -20; echo "-- amd-smi partition"; timeout 60 amd-smi partition 2>&1 | head -40; echo "-- rocm-smi"; timeout 60 rocm-smi --showcomputepartition --showmemorypartition 2>&1 | head -20; python -c "import torch; print('torch devices', torch.cuda.device_count())"; nproc; } > gpurun_out/${tag}_probe.txt 2>&1; cat gpurun_out/${tag}_probe.txt ;;
     cli) timeout 900 python -m pytest tests/test_host_cpp.py -m gpu -x -q 2>&1 | tail -5 ;;
