@@ -148,23 +148,37 @@ __global__ __launch_bounds__(256) void colorder_init_kernel(uint32_t* parent, ui
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) parent[g] = g;
 }
-__device__ __forceinline__ uint32_t uf_root(uint32_t* parent, uint32_t x) {          // (a stale parent is an earlier ancestor: still in the component, still leads to the root)
-    for (;;) { const uint32_t q = load_past_l1(&parent[x]); if (q == x) return x; x = q; }
+// Two levels: 1.25 M threads uniting through 1,000 parent words in global memory -- 64 cache lines -- took 0.9 ms (the L2 serves a line's requests one after the other).  A
+// workgroup unites the neighbours of ITS chunk of the list in a parent array in LDS; what it found (genome, root: at most N pairs, a handful per cluster and chunk)
+// is united once more in the global array.
+struct UfShared { uint32_t* p; __device__ __forceinline__ uint32_t load(uint32_t x) const { return *(volatile uint32_t*)&p[x]; } };
+struct UfGlobal { uint32_t* p; __device__ __forceinline__ uint32_t load(uint32_t x) const { return load_past_l1(&p[x]); } };   // (a stale parent is an earlier ancestor: still in the component, still leads to the root)
+template <class P> __device__ __forceinline__ uint32_t uf_root(const P& parent, uint32_t x) {
+    for (;;) { const uint32_t q = parent.load(x); if (q == x) return x; x = q; }
 }
-__global__ __launch_bounds__(256) void colorder_union_kernel(const uint64_t* keys, uint64_t n_pairs /* incidences e, e + 1 with e < n_pairs */, uint32_t* parent) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_pairs) return;
-    const uint64_t k1 = keys[e], k2 = keys[e + 1];
-    if (skey_prefix(k1) != skey_prefix(k2) || !skey_same_marker(k1, k2)) return;
-    uint32_t a = skey_genome(k1), b = skey_genome(k2);
+template <class P> __device__ __forceinline__ void uf_unite(const P& parent, uint32_t a, uint32_t b) {
     for (;;) {
         a = uf_root(parent, a); b = uf_root(parent, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }                             // a > b: hook a under b
-        const uint32_t old = atomicMin(&parent[a], b);
+        const uint32_t old = atomicMin(&parent.p[a], b);
         if (old == a) return;                                                         // a was a root: done
         a = old;                                                                      // a had been hooked meanwhile: its former parent and b still have to meet
     }
+}
+constexpr uint32_t COLORDER_CHUNK = 1u << 16, COLORDER_N_MAX = 16384;                 // incidences per workgroup; genomes whose parents fit the LDS (64 KB)
+__global__ __launch_bounds__(1024) void colorder_union_kernel(const uint64_t* keys, uint64_t n_pairs /* incidences e, e + 1 with e < n_pairs */, uint32_t N, uint32_t* parent) {
+    SKH_DYN_SMEM(smem);
+    const UfShared mine{(uint32_t*)smem}; const UfGlobal all{parent};
+    for (uint32_t g = threadIdx.x; g < N; g += blockDim.x) mine.p[g] = g;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * COLORDER_CHUNK, hi = n_pairs - lo < COLORDER_CHUNK ? n_pairs : lo + COLORDER_CHUNK;
+    for (uint64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        const uint64_t k1 = keys[e], k2 = keys[e + 1];
+        if (skey_prefix(k1) == skey_prefix(k2) && skey_same_marker(k1, k2)) uf_unite(mine, skey_genome(k1), skey_genome(k2));
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < N; g += blockDim.x) { const uint32_t r = uf_root(mine, g); if (r != g) uf_unite(all, g, r); }
 }
 __global__ __launch_bounds__(256) void colorder_label_kernel(const uint32_t* parent, uint32_t n, uint64_t* lab) {   // (its own launch: every parent is final)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,12 +206,14 @@ __global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sor
 // col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes)
 static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t** col_of, uint32_t** genome_of) {
     *col_of = nullptr; *genome_of = nullptr;
-    if (!ctx->tune.screen_col_order || N < 2 || n_keys < 2) return;
+    if (!ctx->tune.screen_col_order || N < 2 || N > COLORDER_N_MAX || n_keys < 2) return;   // (beyond 16,384 genomes: collection order)
     uint32_t* parent = ctx->arena.get<uint32_t>(N); uint64_t* lab = ctx->arena.get<uint64_t>(N);
     uint32_t* co = ctx->arena.get<uint32_t>(N); uint32_t* go = ctx->arena.get<uint32_t>(N);
-    const uint64_t n_pairs = std::min<uint64_t>(n_keys - 1, std::max<uint64_t>(n_keys / 4, (uint64_t)1 << 20));
+    // a sample of the list's head: ~64 incidences per genome (a pair of genomes that shares a tenth of its markers meets six times; the rest is tied in by closer relatives)
+    const uint64_t n_pairs = std::min<uint64_t>(n_keys - 1, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 17));
     SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, parent, N);
-    SKH_LAUNCH(colorder_union_kernel, (unsigned)((n_pairs + 255) / 256), 256, 0, ctx->stream, keys, n_pairs, parent);
+    kernel_allow_lds(colorder_union_kernel, (size_t)N * 4);
+    SKH_LAUNCH(colorder_union_kernel, (unsigned)((n_pairs + COLORDER_CHUNK - 1) / COLORDER_CHUNK), 1024, (size_t)N * 4, ctx->stream, keys, n_pairs, N, parent);
     SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
     if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, 1, 1024, 0, ctx->stream, (const uint64_t*)lab, N, co, go);
     else {

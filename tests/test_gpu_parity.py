@@ -78,7 +78,9 @@ def test_screen_count_walks():
         finally:
             for k in env: os.environ.pop(k, None)
     pc.case_screen_count_walks(make_ctx)
-def test_screen_from_cells_large_rows(ctx): pc.case_screen_from_cells_large_rows(ctx)
+def test_screen_from_cells_large_rows(ctx):
+    pc.case_screen_from_cells_large_rows(ctx)                # beyond 16,384 genomes: an LDS row of more than 64 KB; columns in collection order
+    pc.case_screen_from_cells_large_rows(ctx, N=6000)        # 4,097 .. 16,384 genomes: the column order's labels through the radix sort
 def test_degenerate(ctx): pc.case_degenerate_pairs(ctx)
 def test_fragmented_genomes(ctx): pc.case_fragmented_genomes(ctx)
 def test_database_formats(ctx, tmp_path): pc.case_database_formats(ctx, str(tmp_path))
