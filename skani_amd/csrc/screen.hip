@@ -140,45 +140,41 @@ __global__ __launch_bounds__(256) void screen_count_qr2_kernel(const uint64_t* q
 
 // ---- the COLUMN ORDER of the triangle's count matrix (round 6).  The row-per-instruction kernel above pays one line request per increment again when the genomes of a
 // group are far apart in the collection -- related genomes under unrelated file names.  The matrix is the screen's own scratch, so its columns may stand in any order:
-// genomes are grouped by the connected component they fall into when the incidences of a quarter of the key range tie them together (a lock-free union-find on the sorted
-// list: neighbours of one marker are united; parents only ever decrease), components in the order of their smallest genome, genomes inside a component by number
-// (a collection that IS in clade order keeps its order).  Cell (row a, genome b) then sits in column col_of[b]; the rule kernels walk the columns and name genome
-// genome_of[column]; the host orders every row's few columns again (screen_pairs).  Which genomes end up next to each other changes no count: the pass set is the same.
+//   1. the head of the sorted list (~64 incidences per genome) is counted into the (zeroed) matrix as it stands, columns = genomes;
+//   2. a workgroup per row reads its cells, puts them back to zero, and unites the row's genome with every genome it shares at least `thr` of those sampled markers
+//      with -- a lock-free union-find in global memory (parents only ever decrease; ~19 links per genome).  A single shared marker does NOT tie two genomes: unrelated
+//      genomes share a marker here and there (5,200 such pairs among the 1,000 genomes of the synthetic collection, tools/exp/cross_clade_cells.py; in real collections
+//      far more), and clusters tied by single markers swallow each other;
+//   3. genomes are ordered by (smallest genome of their cluster, own number): a collection that IS in clade order keeps its order.
+// Cell (row a, genome b) then sits in column col_of[b]; the rule kernels walk the columns and name genome genome_of[column]; the host orders every row's few columns
+// again (order_rows_columns).  Which genomes end up next to each other changes no count: the pass set is the same.
 __global__ __launch_bounds__(256) void colorder_init_kernel(uint32_t* parent, uint32_t n) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) parent[g] = g;
 }
-// Two levels: 1.25 M threads uniting through 1,000 parent words in global memory -- 64 cache lines -- took 0.9 ms (the L2 serves a line's requests one after the other).  A
-// workgroup unites the neighbours of ITS chunk of the list in a parent array in LDS; what it found (genome, root: at most N pairs, a handful per cluster and chunk)
-// is united once more in the global array.
-struct UfShared { uint32_t* p; __device__ __forceinline__ uint32_t load(uint32_t x) const { return *(volatile uint32_t*)&p[x]; } };
-struct UfGlobal { uint32_t* p; __device__ __forceinline__ uint32_t load(uint32_t x) const { return load_past_l1(&p[x]); } };   // (a stale parent is an earlier ancestor: still in the component, still leads to the root)
-template <class P> __device__ __forceinline__ uint32_t uf_root(const P& parent, uint32_t x) {
-    for (;;) { const uint32_t q = parent.load(x); if (q == x) return x; x = q; }
+__device__ __forceinline__ uint32_t uf_root(uint32_t* parent, uint32_t x) {          // (a stale parent is an earlier ancestor: still in the cluster, still leads to the root)
+    for (;;) { const uint32_t q = load_past_l1(&parent[x]); if (q == x) return x; x = q; }
 }
-template <class P> __device__ __forceinline__ void uf_unite(const P& parent, uint32_t a, uint32_t b) {
+__device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t b) {
     for (;;) {
         a = uf_root(parent, a); b = uf_root(parent, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }                             // a > b: hook a under b
-        const uint32_t old = atomicMin(&parent.p[a], b);
+        const uint32_t old = atomicMin(&parent[a], b);
         if (old == a) return;                                                         // a was a root: done
         a = old;                                                                      // a had been hooked meanwhile: its former parent and b still have to meet
     }
 }
-constexpr uint32_t COLORDER_CHUNK = 1u << 16, COLORDER_N_MAX = 16384;                 // incidences per workgroup; genomes whose parents fit the LDS (64 KB)
-__global__ __launch_bounds__(1024) void colorder_union_kernel(const uint64_t* keys, uint64_t n_pairs /* incidences e, e + 1 with e < n_pairs */, uint32_t N, uint32_t* parent) {
-    SKH_DYN_SMEM(smem);
-    const UfShared mine{(uint32_t*)smem}; const UfGlobal all{parent};
-    for (uint32_t g = threadIdx.x; g < N; g += blockDim.x) mine.p[g] = g;
-    __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * COLORDER_CHUNK, hi = n_pairs - lo < COLORDER_CHUNK ? n_pairs : lo + COLORDER_CHUNK;
-    for (uint64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        const uint64_t k1 = keys[e], k2 = keys[e + 1];
-        if (skey_prefix(k1) == skey_prefix(k2) && skey_same_marker(k1, k2)) uf_unite(mine, skey_genome(k1), skey_genome(k2));
+__global__ __launch_bounds__(256) void colorder_links_kernel(uint32_t* cnt, uint32_t N, uint32_t thr, uint32_t* parent) {
+    const uint32_t row = blockIdx.x;
+    uint32_t* crow = cnt + (uint64_t)row * N;
+    for (uint32_t col = ((row + 1) & ~63u) + threadIdx.x; col < N; col += blockDim.x) {
+        if (col <= row) continue;
+        const uint32_t c = crow[col];
+        if (!c) continue;
+        crow[col] = 0;                                                                // the matrix leaves as it came: all zero
+        if (c >= thr) uf_unite(parent, row, col);
     }
-    __syncthreads();
-    for (uint32_t g = threadIdx.x; g < N; g += blockDim.x) { const uint32_t r = uf_root(mine, g); if (r != g) uf_unite(all, g, r); }
 }
 __global__ __launch_bounds__(256) void colorder_label_kernel(const uint32_t* parent, uint32_t n, uint64_t* lab) {   // (its own launch: every parent is final)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,17 +199,18 @@ __global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sor
     const uint32_t g = (uint32_t)sorted[x];
     genome_of[x] = g; col_of[g] = x;
 }
-// col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes)
-static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t** col_of, uint32_t** genome_of) {
+// col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes); `cnt`: N x N zeroed words of scratch, left zeroed
+static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t* cnt, uint32_t** col_of, uint32_t** genome_of) {
     *col_of = nullptr; *genome_of = nullptr;
-    if (!ctx->tune.screen_col_order || N < 2 || N > COLORDER_N_MAX || n_keys < 2) return;   // (beyond 16,384 genomes: collection order)
+    if (!ctx->tune.screen_col_order || N < 2 || n_keys < 2) return;
     uint32_t* parent = ctx->arena.get<uint32_t>(N); uint64_t* lab = ctx->arena.get<uint64_t>(N);
     uint32_t* co = ctx->arena.get<uint32_t>(N); uint32_t* go = ctx->arena.get<uint32_t>(N);
-    // a sample of the list's head: ~64 incidences per genome (a pair of genomes that shares a tenth of its markers meets six times; the rest is tied in by closer relatives)
-    const uint64_t n_pairs = std::min<uint64_t>(n_keys - 1, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 17));
+    const uint64_t n_sample = std::min<uint64_t>(n_keys, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 17));
+    const uint32_t thr = (uint32_t)std::max<uint64_t>(3, n_sample / N / 32);         // ~3 % of a genome's sampled markers (the screen's own cut-off is at 0.9 %: pairs that matter share far more)
     SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, parent, N);
-    kernel_allow_lds(colorder_union_kernel, (size_t)N * 4);
-    SKH_LAUNCH(colorder_union_kernel, (unsigned)((n_pairs + COLORDER_CHUNK - 1) / COLORDER_CHUNK), 1024, (size_t)N * 4, ctx->stream, keys, n_pairs, N, parent);
+    SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((n_sample + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, n_sample, 0u, N, N, cnt, 1u, (uint64_t)N * N, (uint32_t*)nullptr,
+               (const uint32_t*)nullptr);
+    SKH_LAUNCH(colorder_links_kernel, N, 256, 0, ctx->stream, cnt, N, thr, parent);
     SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
     if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, 1, 1024, 0, ctx->stream, (const uint64_t*)lab, N, co, go);
     else {
@@ -222,6 +219,12 @@ static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_key
         SKH_LAUNCH(colorder_place_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)sorted, N, co, go);
     }
     check_launch("screen column order");
+    if (getenv("SKH_DEBUG_COLORDER")) {
+        std::vector<uint64_t> h(N); d2h(h.data(), lab, (size_t)N * 8, ctx->stream);
+        std::vector<uint32_t> roots; for (auto v : h) roots.push_back((uint32_t)(v >> 32));
+        std::sort(roots.begin(), roots.end()); roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+        fprintf(stderr, "[colorder] N %u keys %llu sample %llu thr %u clusters %zu\n", N, (unsigned long long)n_keys, (unsigned long long)n_sample, thr, roots.size());
+    }
     *col_of = co; *genome_of = go;
 }
 // the candidates of rows [from, end) of `first` come out of the rule kernels in column order: every row's genomes ascending again (triangle.rs:90 walks them that way)
@@ -383,8 +386,8 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
     row_end = std::min(row_end, nrows);
-    uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // triangle: the count matrix's columns in an order of their own
-    if (tri && M && ctx->tune.screen_count_rows) make_column_order(ctx, keys, MR, ncols, &col_of, &genome_of);
+    uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // triangle: the count matrix's columns in an order of their own (when the whole matrix is one row block: it is the order's scratch)
+    if (tri && M && ctx->tune.screen_count_rows && row_begin == 0 && rows_per >= nrows) { dzero(cnt, plane * 4, ctx->stream); make_column_order(ctx, keys, MR, ncols, cnt, &col_of, &genome_of); }
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
         const uint32_t rows = std::min(rows_per, row_end - row0);
         dzero(cnt, plane * n_planes * 4, ctx->stream);
@@ -647,7 +650,6 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     tr.mark("screen part: keys, sorted");
     const uint64_t plane = (uint64_t)N * N;
     uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // (each part orders the columns by what ITS keys tie together: the cells name genomes)
-    if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, &col_of, &genome_of);
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
@@ -659,6 +661,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
             dzero(ctx->part_cnt.p, ctx->part_cnt.n * 4, ctx->stream);
         }
         ctx->part_cnt_clean = false;
+        if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, ctx->part_cnt.p, &col_of, &genome_of);
         uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
         dzero(row_nz, (size_t)N * 4, ctx->stream);
         if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz, (const uint32_t*)col_of);
@@ -679,6 +682,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
+    if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, cnt, &col_of, &genome_of);
     if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr, (const uint32_t*)col_of);
     else SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");
