@@ -183,15 +183,16 @@ __global__ __launch_bounds__(256) void colorder_label_kernel(const uint32_t* par
     lab[g] = (uint64_t)r << 32 | g;
 }
 constexpr uint32_t COLORDER_LDS_MAX = 4096;
-__global__ __launch_bounds__(1024) void colorder_rank_kernel(const uint64_t* lab, uint32_t n, uint32_t* col_of, uint32_t* genome_of) {   // n <= COLORDER_LDS_MAX, one workgroup
+// up to COLORDER_LDS_MAX genomes: every workgroup puts all labels into its LDS (its own launch: every parent is final) and each of its threads counts the labels below its genome's
+__global__ __launch_bounds__(256) void colorder_rank_kernel(const uint32_t* parent, uint32_t n, uint32_t* col_of, uint32_t* genome_of) {
     __shared__ uint64_t s[COLORDER_LDS_MAX];
-    for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) s[g] = lab[g];
+    for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) { uint32_t r = g; for (uint32_t q; (q = parent[r]) != r;) r = q; s[g] = (uint64_t)r << 32 | g; }
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) {
-        const uint64_t mine = s[g]; uint32_t rank = 0;
-        for (uint32_t x = 0; x < n; x++) rank += s[x] < mine ? 1u : 0u;                 // (labels are distinct: the genome is part of them)
-        col_of[g] = rank; genome_of[rank] = g;
-    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint64_t mine = s[g]; uint32_t rank = 0;
+    for (uint32_t x = 0; x < n; x++) rank += s[x] < mine ? 1u : 0u;                     // (labels are distinct: the genome is part of them)
+    col_of[g] = rank; genome_of[rank] = g;
 }
 __global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sorted, uint32_t n, uint32_t* col_of, uint32_t* genome_of) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,9 +212,9 @@ static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_key
     SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((n_sample + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, n_sample, 0u, N, N, cnt, 1u, (uint64_t)N * N, (uint32_t*)nullptr,
                (const uint32_t*)nullptr);
     SKH_LAUNCH(colorder_links_kernel, N, 256, 0, ctx->stream, cnt, N, thr, parent);
-    SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
-    if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, 1, 1024, 0, ctx->stream, (const uint64_t*)lab, N, co, go);
+    if (N <= COLORDER_LDS_MAX && !getenv("SKH_DEBUG_COLORDER")) SKH_LAUNCH(colorder_rank_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, co, go);
     else {
+        SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
         uint64_t* sorted = ctx->arena.get<uint64_t>(N);
         sort_keys_u64_into(ctx, lab, sorted, N, 64);
         SKH_LAUNCH(colorder_place_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)sorted, N, co, go);
@@ -270,12 +271,29 @@ __global__ __launch_bounds__(256) void screen_threshold_kernel(const uint32_t* c
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
     const uint32_t base_out = pass ? row_off[r] : 0;
-    for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
-        const uint32_t at = c0 + threadIdx.x;
-        bool ok = false; uint32_t count = 0, col = at;
-        if (at < ncols) {
+    if (genome_of) {
+        // columns in an order of their own: the host puts every row's candidates in order anyway (order_rows_columns), so a row is read without a barrier per 256 columns --
+        // the threads count (pass 0) or take their slots from a counter in LDS (pass 1)
+        uint32_t mine = 0;
+        const bool zero_may_pass = sr.rescue_small && (sr.rule == SKH_SCREEN_QUICK || (sr.rule == SKH_SCREEN_REFS && m_row < SCREEN_MIN_KMERS));   // (cell_passes: the rescued small genomes)
+        for (uint32_t at = threadIdx.x; at < ncols; at += blockDim.x) {
+            uint32_t count = 0;
             for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + at];
-            if (genome_of) col = genome_of[at];
+            if (!count && !zero_may_pass) continue;                                    // (most of a row: no look-ups for it)
+            const uint32_t col = genome_of[at];
+            if (!cell_passes(sr, count, m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col)) continue;
+            if (!pass) { mine++; continue; }
+            const uint32_t o = base_out + atomicAdd(&running, 1u);
+            out_first[o] = row; out_second[o] = col; if (out_count) out_count[o] = count;
+        }
+        if (!pass) { if (mine) atomicAdd(&running, mine); __syncthreads(); if (threadIdx.x == 0) row_cnt[r] = running; }
+        return;
+    }
+    for (uint32_t c0 = 0; c0 < ncols; c0 += blockDim.x) {
+        const uint32_t col = c0 + threadIdx.x;
+        bool ok = false; uint32_t count = 0;
+        if (col < ncols) {
+            for (uint32_t pl = 0; pl < n_planes; pl++) count += crow[(uint64_t)pl * plane + col];
             ok = cell_passes(sr, count, m_row, mk_off_cols[col + 1] - mk_off_cols[col], row, col);
         }
         // workgroup exclusive scan of the flags
@@ -387,10 +405,11 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
     row_end = std::min(row_end, nrows);
     uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // triangle: the count matrix's columns in an order of their own (when the whole matrix is one row block: it is the order's scratch)
-    if (tri && M && ctx->tune.screen_count_rows && row_begin == 0 && rows_per >= nrows) { dzero(cnt, plane * 4, ctx->stream); make_column_order(ctx, keys, MR, ncols, cnt, &col_of, &genome_of); }
+    if (tri && M && ctx->tune.screen_count_rows && row_begin == 0 && rows_per >= nrows) { dzero(cnt, plane * n_planes * 4, ctx->stream); make_column_order(ctx, keys, MR, ncols, cnt, &col_of, &genome_of); }
+    const bool zeroed = col_of != nullptr;                                           // (the order's scratch was the whole matrix: zeroed in front of it and left zeroed)
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
         const uint32_t rows = std::min(rows_per, row_end - row0);
-        dzero(cnt, plane * n_planes * 4, ctx->stream);
+        if (!(zeroed && row0 == row_begin)) dzero(cnt, plane * n_planes * 4, ctx->stream);
         if (M) {
             if (tri && ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((MR + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr, (const uint32_t*)col_of);
             else if (tri) SKH_LAUNCH(screen_count_tri_kernel<false>, (unsigned)((MR + 255) / 256), 256, 0, ctx->stream, keys, MR, row0, rows, ncols, cnt, n_planes, plane, (uint32_t*)nullptr);
