@@ -83,7 +83,8 @@ struct skh_tunables {
 namespace skh {
 struct PendingSort {
     DBuf<uint64_t> raw; DBuf<char> tmp; DevEvent ev; std::mutex mu;                  // raw: the keys in their buckets; tmp: bucket counters, offsets, cursors, range bounds (screen_keys.hip)
-    void release() { std::lock_guard<std::mutex> lk(mu); raw.release(); tmp.release(); }   // (only once the event is done)
+    DBuf<uint32_t> mat; DBuf<uint64_t> work; DBuf<char> sort_tmp;                    // the column order made behind the sort (screen.hip queue_column_order_ahead): its N x N sample matrix, union-find parents and labels
+    void release() { std::lock_guard<std::mutex> lk(mu); raw.release(); tmp.release(); mat.release(); work.release(); sort_tmp.release(); }   // (only once the event is done)
 };
 }  // namespace skh
 
@@ -191,6 +192,7 @@ struct skh_sketch_set {
     // sorted by marker (screen.hip).  The set is otherwise immutable; the mutex makes the one-time build safe when several
     // contexts share the set.
     mutable skh::DBuf<uint64_t> screen_keys;
+    mutable skh::DBuf<uint32_t> screen_col_of, screen_genome_of;   // the triangle screen's column order (screen.hip), made behind the index at sketch time for sets of up to 16,384 genomes
     // The index made at sketch time is sorted on the context's second stream and the sketch call does NOT wait for it (round 5): its last passes run while the host
     // returns to its caller and comes back with the screen -- they used to be a 0.18 ms tail behind the table build in front of ~0.1 ms of host time.  What the
     // sort still works on is let go when the event behind it is done: by the screen that waited for it, by the context's next call, or with the set.

@@ -200,33 +200,45 @@ __global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sor
     const uint32_t g = (uint32_t)sorted[x];
     genome_of[x] = g; col_of[g] = x;
 }
-// col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes); `cnt`: N x N zeroed words of scratch, left zeroed
-static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t* cnt, uint32_t** col_of, uint32_t** genome_of) {
-    *col_of = nullptr; *genome_of = nullptr;
-    if (!ctx->tune.screen_col_order || N < 2 || n_keys < 2) return;
-    uint32_t* parent = ctx->arena.get<uint32_t>(N); uint64_t* lab = ctx->arena.get<uint64_t>(N);
-    uint32_t* co = ctx->arena.get<uint32_t>(N); uint32_t* go = ctx->arena.get<uint32_t>(N);
+// The order's working arrays: the context's arena for an order made inside a screen call; buffers of the set's PendingSort for the one made at sketch time on the second
+// stream, which nobody waits for (the arena is reset when the sketch call returns).  `cnt`: N x N zeroed words of scratch, left zeroed.
+struct ColOrderWork { uint32_t* parent; uint64_t* lab; uint64_t* sorted; DBuf<char>* sort_tmp; };
+static bool column_order_wanted(const skh_ctx* ctx, uint32_t N, uint64_t n_keys) { return ctx->tune.screen_count_rows && ctx->tune.screen_col_order && N >= 2 && n_keys >= 2; }
+static void queue_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t* cnt, const ColOrderWork& w, uint32_t* col_of, uint32_t* genome_of) {
     const uint64_t n_sample = std::min<uint64_t>(n_keys, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 17));
     const uint32_t thr = (uint32_t)std::max<uint64_t>(3, n_sample / N / 32);         // ~3 % of a genome's sampled markers (the screen's own cut-off is at 0.9 %: pairs that matter share far more)
-    SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, parent, N);
+    SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, w.parent, N);
     SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((n_sample + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, n_sample, 0u, N, N, cnt, 1u, (uint64_t)N * N, (uint32_t*)nullptr,
                (const uint32_t*)nullptr);
-    SKH_LAUNCH(colorder_links_kernel, N, 256, 0, ctx->stream, cnt, N, thr, parent);
-    if (N <= COLORDER_LDS_MAX && !getenv("SKH_DEBUG_COLORDER")) SKH_LAUNCH(colorder_rank_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, co, go);
+    SKH_LAUNCH(colorder_links_kernel, N, 256, 0, ctx->stream, cnt, N, thr, w.parent);
+    if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)w.parent, N, col_of, genome_of);
     else {
-        SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)parent, N, lab);
-        uint64_t* sorted = ctx->arena.get<uint64_t>(N);
-        sort_keys_u64_into(ctx, lab, sorted, N, 64);
-        SKH_LAUNCH(colorder_place_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)sorted, N, co, go);
+        SKH_LAUNCH(colorder_label_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)w.parent, N, w.lab);
+        sort_keys_u64_into(ctx, w.lab, w.sorted, N, 64, w.sort_tmp);
+        SKH_LAUNCH(colorder_place_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)w.sorted, N, col_of, genome_of);
     }
     check_launch("screen column order");
-    if (getenv("SKH_DEBUG_COLORDER")) {
-        std::vector<uint64_t> h(N); d2h(h.data(), lab, (size_t)N * 8, ctx->stream);
-        std::vector<uint32_t> roots; for (auto v : h) roots.push_back((uint32_t)(v >> 32));
-        std::sort(roots.begin(), roots.end()); roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
-        fprintf(stderr, "[colorder] N %u keys %llu sample %llu thr %u clusters %zu\n", N, (unsigned long long)n_keys, (unsigned long long)n_sample, thr, roots.size());
-    }
+}
+// inside a screen call: col_of / genome_of in the context's arena (null when the order is switched off: columns = genomes)
+static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t* cnt, uint32_t** col_of, uint32_t** genome_of) {
+    *col_of = nullptr; *genome_of = nullptr;
+    if (!column_order_wanted(ctx, N, n_keys)) return;
+    const ColOrderWork w{ctx->arena.get<uint32_t>(N), ctx->arena.get<uint64_t>(N), ctx->arena.get<uint64_t>(N), nullptr};
+    uint32_t* co = ctx->arena.get<uint32_t>(N); uint32_t* go = ctx->arena.get<uint32_t>(N);
+    queue_column_order(ctx, keys, n_keys, N, cnt, w, co, go);
     *col_of = co; *genome_of = go;
+}
+// at sketch time, behind the index sort on the same stream: the order is cached in the set, the matrix it needs for a moment belongs to the PendingSort.  Up to 16,384
+// genomes (a 1 GB matrix); larger collections make the order inside their screen call, whose own matrix is there anyway.
+constexpr uint32_t COLORDER_AHEAD_MAX = 16384;
+static void queue_column_order_ahead(skh_ctx* ctx, const skh_sketch_set* set, PendingSort* ps) {
+    const uint32_t N = set->n_genomes; const uint64_t n_keys = set->screen_keys.n;
+    if (!column_order_wanted(ctx, N, n_keys) || N > COLORDER_AHEAD_MAX) return;
+    ps->mat.alloc((size_t)N * N); ps->work.alloc((size_t)3 * N);
+    set->screen_col_of.alloc(N); set->screen_genome_of.alloc(N);
+    dzero(ps->mat.p, (size_t)N * N * 4, ctx->stream);
+    const ColOrderWork w{(uint32_t*)ps->work.p, ps->work.p + N, ps->work.p + 2 * (size_t)N, &ps->sort_tmp};
+    queue_column_order(ctx, set->screen_keys.p, n_keys, N, ps->mat.p, w, set->screen_col_of.p, set->screen_genome_of.p);
 }
 // the candidates of rows [from, end) of `first` come out of the rule kernels in column order: every row's genomes ascending again (triangle.rs:90 walks them that way)
 static void order_rows_columns(const std::vector<uint32_t>& first, std::vector<uint32_t>& second, size_t from) {
@@ -338,7 +350,7 @@ void prepare_screen_keys(skh_ctx* ctx, const skh_sketch_set* set, bool async, co
         const ScreenKeysIn in{set->markers.p, set->d_mk_off.p, nullptr, nullptr, ng, 0u};
         if (plan && plan->valid && async) screen_keys_place(ctx, in, MR, *plan, plan_max, set->screen_keys.p, set->screen_sort.get());   // (counted by the marker build already)
         else sorted_screen_keys(ctx, in, MR, 0, 0, set->screen_keys.p, async ? set->screen_sort.get() : nullptr);
-        if (async) { set->screen_sort->ev.record(ctx->stream); ctx->pending_sorts.push_back(set->screen_sort); return; }
+        if (async) { queue_column_order_ahead(ctx, set, set->screen_sort.get()); set->screen_sort->ev.record(ctx->stream); ctx->pending_sorts.push_back(set->screen_sort); return; }
     }
     dsync(ctx->stream);
     set->screen_sort.reset();
@@ -405,8 +417,11 @@ void screen_pairs(skh_ctx* ctx, const skh_sketch_set* refs, const skh_sketch_set
     uint32_t* row_cnt = ctx->arena.get<uint32_t>(rows_per); uint32_t* row_off = ctx->arena.get<uint32_t>(rows_per + 1);
     row_end = std::min(row_end, nrows);
     uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // triangle: the count matrix's columns in an order of their own (when the whole matrix is one row block: it is the order's scratch)
-    if (tri && M && ctx->tune.screen_count_rows && row_begin == 0 && rows_per >= nrows) { dzero(cnt, plane * n_planes * 4, ctx->stream); make_column_order(ctx, keys, MR, ncols, cnt, &col_of, &genome_of); }
-    const bool zeroed = col_of != nullptr;                                           // (the order's scratch was the whole matrix: zeroed in front of it and left zeroed)
+    bool zeroed = false;
+    if (tri && M && ctx->tune.screen_count_rows && ctx->tune.screen_col_order) {
+        if (refs->screen_col_of.n == ncols && refs->screen_genome_of.n == ncols) { col_of = refs->screen_col_of.p; genome_of = refs->screen_genome_of.p; }   // made at sketch time, behind the index sort (whose event this stream has waited for)
+        else if (row_begin == 0 && rows_per >= nrows) { dzero(cnt, plane * n_planes * 4, ctx->stream); make_column_order(ctx, keys, MR, ncols, cnt, &col_of, &genome_of); zeroed = col_of != nullptr; }
+    }                                                                                // (zeroed: the order's scratch was the whole matrix, zeroed in front of it and left zeroed)
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += rows_per) {
         const uint32_t rows = std::min(rows_per, row_end - row0);
         if (!(zeroed && row0 == row_begin)) dzero(cnt, plane * n_planes * 4, ctx->stream);
