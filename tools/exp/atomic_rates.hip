@@ -53,7 +53,7 @@ template <int MODE, int SCOPE> static void run(const char* name, uint32_t* d, ui
 int main() {
     const size_t bytes = (size_t)8 << 22 << 2;   // up to 4 M words x 8 planes
     uint32_t* d; hipMalloc(&d, bytes);
-    printf("| pattern | scope | hot words x planes | ms (best of 4) | M lane-operations/s | M cell increments/s | increments counted |\n|---|---|---|---|---|---|---|\n");
+    printf("| pattern | scope | hot words x planes | ms (best of 4) | G lane-operations/s | G cell increments/s | increments counted |\n|---|---|---|---|---|---|---|\n");
     for (uint32_t words : {16384u, 131072u, 4194304u}) {
         run<0, 0>("scattered", d, words, 8, bytes);            run<0, 1>("scattered", d, words, 1, bytes);
         run<1, 0>("16 lanes = one line", d, words, 8, bytes);  run<1, 1>("16 lanes = one line", d, words, 1, bytes);
