@@ -28,8 +28,13 @@ __device__ __forceinline__ uint32_t wave_excl_small(uint32_t c, uint32_t l, uint
     total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
     return (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
 }
+#ifdef SKH_JOIN_WAVES   // experiment builds (tools/exp/build_variants.py chain.hip SKH_JOIN_WAVES 6 8): the register allocator held to that many waves per SIMD
+#define SKH_JOIN_OCC __attribute__((amdgpu_waves_per_eu(SKH_JOIN_WAVES, SKH_JOIN_WAVES)))
+#else
+#define SKH_JOIN_OCC
+#endif
 template <bool PROF>
-__global__ __launch_bounds__(JOIN_THREADS) void join_count_kernel(const PairDesc* pairs, const uint2* slot_tile,
+__global__ __launch_bounds__(JOIN_THREADS) SKH_JOIN_OCC void join_count_kernel(const PairDesc* pairs, const uint2* slot_tile,
                                                          uint32_t band, uint32_t* tile_anch, uint32_t* tile_hits, uint32_t* pair_anch, uint32_t* pair_inq,
                                                          uint2* hits, unsigned long long* inq_mask, uint32_t lds_words, unsigned long long* prof = nullptr) {
     SKH_DYN_SMEM(smem);

@@ -102,7 +102,10 @@ __host__ __device__ __forceinline__ uint32_t tab_list_code(uint32_t x) { return 
 // Occupancy filter of a seed table, staged in LDS by the join: one 32-bit word per TAB_FILTER_HOMES home slots (home >> 4: the slices of the table build own
 // whole words), two bits per distinct seed chosen by its low hash bits.  A probe whose two bits are not both set is absent for certain and costs no
 // memory request; an absent seed passes with probability (1 - e^(-1/2))^2 = 15 % (one bit per home slot, round 1: 39 %).  4 bits per position: 20 KB per 5 Mbp genome.
-constexpr uint32_t TAB_FILTER_SHIFT = 4, TAB_FILTER_HOMES = 1u << TAB_FILTER_SHIFT;
+#ifndef SKH_TAB_FILTER_SHIFT   // (experiment builds, tools/exp/lib_variant.sh: 5 = a 10 KB filter per 5 Mbp genome, 40 % of the absent seeds pass)
+#define SKH_TAB_FILTER_SHIFT 4
+#endif
+constexpr uint32_t TAB_FILTER_SHIFT = SKH_TAB_FILTER_SHIFT, TAB_FILTER_HOMES = 1u << TAB_FILTER_SHIFT;
 __host__ __device__ __forceinline__ uint32_t tab_filter_bits(uint32_t hash) { return (1u << (hash & 31u)) | (1u << ((hash >> 5) & 31u)); }
 __host__ __device__ __forceinline__ uint32_t tab_slot(uint32_t home) { return home + (home >> TAB_SLICE_SHIFT) * TAB_SLACK; }   // physical slot of a home slot
 
