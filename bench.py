@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 C, K, M = 125, 15, 1000
 CLADE = 20
 SEED0 = 0x5EED0000
+ROOT_CODES = None       # --root-fasta: a device tensor of 2-bit codes that every clade's root is taken from (a real genome) instead of i.i.d. bases
 
 
 def genome_order(n_total, order):
@@ -63,7 +64,10 @@ def make_genomes(torch, device, wanted, members=CLADE, mean_len=5_000_000, keep_
         gen = torch.Generator(device=device); gen.manual_seed(SEED0 + cl)
         cpu_rng = np.random.default_rng(SEED0 + cl)
         L = int(cpu_rng.integers(int(mean_len * 0.9), int(mean_len * 1.1) + 1))
-        root = torch.randint(0, 4, (L,), dtype=torch.uint8, device=device, generator=gen)
+        if ROOT_CODES is not None:
+            root = ROOT_CODES; L = int(root.numel())
+        else:
+            root = torch.randint(0, 4, (L,), dtype=torch.uint8, device=device, generator=gen)
         for m in range(max(want) + 1):
             d = float(cpu_rng.uniform(0.005, 0.08))
             mask = torch.rand(L, device=device, generator=gen) < d
@@ -510,6 +514,79 @@ def pick_sample(canon, n_total, clades):
     return np.nonzero(np.isin(canon // CLADE, list(cl)))[0]
 
 
+def kernel_sources_sha():
+    import hashlib
+    d = os.path.join(ROOT, "skani_amd", "csrc")
+    return hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h")))).hexdigest()[:16]
+
+
+def load_stage_profile(default_workload):
+    """profiles/stage_profile.json (tools/make_stage_profile.py: per-kernel rocprofv3 averages, FETCH_SIZE / WRITE_SIZE bytes, SQ residency of one bench step), quoted only
+    for the workload it was measured on and while the kernel sources are the ones it was measured on.  Returns (profile or None, note)."""
+    path = os.path.join(ROOT, "profiles", "stage_profile.json")
+    if not os.path.exists(path):
+        return None, "no profiles/stage_profile.json"
+    if not default_workload:
+        return None, "profiles/stage_profile.json was measured on the default workload only"
+    try:
+        sp = json.load(open(path))
+    except Exception as e:
+        return None, "unreadable profiles/stage_profile.json: %r" % (e,)
+    sha = kernel_sources_sha()
+    if sp.get("kernel_sources_sha256_16") != sha:
+        return None, "profiles/stage_profile.json was measured on other kernel sources (%s, now %s): not quoted" % (sp.get("kernel_sources_sha256_16"), sha)
+    return sp, "rocprofv3 --kernel-trace + four --pmc passes at commit %s (%s)" % (sp.get("commit"), sp.get("source"))
+
+
+def stage_rooflines(tm, steps, units, c, m, pairs_chained, sp):
+    """Every stage of the step against the HBM roofline (SURVEY 8d asks for seeding, screen and chaining; the table build and the chaining's three parts are listed too).
+    algorithmic bytes = the per-unit figures of DESIGN.md section 4 x the units counted behind the timed steps (`units`); ms_live = this run's HIP-event phase timer where
+    the stage is a phase of the library (the three parts of the chaining share one timer: apportioned by the profile's kernel times); ms_profile / counter bytes /
+    waves per SIMD from the stamped profile (None when it does not apply)."""
+    if not units or "error" in units:
+        return None
+    B, P, Mk, E, A, I = (units[k] for k in ("bases", "seed_positions", "markers", "enumerated_positions", "anchors", "candidate_intervals"))
+    alg = {"seeding": ((0.25 + 12.0 / c + 8.0 / m) * B, "0.25 B/base packed + 12/c B seeds + 8/m B markers"),
+           "tables": (29.0 * P + 40.0 * Mk, "29 B/position (8 read, 4 gathered, 17 written: slots + filter) + 40 B/marker (set: 8 in, 16 out; index: 8 in, 8 out)"),
+           "screen": (8.0 * Mk, "8 B per marker incidence (SURVEY 8d)"),
+           "join": (8.0 * E + 16.0 * A, "8 B per enumerated position + 16 B per anchor (hit record + anchor)"),
+           "chunking + DP": (8.0 * A + 40.0 * I, "8 B per anchor + 40 B per candidate interval"),
+           "selection + estimate": (40.0 * I + 4.0 * E + 64.0 * pairs_chained, "40 B per candidate interval + 4 B per query position + the 64-byte result row")}
+    live = {"seeding": tm["seed_ms"] / steps, "tables": tm["sketch_build_ms"] / steps, "screen": tm["screen_ms"] / steps}
+    chain_live = tm["chain_ms"] / steps
+    prof = {}
+    if sp:
+        for k in sp["kernels"]:
+            e = prof.setdefault(k["stage"], {"ms": 0.0, "read": 0.0, "write": 0.0, "kernels": []})
+            e["ms"] += k["ms_per_step"]
+            rd = k.get("read_bytes_per_step")
+            if rd is not None and k["class"] == "mixed":
+                rd += 8.0 * E / 2                                       # the count pass's stream of seeds and positions: FETCH_SIZE saw half of it (tools/make_stage_profile.py)
+            e["read"] += rd or 0.0; e["write"] += k.get("write_bytes_per_step") or 0.0
+            e["kernels"].append({kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in k.items()
+                                 if kk in ("kernel", "ms_per_step", "launches_per_step", "waves_per_simd", "valu_busy_pct", "wait_any_pct", "vgprs", "lds_bytes")})
+    chain_parts = ("join", "chunking + DP", "selection + estimate")
+    chain_prof = sum(prof.get(x, {}).get("ms", 0.0) for x in chain_parts)
+    rows = []
+    for st in ("seeding", "tables", "screen") + chain_parts:
+        ms_live = live.get(st)
+        apportioned = False
+        if ms_live is None and chain_prof > 0 and st in prof:
+            ms_live = chain_live * prof[st]["ms"] / chain_prof; apportioned = True
+        pr = prof.get(st)
+        ms = ms_live if ms_live else (pr["ms"] if pr else None)
+        row = {"stage": st, "bound": "hbm", "algorithmic_bytes": alg[st][0], "bytes_rule": alg[st][1], "ms_live": ms_live, "ms_live_apportioned": apportioned,
+               "ms_profile": pr["ms"] if pr else None, "counter_bytes": (pr["read"] + pr["write"]) if pr and (pr["read"] + pr["write"]) > 0 else None,
+               "achieved": alg[st][0] / (ms * 1e-3) / 1e9 if ms else None, "peak": 8000.0, "unit": "GB/s"}
+        row["frac"] = row["achieved"] / 8000.0 if row["achieved"] else None
+        if row["counter_bytes"]:
+            row["traffic_over_algorithmic"] = row["counter_bytes"] / alg[st][0]
+        if pr:
+            row["kernels"] = sorted(pr["kernels"], key=lambda k: -k["ms_per_step"])[:6]
+        rows.append(row)
+    return rows
+
+
 def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, steps, warmup, want_cpu, want_e2e, defer_cpu_legs=False):
     """One measured triangle workload: every rank makes its n_local genomes of the collection (n_local * world, in `order`), W warm-up steps, `steps` timed steps
     between barriers, the MAX over ranks.  Rank 0 returns the bench line (a dict), the others None.  want_cpu: the oracle beside it (`cpu_baseline`, rank 0 only:
@@ -527,6 +604,8 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
             cpu_ids = pick_sample(canon, n_total, args.cpu_sample_clades if args.cpu_clades < 0 else args.cpu_clades)
         else:
             cpu_ids = np.arange(n_total if args.cpu_clades < 0 else min(n_total, args.cpu_clades * CLADE), dtype=np.int64)
+        if args.cpu_genomes > 0:                                       # (a dense collection: the oracle on its first genomes, all pairs among them)
+            cpu_ids = np.arange(min(n_total, args.cpu_genomes), dtype=np.int64)
     local_ids = cpu_ids if world == 1 else np.zeros(0, np.int64)      # (several ranks: the sample is made after the timed steps, its members live on every rank)
     keep = np.zeros(n_local, bool); keep[local_ids] = True
     bases, contig_off, contig_genome, ng, host_genomes = make_genomes(torch, device, mine, mean_len=args.mean_len, members=CLADE, keep_host=keep if len(local_ids) else False)
@@ -588,6 +667,23 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
+    units = None
+    if comm is None and not args.no_units:
+        # what the step worked on, counted once OUTSIDE the timed region (a sketch + screen + chaining call with per-pair stage statistics): the units roofline_stages prices
+        try:
+            ss_u = ctx.sketch_genomes(gs, params, genome_rank=genome_rank)
+            meta = ss_u.export_meta()
+            npos = np.diff(np.asarray(meta["pos_off"], np.int64))
+            ui, uj = ctx.screen(ss_u, None, 0.0)
+            _, ust = ctx.chain_pairs(ss_u, None, ui, uj, mp, stats=True)
+            enumerated = np.where(ust["switched"] != 0, npos[ui], npos[uj])                 # chain.rs:625-661: the side that is walked position by position
+            units = {"bases": total_bases_local, "seed_positions": int(meta["pos_off"][-1]), "markers": int(meta["marker_off"][-1]), "candidate_pairs": int(len(ui)),
+                     "enumerated_positions": int(enumerated.sum()), "anchors": int(ust["n_anchors"].sum()), "listed_query_positions": int(ust["n_qpos"].sum()),
+                     "chunks": int(ust["n_chunks"].sum()), "candidate_intervals": int(ust["n_intervals"].sum()), "accepted_intervals": int(ust["n_accepted"].sum())}
+            ss_u.close()
+        except Exception as e:                                        # the line must not depend on it
+            units = {"error": repr(e)}
+        ctx.timings()
     gs.close()
     torch.cuda.empty_cache()
     if os.environ.get("BENCH_STEP_TIMES"):
@@ -633,11 +729,17 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
     roof = {"kernel": "seed_tiles_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": traffic, "traffic_source": traffic_note, "bytes_per_launch": bytes_per_launch, "ms_per_launch": seed_ms_per_launch,
             "launches_per_step": launches / steps,
-            "note": "0.354 algorithmic B/base; the kernel is bound by VALU issue, not by HBM: see valu_frac and profiles/r02_valu_rates.md.  achieved / frac use this run's "
-                    "HIP-event time per launch; frac_rocprof the average duration of the committed rocprofv3 kernel trace of the same kernel source (a few per cent longer)"}
+            "note": "0.354 algorithmic B/base; the kernel is bound by VALU issue, not by HBM: see valu_frac and profiles/r02_valu_rates.md.  frac_basis says which time "
+                    "achieved / frac are divided by; frac_hip_events is always this run's own HIP-event time per launch"}
+    roof["frac_hip_events"] = roof["frac"]; roof["achieved_hip_events"] = roof["achieved"]
+    roof["frac_basis"] = "this run's HIP-event time per launch (no rocprofv3 trace of these kernel sources on this workload is committed)"
     if rocprof_ms:
+        # the judged fraction: algorithmic bytes over the kernel's AVERAGE duration in the committed rocprofv3 --kernel-trace run of the same source (a few per cent longer than
+        # the HIP-event time of this run, which stays on the line as frac_hip_events)
         roof["ms_per_launch_rocprof"] = rocprof_ms
-        roof["frac_rocprof"] = bytes_per_launch / (rocprof_ms * 1e-3) / 1e9 / 8000.0
+        roof["achieved"] = bytes_per_launch / (rocprof_ms * 1e-3) / 1e9
+        roof["frac"] = roof["frac_rocprof"] = roof["achieved"] / 8000.0
+        roof["frac_basis"] = "average duration of the kernel in the committed rocprofv3 --kernel-trace summary of the same kernel source (profiles/seed_traffic.json: rocprof_avg_ms)"
     if valu:
         # VALU issue cycles the kernel's instructions need (static count per wave x measured cycles per instruction class, tools/isa_mix.py) over the
         # SIMD cycles its launch had: 1024 SIMDs x shader clock x kernel time
@@ -700,6 +802,17 @@ def run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, devic
                     out["roofline_chain"]["traffic_source"] = "profiles/chain_traffic.json was measured on other chaining sources: not quoted"
             except Exception as e:
                 out["roofline_chain"]["traffic_source"] = "unreadable profiles/chain_traffic.json: %r" % (e,)
+    out["units"] = units
+    if world == 1:
+        default_workload = n_local == 1000 and args.mean_len == 5_000_000 and C == 125 and order == "clade" and CLADE == 20
+        sp, sp_note = load_stage_profile(default_workload)
+        out["roofline_stages"] = stage_rooflines(tm, steps, units, C, M, chained, sp)
+        out["roofline_stages_source"] = sp_note
+        if out["roofline_stages"]:
+            scr = next(r for r in out["roofline_stages"] if r["stage"] == "screen")
+            out["roofline_screen"] = {"stage": "marker screen (incidence count + rule; the index sort runs at sketch time)", "bound": "hbm", "achieved": scr["achieved"], "peak": 8000.0, "unit": "GB/s",
+                                      "frac": scr["frac"], "bytes_per_step": scr["algorithmic_bytes"], "ms_per_step": scr["ms_live"], "traffic": scr["counter_bytes"],
+                                      "note": "8 B per marker incidence (SURVEY 8d); what bounds the count is the L2's atomic units -- line requests, not bytes: profiles/r06_atomic_rates.md"}
     out["cpu_baseline"] = None
     def cpu_legs(host_genomes=host_genomes):
         """The legs that load the host's cores (the oracle's thread sweep, the command line with its ingest threads): run by the caller AFTER every GPU measurement of the
@@ -737,6 +850,12 @@ def main():
     ap.add_argument("--cpu-clades", type=int, default=-1, help="clades (x20 genomes) the CPU baseline runs on; default -1 = the full workload on one GPU, --cpu-sample-clades "
                     "sampled clades with --collection or on several GPUs; 0 disables")
     ap.add_argument("--no-ci", action="store_true")
+    ap.add_argument("--root-fasta", default="", help="every clade's root is this genome (FASTA, .gz allowed; all records joined, bytes other than ACGT read as A) instead of "
+                    "i.i.d. bases: a rate on real sequence -- repeated seeds, list storage and the join's band rule on the timed path (with --clade = the number of genomes: all pairs chained)")
+    ap.add_argument("--cpu-genomes", type=int, default=0, help="the oracle runs on the first N genomes of the collection (overrides --cpu-clades; for dense collections)")
+    ap.add_argument("--no-variants", action="store_true", help="the default line also measures the secondary scale points (dense, -c 30 / 70 / 200, 5,000 genomes) as its `variants` block; this skips them")
+    ap.add_argument("--no-units", action="store_true", help="skip the untimed pass behind the timed steps that counts the step's units (positions, markers, anchors, ...: roofline_stages); "
+                    "profiling runs pass it so that a trace holds the steps' kernels only")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (FASTA files on a RAM disk through the skani-hip binary, ~20 s)")
     ap.add_argument("--c", type=int, default=125, help="-c compression factor (presets: 30 slow, 70 medium, 125 default, 200 fast)")
     ap.add_argument("--clade", type=int, default=20, help="genomes per clade (= genomes-per-gpu gives the dense single-clade variant)")
@@ -765,7 +884,7 @@ def main():
     import torch
     import torch.distributed as dist
     import skani_amd as sk
-    global C, CLADE
+    global C, CLADE, ROOT_CODES
     C, CLADE = args.c, args.clade
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -823,8 +942,35 @@ def main():
             if comm is None:
                 comm = Comm.host(ctx, dist, rank, world, torch=torch)
 
+    real = None
+    if args.root_fasta:
+        import gzip
+        opener = gzip.open if args.root_fasta.endswith(".gz") else open
+        seq = b"".join(l.strip() for l in opener(args.root_fasta, "rb") if not l.startswith(b">"))
+        lut = np.zeros(256, np.uint8)
+        for ch, code in ((b"Cc", 1), (b"Gg", 2), (b"TtUu", 3)):
+            for b_ in ch: lut[b_] = code
+        ROOT_CODES = torch.from_numpy(lut[np.frombuffer(seq, np.uint8)]).to(device)
+        real = {"root": os.path.basename(args.root_fasta), "root_bases": len(seq),
+                "generator": "every genome = the root with substitution rate U(0.005, 0.08), 0-5 deletions of 10-50 kb, cut into 1-20 contigs (make_genomes; the point-substitution model of tests/helpers.mutate)"}
     out = run_triangle(args, torch, dist, sk, ctx, comm, transport, rank, world, device, n_local, order, strong, args.steps, args.warmup,
-                       want_cpu=True, want_e2e=not args.no_e2e and not strong, defer_cpu_legs=True)
+                       want_cpu=True, want_e2e=not args.no_e2e and not strong and not args.root_fasta, defer_cpu_legs=True)
+    if real is not None and rank == 0:
+        # what a real genome puts on the timed path that i.i.d. sequence does not: seeds with several positions (list storage) and seeds beyond the band (dropped by the join, chain.rs:674-696)
+        b0, co0, cg0, ng0, _ = make_genomes(torch, device, [0], mean_len=args.mean_len, members=CLADE)
+        torch.cuda.synchronize()
+        g0 = ctx.pack_buffer(None, co0, cg0, ng0, sk.SEED_AVX2, device_ptr=b0.data_ptr())
+        s0 = ctx.sketch_genomes(g0, sk.SketchParams(C, K, M, sk.SEED_AVX2))
+        seeds = s0.export(0)["seed"]
+        _, cnt = np.unique(seeds, return_counts=True)
+        band = 2500 // C
+        n_pos = int(cnt.sum()); listed = int(cnt[(cnt > 1) & (cnt <= band)].sum()); rep = int(cnt[cnt > band].sum())
+        words = int((cnt[(cnt > 1) & (cnt <= band)] + 1).sum())                       # a list = its count + its positions
+        real["genome_0"] = {"seed_positions": n_pos, "distinct_seeds": int(len(cnt)), "positions_of_seeds_with_2_to_band_positions": listed, "positions_of_seeds_beyond_the_band": rep,
+                            "share_in_lists": listed / n_pos, "share_repetitive": rep / n_pos, "list_storage_words_used": words, "list_storage_fill": words / (1.5 * n_pos),
+                            "note": "list storage capacity = 6 B per seed position (DESIGN.md section 3); i.i.d. genomes of this size: ~5 % in lists, nothing beyond the band"}
+        s0.close(); g0.close(); del b0
+        out["real_sequence"] = real
     # the same N on the fixed collection (BASELINE config 4's 10,000 genomes): the strong-scaling point that belongs to this line.  A default sweep --gpus 1/2/4/8 then
     # yields the weak series (`value`) AND the strong one (`strong.ms_per_step`) without a second sweep.
     default_shape = not args.genomes_per_gpu and args.mean_len == 5_000_000 and CLADE == 20 and C == 125 and not args.force_dist
@@ -845,6 +991,24 @@ def main():
                                           "N = 1 / at N; every step's wall time on rank 0 is listed (step_wall_ms_rank0)" % (args.strong_collection, sn)})
             if "per_rank" in s:
                 out["strong"]["per_rank"] = s["per_rank"]
+    if world == 1 and default_shape and order == "clade" and not strong and not args.root_fasta and not args.no_variants and n_local == 1000:
+        # SURVEY 8d's secondary scale points on this code, this box: the dense collection (one clade: all 499,500 pairs chained), the other presets (cli.rs:60-68), 5,000 genomes
+        variants = []
+        for name, kw in (("dense: 1,000 genomes in ONE clade, every pair chained", dict(clade=1000, steps=2)), ("-c 30 (--slow)", dict(c=30, steps=3)), ("-c 70 (--medium)", dict(c=70, steps=5)),
+                         ("-c 200 (--fast)", dict(c=200, steps=5)), ("5,000 genomes (250 clades of 20)", dict(n=5000, steps=3))):
+            c0, cl0 = C, CLADE
+            try:
+                C, CLADE = kw.get("c", 125), kw.get("clade", 20)
+                v = run_triangle(args, torch, dist, sk, ctx, None, None, 0, 1, device, kw.get("n", 1000), "clade", False, kw["steps"], 1, want_cpu=False, want_e2e=False)
+                variants.append({"variant": name, "ms_per_step": v["ms_per_step"], "value": v["value"], "unit": v["unit"], "steps": v["steps"], "phase_ms_per_step": v["phase_ms_per_step"],
+                                 "chained_pairs": v["config"]["chained_pairs"], "chained_pairs_per_s": v["chained_pairs_per_s_per_gpu"], "genomes": v["config"]["genomes"],
+                                 "units": v.get("units"), "roofline_frac_seeding_hip_events": v["roofline"]["frac_hip_events"]})
+            except Exception as e:
+                variants.append({"variant": name, "error": repr(e)})
+            finally:
+                C, CLADE = c0, cl0
+            torch.cuda.empty_cache()
+        out["variants"] = variants
     if rank == 0:
         out.pop("_cpu_legs")()                                         # (cpu_baseline, e2e: behind every GPU measurement, see run_triangle)
         print(json.dumps(out))

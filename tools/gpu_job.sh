@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root; through gpurun): tools/gpu_job.sh <tag> <section> [<section> ...]
 # One parameterised job instead of a script per GPU run.  Everything lands in gpurun_out/ under names that carry <tag>.
-# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | screenab | overlap | probe | benchmini (first: stops the job when bench.py fails)
+# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | screenab | overlap | probe | stageprofile | realdense | variants (after bench) | benchmini (first: stops the job when bench.py fails)
 mkdir -p gpurun_out
 tag=$1; shift
 short() { python - "$1" <<'PY'
@@ -28,8 +28,8 @@ import json; d=json.load(open('gpurun_out/bench_$tag.json')); r=d['roofline']; p
     gaps) db=$(find /tmp/prof_$tag -name "*.db" | head -1); python tools/rocpd_gaps.py $db gpurun_out/gaps_$tag.txt | head -3; python tools/rocpd_timeline.py $db gpurun_out/timeline_$tag.txt > /dev/null ;;
     pmc) tools/pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1; tail -2 gpurun_out/pmc_$tag.log | cut -c1-160 ;;
     traffic) timeout 300 python bench.py --no-e2e --cpu-clades 0 --strong-collection 0 > gpurun_out/bench_pre_$tag.json 2>/dev/null
-             python tools/make_seed_traffic.py gpurun_out/pmc_$tag.json "profiles/r05_pmc.json (tools/pmc.sh, $tag)" gpurun_out/trace_$tag.md | tail -3
-             python tools/make_chain_traffic.py gpurun_out/pmc_$tag.json gpurun_out/bench_pre_$tag.json "profiles/r05_pmc.json (tools/pmc.sh, $tag)" | tail -2
+             python tools/make_seed_traffic.py gpurun_out/pmc_$tag.json "profiles/r06_pmc.json (tools/pmc.sh, $tag)" gpurun_out/trace_$tag.md | tail -3
+             python tools/make_chain_traffic.py gpurun_out/pmc_$tag.json gpurun_out/bench_pre_$tag.json "profiles/r06_pmc.json (tools/pmc.sh, $tag)" | tail -2
              cp profiles/seed_traffic.json gpurun_out/seed_traffic_$tag.json; cp profiles/chain_traffic.json gpurun_out/chain_traffic_$tag.json ;;
     forcedist) timeout 300 python bench.py --force-dist --cpu-clades 0 --no-e2e --steps 20 > gpurun_out/${tag}_fd.json 2> gpurun_out/${tag}_fd.err; short gpurun_out/${tag}_fd.json ;;
     config4) timeout 900 python bench.py --collection 10000 --steps 8 --warmup 4 > gpurun_out/${tag}_config4_n1.json 2> gpurun_out/${tag}_config4_n1.err || tail -5 gpurun_out/${tag}_config4_n1.err; short gpurun_out/${tag}_config4_n1.json ;;
@@ -46,7 +46,14 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     presets) for c in 30 70 200; do timeout 300 python bench.py --c $c --cpu-clades 0 --no-e2e --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c=$c', round(d['ms_per_step'],2))"; done
              timeout 300 python bench.py --genomes-per-gpu 5000 --cpu-clades 0 --no-e2e --steps 4 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('n5000', round(d['ms_per_step'],2), round(d['value']/1e6,1))"
              timeout 300 python bench.py --clade 1000 --cpu-clades 0 --no-e2e --steps 2 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dense', round(d['ms_per_step'],1), d['config']['chained_pairs'])" ;;
-    fuzz*) n=${sec#fuzz}; n=${n#:}; timeout 600 python tools/fuzz_parity.py ${n:-400} $RANDOM | tail -1 ;;
+    fuzz*) n=${sec#fuzz}; n=${n#:}; seed=$RANDOM; { echo "tools/fuzz_parity.py ${n:-400} $seed   (rounds, seed)  on $(date -u +%FT%TZ), sources $(cat skani_amd/csrc/*.hip skani_amd/csrc/*.h | sha256sum | cut -c1-16)"; timeout 1200 python tools/fuzz_parity.py ${n:-400} $seed 2>&1 | tail -4; } > gpurun_out/${tag}_fuzz.txt; cat gpurun_out/${tag}_fuzz.txt ;;
+    stageprofile) python tools/make_stage_profile.py gpurun_out/trace_$tag.json gpurun_out/pmc_$tag.json 3 "tools/prof.sh + tools/pmc.sh, $tag" | tail -12; cp profiles/stage_profile.json gpurun_out/stage_profile_$tag.json ;;
+    realdense) timeout 1500 python bench.py --root-fasta tests/golden/e.coli-W.fasta.gz --clade 1000 --cpu-genomes 24 --steps 2 --warmup 1 --strong-collection 0 --no-e2e > gpurun_out/${tag}_real_dense.json 2> gpurun_out/${tag}_real_dense.err || tail -5 gpurun_out/${tag}_real_dense.err
+               short gpurun_out/${tag}_real_dense.json; python -c "
+import json; d=json.load(open('gpurun_out/${tag}_real_dense.json')); print(json.dumps(d.get('real_sequence'))[:900]); print(json.dumps(d.get('units')))" ;;
+    variants) python -c "
+import json; d=json.load(open('gpurun_out/bench_$tag.json')); v=d.get('variants'); json.dump({'commit_note': 'the variants block of gpurun_out/bench_$tag.json (bench.py default run)', 'headline_ms_per_step': d['ms_per_step'], 'variants': v}, open('gpurun_out/${tag}_variants.json','w'), indent=1)
+for x in v or []: print(x.get('variant'), round(x.get('ms_per_step', 0), 2), x.get('chained_pairs'), round(x.get('chained_pairs_per_s', 0)), x.get('error'))" ;;
     wide) for sw in 1 0; do SKH_TUNE_WIDE_SPAN=0 SKH_TUNE_WIDE_SWEEP_DP=$sw timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 10 > gpurun_out/${tag}_wide_sweep$sw.json 2> gpurun_out/${tag}_wide_sweep$sw.err || tail -3 gpurun_out/${tag}_wide_sweep$sw.err; short gpurun_out/${tag}_wide_sweep$sw.json; done
           SKH_TUNE_WIDE_SPAN=0 timeout 900 python bench.py --cpu-clades 5 --no-e2e --strong-collection 0 --steps 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('forced wide vs oracle', d['cpu_baseline']['delta_vs_oracle'])" ;;
     sortab) for r in 1 0; do SKH_TUNE_SCREEN_SORT_RADIX=$r timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/${tag}_sort_radix$r.json 2> gpurun_out/${tag}_sort_radix$r.err || tail -3 gpurun_out/${tag}_sort_radix$r.err; short gpurun_out/${tag}_sort_radix$r.json; done ;;

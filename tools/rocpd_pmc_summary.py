@@ -12,7 +12,7 @@ def main():
                       "sum(grid_size) from counters_collection where kernel_name like ? group by kernel_name, counter_name", ("%" + flt + "%",))
     out = {}
     for name, counter, n, val, dur, lds, vgpr, wg, grid in rows:
-        k = name.split("(")[0]
+        k = name.replace("(anonymous namespace)::", "").split("(")[0]                 # (the kernels of an unnamed namespace keep their names: they all became "skh::" before round 6)
         d = out.setdefault(k, {"dispatches": n, "total_ns": dur, "lds_bytes": lds, "vgprs": vgpr, "workgroup": wg, "threads": grid, "counters": {}})
         d["counters"][counter] = val
     json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)

@@ -17,6 +17,15 @@ def main():
     text = hdr + "total kernel time %.3f ms\n\n" % tot + "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(text)
+        if sys.argv[2].endswith(".md"):                                              # the same rows for tools (tools/make_stage_profile.py), names as tools/rocpd_pmc_summary.py writes them
+            import json
+            js = {}
+            for r in rows:
+                k = r[0].replace("(anonymous namespace)::", "").split("(")[0]
+                e = js.setdefault(k, {"calls": 0, "total_ms": 0.0, "vgprs": r[6], "lds_bytes": r[7], "scratch_bytes": r[8]})
+                e["calls"] += r[1]; e["total_ms"] += r[2]
+            for e in js.values(): e["avg_us"] = 1e3 * e["total_ms"] / max(e["calls"], 1)
+            json.dump(js, open(sys.argv[2][:-3] + ".json", "w"), indent=1, sort_keys=True)
     else:
         print(text)
 
