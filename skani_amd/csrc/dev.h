@@ -206,6 +206,54 @@ __device__ __forceinline__ uint32_t xcc_id() { uint32_t x; asm volatile("s_getre
 __device__ __forceinline__ uint32_t load_past_l1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void atomic_inc_xcd_local(uint32_t* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// ---- the seeding loop's instructions (pack_seed.hip seed_tiles_kernel; the WHY is told there).  The simulator build has plain C++ under the same names (tests/emu/emu_dev.h).
+#define SKH_SEED_DROP_NOTE() ((void)0)
+// lanes with a >= b as a wave mask: ONE compare writing a scalar register pair (__ballot() goes through a select and a second compare)
+__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35 /* ICMP_UGE */); }
+// v |= bits in the lanes of the (wave-uniform, non-empty) mask: ONE vector instruction under a narrowed exec mask (as an `if` it is compare + select + or)
+__device__ __forceinline__ void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(v), "=&s"(save) : "s"(lanes), "s"(bits));
+}
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+template <int SH> __device__ __forceinline__ uint64_t shl_add_u64(uint64_t a, uint64_t b) {          // (a << SH) + b, SH <= 4, one instruction
+    uint64_t d; asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH)); return d;
+}
+// mm_hash64 (types.rs:86-96) of a 32-bit key in 16 instructions
+__device__ __forceinline__ uint64_t seed_hash(uint32_t seed) {
+    const uint64_t p = (uint64_t)seed * 0x200001ull;                   // key + (key << 21) < 2^54; the NOT of step 1 is folded into step 2:
+    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);       //   ~p ^ (~p >> 24) = p ^ (p >> 24) ^ 0xFFFFFF0000000000, and (phi >> 24) = 0
+    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
+    // step 3 (x 265): the high word of step 2, phi ^ 0xFFFFFF00 with phi < 2^22, is a small NEGATIVE number that fits a signed 24-bit operand,
+    // so "hi * 265 + carry word of the low product" is a single 24-bit multiply-add
+    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
+    const uint64_t q = (uint64_t)lo2 * 265u;
+    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
+    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
+    key ^= key >> 14;
+    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
+    key ^= key >> 28;
+    return shl_add_u64<0>(key << 31, key);
+}
+// the same mix up to its last step; returns n = ~hi + ((~hi:~lo) >> 1) of the key before that step, which is ~(hi + ((hi:lo) >> 1) + 1): the complement of
+// "high word of key + (key << 31), carry of the low words taken as one".  ~x comes free: the step before is an XOR, taken as XNOR.
+__device__ __forceinline__ uint32_t seed_probe(uint32_t seed) {
+    const uint64_t p = (uint64_t)seed * 0x200001ull;
+    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
+    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
+    const uint64_t q = (uint64_t)lo2 * 265u;
+    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
+    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
+    key ^= key >> 14;
+    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
+    uint64_t sh; asm("v_lshrrev_b64 %0, 28, %1" : "=v"(sh) : "v"(key));   // (one instruction for both words; hipcc splits the shift into two)
+    uint32_t nlo, nhi;
+    asm("v_xnor_b32 %0, %1, %2" : "=v"(nlo) : "v"((uint32_t)key), "v"((uint32_t)sh));
+    asm("v_xnor_b32 %0, %1, %2" : "=v"(nhi) : "v"((uint32_t)(key >> 32)), "v"((uint32_t)(sh >> 32)));
+    return nhi + __builtin_amdgcn_alignbit(nhi, nlo, 1);
+}
+
 }  // namespace skh
 #endif
 

@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {   // reverse the order
 // integer instruction it can be built from -- v_mad_u64_u32, v_lshrrev_b64, v_lshl_add_u64, v_cmp_gt_u64, v_alignbit_b32 ... -- issues at the same
 // rate, so what counts is the NUMBER of instructions per window.  hipcc turns the multiplications of the Thomas Wang mix into pairs of
 // v_mad_u64_u32 glued with v_mov (registers pairs must be even-aligned) and the hit masks into cmp + cndmask + or: 45 instructions per window.
-// The helpers below pin the cheaper forms (25 per window); the test suite's CPU kernel simulator gets the plain C++ meaning.
+// The helpers in dev.h pin the cheaper forms (25 per window).
 // Round 4: the hot loop no longer decides "hash < threshold" exactly.  It computes seed_probe(), a 32-bit quantity from which a SUPERSET of the hits
 // follows with one 32-bit compare (probe_is_candidate): the last step of the mix, key + (key << 31), is only carried out on the high word, without the
 // carry of the low words -- the true high word is that value or one more -- and a window is a candidate when the larger of the two could be below the
@@ -303,70 +303,8 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {   // reverse the order
 // marker test) and drops those (seed_tiles_kernel).  Against the exact form this saves the 64-bit add, the 64-bit compare and the add-with-carry that
 // collected the per-lane hit bits: the candidates of window j are a wave-wide mask in scalar registers, and a lane's bits are put together from the
 // masks' few set bits (1/c of the windows) by scalar code.
-#ifdef SKANI_EMU
-__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
-__device__ __forceinline__ uint64_t seed_hash(uint32_t seed) { return mm_hash64((uint64_t)seed); }
-// (the simulator's superset is deliberately loose -- the hash's leading 16 bits -- so that the drop path runs in every test genome: ~0.1 % of its candidates are not hits)
-__device__ __forceinline__ uint32_t seed_probe(uint32_t seed) { return ~((uint32_t)(mm_hash64((uint64_t)seed) >> 32) & 0xFFFF0000u); }
-__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __ballot(a >= b); }
-__device__ __forceinline__ void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) { if ((lanes >> (threadIdx.x & 63u)) & 1ull) v |= bits; }
-extern "C" { unsigned long long skh_emu_seed_drops = 0; }              // candidates the dense pass dropped (the tests assert that the path runs)
-#define SKH_SEED_DROP_NOTE() __atomic_fetch_add(&skh_emu_seed_drops, 1ull, __ATOMIC_RELAXED)
-#else
-#define SKH_SEED_DROP_NOTE() ((void)0)
-// lanes with a >= b as a wave mask: ONE compare writing a scalar register pair (__ballot() goes through a select and a second compare)
-#ifdef SKH_SEED_CMP_VCC   // (experiment: the compare in its short encoding writes vcc, a scalar move keeps the mask)
-__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) {
-    unsigned long long m; asm volatile("v_cmp_le_u32_e32 vcc, %2, %1\n\ts_mov_b64 %0, vcc" : "=s"(m) : "v"(a), "s"(b) : "vcc"); return m;
-}
-#else
-__device__ __forceinline__ unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35 /* ICMP_UGE */); }
-#endif
-// v |= bits in the lanes of the (wave-uniform, non-empty) mask: ONE vector instruction under a narrowed exec mask (as an `if` it is compare + select + or)
-__device__ __forceinline__ void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) {
-    unsigned long long save;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_or_b32 %0, %3, %0\n\ts_mov_b64 exec, %1" : "+v"(v), "=&s"(save) : "s"(lanes), "s"(bits));
-}
-__device__ __forceinline__ uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-template <int SH> __device__ __forceinline__ uint64_t shl_add_u64(uint64_t a, uint64_t b) {          // (a << SH) + b, SH <= 4, one instruction
-    uint64_t d; asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH)); return d;
-}
-// mm_hash64 (types.rs:86-96) of a 32-bit key in 16 instructions
-__device__ __forceinline__ uint64_t seed_hash(uint32_t seed) {
-    const uint64_t p = (uint64_t)seed * 0x200001ull;                   // key + (key << 21) < 2^54; the NOT of step 1 is folded into step 2:
-    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);       //   ~p ^ (~p >> 24) = p ^ (p >> 24) ^ 0xFFFFFF0000000000, and (phi >> 24) = 0
-    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
-    // step 3 (x 265): the high word of step 2, phi ^ 0xFFFFFF00 with phi < 2^22, is a small NEGATIVE number that fits a signed 24-bit operand,
-    // so "hi * 265 + carry word of the low product" is a single 24-bit multiply-add
-    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
-    const uint64_t q = (uint64_t)lo2 * 265u;
-    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
-    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
-    key ^= key >> 14;
-    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
-    key ^= key >> 28;
-    return shl_add_u64<0>(key << 31, key);
-}
-// the same mix up to its last step; returns n = ~hi + ((~hi:~lo) >> 1) of the key before that step, which is ~(hi + ((hi:lo) >> 1) + 1): the complement of
-// "high word of key + (key << 31), carry of the low words taken as one".  ~x comes free: the step before is an XOR, taken as XNOR.
-__device__ __forceinline__ uint32_t seed_probe(uint32_t seed) {
-    const uint64_t p = (uint64_t)seed * 0x200001ull;
-    const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
-    const uint32_t lo2 = plo ^ __builtin_amdgcn_alignbit(phi, plo, 24);
-    const uint32_t hi2 = phi ^ 0xFFFFFF00u;
-    const uint64_t q = (uint64_t)lo2 * 265u;
-    uint32_t hi3; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi3) : "v"(hi2), "s"(265u), "v"((uint32_t)(q >> 32)));
-    uint64_t key = ((uint64_t)hi3 << 32) | (uint32_t)q;
-    key ^= key >> 14;
-    key = shl_add_u64<4>(key, shl_add_u64<2>(key, key));               // x 21
-    uint64_t sh; asm("v_lshrrev_b64 %0, 28, %1" : "=v"(sh) : "v"(key));   // (one instruction for both words; hipcc splits the shift into two)
-    uint32_t nlo, nhi;
-    asm("v_xnor_b32 %0, %1, %2" : "=v"(nlo) : "v"((uint32_t)key), "v"((uint32_t)sh));
-    asm("v_xnor_b32 %0, %1, %2" : "=v"(nhi) : "v"((uint32_t)(key >> 32)), "v"((uint32_t)(sh >> 32)));
-    return nhi + __builtin_amdgcn_alignbit(nhi, nlo, 1);
-}
-#endif
-// Candidate test on seed_probe's n (both builds).  With t = high word without the carry, the true high word is t or t + 1 (mod 2^32), and h < thr needs
+// (wave_mask_ge, or_in_lanes, funnel_shr, shl_add_u64, seed_hash, seed_probe: dev.h, "the seeding loop's instructions")
+// Candidate test on seed_probe's n.  With t = high word without the carry, the true high word is t or t + 1 (mod 2^32), and h < thr needs
 // it <= thr_hi: every hit has (t + 1 mod 2^32) <= thr_hi + 1, i.e. ~n <= thr_hi + 1 with n = ~(t + 1), i.e. n >= ~(thr_hi + 1).  (t = 0xFFFFFFFF with a carry
 // wraps to a true high word of 0: t + 1 = 0 passes.)
 __device__ __forceinline__ uint32_t probe_limit(uint64_t thr) { const uint32_t th = (uint32_t)(thr >> 32); return th == 0xFFFFFFFFu ? 0u : ~(th + 1u); }   // (c = 1: every window)

@@ -66,4 +66,18 @@ inline uint32_t xcc_id() { return 0; }
 inline void atomic_inc_xcd_local(uint32_t* p) { atomicAdd(p, 1u); }
 inline uint32_t load_past_l1(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 
+// ---- the seeding loop's instructions (dev.h has the gfx950 forms).  The mix is written out here on its own (types.rs:86-96): this header comes before common.h's mm_hash64.
+inline uint64_t emu_mm_hash64(uint64_t key) {
+    key = ~(key + (key << 21)); key ^= key >> 24; key = key + (key << 3) + (key << 8); key ^= key >> 14; key = key + (key << 2) + (key << 4); key ^= key >> 28; key += key << 31;
+    return key;
+}
+inline uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+inline uint64_t seed_hash(uint32_t seed) { return emu_mm_hash64((uint64_t)seed); }
+// (the simulator's superset is deliberately loose -- the hash's leading 16 bits -- so that the drop path runs in every test genome: ~0.1 % of its candidates are not hits)
+inline uint32_t seed_probe(uint32_t seed) { return ~((uint32_t)(emu_mm_hash64((uint64_t)seed) >> 32) & 0xFFFF0000u); }
+inline unsigned long long wave_mask_ge(uint32_t a, uint32_t b) { return __ballot(a >= b); }
+inline void or_in_lanes(uint32_t& v, unsigned long long lanes, uint32_t bits) { if ((lanes >> (threadIdx.x & 63u)) & 1ull) v |= bits; }
+
 }  // namespace skh
+extern "C" { inline unsigned long long skh_emu_seed_drops = 0; }       // candidates the seeding kernel's dense pass dropped (the tests assert that the path runs)
+#define SKH_SEED_DROP_NOTE() __atomic_fetch_add(&skh_emu_seed_drops, 1ull, __ATOMIC_RELAXED)

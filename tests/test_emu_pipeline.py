@@ -206,7 +206,7 @@ def test_emu_screen_count_walks(monkeypatch):
         try: return sk.Context(0, lib=emu_lib())
         finally:
             for k in env: os.environ.pop(k, None)
-    pc.case_screen_count_walks(make_ctx)
+    pc.case_screen_count_walks(make_ctx, G=800)              # (800 genomes share the universal marker: its group still runs past a tile and its halo on both sides)
 
 
 def test_emu_every_genome_resalted(monkeypatch):
