@@ -991,7 +991,7 @@ def main():
                                           "N = 1 / at N; every step's wall time on rank 0 is listed (step_wall_ms_rank0)" % (args.strong_collection, sn)})
             if "per_rank" in s:
                 out["strong"]["per_rank"] = s["per_rank"]
-    if world == 1 and default_shape and order == "clade" and not strong and not args.root_fasta and not args.no_variants and n_local == 1000:
+    if world == 1 and default_shape and order == "clade" and not strong and not args.root_fasta and not args.no_variants and n_local == 1000 and args.strong_collection > 0:   # (--strong-collection 0 asks for the headline alone)
         # SURVEY 8d's secondary scale points on this code, this box: the dense collection (one clade: all 499,500 pairs chained), the other presets (cli.rs:60-68), 5,000 genomes
         variants = []
         for name, kw in (("dense: 1,000 genomes in ONE clade, every pair chained", dict(clade=1000, steps=2)), ("-c 30 (--slow)", dict(c=30, steps=3)), ("-c 70 (--medium)", dict(c=70, steps=5)),

@@ -23,7 +23,7 @@ for sec in "$@"; do
     bench) timeout 1200 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || tail -5 gpurun_out/bench_$tag.err; short gpurun_out/bench_$tag.json
            python -c "
 import json; d=json.load(open('gpurun_out/bench_$tag.json')); r=d['roofline']; print('roofline', r['frac'], r.get('frac_rocprof'), r.get('valu_frac'), r['ms_per_launch'], r['traffic'], (d.get('roofline_chain') or {}).get('traffic'), 'e2e', (d.get('e2e') or {}).get('wall_s'), (d.get('e2e') or {}).get('error'))" ;;
-    benchquick) timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --steps 20 > gpurun_out/benchq_$tag.json 2> gpurun_out/benchq_$tag.err || tail -5 gpurun_out/benchq_$tag.err; short gpurun_out/benchq_$tag.json ;;
+    benchquick) timeout 600 python bench.py --cpu-clades 0 --no-e2e --strong-collection 0 --no-variants --steps 20 > gpurun_out/benchq_$tag.json 2> gpurun_out/benchq_$tag.err || tail -5 gpurun_out/benchq_$tag.err; short gpurun_out/benchq_$tag.json ;;
     trace) tools/prof.sh $tag --no-e2e --strong-collection 0 > /dev/null 2>&1; head -40 gpurun_out/trace_$tag.txt | cut -c1-66,70-110 ;;
     gaps) db=$(find /tmp/prof_$tag -name "*.db" | head -1); python tools/rocpd_gaps.py $db gpurun_out/gaps_$tag.txt | head -3; python tools/rocpd_timeline.py $db gpurun_out/timeline_$tag.txt > /dev/null ;;
     pmc) tools/pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1; tail -2 gpurun_out/pmc_$tag.log | cut -c1-160 ;;

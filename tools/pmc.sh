@@ -5,7 +5,7 @@ tag=$1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_$tag
-run() { name=$1; shift; rm -rf /tmp/pmc_$name; timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-clades 0 --no-e2e --strong-collection 0 --no-units > /tmp/pmc_$name.log 2>&1; echo $name rc=$?; python $R/tools/rocpd_pmc_summary.py /tmp/pmc_$name/pmc_results.db $R/gpurun_out/pmc_$tag/$name.json > /dev/null; }
+run() { name=$1; shift; rm -rf /tmp/pmc_$name; timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-clades 0 --no-e2e --strong-collection 0 --no-units --no-variants > /tmp/pmc_$name.log 2>&1; echo $name rc=$?; python $R/tools/rocpd_pmc_summary.py /tmp/pmc_$name/pmc_results.db $R/gpurun_out/pmc_$tag/$name.json > /dev/null; }
 run FETCH_SIZE FETCH_SIZE
 run WRITE_SIZE WRITE_SIZE
 run SQ SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
