@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
 // Every unordered pair of a group is met once (by its larger genome), so the counts are the same integers.  A workgroup stages its COUNT_TILE keys and COUNT_HALO keys
 // on either side in LDS; the part of a group beyond that (a marker shared by hundreds of genomes) is read from global memory.
 constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 256;
-template <bool FIRST>
+template <bool FIRST, uint32_t COUNT_TILE = 1024>                                    // (tiles of 256 for the column order's small sample: four times the workgroups)
 __global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
                                                                     uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz, const uint32_t* col_of /* null: columns = genomes */) {
     __shared__ uint64_t sk[COUNT_TILE + 2 * COUNT_HALO];
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256) void colorder_place_kernel(const uint64_t* sor
 struct ColOrderWork { uint32_t* parent; uint64_t* lab; uint64_t* sorted; DBuf<char>* sort_tmp; };
 static bool column_order_wanted(const skh_ctx* ctx, uint32_t N, uint64_t n_keys) { return ctx->tune.screen_count_rows && ctx->tune.screen_col_order && N >= 2 && n_keys >= 2; }
 static void queue_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_keys, uint32_t N, uint32_t* cnt, const ColOrderWork& w, uint32_t* col_of, uint32_t* genome_of) {
-    const uint64_t n_sample = std::min<uint64_t>(n_keys, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 17));
+    const uint64_t n_sample = std::min<uint64_t>(n_keys, std::max<uint64_t>((uint64_t)64 * N, (uint64_t)1 << 15));
     const uint32_t thr = (uint32_t)std::max<uint64_t>(3, n_sample / N / 32);         // ~3 % of a genome's sampled markers (the screen's own cut-off is at 0.9 %: pairs that matter share far more)
     SKH_LAUNCH(colorder_init_kernel, (N + 255) / 256, 256, 0, ctx->stream, w.parent, N);
-    SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (unsigned)((n_sample + COUNT_TILE - 1) / COUNT_TILE), 256, 0, ctx->stream, keys, n_sample, 0u, N, N, cnt, 1u, (uint64_t)N * N, (uint32_t*)nullptr,
+    SKH_LAUNCH((screen_count_tri_rows_kernel<false, 256>), (unsigned)((n_sample + 255) / 256), 256, 0, ctx->stream, keys, n_sample, 0u, N, N, cnt, 1u, (uint64_t)N * N, (uint32_t*)nullptr,
                (const uint32_t*)nullptr);
     SKH_LAUNCH(colorder_links_kernel, N, 256, 0, ctx->stream, cnt, N, thr, w.parent);
     if (N <= COLORDER_LDS_MAX) SKH_LAUNCH(colorder_rank_kernel, (N + 255) / 256, 256, 0, ctx->stream, (const uint32_t*)w.parent, N, col_of, genome_of);
