@@ -113,6 +113,15 @@ void dcache_stats(size_t* live_bytes, size_t* idle_bytes) {
     if (idle_bytes) *idle_bytes = idle;
 }
 
+size_t device_memory_free() {
+    int device = 0; size_t fr = 0, tot = 0;
+    if (hipGetDevice(&device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)16 << 30; }
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.dev.find(device);
+    return fr + (it == P.dev.end() ? 0 : it->second.idle_bytes);
+}
+
 void dcache_trim() {
     Pool& P = pool();
     std::lock_guard<std::mutex> lk(P.mu);

@@ -71,7 +71,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->device = device; ctx->ring.s0 = ctx->stream; ctx->ring.s1 = ctx->stream2;
         ctx->scan_ticket.alloc(2); dzero(ctx->scan_ticket.p, 8, ctx->stream); dsync(ctx->stream);
         auto env = [](const char* n, uint64_t dflt) { const char* v = getenv(n); return v && *v ? (uint64_t)strtoull(v, nullptr, 10) : dflt; };
-        ctx->tune.seed_scratch_bytes = env("SKH_TUNE_SEED_SCRATCH_BYTES", ctx->tune.seed_scratch_bytes);
+        ctx->tune.seed_scratch_bytes = env("SKH_TUNE_SEED_SCRATCH_BYTES", ctx->tune.seed_scratch_bytes); ctx->tune.seed_scratch_fixed = getenv("SKH_TUNE_SEED_SCRATCH_BYTES") != nullptr;
         ctx->tune.seed_tile_cap = (uint32_t)env("SKH_TUNE_SEED_TILE_CAP", ctx->tune.seed_tile_cap);
         ctx->tune.screen_cells = env("SKH_TUNE_SCREEN_CELLS", ctx->tune.screen_cells);
         ctx->tune.chain_anchors = env("SKH_TUNE_CHAIN_ANCHORS", ctx->tune.chain_anchors);

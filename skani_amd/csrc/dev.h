@@ -38,6 +38,7 @@ void* dmalloc(size_t n);
 void dfree(void* p);
 void dcache_trim();                       // hand every cached block back to the driver
 void dcache_stats(size_t* live_bytes, size_t* idle_bytes);   // device memory the library holds in use / idle in its cache (all devices of the process)
+size_t device_memory_free();              // what the current device can still give: the driver's free bytes + this library's idle cached blocks
 // Small uploads (offset tables, descriptors) go through a pinned ring that belongs to the CONTEXT the calling thread is working for (PinScope, set by
 // every entry point of the C ABI): a copy from pageable memory is staged by the runtime and its first device read after the staging was measured
 // at 130-150 us, in front of the kernels that wait for the table (rocpd timeline of a bench step); from pinned memory the copy is an ordinary

@@ -32,6 +32,7 @@ struct Arena {
     void rewind(const std::vector<size_t>& m) {   // callers sync the stream first
         for (size_t i = 0; i < chunks.size(); i++) chunks[i].off = i < m.size() ? m[i] : 0;
     }
+    size_t capacity() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
     void reset() {  // keep the largest chunk, free the rest (callers sync the stream first)
         if (chunks.size() > 1) {
             size_t tot = 0; for (auto& c : chunks) { tot += c.cap; dfree(c.p); }
@@ -53,7 +54,8 @@ struct GbdtModel {  // flat table from tools/extract_gbdt_model.py (regression.r
 // Scratch budgets that decide how work is split into launches/batches.  The defaults suit 288 GB of HBM; tests shrink them
 // (SKH_TUNE_* environment variables, read at context creation) to drive the multi-batch paths with small inputs.
 struct skh_tunables {
-    uint64_t seed_scratch_bytes = (uint64_t)6 << 30;    // capped tile scratch per seeding launch
+    uint64_t seed_scratch_bytes = (uint64_t)16 << 30;   // capped tile scratch per seeding launch (and at most a quarter of the device's free memory unless set by SKH_TUNE_SEED_SCRATCH_BYTES)
+    bool seed_scratch_fixed = false;                    // set from the environment: taken as it is
     uint32_t seed_tile_cap = 0;                         // seeds a tile may list in the capped scratch (0 = 4x the expected number; tests use few: every tile then only counts and is re-run with full capacity)
     uint64_t screen_cells = (uint64_t)2 << 30;          // u32 counters of the screen's dense row block
     uint64_t chain_anchors = (uint64_t)512 << 20;       // anchors per chain batch (~55 B of scratch each: anchors, candidate intervals, 32 B per candidate slot of the pairs that may select in global memory)

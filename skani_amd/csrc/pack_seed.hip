@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void seed_tiles_kernel(const uint32_t* __restr
 //   * the workgroup that finishes LAST (a ticket) scans the block totals (blk_*: exclusive, one more entry = the grand total);
 //   * seed_got_kernel reads out what the host wants to know: the offsets at the first tile of every genome that starts inside this launch, the totals and the overflow count.
 // A tile's offset is loc[t] + blk[t >> 10]: the compaction kernel adds the two itself.
-constexpr uint32_t OFFS_T = 1024, OFFS_MAX_BLOCKS = 4096;                            // (a launch covers at most 4 M tiles)
+constexpr uint32_t OFFS_T = 1024, OFFS_PER = 8, OFFS_MAX_BLOCKS = OFFS_T * OFFS_PER;    // (a launch covers at most 8 M tiles = 69 G windows: the last workgroup scans OFFS_PER block totals per thread)
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* total, uint32_t* lds /* 16 words */) {
     const uint32_t incl = wave_incl_scan(v), w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     if (l == 63) lds[w] = incl;
@@ -511,18 +511,18 @@ __global__ __launch_bounds__(1024) void seed_offsets_kernel(const uint32_t* cnt_
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // the last workgroup: exclusive scan of the block totals, four blocks per thread (what the other workgroups wrote is read past this CU's L1)
+    // the last workgroup: exclusive scan of the block totals, OFFS_PER blocks per thread (what the other workgroups wrote is read past this CU's L1)
     const uint32_t nb = gridDim.x;
-    uint32_t vs[4], vm[4], ss = 0, sm = 0;
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t b = threadIdx.x * 4 + i;
+    uint32_t vs[OFFS_PER], vm[OFFS_PER], ss = 0, sm = 0;
+    for (uint32_t i = 0; i < OFFS_PER; i++) {
+        const uint32_t b = threadIdx.x * OFFS_PER + i;
         vs[i] = b < nb ? __atomic_load_n(&blk_s[b], __ATOMIC_RELAXED) : 0u; vm[i] = b < nb ? __atomic_load_n(&blk_m[b], __ATOMIC_RELAXED) : 0u;
         ss += vs[i]; sm += vm[i];
     }
     uint32_t all_s, all_m;
     uint32_t bs = block_excl_scan_1024(ss, &all_s, lds), bm = block_excl_scan_1024(sm, &all_m, lds);
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t b = threadIdx.x * 4 + i;
+    for (uint32_t i = 0; i < OFFS_PER; i++) {
+        const uint32_t b = threadIdx.x * OFFS_PER + i;
         if (b < nb) { blk_s[b] = bs; blk_m[b] = bm; }
         bs += vs[i]; bm += vm[i];
     }
@@ -607,7 +607,11 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
     const uint32_t cap_s = ctx->tune.seed_tile_cap ? std::min<uint32_t>(SEED_TILE, ctx->tune.seed_tile_cap) : std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(256, 4 * SEED_TILE / sp.c));
     const uint32_t cap_m = std::min<uint32_t>(SEED_TILE, std::max<uint32_t>(64, 4 * SEED_TILE / sp.marker_c));
     const size_t tile_bytes = (size_t)cap_s * 6 + (size_t)cap_m * 8;
-    const size_t MAX_TILES = std::min<size_t>(std::max<size_t>(1, (size_t)ctx->tune.seed_scratch_bytes / tile_bytes), (size_t)OFFS_MAX_BLOCKS * OFFS_T);   // tile scratch per launch
+    // tile scratch per launch: up to 16 GB (10,000 genomes of 5 Mbp in ONE launch: two launches meant 1.8 ms of copies putting their outputs behind one another, and no
+    // compaction left queued behind the call), but never more than a quarter of what the device has to give right now (free + this library's idle and scratch blocks)
+    size_t scratch = (size_t)ctx->tune.seed_scratch_bytes;
+    if (!ctx->tune.seed_scratch_fixed) scratch = std::min<size_t>(scratch, std::max<size_t>((size_t)2 << 30, (device_memory_free() + ctx->arena.capacity()) / 4));
+    const size_t MAX_TILES = std::min<size_t>(std::max<size_t>(1, scratch / tile_bytes), (size_t)OFFS_MAX_BLOCKS * OFFS_T);
     struct Part { DBuf<uint32_t> seed, g; DBuf<uint64_t> g64, mk; uint64_t ns = 0, nm = 0; };
     std::vector<Part> parts;
     const std::vector<uint32_t>& g_first = gs->genome_first_tile;                     // first tile of every genome (tiles are ordered by genome)

@@ -20,6 +20,7 @@ inline void* dmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) throw Erro
 inline void dfree(void* p) { free(p); }
 inline void dcache_trim() {}
 inline void dcache_stats(size_t* live_bytes, size_t* idle_bytes) { if (live_bytes) *live_bytes = 0; if (idle_bytes) *idle_bytes = 0; }
+inline size_t device_memory_free() { return (size_t)64 << 30; }
 struct PinRing { devStream_t s0 = 0, s1 = 0; };
 struct PinScope { PinScope(int, PinRing*) {} };
 inline void h2d(void* d, const void* h, size_t n, devStream_t) { if (n) memcpy(d, h, n); }
