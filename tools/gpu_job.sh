@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root; through gpurun): tools/gpu_job.sh <tag> <section> [<section> ...]
 # One parameterised job instead of a script per GPU run.  Everything lands in gpurun_out/ under names that carry <tag>.
-# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | screenab | overlap | probe | stageprofile | realdense | variants (after bench) | benchmini (first: stops the job when bench.py fails)
+# sections: suite | suite:<pytest -k expr> | smoke | bench | benchquick | trace | gaps | pmc | traffic | forcedist | config4 | config4dist | touch | ranks8 | search | search113k | presets | fuzz[:rounds] | mergejoin | wide | predict | cli | sortab | skeysavg | alloctrace | config4trace | hosttrace | screenab | overlap | probe | stageprofile | realdense | densetraces | variants (after bench) | benchmini (first: stops the job when bench.py fails)
 mkdir -p gpurun_out
 tag=$1; shift
 short() { python - "$1" <<'PY'
@@ -51,6 +51,8 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     realdense) timeout 1500 python bench.py --root-fasta tests/golden/e.coli-W.fasta.gz --clade 1000 --cpu-genomes 24 --steps 2 --warmup 1 --strong-collection 0 --no-e2e > gpurun_out/${tag}_real_dense.json 2> gpurun_out/${tag}_real_dense.err || tail -5 gpurun_out/${tag}_real_dense.err
                short gpurun_out/${tag}_real_dense.json; python -c "
 import json; d=json.load(open('gpurun_out/${tag}_real_dense.json')); print(json.dumps(d.get('real_sequence'))[:900]); print(json.dumps(d.get('units')))" ;;
+    densetraces) tools/prof.sh ${tag}_dense_syn --no-e2e --clade 1000 > /dev/null 2>&1; tools/prof.sh ${tag}_dense_real --no-e2e --clade 1000 --root-fasta tests/golden/e.coli-W.fasta.gz > /dev/null 2>&1
+                 python tools/compare_traces.py gpurun_out/trace_${tag}_dense_syn.json gpurun_out/trace_${tag}_dense_real.json 3 "synthetic dense" "E. coli W derivatives" > gpurun_out/${tag}_dense_compare.md; cat gpurun_out/${tag}_dense_compare.md ;;
     variants) python -c "
 import json; d=json.load(open('gpurun_out/bench_$tag.json')); v=d.get('variants'); json.dump({'commit_note': 'the variants block of gpurun_out/bench_$tag.json (bench.py default run)', 'headline_ms_per_step': d['ms_per_step'], 'variants': v}, open('gpurun_out/${tag}_variants.json','w'), indent=1)
 for x in v or []: print(x.get('variant'), round(x.get('ms_per_step', 0), 2), x.get('chained_pairs'), round(x.get('chained_pairs_per_s', 0)), x.get('error'))" ;;
