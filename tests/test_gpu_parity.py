@@ -545,7 +545,7 @@ def test_screen_counter_planes_agree(monkeypatch):
 def test_sketch_offsets_exact_while_the_gpu_is_busy():
     """The per-genome offsets a sketch call reads back must not depend on what else the GPU is doing: the same genomes are sketched 25 times while three other
     streams of this process keep the device busy with short kernels, and every run's offsets equal the quiet run's.
-    What this test is NOT: a reproducer of round 4's missing barrier in seed_offsets_kernel.  The library without that barrier passes it too
+    What this test is NOT: a reproducer of round 4's missing barrier in seed_offsets_kernel (HISTORY.md section 5b-19).  The library without that barrier passes it too
     (checked on an MI355X) -- only eight PROCESSES sharing the GPU brought that race out (tests/test_zz_bench_multirank.py, test_config4_eight_ranks_one_device)."""
     import threading
     import torch

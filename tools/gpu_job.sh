@@ -51,7 +51,7 @@ import json; d=json.load(open('gpurun_out/${tag}_search_65k.json')); print(json.
     realdense) timeout 1500 python bench.py --root-fasta tests/golden/e.coli-W.fasta.gz --clade 1000 --cpu-genomes 24 --steps 2 --warmup 1 --strong-collection 0 --no-e2e > gpurun_out/${tag}_real_dense.json 2> gpurun_out/${tag}_real_dense.err || tail -5 gpurun_out/${tag}_real_dense.err
                short gpurun_out/${tag}_real_dense.json; python -c "
 import json; d=json.load(open('gpurun_out/${tag}_real_dense.json')); print(json.dumps(d.get('real_sequence'))[:900]); print(json.dumps(d.get('units')))" ;;
-    densetraces) tools/prof.sh ${tag}_dense_syn --no-e2e --clade 1000 > /dev/null 2>&1; tools/prof.sh ${tag}_dense_real --no-e2e --clade 1000 --root-fasta tests/golden/e.coli-W.fasta.gz > /dev/null 2>&1
+    densetraces) tools/prof.sh ${tag}_dense_syn --no-e2e --clade 1000 > /dev/null 2>&1; tools/prof.sh ${tag}_dense_real --no-e2e --clade 1000 --root-fasta $PWD/tests/golden/e.coli-W.fasta.gz > /dev/null 2>&1
                  python tools/compare_traces.py gpurun_out/trace_${tag}_dense_syn.json gpurun_out/trace_${tag}_dense_real.json 3 "synthetic dense" "E. coli W derivatives" > gpurun_out/${tag}_dense_compare.md; cat gpurun_out/${tag}_dense_compare.md ;;
     variants) python -c "
 import json; d=json.load(open('gpurun_out/bench_$tag.json')); v=d.get('variants'); json.dump({'commit_note': 'the variants block of gpurun_out/bench_$tag.json (bench.py default run)', 'headline_ms_per_step': d['ms_per_step'], 'variants': v}, open('gpurun_out/${tag}_variants.json','w'), indent=1)
