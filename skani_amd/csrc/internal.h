@@ -67,7 +67,7 @@ struct skh_tunables {
     uint32_t skeys_cap = 0;                             // != 0: a lower limit than SKEYS_CAP_MAX on the keys of a bucket sorted in LDS (tests of the radix-sort way out)
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_count_rows = 1;                      // triangle screen: the lanes of a marker's group walk it together, one row of the count matrix per instruction (0: lane e pairs with e + s, the form before round 6; A/B runs, tests)
-    uint32_t screen_col_order = 1;                      // triangle screen with screen_count_rows: the count matrix's columns grouped by the clusters the incidences tie together (0: columns = genomes in collection order; A/B runs, tests)
+    uint32_t screen_col_order = 1;                      // triangle screen with screen_count_rows: the count matrix's columns grouped by the clusters the incidences tie together (0: columns = genomes in collection order; 2: also for key-range parts too small for it to pay; A/B runs, tests)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
     uint32_t build_slice_max = 0;                       // table slices per genome the slice-list kernel handles (0 = 8192; tests use 1: larger genomes' slices re-scan)

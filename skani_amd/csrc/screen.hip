@@ -684,6 +684,9 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     tr.mark("screen part: keys, sorted");
     const uint64_t plane = (uint64_t)N * N;
     uint32_t* col_of = nullptr; uint32_t* genome_of = nullptr;                      // (each part orders the columns by what ITS keys tie together: the cells name genomes)
+    // The order is made inside this call (a pass over half the matrix for the links, a sort of N labels, the cells then emitted from whole rows): it pays for itself from ~1,000
+    // incidences per genome on -- config 4's 10,000 genomes: the parts of a world of 1 / 2 / 4 / 8 took 5.3 / 3.5 / 2.1 / 1.56 ms with it and 6.0 / 3.9 / 2.2 / 1.34 without.
+    const bool order_pays = ctx->tune.screen_col_order > 1 || (uint64_t)n >= (uint64_t)1024 * N;
     // one plane of counters per XCD while that stays small (as in screen_pairs; the planes have passed their self-test there or are not used)
     const uint32_t want_planes = std::min<uint32_t>(std::max<uint32_t>(ctx->tune.screen_planes, 1u), 8u);
     const uint32_t n_planes = (ctx->screen_planes_checked && plane * want_planes <= (64ull << 20)) ? want_planes : 1u;
@@ -695,7 +698,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
             dzero(ctx->part_cnt.p, ctx->part_cnt.n * 4, ctx->stream);
         }
         ctx->part_cnt_clean = false;
-        if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, ctx->part_cnt.p, &col_of, &genome_of);
+        if (ctx->tune.screen_count_rows && order_pays) make_column_order(ctx, keys, n, N, ctx->part_cnt.p, &col_of, &genome_of);
         uint32_t* row_nz = ctx->arena.get<uint32_t>(N); uint32_t* row_off = ctx->arena.get<uint32_t>(N + 1);
         dzero(row_nz, (size_t)N * 4, ctx->stream);
         if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<true>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, ctx->part_cnt.p, 1u, plane, row_nz, (const uint32_t*)col_of);
@@ -716,7 +719,7 @@ void screen_partial_cells_dev(skh_ctx* ctx, const skh_sketch_set* S, uint32_t pa
     }
     uint32_t* cnt = ctx->arena.get<uint32_t>(plane * n_planes);
     dzero(cnt, plane * n_planes * 4, ctx->stream);
-    if (ctx->tune.screen_count_rows) make_column_order(ctx, keys, n, N, cnt, &col_of, &genome_of);
+    if (ctx->tune.screen_count_rows && order_pays) make_column_order(ctx, keys, n, N, cnt, &col_of, &genome_of);
     if (ctx->tune.screen_count_rows) SKH_LAUNCH(screen_count_tri_rows_kernel<false>, (n + COUNT_TILE - 1) / COUNT_TILE, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr, (const uint32_t*)col_of);
     else SKH_LAUNCH(screen_count_tri_kernel<false>, (n + 255) / 256, 256, 0, ctx->stream, (const uint64_t*)keys, (uint64_t)n, 0u, N, N, cnt, n_planes, plane, (uint32_t*)nullptr);
     check_launch("screen_count(part)");

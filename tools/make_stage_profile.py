@@ -18,7 +18,8 @@ STAGES = (  # first match wins
     ("ingest (outside the step)", ("pack_kernel", "nmask")),
     ("seeding", ("seed_tiles", "seed_offsets", "seed_got", "seed_compact")),
     ("tables", ("slice_positions", "table_blocks", "build_tables", "marker_set", "marker_gather", "fill_regions", "unpack_positions", "pack_positions")),
-    ("screen", ("skeys_", "colorder_", "screen_")),
+    ("screen index + column order (at sketch time, second stream)", ("skeys_", "colorder_", "screen_count_tri_rows_kernel<false, 256u>")),
+    ("screen", ("screen_",)),
     ("join", ("expand_pairs", "slot_tile", "join_count", "join_fill", "widen_anchors")),
     ("chunking + DP", ("chunk_kernel", "dp_order", "chain_dp", "interval_emit")),
     ("selection + estimate", ("greedy", "chunk_stats", "finalize")),
