@@ -89,17 +89,17 @@ __global__ __launch_bounds__(256) void screen_count_tri_kernel(const uint64_t* k
 // Every unordered pair of a group is met once (by its larger genome), so the counts are the same integers.  A workgroup stages its COUNT_TILE keys and COUNT_HALO keys
 // on either side in LDS; the part of a group beyond that (a marker shared by hundreds of genomes) is read from global memory.
 constexpr uint32_t COUNT_TILE = 1024, COUNT_HALO = 256;
-template <bool FIRST, uint32_t COUNT_TILE = 1024>                                    // (tiles of 256 for the column order's small sample: four times the workgroups)
+template <bool FIRST, uint32_t TILE = COUNT_TILE>                                    // (tiles of 256 for the column order's small sample: four times the workgroups)
 __global__ __launch_bounds__(256) void screen_count_tri_rows_kernel(const uint64_t* keys, uint64_t n, uint32_t row0, uint32_t rows, uint32_t ncols,
                                                                     uint32_t* cnt, uint32_t n_planes, uint64_t plane, uint32_t* row_nz, const uint32_t* col_of /* null: columns = genomes */) {
-    __shared__ uint64_t sk[COUNT_TILE + 2 * COUNT_HALO];
-    const uint64_t base = (uint64_t)blockIdx.x * COUNT_TILE;
-    const uint64_t st_lo = base >= COUNT_HALO ? base - COUNT_HALO : 0, st_hi = n - base < COUNT_TILE + COUNT_HALO ? n : base + COUNT_TILE + COUNT_HALO;
+    __shared__ uint64_t sk[TILE + 2 * COUNT_HALO];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t st_lo = base >= COUNT_HALO ? base - COUNT_HALO : 0, st_hi = n - base < TILE + COUNT_HALO ? n : base + TILE + COUNT_HALO;
     for (uint32_t x = threadIdx.x; x < (uint32_t)(st_hi - st_lo); x += blockDim.x) sk[x] = keys[st_lo + x];
     __syncthreads();
     auto key_at = [&](uint64_t p) { return (p >= st_lo && p < st_hi) ? sk[p - st_lo] : keys[p]; };
     uint32_t* mine = cnt + (n_planes > 1 ? (uint64_t)(xcc_id() % n_planes) * plane : 0ull);
-    const uint64_t own_hi = n - base < COUNT_TILE ? n : base + COUNT_TILE;
+    const uint64_t own_hi = n - base < TILE ? n : base + TILE;
     for (uint64_t e = base + threadIdx.x; e < own_hi; e += blockDim.x) {
         const uint64_t key = key_at(e);
         const uint32_t b = skey_genome(key), prefix = skey_prefix(key);
@@ -233,7 +233,7 @@ static void make_column_order(skh_ctx* ctx, const uint64_t* keys, uint64_t n_key
 constexpr uint32_t COLORDER_AHEAD_MAX = 16384;
 static void queue_column_order_ahead(skh_ctx* ctx, const skh_sketch_set* set, PendingSort* ps) {
     const uint32_t N = set->n_genomes; const uint64_t n_keys = set->screen_keys.n;
-    if (!column_order_wanted(ctx, N, n_keys) || N > COLORDER_AHEAD_MAX) return;
+    if (!column_order_wanted(ctx, N, n_keys) || N > COLORDER_AHEAD_MAX || set->compact) return;   // (compact sets are the shards of a resident database: searched, never screened against themselves)
     ps->mat.alloc((size_t)N * N); ps->work.alloc((size_t)3 * N);
     set->screen_col_of.alloc(N); set->screen_genome_of.alloc(N);
     dzero(ps->mat.p, (size_t)N * N * 4, ctx->stream);

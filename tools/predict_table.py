@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""DESIGN.md section 6's PREDICTED strong-scaling series (bench.py --collection 10000 on 1 / 2 / 4 / 8 GPUs) as a markdown table.  Nothing here is a multi-GPU
+"""the PREDICTED strong-scaling series (bench.py --collection 10000 on 1 / 2 / 4 / 8 GPUs) as a markdown table.  Nothing here is a multi-GPU
 measurement: the inputs are one-GPU measurements (profiles/r04_predict_inputs.json from tools/predict_scaling.py, the N = 1 bench line, the per-rank byte counts of
 the 8-rank run on one device) and the link figures of MI355X_MICROARCH.md.
 usage: predict_table.py [profiles dir]"""
@@ -8,7 +8,7 @@ import os
 import sys
 
 P = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-R = os.environ.get("PREDICT_ROUND", "r05")
+R = os.environ.get("PREDICT_ROUND", "r06")
 inp = json.load(open(os.path.join(P, R + "_predict_inputs.json")))
 n1 = json.loads(open(os.path.join(P, R + "_bench_config4_n1.json")).read().strip().splitlines()[-1])
 ph = n1["phase_ms_per_step"]
