@@ -84,6 +84,7 @@ int skh_ctx_create(int device, skh_ctx** out) {
         ctx->tune.screen_planes = (uint32_t)env("SKH_TUNE_SCREEN_PLANES", ctx->tune.screen_planes);
         ctx->tune.screen_count_rows = (uint32_t)env("SKH_TUNE_SCREEN_COUNT_ROWS", ctx->tune.screen_count_rows);
         ctx->tune.screen_col_order = (uint32_t)env("SKH_TUNE_SCREEN_COL_ORDER", ctx->tune.screen_col_order);
+        ctx->tune.marker_gate = (uint32_t)env("SKH_TUNE_MARKER_GATE", ctx->tune.marker_gate);
         ctx->tune.screen_cells_dense = (uint32_t)env("SKH_TUNE_SCREEN_CELLS_DENSE", 0);
         ctx->tune.build_resalt_all = (uint32_t)env("SKH_TUNE_BUILD_RESALT_ALL", 0);
         ctx->tune.screen_sort_radix = (uint32_t)env("SKH_TUNE_SCREEN_SORT_RADIX", 0);
@@ -272,16 +273,24 @@ int skh_sketch_genomes_ex(skh_ctx* ctx, const skh_genome_set* gs_c, const skh_sk
             book(); tail_guard.armed = false;
             return;
         }
-        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr);
-        tr.mark("sketch: tables queued");
+        // the marker sets' kernel first, on the second stream, with an event behind it that build_tables_kernel waits for (internal.h MarkerBuild)
+        MarkerBuild mb;
         ev[1].make_wait(ctx->stream2);                                                // the raw markers come out of the compaction kernel
+        if (ctx->tune.marker_gate) {
+            std::swap(ctx->stream, ctx->stream2);
+            try { build_markers_begin(ctx, ss, so.markers_raw, so.mk_off, mb); }
+            catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }
+            std::swap(ctx->stream, ctx->stream2);
+        }
+        TableBuild tb = build_sketch_tables_begin(ctx, ss, nullptr, nullptr, mb.launched ? &mb.done : nullptr);
+        tr.mark("sketch: tables queued");
         // (letting the second stream start only beside the table build's big kernels -- instead of beside the small copies and fills in front of them,
         //  which it holds back by ~150 us -- was measured in round 3: the marker-set kernel then starves beside build_tables_kernel, 1.03 instead of 0.31 ms,
         //  and the sketch phase grows from 1.60 to 1.81 ms)
         std::swap(ctx->stream, ctx->stream2);
         try {                                                                          // + the screen's sorted incidence list: counted beside the marker sets, its last kernel queued, not waited for
             ScreenKeysPlan plan; uint32_t plan_max = 0;
-            build_markers(ctx, ss, so.markers_raw, so.mk_off, &plan, &plan_max);
+            build_markers(ctx, ss, so.markers_raw, so.mk_off, &plan, &plan_max, &mb);
             prepare_screen_keys(ctx, ss, /*async=*/true, &plan, plan_max);
         }
         catch (...) { std::swap(ctx->stream, ctx->stream2); device_sync_all(); throw; }

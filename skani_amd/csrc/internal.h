@@ -68,6 +68,7 @@ struct skh_tunables {
     uint32_t screen_cells_dense = 0;                    // 1: the gathered cells of the key-range screen are added up in the dense N x N matrix (the form before round 5; tests)
     uint32_t screen_count_rows = 1;                      // triangle screen: the lanes of a marker's group walk it together, one row of the count matrix per instruction (0: lane e pairs with e + s, the form before round 6; A/B runs, tests)
     uint32_t screen_col_order = 1;                      // triangle screen with screen_count_rows: the count matrix's columns grouped by the clusters the incidences tie together (0: columns = genomes in collection order; 2: also for key-range parts too small for it to pay; A/B runs, tests)
+    uint32_t marker_gate = 1;                           // the sketch call launches the marker sets' kernel first and lets build_tables_kernel wait for it (0: both start together, the form before round 6; A/B runs)
     uint32_t screen_planes = 8;                         // triangle screen: copies of the count matrix, one per XCD (1 = a single device-scope copy)
     uint32_t join_bitmap_words = 8192;                  // LDS words (32 KB) the join may spend on a probed sketch's bucket bitmap; larger bitmaps are not staged
     uint32_t build_slice_max = 0;                       // table slices per genome the slice-list kernel handles (0 = 8192; tests use 1: larger genomes' slices re-scan)
@@ -293,7 +294,7 @@ void seed_genomes(skh_ctx* ctx, skh_genome_set* gs, const skh_sketch_params& sp,
 // arrays of (position in contig, contig << 1 | canonical) in position order, which are converted into p_g
 void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
 struct TableBuild { uint32_t* d_back = nullptr; size_t n = 0; };                    // a table build that is queued but not yet waited for
-TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc);
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc, skh::DevEvent* gate = nullptr);   // gate: build_tables_kernel starts behind this event (the marker sets' kernel on the other stream)
 bool build_sketch_tables_finish(skh_ctx* ctx, skh_sketch_set* ss, TableBuild& tb);   // true: a salt changed or the list storage moved
 void upload_set_offsets(skh_ctx* ctx, skh_sketch_set* ss);
 void copy_segments(skh_ctx* ctx, const uint32_t* src, uint32_t* dst, const std::vector<uint64_t>& seg);   // dist.hip: segments of 32-bit words (src offset, dst offset, words) x n
@@ -305,7 +306,13 @@ struct ScreenKeysPlan {                                   // the sort's first ha
     uint32_t t_base = 0, shift = 0, nb = 0, rb = 0, gg = 0, n_ranges = 0, n_groups = 0, nbp = 0;
     uint32_t *hist = nullptr, *off = nullptr, *cursor = nullptr, *bounds = nullptr;
 };
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan = nullptr, uint32_t* plan_max = nullptr);   // plan: also the first half of the screen's incidence sort (its scratch: the set's PendingSort), the largest bucket read back with the set sizes
+// The marker sets' one kernel launched ahead of everything else the marker build does, with an event behind it: the sketch call queues it BEFORE the seed tables and lets
+// build_tables_kernel wait for that event.  Beside build_tables_kernel (seven workgroups of 22 KB of LDS per CU) marker_set_kernel's workgroups of 64 KB hardly ever find room:
+// at 10,000 genomes it took 12.4 ms instead of 2.5 and the index sort ran alone behind the table build.  Beside slice_positions_kernel it is done first; the sort then runs
+// beside the table build.  (1,000 genomes: the kernel ends before slice_positions_kernel does -- the gate is open when build_tables_kernel arrives.)
+struct MarkerBuild { bool launched = false; uint64_t* d_ro = nullptr; uint32_t* d_uq = nullptr; DevEvent done; };
+void build_markers_begin(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, MarkerBuild& mb);
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan = nullptr, uint32_t* plan_max = nullptr, MarkerBuild* begun = nullptr);   // plan: also the first half of the screen's incidence sort (its scratch: the set's PendingSort), the largest bucket read back with the set sizes
 void finalize_metadata(skh_sketch_set* ss);                                        // host-only: quantiles, means, padded contig starts
 
 // ---- screen.hip

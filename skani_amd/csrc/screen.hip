@@ -244,7 +244,7 @@ static void queue_column_order_ahead(skh_ctx* ctx, const skh_sketch_set* set, Pe
 static void order_rows_columns(const std::vector<uint32_t>& first, std::vector<uint32_t>& second, size_t from) {
     for (size_t x = from; x < first.size();) {
         size_t y = x + 1; while (y < first.size() && first[y] == first[x]) y++;
-        if (y - x > 1) std::sort(second.begin() + x, second.begin() + y);
+        if (y - x > 1 && !std::is_sorted(second.begin() + x, second.begin() + y)) std::sort(second.begin() + x, second.begin() + y);   // (a collection in clade order: nothing to do)
         x = y;
     }
 }

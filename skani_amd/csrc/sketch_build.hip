@@ -379,7 +379,7 @@ void build_sketch_tables(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, 
 
 // The kernels of a table build over the genomes listed in `only` (null: all), queued on the context's stream; returns the device counters the build
 // fills: per genome an error word, the number of distinct seeds and the list words used.  The tables, their geometry and the position records exist.
-static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::vector<uint32_t>* only) {
+static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::vector<uint32_t>* only, DevEvent* gate = nullptr) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     if (!ng) return nullptr;
@@ -430,6 +430,7 @@ static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::
     if (n_blk) {
         const size_t lds = (size_t)(TAB_SLICE + TAB_SLACK) * 8 + TAB_SLICE / TAB_FILTER_HOMES * 4 + (size_t)stage_cap * 4;
         kernel_allow_lds(build_tables_kernel, lds);
+        if (gate) gate->make_wait(ctx->stream);                                       // (internal.h MarkerBuild)
         SKH_LAUNCH(build_tables_kernel, (unsigned)n_blk, TABLE_THREADS, lds, ctx->stream, (const uint2*)d_blk, (const uint32_t*)d_sf, (const uint32_t*)d_ss, (const uint32_t*)d_sc,
                    (const uint2*)d_ps, (const uint32_t*)ss->p_seed.p, (const uint32_t*)d_salt, (const uint32_t*)ss->p_g.p,
                    (const uint64_t*)ss->d_pos_off.p, (const uint32_t*)d_nb, (const uint64_t*)d_to, (const uint64_t*)d_bo, (const uint64_t*)d_mo,
@@ -440,7 +441,7 @@ static uint32_t* queue_table_build(skh_ctx* ctx, skh_sketch_set* ss, const std::
 }
 
 // queues the whole table build on the context's stream and returns without waiting; _finish reads the counts back
-TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc) {
+TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uint32_t* pos, const uint32_t* cc, DevEvent* gate) {
     const uint32_t ng = ss->n_genomes;
     const uint64_t P = ss->pos_off[ng];
     StageTrace tr(ctx);
@@ -487,7 +488,7 @@ TableBuild build_sketch_tables_begin(skh_ctx* ctx, skh_sketch_set* ss, const uin
     }
     ss->indexed = true;
     TableBuild tb; tb.n = 3 * (size_t)ng;                                            // per genome: error bits, distinct seeds, list words used
-    tb.d_back = queue_table_build(ctx, ss, nullptr);
+    tb.d_back = queue_table_build(ctx, ss, nullptr, gate);
     tr.mark("build: seed tables queued");
     return tb;
 }
@@ -606,7 +607,30 @@ __global__ __launch_bounds__(256) void marker_gather_kernel(const uint64_t* __re
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[m0 + i] = raw[r0 + i];
 }
 
-void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan, uint32_t* plan_max) {
+static bool marker_sets_in_lds(const skh_ctx* ctx, uint32_t ng, const std::vector<uint64_t>& raw_off, uint64_t* max_raw_out) {
+    uint64_t max_raw = 0; for (uint32_t g = 0; g < ng; g++) max_raw = std::max(max_raw, raw_off[g + 1] - raw_off[g]);
+    const uint32_t lds_max = ctx->tune.marker_lds_max ? std::min<uint32_t>(ctx->tune.marker_lds_max, MARKER_LDS_MAX) : MARKER_LDS_MAX;
+    *max_raw_out = max_raw;
+    return raw_off[ng] > 0 && max_raw <= lds_max;
+}
+static void launch_marker_sets(skh_ctx* ctx, uint32_t ng, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, uint64_t max_raw, uint64_t** d_ro, uint32_t** d_uq) {
+    *d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(*d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
+    *d_uq = ctx->arena.get<uint32_t>(ng + 1);                                         // (+ the largest bucket of the screen's incidence sort)
+    uint32_t N = 64; while (N < max_raw) N <<= 1;
+    const size_t lds = (size_t)N * 8;
+    kernel_allow_lds(marker_set_kernel, lds);
+    SKH_LAUNCH(marker_set_kernel, ng, MARKER_THREADS, lds, ctx->stream, raw.p, (const uint64_t*)*d_ro, *d_uq);
+    check_launch("marker_set");
+}
+void build_markers_begin(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, MarkerBuild& mb) {
+    const uint32_t ng = ss->n_genomes; uint64_t max_raw = 0;
+    if (ng >= (1u << 22) || raw_off[ng] >= 0xFFFFFFF0ull || !marker_sets_in_lds(ctx, ng, raw_off, &max_raw)) return;   // (build_markers says what is wrong, or takes the device-wide passes)
+    launch_marker_sets(ctx, ng, raw, raw_off, max_raw, &mb.d_ro, &mb.d_uq);
+    mb.done.record(ctx->stream);
+    mb.launched = true;
+}
+// the marker sets of a batch, on the context's stream; begun: their kernel is already queued (build_markers_begin)
+void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const std::vector<uint64_t>& raw_off, ScreenKeysPlan* plan, uint32_t* plan_max, MarkerBuild* begun) {
     if (plan) *plan = ScreenKeysPlan{};
     const uint32_t ng = ss->n_genomes;
     const uint64_t M = raw_off[ng];
@@ -614,16 +638,11 @@ void build_markers(skh_ctx* ctx, skh_sketch_set* ss, DBuf<uint64_t>& raw, const 
     ss->mk_off.assign(ng + 1, 0);
     if (ng >= (1u << 22)) throw Error("more than 4M genomes in one sketch set");
     if (M >= 0xFFFFFFF0ull) throw Error("too many markers for one build; split the batch");
-    uint64_t max_raw = 0; for (uint32_t g = 0; g < ng; g++) max_raw = std::max(max_raw, raw_off[g + 1] - raw_off[g]);
-    const uint32_t lds_max = ctx->tune.marker_lds_max ? std::min<uint32_t>(ctx->tune.marker_lds_max, MARKER_LDS_MAX) : MARKER_LDS_MAX;
-    if (M > 0 && max_raw <= lds_max) {                                               // one workgroup per genome, everything in LDS
-        uint64_t* d_ro = ctx->arena.get<uint64_t>(ng + 1); h2d(d_ro, raw_off.data(), (ng + 1) * 8, ctx->stream);
-        uint32_t* d_uq = ctx->arena.get<uint32_t>(ng + 1);                             // (+ the largest bucket of the screen's incidence sort)
-        uint32_t N = 64; while (N < max_raw) N <<= 1;
-        const size_t lds = (size_t)N * 8;
-        kernel_allow_lds(marker_set_kernel, lds);
-        SKH_LAUNCH(marker_set_kernel, ng, MARKER_THREADS, lds, ctx->stream, raw.p, (const uint64_t*)d_ro, d_uq);
-        check_launch("marker_set");
+    uint64_t max_raw = 0;
+    if (marker_sets_in_lds(ctx, ng, raw_off, &max_raw)) {                            // one workgroup per genome, everything in LDS
+        uint64_t* d_ro = nullptr; uint32_t* d_uq = nullptr;
+        if (begun && begun->launched) { d_ro = begun->d_ro; d_uq = begun->d_uq; }
+        else launch_marker_sets(ctx, ng, raw, raw_off, max_raw, &d_ro, &d_uq);
         // the screen's incidence sort (screen_keys.hip) counts its buckets HERE, over the sets where they were deduplicated (duplicates counted in its plan: a few per cent):
         // its largest bucket -- what decides how its second half runs -- comes back with the set sizes, and its two kernels run while the host adds those up
         if (plan && ng <= SCREEN_ID_MASK && sorted_screen_keys_fits(M)) {
