@@ -222,7 +222,7 @@ def test_emu_every_genome_resalted(monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"SKH_TUNE_SKEYS_AVG": "16"}, {"SKH_TUNE_SKEYS_AVG": "16", "SKH_TUNE_SKEYS_CAP": "16"}, {"SKH_TUNE_SCREEN_SORT_RADIX": "1"},
-                                 {"SKH_TUNE_SCREEN_COL_ORDER": "0"}, {"SKH_TUNE_SCREEN_COL_ORDER": "2"}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}])   # (the last three: the count kernel without its column order / with it also in small key-range parts / the count kernel of rounds 1-5)
+                                 {"SKH_TUNE_SCREEN_COL_ORDER": "0"}, {"SKH_TUNE_SCREEN_COL_ORDER": "2"}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}, {"SKH_TUNE_MARKER_GATE": "0"}])   # (the last three: the count kernel without its column order / with it also in small key-range parts / the count kernel of rounds 1-5; then the sketch call without the marker sets' head start)
 def test_emu_incidence_sort_through_the_sketch_call(monkeypatch, env):
     """The sketch call's own way through the incidence sort -- buckets counted beside the marker sets, their largest read back with the set sizes, keys placed after the
     gather, the last kernel not waited for -- with tiny buckets, with a capacity the largest bucket exceeds (the radix sort takes the bucketed keys, in the set's own

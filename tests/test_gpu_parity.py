@@ -53,7 +53,7 @@ def test_every_genome_resalted(monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"SKH_TUNE_SKEYS_AVG": "16"}, {"SKH_TUNE_SKEYS_AVG": "16", "SKH_TUNE_SKEYS_CAP": "16"}, {"SKH_TUNE_SCREEN_SORT_RADIX": "1"},
-                                 {"SKH_TUNE_SCREEN_COL_ORDER": "0"}, {"SKH_TUNE_SCREEN_COL_ORDER": "2"}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}])   # (the last three: the count kernel without its column order / with it also in small key-range parts / the count kernel of rounds 1-5)
+                                 {"SKH_TUNE_SCREEN_COL_ORDER": "0"}, {"SKH_TUNE_SCREEN_COL_ORDER": "2"}, {"SKH_TUNE_SCREEN_COUNT_ROWS": "0"}, {"SKH_TUNE_MARKER_GATE": "0"}])   # (the last three: the count kernel without its column order / with it also in small key-range parts / the count kernel of rounds 1-5; then the sketch call without the marker sets' head start)
 def test_incidence_sort_through_the_sketch_call(monkeypatch, env):
     """tests/test_emu_pipeline.py has the why: the sketch call's two-halves way through the incidence sort with tiny buckets, with the radix-sort way out, with the radix sort alone."""
     for k, v in env.items(): monkeypatch.setenv(k, v)
