@@ -18,8 +18,6 @@
 #include <cmath>
 
 #include "internal.h"
-#include <thread>
-#include <exception>
 
 namespace skh {
 
@@ -526,8 +524,7 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
         job.wps.clear(); job.host_go_a.clear(); job.host_go_b.clear(); job.host_go_a64.clear(); job.host_go_b64.clear();
         if (wide_run) job.wps.resize(n);
         if (stats) { job.host_go_a.resize(n); job.host_go_b.resize(n); if (wide_run) { job.host_go_a64.resize(n); job.host_go_b64.resize(n); } }
-        auto describe = [&](uint32_t i0, uint32_t i1) {
-        for (uint32_t i = i0; i < i1; i++) {
+        for (uint32_t i = 0; i < n; i++) {
             const uint32_t p = idx ? idx[i] : i;
             const skh_sketch_set *R, *Q; uint32_t rs, qs; halves_of(p, R, Q, rs, qs);
             const uint32_t r = pair_ref[p], q = pair_query[p];
@@ -560,21 +557,6 @@ void chain_pairs(skh_ctx* ctx, const skh_sketch_set* const* Rsets, uint32_t n_rs
             }
             job.pair_key[i] = gb + 3u * (sw ? n_rsets + qs : rs);                    // tiles probing the same sketch share an XCD
             job.chunk_bound[i] = A.chunk_bound;
-        }
-        };
-        // A pair is two per-genome records read at random and four small stores: ~11 ns, 1.06 ms for config 4's 95,000 pairs with the device idle.  From 32,768 pairs on
-        // the list is dealt to four threads (pairs are independent; the first exception wins): 0.35 ms.  Below that a thread costs more than it saves (9,500 pairs: 0.09 ms).
-        const uint32_t n_thr = n >= 32768 ? 4u : 1u;
-        if (n_thr == 1) describe(0, n);
-        else {
-            std::exception_ptr err; std::mutex err_mu;
-            std::vector<std::thread> th;
-            for (uint32_t t = 0; t < n_thr; t++) th.emplace_back([&, t] {
-                try { describe((uint32_t)((uint64_t)n * t / n_thr), (uint32_t)((uint64_t)n * (t + 1) / n_thr)); }
-                catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
-            });
-            for (auto& t : th) t.join();
-            if (err) std::rethrow_exception(err);
         }
         tr.mark("host: pair descriptors");
         if (tables_pending && !pending_done) {
