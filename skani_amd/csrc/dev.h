@@ -277,7 +277,7 @@ template <class T> struct DBuf {
     DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DBuf() { release(); }
-    void alloc(size_t n_) { release(); n = n_; p = (T*)dmalloc(n_ * sizeof(T)); }
+    void alloc(size_t n_) { release(); p = (T*)dmalloc(n_ * sizeof(T)); n = n_; }   // (an allocation that throws leaves the buffer empty)
     void release() { if (p) dfree(p); p = nullptr; n = 0; }
     size_t bytes() const { return n * sizeof(T); }
 };

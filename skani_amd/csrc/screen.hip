@@ -234,8 +234,11 @@ constexpr uint32_t COLORDER_AHEAD_MAX = 16384;
 static void queue_column_order_ahead(skh_ctx* ctx, const skh_sketch_set* set, PendingSort* ps) {
     const uint32_t N = set->n_genomes; const uint64_t n_keys = set->screen_keys.n;
     if (!column_order_wanted(ctx, N, n_keys) || N > COLORDER_AHEAD_MAX || set->compact) return;   // (compact sets are the shards of a resident database: searched, never screened against themselves)
-    ps->mat.alloc((size_t)N * N); ps->work.alloc((size_t)3 * N);
-    set->screen_col_of.alloc(N); set->screen_genome_of.alloc(N);
+    try { ps->mat.alloc((size_t)N * N); ps->work.alloc((size_t)3 * N); set->screen_col_of.alloc(N); set->screen_genome_of.alloc(N); }
+    catch (...) {                                                                    // no room for the sample's matrix (up to 1 GB): the screen call makes the order in its own matrix, or counts in collection order
+        ps->mat.release(); ps->work.release(); set->screen_col_of.release(); set->screen_genome_of.release();
+        return;
+    }
     dzero(ps->mat.p, (size_t)N * N * 4, ctx->stream);
     const ColOrderWork w{(uint32_t*)ps->work.p, ps->work.p + N, ps->work.p + 2 * (size_t)N, &ps->sort_tmp};
     queue_column_order(ctx, set->screen_keys.p, n_keys, N, ps->mat.p, w, set->screen_col_of.p, set->screen_genome_of.p);
